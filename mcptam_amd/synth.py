@@ -1,0 +1,280 @@
+"""Seeded synthetic maps for the ChainBundle hot path.
+
+The reference ships no datasets or loaders; this generator produces the problems named in
+BASELINE.json (multi-camera rig on a loop trajectory, points in a shell around it, noisy
+and partly gross-outlier measurements, perturbed initial state) and replays them into any
+object that offers the ChainBundle surface (AddPose / AddPoint / AddMeas) in the order
+BundleAdjusterMulti::BundleAdjust / BundleAdjusterSingle::BundleAdjust populate it
+(/root/reference/src/BundleAdjusterMulti.cc:83-200, BundleAdjusterSingle.cc:76-151).
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .taylor_camera import TaylorCamera
+
+DEFAULT_SEED = 20260927
+# (a0, a2, a3, a4, xc, yc, c, d, e): fisheye looking along +z, ~163 deg field of view
+DEFAULT_CAM_PARAMS = (250.0, -1.2e-3, 1.0e-7, -1.0e-10, 320.0, 240.0, 1.0, 0.0, 0.0)
+
+
+def so3_exp(w):
+    """TooN SO3::exp (Rodrigues with the TooN small-angle thresholds)."""
+    w = np.asarray(w, dtype=np.float64)
+    th2 = float(w @ w)
+    th = math.sqrt(th2)
+    if th2 < 1e-8:
+        A, B = 1.0 - th2 / 6.0, 0.5
+    elif th2 < 1e-6:
+        B = 0.5 - 0.25 * th2 / 6.0
+        A = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0)
+    else:
+        A, B = math.sin(th) / th, (1 - math.cos(th)) / th2
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) + A * K + B * (K @ K)
+
+
+def se3_exp(mu):
+    """TooN SE3::exp, mu = (t, w)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    t, w = mu[:3], mu[3:]
+    th2 = float(w @ w)
+    th = math.sqrt(th2)
+    cr = np.cross(w, t)
+    if th2 < 1e-8:
+        tr = t + 0.5 * cr
+    else:
+        if th2 < 1e-6:
+            C = (1.0 - th2 / 20.0) / 6.0
+            B = 0.5 - 0.25 * th2 / 6.0
+        else:
+            A = math.sin(th) / th
+            B = (1 - math.cos(th)) / th2
+            C = (1 - A) / th2
+        tr = t + B * cr + C * np.cross(w, cr)
+    return so3_exp(w), tr
+
+
+def rot_z(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+@dataclass
+class Problem:
+    """A bundle problem in reference vocabulary, ready to replay into a ChainBundle."""
+    cams: list                      # TaylorCamera per camera index
+    mode: str                       # "multi" (chains MKF->cam) or "single" (chains KF)
+    n_mkf: int
+    base_R: np.ndarray              # (P,3,3) BaseFromWorld rotation (initial, perturbed)
+    base_t: np.ndarray              # (P,3)
+    base_fixed: np.ndarray          # (P,) bool
+    cam_R: np.ndarray               # (C,3,3) CamFromBase
+    cam_t: np.ndarray               # (C,3)
+    pt_x: np.ndarray                # (N,3) point in its source camera frame (initial)
+    pt_src: np.ndarray              # (N,2) source (mkf, cam)
+    pt_fixed: np.ndarray            # (N,) bool (fixed points are given in world coordinates)
+    ms_mkf: np.ndarray              # (M,) observer mkf
+    ms_cam: np.ndarray              # (M,)
+    ms_pt: np.ndarray               # (M,) point index
+    ms_uv: np.ndarray               # (M,2)
+    ms_level: np.ndarray            # (M,)
+    true_base_R: np.ndarray = None
+    true_base_t: np.ndarray = None
+    true_world: np.ndarray = None   # (N,3)
+    ids: dict = field(default_factory=dict)
+
+    @property
+    def n_points(self):
+        return self.pt_x.shape[0]
+
+    @property
+    def n_meas(self):
+        return self.ms_uv.shape[0]
+
+    def populate(self, bundle, batch=True):
+        """Replay into `bundle` (AddPose/AddPoint/AddMeas or their *_batch forms).
+
+        Returns dict with the bundle ids: 'mkf' (P,), 'cam' (C,), 'point' (N,), 'world'."""
+        P, C = self.n_mkf, len(self.cams)
+        mkf_id = np.zeros(P, dtype=np.int32)
+        cam_id = np.zeros(C, dtype=np.int32)
+        world_id = -1
+        if self.mode == "multi":
+            # BundleAdjusterMulti.cc:83-134: MKF pose, then a fixed pose per camera name when first met
+            for k in range(P):
+                mkf_id[k] = bundle.AddPose(self.base_R[k], self.base_t[k], bool(self.base_fixed[k]))
+                if k == 0:
+                    for c in range(C):
+                        cam_id[c] = bundle.AddPose(self.cam_R[c], self.cam_t[c], True)
+        else:
+            # BundleAdjusterSingle.cc:76-101: one pose per KeyFrame = CamFromWorld
+            assert C == 1
+            for k in range(P):
+                R = self.cam_R[0] @ self.base_R[k]
+                t = self.cam_R[0] @ self.base_t[k] + self.cam_t[0]
+                mkf_id[k] = bundle.AddPose(R, t, bool(self.base_fixed[k]))
+        if self.pt_fixed.any():
+            world_id = bundle.AddPose(np.eye(3), np.zeros(3), True)      # BundleAdjusterMulti.cc:147-149
+        N = self.n_points
+        chains = np.zeros((N, 2), dtype=np.int32)
+        chain_len = np.zeros(N, dtype=np.int32)
+        for i in range(N):
+            if self.pt_fixed[i]:
+                chains[i, 0] = world_id
+                chain_len[i] = 1
+            elif self.mode == "multi":
+                chains[i] = (mkf_id[self.pt_src[i, 0]], cam_id[self.pt_src[i, 1]])
+                chain_len[i] = 2
+            else:
+                chains[i, 0] = mkf_id[self.pt_src[i, 0]]
+                chain_len[i] = 1
+        if batch and hasattr(bundle, "AddPointBatch"):
+            pt_id = bundle.AddPointBatch(self.pt_x, chains, chain_len, self.pt_fixed)
+        else:
+            pt_id = np.array([bundle.AddPoint(self.pt_x[i], [int(v) for v in chains[i, :chain_len[i]]], bool(self.pt_fixed[i]))
+                              for i in range(N)], dtype=np.int32)
+        M = self.n_meas
+        mch = np.zeros((M, 2), dtype=np.int32)
+        mlen = np.full(M, 2 if self.mode == "multi" else 1, dtype=np.int32)
+        mch[:, 0] = mkf_id[self.ms_mkf]
+        if self.mode == "multi":
+            mch[:, 1] = cam_id[self.ms_cam]
+        sig = (4.0 ** self.ms_level).astype(np.float64)     # LevelScale^2, BundleAdjusterMulti.cc:196
+        if batch and hasattr(bundle, "AddMeasBatch"):
+            bundle.AddMeasBatch(mch, mlen, pt_id[self.ms_pt], self.ms_uv, sig, self.ms_cam.astype(np.int32))
+        else:
+            for j in range(M):
+                bundle.AddMeas([int(v) for v in mch[j, :mlen[j]]], int(pt_id[self.ms_pt[j]]), self.ms_uv[j], float(sig[j]), int(self.ms_cam[j]))
+        self.ids = {"mkf": mkf_id, "cam": cam_id, "point": np.asarray(pt_id, dtype=np.int32), "world": world_id}
+        return self.ids
+
+
+def make_rig(n_cams, lever=0.1):
+    """n_cams cameras at 360/n yaw steps with `lever` m lever arms; camera looks along its +z."""
+    R0 = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])   # base x-forward/z-up -> cam z-forward/y-down
+    Rs, ts = [], []
+    for k in range(n_cams):
+        yaw = 2 * math.pi * k / max(n_cams, 1) if n_cams > 1 else 0.0
+        R = R0 @ rot_z(-yaw)
+        p = lever * np.array([math.cos(yaw), math.sin(yaw), 0.0]) if n_cams > 1 else np.zeros(3)
+        Rs.append(R)
+        ts.append(-R @ p)
+    return np.array(Rs), np.array(ts)
+
+
+def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", seed=DEFAULT_SEED,
+                 radius=5.0, arc_step=None, pixel_sigma=0.5, outlier_frac=0.02, pose_sigma=(0.02, 0.5),
+                 depth_sigma=0.05, n_fixed_points=0, cam_params=DEFAULT_CAM_PARAMS, image_size=(640, 480),
+                 noise=True, perturb=True, k_near=12, n_fixed_mkf=1):
+    """SURVEY.md 8(d) generator.  Returns a Problem with exactly n_points points and
+    per_point*n_points measurements."""
+    rng = np.random.default_rng(seed)
+    cam = TaylorCamera(cam_params, image_size, image_size, image_size)
+    cams = [cam] * n_cams
+    cam_R, cam_t = make_rig(n_cams)
+    # trajectory: loop (or arc) of radius `radius` with sinusoidal height
+    dphi = (2 * math.pi / n_mkf) if arc_step is None else arc_step / radius
+    phis = dphi * np.arange(n_mkf)
+    centres = np.stack([radius * np.cos(phis), radius * np.sin(phis), 0.3 * np.sin(3 * phis)], axis=1)
+    tR = np.array([rot_z(ph + math.pi / 2).T for ph in phis])            # BaseFromWorld rotation
+    tt = np.array([-tR[k] @ centres[k] for k in range(n_mkf)])
+    # points in a 2..15 m shell around the trajectory; over-generate then keep well-observed ones
+    need = n_points
+    world, obs_list = [], []
+    kk = min(k_near, n_mkf)
+    while need > 0:
+        n_try = int(need * 1.5) + 64
+        anchor = rng.integers(0, n_mkf, n_try)
+        u = rng.normal(size=(n_try, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        d = rng.uniform(2.0, 15.0, n_try)
+        X = centres[anchor] + u * d[:, None]
+        d2 = ((X[:, None, :] - centres[None, :, :]) ** 2).sum(axis=2)   # (n_try, P)
+        near = np.argsort(d2, axis=1, kind="stable")[:, :kk]
+        # candidate observations ordered by (distance rank, cam)
+        cand_valid = np.zeros((n_try, kk, n_cams), dtype=bool)
+        cand_uv = np.zeros((n_try, kk, n_cams, 2))
+        for r in range(kk):
+            mk = near[:, r]
+            xb = np.einsum("nij,nj->ni", tR[mk], X) + tt[mk]
+            for c in range(n_cams):
+                xc = xb @ cam_R[c].T + cam_t[c]
+                uv, inv = cam.project(xc)
+                cand_valid[:, r, c] = ~inv
+                cand_uv[:, r, c] = uv
+        flat_valid = cand_valid.reshape(n_try, -1)
+        count = flat_valid.sum(axis=1)
+        good = np.nonzero(count >= per_point)[0][:need]
+        for i in good:
+            sel = np.nonzero(flat_valid[i])[0][:per_point]
+            obs = [(int(near[i, s // n_cams]), int(s % n_cams), cand_uv[i, s // n_cams, s % n_cams]) for s in sel]
+            world.append(X[i])
+            obs_list.append(obs)
+        need -= len(good)
+    world = np.array(world)
+    N = n_points
+    # fixed (calibration) points: stored in world coordinates with chain {world}
+    pt_fixed = np.zeros(N, dtype=bool)
+    if n_fixed_points:
+        pt_fixed[rng.choice(N, n_fixed_points, replace=False)] = True
+    # measurements, populated MKF-major then camera then point (BundleAdjusterMulti.cc:168-200)
+    rows = []
+    pt_src = np.zeros((N, 2), dtype=np.int32)
+    for i, obs in enumerate(obs_list):
+        src = min(obs, key=lambda o: (o[0], o[1]))                       # "first KF that sees it"
+        pt_src[i] = (src[0], src[1])
+        for (mk, c, uv) in obs:
+            rows.append((mk, c, i, uv[0], uv[1]))
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    ms_mkf = np.array([r[0] for r in rows], dtype=np.int32)
+    ms_cam = np.array([r[1] for r in rows], dtype=np.int32)
+    ms_pt = np.array([r[2] for r in rows], dtype=np.int32)
+    ms_uv = np.array([[r[3], r[4]] for r in rows], dtype=np.float64)
+    M = ms_uv.shape[0]
+    ms_level = rng.choice(4, size=M, p=[0.55, 0.25, 0.15, 0.05]).astype(np.int32)
+    if noise:
+        ms_uv = ms_uv + rng.normal(size=(M, 2)) * (pixel_sigma * (2.0 ** ms_level))[:, None]
+        n_out = int(round(outlier_frac * M))
+        if n_out:
+            oi = rng.choice(M, n_out, replace=False)
+            ms_uv[oi] = rng.uniform([0, 0], image_size, size=(n_out, 2))
+    # true relative coordinates in the (true) source camera frame
+    srcR = np.einsum("nij,njk->nik", cam_R[pt_src[:, 1]], tR[pt_src[:, 0]])
+    srct = np.einsum("nij,nj->ni", cam_R[pt_src[:, 1]], tt[pt_src[:, 0]]) + cam_t[pt_src[:, 1]]
+    x_rel = np.einsum("nij,nj->ni", srcR, world) + srct
+    base_R, base_t = tR.copy(), tt.copy()
+    base_fixed = np.zeros(n_mkf, dtype=bool)
+    base_fixed[:n_fixed_mkf] = True
+    pt_x = x_rel.copy()
+    if perturb:
+        for k in range(n_mkf):
+            if base_fixed[k]:
+                continue
+            xi = np.concatenate([rng.normal(size=3) * pose_sigma[0], rng.normal(size=3) * math.radians(pose_sigma[1])])
+            R, t = se3_exp(xi)
+            base_R[k] = R @ tR[k]
+            base_t[k] = R @ tt[k] + t
+        pt_x = x_rel * (1.0 + rng.normal(size=(N, 1)) * depth_sigma)
+    pt_x[pt_fixed] = world[pt_fixed]
+    return Problem(cams=cams, mode=mode, n_mkf=n_mkf, base_R=base_R, base_t=base_t, base_fixed=base_fixed,
+                   cam_R=cam_R, cam_t=cam_t, pt_x=pt_x, pt_src=pt_src, pt_fixed=pt_fixed,
+                   ms_mkf=ms_mkf, ms_cam=ms_cam, ms_pt=ms_pt, ms_uv=ms_uv, ms_level=ms_level,
+                   true_base_R=tR, true_base_t=tt, true_world=world)
+
+
+# the BASELINE.json configurations (SURVEY.md 8 notation)
+CONFIGS = {
+    "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3),
+    "c2": dict(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi"),
+    "metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi"),
+    "c4": dict(n_cams=4, n_mkf=500, n_points=100000, per_point=8, mode="multi"),
+    "tiny": dict(n_cams=2, n_mkf=6, n_points=60, per_point=4, mode="multi", arc_step=0.4),
+}
+
+
+def make_config(name, **over):
+    kw = dict(CONFIGS[name])
+    kw.update(over)
+    return make_problem(**kw)

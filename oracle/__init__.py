@@ -1,0 +1,204 @@
+"""ctypes loader for the CPU oracle (liborc.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from mcptam_amd/ (the product path).  PARITY UNPINNED: see
+oracle/ba_oracle.h.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class OrcIterLog(ctypes.Structure):
+    _fields_ = [("chi2_start", ctypes.c_double), ("chi2_end", ctypes.c_double),
+                ("lambda_end", ctypes.c_double), ("sigma_sq", ctypes.c_double),
+                ("rms_update", ctypes.c_double), ("trials", ctypes.c_int), ("accepted", ctypes.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in ("ba_oracle.c", "ba_oracle.h", "img_oracle.c", "img_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.orc_ba_create.restype = ctypes.c_void_p
+        L.orc_ba_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_ba_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_ba_set_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        L.orc_ba_disable_convergence.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_ba_add_pose.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int]
+        L.orc_ba_add_point.argtypes = [ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_int, ctypes.c_int]
+        L.orc_ba_add_meas.argtypes = [ctypes.c_void_p, c_int_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_double, ctypes.c_int]
+        L.orc_ba_compute.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int, ctypes.c_double]
+        for f in ("orc_ba_converged", "orc_ba_total_iterations", "orc_ba_num_outliers", "orc_ba_num_iter_logs",
+                  "orc_ba_num_meas", "orc_ba_prepare"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        for f in ("orc_ba_sigma_squared", "orc_ba_mean_chi_squared", "orc_ba_max_cov", "orc_ba_lambda"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+            getattr(L, f).restype = ctypes.c_double
+        L.orc_ba_get_point.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
+        L.orc_ba_get_pose.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]
+        L.orc_ba_get_outliers.argtypes = [ctypes.c_void_p, c_int_p, ctypes.c_int]
+        L.orc_ba_get_iter_logs.argtypes = [ctypes.c_void_p, ctypes.POINTER(OrcIterLog), ctypes.c_int]
+        L.orc_ba_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+        L.orc_ba_jacobian.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]
+        L.orc_ba_numeric_jacobian.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p]
+        L.orc_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p, c_double_p]
+        L.orc_ba_debug_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p]
+        L.orc_ba_debug_robust_chi2.restype = ctypes.c_double
+        L.orc_cam_project.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
+        L.orc_cam_sphere_deriv.argtypes = [c_double_p, c_double_p, c_double_p]
+        L.orc_se3_exp.argtypes = [c_double_p, c_double_p, c_double_p]
+        L.orc_so3_exp.argtypes = [c_double_p, c_double_p]
+        L.orc_huber_sigma_squared.argtypes = [c_double_p, ctypes.c_int]
+        L.orc_huber_sigma_squared.restype = ctypes.c_double
+        L.orc_tukey_sigma_squared.argtypes = [c_double_p, ctypes.c_int]
+        L.orc_tukey_sigma_squared.restype = ctypes.c_double
+        L.orc_tukey_weight.argtypes = [ctypes.c_double, ctypes.c_double]
+        L.orc_tukey_weight.restype = ctypes.c_double
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+class OracleBundle:
+    """ChainBundle-shaped wrapper over the oracle (same surface as mcptam_amd.ChainBundle)."""
+
+    def __init__(self, cams, use_robust=True, use_tukey=True, verbose=False):
+        from mcptam_amd.taylor_camera import camera_array
+        self._L = lib()
+        self._cams = camera_array(cams)
+        self._h = self._L.orc_ba_create(ctypes.cast(self._cams, ctypes.c_void_p), len(cams), int(use_robust), int(use_tukey), int(verbose))
+        self.abort = ctypes.c_ubyte(0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_ba_destroy(self._h)
+            self._h = None
+
+    def SetLimits(self, max_trials=100, pct_limit=1e-10, rms_limit=1e-10, min_sigma=0.5):
+        self._L.orc_ba_set_limits(self._h, max_trials, pct_limit, rms_limit, min_sigma)
+
+    def DisableConvergence(self, disable=True):
+        self._L.orc_ba_disable_convergence(self._h, int(disable))
+
+    def AddPose(self, R, t, fixed):
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+        return self._L.orc_ba_add_pose(self._h, _dp(R), _dp(t), int(fixed))
+
+    def AddPoint(self, x, chain, fixed):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(3)
+        c = np.ascontiguousarray(chain, dtype=np.int32)
+        r = self._L.orc_ba_add_point(self._h, _dp(x), _ip(c), len(c), int(fixed))
+        if r < 0:
+            raise ValueError("AddPoint: bad chain")
+        return r
+
+    def AddMeas(self, chain, point_id, uv, sigma_sq, cam_index):
+        c = np.ascontiguousarray(chain, dtype=np.int32)
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(2)
+        if self._L.orc_ba_add_meas(self._h, _ip(c), len(c), int(point_id), _dp(uv), float(sigma_sq), int(cam_index)) < 0:
+            raise ValueError("AddMeas: bad arguments")
+
+    def Compute(self, n_iter=100, user_lambda=-1.0):
+        return self._L.orc_ba_compute(self._h, ctypes.byref(self.abort), int(n_iter), float(user_lambda))
+
+    def Converged(self):
+        return bool(self._L.orc_ba_converged(self._h))
+
+    def TotalIterations(self):
+        return self._L.orc_ba_total_iterations(self._h)
+
+    def GetPoint(self, pid):
+        x = np.zeros(3)
+        assert self._L.orc_ba_get_point(self._h, int(pid), _dp(x)) == 0
+        return x
+
+    def GetPose(self, pid):
+        R = np.zeros(9)
+        t = np.zeros(3)
+        assert self._L.orc_ba_get_pose(self._h, int(pid), _dp(R), _dp(t)) == 0
+        return R.reshape(3, 3), t
+
+    def GetOutlierMeasurements(self):
+        n = self._L.orc_ba_num_outliers(self._h)
+        out = np.zeros((max(n, 1), 3), dtype=np.int32)
+        n = self._L.orc_ba_get_outliers(self._h, _ip(out), n)
+        return [tuple(int(v) for v in out[i]) for i in range(n)]
+
+    def GetSigmaSquared(self):
+        return self._L.orc_ba_sigma_squared(self._h)
+
+    def GetMeanChiSquared(self):
+        return self._L.orc_ba_mean_chi_squared(self._h)
+
+    def GetMaxCov(self):
+        return self._L.orc_ba_max_cov(self._h)
+
+    def GetLambda(self):
+        return self._L.orc_ba_lambda(self._h)
+
+    def IterLogs(self):
+        n = self._L.orc_ba_num_iter_logs(self._h)
+        arr = (OrcIterLog * max(n, 1))()
+        n = self._L.orc_ba_get_iter_logs(self._h, arr, n)
+        return [dict(chi2_start=a.chi2_start, chi2_end=a.chi2_end, lambda_end=a.lambda_end, sigma_sq=a.sigma_sq,
+                     rms_update=a.rms_update, trials=a.trials, accepted=a.accepted) for a in arr[:n]]
+
+    # ---- introspection for the self-consistency tests ----
+    def Prepare(self):
+        return self._L.orc_ba_prepare(self._h)
+
+    def NumMeas(self):
+        return self._L.orc_ba_num_meas(self._h)
+
+    def Eval(self):
+        m = self.NumMeas()
+        chi2 = np.zeros(m)
+        err = np.zeros((m, 2))
+        self._L.orc_ba_eval(self._h, _dp(chi2), _dp(err))
+        return chi2, err
+
+    def Jacobian(self, m, numeric=False, delta=1e-6):
+        jo = np.zeros((4, 2, 6))
+        js = np.zeros((4, 2, 6))
+        jp = np.zeros((2, 3))
+        if numeric:
+            mask = self._L.orc_ba_numeric_jacobian(self._h, int(m), float(delta), _dp(jo), _dp(js), _dp(jp))
+        else:
+            mask = self._L.orc_ba_jacobian(self._h, int(m), _dp(jo), _dp(js), _dp(jp))
+        return mask, jo, js, jp
+
+    def DebugSolve(self, lam):
+        n = self.Prepare()
+        xs = np.zeros(n)
+        xd = np.zeros(n)
+        rc = self._L.orc_ba_debug_solve(self._h, float(lam), _dp(xs), _dp(xd))
+        return rc, xs, xd
+
+    def DebugRobustChi2(self):
+        s = ctypes.c_double(0)
+        c = self._L.orc_ba_debug_robust_chi2(self._h, ctypes.byref(s))
+        return c, s.value
