@@ -1,0 +1,169 @@
+/*
+ * mcp_ba.h -- C ABI of the MI355X (gfx950) ChainBundle back end.
+ *
+ * Drop-in boundary for the bundle-adjustment hot path of MCPTAM.  The reference has no
+ * FFI; its seam is the public surface of class ChainBundle
+ * (/root/reference/include/mcptam/ChainBundle.h:106-186), which is everything
+ * BundleAdjuster{Multi,Single,Calib} call (BundleAdjusterMulti.cc:75,90,101,116,126,148,
+ * 160,196,272-274,298,310,328-330,246).  Each entry point below names the member it
+ * replaces; INTEGRATION.md shows the ChainBundle.cc shim a maintainer would compile
+ * against this header.
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no exceptions cross the ABI; the library copies
+ *    every input at add_* time (caller keeps ownership).
+ *  - ids start at 1 and poses and points share one counter (ChainBundle.cc:1145,1201,1215).
+ *  - one handle lives for one BundleAdjust call like the stack ChainBundle object
+ *    (BundleAdjusterMulti.cc:75); mcp_ba_compute may be called on it repeatedly (two-step
+ *    mode, :210-224); every call re-initialises the optimiser and re-seeds lambda
+ *    (ChainBundle.cc:1307).
+ *  - rotation matrices are row-major double[9]; an SE3 is (R,t) with x' = R x + t.
+ *  - all arithmetic is fp64 on the device.  There is NO CPU fallback: if no gfx950 device
+ *    (or no HIP runtime) is usable, mcp_ba_create returns NULL and
+ *    mcp_last_error() says why.
+ *  - threading: a handle is driven from one thread (the MapMaker thread in MCPTAM);
+ *    abort_flag may be written asynchronously by another thread AND is written by the
+ *    solver itself on convergence (ChainBundle.cc:1027-1028,1105-1113); it is polled once
+ *    per LM trial.
+ */
+#ifndef MCP_BA_H
+#define MCP_BA_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCP_MAX_CHAIN 4      /* longest pose chain accepted (reference uses 1 and 2) */
+#define MCP_MAX_INV   31     /* MAX_INV_DEGREE+1, include/mcptam/TaylorCamera.h:74 */
+
+/* The already-fitted TaylorCamera, i.e. the state after TaylorCamera::RefreshParams
+ * (src/TaylorCamera.cc:84-198), so the device never needs the root finder / SVD fit. */
+typedef struct mcp_camera {
+  double params[9];      /* mv9CameraParams: a0,a2,a3,a4,xc,yc,c,d,e   :89-99   */
+  double image_size[2];  /* mv2ImageSize                                         */
+  double affine[4];      /* mm2Affine, row-major                        :183-186 */
+  double center[2];      /* mv2Center                                   :127-128 */
+  double min_theta;      /* mdMinTheta                                  :152     */
+  double max_rho;        /* mdMaxRho                                    :147     */
+  double theta_mean;     /* mdThetaMean                                 :551-565 */
+  double theta_std;      /* mdThetaStd                                  :569     */
+  int    n_inv;          /* number of inverse polynomial coefficients; 0 (= the reference's
+                            Newton fallback, :161-176) is rejected                  */
+  int    pad_;
+  double inv_coeffs[MCP_MAX_INV];   /* mvxPolyInvCoeffs, x^0 first       :157     */
+} mcp_camera;
+
+/* ChainBundle statics (src/ChainBundle.cc:1132-1136; ROS overrides
+ * include/mcptam/LoadStaticParamsServer.h:63-66).  Pass NULL for the defaults. */
+typedef struct mcp_ba_params {
+  int    max_iterations;             /* snMaxIterations = 100 (default n_iter)  */
+  int    max_trials_after_failure;   /* snMaxTrialsAfterFailure = 100           */
+  double update_percent_limit;       /* sdUpdatePercentConvergenceLimit = 1e-10 */
+  double update_rms_limit;           /* sdUpdateRMSConvergenceLimit = 1e-10     */
+  double min_mestimator_sigma;       /* sdMinMEstimatorSigma = 0.5              */
+  int    disable_convergence;        /* 0; nonzero: convergence actions never fire
+                                        (timing runs)            */
+  int    device;                     /* HIP device ordinal, -1 = current device */
+  int    profile;                    /* nonzero: bracket every stage with HIP events
+                                        on the solver stream (mcp_ba_get_timing)  */
+} mcp_ba_params;
+
+typedef struct mcp_ba mcp_ba;
+
+/* per-outer-iteration trace (what the reference only prints with ROS_DEBUG) */
+typedef struct mcp_ba_iter_log {
+  double chi2_start, chi2_end, lambda_end, sigma_sq, rms_update;
+  int trials, accepted;
+} mcp_ba_iter_log;
+
+/* per-stage device time of the last mcp_ba_compute, milliseconds (HIP events on the
+ * solver's stream) -- the analogue of the reference's timing topics (MapMakerTiming.msg) */
+typedef struct mcp_ba_timing {
+  double total_ms;
+  double structure_ms;    /* host: initializeOptimization analogue + upload */
+  double eval_ms, select_ms, linearize_ms, schur_ms, cholesky_ms, solve_ms, update_ms;
+  int    n_linearize, n_trials;
+} mcp_ba_timing;
+
+const char* mcp_last_error(void);
+/* number of usable gfx950 devices (0 if none / runtime missing) */
+int mcp_device_count(void);
+
+/* ChainBundle::ChainBundle(TaylorCameraMap&, bool, bool, bool)   ChainBundle.cc:1139-1181 */
+mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_tukey,
+                      int verbose, const mcp_ba_params* params);
+/* ChainBundle::~ChainBundle                                       ChainBundle.cc:1183-1195 */
+void    mcp_ba_destroy(mcp_ba*);
+
+/* int ChainBundle::AddPose(SE3<> se3PoseFromRef, bool bFixed)     ChainBundle.cc:1198-1208 */
+int mcp_ba_add_pose(mcp_ba*, const double R[9], const double t[3], int fixed);
+/* int ChainBundle::AddPoint(Vector<3>, std::vector<int> vCams, bool bFixed)   :1211-1236
+ * returns the id, or -1 (bad chain: unknown pose id, n<1 or n>MCP_MAX_CHAIN) */
+int mcp_ba_add_point(mcp_ba*, const double x[3], const int* chain, int n, int fixed);
+/* void ChainBundle::AddMeas(vector<int> vCams, int nPointIdx, Vector<2> v2Pos,
+ *                           double dNoiseSigmaSquared, std::string cameraName) :1239-1281
+ * cam_index indexes the cams[] passed at create (the reference keys cameras by name; the
+ * shim maps name -> index).  returns 0, or -1 on a bad argument. */
+int mcp_ba_add_meas(mcp_ba*, const int* chain, int n, int point_id, const double uv[2],
+                    double sigma_sq, int cam_index);
+/* Batched forms of the two calls above (same semantics, one ABI crossing): `chains` holds
+ * `count` rows of `stride` ints of which chain_len[i] are used; add_points writes the new
+ * ids to ids_out[count] (may be NULL). */
+int mcp_ba_add_points(mcp_ba*, int count, const double* x /*count*3*/, const int* chains,
+                      int stride, const int* chain_len, const unsigned char* fixed, int* ids_out);
+int mcp_ba_add_measurements(mcp_ba*, int count, const int* chains, int stride,
+                            const int* chain_len, const int* point_ids, const double* uv /*count*2*/,
+                            const double* sigma_sq, const int* cam_index);
+
+/* int ChainBundle::Compute(bool* pAbortSignal, int nNumIter, double dUserLambda) :1305-1451
+ * n_iter <= 0 selects params.max_iterations.  Return value as the reference: number of
+ * outer iterations run (>0), 0 = aborted before any step, -1 = failure. */
+int mcp_ba_compute(mcp_ba*, volatile unsigned char* abort_flag, int n_iter, double user_lambda);
+
+int    mcp_ba_converged(mcp_ba*);                 /* Converged()          ChainBundle.h:146 */
+int    mcp_ba_total_iterations(mcp_ba*);          /* TotalIterations()    ChainBundle.h:148 */
+int    mcp_ba_get_point(mcp_ba*, int id, double x[3]);               /* GetPoint  :1453-1457 */
+int    mcp_ba_get_pose(mcp_ba*, int id, double R[9], double t[3]);   /* GetPose   :1459-1463 */
+/* bulk read-back: ids[count] -> x[count*3] / R[count*9], t[count*3] */
+int    mcp_ba_get_points(mcp_ba*, int count, const int* ids, double* x);
+int    mcp_ba_get_poses(mcp_ba*, int count, const int* ids, double* R, double* t);
+/* GetOutlierMeasurements()  :1465-1468, filled at :1368-1399.  out = triples
+ * (point id, id of the FIRST pose of the observer chain, cam index). */
+int    mcp_ba_num_outliers(mcp_ba*);
+int    mcp_ba_get_outliers(mcp_ba*, int* out, int cap);
+double mcp_ba_sigma_squared(mcp_ba*);             /* GetSigmaSquared()    :1470-1474 */
+double mcp_ba_mean_chi_squared(mcp_ba*);          /* GetMeanChiSquared()  :1476-1481 */
+double mcp_ba_max_cov(mcp_ba*);                   /* GetMaxCov()          ChainBundle.h:173 */
+double mcp_ba_lambda(mcp_ba*);                    /* GetLambda()          :1483-1487 */
+
+int    mcp_ba_num_iter_logs(mcp_ba*);
+int    mcp_ba_get_iter_logs(mcp_ba*, mcp_ba_iter_log* out, int cap);
+int    mcp_ba_get_timing(mcp_ba*, mcp_ba_timing* out);
+
+/* ---- multi-GPU: points/measurements are sharded across ranks, poses
+ * are replicated, and the reduced pose system is summed once per linearisation and once
+ * per trial.  The library is collective-agnostic: the host installs a hook that performs
+ * an in-place SUM all-reduce of `count` doubles at device pointer `buf` on `stream`
+ * (RCCL in production, see mcptam_amd/dist.py).  It returns 0 on success.
+ * hook == NULL (default) means single rank. */
+typedef int (*mcp_allreduce_fn)(void* user, void* device_buf, size_t count, void* hip_stream);
+int mcp_ba_set_allreduce(mcp_ba*, mcp_allreduce_fn hook, void* user, int rank, int world_size);
+
+/* ---- introspection used by the parity tests (no reference counterpart) ---- */
+/* structure build + upload without solving; returns the number of unknowns 6P+3N */
+int mcp_ba_prepare(mcp_ba*);
+/* computeActiveErrors at the current state: chi2 (signed as EdgeChainMeas::chi2, :401-417)
+ * per measurement in ADD ORDER; err = 2 doubles per measurement (may be NULL) */
+int mcp_ba_eval(mcp_ba*, double* chi2_out, double* err_out);
+/* sigma^2 (raw Huber, MEstimator.h:194-204 over |chi2|) and robust chi2 sum at the current state */
+int mcp_ba_robust_chi2(mcp_ba*, double* sigma_sq_raw, double* chi2_sum);
+/* build the normal equations at the current state and solve (H + lambda I) x = b on the
+ * device; x has mcp_ba_prepare() entries: free poses (id order) then free points (id order) */
+int mcp_ba_debug_solve(mcp_ba*, double lambda, double* x_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

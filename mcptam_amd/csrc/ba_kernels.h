@@ -1,0 +1,531 @@
+// ba_kernels.h -- HIP kernels of the ChainBundle LM iteration (gfx950, fp64).
+//
+// One LM outer iteration (g2o OptimizationAlgorithmLevenberg::solve as configured at
+// src/ChainBundle.cc:1156-1161) maps to:
+//   k_chains      PoseChainHelper::UpdateTransforms               ChainBundle.cc:120-150
+//   k_eval        EdgeChainMeas::computeError + chi2              :376-417
+//   select_*      Huber/Tukey::FindSigmaSquared median            MEstimator.h:109-124,194-204
+//   k_robust_sum  SparseOptimizer::activeRobustChi2 + robustify   ChainBundle.cc:871-897
+//   k_linearize   EdgeChainMeas::linearizeOplus + constructQuadraticForm  :449-749
+//   k_schur*      point elimination of (H + lambda I) x = b
+//   chol_*        dense Cholesky of the reduced pose system (ba_chol.h)
+//   k_backsub / k_update_poses   back-substitution + oplus        :82-86, :237-281
+#pragma once
+#include "ba_device.h"
+
+namespace mcp {
+
+// device-resident problem description (SoA, sorted by point)
+struct DevProblem {
+  // cameras
+  const mcp_camera* cams;
+  // chains
+  int nchain;
+  const int* chain_len;       // [nchain]
+  const int* chain_pose;      // [nchain*4] pose array index
+  // poses
+  int npose;
+  const int* pose_unk;        // [npose] unknown index or -1
+  // points
+  int npoint;
+  const int* pt_chain;        // [npoint]
+  const int* pt_unk;          // [npoint] free-point index or -1
+  const unsigned char* pt_fixed;
+  // measurements (sorted by point)
+  int nmeas;
+  const int* m_pt; const int* m_chain; const unsigned char* m_cam; const unsigned short* m_mask;
+  const double* m_u; const double* m_v; const double* m_omega;
+  const int* slot_start;      // [nmeas+1]
+  const int* slot_unk;        // [nslot] pose unknown of the slot
+  const int* slot_inc;        // [nslot] incidence index (W block) or -1 (fixed point)
+  // incidences (point-pose blocks), CSR by free point
+  int nfl, ninc, np;
+  const int* inc_start;       // [nfl+1]
+  const int* inc_unk;         // [ninc]
+  const int* fl_point;        // [nfl] free point -> point index
+  int robust;
+};
+
+// chain transforms: first[c*4+i] = link i from world (12 doubles), second[c*4+i] = rotation of last from link i
+__global__ void k_chains(DevProblem P, const double* __restrict__ pose_T, double* __restrict__ first,
+                         double* __restrict__ second, double* __restrict__ last) {
+  const int c = blockIdx.x*blockDim.x + threadIdx.x;
+  if (c >= P.nchain) return;
+  const int len = P.chain_len[c];
+  Se3 acc; se3_identity(acc);
+  for (int i = 0; i < len; ++i) {
+    Se3 v; const double* p = pose_T + 12*(size_t)P.chain_pose[c*4+i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v.R[k] = p[k];
+    v.t[0] = p[9]; v.t[1] = p[10]; v.t[2] = p[11];
+    se3_compose(v, acc, acc);
+    double* o = first + 12*(size_t)(c*4+i);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = acc.R[k];
+    o[9] = acc.t[0]; o[10] = acc.t[1]; o[11] = acc.t[2];
+  }
+  {
+    double* o = last + 12*(size_t)c;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = acc.R[k];
+    o[9] = acc.t[0]; o[10] = acc.t[1]; o[11] = acc.t[2];
+  }
+  double Rc[9] = {1,0,0, 0,1,0, 0,0,1};
+  for (int i = len - 1; i >= 0; --i) {
+    double* o = second + 9*(size_t)(c*4+i);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = Rc[k];
+    mat3_mul(Rc, pose_T + 12*(size_t)P.chain_pose[c*4+i], Rc);
+  }
+}
+
+__device__ inline void load_se3(const double* p, Se3& T) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T.R[k] = p[k];
+  T.t[0] = p[9]; T.t[1] = p[10]; T.t[2] = p[11];
+}
+
+// block-wide deterministic sum (fixed tree): returns the total in thread 0
+template <int BLOCK>
+__device__ inline double block_sum(double v, double* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) lds[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) { for (int i = 0; i < BLOCK/64; ++i) t += lds[i]; }
+  __syncthreads();
+  return t;
+}
+template <int BLOCK>
+__device__ inline double block_max(double v, double* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) lds[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) { for (int i = 0; i < BLOCK/64; ++i) t = fmax(t, lds[i]); }
+  __syncthreads();
+  return t;
+}
+
+// Huber on chi2 with the adaptive sigma (RobustKernelAdaptive::robustify, ChainBundle.cc:871-897)
+__device__ inline void robustify(double e2, double s2, double s, double& rho0, double& rho1) {
+  if (e2 <= s2) { rho0 = fabs(e2); rho1 = 1.0; }
+  else { const double e = sqrt(e2); rho0 = 2.0*s*e - s2; rho1 = s/e; }
+}
+
+// sigma block in device memory: [0] raw sigma^2, [1] limited sigma^2, [2] limited sigma, [3] median
+constexpr int EVAL_BLOCK = 256;
+
+// computeError + chi2 for every measurement; optional fused robust sum (sigma known: LM trials).
+// err_out (2 per measurement) only for introspection.
+template <bool SUM>
+__global__ void __launch_bounds__(EVAL_BLOCK)
+k_eval(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ last,
+       double* __restrict__ chi2, double* __restrict__ err_out, const double* __restrict__ sigma,
+       double* __restrict__ partial) {
+  __shared__ double lds[EVAL_BLOCK/64];
+  const int m = blockIdx.x*EVAL_BLOCK + threadIdx.x;
+  double contrib = 0.0;
+  if (m < P.nmeas) {
+    const int pt = P.m_pt[m];
+    Se3 Ts, To;
+    load_se3(last + 12*(size_t)P.pt_chain[pt], Ts);
+    load_se3(last + 12*(size_t)P.m_chain[m], To);
+    const double x[3] = { pt_x[3*(size_t)pt], pt_x[3*(size_t)pt+1], pt_x[3*(size_t)pt+2] };
+    double xw[3], xc[3];
+    se3_apply_inv(Ts, x, xw);
+    se3_apply(To, xw, xc);
+    Projection pr;
+    cam_project<false>(P.cams[P.m_cam[m]], xc, pr);
+    const double e0 = P.m_u[m] - pr.u, e1 = P.m_v[m] - pr.v;
+    double c = P.m_omega[m]*(e0*e0 + e1*e1);
+    if (P.pt_fixed[pt] && P.robust) c = -c;
+    chi2[m] = c;
+    if (err_out) { err_out[2*(size_t)m] = e0; err_out[2*(size_t)m+1] = e1; }
+    if (SUM) {
+      if (P.robust) { double r0, r1; robustify(c, sigma[1], sigma[2], r0, r1); contrib = r0; }
+      else contrib = c;
+    }
+  }
+  if (SUM) {
+    const double t = block_sum<EVAL_BLOCK>(contrib, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+  }
+}
+
+// robust sum over an existing chi2 array (first evaluation of an iteration, after the median)
+__global__ void __launch_bounds__(EVAL_BLOCK)
+k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* __restrict__ sigma,
+             double* __restrict__ partial) {
+  __shared__ double lds[EVAL_BLOCK/64];
+  const int m = blockIdx.x*EVAL_BLOCK + threadIdx.x;
+  double contrib = 0.0;
+  if (m < n) {
+    const double c = chi2[m];
+    if (robust) { double r0, r1; robustify(c, sigma[1], sigma[2], r0, r1); contrib = r0; }
+    else contrib = c;
+  }
+  const double t = block_sum<EVAL_BLOCK>(contrib, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// fixed-order final reduction of up to 4 partial arrays into out[0..3] (single block)
+__global__ void __launch_bounds__(256)
+k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
+             double* __restrict__ out, int off) {
+  __shared__ double lds[4];
+  const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
+  for (int a = 0; a < 3; ++a) {
+    if (!ps[a]) continue;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < ns[a]; i += 256) v += ps[a][i];
+    const double t = block_sum<256>(v, lds);
+    if (threadIdx.x == 0) out[off + a] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// linearize: Jacobians + weighted normal-equation accumulation, one thread per measurement.
+// U (np x np, lower triangle maintained), bp, V (6 per free point: xx,xy,xz,yy,yz,zz), g, W (18 per incidence).
+struct SlotGeom { double B[6]; double base[3]; double sign; };
+
+__device__ inline void slot_jacobian(const SlotGeom& s, double* J /*2x6 row-major*/) {
+  // J[:,k] = sign * B * gen_k(base);  k<3: B[:,k];  k>=3: B * (e_{k-3} x base)
+  const double* B = s.B; const double* p = s.base; const double sg = s.sign;
+  J[0] = sg*B[0]; J[1] = sg*B[1]; J[2] = sg*B[2];
+  J[6] = sg*B[3]; J[7] = sg*B[4]; J[8] = sg*B[5];
+  J[3]  = sg*(-B[1]*p[2] + B[2]*p[1]);  J[9]  = sg*(-B[4]*p[2] + B[5]*p[1]);
+  J[4]  = sg*( B[0]*p[2] - B[2]*p[0]);  J[10] = sg*( B[3]*p[2] - B[5]*p[0]);
+  J[5]  = sg*(-B[0]*p[1] + B[1]*p[0]);  J[11] = sg*(-B[3]*p[1] + B[4]*p[0]);
+}
+
+__device__ inline void make_slot(int side, int link, const double* A /*2x3*/, const double* xw,
+                                 const double* first, const double* second, int oc, int sc,
+                                 const double* Robs_last, SlotGeom& s) {
+  Se3 F;
+  if (side == 0) {
+    load_se3(first + 12*(size_t)(oc*4+link), F);
+    se3_apply(F, xw, s.base);
+    const double* R2 = second + 9*(size_t)(oc*4+link);
+    // B = A * R2
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.B[3*r+c] = A[3*r]*R2[c] + A[3*r+1]*R2[3+c] + A[3*r+2]*R2[6+c];
+    s.sign = 1.0;
+  } else {
+    load_se3(first + 12*(size_t)(sc*4+link), F);
+    se3_apply(F, xw, s.base);
+    double Rrel[9];
+    mat3_mul_t(Robs_last, F.R, Rrel);          // R(T_obs * T_src_i^-1)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.B[3*r+c] = A[3*r]*Rrel[c] + A[3*r+1]*Rrel[3+c] + A[3*r+2]*Rrel[6+c];
+    s.sign = -1.0;
+  }
+}
+
+constexpr int LIN_BLOCK = 128;
+
+__global__ void __launch_bounds__(LIN_BLOCK)
+k_linearize(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+            const double* __restrict__ second, const double* __restrict__ sigma,
+            double* __restrict__ U, double* __restrict__ bp, double* __restrict__ V,
+            double* __restrict__ g, double* __restrict__ W) {
+  const int m = blockIdx.x*LIN_BLOCK + threadIdx.x;
+  if (m >= P.nmeas) return;
+  const int pt = P.m_pt[m];
+  const int oc = P.m_chain[m], sc = P.pt_chain[pt];
+  const int olen = P.chain_len[oc], slen = P.chain_len[sc];
+  const int mask = P.m_mask[m];
+  const int lpt = P.pt_unk[pt];
+  if ((mask & 0xff) == 0 && lpt < 0) return;
+  Se3 Ts, To;
+  load_se3(first + 12*(size_t)(sc*4 + slen - 1), Ts);
+  load_se3(first + 12*(size_t)(oc*4 + olen - 1), To);
+  const double x[3] = { pt_x[3*(size_t)pt], pt_x[3*(size_t)pt+1], pt_x[3*(size_t)pt+2] };
+  double xw[3], xc[3];
+  se3_apply_inv(Ts, x, xw);
+  se3_apply(To, xw, xc);
+  Projection pr;
+  cam_project<true>(P.cams[P.m_cam[m]], xc, pr);
+  const double e0 = P.m_u[m] - pr.u, e1 = P.m_v[m] - pr.v;
+  const double omega = P.m_omega[m];
+  double c2 = omega*(e0*e0 + e1*e1);
+  if (P.pt_fixed[pt] && P.robust) c2 = -c2;
+  double w = omega;
+  if (P.robust) { double r0, r1; robustify(c2, sigma[1], sigma[2], r0, r1); w *= r1; }
+  double dT[3], dP[3];
+  cam_sphere_deriv(xc, dT, dP);
+  // A = -D * [dT; dP]  (2x3): change of the ERROR per unit motion of the camera-frame point
+  double A[6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    A[c]     = -(pr.D[0]*dT[c] + pr.D[1]*dP[c]);
+    A[3 + c] = -(pr.D[2]*dT[c] + pr.D[3]*dP[c]);
+  }
+  // point block
+  double Jp[6];
+  if (lpt >= 0) {
+    double Rp[9], dir[3], rho;
+    point_frame(x, Rp, dir, rho);
+    double rx[3], g0[3], g1[3], c0[3], c1[3];
+    mat3_vec(Rp, x, rx);
+    generator(3, rx, g0); generator(4, rx, g1);
+    mat3t_vec(Rp, g0, c0); mat3t_vec(Rp, g1, c1);
+    const double c2v[3] = { -x[0]/rho, -x[1]/rho, -x[2]/rho };
+    double Rcs[9];
+    mat3_mul_t(To.R, Ts.R, Rcs);
+    double AR[6];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) AR[3*r+c] = A[3*r]*Rcs[c] + A[3*r+1]*Rcs[3+c] + A[3*r+2]*Rcs[6+c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      Jp[3*r]   = AR[3*r]*c0[0]  + AR[3*r+1]*c0[1]  + AR[3*r+2]*c0[2];
+      Jp[3*r+1] = AR[3*r]*c1[0]  + AR[3*r+1]*c1[1]  + AR[3*r+2]*c1[2];
+      Jp[3*r+2] = AR[3*r]*c2v[0] + AR[3*r+1]*c2v[1] + AR[3*r+2]*c2v[2];
+    }
+    double* Vp = V + 6*(size_t)lpt; double* gp = g + 3*(size_t)lpt;
+    unsafeAtomicAdd(Vp + 0, w*(Jp[0]*Jp[0] + Jp[3]*Jp[3]));
+    unsafeAtomicAdd(Vp + 1, w*(Jp[0]*Jp[1] + Jp[3]*Jp[4]));
+    unsafeAtomicAdd(Vp + 2, w*(Jp[0]*Jp[2] + Jp[3]*Jp[5]));
+    unsafeAtomicAdd(Vp + 3, w*(Jp[1]*Jp[1] + Jp[4]*Jp[4]));
+    unsafeAtomicAdd(Vp + 4, w*(Jp[1]*Jp[2] + Jp[4]*Jp[5]));
+    unsafeAtomicAdd(Vp + 5, w*(Jp[2]*Jp[2] + Jp[5]*Jp[5]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) unsafeAtomicAdd(gp + c, -w*(Jp[c]*e0 + Jp[3+c]*e1));
+  }
+  // pose slots
+  const int s0 = P.slot_start[m], ns = P.slot_start[m+1] - s0;
+  const int np = P.np;
+  int ia = 0;
+  for (int bit_a = 0; bit_a < 8 && ia < ns; ++bit_a) {
+    if (!(mask & (1 << bit_a))) continue;
+    SlotGeom sa; double Ja[12];
+    make_slot(bit_a >> 2, bit_a & 3, A, xw, first, second, oc, sc, To.R, sa);
+    slot_jacobian(sa, Ja);
+    const int ua = P.slot_unk[s0 + ia];
+    double* b = bp + 6*(size_t)ua;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) unsafeAtomicAdd(b + r, -w*(Ja[r]*e0 + Ja[6+r]*e1));
+    // diagonal block, lower triangle
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c)
+        unsafeAtomicAdd(U + (size_t)(6*ua + r)*np + 6*ua + c, w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
+    if (lpt >= 0) {
+      double* Wb = W + 18*(size_t)P.slot_inc[s0 + ia];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) unsafeAtomicAdd(Wb + 3*r + c, w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]));
+    }
+    // cross blocks with later slots
+    int ib = ia + 1;
+    for (int bit_b = bit_a + 1; bit_b < 8 && ib < ns; ++bit_b) {
+      if (!(mask & (1 << bit_b))) continue;
+      SlotGeom sb; double Jb[12];
+      make_slot(bit_b >> 2, bit_b & 3, A, xw, first, second, oc, sc, To.R, sb);
+      slot_jacobian(sb, Jb);
+      const int ub = P.slot_unk[s0 + ib];
+      if (ua > ub) {
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
+          unsafeAtomicAdd(U + (size_t)(6*ua + r)*np + 6*ub + c, w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c]));
+      } else if (ub > ua) {
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
+          unsafeAtomicAdd(U + (size_t)(6*ub + r)*np + 6*ua + c, w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+      } else {   // the same vertex in both chains: symmetric sum, lower triangle
+        for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c)
+          unsafeAtomicAdd(U + (size_t)(6*ua + r)*np + 6*ua + c,
+                          w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+      }
+      ++ib;
+    }
+    ++ia;
+  }
+}
+
+// max |diag| of U and V  (computeLambdaInit [g2o])
+__global__ void k_extract_diag(int np, const double* __restrict__ U, double* __restrict__ d) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < np) d[i] = U[(size_t)i*np + i];
+}
+__global__ void __launch_bounds__(256)
+k_max_diag(int np, const double* __restrict__ U, int stride, int nfl, const double* __restrict__ V, double* out) {
+  __shared__ double lds[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) v = fmax(v, fabs(U[(size_t)i*stride]));
+  for (int i = threadIdx.x; i < nfl; i += 256) {
+    const double* Vp = V + 6*(size_t)i;
+    v = fmax(v, fmax(fabs(Vp[0]), fmax(fabs(Vp[3]), fabs(Vp[5]))));
+  }
+  const double t = block_max<256>(v, lds);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// S = U (+ lambda on the diagonal), rhs = bp.   Lower triangle only is meaningful.
+__global__ void k_schur_init(int np, double lambda, const double* __restrict__ U, const double* __restrict__ bp,
+                             double* __restrict__ S, double* __restrict__ rhs) {
+  const size_t n2 = (size_t)np*np;
+  for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x*blockDim.x) {
+    const int r = (int)(i / np), c = (int)(i % np);
+    double v = U[i];
+    if (r == c) v += lambda;
+    S[i] = v;
+    if (c == 0) rhs[r] = bp[r];
+  }
+}
+
+// inverse of the symmetric 3x3 (V + lambda I); returns false if not positive definite
+__device__ inline bool inv_sym3(const double* V6, double lambda, double* I6) {
+  const double a = V6[0] + lambda, b = V6[1], c = V6[2], d = V6[3] + lambda, e = V6[4], f = V6[5] + lambda;
+  const double c00 = d*f - e*e, c01 = c*e - b*f, c02 = b*e - c*d;
+  const double det = a*c00 + b*c01 + c*c02;
+  const double m2 = a*d - b*b;
+  const bool ok = (a > 0.0) && (m2 > 0.0) && (det > 0.0);
+  const double id = 1.0/det;
+  I6[0] = c00*id; I6[1] = c01*id; I6[2] = c02*id;
+  I6[3] = (a*f - c*c)*id; I6[4] = (b*c - a*e)*id; I6[5] = m2*id;
+  return ok;
+}
+
+// point elimination: S -= W Vinv W^T, rhs -= W Vinv g.  One wave per free point.
+__global__ void __launch_bounds__(256)
+k_schur(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
+        const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
+        double* __restrict__ rhs, int* __restrict__ fail) {
+  const int l = blockIdx.x*4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (l >= P.nfl) return;
+  double I6[6];
+  const bool ok = inv_sym3(V + 6*(size_t)l, lambda, I6);
+  if (lane == 0) {
+    if (!ok) atomicOr(fail, 1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Vinv[6*(size_t)l + k] = I6[k];
+  }
+  const int i0 = P.inc_start[l], q = P.inc_start[l+1] - i0;
+  const double Vi[9] = { I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5] };
+  const double g0 = g[3*(size_t)l], g1 = g[3*(size_t)l+1], g2 = g[3*(size_t)l+2];
+  const int np = P.np;
+  // rhs: q*6 items
+  for (int it = lane; it < q*6; it += 64) {
+    const int a = it / 6, r = it % 6;
+    const double* Wa = W + 18*(size_t)(i0 + a) + 3*r;
+    const double y0 = Wa[0]*Vi[0] + Wa[1]*Vi[3] + Wa[2]*Vi[6];
+    const double y1 = Wa[0]*Vi[1] + Wa[1]*Vi[4] + Wa[2]*Vi[7];
+    const double y2 = Wa[0]*Vi[2] + Wa[1]*Vi[5] + Wa[2]*Vi[8];
+    unsafeAtomicAdd(rhs + 6*(size_t)P.inc_unk[i0 + a] + r, -(y0*g0 + y1*g1 + y2*g2));
+  }
+  const int items = q*q*36;
+  for (int it = lane; it < items; it += 64) {
+    const int pair = it / 36, e = it % 36;
+    const int a = pair / q, b = pair % q, r = e / 6, c = e % 6;
+    const int ua = P.inc_unk[i0 + a], ub = P.inc_unk[i0 + b];
+    if (ua < ub || (ua == ub && c > r)) continue;
+    const double* Wa = W + 18*(size_t)(i0 + a) + 3*r;
+    const double* Wb = W + 18*(size_t)(i0 + b) + 3*c;
+    const double y0 = Wa[0]*Vi[0] + Wa[1]*Vi[3] + Wa[2]*Vi[6];
+    const double y1 = Wa[0]*Vi[1] + Wa[1]*Vi[4] + Wa[2]*Vi[7];
+    const double y2 = Wa[0]*Vi[2] + Wa[1]*Vi[5] + Wa[2]*Vi[8];
+    unsafeAtomicAdd(S + (size_t)(6*ua + r)*np + 6*ub + c, -(y0*Wb[0] + y1*Wb[1] + y2*Wb[2]));
+  }
+}
+
+// pose update: T_trial = exp(x) * T_cur for free poses; pose part of sum x(lambda x + b) and sum x^2
+__global__ void __launch_bounds__(256)
+k_update_poses(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
+               const double* __restrict__ T_cur, double* __restrict__ T_trial, double* __restrict__ out /*[2]*/) {
+  __shared__ double lds[4];
+  double sc = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < P.npose; i += 256) {
+    const int u = P.pose_unk[i];
+    if (u < 0) continue;
+    const double* d = xp + 6*(size_t)u;
+    Se3 E, T, R;
+    se3_exp(d, E);
+    load_se3(T_cur + 12*(size_t)i, T);
+    se3_compose(E, T, R);
+    double* o = T_trial + 12*(size_t)i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = R.R[k];
+    o[9] = R.t[0]; o[10] = R.t[1]; o[11] = R.t[2];
+    for (int k = 0; k < 6; ++k) { sc += d[k]*(lambda*d[k] + bp[6*(size_t)u + k]); ss += d[k]*d[k]; }
+  }
+  const double t0 = block_sum<256>(sc, lds);
+  const double t1 = block_sum<256>(ss, lds);
+  if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; }
+}
+
+constexpr int BS_BLOCK = 256;
+// back-substitution for the points + oplus; partial sums of x(lambda x + b) and x^2
+__global__ void __launch_bounds__(BS_BLOCK)
+k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ g,
+          const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ pt_cur,
+          double* __restrict__ pt_trial, double* __restrict__ xl, double* __restrict__ part_scale,
+          double* __restrict__ part_ss) {
+  __shared__ double lds[BS_BLOCK/64];
+  const int l = blockIdx.x*BS_BLOCK + threadIdx.x;
+  double sc = 0.0, ss = 0.0;
+  if (l < P.nfl) {
+    const double b0 = g[3*(size_t)l], b1 = g[3*(size_t)l+1], b2 = g[3*(size_t)l+2];
+    double t0 = b0, t1 = b1, t2 = b2;
+    const int i0 = P.inc_start[l], i1 = P.inc_start[l+1];
+    for (int i = i0; i < i1; ++i) {
+      const double* Wa = W + 18*(size_t)i; const double* xa = xp + 6*(size_t)P.inc_unk[i];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { t0 -= Wa[3*r]*xa[r]; t1 -= Wa[3*r+1]*xa[r]; t2 -= Wa[3*r+2]*xa[r]; }
+    }
+    const double* I6 = Vinv + 6*(size_t)l;
+    const double d[3] = { I6[0]*t0 + I6[1]*t1 + I6[2]*t2, I6[1]*t0 + I6[3]*t1 + I6[4]*t2, I6[2]*t0 + I6[4]*t1 + I6[5]*t2 };
+    xl[3*(size_t)l] = d[0]; xl[3*(size_t)l+1] = d[1]; xl[3*(size_t)l+2] = d[2];
+    sc = d[0]*(lambda*d[0] + b0) + d[1]*(lambda*d[1] + b1) + d[2]*(lambda*d[2] + b2);
+    ss = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+    const int pt = P.fl_point[l];
+    double o[3];
+    point_oplus(pt_cur + 3*(size_t)pt, d, o);
+    pt_trial[3*(size_t)pt] = o[0]; pt_trial[3*(size_t)pt+1] = o[1]; pt_trial[3*(size_t)pt+2] = o[2];
+  }
+  const double a = block_sum<BS_BLOCK>(sc, lds);
+  const double b = block_sum<BS_BLOCK>(ss, lds);
+  if (threadIdx.x == 0) { part_scale[blockIdx.x] = a; part_ss[blockIdx.x] = b; }
+}
+
+// Tukey outlier flags in sorted order (ChainBundle.cc:1385-1398 with MEstimator.h:84-96)
+__global__ void k_tukey_flags(int n, const double* __restrict__ chi2, double s2, unsigned char* __restrict__ flag) {
+  const int m = blockIdx.x*blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  const double e = fabs(chi2[m]);
+  const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
+  flag[m] = (sq*sq == 0.0) ? 1 : 0;
+}
+
+// (2,2) entry of each free point's marginal covariance: Vi[2][2] + u^T Sinv u, u = W Vi[:,2]
+// (ChainBundle.cc:1419-1437); np <= 12 here.
+__global__ void k_point_cov22(DevProblem P, const double* __restrict__ Vinv, const double* __restrict__ W,
+                              const double* __restrict__ Sinv, double* __restrict__ cov) {
+  const int l = blockIdx.x*blockDim.x + threadIdx.x;
+  if (l >= P.nfl) return;
+  const double* I6 = Vinv + 6*(size_t)l;
+  const double v2[3] = { I6[2], I6[4], I6[5] };
+  double u[12];
+  for (int i = 0; i < 12; ++i) u[i] = 0.0;
+  for (int i = P.inc_start[l]; i < P.inc_start[l+1]; ++i) {
+    const double* Wa = W + 18*(size_t)i; const int ua = P.inc_unk[i];
+    for (int r = 0; r < 6; ++r) u[6*ua + r] += Wa[3*r]*v2[0] + Wa[3*r+1]*v2[1] + Wa[3*r+2]*v2[2];
+  }
+  double c = I6[5];
+  const int np = P.np;
+  for (int i = 0; i < np; ++i) { double s = 0.0; for (int j = 0; j < np; ++j) s += Sinv[i*np + j]*u[j]; c += u[i]*s; }
+  cov[l] = c;
+}
+
+}  // namespace mcp

@@ -1,0 +1,113 @@
+// ba_select.h -- exact k-th order statistic of |x| over a device array (fp64), gfx950.
+//
+// The reference takes medians with a full std::sort and indexes element [size/2]
+// (include/mcptam/MEstimator.h:109-124,194-204; src/ChainBundle.cc:1433-1434).  On the
+// device the same element is found without sorting: a most-significant-digit radix select
+// over the IEEE-754 bit pattern of |x| (monotone for non-negative doubles), 11 bits per
+// pass, 6 passes.  Histograms are integer-valued doubles so that a multi-GPU run can sum
+// them with the same all-reduce hook as everything else (exact below 2^53).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mcp {
+
+constexpr int SEL_BITS = 11;
+constexpr int SEL_BINS = 1 << SEL_BITS;      // 2048
+constexpr int SEL_PASSES = 6;                // 5 x 11 + 9 bits
+constexpr int SEL_BLOCK = 256;
+
+struct SelState { unsigned long long prefix; unsigned long long k; };
+
+__host__ __device__ inline int sel_shift(int pass) { return pass < 5 ? 64 - SEL_BITS*(pass + 1) : 0; }
+__host__ __device__ inline int sel_nbits(int pass) { return pass < 5 ? SEL_BITS : 9; }
+
+// all threads of the block: locate the bin of `hist` (nbins doubles) holding rank k; returns via refs
+__device__ inline void sel_find_bin(const double* __restrict__ hist, int nbins, unsigned long long k,
+                                    int& bin_out, unsigned long long& k_in, unsigned long long* lds /*SEL_BLOCK+2*/) {
+  const int per = (nbins + SEL_BLOCK - 1)/SEL_BLOCK;
+  const int b0 = threadIdx.x*per;
+  unsigned long long loc = 0;
+  for (int i = 0; i < per; ++i) if (b0 + i < nbins) loc += (unsigned long long)hist[b0 + i];
+  lds[threadIdx.x] = loc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long acc = 0; int t = 0;
+    for (; t < SEL_BLOCK; ++t) { if (acc + lds[t] > k) break; acc += lds[t]; }
+    if (t == SEL_BLOCK) { t = SEL_BLOCK - 1; acc -= lds[t]; }      // k beyond the end: clamp to the last element
+    lds[SEL_BLOCK] = (unsigned long long)t; lds[SEL_BLOCK + 1] = acc;
+  }
+  __syncthreads();
+  const int t = (int)lds[SEL_BLOCK];
+  unsigned long long acc = lds[SEL_BLOCK + 1];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int b = t*per; const int be = min(nbins, b + per);
+    for (; b < be; ++b) { const unsigned long long c = (unsigned long long)hist[b]; if (acc + c > k) break; acc += c; }
+    if (b >= be) b = be - 1;
+    lds[SEL_BLOCK] = (unsigned long long)b; lds[SEL_BLOCK + 1] = k - acc;
+  }
+  __syncthreads();
+  bin_out = (int)lds[SEL_BLOCK];
+  k_in = lds[SEL_BLOCK + 1];
+  __syncthreads();
+}
+
+// pass kernel: derive state[pass] from state[pass-1] and hist[pass-1], then histogram digit `pass`
+// of the elements that match the prefix.  hist: SEL_PASSES x SEL_BINS doubles, zeroed beforehand.
+__global__ void __launch_bounds__(SEL_BLOCK)
+k_select_pass(int pass, int n, const double* __restrict__ x, double* __restrict__ hist, SelState* __restrict__ state,
+              unsigned long long k0) {
+  __shared__ unsigned int lh[SEL_BINS];
+  __shared__ unsigned long long sc[SEL_BLOCK + 2];
+  SelState st;
+  if (pass == 0) { st.prefix = 0; st.k = k0; }
+  else {
+    const SelState prev = state[pass - 1];
+    int bin; unsigned long long kin;
+    sel_find_bin(hist + (size_t)(pass - 1)*SEL_BINS, 1 << sel_nbits(pass - 1), prev.k, bin, kin, sc);
+    st.prefix = prev.prefix | ((unsigned long long)bin << sel_shift(pass - 1));
+    st.k = kin;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[pass] = st;
+  for (int i = threadIdx.x; i < SEL_BINS; i += SEL_BLOCK) lh[i] = 0;
+  __syncthreads();
+  const int sh = sel_shift(pass);
+  const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+  const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+  for (size_t i = blockIdx.x*(size_t)SEL_BLOCK + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x*SEL_BLOCK) {
+    const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(x[i]));
+    if ((key & himask) == st.prefix) atomicAdd(&lh[(unsigned int)(key >> sh) & dmask], 1u);
+  }
+  __syncthreads();
+  double* gh = hist + (size_t)pass*SEL_BINS;
+  for (int i = threadIdx.x; i < SEL_BINS; i += SEL_BLOCK) if (lh[i]) unsafeAtomicAdd(gh + i, (double)lh[i]);
+}
+
+// final: resolve the last digit; out[0] = the k-th smallest |x|
+__global__ void __launch_bounds__(SEL_BLOCK)
+k_select_final(const double* __restrict__ hist, const SelState* __restrict__ state, double* __restrict__ out) {
+  __shared__ unsigned long long sc[SEL_BLOCK + 2];
+  const SelState prev = state[SEL_PASSES - 1];
+  int bin; unsigned long long kin;
+  sel_find_bin(hist + (size_t)(SEL_PASSES - 1)*SEL_BINS, 1 << sel_nbits(SEL_PASSES - 1), prev.k, bin, kin, sc);
+  if (threadIdx.x == 0) {
+    const unsigned long long key = prev.prefix | ((unsigned long long)bin << sel_shift(SEL_PASSES - 1));
+    out[0] = __longlong_as_double((long long)key);
+  }
+}
+
+// sigma block from the median (Huber::FindSigmaSquared + RobustKernelData::RecomputeNow limits,
+// MEstimator.h:194-204, ChainBundle.cc:822-830):  sig[0] raw sigma^2, [1] limited, [2] sqrt(limited), [3] median
+__global__ void k_sigma_from_median(const double* __restrict__ med, double n_total, double min_sigma_sq,
+                                    double* __restrict__ sig) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double m = med[0];
+    double s = 1.4826*(1 + 5.0/(n_total*2 - 6))*sqrt(m);
+    s = 1.345*s;
+    const double s2 = s*s;
+    const double lim = (s2 < min_sigma_sq) ? min_sigma_sq : s2;
+    sig[0] = s2; sig[1] = lim; sig[2] = sqrt(lim); sig[3] = m;
+  }
+}
+
+}  // namespace mcp

@@ -1,0 +1,871 @@
+// ba_solver.hip -- host driver and C ABI of the MI355X ChainBundle back end.
+//
+// Mirrors the control flow of ChainBundle::Compute (/root/reference/src/ChainBundle.cc:1305-1451)
+// with g2o's SparseOptimizer::optimize / OptimizationAlgorithmLevenberg::solve schedule
+// (SURVEY.md Appendix A.5); all numeric work runs in the HIP kernels of ba_kernels.h,
+// ba_select.h and ba_chol.h.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mcp_ba.h"
+#include "ba_kernels.h"
+#include "ba_select.h"
+#include "ba_chol.h"
+
+using namespace mcp;
+
+static thread_local std::string g_err;
+static void set_err(const std::string& s) { g_err = s; }
+extern "C" const char* mcp_last_error(void) { return g_err.c_str(); }
+
+#define HIPCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+  set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
+#define HIPCKV(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+  set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+
+static bool is_gfx950(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+extern "C" int mcp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { set_err("hipGetDeviceCount failed: no HIP runtime/device"); return 0; }
+  int c = 0;
+  for (int i = 0; i < n; ++i) if (is_gfx950(i)) ++c;
+  return c;
+}
+
+namespace {
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  int alloc(size_t count) {
+    if (count == 0) count = 1;
+    if (count <= n) return 0;
+    release();
+    hipError_t e = hipMalloc((void**)&p, count*sizeof(T));
+    if (e != hipSuccess) { set_err(std::string("hipMalloc: ") + hipGetErrorString(e)); p = nullptr; return -1; }
+    n = count; return 0;
+  }
+  int upload(const std::vector<T>& v, hipStream_t st) {
+    if (alloc(v.size())) return -1;
+    if (!v.empty()) HIPCK(hipMemcpyAsync(p, v.data(), v.size()*sizeof(T), hipMemcpyHostToDevice, st));
+    return 0;
+  }
+};
+
+struct HPose { int id; int fixed; double T[12]; int unk; int active; };
+struct HPoint { int id; int fixed; double x[3]; int chain; int unk; int active; };
+struct HMeas { int chain, point, cam; double u, v, omega; };
+struct HChain { int len; int v[4]; };
+
+enum Stage { ST_EVAL = 0, ST_SELECT, ST_LIN, ST_SCHUR, ST_CHOL, ST_SOLVE, ST_UPDATE, ST_N };
+
+}  // namespace
+
+struct mcp_ba {
+  int device = 0;
+  hipStream_t st = nullptr;
+  std::vector<mcp_camera> cams;
+  int robust = 1, tukey = 1, verbose = 0;
+  mcp_ba_params prm;
+
+  std::vector<HPose> poses;
+  std::vector<HPoint> points;
+  std::vector<HMeas> meas;
+  std::vector<HChain> chains;
+  std::map<std::array<int, 5>, int> chain_map;
+  std::vector<int> id_kind, id_index;   // by id; kind 1 pose, 2 point
+  int next_id = 1;
+  bool dirty = true;
+
+  // structure
+  int nfp = 0, nfl = 0, np = 0, nx = 0, ninc = 0, nslot = 0;
+  std::vector<int> perm;           // sorted position -> add-order index
+  std::vector<int> fl_point, fp_pose;
+  double m_total = 0;              // global measurement count (all ranks)
+  double nfl_total = 0;            // global free-point count (all ranks)
+  int nx_total() const { return np + 3*(int)nfl_total; }
+
+  // device problem
+  DevBuf<mcp_camera> d_cams;
+  DevBuf<int> d_chain_len, d_chain_pose, d_pose_unk, d_pt_chain, d_pt_unk, d_m_pt, d_m_chain;
+  DevBuf<unsigned char> d_pt_fixed, d_m_cam, d_flags;
+  DevBuf<unsigned short> d_m_mask;
+  DevBuf<double> d_m_u, d_m_v, d_m_omega;
+  DevBuf<int> d_slot_start, d_slot_unk, d_slot_inc, d_inc_start, d_inc_unk, d_fl_point;
+  // state (double buffered: cur / trial)
+  DevBuf<double> d_pose[2], d_pt[2], d_first[2], d_second[2], d_last[2], d_chi2[2];
+  int cur = 0;
+  // system
+  DevBuf<double> d_lin;     // [U (np*np) | bp (np)]
+  DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp copy (np)]   (the all-reduced block)
+  DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
+  DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
+  DevBuf<SelState> d_selstate;
+  DevBuf<int> d_fail;
+  double* h_res = nullptr;  // pinned
+  int* h_fail = nullptr;    // pinned
+
+  // robust data
+  double sigma_sq = 0, sigma_sq_lim = 0;
+  // results
+  int converged = 0, total_iterations = 0; double lambda = 0, max_cov = DBL_MAX, mean_chi2 = 0;
+  double last_chi2_action = DBL_MAX;
+  std::vector<int> outliers;
+  std::vector<mcp_ba_iter_log> logs;
+  mcp_ba_timing timing;
+
+  // multi-rank
+  mcp_allreduce_fn hook = nullptr; void* hook_user = nullptr; int rank = 0, world = 1;
+
+  // profiling
+  struct Ev { int stage; hipEvent_t a, b; };
+  std::vector<Ev> evs; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+
+  DevProblem P;
+
+  ~mcp_ba() {
+    if (h_res) (void)hipHostFree(h_res);
+    if (h_fail) (void)hipHostFree(h_fail);
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  double* U() { return d_lin.p; }
+  double* bp() { return d_lin.p + (size_t)np*np; }
+  double* S() { return d_red.p; }
+  double* rhs() { return d_red.p + (size_t)np*np; }
+
+  hipEvent_t get_event() {
+    if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+    return ev_pool[ev_used++];
+  }
+  void tic(int stage) { if (!prm.profile) return; Ev e{stage, get_event(), get_event()}; (void)hipEventRecord(e.a, st); evs.push_back(e); }
+  void toc() { if (!prm.profile) return; (void)hipEventRecord(evs.back().b, st); }
+
+  int new_id(int kind, int index) {
+    int id = next_id++;
+    if ((int)id_kind.size() <= id) { id_kind.resize(id + 1024, 0); id_index.resize(id + 1024, 0); }
+    id_kind[id] = kind; id_index[id] = index; return id;
+  }
+  int find_chain(const int* ids, int n) {
+    if (n < 1 || n > MCP_MAX_CHAIN) return -1;
+    std::array<int, 5> key{n, -1, -1, -1, -1};
+    for (int i = 0; i < n; ++i) {
+      if (ids[i] <= 0 || ids[i] >= next_id || id_kind[ids[i]] != 1) return -1;
+      key[1 + i] = id_index[ids[i]];
+    }
+    auto it = chain_map.find(key);
+    if (it != chain_map.end()) return it->second;
+    HChain c; c.len = n; for (int i = 0; i < 4; ++i) c.v[i] = (i < n) ? key[1 + i] : 0;
+    chains.push_back(c);
+    int idx = (int)chains.size() - 1; chain_map[key] = idx; return idx;
+  }
+  // PoseChainHelper::MoveTogether, ChainBundle.cc:157-199 (structural: evaluated once per chain pair)
+  bool move_together(const HChain& a, const HChain& b, int depth) const {
+    int furthest = -1;
+    for (;;) {
+      int t = furthest + 1;
+      if (a.len <= t || b.len <= t) break;
+      if (a.v[t] != b.v[t]) break;
+      furthest = t;
+      if (furthest == depth) return true;
+    }
+    if (furthest == -1) return false;
+    for (int i = furthest; i <= depth; ++i) if (!poses[a.v[i]].fixed) return false;
+    return true;
+  }
+
+  int allreduce(double* buf, size_t count) {
+    if (!hook || world <= 1) return 0;
+    HIPCK(hipStreamSynchronize(st));
+    if (hook(hook_user, buf, count, (void*)st) != 0) { set_err("all-reduce hook failed"); return -1; }
+    return 0;
+  }
+
+  int prepare();
+  int upload_state();
+  int download_state();
+  void launch_chains(int which);
+  void launch_eval(int which, bool sum, double* err_out);
+  int select_kth(const double* x, int n, unsigned long long k, double* out_dev);
+  int median_sigma(int which);
+  int read_results(int count);
+  int linearize();
+  int solve_trial(double lam, bool& ok2);
+  int compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda);
+  int final_stats(int nCounter);
+};
+
+// ------------------------------------------------------------------------------------------
+int mcp_ba::prepare() {
+  auto t0 = std::chrono::steady_clock::now();
+  HIPCK(hipSetDevice(device));
+  const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
+  for (auto& p : poses) { p.active = 0; p.unk = -1; }
+  for (auto& p : points) { p.active = 0; p.unk = -1; }
+  for (const auto& m : meas) {
+    HPoint& p = points[m.point]; p.active = 1;
+    const HChain& oc = chains[m.chain]; const HChain& sc = chains[p.chain];
+    for (int k = 0; k < oc.len; ++k) poses[oc.v[k]].active = 1;
+    for (int k = 0; k < sc.len; ++k) poses[sc.v[k]].active = 1;
+  }
+  m_total = (double)nmeas;
+  if (hook && world > 1) {
+    // ranks hold different measurement shards: agree on the active poses and the global count
+    std::vector<double> flags(npose + 2);
+    for (int i = 0; i < npose; ++i) flags[i] = poses[i].active;
+    flags[npose] = (double)nmeas;
+    double nfree = 0; for (const auto& p : points) if (p.active && !p.fixed) nfree += 1;
+    flags[npose + 1] = nfree;
+    DevBuf<double> tmp;
+    if (tmp.upload(flags, st)) return -1;
+    if (allreduce(tmp.p, flags.size())) return -1;
+    HIPCK(hipMemcpy(flags.data(), tmp.p, flags.size()*sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < npose; ++i) poses[i].active = flags[i] > 0;
+    m_total = flags[npose]; nfl_total = flags[npose + 1];
+  }
+  fp_pose.clear(); fl_point.clear();
+  for (int i = 0; i < npose; ++i) if (poses[i].active && !poses[i].fixed) { poses[i].unk = (int)fp_pose.size(); fp_pose.push_back(i); }
+  for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
+  nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
+  if (!(hook && world > 1)) nfl_total = nfl;
+  // sort measurements by point (stable counting sort keeps add order within a point)
+  std::vector<int> cnt(npoint + 1, 0);
+  for (const auto& m : meas) cnt[m.point + 1]++;
+  for (int i = 0; i < npoint; ++i) cnt[i + 1] += cnt[i];
+  perm.assign(nmeas, 0);
+  { std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < nmeas; ++i) perm[pos[meas[i].point]++] = i; }
+  // per (obs chain, src chain) activity mask
+  std::map<std::pair<int, int>, unsigned short> mask_cache;
+  auto pair_mask = [&](int oc, int sc) -> unsigned short {
+    auto key = std::make_pair(oc, sc);
+    auto it = mask_cache.find(key);
+    if (it != mask_cache.end()) return it->second;
+    unsigned short mk = 0;
+    const HChain& o = chains[oc]; const HChain& s = chains[sc];
+    for (int i = 0; i < o.len; ++i) if (!poses[o.v[i]].fixed && !move_together(o, s, i)) mk |= (1 << i);
+    for (int i = 0; i < s.len; ++i) if (!poses[s.v[i]].fixed && !move_together(s, o, i)) mk |= (1 << (4 + i));
+    mask_cache[key] = mk; return mk;
+  };
+  std::vector<int> m_pt(nmeas), m_chain(nmeas), slot_start(nmeas + 1, 0), slot_unk, slot_inc;
+  std::vector<unsigned char> m_cam(nmeas);
+  std::vector<unsigned short> m_mask(nmeas);
+  std::vector<double> m_u(nmeas), m_v(nmeas), m_om(nmeas);
+  std::vector<int> inc_start(nfl + 1, 0), inc_unk;
+  slot_unk.reserve((size_t)nmeas*2); slot_inc.reserve((size_t)nmeas*2); inc_unk.reserve((size_t)nfl*8);
+  int s = 0;
+  while (s < nmeas) {
+    const int pt = meas[perm[s]].point;
+    int e = s; while (e < nmeas && meas[perm[e]].point == pt) ++e;
+    const int lpt = points[pt].unk;
+    const int ibase = (int)inc_unk.size();
+    for (int j = s; j < e; ++j) {
+      const HMeas& m = meas[perm[j]];
+      m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega;
+      const unsigned short mk = pair_mask(m.chain, points[pt].chain);
+      m_mask[j] = mk;
+      slot_start[j] = (int)slot_unk.size();
+      for (int b = 0; b < 8; ++b) {
+        if (!(mk & (1 << b))) continue;
+        const HChain& c = (b < 4) ? chains[m.chain] : chains[points[pt].chain];
+        const int u = poses[c.v[b & 3]].unk;
+        slot_unk.push_back(u);
+        int inc = -1;
+        if (lpt >= 0) {
+          for (int q = ibase; q < (int)inc_unk.size(); ++q) if (inc_unk[q] == u) { inc = q; break; }
+          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); }
+        }
+        slot_inc.push_back(inc);
+      }
+    }
+    if (lpt >= 0) { inc_start[lpt] = ibase; inc_start[lpt + 1] = (int)inc_unk.size(); }
+    s = e;
+  }
+  slot_start[nmeas] = (int)slot_unk.size();
+  // free points without any incidence keep an empty range; make inc_start monotone
+  for (int l = 0, last = 0; l <= nfl; ++l) { if (l > 0 && inc_start[l] < last) inc_start[l] = last; last = inc_start[l]; }
+  ninc = (int)inc_unk.size(); nslot = (int)slot_unk.size();
+
+  // upload
+  std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*4), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
+  std::vector<unsigned char> pt_fixed(npoint);
+  for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < 4; ++i) chain_pose[c*4 + i] = chains[c].v[i]; }
+  for (int i = 0; i < npose; ++i) pose_unk[i] = poses[i].unk;
+  for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
+  if (d_cams.upload(cams, st) || d_chain_len.upload(chain_len, st) || d_chain_pose.upload(chain_pose, st) ||
+      d_pose_unk.upload(pose_unk, st) || d_pt_chain.upload(pt_chain, st) || d_pt_unk.upload(pt_unk, st) ||
+      d_pt_fixed.upload(pt_fixed, st) || d_m_pt.upload(m_pt, st) || d_m_chain.upload(m_chain, st) ||
+      d_m_cam.upload(m_cam, st) || d_m_mask.upload(m_mask, st) || d_m_u.upload(m_u, st) || d_m_v.upload(m_v, st) ||
+      d_m_omega.upload(m_om, st) || d_slot_start.upload(slot_start, st) || d_slot_unk.upload(slot_unk, st) ||
+      d_slot_inc.upload(slot_inc, st) || d_inc_start.upload(inc_start, st) || d_inc_unk.upload(inc_unk, st) ||
+      d_fl_point.upload(fl_point, st)) return -1;
+  const size_t nc = chains.size();
+  for (int b = 0; b < 2; ++b)
+    if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
+        d_second[b].alloc(nc*4*9) || d_last[b].alloc(nc*12) || d_chi2[b].alloc(nmeas)) return -1;
+  const size_t n2 = (size_t)np*np;
+  const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
+  if (d_lin.alloc(n2 + np) || d_red.alloc(n2 + 2*(size_t)np) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
+      d_W.alloc((size_t)ninc*18) || d_Vinv.alloc((size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
+      d_xp_good.alloc(np) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
+      d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
+      d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
+  if (!h_res) HIPCK(hipHostMalloc((void**)&h_res, 32*sizeof(double)));
+  if (!h_fail) HIPCK(hipHostMalloc((void**)&h_fail, 4*sizeof(int)));
+  HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
+  HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
+  HIPCK(hipMemsetAsync(d_sigma.p, 0, 8*sizeof(double), st));
+
+  P.cams = d_cams.p; P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
+  P.npose = npose; P.pose_unk = d_pose_unk.p; P.npoint = npoint; P.pt_chain = d_pt_chain.p; P.pt_unk = d_pt_unk.p;
+  P.pt_fixed = d_pt_fixed.p; P.nmeas = nmeas; P.m_pt = d_m_pt.p; P.m_chain = d_m_chain.p; P.m_cam = d_m_cam.p;
+  P.m_mask = d_m_mask.p; P.m_u = d_m_u.p; P.m_v = d_m_v.p; P.m_omega = d_m_omega.p; P.slot_start = d_slot_start.p;
+  P.slot_unk = d_slot_unk.p; P.slot_inc = d_slot_inc.p; P.nfl = nfl; P.ninc = ninc; P.np = np;
+  P.inc_start = d_inc_start.p; P.inc_unk = d_inc_unk.p; P.fl_point = d_fl_point.p; P.robust = robust;
+  if (upload_state()) return -1;
+  HIPCK(hipStreamSynchronize(st));
+  dirty = false;
+  timing.structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int mcp_ba::upload_state() {
+  std::vector<double> pt((size_t)points.size()*3), ps((size_t)poses.size()*12);
+  for (size_t i = 0; i < poses.size(); ++i) std::memcpy(&ps[i*12], poses[i].T, 96);
+  for (size_t i = 0; i < points.size(); ++i) std::memcpy(&pt[i*3], points[i].x, 24);
+  cur = 0;
+  for (int b = 0; b < 2; ++b) {
+    if (!ps.empty()) HIPCK(hipMemcpyAsync(d_pose[b].p, ps.data(), ps.size()*8, hipMemcpyHostToDevice, st));
+    if (!pt.empty()) HIPCK(hipMemcpyAsync(d_pt[b].p, pt.data(), pt.size()*8, hipMemcpyHostToDevice, st));
+  }
+  HIPCK(hipStreamSynchronize(st));
+  return 0;
+}
+int mcp_ba::download_state() {
+  std::vector<double> pt((size_t)points.size()*3), ps((size_t)poses.size()*12);
+  if (!ps.empty()) HIPCK(hipMemcpyAsync(ps.data(), d_pose[cur].p, ps.size()*8, hipMemcpyDeviceToHost, st));
+  if (!pt.empty()) HIPCK(hipMemcpyAsync(pt.data(), d_pt[cur].p, pt.size()*8, hipMemcpyDeviceToHost, st));
+  HIPCK(hipStreamSynchronize(st));
+  for (size_t i = 0; i < poses.size(); ++i) std::memcpy(poses[i].T, &ps[i*12], 96);
+  for (size_t i = 0; i < points.size(); ++i) std::memcpy(points[i].x, &pt[i*3], 24);
+  return 0;
+}
+
+void mcp_ba::launch_chains(int w) {
+  const int nc = P.nchain;
+  if (nc == 0) return;
+  hipLaunchKernelGGL(k_chains, dim3((nc + 63)/64), dim3(64), 0, st, P, d_pose[w].p, d_first[w].p, d_second[w].p, d_last[w].p);
+}
+void mcp_ba::launch_eval(int w, bool sum, double* err_out) {
+  const int nb = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  if (nb == 0) return;
+  if (sum) hipLaunchKernelGGL((k_eval<true>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, d_sigma.p, d_part0.p);
+  else hipLaunchKernelGGL((k_eval<false>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, d_sigma.p, d_part0.p);
+}
+
+// exact k-th smallest |x| (global over ranks when a hook is installed); result left at out_dev[0]
+int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out_dev) {
+  HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
+  const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
+  for (int p = 0; p < SEL_PASSES; ++p) {
+    hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
+    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
+  }
+  hipLaunchKernelGGL(k_select_final, dim3(1), dim3(SEL_BLOCK), 0, st, d_hist.p, d_selstate.p, out_dev);
+  return 0;
+}
+// RobustKernelData::RecomputeNow on the chi2 array of buffer `w`
+int mcp_ba::median_sigma(int w) {
+  tic(ST_SELECT);
+  const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
+  if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8)) return -1;
+  hipLaunchKernelGGL(k_sigma_from_median, dim3(1), dim3(64), 0, st, d_res.p + 8, m_total,
+                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p);
+  toc();
+  return 0;
+}
+int mcp_ba::read_results(int count) {
+  HIPCK(hipMemcpyAsync(h_res, d_res.p, count*sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// buildSystem at the current state (sigma block must be current)
+int mcp_ba::linearize() {
+  tic(ST_LIN);
+  const size_t n2 = (size_t)np*np;
+  HIPCK(hipMemsetAsync(d_lin.p, 0, (n2 + np)*sizeof(double), st));
+  if (nfl) {
+    HIPCK(hipMemsetAsync(d_V.p, 0, (size_t)nfl*6*sizeof(double), st));
+    HIPCK(hipMemsetAsync(d_g.p, 0, (size_t)nfl*3*sizeof(double), st));
+  }
+  if (ninc) HIPCK(hipMemsetAsync(d_W.p, 0, (size_t)ninc*18*sizeof(double), st));
+  if (P.nmeas)
+    hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P,
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
+  toc();
+  timing.n_linearize++;
+  return 0;
+}
+
+// one LM trial up to and including the evaluation of the trial state.
+// on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
+int mcp_ba::solve_trial(double lam, bool& ok2) {
+  const size_t n2 = (size_t)np*np;
+  const int tr = cur ^ 1;
+  HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+  tic(ST_SCHUR);
+  if (np) {
+    // every rank contributes U_r - Schur_r (+ lambda I once, on rank 0), bp_r - W V^-1 g, and bp_r
+    const double lam_here = (rank == 0) ? lam : 0.0;
+    const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
+    hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, lam_here, U(), bp(), S(), rhs());
+    if (world > 1) HIPCK(hipMemcpyAsync(rhs() + np, bp(), np*sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  if (nfl) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+  toc();
+  if (np && allreduce(d_red.p, n2 + 2*(size_t)np)) return -1;
+  const double* bp_glob = (world > 1) ? rhs() + np : bp();
+  if (np) {
+    tic(ST_CHOL); chol_factor(st, S(), np, d_fail.p); toc();
+    tic(ST_SOLVE); chol_solve(st, S(), np, rhs()); toc();
+  }
+  tic(ST_UPDATE);
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 3);
+  const int nbb = (nfl + BS_BLOCK - 1)/BS_BLOCK;
+  if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, d_Vinv.p,
+                              d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
+  toc();
+  tic(ST_EVAL);
+  launch_chains(tr);
+  launch_eval(tr, true, nullptr);
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
+                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0);
+  toc();
+  if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
+  if (allreduce(d_res.p, 3)) return -1;
+  if (read_results(5)) return -1;
+  h_res[1] += h_res[3]; h_res[2] += h_res[4];
+  ok2 = (h_fail[0] == 0);
+  timing.n_trials++;
+  return 0;
+}
+
+int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda) {
+  auto t_begin = std::chrono::steady_clock::now();
+  HIPCK(hipSetDevice(device));
+  std::memset(&timing, 0, sizeof timing);
+  evs.clear(); ev_used = 0;
+  if (n_iter <= 0) n_iter = prm.max_iterations;
+  auto terminate = [&]() { return abort_flag && *abort_flag; };
+  // Initialize(), ChainBundle.cc:1284-1298
+  outliers.clear(); logs.clear();
+  int conv_mag = 0, conv_res = 0;
+  if (dirty) { if (prepare()) return -1; }
+  converged = 0; total_iterations = 0;
+  int nCounter = 0;
+  if (nx == 0 || P.nmeas == 0) { nCounter = -1; if (P.nmeas) { launch_chains(cur); launch_eval(cur, false, nullptr); } }
+  else {
+    tic(ST_EVAL); launch_chains(cur); launch_eval(cur, false, nullptr); toc();
+    double ni = 2; bool ok = true; int cj = 0;
+    for (int it = 0; it < n_iter && !terminate() && ok; ++it) {
+      mcp_ba_iter_log lg; std::memset(&lg, 0, sizeof lg);
+      // preIteration + first robustify: sigma^2 from |chi2| at the iteration-start state
+      if (robust) { if (median_sigma(cur)) return -1; }
+      tic(ST_EVAL);
+      const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+      hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+      hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0);
+      toc();
+      if (allreduce(d_res.p, 1)) return -1;
+      if (linearize()) return -1;
+      if (it == 0 && !(user_lambda > 0)) {
+        if (world > 1 && np) {     // the diagonal of U is a sum over ranks
+          hipLaunchKernelGGL(k_extract_diag, dim3((np + 255)/256), dim3(256), 0, st, np, (const double*)U(), d_xp_good.p);
+          if (allreduce(d_xp_good.p, np)) return -1;
+          hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_xp_good.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
+          HIPCK(hipMemsetAsync(d_xp_good.p, 0, np*sizeof(double), st));
+        } else
+          hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)U(), np + 1, nfl, (const double*)d_V.p, d_res.p + 5);
+      }
+      HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (read_results(13)) return -1;
+      double currentChi = h_res[0];
+      double tempChi = currentChi;
+      if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
+      lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
+      if (it == 0) {
+        if (user_lambda > 0) lambda = user_lambda;
+        else {
+          double md = h_res[5];
+          if (world > 1) {   // max over ranks of the V diagonals (U is already global)
+            std::vector<double> slots(world, 0.0); slots[rank] = md;
+            HIPCK(hipMemcpyAsync(d_res.p + 16, slots.data(), world*sizeof(double), hipMemcpyHostToDevice, st));
+            if (allreduce(d_res.p + 16, world)) return -1;
+            HIPCK(hipMemcpy(slots.data(), d_res.p + 16, world*sizeof(double), hipMemcpyDeviceToHost));
+            for (double v : slots) md = std::max(md, v);
+          }
+          lambda = 1e-5*md;
+        }
+        ni = 2;
+      }
+      double rho = 0; int qmax = 0; int accepted = 0; double ss_last = 0; double trial_chi_raw = currentChi;
+      do {
+        bool ok2 = true;
+        if (solve_trial(lambda, ok2)) return -1;
+        double scale, ss;
+        trial_chi_raw = h_res[0];
+        if (ok2) {
+          tempChi = h_res[0]; scale = h_res[1]; ss = h_res[2];
+          HIPCK(hipMemcpyAsync(d_xp_good.p, rhs(), std::max(np, 1)*sizeof(double), hipMemcpyDeviceToDevice, st));
+          if (nfl) HIPCK(hipMemcpyAsync(d_xl_good.p, d_xl.p, (size_t)nfl*3*sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else {
+          // CHOLMOD-failure analogue: the solver's x keeps its previous content [g2o]; recompute the
+          // scale terms from it with the current lambda and b
+          tempChi = DBL_MAX;
+          scale = 0; ss = 0;
+          std::vector<double> xp(np), xl((size_t)nfl*3), bpv(np), gv((size_t)nfl*3);
+          if (np) { HIPCK(hipMemcpy(xp.data(), d_xp_good.p, (size_t)np*8, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(bpv.data(), (world > 1) ? rhs() + np : bp(), (size_t)np*8, hipMemcpyDeviceToHost)); }
+          if (nfl) { HIPCK(hipMemcpy(xl.data(), d_xl_good.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(gv.data(), d_g.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); }
+          for (int j = 0; j < np; ++j) { scale += xp[j]*(lambda*xp[j] + bpv[j]); ss += xp[j]*xp[j]; }
+          double sl = 0, sq = 0;
+          for (size_t j = 0; j < xl.size(); ++j) { sl += xl[j]*(lambda*xl[j] + gv[j]); sq += xl[j]*xl[j]; }
+          if (world > 1) {   // point parts are rank-local
+            double v2[2] = { sl, sq };
+            HIPCK(hipMemcpy(d_res.p + 16, v2, 16, hipMemcpyHostToDevice));
+            if (allreduce(d_res.p + 16, 2)) return -1;
+            HIPCK(hipMemcpy(v2, d_res.p + 16, 16, hipMemcpyDeviceToHost)); sl = v2[0]; sq = v2[1];
+          }
+          scale += sl; ss += sq;
+        }
+        ss_last = ss;
+        rho = currentChi - tempChi;
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2*rho - 1), 3);
+          alpha = std::min(alpha, 2./3.);
+          const double sf = std::max(1./3., alpha);
+          lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
+          cur ^= 1;                                  // discardTop: the trial state becomes current
+        } else {
+          lambda *= ni; ni *= 2; accepted = 0;       // pop: the current buffers were never touched
+        }
+        ++qmax;
+      } while (rho < 0 && qmax < prm.max_trials_after_failure && !terminate());
+      ok = !(qmax == prm.max_trials_after_failure || rho == 0);
+      ++cj;
+      // post-iteration actions
+      const double rms = std::sqrt(ss_last/(double)nx_total());
+      if (rms < prm.update_rms_limit && !prm.disable_convergence) { conv_mag = 1; if (abort_flag) *abort_flag = 1; }
+      {
+        // activeRobustChi2 of whatever errors the edges hold: the last trial's (or, when verbose, the
+        // recomputed errors of the current state)
+        double curchi = accepted ? currentChi : (verbose ? currentChi : trial_chi_raw);
+        const double pct = (last_chi2_action - curchi)/last_chi2_action;
+        if (!prm.disable_convergence) {
+          if (pct >= 0 && pct <= prm.update_percent_limit) { conv_res = 1; if (abort_flag) *abort_flag = 1; }
+          else if (curchi == 0) { conv_res = 1; if (abort_flag) *abort_flag = 1; }
+        }
+        last_chi2_action = curchi;
+        lg.chi2_end = curchi;
+      }
+      total_iterations += qmax;
+      lg.lambda_end = lambda; lg.trials = qmax; lg.accepted = accepted; lg.rms_update = rms;
+      logs.push_back(lg);
+    }
+    nCounter = cj;
+  }
+  int rc = final_stats(nCounter);
+  if (rc != -2) {
+    converged = (conv_mag || conv_res);
+    bool external_abort = terminate() && !converged;
+    if (nCounter == 0 && !external_abort) rc = -1;
+    else if (nCounter == 0 && terminate()) rc = 0;
+    else rc = nCounter;
+  } else rc = -1;
+  if (download_state()) return -1;
+  // stage timings
+  if (prm.profile) {
+    (void)hipStreamSynchronize(st);
+    double acc[ST_N] = {0};
+    for (auto& e : evs) { float ms = 0; if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) acc[e.stage] += ms; }
+    timing.eval_ms = acc[ST_EVAL]; timing.select_ms = acc[ST_SELECT]; timing.linearize_ms = acc[ST_LIN];
+    timing.schur_ms = acc[ST_SCHUR]; timing.cholesky_ms = acc[ST_CHOL]; timing.solve_ms = acc[ST_SOLVE]; timing.update_ms = acc[ST_UPDATE];
+  }
+  timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return rc;
+}
+
+// ChainBundle.cc:1339-1345 (final sigma^2), :1368-1399 (Tukey outliers), :1401-1448 (depth covariance)
+int mcp_ba::final_stats(int nCounter) {
+  if (P.nmeas == 0 || dirty) { max_cov = 0; return 0; }
+  if (median_sigma(cur)) return -2;
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0);
+  if (allreduce(d_res.p, 1)) return -2;
+  HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (read_results(13)) return -2;
+  if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
+  mean_chi2 = h_res[0]/m_total;
+  const double median = h_res[12];
+  if (nCounter == 0) return 0;
+  if (tukey) {
+    double s = 1.4826*(1 + 5.0/(m_total*2 - 6))*std::sqrt(median);     // Tukey::FindSigmaSquared, MEstimator.h:109-124
+    s = 4.6851*s;
+    double s2 = s*s;
+    const double mins = prm.min_mestimator_sigma*prm.min_mestimator_sigma;
+    if (s2 < mins) s2 = mins;
+    hipLaunchKernelGGL(k_tukey_flags, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, s2, d_flags.p);
+    std::vector<unsigned char> fl(P.nmeas);
+    HIPCK(hipMemcpyAsync(fl.data(), d_flags.p, P.nmeas, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    std::vector<unsigned char> by_add(P.nmeas, 0);
+    for (int j = 0; j < P.nmeas; ++j) if (fl[j]) by_add[perm[j]] = 1;
+    for (int i = 0; i < P.nmeas; ++i) if (by_add[i]) {
+      const HMeas& m = meas[i];
+      outliers.push_back(points[m.point].id);
+      outliers.push_back(poses[chains[m.chain].v[0]].id);      // vertices().front(), :1394
+      outliers.push_back(m.cam);
+    }
+  }
+  // depth covariance only when fewer than 3 free poses (:1419); Hessian of the last buildSystem, no lambda
+  if (nfp < 3 && nCounter > 0 && world == 1) {
+    bool okm = true;
+    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    const size_t n2 = (size_t)np*np;
+    if (np) {
+      const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
+      hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, 0.0, U(), bp(), S(), rhs());
+    }
+    if (nfl) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+    std::vector<double> Sh(n2 + 1), Sinv(n2 + 1, 0.0);
+    if (np) HIPCK(hipMemcpyAsync(Sh.data(), S(), n2*8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (h_fail[0]) okm = false;
+    if (okm && np) {
+      // <= 12x12 control-plane inverse on the host (lower triangle of S is valid)
+      std::vector<double> L(n2, 0.0);
+      for (int i = 0; i < np && okm; ++i) for (int j = 0; j <= i; ++j) {
+        double sacc = Sh[(size_t)i*np + j];
+        for (int k = 0; k < j; ++k) sacc -= L[(size_t)i*np + k]*L[(size_t)j*np + k];
+        if (i == j) { if (!(sacc > 0)) { okm = false; break; } L[(size_t)i*np + j] = std::sqrt(sacc); }
+        else L[(size_t)i*np + j] = sacc/L[(size_t)j*np + j];
+      }
+      for (int c = 0; c < np && okm; ++c) {
+        std::vector<double> e(np, 0.0); e[c] = 1;
+        for (int i = 0; i < np; ++i) { double sacc = e[i]; for (int k = 0; k < i; ++k) sacc -= L[(size_t)i*np + k]*e[k]; e[i] = sacc/L[(size_t)i*np + i]; }
+        for (int i = np - 1; i >= 0; --i) { double sacc = e[i]; for (int k = i + 1; k < np; ++k) sacc -= L[(size_t)k*np + i]*e[k]; e[i] = sacc/L[(size_t)i*np + i]; }
+        for (int i = 0; i < np; ++i) Sinv[(size_t)i*np + c] = e[i];
+      }
+    }
+    if (okm) {
+      if (nfl > 0) {
+        DevBuf<double> dSinv;
+        std::vector<double> tmp(Sinv.begin(), Sinv.begin() + std::max<size_t>(n2, 1));
+        if (dSinv.upload(tmp, st)) return -2;
+        hipLaunchKernelGGL(k_point_cov22, dim3((nfl + 63)/64), dim3(64), 0, st, P, (const double*)d_Vinv.p, (const double*)d_W.p, (const double*)dSinv.p, d_cov.p);
+        const double m_keep = m_total; (void)m_keep;
+        if (select_kth(d_cov.p, nfl, (unsigned long long)(nfl/2), d_res.p + 8)) return -2;
+        HIPCK(hipMemcpyAsync(h_res, d_res.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        max_cov = h_res[0];
+      } else max_cov = DBL_MAX;                                   // :1441
+    } else max_cov = 0;                                           // :1447
+  } else max_cov = 0;                                             // :1444-1448
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_tukey, int verbose,
+                      const mcp_ba_params* params) {
+  if (!cams || ncam <= 0 || ncam > 255) { set_err("mcp_ba_create: need 1..255 cameras"); return nullptr; }
+  for (int i = 0; i < ncam; ++i)
+    if (cams[i].n_inv <= 0 || cams[i].n_inv > MCP_MAX_INV) { set_err("mcp_ba_create: camera without inverse polynomial (Newton fallback unsupported)"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("mcp_ba_create: no HIP device available (the HIP path has no CPU fallback)"); return nullptr; }
+  mcp_ba_params p;
+  p.max_iterations = 100; p.max_trials_after_failure = 100; p.update_percent_limit = 1e-10; p.update_rms_limit = 1e-10;
+  p.min_mestimator_sigma = 0.5; p.disable_convergence = 0; p.device = -1; p.profile = 0;
+  if (params) p = *params;
+  int dev = p.device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) { set_err("mcp_ba_create: device ordinal out of range"); return nullptr; }
+  if (!is_gfx950(dev)) { set_err("mcp_ba_create: device is not gfx950 (MI355X); this library carries gfx950 code only"); return nullptr; }
+  if (hipSetDevice(dev) != hipSuccess) { set_err("hipSetDevice failed"); return nullptr; }
+  mcp_ba* h = new mcp_ba();
+  h->device = dev; h->prm = p; h->robust = use_robust ? 1 : 0; h->tukey = use_tukey ? 1 : 0; h->verbose = verbose;
+  h->cams.assign(cams, cams + ncam);
+  std::memset(&h->timing, 0, sizeof h->timing);
+  std::memset(&h->P, 0, sizeof h->P);
+  if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
+  return h;
+}
+void mcp_ba_destroy(mcp_ba* h) { if (h) { (void)hipSetDevice(h->device); delete h; } }
+
+int mcp_ba_add_pose(mcp_ba* h, const double R[9], const double t[3], int fixed) {
+  HPose p; std::memset(&p, 0, sizeof p);
+  std::memcpy(p.T, R, 72); std::memcpy(p.T + 9, t, 24); p.fixed = fixed ? 1 : 0; p.unk = -1;
+  p.id = h->new_id(1, (int)h->poses.size());
+  h->poses.push_back(p); h->dirty = true;
+  return p.id;
+}
+int mcp_ba_add_point(mcp_ba* h, const double x[3], const int* chain, int n, int fixed) {
+  int c = h->find_chain(chain, n);
+  if (c < 0) { set_err("mcp_ba_add_point: bad chain"); return -1; }
+  HPoint p; std::memset(&p, 0, sizeof p);
+  std::memcpy(p.x, x, 24); p.chain = c; p.fixed = fixed ? 1 : 0; p.unk = -1;
+  p.id = h->new_id(2, (int)h->points.size());
+  h->points.push_back(p); h->dirty = true;
+  return p.id;
+}
+int mcp_ba_add_meas(mcp_ba* h, const int* chain, int n, int point_id, const double uv[2], double sigma_sq, int cam_index) {
+  if (point_id <= 0 || point_id >= h->next_id || h->id_kind[point_id] != 2) { set_err("mcp_ba_add_meas: unknown point id"); return -1; }
+  if (cam_index < 0 || cam_index >= (int)h->cams.size()) { set_err("mcp_ba_add_meas: bad camera index"); return -1; }
+  int c = h->find_chain(chain, n);
+  if (c < 0) { set_err("mcp_ba_add_meas: bad chain"); return -1; }
+  HMeas m; m.chain = c; m.point = h->id_index[point_id]; m.cam = cam_index; m.u = uv[0]; m.v = uv[1];
+  m.omega = 1/std::sqrt(sigma_sq);                    // information = I / sqrt(sigma^2), ChainBundle.cc:1244-1245
+  h->meas.push_back(m); h->dirty = true;
+  return 0;
+}
+int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, int stride, const int* chain_len,
+                      const unsigned char* fixed, int* ids_out) {
+  for (int i = 0; i < count; ++i) {
+    int id = mcp_ba_add_point(h, x + 3*(size_t)i, chains + (size_t)stride*i, chain_len[i], fixed ? fixed[i] : 0);
+    if (id < 0) return -1;
+    if (ids_out) ids_out[i] = id;
+  }
+  return 0;
+}
+int mcp_ba_add_measurements(mcp_ba* h, int count, const int* chains, int stride, const int* chain_len, const int* point_ids,
+                            const double* uv, const double* sigma_sq, const int* cam_index) {
+  h->meas.reserve(h->meas.size() + count);
+  for (int i = 0; i < count; ++i)
+    if (mcp_ba_add_meas(h, chains + (size_t)stride*i, chain_len[i], point_ids[i], uv + 2*(size_t)i, sigma_sq[i], cam_index[i])) return -1;
+  return 0;
+}
+
+int mcp_ba_compute(mcp_ba* h, volatile unsigned char* abort_flag, int n_iter, double user_lambda) {
+  return h->compute(abort_flag, n_iter, user_lambda);
+}
+int mcp_ba_converged(mcp_ba* h) { return h->converged; }
+int mcp_ba_total_iterations(mcp_ba* h) { return h->total_iterations; }
+int mcp_ba_get_point(mcp_ba* h, int id, double x[3]) {
+  if (id <= 0 || id >= h->next_id || h->id_kind[id] != 2) { set_err("mcp_ba_get_point: unknown id"); return -1; }
+  std::memcpy(x, h->points[h->id_index[id]].x, 24); return 0;
+}
+int mcp_ba_get_pose(mcp_ba* h, int id, double R[9], double t[3]) {
+  if (id <= 0 || id >= h->next_id || h->id_kind[id] != 1) { set_err("mcp_ba_get_pose: unknown id"); return -1; }
+  const HPose& p = h->poses[h->id_index[id]];
+  std::memcpy(R, p.T, 72); std::memcpy(t, p.T + 9, 24); return 0;
+}
+int mcp_ba_get_points(mcp_ba* h, int count, const int* ids, double* x) {
+  for (int i = 0; i < count; ++i) if (mcp_ba_get_point(h, ids[i], x + 3*(size_t)i)) return -1;
+  return 0;
+}
+int mcp_ba_get_poses(mcp_ba* h, int count, const int* ids, double* R, double* t) {
+  for (int i = 0; i < count; ++i) if (mcp_ba_get_pose(h, ids[i], R + 9*(size_t)i, t + 3*(size_t)i)) return -1;
+  return 0;
+}
+int mcp_ba_num_outliers(mcp_ba* h) { return (int)h->outliers.size()/3; }
+int mcp_ba_get_outliers(mcp_ba* h, int* out, int cap) {
+  int n = std::min((int)h->outliers.size()/3, cap);
+  if (n > 0) std::memcpy(out, h->outliers.data(), sizeof(int)*3*(size_t)n);
+  return n;
+}
+double mcp_ba_sigma_squared(mcp_ba* h) { return h->sigma_sq; }
+double mcp_ba_mean_chi_squared(mcp_ba* h) { return h->mean_chi2; }
+double mcp_ba_max_cov(mcp_ba* h) { return h->max_cov; }
+double mcp_ba_lambda(mcp_ba* h) { return h->lambda; }
+int mcp_ba_num_iter_logs(mcp_ba* h) { return (int)h->logs.size(); }
+int mcp_ba_get_iter_logs(mcp_ba* h, mcp_ba_iter_log* out, int cap) {
+  int n = std::min((int)h->logs.size(), cap);
+  if (n > 0) std::memcpy(out, h->logs.data(), sizeof(mcp_ba_iter_log)*(size_t)n);
+  return n;
+}
+int mcp_ba_get_timing(mcp_ba* h, mcp_ba_timing* out) { *out = h->timing; return 0; }
+
+int mcp_ba_set_allreduce(mcp_ba* h, mcp_allreduce_fn hook, void* user, int rank, int world_size) {
+  if (world_size < 1 || rank < 0 || rank >= world_size) { set_err("mcp_ba_set_allreduce: bad rank/world"); return -1; }
+  h->hook = hook; h->hook_user = user; h->rank = rank; h->world = hook ? world_size : 1; h->dirty = true;
+  return 0;
+}
+
+int mcp_ba_prepare(mcp_ba* h) {
+  if (h->prepare()) return -1;
+  return h->nx_total();
+}
+int mcp_ba_eval(mcp_ba* h, double* chi2_out, double* err_out) {
+  if (h->dirty && h->prepare()) return -1;
+  const int n = h->P.nmeas;
+  if (n == 0) return 0;
+  if (err_out && h->d_err.alloc((size_t)n*2)) return -1;
+  h->launch_chains(h->cur);
+  h->launch_eval(h->cur, false, err_out ? h->d_err.p : nullptr);
+  std::vector<double> c(n), e(err_out ? (size_t)n*2 : 0);
+  HIPCK(hipMemcpyAsync(c.data(), h->d_chi2[h->cur].p, (size_t)n*8, hipMemcpyDeviceToHost, h->st));
+  if (err_out) HIPCK(hipMemcpyAsync(e.data(), h->d_err.p, (size_t)n*16, hipMemcpyDeviceToHost, h->st));
+  HIPCK(hipStreamSynchronize(h->st));
+  for (int j = 0; j < n; ++j) {
+    const int i = h->perm[j];
+    if (chi2_out) chi2_out[i] = c[j];
+    if (err_out) { err_out[2*(size_t)i] = e[2*(size_t)j]; err_out[2*(size_t)i + 1] = e[2*(size_t)j + 1]; }
+  }
+  return 0;
+}
+int mcp_ba_robust_chi2(mcp_ba* h, double* sigma_sq_raw, double* chi2_sum) {
+  if (h->dirty && h->prepare()) return -1;
+  const int n = h->P.nmeas;
+  if (n == 0) return -1;
+  h->launch_chains(h->cur);
+  h->launch_eval(h->cur, false, nullptr);
+  if (h->robust && h->median_sigma(h->cur)) return -1;
+  const int nbe = (n + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, h->st, n, h->robust, (const double*)h->d_chi2[h->cur].p, (const double*)h->d_sigma.p, h->d_part0.p);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, h->st, nbe, (const double*)h->d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, h->d_res.p, 0);
+  if (h->allreduce(h->d_res.p, 1)) return -1;
+  HIPCK(hipMemcpyAsync(h->d_res.p + 9, h->d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  if (h->read_results(13)) return -1;
+  if (sigma_sq_raw) *sigma_sq_raw = h->h_res[9];
+  if (chi2_sum) *chi2_sum = h->h_res[0];
+  return 0;
+}
+int mcp_ba_debug_solve(mcp_ba* h, double lambda, double* x_out) {
+  if (h->dirty && h->prepare()) return -1;
+  if (h->P.nmeas == 0 || h->nx == 0) { set_err("mcp_ba_debug_solve: empty problem"); return -1; }
+  h->launch_chains(h->cur);
+  h->launch_eval(h->cur, false, nullptr);
+  if (h->robust && h->median_sigma(h->cur)) return -1;
+  if (h->linearize()) return -1;
+  bool ok2 = true;
+  if (h->solve_trial(lambda, ok2)) return -1;
+  if (!ok2) { set_err("mcp_ba_debug_solve: system not positive definite"); return -1; }
+  if (h->np) HIPCK(hipMemcpy(x_out, h->rhs(), (size_t)h->np*8, hipMemcpyDeviceToHost));
+  if (h->nfl) HIPCK(hipMemcpy(x_out + h->np, h->d_xl.p, (size_t)h->nfl*24, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

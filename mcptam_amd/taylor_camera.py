@@ -19,7 +19,7 @@ MAX_INV_DEGREE = 30  # include/mcptam/TaylorCamera.h:74
 
 
 class McpCamera(ctypes.Structure):
-    """ctypes image of `mcp_camera` (include/mcp_ba.h) == `orc_camera` (oracle/ba_oracle.h)."""
+    """ctypes image of `mcp_camera` (include/mcp_ba.h)."""
     _fields_ = [
         ("params", ctypes.c_double * 9),
         ("image_size", ctypes.c_double * 2),

@@ -1,0 +1,192 @@
+"""Parity of the HIP ChainBundle path (through the C ABI) against the CPU oracle, on a real MI355X."""
+import numpy as np
+import pytest
+
+from helpers import compare_runs, rel_err, run_bundle
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(cams, **kw):
+    from mcptam_amd.chain_bundle import ChainBundle
+    return ChainBundle(cams, kw.pop("robust", True), kw.pop("tukey", True), kw.pop("verbose", False), **kw)
+
+
+def _orc(cams, robust=True, tukey=True, verbose=False):
+    from oracle import OracleBundle
+    return OracleBundle(cams, robust, tukey, verbose)
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "c1", "c2small"])
+def test_eval_and_sigma_match_oracle(gpu_required, cfg):
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg)
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    n = g.Prepare()
+    assert n == o.Prepare()
+    chi_g, err_g = g.Eval(p.n_meas)
+    chi_o, err_o = o.Eval()
+    assert rel_err(err_g, err_o) < 1e-10
+    assert rel_err(chi_g, chi_o) < 1e-10
+    cg, sg = g.DebugRobustChi2()
+    co, so = o.DebugRobustChi2()
+    assert abs(sg - so) <= 1e-12 * so          # the median is an exact element
+    assert abs(cg - co) <= 1e-11 * co
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "c1", "c2small"])
+def test_normal_equations_solution_matches_oracle(gpu_required, cfg):
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg)
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    for lam in (1e-3, 10.0):
+        xg = g.DebugSolve(lam)
+        rc, xs, xd = o.DebugSolve(lam)
+        assert rc == 0
+        assert rel_err(xg, xs) < 1e-7, (cfg, lam)
+
+
+@pytest.mark.parametrize("cfg,iters", [("tiny", 15), ("c1", 25), ("c2small", 12)])
+def test_compute_matches_oracle(gpu_required, cfg, iters):
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg)
+    gpu = run_bundle(_gpu(p.cams), p, iters)
+    ref = run_bundle(_orc(p.cams), p, iters)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0
+    assert gpu["outliers"] == ref["outliers"]
+    assert abs(gpu["sigma_sq"] - ref["sigma_sq"]) <= 1e-6 * ref["sigma_sq"]
+    assert abs(gpu["mean_chi2"] - ref["mean_chi2"]) <= 1e-6 * ref["mean_chi2"]
+    assert abs(gpu["lam"] - ref["lam"]) <= 1e-6 * ref["lam"]
+
+
+def test_c2_full_size_matches_oracle(gpu_required):
+    """BASELINE config c2: 4 cameras, 50 MKF, 10k points, 80k measurements."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2")
+    assert p.n_meas == 80000
+    gpu = run_bundle(_gpu(p.cams), p, 8)
+    ref = run_bundle(_orc(p.cams), p, 8)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0
+    assert gpu["outliers"] == ref["outliers"]
+
+
+def test_zero_noise_recovers_ground_truth(gpu_required):
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=16, n_points=2000, noise=False)
+    gpu = run_bundle(_gpu(p.cams), p, 40)
+    assert gpu["rc"] > 0 and gpu["converged"]
+    assert np.abs(gpu["R"] - p.true_base_R).max() < 1e-9
+    assert np.abs(gpu["t"] - p.true_base_t).max() < 1e-8
+    assert gpu["mean_chi2"] < 1e-12
+
+
+def test_non_robust_and_verbose_modes(gpu_required):
+    from mcptam_amd import synth
+    p = synth.make_config("tiny", n_points=120)
+    for robust, verbose in ((False, False), (True, True)):
+        gpu = run_bundle(_gpu(p.cams, robust=robust, tukey=True, verbose=verbose), p, 10)
+        ref = run_bundle(_orc(p.cams, robust, True, verbose), p, 10)
+        compare_runs(gpu, ref)
+        assert gpu["outliers"] == ref["outliers"]
+
+
+def test_fixed_points_and_single_chain(gpu_required):
+    """Calibration-style fixed points use the chain {world} and chi2 < 0 forces weight 1 (ChainBundle.cc:401-417)."""
+    from mcptam_amd import synth
+    p = synth.make_config("c1", n_fixed_points=40)
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    chi_g, _ = g.Eval(p.n_meas)
+    chi_o, _ = o.Eval()
+    assert (chi_g < 0).sum() == (chi_o < 0).sum() > 0
+    gpu = run_bundle(_gpu(p.cams), p, 12)
+    ref = run_bundle(_orc(p.cams), p, 12)
+    compare_runs(gpu, ref)
+    fixed = p.pt_fixed
+    assert np.array_equal(gpu["X"][fixed], p.pt_x[fixed])      # fixed points never move
+
+
+def test_all_poses_fixed_and_small_cov(gpu_required):
+    """Fewer than 3 free poses: the depth-covariance median is produced (ChainBundle.cc:1419-1437)."""
+    from mcptam_amd import synth
+    p = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=1)
+    gpu = run_bundle(_gpu(p.cams), p, 10)
+    ref = run_bundle(_orc(p.cams), p, 10)
+    compare_runs(gpu, ref)
+    assert ref["max_cov"] > 0
+    assert abs(gpu["max_cov"] - ref["max_cov"]) <= 1e-6 * ref["max_cov"]
+    q = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=3)      # points only
+    gpu = run_bundle(_gpu(q.cams), q, 10)
+    ref = run_bundle(_orc(q.cams), q, 10)
+    compare_runs(gpu, ref)
+    assert abs(gpu["max_cov"] - ref["max_cov"]) <= 1e-6 * max(ref["max_cov"], 1e-300)
+
+
+def test_abort_flag_and_two_step(gpu_required):
+    from mcptam_amd import synth
+    p = synth.make_config("c1")
+    g = _gpu(p.cams)
+    p.populate(g)
+    g.abort.value = 1
+    assert g.Compute(10) == 0                  # aborted before any step (ChainBundle.cc:1365-1366)
+    g.abort.value = 0
+    # two-step mode (BundleAdjusterMulti.cc:210-224): 10 iterations, then to convergence on the same object
+    g2, o2 = _gpu(p.cams), _orc(p.cams)
+    ids = p.populate(g2)
+    p.populate(o2)
+    a, b = g2.Compute(10), o2.Compute(10)
+    assert a == b == 10
+    if not g2.Converged():
+        g2.abort.value = 0
+        o2.abort.value = 0
+        a, b = g2.Compute(), o2.Compute()
+        assert abs(a - b) <= 1
+    Rg, tg = g2.GetPoses(ids["mkf"])
+    Ro = np.array([o2.GetPose(int(i))[0] for i in ids["mkf"]])
+    assert rel_err(Rg, Ro) < 1e-6
+
+
+def test_empty_and_degenerate_inputs(gpu_required):
+    from mcptam_amd import synth
+    p = synth.make_config("tiny")
+    g = _gpu(p.cams)
+    assert g.Compute(5) == -1                  # nothing to optimise: the reference returns -1 (:1362-1363)
+    g = _gpu(p.cams)
+    a = g.AddPose(np.eye(3), np.zeros(3), True)
+    with pytest.raises(RuntimeError):
+        g.AddPoint(np.ones(3), [a + 7], False)                  # unknown pose id in the chain
+    pid = g.AddPoint(np.array([0.1, 0.2, 3.0]), [a], False)
+    with pytest.raises(RuntimeError):
+        g.AddMeas([a], pid + 5, np.zeros(2), 1.0, 0)            # unknown point id
+    with pytest.raises(RuntimeError):
+        g.AddMeas([a], pid, np.zeros(2), 1.0, 9)                # unknown camera
+
+
+def test_metric_size_properties(gpu_required):
+    """BASELINE metric configuration (4-cam, 200 MKF, 50k points, 400k measurements): size-independent
+    properties -- zero-noise recovery of the true trajectory and exactness of the selected median."""
+    from mcptam_amd import synth
+    p = synth.make_config("metric", noise=False)
+    assert p.n_meas == 400000 and p.n_points == 50000
+    g = _gpu(p.cams)
+    ids = p.populate(g)
+    chi2, _ = g.Eval(p.n_meas)
+    _, s_raw = g.DebugRobustChi2()
+    med = np.sort(np.abs(chi2))[p.n_meas // 2]
+    expect = (1.345 * 1.4826 * (1 + 5.0 / (2 * p.n_meas - 6)) * np.sqrt(med)) ** 2
+    assert abs(s_raw - expect) <= 1e-12 * expect
+    rc = g.Compute(30)
+    assert rc > 0 and g.Converged()
+    R, t = g.GetPoses(ids["mkf"])
+    assert np.abs(R - p.true_base_R).max() < 1e-8
+    assert np.abs(t - p.true_base_t).max() < 1e-7
+    logs = g.IterLogs()
+    chis = [l["chi2_end"] for l in logs if l["accepted"]]
+    assert chis[-1] < 1e-10 * logs[0]["chi2_start"]
