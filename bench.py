@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- ChainBundle LM iterations/s on the BASELINE.json metric map (MI355X).
+
+A "step" is one LM outer iteration (one linearisation + T>=1 trial solves + evaluations + one
+Huber sigma^2 recompute) over one 4-camera, 200-MKF, 50k-point, 400k-measurement
+synthetic map shard, with the map resident in HBM before the timed region.  With N ranks every
+rank holds all 200 poses and its own 50k-point / 400k-measurement shard (weak scaling); the
+reduced pose system is summed with RCCL once per trial.  value = N * K / time.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
+
+
+def stage_rooflines(tm, M, N, np_, n_lin, n_trials):
+    """Algorithmic bytes / flops per launch group (meas record 36 B, point 24 B,
+    V+g 72 B, chi2 8 B) over the measured per-launch duration of each stage."""
+    out = {}
+    def hbm(name, ms_total, launches, nbytes):
+        if launches and ms_total > 0:
+            dur = ms_total / launches * 1e-3
+            ach = nbytes / dur / 1e9
+            out[name] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                             traffic=None, avg_ms=ms_total / launches, launches=launches, bytes_per_launch=nbytes)
+    hbm("linearize", tm["linearize_ms"], n_lin, M * 36 + N * 24 + N * 72)
+    hbm("schur", tm["schur_ms"], n_trials, M * 36 + N * 72)
+    hbm("backsub_update", tm["update_ms"], n_trials, M * 36 + N * 72 + N * 24)
+    hbm("eval", tm["eval_ms"], n_trials + n_lin, M * 36 + N * 24 + M * 8)
+    hbm("select", tm["select_ms"], n_lin + 1, M * 8)
+    for name, key, flops in (("cholesky", "cholesky_ms", np_ ** 3 / 3.0), ("tri_solve", "solve_ms", 2.0 * np_ ** 2)):
+        if n_trials and tm[key] > 0:
+            dur = tm[key] / n_trials * 1e-3
+            ach = flops / dur / 1e12
+            out[name] = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
+                             traffic=None, avg_ms=tm[key] / n_trials, launches=n_trials, flops_per_launch=flops)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="metric")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="LM iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import RcclAllReduce
+
+    problem = synth.make_config(args.config, shard=rank)
+    hook = RcclAllReduce(dev) if world > 1 else None
+
+    def fresh(profile=False):
+        b = chain_bundle.ChainBundle(problem.cams, True, True, False, disable_convergence=True, device=local_rank, profile=profile)
+        problem.populate(b)
+        if hook is not None:
+            b.SetAllReduce(hook, rank, world)
+        b.Prepare()          # structure + upload: the map is resident in HBM before the timed region
+        return b
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup: W untimed LM iterations (code objects, allocations, clocks)
+    if args.warmup > 0:
+        b = fresh()
+        b.Compute(args.warmup)
+        b.close()
+    b = fresh()
+    barrier()
+    t0 = time.perf_counter()
+    rc = b.Compute(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if rc != args.steps:
+        raise SystemExit("bench: Compute ran %d of %d iterations (%s)" % (rc, args.steps, chain_bundle.last_error()))
+    logs = b.IterLogs()
+    trials = sum(l["trials"] for l in logs)
+    chi_first, chi_last = logs[0]["chi2_start"], logs[-1]["chi2_end"]
+    b.close()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        value = world * args.steps / dt
+        result = {
+            "metric": "ChainBundle LM iters/sec (4-cam, 200 MKF, 50k pts, 400k meas) @1/2/4/8 GPU",
+            "value": value, "unit": "LM iterations/s (x map shards)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (seed %d, SURVEY.md 8(d) generator)" % synth.DEFAULT_SEED,
+            "config": {"workload": "%s: %d cams, %d MKF, %d points, %d measurements per rank" % (
+                args.config, len(problem.cams), problem.n_mkf, problem.n_points, problem.n_meas),
+                "trials_per_iteration": trials / args.steps, "parallelism": "points sharded x%d, poses replicated" % world,
+                "chi2_first": chi_first, "chi2_last": chi_last},
+        }
+    # per-stage HIP-event timing of the same run shape (separate pass so the events do not perturb `value`)
+    if not args.no_roofline:
+        bp = fresh(profile=True)
+        bp.Compute(args.steps)
+        tm = bp.Timing()
+        np_ = 6 * int((~problem.base_fixed).sum())
+        bp.close()
+        if rank == 0:
+            roofs = stage_rooflines(tm, problem.n_meas, problem.n_points, np_, tm["n_linearize"], tm["n_trials"])
+            stage_ms = {k: tm[k] for k in ("eval_ms", "select_ms", "linearize_ms", "schur_ms", "cholesky_ms", "solve_ms", "update_ms")}
+            dom = max(roofs.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches"])
+            r = dict(dom[1])
+            r["kernel"] = dom[0]
+            result["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms")}
+            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches")} for k, v in roofs.items()}}
+    # CPU baseline: the oracle (a scalar single-thread port of the reference algorithm) on the same map
+    if rank == 0 and world == 1 and args.cpu_iters > 0:
+        from oracle import OracleBundle
+        o = OracleBundle(problem.cams, True, True, False)
+        o.DisableConvergence(True)
+        problem.populate(o)
+        o.Prepare()
+        t0 = time.perf_counter()
+        rc = o.Compute(args.cpu_iters)
+        cdt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": rc / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                                  "sample": "%d LM iterations of the same %d-measurement map (oracle/ba_oracle.c, gcc -O2, 1 thread; "
+                                            "the reference's g2o+CHOLMOD stack cannot be built here)" % (rc, problem.n_meas),
+                                  "host_cores_available": os.cpu_count()}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,10 +167,15 @@ def make_rig(n_cams, lever=0.1):
 def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", seed=DEFAULT_SEED,
                  radius=5.0, arc_step=None, pixel_sigma=0.5, outlier_frac=0.02, pose_sigma=(0.02, 0.5),
                  depth_sigma=0.05, n_fixed_points=0, cam_params=DEFAULT_CAM_PARAMS, image_size=(640, 480),
-                 noise=True, perturb=True, k_near=12, n_fixed_mkf=1):
+                 noise=True, perturb=True, k_near=12, n_fixed_mkf=1, shard=0):
     """SURVEY.md 8(d) generator.  Returns a Problem with exactly n_points points and
-    per_point*n_points measurements."""
-    rng = np.random.default_rng(seed)
+    per_point*n_points measurements.
+
+    `shard` selects an independent set of points/measurements over the SAME trajectory and the
+    same initial pose perturbation (multi-GPU runs: every rank holds all poses and its own shard
+    of the map)."""
+    rng = np.random.default_rng([seed, 1 + shard])      # points, measurements, noise
+    rng_pose = np.random.default_rng([seed, 0])        # pose perturbation: identical on every shard
     cam = TaylorCamera(cam_params, image_size, image_size, image_size)
     cams = [cam] * n_cams
     cam_R, cam_t = make_rig(n_cams)
@@ -252,7 +257,7 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
         for k in range(n_mkf):
             if base_fixed[k]:
                 continue
-            xi = np.concatenate([rng.normal(size=3) * pose_sigma[0], rng.normal(size=3) * math.radians(pose_sigma[1])])
+            xi = np.concatenate([rng_pose.normal(size=3) * pose_sigma[0], rng_pose.normal(size=3) * math.radians(pose_sigma[1])])
             R, t = se3_exp(xi)
             base_R[k] = R @ tR[k]
             base_t[k] = R @ tt[k] + t
@@ -266,7 +271,7 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
 
 # the BASELINE.json configurations (SURVEY.md 8 notation)
 CONFIGS = {
-    "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3),
+    "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3, n_fixed_mkf=2),  # 2 fixed KFs pin the monocular scale gauge
     "c2": dict(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi"),
     "metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi"),
     "c4": dict(n_cams=4, n_mkf=500, n_points=100000, per_point=8, mode="multi"),
