@@ -163,6 +163,10 @@ int mcp_ba_robust_chi2(mcp_ba*, double* sigma_sq_raw, double* chi2_sum);
  * device; x has mcp_ba_prepare() entries: free poses (id order) then free points (id order) */
 int mcp_ba_debug_solve(mcp_ba*, double lambda, double* x_out);
 
+/* dense SPD solve A x = b (row-major n x n, lower triangle read) with the reduced-system
+ * Cholesky kernels; returns -1 if A is not positive definite.  n <= 6144. */
+int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x);
+
 #ifdef __cplusplus
 }
 #endif

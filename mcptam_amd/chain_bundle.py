@@ -50,7 +50,7 @@ BA_SYMBOLS = [
     "mcp_ba_total_iterations", "mcp_ba_get_point", "mcp_ba_get_pose", "mcp_ba_get_points", "mcp_ba_get_poses",
     "mcp_ba_num_outliers", "mcp_ba_get_outliers", "mcp_ba_sigma_squared", "mcp_ba_mean_chi_squared", "mcp_ba_max_cov",
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
-    "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve",
+    "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
     L.mcp_ba_eval.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.mcp_ba_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.mcp_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
+    L.mcp_dense_spd_solve.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p]
     _LIB = L
     return L
 
@@ -107,6 +108,16 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(c_int_p)
+
+
+def dense_spd_solve(A, b):
+    """Solve A x = b on the GPU with the reduced-system Cholesky kernels (test hook)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    if lib().mcp_dense_spd_solve(_dp(A), A.shape[0], _dp(b), _dp(x)) != 0:
+        raise RuntimeError("mcp_dense_spd_solve failed: " + last_error())
+    return x
 
 
 class ChainBundle:

@@ -1,163 +1,223 @@
-// ba_chol.h -- dense fp64 Cholesky of the reduced pose system on gfx950.
+// ba_chol.h -- dense fp64 Cholesky solve of the reduced pose system on gfx950.
 //
 // Replaces g2o::LinearSolverCholmod (src/ChainBundle.cc:1156) for the (6P x 6P) system that
-// remains after the points are eliminated.  S is row-major n x n with leading dimension n;
-// only the lower triangle is read and written.  Blocked right-looking factorisation with
-// 32-wide panels; a failed pivot (matrix not positive definite == CHOLMOD failure, which
-// g2o turns into a rejected LM trial) raises *fail.
+// remains after the points are eliminated.  Layout: S is row-major n x n (leading dimension
+// n, lower triangle meaningful) and the right-hand side is stored directly behind it, i.e. it
+// is row n of an (n+1) x n matrix.  Factoring that augmented matrix gives the forward
+// substitution for free: after the last step row n holds y = L^-1 rhs.
+//
+// One launch per 32-wide block step (launch boundaries are ~1.5 us on MI355X, cheaper than
+// any grid barrier).  Launch k:
+//   every tile (ti >= tj >= k):  C -= L(ti,k-1) L(tj,k-1)^T      fp64 MFMA 16x16x4
+//   tiles of block column k:     redundantly update + factor the diagonal tile in registers
+//                                (one wavefront, v_readlane broadcasts), then X L_kk^T = C.
+// A non-positive pivot (CHOLMOD failure in the reference == rejected LM trial) raises *fail.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace mcp {
 
 constexpr int CH_NB = 32;
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
 
-// factor the diagonal block at k0 (nbe x nbe, nbe <= 32) with one wavefront
-__global__ void __launch_bounds__(64)
-k_potrf_diag(double* __restrict__ S, int n, int k0, int nbe, int* __restrict__ fail) {
-  __shared__ double T[CH_NB][CH_NB + 1];
-  const int t = threadIdx.x;
-  for (int i = t; i < nbe*nbe; i += 64) { const int r = i / nbe, c = i % nbe; T[r][c] = (c <= r) ? S[(size_t)(k0 + r)*n + k0 + c] : 0.0; }
-  __syncthreads();
-  for (int j = 0; j < nbe; ++j) {
-    if (t == j) {
-      double d = T[j][j];
-      if (!(d > 0.0)) { atomicOr(fail, 2); d = 1.0; }
-      T[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    if (t > j && t < nbe) T[t][j] /= T[j][j];
-    __syncthreads();
-    if (t > j && t < nbe) { const double l = T[t][j]; for (int c = j + 1; c <= t; ++c) T[t][c] -= l*T[c][j]; }
-    __syncthreads();
-  }
-  for (int i = t; i < nbe*nbe; i += 64) { const int r = i / nbe, c = i % nbe; if (c <= r) S[(size_t)(k0 + r)*n + k0 + c] = T[r][c]; }
+__device__ inline double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
 }
 
-// panel: rows below the diagonal block, X L_kk^T = A  (one thread per row)
-__global__ void __launch_bounds__(64)
-k_trsm_panel(double* __restrict__ S, int n, int k0) {
-  __shared__ double L[CH_NB][CH_NB + 1];
-  const int t = threadIdx.x;
-  for (int i = t; i < CH_NB*CH_NB; i += 64) { const int r = i / CH_NB, c = i % CH_NB; L[r][c] = S[(size_t)(k0 + r)*n + k0 + c]; }
-  __syncthreads();
-  const int row = k0 + CH_NB + blockIdx.x*64 + t;
-  if (row >= n) return;
-  double a[CH_NB];
-  double* p = S + (size_t)row*n + k0;
+// load a 32x32 tile (rows r0.., cols c0..) into LDS, zero outside [nrows) x [ncols)
+__device__ inline void chol_load_tile(const double* __restrict__ A, int ld, int nrows, int ncols, int r0, int c0,
+                                      double (*T)[CH_NB + 1]) {
+  const int lane = threadIdx.x;
+  const int c = lane & 31, rb = lane >> 5;
 #pragma unroll
-  for (int c = 0; c < CH_NB; ++c) a[c] = p[c];
-#pragma unroll
-  for (int c = 0; c < CH_NB; ++c) {
-    double s = a[c];
-#pragma unroll
-    for (int j = 0; j < c; ++j) s -= a[j]*L[c][j];
-    a[c] = s / L[c][c];
+  for (int i = 0; i < 16; ++i) {
+    const int r = 2*i + rb;
+    T[r][c] = (r0 + r < nrows && c0 + c < ncols) ? A[(size_t)(r0 + r)*ld + c0 + c] : 0.0;
   }
-#pragma unroll
-  for (int c = 0; c < CH_NB; ++c) p[c] = a[c];
 }
 
-// trailing update: C(ti,tj) -= P_ti P_tj^T for 32x32 tiles ti >= tj beyond the panel
-__global__ void __launch_bounds__(256)
-k_syrk_tile(double* __restrict__ S, int n, int k0) {
-  const int tj = blockIdx.x, ti = blockIdx.y;
+// acc(2x2 MFMA tiles, C/D layout) -= Pi * Pj^T over K = 32
+__device__ inline void chol_tile_mma(double (*Pi)[CH_NB + 1], double (*Pj)[CH_NB + 1], chol_d4 acc[2][2]) {
+  const int lane = threadIdx.x;
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < CH_NB; kk += 4) {
+    const double a0 = -Pi[i][kk + kq], a1 = -Pi[16 + i][kk + kq];
+    const double b0 = Pj[i][kk + kq], b1 = Pj[16 + i][kk + kq];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+// C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
+__device__ inline void chol_acc_from_lds(double (*T)[CH_NB + 1], chol_d4 acc[2][2]) {
+  const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[bi][bj][g] = T[16*bi + rq + 4*g][16*bj + c];
+}
+__device__ inline void chol_acc_to_lds(double (*T)[CH_NB + 1], const chol_d4 acc[2][2]) {
+  const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) T[16*bi + rq + 4*g][16*bj + c] = acc[bi][bj][g];
+}
+
+__global__ void __launch_bounds__(64)
+k_chol_step(double* __restrict__ S, int n, int nrows, int k, int* __restrict__ fail) {
+  const int ti = k + blockIdx.x, tj = k + blockIdx.y;
   if (tj > ti) return;
-  __shared__ double Pi[CH_NB][CH_NB + 1];
-  __shared__ double Pj[CH_NB][CH_NB + 1];
-  const int base = k0 + CH_NB;
-  const int r0 = base + ti*CH_NB, c0 = base + tj*CH_NB;
-  for (int i = threadIdx.x; i < CH_NB*CH_NB; i += 256) {
-    const int r = i / CH_NB, c = i % CH_NB;
-    Pi[r][c] = (r0 + r < n) ? S[(size_t)(r0 + r)*n + k0 + c] : 0.0;
-    Pj[r][c] = (c0 + r < n) ? S[(size_t)(c0 + r)*n + k0 + c] : 0.0;
+  __shared__ double Ta[CH_NB][CH_NB + 1];
+  __shared__ double Tb[CH_NB][CH_NB + 1];
+  __shared__ double Tc[CH_NB][CH_NB + 1];
+  __shared__ double Td[CH_NB][CH_NB + 1];
+  __shared__ double Te[CH_NB][CH_NB + 1];
+  const int lane = threadIdx.x;
+  const int r0 = ti*CH_NB, c0 = tj*CH_NB, k0 = k*CH_NB, p0 = (k - 1)*CH_NB;
+  const bool panel = (tj == k), offdiag = (ti != k);
+  // ---- all global loads up front: own tile, the two tiles of panel k-1, and (block column k) the diagonal tile
+  chol_load_tile(S, n, nrows, n, r0, c0, Tc);
+  if (k > 0) {
+    chol_load_tile(S, n, nrows, n, r0, p0, Ta);
+    chol_load_tile(S, n, nrows, n, c0, p0, Tb);
+  }
+  if (panel && offdiag) {
+    chol_load_tile(S, n, nrows, n, k0, k0, Td);
+    if (k > 0) chol_load_tile(S, n, nrows, n, k0, p0, Te);
   }
   __syncthreads();
-  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-  double acc[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll 8
-  for (int k = 0; k < CH_NB; ++k) {
-    const double a0 = Pi[2*ty][k], a1 = Pi[2*ty+1][k], b0 = Pj[2*tx][k], b1 = Pj[2*tx+1][k];
-    acc[0][0] += a0*b0; acc[0][1] += a0*b1; acc[1][0] += a1*b0; acc[1][1] += a1*b1;
+  chol_d4 acc[2][2];
+  chol_acc_from_lds(Tc, acc);
+  if (k > 0) chol_tile_mma(Ta, Tb, acc);
+  chol_d4 dacc[2][2];
+  if (panel && offdiag) {
+    chol_acc_from_lds(Td, dacc);
+    if (k > 0) chol_tile_mma(Te, Te, dacc);
   }
+  __syncthreads();
+  chol_acc_to_lds(Tc, acc);
+  if (panel && offdiag) chol_acc_to_lds(Td, dacc);
+  __syncthreads();
+  if (!panel) {      // plain trailing tile: write back and leave
+    const int c = lane & 31, rb = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = r0 + 2*ty + i, c = c0 + 2*tx + j;
-      if (r < n && c < n && c <= r) S[(size_t)r*n + c] -= acc[i][j];
+    for (int i = 0; i < 16; ++i) {
+      const int r = 2*i + rb;
+      if (r0 + r < nrows && c0 + c < n && (ti > tj || c <= r)) S[(size_t)(r0 + r)*n + c0 + c] = Tc[r][c];
     }
+    return;
+  }
+  // ---- block column k: unblocked panel factorisation of [diagonal tile ; own tile], one row per lane.
+  // lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the own tile (for the diagonal
+  // block itself: only rows beyond the matrix, i.e. the right-hand-side row).  Applying the column operations
+  // of the Cholesky factorisation to the lower rows yields X = C L_kk^-T without a separate triangular solve.
+  double (*Tdiag)[CH_NB + 1] = offdiag ? Td : Tc;
+  const int nbe = min(CH_NB, n - k0);
+  const int rr = lane & 31;
+  const bool low = lane >= 32;
+  double d[CH_NB];
+  if (!low) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) d[c] = (c <= rr && rr < nbe && c < nbe) ? Tdiag[rr][c] : ((c == rr) ? 1.0 : 0.0);
+  } else {
+    const bool use = offdiag || rr >= nbe;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) d[c] = (use && c < nbe) ? Tc[rr][c] : 0.0;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < CH_NB; ++j) {
+    double piv = readlane_f64(d[j], j);
+    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+    const double inv = rsqrt(piv);
+    d[j] = (lane == j) ? piv*inv : d[j]*inv;
+    // broadcast column j of L_kk (independent v_readlane pairs), then the rank-1 update of the remaining columns
+    double lc[CH_NB];
+#pragma unroll
+    for (int c = j + 1; c < CH_NB; ++c) lc[c] = readlane_f64(d[j], c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = j + 1; c < CH_NB; ++c) d[c] -= d[j]*lc[c];    // entries above the diagonal: unused garbage
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (bad && lane == 0) atomicOr(fail, 2);
+  if (!low) {
+    if (!offdiag && lane < nbe) {
+      double* p = S + (size_t)(k0 + lane)*n + k0;
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) if (c <= lane) p[c] = d[c];
+    }
+  } else if (r0 + rr < nrows && (offdiag || rr >= nbe)) {
+    double* p = S + (size_t)(r0 + rr)*n + k0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) if (c < nbe) p[c] = d[c];
+  }
 }
 
-// solve L L^T x = b in place (b -> x); single workgroup, x staged in LDS.  n <= CH_TRSV_MAX.
-constexpr int CH_TRSV_MAX = 6144;
-__global__ void __launch_bounds__(1024)
-k_chol_solve(const double* __restrict__ S, int n, double* __restrict__ b) {
+// backward substitution L^T x = y (y = row n of the augmented matrix); single workgroup.
+constexpr int CH_BACK_THREADS = 512;
+constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
+__global__ void __launch_bounds__(CH_BACK_THREADS)
+k_chol_back(const double* __restrict__ S, int n, double* __restrict__ xout) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   const int t = threadIdx.x;
-  for (int i = t; i < n; i += 1024) xs[i] = b[i];
+  const double* y = S + (size_t)n*n;
+  for (int i = t; i < n; i += CH_BACK_THREADS) xs[i] = y[i];
   __syncthreads();
-  // forward: L y = b
-  for (int k0 = 0; k0 < n; k0 += CH_NB) {
-    const int nbe = min(CH_NB, n - k0);
-    if (t < 64) {        // wave 0 solves the diagonal block
-      double y = (t < nbe) ? xs[k0 + t] : 0.0;
-      for (int c = 0; c < nbe; ++c) {
-        const double lcc = S[(size_t)(k0 + c)*n + k0 + c];
-        const double yc = __shfl(y, c, 64) / lcc;
-        if (t == c) y = yc;
-        else if (t > c && t < nbe) y -= S[(size_t)(k0 + t)*n + k0 + c]*yc;
-      }
-      if (t < nbe) xs[k0 + t] = y;
-    }
-    __syncthreads();
-    for (int r = k0 + nbe + t; r < n; r += 1024) {
-      const double* Lr = S + (size_t)r*n + k0;
-      double s = 0.0;
-      for (int c = 0; c < nbe; ++c) s += Lr[c]*xs[k0 + c];
-      xs[r] -= s;
-    }
-    __syncthreads();
-  }
-  // backward: L^T x = y
   const int nblk = (n + CH_NB - 1)/CH_NB;
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
     if (t < 64) {
-      double y = (t < nbe) ? xs[k0 + t] : 0.0;
-      for (int c = nbe - 1; c >= 0; --c) {
-        const double lcc = S[(size_t)(k0 + c)*n + k0 + c];
-        const double xc = __shfl(y, c, 64) / lcc;
-        if (t == c) y = xc;
-        else if (t < c) y -= S[(size_t)(k0 + c)*n + k0 + t]*xc;
+      const int rr = t & 31;
+      // column rr of L_kk: Lc[c] = L[k0+c][k0+rr], c >= rr
+      double Lc[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) Lc[c] = (c >= rr && c < nbe && rr < nbe) ? S[(size_t)(k0 + c)*n + k0 + rr] : ((c == rr) ? 1.0 : 0.0);
+      double yv = (rr < nbe) ? xs[k0 + rr] : 0.0;
+      double dg = 1.0;
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) if (c == rr) dg = Lc[c];
+      const double rinv = 1.0/dg;
+#pragma unroll
+      for (int c = CH_NB - 1; c >= 0; --c) {
+        const double xc = readlane_f64(yv, c)*readlane_f64(rinv, c);
+        if (rr == c) yv = xc;
+        else if (rr < c) yv -= Lc[c]*xc;
       }
-      if (t < nbe) xs[k0 + t] = y;
+      if (t < nbe) xs[k0 + t] = yv;
     }
     __syncthreads();
-    for (int c = t; c < k0; c += 1024) {
+    for (int c = t; c < k0; c += CH_BACK_THREADS) {
       double s = 0.0;
+#pragma unroll 8
       for (int r = 0; r < nbe; ++r) s += S[(size_t)(k0 + r)*n + c]*xs[k0 + r];
       xs[c] -= s;
     }
     __syncthreads();
   }
-  for (int i = t; i < n; i += 1024) b[i] = xs[i];
+  for (int i = t; i < n; i += CH_BACK_THREADS) xout[i] = xs[i];
 }
 
+// factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
 inline void chol_factor(hipStream_t st, double* S, int n, int* fail) {
-  for (int k0 = 0; k0 < n; k0 += CH_NB) {
-    const int nbe = (n - k0 < CH_NB) ? n - k0 : CH_NB;
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, st, S, n, k0, nbe, fail);
-    const int rem = n - k0 - CH_NB;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3((rem + 63)/64), dim3(64), 0, st, S, n, k0);
-      const int T = (rem + CH_NB - 1)/CH_NB;
-      hipLaunchKernelGGL(k_syrk_tile, dim3(T, T), dim3(256), 0, st, S, n, k0);
-    }
-  }
+  const int nrows = n + 1;
+  const int ntc = (n + CH_NB - 1)/CH_NB, ntr = (nrows + CH_NB - 1)/CH_NB;
+  for (int k = 0; k < ntc; ++k)
+    hipLaunchKernelGGL(k_chol_step, dim3(ntr - k, ntc - k), dim3(64), 0, st, S, n, nrows, k, fail);
 }
-inline void chol_solve(hipStream_t st, const double* S, int n, double* b) {
-  hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(1024), (size_t)n*sizeof(double), st, S, n, b);
+// row n: y -> x = L^-T y
+inline void chol_back(hipStream_t st, double* S, int n) {
+  hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n, S + (size_t)n*n);
 }
 
 }  // namespace mcp

@@ -1,0 +1,363 @@
+// ba_group.h -- group-tiled linearisation and point elimination (gfx950, fp64).
+//
+// The host packs the map points (sorted by the pose their coordinates are expressed in) into
+// groups of <= 64 points that touch <= 16 free poses.  Inside a group every pose-pose block of
+// the normal equations lives in a 96x96 local tile, so the 400k-measurement accumulations that
+// g2o performs edge by edge (BaseMultiEdge::constructQuadraticForm, called from
+// src/ChainBundle.cc via optimizer.optimize) never touch HBM with an atomic:
+//   k_linearize_group : one wavefront per group, one lane per point; Jacobians of
+//                       EdgeChainMeas::linearizeOplus (ChainBundle.cc:449-749); V, g, W go out
+//                       with plain stores, the pose blocks are summed in an LDS tile (ds_add_f64)
+//                       and flushed once per group.
+//   k_schur_group     : S -= W V^-1 W^T as a dense zero-filled (96 x 3*16)(3*16 x 96) product
+//                       per 16-point chunk on the fp64 matrix cores (v_mfma_f64_16x16x4).
+#pragma once
+#include "ba_kernels.h"
+
+namespace mcp {
+
+// packed lower-triangular index of the local tile
+__device__ inline int tri(int r, int c) { return r*(r + 1)/2 + c; }
+constexpr int GRP_TRI = GRP_DOF*(GRP_DOF + 1)/2;     // 4656
+
+__device__ inline void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// add w * Ja^T Jb (6x6) into the local tile at local poses (la, lb); la != lb or full symmetric handled by caller
+__device__ inline void tile_add_cross(double* Sl, int la, int lb, const double* Ja, const double* Jb, double w) {
+  // block rows belong to the larger local index (lower triangle)
+  if (la > lb) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) lds_add(Sl + tri(6*la + r, 6*lb + c), w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c]));
+  } else if (lb > la) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) lds_add(Sl + tri(6*lb + r, 6*la + c), w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c)
+        lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+                  const double* __restrict__ second, const double* __restrict__ sigma,
+                  double* __restrict__ U, double* __restrict__ bp, double* __restrict__ V,
+                  double* __restrict__ g, double* __restrict__ W) {
+  __shared__ double Sl[GRP_TRI];
+  __shared__ double bl[GRP_DOF];
+  const int grp = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < GRP_TRI; i += 64) Sl[i] = 0.0;
+  for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
+  __syncthreads();
+  const int sp = P.g_sp0[grp] + lane;
+  const bool valid = sp < P.g_sp0[grp + 1] && !P.sp_big[sp];
+  // register accumulators of the first source-chain slot (the pose the point is expressed in)
+  double Uss[21], bs[6];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) Uss[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) bs[i] = 0.0;
+  int ls = -1;
+  if (valid) {
+    const int pt = P.sp_pt[sp];
+    const int sc = P.pt_chain[pt], slen = P.chain_len[sc];
+    const int lpt = P.pt_unk[pt];
+    const double x[3] = { pt_x[3*(size_t)pt], pt_x[3*(size_t)pt+1], pt_x[3*(size_t)pt+2] };
+    Se3 Ts;
+    load_se3(first + 12*(size_t)(sc*4 + slen - 1), Ts);
+    double xw[3];
+    se3_apply_inv(Ts, x, xw);
+    // point frame (shared by all measurements of the point)
+    double c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0}, c2v[3] = {0, 0, 0};
+    if (lpt >= 0) {
+      double Rp[9], dir[3], rho, rx[3], g0[3], g1[3];
+      point_frame(x, Rp, dir, rho);
+      mat3_vec(Rp, x, rx);
+      generator(3, rx, g0); generator(4, rx, g1);
+      mat3t_vec(Rp, g0, c0); mat3t_vec(Rp, g1, c1);
+      c2v[0] = -x[0]/rho; c2v[1] = -x[1]/rho; c2v[2] = -x[2]/rho;
+    }
+    double Vp[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+    const bool fixed_neg = P.pt_fixed[pt] && P.robust;
+    for (int m = P.sp_m[sp]; m < P.sp_m[sp + 1]; ++m) {
+      const int oc = P.m_chain[m], olen = P.chain_len[oc];
+      const int mask = P.m_mask[m];
+      if ((mask & 0xff) == 0 && lpt < 0) continue;
+      Se3 To;
+      load_se3(first + 12*(size_t)(oc*4 + olen - 1), To);
+      double xc[3];
+      se3_apply(To, xw, xc);
+      Projection pr;
+      cam_project<true>(P.cams[P.m_cam[m]], xc, pr);
+      const double e0 = P.m_u[m] - pr.u, e1 = P.m_v[m] - pr.v;
+      const double omega = P.m_omega[m];
+      double c2 = omega*(e0*e0 + e1*e1);
+      if (fixed_neg) c2 = -c2;
+      double w = omega;
+      if (P.robust) { double r0, r1; robustify(c2, sigma[1], sigma[2], r0, r1); w *= r1; }
+      double dT[3], dP[3];
+      cam_sphere_deriv(xc, dT, dP);
+      double A[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        A[c]     = -(pr.D[0]*dT[c] + pr.D[1]*dP[c]);
+        A[3 + c] = -(pr.D[2]*dT[c] + pr.D[3]*dP[c]);
+      }
+      double Jp[6] = {0, 0, 0, 0, 0, 0};
+      if (lpt >= 0) {
+        double Rcs[9], AR[6];
+        mat3_mul_t(To.R, Ts.R, Rcs);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) AR[3*r+c] = A[3*r]*Rcs[c] + A[3*r+1]*Rcs[3+c] + A[3*r+2]*Rcs[6+c];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          Jp[3*r]   = AR[3*r]*c0[0]  + AR[3*r+1]*c0[1]  + AR[3*r+2]*c0[2];
+          Jp[3*r+1] = AR[3*r]*c1[0]  + AR[3*r+1]*c1[1]  + AR[3*r+2]*c1[2];
+          Jp[3*r+2] = AR[3*r]*c2v[0] + AR[3*r+1]*c2v[1] + AR[3*r+2]*c2v[2];
+        }
+        Vp[0] += w*(Jp[0]*Jp[0] + Jp[3]*Jp[3]); Vp[1] += w*(Jp[0]*Jp[1] + Jp[3]*Jp[4]); Vp[2] += w*(Jp[0]*Jp[2] + Jp[3]*Jp[5]);
+        Vp[3] += w*(Jp[1]*Jp[1] + Jp[4]*Jp[4]); Vp[4] += w*(Jp[1]*Jp[2] + Jp[4]*Jp[5]); Vp[5] += w*(Jp[2]*Jp[2] + Jp[5]*Jp[5]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gp[c] += -w*(Jp[c]*e0 + Jp[3+c]*e1);
+      }
+      const int s0 = P.slot_start[m], ns = P.slot_start[m+1] - s0;
+      int ia = 0;
+      for (int bit_a = 0; bit_a < 8 && ia < ns; ++bit_a) {
+        if (!(mask & (1 << bit_a))) continue;
+        SlotGeom sa; double Ja[12];
+        make_slot(bit_a >> 2, bit_a & 3, A, xw, first, second, oc, sc, To.R, sa);
+        slot_jacobian(sa, Ja);
+        const int la = P.slot_lp[s0 + ia];
+        if (bit_a == 4) {            // first source link: private accumulators, reduced across the wave below
+          ls = la;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) bs[r] += -w*(Ja[r]*e0 + Ja[6+r]*e1);
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) { Uss[q] += w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]); ++q; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) lds_add(bl + 6*la + r, -w*(Ja[r]*e0 + Ja[6+r]*e1));
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
+        }
+        if (lpt >= 0) {
+          double* Wb = W + 18*(size_t)P.slot_inc[s0 + ia];
+          if (P.slot_first[s0 + ia]) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) Wb[3*r + c] = w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) Wb[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+          }
+        }
+        int ib = ia + 1;
+        for (int bit_b = bit_a + 1; bit_b < 8 && ib < ns; ++bit_b) {
+          if (!(mask & (1 << bit_b))) continue;
+          SlotGeom sb; double Jb[12];
+          make_slot(bit_b >> 2, bit_b & 3, A, xw, first, second, oc, sc, To.R, sb);
+          slot_jacobian(sb, Jb);
+          tile_add_cross(Sl, la, P.slot_lp[s0 + ib], Ja, Jb, w);
+          ++ib;
+        }
+        ++ia;
+      }
+    }
+    if (lpt >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) V[6*(size_t)lpt + k] = Vp[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[3*(size_t)lpt + k] = gp[k];
+    }
+  }
+  // segmented wave reduction of the source-pose accumulators, one LDS update per distinct pose
+  unsigned long long todo = __ballot(ls >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int key = __shfl(ls, leader, 64);
+    const bool mine = (ls == key);
+    double vals[27];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) vals[i] = mine ? Uss[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vals[21 + i] = mine ? bs[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+      double v = vals[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      vals[i] = v;
+    }
+    if (lane == leader) {
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) { Sl[tri(6*key + r, 6*key + c)] += vals[q]; ++q; }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) bl[6*key + r] += vals[21 + r];
+    }
+    todo &= ~__ballot(mine);
+    __syncthreads();
+  }
+  __syncthreads();
+  // flush the local tile: one global atomic per touched entry
+  const int* gp_ = P.g_pose + grp*GRP_LMAX;
+  const int np = P.np;
+  for (int i = lane; i < GRP_DOF; i += 64) {
+    const int u = gp_[i/6];
+    const double v = bl[i];
+    if (u >= 0 && v != 0.0) unsafeAtomicAdd(bp + 6*(size_t)u + i%6, v);
+  }
+  for (int r = 0; r < GRP_DOF; ++r) {
+    const int ur = gp_[r/6];
+    if (ur < 0) break;
+    for (int c = lane; c <= r; c += 64) {
+      const double v = Sl[tri(r, c)];
+      if (v != 0.0) unsafeAtomicAdd(U + (size_t)(6*ur + r%6)*np + 6*gp_[c/6] + c%6, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int SCH_CHUNK = 16;                 // points per MFMA chunk
+constexpr int SCH_K = 3*SCH_CHUNK;            // 48
+constexpr int SCH_LD = SCH_K + 1;             // LDS row stride (doubles)
+typedef double sch_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
+              const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
+              double* __restrict__ rhs, int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Yd = lds;                            // [GRP_DOF][SCH_LD]
+  double* Wd = lds + GRP_DOF*SCH_LD;           // [GRP_DOF][SCH_LD]
+  double* Vi = Wd + GRP_DOF*SCH_LD;            // [SCH_CHUNK][6]
+  double* gl = Vi + SCH_CHUNK*6;               // [SCH_K]
+  const int grp = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int sp0 = P.g_sp0[grp], sp1 = P.g_sp0[grp + 1];
+  const int* gp_ = P.g_pose + grp*GRP_LMAX;
+  int npl = 0;
+  for (int i = 0; i < GRP_LMAX; ++i) if (gp_[i] >= 0) npl = i + 1;
+  const int ntile = (6*npl + 15)/16;           // 16-row tiles in use
+  // lower-triangular tile pairs handled by this wave: t = wave, wave+4, ...
+  sch_d4 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = (sch_d4){0.0, 0.0, 0.0, 0.0};
+  double racc = 0.0;                           // rhs entry t (t < GRP_DOF)
+  for (int base = sp0; base < sp1; base += SCH_CHUNK) {
+    for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
+    if (t < SCH_CHUNK) {
+      const int sp = base + t;
+      double I6[6] = {0, 0, 0, 0, 0, 0}; double g3[3] = {0, 0, 0};
+      if (sp < sp1 && !P.sp_big[sp]) {
+        const int lpt = P.pt_unk[P.sp_pt[sp]];
+        if (lpt >= 0) {
+          if (!inv_sym3(V + 6*(size_t)lpt, lambda, I6)) atomicOr(fail, 1);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Vinv[6*(size_t)lpt + k] = I6[k];
+          g3[0] = g[3*(size_t)lpt]; g3[1] = g[3*(size_t)lpt + 1]; g3[2] = g[3*(size_t)lpt + 2];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Vi[6*t + k] = I6[k];
+      gl[3*t] = g3[0]; gl[3*t + 1] = g3[1]; gl[3*t + 2] = g3[2];
+    }
+    __syncthreads();
+    {   // scatter W and Y = W V^-1 rows: 16 threads per point
+      const int pl = t >> 4, sub = t & 15;
+      const int sp = base + pl;
+      if (sp < sp1 && !P.sp_big[sp]) {
+        const int i0 = P.sp_i[sp], i1 = P.sp_i[sp + 1];
+        const double* I6 = Vi + 6*pl;
+        for (int it = sub; it < (i1 - i0)*6; it += 16) {
+          const int inc = i0 + it/6, r = it%6;
+          const double* Wr = W + 18*(size_t)inc + 3*r;
+          const double w0 = Wr[0], w1 = Wr[1], w2 = Wr[2];
+          const int row = 6*P.inc_lp[inc] + r;
+          double* wd = Wd + row*SCH_LD + 3*pl;
+          double* yd = Yd + row*SCH_LD + 3*pl;
+          wd[0] = w0; wd[1] = w1; wd[2] = w2;
+          yd[0] = w0*I6[0] + w1*I6[1] + w2*I6[2];
+          yd[1] = w0*I6[1] + w1*I6[3] + w2*I6[4];
+          yd[2] = w0*I6[2] + w1*I6[4] + w2*I6[5];
+        }
+      }
+    }
+    __syncthreads();
+    // S_loc += Y W^T on the matrix cores; wave w owns the lower-triangular tile pairs w, w+4, ...
+    {
+      const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        const int p = wave + 4*s;
+        int tr = 0;
+        while ((tr + 1)*(tr + 2)/2 <= p) ++tr;
+        const int tc = p - tr*(tr + 1)/2;
+        if (p < 21 && tr < ntile) {
+          const double* Ya = Yd + (16*tr + i)*SCH_LD + kq;
+          const double* Wb = Wd + (16*tc + i)*SCH_LD + kq;
+          sch_d4 a = acc[s];
+#pragma unroll
+          for (int kk = 0; kk < SCH_K; kk += 4) a = __builtin_amdgcn_mfma_f64_16x16x4f64(Ya[kk], Wb[kk], a, 0, 0, 0);
+          acc[s] = a;
+        }
+      }
+    }
+    if (t < GRP_DOF) {
+      const double* yr = Yd + t*SCH_LD;
+      double s = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < SCH_K; ++k) s += yr[k]*gl[k];
+      racc += s;
+    }
+    __syncthreads();
+  }
+  // flush: S -= S_loc (lower triangle in global order), rhs -= r_loc
+  const int np = P.np;
+  if (t < GRP_DOF) {
+    const int u = gp_[t/6];
+    if (u >= 0 && racc != 0.0) unsafeAtomicAdd(rhs + 6*(size_t)u + t%6, -racc);
+  }
+  {
+    const int col_l = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const int p = wave + 4*s;
+      int tr = 0;
+      while ((tr + 1)*(tr + 2)/2 <= p) ++tr;
+      const int tc = p - tr*(tr + 1)/2;
+      if (p < 21 && tr < ntile) {
+        const sch_d4 a = acc[s];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int r = 16*tr + rq + 4*gq, c = 16*tc + col_l;
+          const double v = a[gq];
+          if (c <= r && r < 6*npl && v != 0.0) {
+            const int ur = gp_[r/6], uc = gp_[c/6];
+            unsafeAtomicAdd(S + (size_t)(6*ur + r%6)*np + 6*uc + c%6, -v);
+          }
+        }
+      }
+    }
+  }
+}
+constexpr size_t SCH_LDS_BYTES = (size_t)(2*GRP_DOF*SCH_LD + SCH_CHUNK*6 + SCH_K)*sizeof(double);
+
+}  // namespace mcp

@@ -40,11 +40,28 @@ struct DevProblem {
   const int* slot_inc;        // [nslot] incidence index (W block) or -1 (fixed point)
   // incidences (point-pose blocks), CSR by free point
   int nfl, ninc, np;
-  const int* inc_start;       // [nfl+1]
+  const int* l_i0;            // [nfl] incidence range of free point l
+  const int* l_i1;
   const int* inc_unk;         // [ninc]
   const int* fl_point;        // [nfl] free point -> point index
   int robust;
+  // points in group order ("sp" = sorted point slot); measurements and incidences are contiguous per sp
+  int nsp, ngroup;
+  const int* sp_pt;           // [nsp] point index
+  const int* sp_m;            // [nsp+1] measurement range
+  const int* sp_i;            // [nsp+1] incidence range
+  const unsigned char* sp_big;// [nsp] 1: more than GRP_LMAX poses -> generic (global atomics) path
+  const int* m_sp;            // [nmeas] sp of the measurement
+  const int* l_sp;            // [nfl] sp of free point l
+  const int* g_sp0;           // [ngroup+1] sp range of the group
+  const int* g_pose;          // [ngroup*GRP_LMAX] pose unknowns of the group (ascending), -1 padded
+  const unsigned char* slot_lp;   // [nslot] local pose index of the slot inside its group
+  const unsigned char* slot_first;// [nslot] 1: first contribution to its incidence (store), 0: accumulate
+  const unsigned char* inc_lp;    // [ninc] local pose index of the incidence
 };
+constexpr int GRP_LMAX = 16;      // poses per group (6*16 = 96 local dof)
+constexpr int GRP_PTS = 64;       // points per group (one lane each in k_linearize_group)
+constexpr int GRP_DOF = 6*GRP_LMAX;
 
 // chain transforms: first[c*4+i] = link i from world (12 doubles), second[c*4+i] = rotation of last from link i
 __global__ void k_chains(DevProblem P, const double* __restrict__ pose_T, double* __restrict__ first,
@@ -233,12 +250,13 @@ __device__ inline void make_slot(int side, int link, const double* A /*2x3*/, co
 constexpr int LIN_BLOCK = 128;
 
 __global__ void __launch_bounds__(LIN_BLOCK)
-k_linearize(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const double* __restrict__ first,
             const double* __restrict__ second, const double* __restrict__ sigma,
             double* __restrict__ U, double* __restrict__ bp, double* __restrict__ V,
             double* __restrict__ g, double* __restrict__ W) {
   const int m = blockIdx.x*LIN_BLOCK + threadIdx.x;
   if (m >= P.nmeas) return;
+  if (only_big && !P.sp_big[P.m_sp[m]]) return;
   const int pt = P.m_pt[m];
   const int oc = P.m_chain[m], sc = P.pt_chain[pt];
   const int olen = P.chain_len[oc], slen = P.chain_len[sc];
@@ -399,12 +417,13 @@ __device__ inline bool inv_sym3(const double* V6, double lambda, double* I6) {
 
 // point elimination: S -= W Vinv W^T, rhs -= W Vinv g.  One wave per free point.
 __global__ void __launch_bounds__(256)
-k_schur(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
+k_schur(DevProblem P, int only_big, double lambda, const double* __restrict__ V, const double* __restrict__ g,
         const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
         double* __restrict__ rhs, int* __restrict__ fail) {
   const int l = blockIdx.x*4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (l >= P.nfl) return;
+  if (only_big && !P.sp_big[P.l_sp[l]]) return;
   double I6[6];
   const bool ok = inv_sym3(V + 6*(size_t)l, lambda, I6);
   if (lane == 0) {
@@ -412,7 +431,7 @@ k_schur(DevProblem P, double lambda, const double* __restrict__ V, const double*
 #pragma unroll
     for (int k = 0; k < 6; ++k) Vinv[6*(size_t)l + k] = I6[k];
   }
-  const int i0 = P.inc_start[l], q = P.inc_start[l+1] - i0;
+  const int i0 = P.l_i0[l], q = P.l_i1[l] - i0;
   const double Vi[9] = { I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5] };
   const double g0 = g[3*(size_t)l], g1 = g[3*(size_t)l+1], g2 = g[3*(size_t)l+2];
   const int np = P.np;
@@ -478,7 +497,7 @@ k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const doub
   if (l < P.nfl) {
     const double b0 = g[3*(size_t)l], b1 = g[3*(size_t)l+1], b2 = g[3*(size_t)l+2];
     double t0 = b0, t1 = b1, t2 = b2;
-    const int i0 = P.inc_start[l], i1 = P.inc_start[l+1];
+    const int i0 = P.l_i0[l], i1 = P.l_i1[l];
     for (int i = i0; i < i1; ++i) {
       const double* Wa = W + 18*(size_t)i; const double* xa = xp + 6*(size_t)P.inc_unk[i];
 #pragma unroll
@@ -518,7 +537,7 @@ __global__ void k_point_cov22(DevProblem P, const double* __restrict__ Vinv, con
   const double v2[3] = { I6[2], I6[4], I6[5] };
   double u[12];
   for (int i = 0; i < 12; ++i) u[i] = 0.0;
-  for (int i = P.inc_start[l]; i < P.inc_start[l+1]; ++i) {
+  for (int i = P.l_i0[l]; i < P.l_i1[l]; ++i) {
     const double* Wa = W + 18*(size_t)i; const int ua = P.inc_unk[i];
     for (int r = 0; r < 6; ++r) u[6*ua + r] += Wa[3*r]*v2[0] + Wa[3*r+1]*v2[1] + Wa[3*r+2]*v2[2];
   }

@@ -21,6 +21,7 @@
 #include "ba_kernels.h"
 #include "ba_select.h"
 #include "ba_chol.h"
+#include "ba_group.h"
 
 using namespace mcp;
 
@@ -106,7 +107,10 @@ struct mcp_ba {
   DevBuf<unsigned char> d_pt_fixed, d_m_cam, d_flags;
   DevBuf<unsigned short> d_m_mask;
   DevBuf<double> d_m_u, d_m_v, d_m_omega;
-  DevBuf<int> d_slot_start, d_slot_unk, d_slot_inc, d_inc_start, d_inc_unk, d_fl_point;
+  DevBuf<int> d_slot_start, d_slot_unk, d_slot_inc, d_l_i0, d_l_i1, d_inc_unk, d_fl_point;
+  DevBuf<int> d_sp_pt, d_sp_m, d_sp_i, d_m_sp, d_l_sp, d_g_sp0, d_g_pose;
+  DevBuf<unsigned char> d_sp_big, d_slot_lp, d_slot_first, d_inc_lp;
+  int nsp = 0, ngroup = 0, nbig = 0;
   // state (double buffered: cur / trial)
   DevBuf<double> d_pose[2], d_pt[2], d_first[2], d_second[2], d_last[2], d_chi2[2];
   int cur = 0;
@@ -243,14 +247,27 @@ int mcp_ba::prepare() {
   for (int i = 0; i < npose; ++i) if (poses[i].active && !poses[i].fixed) { poses[i].unk = (int)fp_pose.size(); fp_pose.push_back(i); }
   for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
   nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
+  if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
   if (!(hook && world > 1)) nfl_total = nfl;
-  // sort measurements by point (stable counting sort keeps add order within a point)
+  // ---- measurements by point (add order kept inside a point)
   std::vector<int> cnt(npoint + 1, 0);
   for (const auto& m : meas) cnt[m.point + 1]++;
   for (int i = 0; i < npoint; ++i) cnt[i + 1] += cnt[i];
-  perm.assign(nmeas, 0);
+  std::vector<int> by_point(nmeas);
   { std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-    for (int i = 0; i < nmeas; ++i) perm[pos[meas[i].point]++] = i; }
+    for (int i = 0; i < nmeas; ++i) by_point[pos[meas[i].point]++] = i; }
+  // ---- point order: by the first free pose of the chain the point is expressed in
+  std::vector<int> order;
+  order.reserve(npoint);
+  std::vector<int> pkey(npoint, INT32_MAX);
+  for (int i = 0; i < npoint; ++i) {
+    if (!points[i].active) continue;
+    const HChain& c = chains[points[i].chain];
+    for (int k = 0; k < c.len; ++k) if (poses[c.v[k]].unk >= 0) { pkey[i] = poses[c.v[k]].unk; break; }
+    order.push_back(i);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pkey[a] < pkey[b]; });
+  nsp = (int)order.size();
   // per (obs chain, src chain) activity mask
   std::map<std::pair<int, int>, unsigned short> mask_cache;
   auto pair_mask = [&](int oc, int sc) -> unsigned short {
@@ -263,21 +280,28 @@ int mcp_ba::prepare() {
     for (int i = 0; i < s.len; ++i) if (!poses[s.v[i]].fixed && !move_together(s, o, i)) mk |= (1 << (4 + i));
     mask_cache[key] = mk; return mk;
   };
-  std::vector<int> m_pt(nmeas), m_chain(nmeas), slot_start(nmeas + 1, 0), slot_unk, slot_inc;
-  std::vector<unsigned char> m_cam(nmeas);
+  std::vector<int> m_pt(nmeas), m_chain(nmeas), m_sp(nmeas), slot_start(nmeas + 1, 0), slot_unk, slot_inc;
+  std::vector<unsigned char> m_cam(nmeas), slot_first;
   std::vector<unsigned short> m_mask(nmeas);
   std::vector<double> m_u(nmeas), m_v(nmeas), m_om(nmeas);
-  std::vector<int> inc_start(nfl + 1, 0), inc_unk;
-  slot_unk.reserve((size_t)nmeas*2); slot_inc.reserve((size_t)nmeas*2); inc_unk.reserve((size_t)nfl*8);
-  int s = 0;
-  while (s < nmeas) {
-    const int pt = meas[perm[s]].point;
-    int e = s; while (e < nmeas && meas[perm[e]].point == pt) ++e;
+  std::vector<int> l_i0(nfl + 1, 0), l_i1(nfl + 1, 0), l_sp(nfl + 1, 0), inc_unk;
+  std::vector<int> sp_pt(nsp), sp_m(nsp + 1, 0), sp_i(nsp + 1, 0);
+  std::vector<unsigned char> sp_big(nsp, 0);
+  std::vector<std::vector<int>> sp_poses(nsp);       // distinct pose unknowns touched by the point
+  slot_unk.reserve((size_t)nmeas*2); slot_inc.reserve((size_t)nmeas*2); slot_first.reserve((size_t)nmeas*2); inc_unk.reserve((size_t)nfl*8);
+  perm.assign(nmeas, 0);
+  int j = 0;
+  for (int sp = 0; sp < nsp; ++sp) {
+    const int pt = order[sp];
     const int lpt = points[pt].unk;
     const int ibase = (int)inc_unk.size();
-    for (int j = s; j < e; ++j) {
-      const HMeas& m = meas[perm[j]];
-      m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega;
+    sp_pt[sp] = pt; sp_m[sp] = j; sp_i[sp] = ibase;
+    std::vector<int>& q = sp_poses[sp];
+    for (int k = cnt[pt]; k < cnt[pt + 1]; ++k, ++j) {
+      const int mi = by_point[k];
+      const HMeas& m = meas[mi];
+      perm[j] = mi;
+      m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega; m_sp[j] = sp;
       const unsigned short mk = pair_mask(m.chain, points[pt].chain);
       m_mask[j] = mk;
       slot_start[j] = (int)slot_unk.size();
@@ -286,21 +310,57 @@ int mcp_ba::prepare() {
         const HChain& c = (b < 4) ? chains[m.chain] : chains[points[pt].chain];
         const int u = poses[c.v[b & 3]].unk;
         slot_unk.push_back(u);
-        int inc = -1;
+        if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
+        int inc = -1; unsigned char first = 0;
         if (lpt >= 0) {
-          for (int q = ibase; q < (int)inc_unk.size(); ++q) if (inc_unk[q] == u) { inc = q; break; }
-          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); }
+          for (int t = ibase; t < (int)inc_unk.size(); ++t) if (inc_unk[t] == u) { inc = t; break; }
+          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); first = 1; }
         }
-        slot_inc.push_back(inc);
+        slot_inc.push_back(inc); slot_first.push_back(first);
       }
     }
-    if (lpt >= 0) { inc_start[lpt] = ibase; inc_start[lpt + 1] = (int)inc_unk.size(); }
-    s = e;
+    if (lpt >= 0) { l_i0[lpt] = ibase; l_i1[lpt] = (int)inc_unk.size(); l_sp[lpt] = sp; }
+    if ((int)q.size() > GRP_LMAX) sp_big[sp] = 1;
   }
+  sp_m[nsp] = j; sp_i[nsp] = (int)inc_unk.size();
   slot_start[nmeas] = (int)slot_unk.size();
-  // free points without any incidence keep an empty range; make inc_start monotone
-  for (int l = 0, last = 0; l <= nfl; ++l) { if (l > 0 && inc_start[l] < last) inc_start[l] = last; last = inc_start[l]; }
   ninc = (int)inc_unk.size(); nslot = (int)slot_unk.size();
+  // ---- groups: consecutive points, <= GRP_PTS points and <= GRP_LMAX distinct poses
+  std::vector<int> g_sp0, g_pose;
+  nbig = 0;
+  {
+    std::vector<int> curset;
+    int start = 0;
+    auto close = [&](int end) {
+      if (end <= start) return;
+      std::sort(curset.begin(), curset.end());
+      g_sp0.push_back(start);
+      for (int k = 0; k < GRP_LMAX; ++k) g_pose.push_back(k < (int)curset.size() ? curset[k] : -1);
+      curset.clear(); start = end;
+    };
+    for (int sp = 0; sp < nsp; ++sp) {
+      const std::vector<int>& q = sp_big[sp] ? std::vector<int>() : sp_poses[sp];   // big points ride along with no poses
+      if (sp_big[sp]) ++nbig;
+      std::vector<int> merged = curset;
+      for (int u : q) if (std::find(merged.begin(), merged.end(), u) == merged.end()) merged.push_back(u);
+      if ((int)merged.size() > GRP_LMAX || sp - start >= GRP_PTS) { close(sp); merged = q; }
+      curset = merged;
+    }
+    close(nsp);
+    g_sp0.push_back(nsp);
+  }
+  ngroup = (int)g_sp0.size() - 1;
+  // local pose indices of slots and incidences
+  std::vector<unsigned char> slot_lp(nslot + 1, 0), inc_lp(ninc + 1, 0);
+  for (int gi = 0; gi < ngroup; ++gi) {
+    const int* gp = &g_pose[(size_t)gi*GRP_LMAX];
+    auto local = [&](int u) -> unsigned char { for (int k = 0; k < GRP_LMAX; ++k) if (gp[k] == u) return (unsigned char)k; return 0; };
+    for (int sp = g_sp0[gi]; sp < g_sp0[gi + 1]; ++sp) {
+      if (sp_big[sp]) continue;
+      for (int s2 = slot_start[sp_m[sp]]; s2 < slot_start[sp_m[sp + 1]]; ++s2) slot_lp[s2] = local(slot_unk[s2]);
+      for (int i2 = sp_i[sp]; i2 < sp_i[sp + 1]; ++i2) inc_lp[i2] = local(inc_unk[i2]);
+    }
+  }
 
   // upload
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*4), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
@@ -313,8 +373,11 @@ int mcp_ba::prepare() {
       d_pt_fixed.upload(pt_fixed, st) || d_m_pt.upload(m_pt, st) || d_m_chain.upload(m_chain, st) ||
       d_m_cam.upload(m_cam, st) || d_m_mask.upload(m_mask, st) || d_m_u.upload(m_u, st) || d_m_v.upload(m_v, st) ||
       d_m_omega.upload(m_om, st) || d_slot_start.upload(slot_start, st) || d_slot_unk.upload(slot_unk, st) ||
-      d_slot_inc.upload(slot_inc, st) || d_inc_start.upload(inc_start, st) || d_inc_unk.upload(inc_unk, st) ||
-      d_fl_point.upload(fl_point, st)) return -1;
+      d_slot_inc.upload(slot_inc, st) || d_l_i0.upload(l_i0, st) || d_l_i1.upload(l_i1, st) || d_inc_unk.upload(inc_unk, st) ||
+      d_fl_point.upload(fl_point, st) || d_sp_pt.upload(sp_pt, st) || d_sp_m.upload(sp_m, st) || d_sp_i.upload(sp_i, st) ||
+      d_sp_big.upload(sp_big, st) || d_m_sp.upload(m_sp, st) || d_l_sp.upload(l_sp, st) || d_g_sp0.upload(g_sp0, st) ||
+      d_g_pose.upload(g_pose, st) || d_slot_lp.upload(slot_lp, st) || d_slot_first.upload(slot_first, st) ||
+      d_inc_lp.upload(inc_lp, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < 2; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
@@ -337,7 +400,11 @@ int mcp_ba::prepare() {
   P.pt_fixed = d_pt_fixed.p; P.nmeas = nmeas; P.m_pt = d_m_pt.p; P.m_chain = d_m_chain.p; P.m_cam = d_m_cam.p;
   P.m_mask = d_m_mask.p; P.m_u = d_m_u.p; P.m_v = d_m_v.p; P.m_omega = d_m_omega.p; P.slot_start = d_slot_start.p;
   P.slot_unk = d_slot_unk.p; P.slot_inc = d_slot_inc.p; P.nfl = nfl; P.ninc = ninc; P.np = np;
-  P.inc_start = d_inc_start.p; P.inc_unk = d_inc_unk.p; P.fl_point = d_fl_point.p; P.robust = robust;
+  P.l_i0 = d_l_i0.p; P.l_i1 = d_l_i1.p; P.inc_unk = d_inc_unk.p; P.fl_point = d_fl_point.p; P.robust = robust;
+  P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
+  P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
+  P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p;
+  HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
   if (upload_state()) return -1;
   HIPCK(hipStreamSynchronize(st));
   dirty = false;
@@ -412,13 +479,17 @@ int mcp_ba::linearize() {
   tic(ST_LIN);
   const size_t n2 = (size_t)np*np;
   HIPCK(hipMemsetAsync(d_lin.p, 0, (n2 + np)*sizeof(double), st));
-  if (nfl) {
-    HIPCK(hipMemsetAsync(d_V.p, 0, (size_t)nfl*6*sizeof(double), st));
-    HIPCK(hipMemsetAsync(d_g.p, 0, (size_t)nfl*3*sizeof(double), st));
+  if (nbig) {      // points that touch more than GRP_LMAX poses go through the generic atomic path
+    if (nfl) {
+      HIPCK(hipMemsetAsync(d_V.p, 0, (size_t)nfl*6*sizeof(double), st));
+      HIPCK(hipMemsetAsync(d_g.p, 0, (size_t)nfl*3*sizeof(double), st));
+    }
+    if (ninc) HIPCK(hipMemsetAsync(d_W.p, 0, (size_t)ninc*18*sizeof(double), st));
+    hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
   }
-  if (ninc) HIPCK(hipMemsetAsync(d_W.p, 0, (size_t)ninc*18*sizeof(double), st));
-  if (P.nmeas)
-    hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P,
+  if (ngroup)
+    hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), 0, st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
   toc();
   timing.n_linearize++;
@@ -439,13 +510,14 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
     hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, lam_here, U(), bp(), S(), rhs());
     if (world > 1) HIPCK(hipMemcpyAsync(rhs() + np, bp(), np*sizeof(double), hipMemcpyDeviceToDevice, st));
   }
-  if (nfl) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+  if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
   toc();
   if (np && allreduce(d_red.p, n2 + 2*(size_t)np)) return -1;
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
   if (np) {
     tic(ST_CHOL); chol_factor(st, S(), np, d_fail.p); toc();
-    tic(ST_SOLVE); chol_solve(st, S(), np, rhs()); toc();
+    tic(ST_SOLVE); chol_back(st, S(), np); toc();
   }
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 3);
@@ -657,7 +729,8 @@ int mcp_ba::final_stats(int nCounter) {
       const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
       hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, 0.0, U(), bp(), S(), rhs());
     }
-    if (nfl) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
     std::vector<double> Sh(n2 + 1), Sinv(n2 + 1, 0.0);
     if (np) HIPCK(hipMemcpyAsync(Sh.data(), S(), n2*8, hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -865,6 +938,23 @@ int mcp_ba_debug_solve(mcp_ba* h, double lambda, double* x_out) {
   if (!ok2) { set_err("mcp_ba_debug_solve: system not positive definite"); return -1; }
   if (h->np) HIPCK(hipMemcpy(x_out, h->rhs(), (size_t)h->np*8, hipMemcpyDeviceToHost));
   if (h->nfl) HIPCK(hipMemcpy(x_out + h->np, h->d_xl.p, (size_t)h->nfl*24, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Dense SPD solve A x = b on the device with the reduced-system kernels (test hook for ba_chol.h)
+int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
+  if (n <= 0 || n > CH_SOLVE_MAX) { set_err("mcp_dense_spd_solve: bad n"); return -1; }
+  DevBuf<double> d; DevBuf<int> f;
+  if (d.alloc((size_t)n*n + n) || f.alloc(4)) return -1;
+  HIPCK(hipMemcpy(d.p, A, (size_t)n*n*8, hipMemcpyHostToDevice));
+  HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
+  HIPCK(hipMemset(f.p, 0, 16));
+  chol_factor(nullptr, d.p, n, f.p);
+  chol_back(nullptr, d.p, n);
+  int fl = 0;
+  HIPCK(hipMemcpy(&fl, f.p, 4, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(x, d.p + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
+  if (fl) { set_err("mcp_dense_spd_solve: matrix not positive definite"); return -1; }
   return 0;
 }
 

@@ -189,7 +189,12 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
     need = n_points
     world, obs_list = [], []
     kk = min(k_near, n_mkf)
+    rounds = 0
     while need > 0:
+        rounds += 1
+        if rounds > 200:
+            raise ValueError("synth.make_problem: cannot find points with %d valid observations "
+                             "(n_mkf=%d, n_cams=%d): lower per_point" % (per_point, n_mkf, n_cams))
         n_try = int(need * 1.5) + 64
         anchor = rng.integers(0, n_mkf, n_try)
         u = rng.normal(size=(n_try, 3))

@@ -76,6 +76,21 @@ def test_c2_full_size_matches_oracle(gpu_required):
     assert gpu["outliers"] == ref["outliers"]
 
 
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 64, 65, 100, 1194])
+def test_dense_cholesky_solve_matches_numpy(gpu_required, n):
+    """ba_chol.h (MFMA tile updates, in-register panel factor, fused forward solve) against numpy."""
+    from mcptam_amd.chain_bundle import dense_spd_solve
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    x = dense_spd_solve(np.tril(A), b)          # only the lower triangle is read
+    ref = np.linalg.solve(A, b)
+    assert rel_err(x, ref) < 1e-11
+    with pytest.raises(RuntimeError):
+        dense_spd_solve(-A, b)                  # not positive definite -> loud failure
+
+
 def test_zero_noise_recovers_ground_truth(gpu_required):
     from mcptam_amd import synth
     p = synth.make_config("c2", n_mkf=16, n_points=2000, noise=False)
@@ -116,13 +131,13 @@ def test_fixed_points_and_single_chain(gpu_required):
 def test_all_poses_fixed_and_small_cov(gpu_required):
     """Fewer than 3 free poses: the depth-covariance median is produced (ChainBundle.cc:1419-1437)."""
     from mcptam_amd import synth
-    p = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=1)
+    p = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=1, per_point=3)
     gpu = run_bundle(_gpu(p.cams), p, 10)
     ref = run_bundle(_orc(p.cams), p, 10)
     compare_runs(gpu, ref)
     assert ref["max_cov"] > 0
     assert abs(gpu["max_cov"] - ref["max_cov"]) <= 1e-6 * ref["max_cov"]
-    q = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=3)      # points only
+    q = synth.make_config("tiny", n_mkf=3, n_points=80, n_fixed_mkf=3, per_point=3)      # points only
     gpu = run_bundle(_gpu(q.cams), q, 10)
     ref = run_bundle(_orc(q.cams), q, 10)
     compare_runs(gpu, ref)
@@ -147,7 +162,13 @@ def test_abort_flag_and_two_step(gpu_required):
         g2.abort.value = 0
         o2.abort.value = 0
         a, b = g2.Compute(), o2.Compute()
-        assert abs(a - b) <= 1
+        # the stopping test (0 <= dchi2/chi2 <= 1e-10, ChainBundle.cc:1101) sits at round-off level, so the
+        # two runs may stop a few iterations apart; both must land on the same state
+        # (or stall with rho == 0, which g2o turns into Terminate without a convergence flag)
+        assert a > 0 and b > 0
+        lg, lo = g2.IterLogs(), o2.IterLogs()
+        for x, y in zip(lg[:3], lo[:3]):
+            assert abs(x["chi2_start"] - y["chi2_start"]) <= 1e-9 * y["chi2_start"]
     Rg, tg = g2.GetPoses(ids["mkf"])
     Ro = np.array([o2.GetPose(int(i))[0] for i in ids["mkf"]])
     assert rel_err(Rg, Ro) < 1e-6
@@ -190,3 +211,19 @@ def test_metric_size_properties(gpu_required):
     logs = g.IterLogs()
     chis = [l["chi2_end"] for l in logs if l["accepted"]]
     assert chis[-1] < 1e-10 * logs[0]["chi2_start"]
+
+
+def test_point_seen_from_many_poses_uses_generic_path(gpu_required):
+    """A point observed from more than 16 free poses cannot live in a 16-pose group tile and is
+    routed through the generic (global atomic) kernels; results must not change."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=30, n_points=300, per_point=24, k_near=30, radius=2.0)
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    xg = g.DebugSolve(1e-2)
+    rc, xs, _ = o.DebugSolve(1e-2)
+    assert rc == 0 and rel_err(xg, xs) < 1e-7
+    gpu = run_bundle(_gpu(p.cams), p, 8)
+    ref = run_bundle(_orc(p.cams), p, 8)
+    compare_runs(gpu, ref)
