@@ -1,0 +1,128 @@
+/*
+ * mcp_img.h -- C ABI of the MI355X (gfx950) KeyFrame / Tracker image path.
+ *
+ * Second drop-in boundary of the MCPTAM back end (SURVEY.md 8(b) "Image/track seam"): the
+ * inner loops of KeyFrame::MakeKeyFrame_Lite / MakeKeyFrame_Rest
+ * (/root/reference/src/KeyFrame.cc:145-360, 363-450), ShiTomasi.cc, MiniPatch.cc, PatchFinder.cc
+ * and the per-point part of Tracker::SearchForPoints / CalcPoseUpdate
+ * (src/Tracker.cc:1299-1377, 1386-1512; include/mcptam/TrackerData.h:102-185).
+ * Control flow (which points to search, shuffles, budgets) stays in the reference's Tracker /
+ * MapMaker; they hand BATCHES to these entry points.
+ *
+ * A keyframe handle owns the 4-level pyramid, the FAST corner lists and the row look-up
+ * tables ON THE DEVICE: source keyframes of map points stay resident so that template warps
+ * (PatchFinder::MakeTemplateCoarseCont) gather from HBM, not over PCIe.
+ * Integer results (pyramids, corner lists and order, LUTs, thresholds, ZMSSD / SSD scores,
+ * coarse positions) are bit-exact against the CPU oracle; floating-point results follow the
+ * reference's float/double mix.  No CPU fallback: every entry point fails (-1 / NULL, see
+ * mcp_last_error()) when no gfx950 device is usable.
+ */
+#ifndef MCP_IMG_H
+#define MCP_IMG_H
+
+#include <stdint.h>
+#include "mcp_ba.h"      /* mcp_camera, mcp_last_error */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCP_LEVELS 4            /* LEVELS, include/mcptam/KeyFrame.h:85 */
+#define MCP_MIN_FAST_THRESH 5   /* KeyFrame.h:88 */
+#define MCP_MAX_FAST_THRESH 30  /* KeyFrame.h:89 */
+
+typedef struct mcp_kf mcp_kf;
+
+typedef struct mcp_int2 { int x, y; } mcp_int2;
+
+/* options of MakeKeyFrame_Lite that are statics / GVars in the reference */
+typedef struct mcp_kf_params {
+  int adaptive_thresh;        /* KeyFrame::sbAdaptiveThresh (default 1)                        */
+  int glare_masking;          /* GVar GlareMasking (default 0, src/System.cc:121)              */
+  int half_sample_pavgb;      /* 0: truncating 2x2 mean (libCVD generic halfSample);
+                                 1: cascaded round-half-up averages (libCVD SSE2 byte path)    */
+  int device;                 /* HIP device ordinal, -1 = current                              */
+} mcp_kf_params;
+
+/* KeyFrame + its Levels (include/mcptam/KeyFrame.h:93-150).  w,h = level-0 size. */
+mcp_kf* mcp_kf_create(int w, int h, const mcp_kf_params* params);
+void    mcp_kf_destroy(mcp_kf*);
+
+/* KeyFrame::MakeKeyFrame_Lite(CVD::Image<byte>& im, bool, bool bGlareMasking)  KeyFrame.cc:145-360
+ * img: level-0 image, row stride in bytes.  masks: NULL, or MCP_LEVELS pointers (each NULL or a
+ * tightly packed mask of that level's size; a corner is kept only where mask == 255, :305). */
+int mcp_kf_make_lite(mcp_kf*, const uint8_t* img, int stride, const uint8_t* const* masks);
+
+/* read-back of what MakeKeyFrame_Lite leaves in Level (image, vCorners, vCornerRowLUT, nFastThresh,
+ * vFastFrequency) */
+int mcp_kf_level_size(mcp_kf*, int level, int* w, int* h);
+int mcp_kf_get_image(mcp_kf*, int level, uint8_t* out /* w*h, packed */);
+int mcp_kf_num_corners(mcp_kf*, int level);
+int mcp_kf_get_corners(mcp_kf*, int level, mcp_int2* out, int cap);
+int mcp_kf_get_row_lut(mcp_kf*, int level, int* out /* h */);
+int mcp_kf_fast_thresh(mcp_kf*, int level);
+int mcp_kf_get_fast_frequency(mcp_kf*, int level, double* out /* MCP_MAX_FAST_THRESH+1 */);
+
+/* KeyFrame::MakeKeyFrame_Rest, candidate part                         KeyFrame.cc:363-450
+ * use_shi: ssCandidateType ("shi" = 1 / "fast" = 0); use_percent: ssCandidateCriterion;
+ * top_fraction = sdCandidateTopFraction (0.8); thresh = sdCandidateThresh (70).
+ * nonmax_score: score used by CVD::fast_nonmax -- 0: FAST-10 binary-search score,
+ * 1: the classic ring SAD corner_score (libCVD vintage dependent). */
+int mcp_kf_make_rest(mcp_kf*, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score);
+int mcp_kf_num_candidates(mcp_kf*, int level);
+int mcp_kf_get_candidates(mcp_kf*, int level, mcp_int2* pos, double* score, int cap);
+
+/* MiniPatch::SampleFromImage + FindPatch, batched                      MiniPatch.cc:34-122
+ * For each i: 9x9 patch of `src` level `level` at src_pos[i], searched among the FAST corners of
+ * `dst` level `level` inside +-range of dst_pos[i] (row LUT used).  out_pos / out_found per i. */
+int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int2* src_pos,
+                       const mcp_int2* dst_pos, int range, mcp_int2* out_pos, uint8_t* out_found, int* out_ssd);
+
+/* one tracked map point as seen by Tracker::SearchForPoints */
+typedef struct mcp_td_in {
+  double world_pos[3];          /* MapPoint::mv3WorldPos                                   */
+  double pixel_right_w[3];      /* MapPoint::mv3PixelRight_W                               */
+  double pixel_down_w[3];       /* MapPoint::mv3PixelDown_W                                */
+  const mcp_kf* source_kf;      /* MapPoint::mpPatchSourceKF (resident pyramid)            */
+  int source_level;             /* MapPoint::mnSourceLevel                                 */
+  int center_x, center_y;       /* MapPoint::mirCenter                                     */
+  int fixed;                    /* MapPoint::mbFixed (exhaustive search + 10 sub-pix its)  */
+} mcp_td_in;
+
+typedef struct mcp_td_out {
+  double image[2];              /* TrackerData::mv2Image (projection)                      */
+  double cam_derivs[4];         /* mm2CamDerivs, row-major                                 */
+  double jacobian[12];          /* mm26Jacobian 2x6 row-major (w.r.t. the BASE pose)       */
+  double found_pos[2];          /* mv2Found (sub-pixel or coarse, level-0 coordinates)     */
+  double sqrt_inv_noise;        /* mdSqrtInvNoise = 1 / LevelScale                         */
+  double warp_inverse[4];       /* PatchFinder::mm2WarpInverse                             */
+  int in_image;                 /* mbInImage                                               */
+  int search_level;             /* PatchFinder::mnSearchLevel, -1 = rejected warp          */
+  int template_bad;             /* PatchFinder::TemplateBad()                              */
+  int searched, found, did_subpix;
+  int coarse_x, coarse_y;       /* best corner at search level (irBest)                    */
+  int score;                    /* nBestSSD                                                */
+  uint8_t templ[64];            /* mimTemplate (8x8, row-major)                            */
+} mcp_td_out;
+
+/* TrackerData::Project + GetDerivsUnsafe + CalcJacobian, PatchFinder::CalcSearchLevelAndWarpMatrix,
+ * MakeTemplateCoarseCont (template cache neutralised: always refreshed), FindPatchCoarse,
+ * MakeSubPixTemplate + IterateSubPixToConvergence, for n points against keyframe `target`.
+ * base_from_world / cam_from_base: (R row-major 9, t 3).  range, subpix_its, exhaustive as
+ * Tracker::SearchForPoints(vTD, cam, nRange, nSubPixIts, bExhaustive). */
+int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double base_from_world[12],
+                     const double cam_from_base[12], int n, const mcp_td_in* in, int range,
+                     int subpix_its, int exhaustive, mcp_td_out* out);
+
+/* Tracker::CalcPoseUpdate (Tukey M-estimator, WLS<6> with prior 100)   Tracker.cc:1386-1512
+ * found[i] != 0 rows contribute.  override_sigma <= 0: Tukey sigma^2 from the median.
+ * mu[6] out; weights_out[n] (may be NULL) = Tukey weight per row (0 = outlier). */
+int mcp_track_pose_update(int n, const uint8_t* found, const double* found_pos /*n*2*/,
+                          const double* image_pos /*n*2*/, const double* sqrt_inv_noise /*n*/,
+                          const double* jacobian /*n*12*/, double override_sigma, double mu[6],
+                          double* weights_out, double* sigma_sq_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -54,7 +54,7 @@ __device__ inline void sel_find_bin(const double* __restrict__ hist, int nbins, 
 
 // pass kernel: derive state[pass] from state[pass-1] and hist[pass-1], then histogram digit `pass`
 // of the elements that match the prefix.  hist: SEL_PASSES x SEL_BINS doubles, zeroed beforehand.
-__global__ void __launch_bounds__(SEL_BLOCK)
+static __global__ void __launch_bounds__(SEL_BLOCK)
 k_select_pass(int pass, int n, const double* __restrict__ x, double* __restrict__ hist, SelState* __restrict__ state,
               unsigned long long k0) {
   __shared__ unsigned int lh[SEL_BINS];
@@ -84,7 +84,7 @@ k_select_pass(int pass, int n, const double* __restrict__ x, double* __restrict_
 }
 
 // final: resolve the last digit; out[0] = the k-th smallest |x|
-__global__ void __launch_bounds__(SEL_BLOCK)
+static __global__ void __launch_bounds__(SEL_BLOCK)
 k_select_final(const double* __restrict__ hist, const SelState* __restrict__ state, double* __restrict__ out) {
   __shared__ unsigned long long sc[SEL_BLOCK + 2];
   const SelState prev = state[SEL_PASSES - 1];
@@ -98,7 +98,7 @@ k_select_final(const double* __restrict__ hist, const SelState* __restrict__ sta
 
 // sigma block from the median (Huber::FindSigmaSquared + RobustKernelData::RecomputeNow limits,
 // MEstimator.h:194-204, ChainBundle.cc:822-830):  sig[0] raw sigma^2, [1] limited, [2] sqrt(limited), [3] median
-__global__ void k_sigma_from_median(const double* __restrict__ med, double n_total, double min_sigma_sq,
+static __global__ void k_sigma_from_median(const double* __restrict__ med, double n_total, double min_sigma_sq,
                                     double* __restrict__ sig) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double m = med[0];

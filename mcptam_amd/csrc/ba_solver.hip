@@ -28,6 +28,7 @@ using namespace mcp;
 static thread_local std::string g_err;
 static void set_err(const std::string& s) { g_err = s; }
 extern "C" const char* mcp_last_error(void) { return g_err.c_str(); }
+void mcp_set_error(const char* s) { g_err = s; }      // shared with img_api.hip
 
 #define HIPCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
   set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return -1; } } while (0)

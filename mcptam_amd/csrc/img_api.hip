@@ -1,0 +1,274 @@
+// img_api.hip -- C ABI of the KeyFrame / Tracker image path (include/mcp_img.h); host side only
+// marshals buffers and launches the kernels of img_kernels.h.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcp_img.h"
+#include "img_kernels.h"
+#include "ba_select.h"
+
+using namespace mcp;
+
+extern void mcp_set_error(const char* s);     // ba_solver.hip
+static int img_fail(const std::string& s) { mcp_set_error(s.c_str()); return -1; }
+#define ICK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return img_fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+template <class T> struct Buf {
+  T* p = nullptr; size_t n = 0;
+  ~Buf() { if (p) (void)hipFree(p); }
+  int alloc(size_t c) { if (c == 0) c = 1; if (c <= n) return 0; if (p) (void)hipFree(p); p = nullptr; n = 0;
+    if (hipMalloc((void**)&p, c*sizeof(T)) != hipSuccess) { mcp_set_error("hipMalloc failed"); return -1; } n = c; return 0; }
+};
+struct Level {
+  int w = 0, h = 0, cap = 0;
+  Buf<uint8_t> img, mask, tmp_a, tmp_b;
+  Buf<mcp_int2> all_xy, corners, cand_pos;
+  Buf<int> all_score, lut, blk_cnt, score_img;
+  Buf<double> cand_score;
+  Buf<LevelInfo> info;
+  bool has_mask = false;
+  std::vector<mcp_int2> h_cand; std::vector<double> h_cand_score;
+};
+}  // namespace
+
+struct mcp_kf {
+  int device = 0; hipStream_t st = nullptr;
+  mcp_kf_params prm;
+  Level lev[MCP_LEVELS];
+  ~mcp_kf() { if (st) (void)hipStreamDestroy(st); }
+  DevKfView view() const {
+    DevKfView v;
+    for (int l = 0; l < MCP_LEVELS; ++l) { v.img[l] = lev[l].img.p; v.w[l] = lev[l].w; v.h[l] = lev[l].h; v.corners[l] = lev[l].corners.p; v.lut[l] = lev[l].lut.p; v.info[l] = lev[l].info.p; }
+    return v;
+  }
+};
+
+static bool gfx950(int dev) { hipDeviceProp_t p; return hipGetDeviceProperties(&p, dev) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0; }
+
+extern "C" {
+
+mcp_kf* mcp_kf_create(int w, int h, const mcp_kf_params* params) {
+  if (w < 64 || h < 64) { mcp_set_error("mcp_kf_create: image too small"); return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { mcp_set_error("mcp_kf_create: no HIP device available (the HIP path has no CPU fallback)"); return nullptr; }
+  mcp_kf_params p; p.adaptive_thresh = 1; p.glare_masking = 0; p.half_sample_pavgb = 0; p.device = -1;
+  if (params) p = *params;
+  int dev = p.device; if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= ndev || !gfx950(dev)) { mcp_set_error("mcp_kf_create: device is not a gfx950 (MI355X)"); return nullptr; }
+  if (hipSetDevice(dev) != hipSuccess) { mcp_set_error("hipSetDevice failed"); return nullptr; }
+  mcp_kf* k = new mcp_kf(); k->device = dev; k->prm = p;
+  if (hipStreamCreateWithFlags(&k->st, hipStreamNonBlocking) != hipSuccess) { mcp_set_error("hipStreamCreate failed"); delete k; return nullptr; }
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    Level& L = k->lev[l]; L.w = w >> l; L.h = h >> l; L.cap = std::max(1024, L.w*L.h/2);
+    const size_t npx = (size_t)L.w*L.h; const int nblk = (int)((npx + FAST_BLOCK - 1)/FAST_BLOCK) + (L.cap + FAST_BLOCK - 1)/FAST_BLOCK + 2;
+    if (L.img.alloc(npx) || L.mask.alloc(npx) || L.all_xy.alloc(L.cap) || L.all_score.alloc(L.cap) || L.corners.alloc(L.cap) ||
+        L.lut.alloc(L.h) || L.blk_cnt.alloc(nblk) || L.info.alloc(1) || L.cand_pos.alloc(L.cap) || L.cand_score.alloc(L.cap)) { delete k; return nullptr; }
+    (void)hipMemset(L.info.p, 0, sizeof(LevelInfo));
+  }
+  return k;
+}
+void mcp_kf_destroy(mcp_kf* k) { if (k) { (void)hipSetDevice(k->device); delete k; } }
+
+int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
+  ICK(hipSetDevice(k->device));
+  hipStream_t st = k->st;
+  static const int fixed_t[4] = { 10, 15, 15, 10 };
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    Level& L = k->lev[l];
+    const size_t npx = (size_t)L.w*L.h;
+    if (l == 0) ICK(hipMemcpy2DAsync(L.img.p, L.w, img, stride, L.w, L.h, hipMemcpyHostToDevice, st));
+    else {
+      const Level& Pv = k->lev[l - 1];
+      hipLaunchKernelGGL(k_half_sample, dim3((L.w + 31)/32, (L.h + 7)/8), dim3(32, 8), 0, st, (const uint8_t*)Pv.img.p, Pv.w, L.img.p, L.w, L.h, k->prm.half_sample_pavgb);
+    }
+    const uint8_t* internal = nullptr;
+    if (masks && masks[l]) { ICK(hipMemcpyAsync(L.mask.p, masks[l], npx, hipMemcpyHostToDevice, st)); internal = L.mask.p; }
+    const uint8_t* mask = internal;
+    if (k->prm.glare_masking) {
+      if (L.tmp_a.alloc(npx) || L.tmp_b.alloc(npx)) return -1;
+      const uint8_t* src = L.img.p; uint8_t* a = L.tmp_a.p; uint8_t* b = L.tmp_b.p;
+      for (int it = 0; it < 5; ++it) { hipLaunchKernelGGL(k_dilate5, dim3((L.w + 31)/32, (L.h + 7)/8), dim3(32, 8), 0, st, src, a, L.w, L.h); src = a; std::swap(a, b); }
+      hipLaunchKernelGGL(k_glare_mask, dim3((unsigned)((npx + 255)/256)), dim3(256), 0, st, src, internal, L.mask.p, (int)npx);
+      mask = L.mask.p;
+    }
+    L.has_mask = mask != nullptr;
+    ICK(hipMemsetAsync(L.info.p, 0, sizeof(LevelInfo), st));
+    const int nb = (int)((npx + FAST_BLOCK - 1)/FAST_BLOCK);
+    const int b = k->prm.adaptive_thresh ? MCP_MIN_FAST_THRESH : fixed_t[l];
+    hipLaunchKernelGGL(k_fast_count, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, L.blk_cnt.p);
+    if (k->prm.adaptive_thresh) {
+      hipLaunchKernelGGL(k_fast_write, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, (const int*)L.blk_cnt.p, L.cap, L.all_xy.p, L.all_score.p, L.info.p, 1);
+      const int nb2 = (L.cap + FAST_BLOCK - 1)/FAST_BLOCK;
+      int* cnt2 = L.blk_cnt.p + nb + 1;
+      hipLaunchKernelGGL(k_thresh_count, dim3(nb2), dim3(FAST_BLOCK), 0, st, (const mcp_int2*)L.all_xy.p, (const int*)L.all_score.p, mask, L.w, L.h, L.info.p, cnt2);
+      hipLaunchKernelGGL(k_thresh_write, dim3(nb2), dim3(FAST_BLOCK), 0, st, (const mcp_int2*)L.all_xy.p, (const int*)L.all_score.p, mask, L.w, L.info.p, (const int*)cnt2, L.corners.p);
+    } else {
+      hipLaunchKernelGGL(k_fast_write, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, (const int*)L.blk_cnt.p, L.cap, L.corners.p, L.all_score.p, L.info.p, 0);
+    }
+    hipLaunchKernelGGL(k_row_lut, dim3((L.h + 63)/64), dim3(64), 0, st, (const mcp_int2*)L.corners.p, (const LevelInfo*)L.info.p, L.h, L.lut.p);
+  }
+  ICK(hipStreamSynchronize(st));
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    LevelInfo inf; ICK(hipMemcpy(&inf, k->lev[l].info.p, sizeof inf, hipMemcpyDeviceToHost));
+    if (inf.overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
+  }
+  return 0;
+}
+
+static int get_info(mcp_kf* k, int level, LevelInfo* inf) {
+  if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level");
+  ICK(hipSetDevice(k->device));
+  ICK(hipMemcpy(inf, k->lev[level].info.p, sizeof *inf, hipMemcpyDeviceToHost));
+  return 0;
+}
+int mcp_kf_level_size(mcp_kf* k, int level, int* w, int* h) { if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level"); *w = k->lev[level].w; *h = k->lev[level].h; return 0; }
+int mcp_kf_get_image(mcp_kf* k, int level, uint8_t* out) {
+  if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level");
+  ICK(hipSetDevice(k->device));
+  ICK(hipMemcpy(out, k->lev[level].img.p, (size_t)k->lev[level].w*k->lev[level].h, hipMemcpyDeviceToHost)); return 0;
+}
+int mcp_kf_num_corners(mcp_kf* k, int level) { LevelInfo inf; if (get_info(k, level, &inf)) return -1; return inf.n_corners; }
+int mcp_kf_get_corners(mcp_kf* k, int level, mcp_int2* out, int cap) {
+  LevelInfo inf; if (get_info(k, level, &inf)) return -1;
+  const int n = std::min(inf.n_corners, cap);
+  if (n > 0) ICK(hipMemcpy(out, k->lev[level].corners.p, sizeof(mcp_int2)*(size_t)n, hipMemcpyDeviceToHost));
+  return n;
+}
+int mcp_kf_get_row_lut(mcp_kf* k, int level, int* out) {
+  if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level");
+  ICK(hipSetDevice(k->device));
+  ICK(hipMemcpy(out, k->lev[level].lut.p, sizeof(int)*(size_t)k->lev[level].h, hipMemcpyDeviceToHost)); return 0;
+}
+int mcp_kf_fast_thresh(mcp_kf* k, int level) { LevelInfo inf; if (get_info(k, level, &inf)) return -1; return inf.thresh; }
+int mcp_kf_get_fast_frequency(mcp_kf* k, int level, double* out) {
+  LevelInfo inf; if (get_info(k, level, &inf)) return -1;
+  for (int t = 0; t <= MCP_MAX_FAST_THRESH; ++t) out[t] = (double)inf.hist[t];
+  return 0;
+}
+
+int mcp_kf_make_rest(mcp_kf* k, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score) {
+  ICK(hipSetDevice(k->device));
+  hipStream_t st = k->st;
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    Level& L = k->lev[l];
+    const size_t npx = (size_t)L.w*L.h;
+    if (L.score_img.alloc(npx)) return -1;
+    ICK(hipMemsetAsync(L.score_img.p, 0, npx*sizeof(int), st));
+    const int nb = (L.cap + FAST_BLOCK - 1)/FAST_BLOCK;
+    hipLaunchKernelGGL(k_nonmax_scores, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, (const mcp_int2*)L.corners.p, (const LevelInfo*)L.info.p, nonmax_score, L.score_img.p);
+    hipLaunchKernelGGL((k_candidates<false>), dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, (const mcp_int2*)L.corners.p, L.info.p, (const int*)L.score_img.p, use_shi, L.blk_cnt.p, L.cand_pos.p, L.cand_score.p);
+    hipLaunchKernelGGL((k_candidates<true>), dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, (const mcp_int2*)L.corners.p, L.info.p, (const int*)L.score_img.p, use_shi, L.blk_cnt.p, L.cand_pos.p, L.cand_score.p);
+  }
+  ICK(hipStreamSynchronize(st));
+  // selection of the scored candidates (a few thousand pairs): sort / threshold on the host, KeyFrame.cc:422-452
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    Level& L = k->lev[l];
+    LevelInfo inf; ICK(hipMemcpy(&inf, L.info.p, sizeof inf, hipMemcpyDeviceToHost));
+    std::vector<mcp_int2> pos(inf.n_cand); std::vector<double> sc(inf.n_cand);
+    if (inf.n_cand) { ICK(hipMemcpy(pos.data(), L.cand_pos.p, sizeof(mcp_int2)*pos.size(), hipMemcpyDeviceToHost)); ICK(hipMemcpy(sc.data(), L.cand_score.p, sizeof(double)*sc.size(), hipMemcpyDeviceToHost)); }
+    std::vector<int> idx(inf.n_cand); for (int i = 0; i < inf.n_cand; ++i) idx[i] = i;
+    L.h_cand.clear(); L.h_cand_score.clear();
+    if (use_percent) {
+      std::sort(idx.begin(), idx.end(), [&](int a, int b) {           // descending (score, ImageRef) as std::sort(rbegin, rend)
+        if (sc[a] != sc[b]) return sc[a] > sc[b];
+        if (pos[a].y != pos[b].y) return pos[a].y > pos[b].y;
+        return pos[a].x > pos[b].x; });
+      const int num = (int)(inf.n_cand*top_fraction);
+      for (int i = 0; i < num && i < inf.n_cand; ++i) { L.h_cand.push_back(pos[idx[i]]); L.h_cand_score.push_back(sc[idx[i]]); }
+    } else {
+      for (int i = 0; i < inf.n_cand; ++i) if (sc[i] > thresh) { L.h_cand.push_back(pos[i]); L.h_cand_score.push_back(sc[i]); }
+    }
+  }
+  return 0;
+}
+int mcp_kf_num_candidates(mcp_kf* k, int level) { if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level"); return (int)k->lev[level].h_cand.size(); }
+int mcp_kf_get_candidates(mcp_kf* k, int level, mcp_int2* pos, double* score, int cap) {
+  if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level");
+  const Level& L = k->lev[level];
+  const int n = std::min((int)L.h_cand.size(), cap);
+  if (n) { std::memcpy(pos, L.h_cand.data(), sizeof(mcp_int2)*n); std::memcpy(score, L.h_cand_score.data(), sizeof(double)*n); }
+  return n;
+}
+
+int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int2* src_pos, const mcp_int2* dst_pos, int range,
+                       mcp_int2* out_pos, uint8_t* out_found, int* out_ssd) {
+  if (level < 0 || level >= MCP_LEVELS || n < 0) return img_fail("mcp_minipatch_find: bad arguments");
+  if (n == 0) return 0;
+  ICK(hipSetDevice(dst->device));
+  Buf<mcp_int2> dsp, ddp, dop; Buf<uint8_t> dfound; Buf<int> dssd;
+  if (dsp.alloc(n) || ddp.alloc(n) || dop.alloc(n) || dfound.alloc(n) || dssd.alloc(n)) return -1;
+  ICK(hipMemcpy(dsp.p, src_pos, sizeof(mcp_int2)*(size_t)n, hipMemcpyHostToDevice));
+  ICK(hipMemcpy(ddp.p, dst_pos, sizeof(mcp_int2)*(size_t)n, hipMemcpyHostToDevice));
+  const Level& S = src->lev[level]; const Level& D = dst->lev[level];
+  hipLaunchKernelGGL(k_minipatch, dim3(n), dim3(64), 0, dst->st, (const uint8_t*)S.img.p, S.w, S.h, (const uint8_t*)D.img.p, D.w, D.h,
+                     (const mcp_int2*)D.corners.p, (const LevelInfo*)D.info.p, (const int*)D.lut.p, n, (const mcp_int2*)dsp.p, (const mcp_int2*)ddp.p, range, dop.p, dfound.p, dssd.p);
+  ICK(hipStreamSynchronize(dst->st));
+  ICK(hipMemcpy(out_pos, dop.p, sizeof(mcp_int2)*(size_t)n, hipMemcpyDeviceToHost));
+  ICK(hipMemcpy(out_found, dfound.p, (size_t)n, hipMemcpyDeviceToHost));
+  if (out_ssd) ICK(hipMemcpy(out_ssd, dssd.p, sizeof(int)*(size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12], const double cfb[12], int n, const mcp_td_in* in,
+                     int range, int subpix_its, int exhaustive, mcp_td_out* out) {
+  if (n < 0 || !cam || cam->n_inv <= 0) return img_fail("mcp_track_search: bad arguments");
+  if (n == 0) return 0;
+  ICK(hipSetDevice(target->device));
+  std::vector<DevTdIn> h(n);
+  for (int i = 0; i < n; ++i) {
+    const mcp_td_in& p = in[i];
+    if (!p.source_kf || p.source_level < 0 || p.source_level >= MCP_LEVELS) return img_fail("mcp_track_search: point without a resident source keyframe");
+    std::memcpy(h[i].world_pos, p.world_pos, 24); std::memcpy(h[i].pixel_right_w, p.pixel_right_w, 24); std::memcpy(h[i].pixel_down_w, p.pixel_down_w, 24);
+    const Level& S = p.source_kf->lev[p.source_level];
+    h[i].src_img = S.img.p; h[i].src_w = S.w; h[i].src_h = S.h; h[i].center_x = p.center_x; h[i].center_y = p.center_y; h[i].fixed = p.fixed;
+  }
+  Buf<DevTdIn> din; Buf<mcp_td_out> dout;
+  if (din.alloc(n) || dout.alloc(n)) return -1;
+  ICK(hipMemcpy(din.p, h.data(), sizeof(DevTdIn)*(size_t)n, hipMemcpyHostToDevice));
+  Se3 B, C; std::memcpy(B.R, bfw, 72); std::memcpy(B.t, bfw + 9, 24); std::memcpy(C.R, cfb, 72); std::memcpy(C.t, cfb + 9, 24);
+  hipLaunchKernelGGL(k_track_search, dim3(n), dim3(64), 0, target->st, target->view(), *cam, B, C, n, (const DevTdIn*)din.p, range, subpix_its, exhaustive, dout.p);
+  ICK(hipStreamSynchronize(target->st));
+  ICK(hipMemcpy(out, dout.p, sizeof(mcp_td_out)*(size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mcp_track_pose_update(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sinv, const double* J,
+                          double override_sigma, double mu[6], double* wout, double* sigma_out) {
+  for (int k = 0; k < 6; ++k) mu[k] = 0;
+  if (sigma_out) *sigma_out = 0;
+  if (n <= 0) return 0;
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_update: no HIP device");
+  std::vector<int> slot(n, 0); int ne = 0;
+  for (int i = 0; i < n; ++i) { slot[i] = ne; if (found[i]) ++ne; }
+  if (wout) std::memset(wout, 0, sizeof(double)*(size_t)n);
+  if (ne == 0) return 0;
+  Buf<uint8_t> dfound; Buf<double> dfp, dip, dsi, dJ, dex, de2, dsig, dmu, dw, dhist; Buf<int> dslot; Buf<SelState> dst;
+  if (dfound.alloc(n) || dfp.alloc(2*(size_t)n) || dip.alloc(2*(size_t)n) || dsi.alloc(n) || dJ.alloc(12*(size_t)n) || dex.alloc(2*(size_t)n) ||
+      de2.alloc(ne) || dsig.alloc(4) || dmu.alloc(8) || dw.alloc(n) || dhist.alloc((size_t)SEL_PASSES*SEL_BINS) || dslot.alloc(n) || dst.alloc(SEL_PASSES + 1)) return -1;
+  ICK(hipMemcpy(dfound.p, found, (size_t)n, hipMemcpyHostToDevice));
+  ICK(hipMemcpy(dfp.p, fpos, 16*(size_t)n, hipMemcpyHostToDevice)); ICK(hipMemcpy(dip.p, ipos, 16*(size_t)n, hipMemcpyHostToDevice));
+  ICK(hipMemcpy(dsi.p, sinv, 8*(size_t)n, hipMemcpyHostToDevice)); ICK(hipMemcpy(dJ.p, J, 96*(size_t)n, hipMemcpyHostToDevice));
+  ICK(hipMemcpy(dslot.p, slot.data(), sizeof(int)*(size_t)n, hipMemcpyHostToDevice));
+  hipStream_t st = nullptr;
+  hipLaunchKernelGGL(k_pose_errors, dim3((n + 255)/256), dim3(256), 0, st, n, (const uint8_t*)dfound.p, (const double*)dfp.p, (const double*)dip.p, (const double*)dsi.p, dex.p, de2.p, (const int*)dslot.p);
+  if (!(override_sigma > 0)) {         // Tukey::FindSigmaSquared: exact median of the squared errors
+    ICK(hipMemsetAsync(dhist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
+    const int grid = std::max(1, std::min(256, (ne + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
+    for (int p = 0; p < SEL_PASSES; ++p) hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, ne, (const double*)de2.p, dhist.p, dst.p, (unsigned long long)(ne/2));
+    hipLaunchKernelGGL(k_select_final, dim3(1), dim3(SEL_BLOCK), 0, st, (const double*)dhist.p, (const SelState*)dst.p, dsig.p + 1);
+  }
+  hipLaunchKernelGGL(k_tukey_sigma, dim3(1), dim3(64), 0, st, (const double*)(dsig.p + 1), (double)ne, override_sigma, dsig.p);
+  hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(256), 0, st, n, (const uint8_t*)dfound.p, (const double*)dex.p, (const double*)dsi.p, (const double*)dJ.p, (const double*)dsig.p, dmu.p, dw.p);
+  ICK(hipDeviceSynchronize());
+  ICK(hipMemcpy(mu, dmu.p, 48, hipMemcpyDeviceToHost));
+  if (wout) ICK(hipMemcpy(wout, dw.p, 8*(size_t)n, hipMemcpyDeviceToHost));
+  if (sigma_out) ICK(hipMemcpy(sigma_out, dsig.p, 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,598 @@
+// img_kernels.h -- HIP kernels of the KeyFrame / Tracker image path (gfx950).
+//
+//   k_half_sample            CVD::halfSample                         src/KeyFrame.cc:189-190
+//   k_dilate5 / k_glare_mask cv::dilate x5 + threshold + AND         :214-238
+//   k_fast_count / k_fast_write   fast_corner_detect_10 + fast_corner_score_10, raster-ordered   :259-262
+//   k_thresh_count / k_thresh_write   histogram knee + score/mask filter                  :264-315
+//   k_row_lut                vCornerRowLUT                            :346-355
+//   k_nonmax_* / k_candidates     fast_nonmax + FAST / Shi-Tomasi scores, border 10       :393-420
+//   k_minipatch              MiniPatch::FindPatch                     src/MiniPatch.cc:34-113
+//   k_track_search           TrackerData::Project/CalcJacobian + PatchFinder (warp, template,
+//                            ZMSSD search, sub-pixel)                 src/PatchFinder.cc:69-472,511-664
+//   k_pose_*                 Tracker::CalcPoseUpdate                  src/Tracker.cc:1386-1512
+// This translation unit is compiled with -ffp-contract=off so that the float/double arithmetic
+// of the sub-pixel iterations rounds exactly as the scalar reference code does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ba_device.h"
+#include "../../include/mcp_img.h"
+
+namespace mcp {
+
+struct LevelInfo {            // device-resident bookkeeping of one pyramid level
+  int n_all;                  // corners detected at the minimum threshold (raster order)
+  int n_corners;              // corners kept (Level::vCorners)
+  int thresh;                 // Level::nFastThresh
+  int n_cand;                 // nonmax survivors inside the border (MakeKeyFrame_Rest)
+  int hist[32];               // Level::vFastFrequency (cumulative)
+  int overflow;
+};
+
+__global__ void k_half_sample(const uint8_t* __restrict__ in, int iw, uint8_t* __restrict__ out, int ow, int oh, int pavgb) {
+  const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y*blockDim.y + threadIdx.y;
+  if (x >= ow || y >= oh) return;
+  const uint8_t* p = in + (size_t)(2*y)*iw + 2*x;
+  const int a = p[0], b = p[1], c = p[iw], d = p[iw + 1];
+  int v;
+  if (pavgb) { const int v0 = (a + c + 1) >> 1, v1 = (b + d + 1) >> 1; v = (v0 + v1 + 1) >> 1; }
+  else v = (a + b + c + d)/4;
+  out[(size_t)y*ow + x] = (uint8_t)v;
+}
+
+__global__ void k_dilate5(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h) {
+  const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y*blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  int m = 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      if ((dy == -2 || dy == 2) && dx != 0) continue;      // 5x5 MORPH_ELLIPSE
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+      m = max(m, (int)in[(size_t)yy*w + xx]);
+    }
+  out[(size_t)y*w + x] = (uint8_t)m;
+}
+__global__ void k_glare_mask(const uint8_t* __restrict__ dil, const uint8_t* __restrict__ internal, uint8_t* __restrict__ out, int n) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t g = dil[i] > 245 ? 0 : 255;
+  out[i] = internal ? (internal[i] & g) : g;
+}
+
+// ---- FAST-10 -------------------------------------------------------------------------------
+__device__ inline void fast_ring(const uint8_t* __restrict__ p, int w, int* r) {
+  r[0] = p[3*w];       r[1] = p[3*w + 1];   r[2] = p[2*w + 2];   r[3] = p[w + 3];
+  r[4] = p[3];         r[5] = p[-w + 3];    r[6] = p[-2*w + 2];  r[7] = p[-3*w + 1];
+  r[8] = p[-3*w];      r[9] = p[-3*w - 1];  r[10] = p[-2*w - 2]; r[11] = p[-w - 3];
+  r[12] = p[-3];       r[13] = p[w - 3];    r[14] = p[2*w - 2];  r[15] = p[3*w - 1];
+}
+__device__ inline unsigned rot16(unsigned m, int k) { return ((m >> k) | (m << (16 - k))) & 0xffffu; }
+__device__ inline bool run10(unsigned m) {       // >= 10 contiguous set bits on the 16-ring
+  unsigned a = m & rot16(m, 1);        // 2
+  a &= rot16(a, 2);                    // 4
+  unsigned b = a & rot16(a, 4);        // 8
+  return (b & rot16(a, 6)) != 0;       // 8 + window shifted by 6 covers bits s..s+9
+}
+__device__ inline bool fast10_corner(const int* r, int c, int b) {
+  unsigned br = 0, dk = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { br |= (unsigned)(r[k] > c + b) << k; dk |= (unsigned)(r[k] < c - b) << k; }
+  return run10(br) || run10(dk);
+}
+// largest threshold that still passes the segment test == max over arcs of the arc minimum of the
+// signed differences, minus one (what the reference's binary search converges to)
+__device__ inline int fast10_score(const int* r, int c) {
+  int best = -1000;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = pass ? (c - r[k]) : (r[k] - c);
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) best = max(best, min(m8[k], m2[(k + 8) & 15]));
+  }
+  return min(best - 1, 254);
+}
+__device__ inline int ring_sad_score(const int* r, int c, int barrier) {
+  const int cb = c + barrier, c_b = c - barrier;
+  int sp = 0, sn = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { if (r[k] > cb) sp += r[k] - cb; else if (r[k] < c_b) sn += c_b - r[k]; }
+  return max(sp, sn);
+}
+
+constexpr int FAST_BLOCK = 256;
+// rank of this thread among the flagged threads of the block (raster order) and the block total
+__device__ inline int block_rank(bool flag, int* total, int* lds /* FAST_BLOCK/64 + 1 */) {
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) lds[wave] = __popcll(bal);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < FAST_BLOCK/64; ++i) { if (i < wave) base += lds[i]; tot += lds[i]; }
+  __syncthreads();
+  *total = tot;
+  return base + in_wave;
+}
+__device__ inline int block_prefix(const int* __restrict__ cnt, int b, int* lds) {   // sum of cnt[0..b)
+  int s = 0;
+  for (int i = threadIdx.x; i < b; i += FAST_BLOCK) s += cnt[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  int t = 0;
+  for (int i = 0; i < FAST_BLOCK/64; ++i) t += lds[i];
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(FAST_BLOCK)
+k_fast_count(const uint8_t* __restrict__ img, int w, int h, int b, int* __restrict__ blk_cnt) {
+  __shared__ int lds[FAST_BLOCK/64 + 1];
+  const int idx = blockIdx.x*FAST_BLOCK + threadIdx.x;
+  const int x = idx % w, y = idx / w;
+  bool corner = false;
+  if (y >= 3 && y < h - 3 && x >= 3 && x < w - 3) {
+    int r[16]; const uint8_t* p = img + (size_t)y*w + x;
+    fast_ring(p, w, r);
+    corner = fast10_corner(r, *p, b);
+  }
+  int tot; (void)block_rank(corner, &tot, lds);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(FAST_BLOCK)
+k_fast_write(const uint8_t* __restrict__ img, int w, int h, int b, const int* __restrict__ blk_cnt, int cap,
+             mcp_int2* __restrict__ xy, int* __restrict__ score, LevelInfo* __restrict__ info, int do_hist) {
+  __shared__ int lds[FAST_BLOCK/64 + 1];
+  __shared__ int lh[32];
+  if (threadIdx.x < 32) lh[threadIdx.x] = 0;
+  const int off = block_prefix(blk_cnt, blockIdx.x, lds);
+  const int idx = blockIdx.x*FAST_BLOCK + threadIdx.x;
+  const int x = idx % w, y = idx / w;
+  bool corner = false; int sc = 0;
+  if (y >= 3 && y < h - 3 && x >= 3 && x < w - 3) {
+    int r[16]; const uint8_t* p = img + (size_t)y*w + x;
+    fast_ring(p, w, r);
+    corner = fast10_corner(r, *p, b);
+    if (corner) sc = fast10_score(r, *p);
+  }
+  int tot; const int rank = block_rank(corner, &tot, lds);
+  if (corner) {
+    const int o = off + rank;
+    if (o < cap) { xy[o].x = x; xy[o].y = y; score[o] = sc; } else info->overflow = 1;
+    if (do_hist) { const int top = min(sc, MCP_MAX_FAST_THRESH); for (int t = MCP_MIN_FAST_THRESH; t <= top; ++t) atomicAdd(&lh[t], 1); }
+  }
+  __syncthreads();
+  if (do_hist && threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&info->hist[threadIdx.x], lh[threadIdx.x]);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { info->n_all = min(off + tot, cap); if (!do_hist) { info->n_corners = min(off + tot, cap); info->thresh = b; } }
+}
+// knee of the cumulative histogram (KeyFrame.cc:279-300)
+__device__ inline int knee_threshold(const int* hist, int w, int h) {
+  const double target = -1*(w*h)/500.0;
+  int th = MCP_MIN_FAST_THRESH;
+  for (int t = MCP_MIN_FAST_THRESH; t <= MCP_MAX_FAST_THRESH; ++t) {
+    double deriv;
+    if (t == MCP_MIN_FAST_THRESH) deriv = (double)hist[t + 1] - (double)hist[t];
+    else if (t == MCP_MAX_FAST_THRESH) deriv = (double)hist[t] - (double)hist[t - 1];
+    else deriv = ((double)hist[t + 1] - (double)hist[t - 1])/2.0;
+    th = t;
+    if (deriv > target) break;
+  }
+  return th;
+}
+__global__ void __launch_bounds__(FAST_BLOCK)
+k_thresh_count(const mcp_int2* __restrict__ xy, const int* __restrict__ score, const uint8_t* __restrict__ mask, int w, int h,
+               LevelInfo* __restrict__ info, int* __restrict__ blk_cnt) {
+  __shared__ int lds[FAST_BLOCK/64 + 1];
+  __shared__ int th_s;
+  if (threadIdx.x == 0) { th_s = knee_threshold(info->hist, w, h); if (blockIdx.x == 0) info->thresh = th_s; }
+  __syncthreads();
+  const int i = blockIdx.x*FAST_BLOCK + threadIdx.x;
+  bool keep = false;
+  if (i < info->n_all) keep = (score[i] >= th_s) && (!mask || mask[(size_t)xy[i].y*w + xy[i].x] == 255);
+  int tot; (void)block_rank(keep, &tot, lds);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(FAST_BLOCK)
+k_thresh_write(const mcp_int2* __restrict__ xy, const int* __restrict__ score, const uint8_t* __restrict__ mask, int w,
+               LevelInfo* __restrict__ info, const int* __restrict__ blk_cnt, mcp_int2* __restrict__ out) {
+  __shared__ int lds[FAST_BLOCK/64 + 1];
+  const int th = info->thresh;
+  const int off = block_prefix(blk_cnt, blockIdx.x, lds);
+  const int i = blockIdx.x*FAST_BLOCK + threadIdx.x;
+  bool keep = false;
+  if (i < info->n_all) keep = (score[i] >= th) && (!mask || mask[(size_t)xy[i].y*w + xy[i].x] == 255);
+  int tot; const int rank = block_rank(keep, &tot, lds);
+  if (keep) out[off + rank] = xy[i];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) info->n_corners = off + tot;
+}
+// LUT[y] = index of the first corner with row >= y
+__global__ void k_row_lut(const mcp_int2* __restrict__ corners, const LevelInfo* __restrict__ info, int h, int* __restrict__ lut) {
+  const int y = blockIdx.x*blockDim.x + threadIdx.x;
+  if (y >= h) return;
+  int lo = 0, hi = info->n_corners;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid].y < y) lo = mid + 1; else hi = mid; }
+  lut[y] = lo;
+}
+
+// ---- MakeKeyFrame_Rest -----------------------------------------------------------------------
+__global__ void k_nonmax_scores(const uint8_t* __restrict__ img, int w, const mcp_int2* __restrict__ corners,
+                                const LevelInfo* __restrict__ info, int mode, int* __restrict__ score_img) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= info->n_corners) return;
+  const int x = corners[i].x, y = corners[i].y;
+  int r[16]; const uint8_t* p = img + (size_t)y*w + x;
+  fast_ring(p, w, r);
+  const int s = mode ? ring_sad_score(r, *p, info->thresh) : fast10_score(r, *p);
+  score_img[(size_t)y*w + x] = s + 1;            // 0 = not a corner
+}
+__device__ inline double shi_tomasi7(const uint8_t* __restrict__ img, int w, int cx, int cy) {
+  double dXX = 0, dYY = 0, dXY = 0;
+  for (int y = cy - 3; y <= cy + 3; ++y)
+    for (int x = cx - 3; x <= cx + 3; ++x) {
+      const double dx = (double)((int)img[(size_t)y*w + x + 1] - (int)img[(size_t)y*w + x - 1]);
+      const double dy = (double)((int)img[(size_t)(y + 1)*w + x] - (int)img[(size_t)(y - 1)*w + x]);
+      dXX += dx*dx; dYY += dy*dy; dXY += dx*dy;
+    }
+  dXX = dXX/(2.0*49); dYY = dYY/(2.0*49); dXY = dXY/(2.0*49);
+  return 0.5*(dXX + dYY - sqrt((dXX + dYY)*(dXX + dYY) - 4*(dXX*dYY - dXY*dXY)));
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(FAST_BLOCK)
+k_candidates(const uint8_t* __restrict__ img, int w, int h, const mcp_int2* __restrict__ corners, LevelInfo* __restrict__ info,
+             const int* __restrict__ score_img, int use_shi, int* __restrict__ blk_cnt, mcp_int2* __restrict__ out_pos, double* __restrict__ out_score) {
+  __shared__ int lds[FAST_BLOCK/64 + 1];
+  int off = 0;
+  if (WRITE) off = block_prefix(blk_cnt, blockIdx.x, lds);
+  const int i = blockIdx.x*FAST_BLOCK + threadIdx.x;
+  bool keep = false; int x = 0, y = 0;
+  if (i < info->n_corners) {
+    x = corners[i].x; y = corners[i].y;
+    const int s = score_img[(size_t)y*w + x];
+    keep = true;
+    for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+      if (!dx && !dy) continue;
+      const int xx = x + dx, yy = y + dy;
+      if (xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
+      if (score_img[(size_t)yy*w + xx] > s) keep = false;
+    }
+    if (!(x >= 10 && y >= 10 && x < w - 10 && y < h - 10)) keep = false;
+  }
+  int tot; const int rank = block_rank(keep, &tot, lds);
+  if (!WRITE) { if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot; return; }
+  if (keep) {
+    double sc;
+    if (use_shi) sc = shi_tomasi7(img, w, x, y);
+    else { int r[16]; const uint8_t* p = img + (size_t)y*w + x; fast_ring(p, w, r); sc = (double)fast10_score(r, *p); }
+    out_pos[off + rank].x = x; out_pos[off + rank].y = y; out_score[off + rank] = sc;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) info->n_cand = off + tot;
+}
+
+// ---- MiniPatch ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_minipatch(const uint8_t* __restrict__ simg, int sw, int sh, const uint8_t* __restrict__ dimg, int dw, int dh,
+            const mcp_int2* __restrict__ corners, const LevelInfo* __restrict__ info, const int* __restrict__ lut, int n,
+            const mcp_int2* __restrict__ src_pos, const mcp_int2* __restrict__ dst_pos, int range,
+            mcp_int2* __restrict__ out_pos, uint8_t* __restrict__ out_found, int* __restrict__ out_ssd) {
+  __shared__ uint8_t patch[96];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  const int H = 4, MAXSSD = 9999;
+  const mcp_int2 sp = src_pos[i], dp = dst_pos[i];
+  const bool ok = sp.x >= H && sp.y >= H && sp.x < sw - H && sp.y < sh - H;
+  for (int k = lane; k < 81; k += 64) patch[k] = ok ? simg[(size_t)(sp.y - H + k/9)*sw + sp.x - H + k%9] : 0;
+  __syncthreads();
+  int best = MAXSSD + 1, best_c = 0x7fffffff;
+  if (ok) {
+    const int tlx = dp.x - range, brx = dp.x + range, bry = dp.y + range;
+    int top = dp.y - range; if (top < 0) top = 0; if (top >= dh) top = dh - 1;
+    const int c0 = lut[top], c1 = (bry + 1 < dh) ? ((bry + 1 < 0) ? 0 : lut[bry + 1]) : info->n_corners;
+    for (int c = c0 + lane; c < c1; c += 64) {
+      const mcp_int2 p = corners[c];
+      if (p.x < tlx || p.x > brx) continue;
+      int ssd;
+      if (!(p.x >= H && p.y >= H && p.x < dw - H && p.y < dh - H)) ssd = MAXSSD + 1;
+      else {
+        ssd = 0;
+        for (int r = 0; r < 9; ++r) { const uint8_t* q = dimg + (size_t)(p.y - H + r)*dw + p.x - H; for (int k = 0; k < 9; ++k) { const int df = (int)q[k] - (int)patch[9*r + k]; ssd += df*df; } }
+      }
+      if (ssd < best) { best = ssd; best_c = c; }          // ascending c within the lane: first best kept
+    }
+  }
+  // wave arg-min with "first best" semantics: smallest ssd, then smallest corner index
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o, 64), oc = __shfl_xor(best_c, o, 64);
+    if (ob < best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+  }
+  if (lane == 0) {
+    out_found[i] = 0; out_pos[i] = dp; if (out_ssd) out_ssd[i] = best;
+    if (best < MAXSSD) { out_pos[i] = corners[best_c]; out_found[i] = 1; }
+  }
+}
+
+// ---- Tracker per-point search ---------------------------------------------------------------------
+struct DevKfView {            // what a kernel needs of a keyframe
+  const uint8_t* img[MCP_LEVELS]; int w[MCP_LEVELS], h[MCP_LEVELS];
+  const mcp_int2* corners[MCP_LEVELS]; const int* lut[MCP_LEVELS]; const LevelInfo* info[MCP_LEVELS];
+};
+struct DevTdIn {
+  double world_pos[3], pixel_right_w[3], pixel_down_w[3];
+  const uint8_t* src_img; int src_w, src_h;
+  int center_x, center_y, fixed;
+};
+
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTdIn* __restrict__ in, int range,
+               int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
+  __shared__ uint8_t tmpl[64];
+  __shared__ double dprod[3][36];
+  const int pi = blockIdx.x, lane = threadIdx.x;
+  if (pi >= n) return;
+  const DevTdIn& P = in[pi];
+  mcp_td_out& O = out[pi];
+  const int MAXSSD = 8*8*250;
+  // all lanes compute the (uniform) geometry redundantly
+  Se3 cfw; se3_compose(cfb, bfw, cfw);
+  double xc[3]; se3_apply(cfw, P.world_pos, xc);
+  Projection pr; cam_project<true>(cam, xc, pr);
+  bool in_image = !pr.invalid;
+  if (in_image && (pr.u < 0 || pr.v < 0 || pr.u > cam.image_size[0] || pr.v > cam.image_size[1])) in_image = false;
+  int level = -1, template_bad = 0, searched = 0, found = 0, did_subpix = 0, bx = 0, by = 0, best = MAXSSD + 1;
+  double WI[4] = {0, 0, 0, 0}, J[12], fpos[2] = {0, 0}, sinv = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) J[k] = 0;
+  if (in_image) {
+    double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
+    double xb[3]; se3_apply(bfw, P.world_pos, xb);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb.R, mb, mc);
+      const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+      J[m] = pr.D[0]*s0 + pr.D[1]*s1; J[6 + m] = pr.D[2]*s0 + pr.D[3]*s1;
+    }
+    double mr[3], md[3]; mat3_vec(cfw.R, P.pixel_right_w, mr); mat3_vec(cfw.R, P.pixel_down_w, md);
+    const double sr0 = dT[0]*mr[0] + dT[1]*mr[1] + dT[2]*mr[2], sr1 = dP[0]*mr[0] + dP[1]*mr[1] + dP[2]*mr[2];
+    const double sd0 = dT[0]*md[0] + dT[1]*md[1] + dT[2]*md[2], sd1 = dP[0]*md[0] + dP[1]*md[1] + dP[2]*md[2];
+    WI[0] = pr.D[0]*sr0 + pr.D[1]*sr1; WI[2] = pr.D[2]*sr0 + pr.D[3]*sr1;
+    WI[1] = pr.D[0]*sd0 + pr.D[1]*sd1; WI[3] = pr.D[2]*sd0 + pr.D[3]*sd1;
+    double dDet = WI[0]*WI[3] - WI[1]*WI[2];
+    int lv = 0;
+    while (dDet > 3 && lv < MCP_LEVELS - 1) { lv++; dDet *= 0.25; }
+    if (dDet > 3 || dDet < 0.5 || !isfinite(dDet)) template_bad = 1; else level = lv;
+  }
+  if (level >= 0) {
+    const int scale = 1 << level;
+    double m2[4];
+    { const double det = WI[0]*WI[3] - WI[1]*WI[2], id = 1.0/det;
+      m2[0] = WI[3]*id*scale; m2[3] = WI[0]*id*scale; m2[2] = -WI[2]*id*scale; m2[1] = -WI[1]*id*scale; }
+    // CVD::transform: incremental source position, replayed up to this lane's pixel so that it rounds identically
+    const int iw = P.src_w, ih = P.src_h;
+    const double across[2] = { m2[0], m2[2] }, down[2] = { m2[1], m2[3] };
+    double p0[2] = { (double)P.center_x - (m2[0]*4.0 + m2[1]*4.0), (double)P.center_y - (m2[2]*4.0 + m2[3]*4.0) };
+    double min_x = p0[0], min_y = p0[1], max_x = min_x, max_y = min_y;
+    if (across[0] < 0) min_x += 8*across[0]; else max_x += 8*across[0];
+    if (down[0] < 0) min_x += 8*down[0]; else max_x += 8*down[0];
+    if (across[1] < 0) min_y += 8*across[1]; else max_y += 8*across[1];
+    if (down[1] < 0) min_y += 8*down[1]; else max_y += 8*down[1];
+    const double cr[2] = { down[0] - 8*across[0], down[1] - 8*across[1] };
+    const bool inside = (min_x >= 0 && min_y >= 0 && max_x < iw - 1 && max_y < ih - 1);
+    double p[2] = { p0[0], p0[1] };
+    for (int q = 0; q < lane; ++q) { p[0] += across[0]; p[1] += across[1]; if ((q & 7) == 7) { p[0] += cr[0]; p[1] += cr[1]; } }
+    bool outside = false; int tv = 0;
+    if (inside || (0 <= p[0] && 0 <= p[1] && p[0] < (double)(iw - 1) && p[1] < (double)(ih - 1))) {
+      const int lx = (int)p[0], ly = (int)p[1];
+      const double x = p[0] - lx, y = p[1] - ly;
+      const uint8_t* q = P.src_img + (size_t)ly*iw + lx;
+      const double v = (1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]);
+      tv = (int)(uint8_t)v;
+    } else outside = true;
+    tmpl[lane] = (uint8_t)tv;
+    O.templ[lane] = (uint8_t)tv;
+    __syncthreads();
+    if (__ballot(outside) != 0ull) template_bad = 1;
+    else {
+      const int tsum = wave_sum_i(tv), tsumsq = wave_sum_i(tv*tv);
+      const bool bex = P.fixed || exhaustive;
+      const int its = bex ? 10 : subpix_its;
+      const int lw = T.w[level], lh = T.h[level];
+      const uint8_t* limg = T.img[level];
+      int px = (int)pr.u, py = (int)pr.v;
+      px = px/scale; py = py/scale;
+      const unsigned nr = ((unsigned)range + scale - 1)/scale;
+      int top = py - (int)nr, bot1 = py + (int)nr + 1, left = px - (int)nr, right = px + (int)nr;
+      searched = 1;
+      bool early = false;
+      if (top < 0) top = 0;
+      if (top >= lh) early = true;
+      if (bot1 <= 0) early = true;
+      if (left < 0) left = 0;
+      if (left >= lw) early = true;
+      if (!early) {
+        // candidates in reference order; one candidate per lane, first-best arg-min
+        int nc, c0 = 0, bw = 0;
+        if (bex) { const int yb = min(bot1, lh), xr = min(right, lw - 1); bw = xr - left + 1; nc = (bw > 0 && yb > top) ? bw*(yb - top) : 0; }
+        else { c0 = T.lut[level][top]; const int c1 = (bot1 >= lh) ? T.info[level]->n_corners : T.lut[level][bot1]; nc = c1 - c0; }
+        int mybest = MAXSSD + 1, myidx = 0x7fffffff, mx = 0, my = 0;
+        for (int c = lane; c < nc; c += 64) {
+          int x, y;
+          if (bex) { x = left + c % bw; y = top + c / bw; }
+          else { x = T.corners[level][c0 + c].x; y = T.corners[level][c0 + c].y; if (x < left || x > right) continue; }
+          if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+          int s;
+          if (!(x >= 4 && y >= 4 && x < lw - 4 && y < lh - 4)) s = MAXSSD + 1;
+          else {
+            int isum = 0, isumsq = 0, cross = 0;
+            for (int r = 0; r < 8; ++r) { const uint8_t* ip = limg + (size_t)(y - 4 + r)*lw + x - 4;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { const int v = ip[k]; isum += v; isumsq += v*v; cross += v*(int)tmpl[8*r + k]; } }
+            s = ((2*tsum*isum - tsum*tsum - isum*isum)/64 + isumsq + tsumsq - 2*cross);
+          }
+          if (s < mybest) { mybest = s; myidx = c; mx = x; my = y; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const int ob = __shfl_xor(mybest, o, 64), oi = __shfl_xor(myidx, o, 64), ox = __shfl_xor(mx, o, 64), oy = __shfl_xor(my, o, 64);
+          if (ob < mybest || (ob == mybest && oi < myidx)) { mybest = ob; myidx = oi; mx = ox; my = oy; }
+        }
+        best = mybest;
+        if (best < MAXSSD) {
+          found = 1; bx = mx; by = my;
+          const double coarse[2] = { (bx + 0.5)*scale - 0.5, (by + 0.5)*scale - 0.5 };
+          sinv = 1.0/scale; fpos[0] = coarse[0]; fpos[1] = coarse[1];
+          if (its > 0) {
+            did_subpix = 1;
+            // MakeSubPixTemplate: lanes 0..35 own the interior pixels (y outer, x inner)
+            const int sy = lane/6 + 1, sx = lane%6 + 1;
+            double gx = 0, gy = 0;
+            if (lane < 36) { gx = 0.5*((int)tmpl[8*sy + sx + 1] - (int)tmpl[8*sy + sx - 1]); gy = 0.5*((int)tmpl[8*(sy + 1) + sx] - (int)tmpl[8*(sy - 1) + sx]); }
+            // J^T J: sums of multiples of 1/4 -- exact in any order
+            double H[9];
+            { const double g[3] = { gx, gy, lane < 36 ? 1.0 : 0.0 };
+#pragma unroll
+              for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) { double v = g[a]*g[b];
+#pragma unroll
+                  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                  H[3*a + b] = v; } }
+            double Hi[9];
+            { const double c00 = H[4]*H[8] - H[5]*H[7], c01 = H[5]*H[6] - H[3]*H[8], c02 = H[3]*H[7] - H[4]*H[6];
+              const double det = H[0]*c00 + H[1]*c01 + H[2]*c02, id = 1.0/det;
+              Hi[0] = c00*id; Hi[1] = (H[2]*H[7] - H[1]*H[8])*id; Hi[2] = (H[1]*H[5] - H[2]*H[4])*id;
+              Hi[3] = c01*id; Hi[4] = (H[0]*H[8] - H[2]*H[6])*id; Hi[5] = (H[2]*H[3] - H[0]*H[5])*id;
+              Hi[6] = c02*id; Hi[7] = (H[1]*H[6] - H[0]*H[7])*id; Hi[8] = (H[0]*H[4] - H[1]*H[3])*id; }
+            double sp[2] = { coarse[0], coarse[1] }, mean = 0.0;
+            int conv = 0;
+            for (int it = 0; it < its && conv == 0; ++it) {
+              const double cx = (sp[0] + 0.5)/scale - 0.5, cy = (sp[1] + 0.5)/scale - 0.5;
+              const int rx = (int)round(cx), ry = (int)round(cy);
+              if (!(rx >= 5 && ry >= 5 && rx < lw - 5 && ry < lh - 5)) { conv = -1; break; }
+              const double bxs = cx - 4, bys = cy - 4;
+              const double dX = bxs - floor(bxs), dY = bys - floor(bys);
+              const float fTL = (float)((1.0 - dX)*(1.0 - dY)), fTR = (float)(dX*(1.0 - dY)), fBL = (float)((1.0 - dX)*dY), fBR = (float)(dX*dY);
+              if (lane < 36) {
+                const uint8_t* q = limg + (size_t)((int)bys + sy)*lw + (int)bxs + sx;
+                float fPixel = fTL*(float)q[0] + fTR*(float)q[1];
+                fPixel = fPixel + fBL*(float)q[lw];
+                fPixel = fPixel + fBR*(float)q[lw + 1];
+                const double d = (double)fPixel - (double)tmpl[8*sy + sx] + mean;
+                dprod[0][lane] = d*gx; dprod[1][lane] = d*gy; dprod[2][lane] = d;
+              }
+              __syncthreads();
+              double acc[3] = {0, 0, 0};          // summed in the reference's pixel order for bit-equal rounding
+              for (int q = 0; q < 36; ++q) { acc[0] += dprod[0][q]; acc[1] += dprod[1][q]; acc[2] += dprod[2][q]; }
+              __syncthreads();
+              double up[3]; mat3_vec(Hi, acc, up);
+              sp[0] -= up[0]*scale; sp[1] -= up[1]*scale; mean -= up[2];
+              const double u2 = up[0]*up[0] + up[1]*up[1];
+              if (u2 < 0.03*0.03) conv = 1;
+            }
+            if (conv != 1) found = 0; else { fpos[0] = sp[0]; fpos[1] = sp[1]; }
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    O.image[0] = pr.u; O.image[1] = pr.v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { O.cam_derivs[k] = pr.D[k]; O.warp_inverse[k] = WI[k]; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) O.jacobian[k] = J[k];
+    O.found_pos[0] = fpos[0]; O.found_pos[1] = fpos[1]; O.sqrt_inv_noise = sinv;
+    O.in_image = in_image; O.search_level = level; O.template_bad = template_bad; O.searched = searched;
+    O.found = found; O.did_subpix = did_subpix; O.coarse_x = bx; O.coarse_y = by; O.score = best;
+  }
+  if (level < 0 || !in_image) O.templ[lane] = 0;
+}
+
+// ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------
+__global__ void k_pose_errors(int n, const uint8_t* __restrict__ found, const double* __restrict__ fpos, const double* __restrict__ ipos,
+                              const double* __restrict__ sinv, double* __restrict__ ex, double* __restrict__ e2_compact,
+                              const int* __restrict__ slot) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= n || !found[i]) return;
+  const double a = sinv[i]*(fpos[2*i] - ipos[2*i]), b = sinv[i]*(fpos[2*i + 1] - ipos[2*i + 1]);
+  ex[2*i] = a; ex[2*i + 1] = b;
+  e2_compact[slot[i]] = a*a + b*b;
+}
+// one block: Tukey weights, WLS<6> accumulation (prior 100), 6x6 Cholesky solve.  sig[0] = sigma^2
+__global__ void __launch_bounds__(256)
+k_pose_solve(int n, const uint8_t* __restrict__ found, const double* __restrict__ ex, const double* __restrict__ sinv,
+             const double* __restrict__ J, const double* __restrict__ sig, double* __restrict__ mu, double* __restrict__ wout) {
+  __shared__ double red[27][4];
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  const double s2 = sig[0];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double w = 0.0;
+    if (found[i]) {
+      const double e = ex[2*i]*ex[2*i] + ex[2*i + 1]*ex[2*i + 1];
+      const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
+      w = sq*sq;
+      if (w != 0.0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double Jr[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Jr[k] = sinv[i]*J[12*(size_t)i + 6*r + k];
+          const double m = ex[2*i + r];
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) { acc[21 + a] += w*m*Jr[a];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) { acc[q] += w*Jr[a]*Jr[b]; ++q; } }
+        }
+      }
+    }
+    if (wout) wout[i] = w;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double C[36], v[6], L[36], x[6];
+    int q = 0;
+    for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) { const double t = red[q][0] + red[q][1] + red[q][2] + red[q][3]; C[6*a + b] = t; C[6*b + a] = t; ++q; }
+    for (int a = 0; a < 6; ++a) { C[7*a] += 100.0; v[a] = red[21 + a][0] + red[21 + a][1] + red[21 + a][2] + red[21 + a][3]; }
+    for (int i = 0; i < 36; ++i) L[i] = C[i];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) { double s = L[6*i + j]; for (int k = 0; k < j; ++k) s -= L[6*i + k]*L[6*j + k]; L[6*i + j] = (i == j) ? sqrt(s) : s/L[6*j + j]; }
+    for (int i = 0; i < 6; ++i) { double s = v[i]; for (int k = 0; k < i; ++k) s -= L[6*i + k]*x[k]; x[i] = s/L[6*i + i]; }
+    for (int i = 5; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < 6; ++k) s -= L[6*k + i]*x[k]; x[i] = s/L[6*i + i]; }
+    for (int i = 0; i < 6; ++i) mu[i] = x[i];
+  }
+}
+__global__ void k_tukey_sigma(const double* __restrict__ med, double n, double override_sigma, double* __restrict__ sig) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (override_sigma > 0) sig[0] = override_sigma;
+    else { double s = 1.4826*(1 + 5.0/(n*2 - 6))*sqrt(med[0]); s = 4.6851*s; sig[0] = s*s; }
+  }
+}
+
+}  // namespace mcp

@@ -1,0 +1,211 @@
+"""ctypes binding of the image-path C ABI (include/mcp_img.h) with the reference's vocabulary:
+KeyFrame.MakeKeyFrame_Lite / MakeKeyFrame_Rest, MiniPatch FindPatch, the Tracker's per-point
+PatchFinder search and CalcPoseUpdate.  All numeric work happens in libmcptam_hip.so on the GPU."""
+import ctypes
+
+import numpy as np
+
+from . import chain_bundle as _cb
+from .taylor_camera import McpCamera
+
+LEVELS = 4
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_ubyte_p = ctypes.POINTER(ctypes.c_ubyte)
+
+
+class McpKfParams(ctypes.Structure):
+    _fields_ = [("adaptive_thresh", ctypes.c_int), ("glare_masking", ctypes.c_int), ("half_sample_pavgb", ctypes.c_int),
+                ("device", ctypes.c_int)]
+
+
+class TdIn(ctypes.Structure):
+    _fields_ = [("world_pos", ctypes.c_double * 3), ("pixel_right_w", ctypes.c_double * 3), ("pixel_down_w", ctypes.c_double * 3),
+                ("source_kf", ctypes.c_void_p), ("source_level", ctypes.c_int), ("center_x", ctypes.c_int),
+                ("center_y", ctypes.c_int), ("fixed", ctypes.c_int)]
+
+
+class TdOut(ctypes.Structure):
+    _fields_ = [("image", ctypes.c_double * 2), ("cam_derivs", ctypes.c_double * 4), ("jacobian", ctypes.c_double * 12),
+                ("found_pos", ctypes.c_double * 2), ("sqrt_inv_noise", ctypes.c_double), ("warp_inverse", ctypes.c_double * 4),
+                ("in_image", ctypes.c_int), ("search_level", ctypes.c_int), ("template_bad", ctypes.c_int),
+                ("searched", ctypes.c_int), ("found", ctypes.c_int), ("did_subpix", ctypes.c_int),
+                ("coarse_x", ctypes.c_int), ("coarse_y", ctypes.c_int), ("score", ctypes.c_int), ("templ", ctypes.c_ubyte * 64)]
+
+
+TD_OUT_DTYPE = np.dtype([("image", "f8", 2), ("cam_derivs", "f8", 4), ("jacobian", "f8", 12), ("found_pos", "f8", 2),
+                         ("sqrt_inv_noise", "f8"), ("warp_inverse", "f8", 4), ("in_image", "i4"), ("search_level", "i4"),
+                         ("template_bad", "i4"), ("searched", "i4"), ("found", "i4"), ("did_subpix", "i4"),
+                         ("coarse_x", "i4"), ("coarse_y", "i4"), ("score", "i4"), ("templ", "u1", 64)], align=True)
+assert TD_OUT_DTYPE.itemsize == ctypes.sizeof(TdOut)
+
+IMG_SYMBOLS = [
+    "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
+    "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
+    "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
+]
+_BOUND = False
+
+
+def lib():
+    global _BOUND
+    L = _cb.lib()
+    if not _BOUND:
+        L.mcp_kf_create.restype = ctypes.c_void_p
+        L.mcp_kf_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_kf_destroy.argtypes = [ctypes.c_void_p]
+        L.mcp_kf_make_lite.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_kf_level_size.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
+        L.mcp_kf_get_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mcp_kf_get_corners.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.mcp_kf_get_row_lut.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p]
+        L.mcp_kf_fast_thresh.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mcp_kf_get_fast_frequency.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
+        L.mcp_kf_make_rest.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        L.mcp_kf_num_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mcp_kf_get_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_double_p, ctypes.c_int]
+        L.mcp_minipatch_find.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_track_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            ctypes.c_double, c_double_p, c_double_p, c_double_p]
+        _BOUND = True
+    return L
+
+
+def _chk(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise RuntimeError("%s failed: %s" % (what, _cb.last_error()))
+    return rc
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class KeyFrame:
+    """One camera's KeyFrame with a device-resident 4-level pyramid (include/mcptam/KeyFrame.h:93-150)."""
+
+    def __init__(self, w, h, adaptive=True, glare=False, pavgb=False, device=-1):
+        self._L = lib()
+        prm = McpKfParams(int(adaptive), int(glare), int(pavgb), int(device))
+        self._h = self._L.mcp_kf_create(int(w), int(h), ctypes.byref(prm))
+        if not self._h:
+            raise RuntimeError("mcp_kf_create failed: " + _cb.last_error())
+        self.w, self.h = w, h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mcp_kf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def MakeKeyFrame_Lite(self, img, masks=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        assert img.shape == (self.h, self.w)
+        mp = None
+        if masks is not None:
+            self._masks = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+            arr = (ctypes.c_void_p * LEVELS)(*[None if m is None else m.ctypes.data for m in self._masks])
+            mp = ctypes.cast(arr, ctypes.c_void_p)
+        _chk(self._L.mcp_kf_make_lite(self._h, img.ctypes.data, img.strides[0], mp), "MakeKeyFrame_Lite")
+
+    def LevelSize(self, level):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        _chk(self._L.mcp_kf_level_size(self._h, level, ctypes.byref(w), ctypes.byref(h)), "LevelSize")
+        return w.value, h.value
+
+    def Image(self, level):
+        w, h = self.LevelSize(level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        _chk(self._L.mcp_kf_get_image(self._h, level, out.ctypes.data), "Image")
+        return out
+
+    def Corners(self, level):
+        n = _chk(self._L.mcp_kf_num_corners(self._h, level), "Corners")
+        out = np.zeros((max(n, 1), 2), dtype=np.int32)
+        n = _chk(self._L.mcp_kf_get_corners(self._h, level, out.ctypes.data, n), "Corners")
+        return out[:n]
+
+    def RowLUT(self, level):
+        _, h = self.LevelSize(level)
+        out = np.zeros(h, dtype=np.int32)
+        _chk(self._L.mcp_kf_get_row_lut(self._h, level, out.ctypes.data_as(c_int_p)), "RowLUT")
+        return out
+
+    def FastThresh(self, level):
+        return _chk(self._L.mcp_kf_fast_thresh(self._h, level), "FastThresh")
+
+    def FastFrequency(self, level):
+        out = np.zeros(31)
+        _chk(self._L.mcp_kf_get_fast_frequency(self._h, level, _dp(out)), "FastFrequency")
+        return out
+
+    def MakeKeyFrame_Rest(self, use_shi=False, use_percent=True, top_fraction=0.8, thresh=70.0, nonmax_score=0):
+        _chk(self._L.mcp_kf_make_rest(self._h, int(use_shi), int(use_percent), float(top_fraction), float(thresh), int(nonmax_score)), "MakeKeyFrame_Rest")
+
+    def Candidates(self, level):
+        n = _chk(self._L.mcp_kf_num_candidates(self._h, level), "Candidates")
+        pos = np.zeros((max(n, 1), 2), dtype=np.int32)
+        sc = np.zeros(max(n, 1))
+        n = _chk(self._L.mcp_kf_get_candidates(self._h, level, pos.ctypes.data, _dp(sc), n), "Candidates")
+        return pos[:n], sc[:n]
+
+
+def minipatch_find(src, dst, level, src_pos, dst_pos, rng):
+    src_pos = np.ascontiguousarray(src_pos, dtype=np.int32)
+    dst_pos = np.ascontiguousarray(dst_pos, dtype=np.int32)
+    n = src_pos.shape[0]
+    out_pos = np.zeros((n, 2), dtype=np.int32)
+    found = np.zeros(n, dtype=np.uint8)
+    ssd = np.zeros(n, dtype=np.int32)
+    _chk(lib().mcp_minipatch_find(src._h, dst._h, level, n, src_pos.ctypes.data, dst_pos.ctypes.data, int(rng),
+                                  out_pos.ctypes.data, found.ctypes.data, ssd.ctypes.data), "minipatch_find")
+    return out_pos, found.astype(bool), ssd
+
+
+def pack_points(points, handle_of):
+    """points: list of dicts(world_pos, pixel_right_w, pixel_down_w, source_kf, source_level, center, fixed)."""
+    arr = (TdIn * len(points))()
+    for i, p in enumerate(points):
+        for k in range(3):
+            arr[i].world_pos[k] = p["world_pos"][k]
+            arr[i].pixel_right_w[k] = p["pixel_right_w"][k]
+            arr[i].pixel_down_w[k] = p["pixel_down_w"][k]
+        arr[i].source_kf = handle_of(p["source_kf"])
+        arr[i].source_level = int(p["source_level"])
+        arr[i].center_x, arr[i].center_y = int(p["center"][0]), int(p["center"][1])
+        arr[i].fixed = int(p.get("fixed", 0))
+    return arr
+
+
+def _pose12(R, t):
+    return np.ascontiguousarray(np.concatenate([np.asarray(R, dtype=np.float64).reshape(9), np.asarray(t, dtype=np.float64).reshape(3)]))
+
+
+def track_search(target, cam, base_from_world, cam_from_base, points, rng, subpix_its, exhaustive=False):
+    arr = pack_points(points, lambda kf: kf._h)
+    out = np.zeros(len(points), dtype=TD_OUT_DTYPE)
+    cs = cam.to_struct()
+    b, c = _pose12(*base_from_world), _pose12(*cam_from_base)
+    _chk(lib().mcp_track_search(target._h, ctypes.byref(cs), _dp(b), _dp(c), len(points), ctypes.cast(arr, ctypes.c_void_p),
+                                int(rng), int(subpix_its), int(exhaustive), out.ctypes.data), "track_search")
+    return out
+
+
+def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):
+    found = np.ascontiguousarray(found, dtype=np.uint8)
+    n = found.shape[0]
+    fp = np.ascontiguousarray(found_pos, dtype=np.float64)
+    ip = np.ascontiguousarray(image_pos, dtype=np.float64)
+    si = np.ascontiguousarray(sqrt_inv_noise, dtype=np.float64)
+    J = np.ascontiguousarray(jacobian, dtype=np.float64)
+    mu = np.zeros(6)
+    w = np.zeros(max(n, 1))
+    s = ctypes.c_double(0)
+    _chk(lib().mcp_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s)), "track_pose_update")
+    return mu, w[:n], s.value

@@ -202,3 +202,153 @@ class OracleBundle:
         s = ctypes.c_double(0)
         c = self._L.orc_ba_debug_robust_chi2(self._h, ctypes.byref(s))
         return c, s.value
+
+
+# ------------------------------------------------------------------ image path oracle
+class OrcTdIn(ctypes.Structure):
+    _fields_ = [("world_pos", ctypes.c_double * 3), ("pixel_right_w", ctypes.c_double * 3), ("pixel_down_w", ctypes.c_double * 3),
+                ("source_kf", ctypes.c_void_p), ("source_level", ctypes.c_int), ("center_x", ctypes.c_int),
+                ("center_y", ctypes.c_int), ("fixed", ctypes.c_int)]
+
+
+_IMG_BOUND = False
+
+
+def img_lib():
+    global _IMG_BOUND
+    L = lib()
+    if not _IMG_BOUND:
+        L.orc_kf_create.restype = ctypes.c_void_p
+        L.orc_kf_create.argtypes = [ctypes.c_int] * 5
+        L.orc_kf_destroy.argtypes = [ctypes.c_void_p]
+        L.orc_kf_make_lite.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_kf_level_size.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
+        L.orc_kf_image.restype = ctypes.c_void_p
+        L.orc_kf_image.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_corners.restype = ctypes.c_void_p
+        L.orc_kf_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_row_lut.restype = ctypes.c_void_p
+        L.orc_kf_row_lut.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_fast_thresh.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_fast_frequency.restype = ctypes.c_void_p
+        L.orc_kf_fast_frequency.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_make_rest.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        L.orc_kf_num_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_get_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_double_p, ctypes.c_int]
+        L.orc_fast10_is_corner.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.orc_fast10_score.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.orc_shi_tomasi.restype = ctypes.c_double
+        L.orc_shi_tomasi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_minipatch_find.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_track_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.orc_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                            ctypes.c_double, c_double_p, c_double_p, c_double_p]
+        _IMG_BOUND = True
+    return L
+
+
+class OracleKeyFrame:
+    def __init__(self, w, h, adaptive=True, glare=False, pavgb=False):
+        self._L = img_lib()
+        self._h = self._L.orc_kf_create(int(w), int(h), int(adaptive), int(glare), int(pavgb))
+        self.w, self.h = w, h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_kf_destroy(self._h)
+            self._h = None
+
+    def MakeKeyFrame_Lite(self, img, masks=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        mp = None
+        if masks is not None:
+            self._masks = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in masks]
+            arr = (ctypes.c_void_p * 4)(*[None if m is None else m.ctypes.data for m in self._masks])
+            mp = ctypes.cast(arr, ctypes.c_void_p)
+        self._L.orc_kf_make_lite(self._h, img.ctypes.data, img.strides[0], mp)
+
+    def LevelSize(self, level):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self._L.orc_kf_level_size(self._h, level, ctypes.byref(w), ctypes.byref(h))
+        return w.value, h.value
+
+    def Image(self, level):
+        w, h = self.LevelSize(level)
+        p = self._L.orc_kf_image(self._h, level)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_ubyte)), shape=(h, w)).copy()
+
+    def Corners(self, level):
+        n = self._L.orc_kf_num_corners(self._h, level)
+        if n == 0:
+            return np.zeros((0, 2), dtype=np.int32)
+        p = self._L.orc_kf_corners(self._h, level)
+        return np.ctypeslib.as_array(ctypes.cast(p, c_int_p), shape=(n, 2)).copy()
+
+    def RowLUT(self, level):
+        _, h = self.LevelSize(level)
+        p = self._L.orc_kf_row_lut(self._h, level)
+        return np.ctypeslib.as_array(ctypes.cast(p, c_int_p), shape=(h,)).copy()
+
+    def FastThresh(self, level):
+        return self._L.orc_kf_fast_thresh(self._h, level)
+
+    def FastFrequency(self, level):
+        p = self._L.orc_kf_fast_frequency(self._h, level)
+        return np.ctypeslib.as_array(ctypes.cast(p, c_double_p), shape=(31,)).copy()
+
+    def MakeKeyFrame_Rest(self, use_shi=False, use_percent=True, top_fraction=0.8, thresh=70.0, nonmax_score=0):
+        self._L.orc_kf_make_rest(self._h, int(use_shi), int(use_percent), float(top_fraction), float(thresh), int(nonmax_score))
+
+    def Candidates(self, level):
+        n = self._L.orc_kf_num_candidates(self._h, level)
+        pos = np.zeros((max(n, 1), 2), dtype=np.int32)
+        sc = np.zeros(max(n, 1))
+        n = self._L.orc_kf_get_candidates(self._h, level, pos.ctypes.data, _dp(sc), n)
+        return pos[:n], sc[:n]
+
+
+def oracle_minipatch_find(src, dst, level, src_pos, dst_pos, rng):
+    src_pos = np.ascontiguousarray(src_pos, dtype=np.int32)
+    dst_pos = np.ascontiguousarray(dst_pos, dtype=np.int32)
+    n = src_pos.shape[0]
+    out_pos = np.zeros((n, 2), dtype=np.int32)
+    found = np.zeros(n, dtype=np.uint8)
+    ssd = np.zeros(n, dtype=np.int32)
+    img_lib().orc_minipatch_find(src._h, dst._h, level, n, src_pos.ctypes.data, dst_pos.ctypes.data, int(rng), out_pos.ctypes.data, found.ctypes.data, ssd.ctypes.data)
+    return out_pos, found.astype(bool), ssd
+
+
+def oracle_track_search(target, cam, base_from_world, cam_from_base, points, rng, subpix_its, exhaustive=False):
+    from mcptam_amd.keyframe import TD_OUT_DTYPE, _pose12
+    arr = (OrcTdIn * len(points))()
+    for i, p in enumerate(points):
+        for k in range(3):
+            arr[i].world_pos[k] = p["world_pos"][k]
+            arr[i].pixel_right_w[k] = p["pixel_right_w"][k]
+            arr[i].pixel_down_w[k] = p["pixel_down_w"][k]
+        arr[i].source_kf = p["source_kf_oracle"]._h
+        arr[i].source_level = int(p["source_level"])
+        arr[i].center_x, arr[i].center_y = int(p["center"][0]), int(p["center"][1])
+        arr[i].fixed = int(p.get("fixed", 0))
+    out = np.zeros(len(points), dtype=TD_OUT_DTYPE)
+    cs = cam.to_struct()
+    b, c = _pose12(*base_from_world), _pose12(*cam_from_base)
+    img_lib().orc_track_search(target._h, ctypes.byref(cs), _dp(b), _dp(c), len(points), ctypes.cast(arr, ctypes.c_void_p), int(rng), int(subpix_its), int(exhaustive), out.ctypes.data)
+    return out
+
+
+def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):
+    found = np.ascontiguousarray(found, dtype=np.uint8)
+    n = found.shape[0]
+    fp = np.ascontiguousarray(found_pos, dtype=np.float64)
+    ip = np.ascontiguousarray(image_pos, dtype=np.float64)
+    si = np.ascontiguousarray(sqrt_inv_noise, dtype=np.float64)
+    J = np.ascontiguousarray(jacobian, dtype=np.float64)
+    mu = np.zeros(6)
+    w = np.zeros(max(n, 1))
+    s = ctypes.c_double(0)
+    img_lib().orc_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s))
+    return mu, w[:n], s.value

@@ -1,0 +1,509 @@
+/*
+ * img_oracle.c -- CPU ORACLE for the KeyFrame / Tracker image path (test infrastructure only).
+ * PARITY UNPINNED (see img_oracle.h).  Every function cites the reference lines it follows;
+ * libCVD / OpenCV / TooN semantics are restated from their published algorithms [3P-memory].
+ */
+#include "img_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define MIN_FAST_THRESH 5      /* include/mcptam/KeyFrame.h:88 */
+#define MAX_FAST_THRESH 30     /* :89 */
+
+typedef struct { int w, h; uint8_t* img; uint8_t* mask; int ncorners, ccorners; orc_int2* corners; int* lut;
+                 int thresh; double freq[MAX_FAST_THRESH + 1];
+                 int ncand; orc_int2* cand; double* cand_score; } olevel;
+struct orc_kf { olevel lev[ORC_LEVELS]; int adaptive, glare, pavgb; };
+
+orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb) {
+  orc_kf* k = (orc_kf*)calloc(1, sizeof *k);
+  k->adaptive = adaptive; k->glare = glare; k->pavgb = pavgb;
+  for (int l = 0; l < ORC_LEVELS; l++) {
+    olevel* L = &k->lev[l];
+    L->w = w >> l; L->h = h >> l;               /* size / 2 per level, KeyFrame.cc:189 */
+    L->img = (uint8_t*)calloc((size_t)L->w*L->h + 1, 1);
+    L->mask = (uint8_t*)malloc((size_t)L->w*L->h + 1);
+    L->lut = (int*)calloc(L->h + 1, sizeof(int));
+  }
+  return k;
+}
+void orc_kf_destroy(orc_kf* k) {
+  if (!k) return;
+  for (int l = 0; l < ORC_LEVELS; l++) { olevel* L = &k->lev[l]; free(L->img); free(L->mask); free(L->corners); free(L->lut); free(L->cand); free(L->cand_score); }
+  free(k);
+}
+
+/* CVD::halfSample [3P-memory]: generic template = truncating mean of the 2x2 block; the SSE2 byte
+ * path = cascaded pavgb (round-half-up vertical average, then horizontal). */
+static void half_sample(const uint8_t* in, int iw, int ih, uint8_t* out, int ow, int oh, int pavgb) {
+  (void)ih;
+  for (int y = 0; y < oh; y++) for (int x = 0; x < ow; x++) {
+    const int a = in[(2*y)*iw + 2*x], b = in[(2*y)*iw + 2*x + 1], c = in[(2*y + 1)*iw + 2*x], d = in[(2*y + 1)*iw + 2*x + 1];
+    if (pavgb) { const int v0 = (a + c + 1) >> 1, v1 = (b + d + 1) >> 1; out[y*ow + x] = (uint8_t)((v0 + v1 + 1) >> 1); }
+    else out[y*ow + x] = (uint8_t)((a + b + c + d)/4);
+  }
+}
+
+/* libCVD fast_pixel_ring [3P-memory]: Bresenham circle of radius 3 */
+static const int RING_X[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+static const int RING_Y[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+
+/* FAST-10 segment test: >= 10 contiguous ring pixels all > p+b or all < p-b */
+int orc_fast10_is_corner(const uint8_t* p, int stride, int b) {
+  const int cb = *p + b, c_b = *p - b;
+  int bright = 0, dark = 0;
+  for (int k = 0; k < 16; k++) {
+    const int v = p[RING_Y[k]*stride + RING_X[k]];
+    if (v > cb) bright |= 1 << k;
+    if (v < c_b) dark |= 1 << k;
+  }
+  for (int pass = 0; pass < 2; pass++) {
+    const int m = pass ? dark : bright;
+    for (int s = 0; s < 16; s++) {
+      int ok = 1;
+      for (int j = 0; j < 10; j++) if (!(m & (1 << ((s + j) & 15)))) { ok = 0; break; }
+      if (ok) return 1;
+    }
+  }
+  return 0;
+}
+/* CVD::fast_corner_score_10 [3P-memory]: binary search for the largest threshold that still
+ * passes the segment test */
+int orc_fast10_score(const uint8_t* p, int stride, int bstart) {
+  int bmin = bstart, bmax = 255, b = (bmax + bmin)/2;
+  for (;;) {
+    if (orc_fast10_is_corner(p, stride, b)) bmin = b; else bmax = b;
+    if (bmin == bmax - 1 || bmin == bmax) return bmin;
+    b = (bmin + bmax)/2;
+  }
+}
+/* the classic FAST corner_score used by older fast_nonmax [3P-memory]: ring SAD above the barrier */
+int orc_fast_ring_sad_score(const uint8_t* p, int stride, int barrier) {
+  const int cb = *p + barrier, c_b = *p - barrier;
+  int sp = 0, sn = 0;
+  for (int k = 0; k < 16; k++) {
+    const int v = p[RING_Y[k]*stride + RING_X[k]];
+    if (v > cb) sp += v - cb; else if (v < c_b) sn += c_b - v;
+  }
+  return sp > sn ? sp : sn;
+}
+/* CVD::fast_corner_detect_10 [3P-memory]: raster scan of y in [3,h-3), x in [3,w-3) */
+static void fast_detect(olevel* L, int b) {
+  L->ncorners = 0;
+  for (int y = 3; y < L->h - 3; y++) for (int x = 3; x < L->w - 3; x++)
+    if (orc_fast10_is_corner(L->img + (size_t)y*L->w + x, L->w, b)) {
+      if (L->ncorners >= L->ccorners) { L->ccorners = L->ccorners ? 2*L->ccorners : 4096; L->corners = (orc_int2*)realloc(L->corners, sizeof(orc_int2)*L->ccorners); }
+      L->corners[L->ncorners].x = x; L->corners[L->ncorners].y = y; L->ncorners++;
+    }
+}
+
+/* OpenCV dilate with the 5x5 MORPH_ELLIPSE element, constant border = -inf [3P-memory] (KeyFrame.cc:217) */
+static void dilate5(const uint8_t* in, uint8_t* out, int w, int h) {
+  static const int EL[5][5] = { {0,0,1,0,0}, {1,1,1,1,1}, {1,1,1,1,1}, {1,1,1,1,1}, {0,0,1,0,0} };
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    int m = 0;
+    for (int dy = -2; dy <= 2; dy++) for (int dx = -2; dx <= 2; dx++) {
+      if (!EL[dy + 2][dx + 2]) continue;
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+      if (in[yy*w + xx] > m) m = in[yy*w + xx];
+    }
+    out[y*w + x] = (uint8_t)m;
+  }
+}
+
+/* KeyFrame::MakeKeyFrame_Lite, KeyFrame.cc:145-360 */
+int orc_kf_make_lite(orc_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
+  for (int l = 0; l < ORC_LEVELS; l++) {
+    olevel* L = &k->lev[l];
+    if (l == 0) { for (int y = 0; y < L->h; y++) memcpy(L->img + (size_t)y*L->w, img + (size_t)y*stride, L->w); }
+    else half_sample(k->lev[l-1].img, k->lev[l-1].w, k->lev[l-1].h, L->img, L->w, L->h, k->pavgb);     /* :189-190 */
+    const size_t npx = (size_t)L->w*L->h;
+    /* mask, :214-243 */
+    const uint8_t* internal = masks ? masks[l] : NULL;
+    if (k->glare) {
+      uint8_t* a = (uint8_t*)malloc(npx + 1); uint8_t* b = (uint8_t*)malloc(npx + 1);
+      memcpy(a, L->img, npx);
+      for (int it = 0; it < 5; it++) { dilate5(a, b, L->w, L->h); uint8_t* t = a; a = b; b = t; }      /* 5 iterations, :217 */
+      for (size_t i = 0; i < npx; i++) { const uint8_t g = a[i] > 245 ? 0 : 255; L->mask[i] = internal ? (internal[i] & g) : g; }   /* :218, :227 */
+      free(a); free(b);
+    } else if (internal) memcpy(L->mask, internal, npx);
+    else memset(L->mask, 255, npx);
+    memset(L->freq, 0, sizeof L->freq); L->thresh = 0;
+    if (k->adaptive) {
+      fast_detect(L, MIN_FAST_THRESH);                                                          /* :259 */
+      int* scores = (int*)malloc(sizeof(int)*(L->ncorners + 1));
+      for (int j = 0; j < L->ncorners; j++) scores[j] = orc_fast10_score(L->img + (size_t)L->corners[j].y*L->w + L->corners[j].x, L->w, MIN_FAST_THRESH);   /* :262 */
+      for (int j = 0; j < L->ncorners; j++)                                                       /* :264-275 */
+        for (int t = MIN_FAST_THRESH; t <= MAX_FAST_THRESH; ++t) { if (scores[j] >= t) L->freq[t]++; if (scores[j] == t) break; }
+      const double targetDeriv = -1*(L->w*L->h)/500.0;                                          /* :279 */
+      L->thresh = MIN_FAST_THRESH;
+      for (int t = MIN_FAST_THRESH; t <= MAX_FAST_THRESH; ++t) {                                 /* :283-300 */
+        double deriv;
+        if (t == MIN_FAST_THRESH) deriv = L->freq[t+1] - L->freq[t];
+        else if (t == MAX_FAST_THRESH) deriv = L->freq[t] - L->freq[t-1];
+        else deriv = (L->freq[t+1] - L->freq[t-1])/2.0;
+        L->thresh = t;
+        if (deriv > targetDeriv) break;
+      }
+      int n = 0;
+      for (int j = 0; j < L->ncorners; j++) {                                                    /* :302-315 */
+        if (L->mask[(size_t)L->corners[j].y*L->w + L->corners[j].x] < 255) continue;
+        if (scores[j] < L->thresh) continue;
+        L->corners[n++] = L->corners[j];
+      }
+      L->ncorners = n;
+      free(scores);
+    } else {                                                                                     /* :318-343 */
+      static const int fixed_t[4] = { 10, 15, 15, 10 };
+      fast_detect(L, fixed_t[l]); L->thresh = fixed_t[l];
+    }
+    unsigned v = 0;                                                                              /* :346-355 */
+    for (int y = 0; y < L->h; y++) { while (v < (unsigned)L->ncorners && y > L->corners[v].y) v++; L->lut[y] = (int)v; }
+  }
+  return 0;
+}
+int orc_kf_level_size(orc_kf* k, int l, int* w, int* h) { *w = k->lev[l].w; *h = k->lev[l].h; return 0; }
+const uint8_t* orc_kf_image(orc_kf* k, int l) { return k->lev[l].img; }
+int orc_kf_num_corners(orc_kf* k, int l) { return k->lev[l].ncorners; }
+const orc_int2* orc_kf_corners(orc_kf* k, int l) { return k->lev[l].corners; }
+const int* orc_kf_row_lut(orc_kf* k, int l) { return k->lev[l].lut; }
+int orc_kf_fast_thresh(orc_kf* k, int l) { return k->lev[l].thresh; }
+const double* orc_kf_fast_frequency(orc_kf* k, int l) { return k->lev[l].freq; }
+
+/* FindShiTomasiScoreAtPoint, ShiTomasi.cc:34-63 */
+double orc_shi_tomasi(const uint8_t* img, int stride, int half, int cx, int cy) {
+  double dXX = 0, dYY = 0, dXY = 0;
+  for (int y = cy - half; y <= cy + half; y++) for (int x = cx - half; x <= cx + half; x++) {
+    const double dx = img[y*stride + x + 1] - img[y*stride + x - 1];
+    const double dy = img[(y + 1)*stride + x] - img[(y - 1)*stride + x];
+    dXX += dx*dx; dYY += dy*dy; dXY += dx*dy;
+  }
+  const int nPixels = (2*half + 1)*(2*half + 1);
+  dXX = dXX/(2.0*nPixels); dYY = dYY/(2.0*nPixels); dXY = dXY/(2.0*nPixels);
+  return 0.5*(dXX + dYY - sqrt((dXX + dYY)*(dXX + dYY) - 4*(dXX*dYY - dXY*dXY)));
+}
+
+static int in_border(const olevel* L, int x, int y, int b) { return x >= b && y >= b && x < L->w - b && y < L->h - b; }
+
+/* CVD::fast_nonmax -> nonmax_suppression [3P-memory]: keep a corner iff none of its 8 neighbours that are
+ * corners has a strictly greater score; raster order preserved */
+static int nonmax(const olevel* L, const int* score, orc_int2* out) {
+  int n = 0;
+  /* index image for neighbour lookup */
+  int* idx = (int*)malloc(sizeof(int)*(size_t)L->w*L->h);
+  for (size_t i = 0; i < (size_t)L->w*L->h; i++) idx[i] = -1;
+  for (int i = 0; i < L->ncorners; i++) idx[(size_t)L->corners[i].y*L->w + L->corners[i].x] = i;
+  for (int i = 0; i < L->ncorners; i++) {
+    const int x = L->corners[i].x, y = L->corners[i].y; int keep = 1;
+    for (int dy = -1; dy <= 1 && keep; dy++) for (int dx = -1; dx <= 1; dx++) {
+      if (!dx && !dy) continue;
+      const int xx = x + dx, yy = y + dy;
+      if (xx < 0 || yy < 0 || xx >= L->w || yy >= L->h) continue;
+      const int j = idx[(size_t)yy*L->w + xx];
+      if (j >= 0 && score[j] > score[i]) { keep = 0; break; }
+    }
+    if (keep) out[n++] = L->corners[i];
+  }
+  free(idx);
+  return n;
+}
+typedef struct { double s; orc_int2 p; } scored;
+static int cmp_scored_desc(const void* a, const void* b) {       /* std::sort on reverse iterators of pair<double,ImageRef> */
+  const scored* x = (const scored*)a; const scored* y = (const scored*)b;
+  if (x->s != y->s) return (x->s < y->s) - (x->s > y->s);
+  /* ImageRef operator< [3P-memory]: y first, then x */
+  if (x->p.y != y->p.y) return (x->p.y < y->p.y) - (x->p.y > y->p.y);
+  return (x->p.x < y->p.x) - (x->p.x > y->p.x);
+}
+/* KeyFrame::MakeKeyFrame_Rest, candidate part, KeyFrame.cc:363-450 */
+int orc_kf_make_rest(orc_kf* k, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score) {
+  for (int l = 0; l < ORC_LEVELS; l++) {
+    olevel* L = &k->lev[l];
+    int* sc = (int*)malloc(sizeof(int)*(L->ncorners + 1));
+    for (int i = 0; i < L->ncorners; i++) {
+      const uint8_t* p = L->img + (size_t)L->corners[i].y*L->w + L->corners[i].x;
+      sc[i] = nonmax_score ? orc_fast_ring_sad_score(p, L->w, L->thresh) : orc_fast10_score(p, L->w, L->thresh);
+    }
+    orc_int2* mx = (orc_int2*)malloc(sizeof(orc_int2)*(L->ncorners + 1));
+    const int nm = nonmax(L, sc, mx);                                               /* :393 / :411 */
+    scored* v = (scored*)malloc(sizeof(scored)*(nm + 1)); int nv = 0;
+    for (int i = 0; i < nm; i++) {
+      if (!in_border(L, mx[i].x, mx[i].y, 10)) continue;                             /* :402, :415 */
+      const uint8_t* p = L->img + (size_t)mx[i].y*L->w + mx[i].x;
+      v[nv].s = use_shi ? orc_shi_tomasi(L->img, L->w, 3, mx[i].x, mx[i].y) : (double)orc_fast10_score(p, L->w, L->thresh);   /* :396, :418 */
+      v[nv].p = mx[i]; nv++;
+    }
+    free(L->cand); free(L->cand_score);
+    L->cand = (orc_int2*)malloc(sizeof(orc_int2)*(nv + 1)); L->cand_score = (double*)malloc(sizeof(double)*(nv + 1)); L->ncand = 0;
+    if (use_percent) {                                                               /* :424-438 */
+      qsort(v, nv, sizeof(scored), cmp_scored_desc);
+      const int num = (int)(nv*top_fraction);
+      for (int i = 0; i < num && i < nv; i++) { L->cand[L->ncand] = v[i].p; L->cand_score[L->ncand++] = v[i].s; }
+    } else {                                                                         /* :439-452 */
+      for (int i = 0; i < nv; i++) if (v[i].s > thresh) { L->cand[L->ncand] = v[i].p; L->cand_score[L->ncand++] = v[i].s; }
+    }
+    free(sc); free(mx); free(v);
+  }
+  return 0;
+}
+int orc_kf_num_candidates(orc_kf* k, int l) { return k->lev[l].ncand; }
+int orc_kf_get_candidates(orc_kf* k, int l, orc_int2* pos, double* score, int cap) {
+  const int n = k->lev[l].ncand < cap ? k->lev[l].ncand : cap;
+  memcpy(pos, k->lev[l].cand, sizeof(orc_int2)*n); memcpy(score, k->lev[l].cand_score, sizeof(double)*n); return n;
+}
+
+/* MiniPatch::SampleFromImage + FindPatch + SSDAtPoint, MiniPatch.cc:34-122 (half size 4, max SSD 9999) */
+int orc_minipatch_find(orc_kf* src, orc_kf* dst, int level, int n, const orc_int2* src_pos, const orc_int2* dst_pos,
+                       int range, orc_int2* out_pos, uint8_t* out_found, int* out_ssd) {
+  const olevel* S = &src->lev[level]; const olevel* D = &dst->lev[level];
+  const int H = 4, MAXSSD = 9999;
+  for (int i = 0; i < n; i++) {
+    out_found[i] = 0; out_pos[i] = dst_pos[i]; if (out_ssd) out_ssd[i] = MAXSSD + 1;
+    if (!in_border(S, src_pos[i].x, src_pos[i].y, H)) continue;                      /* assert in SampleFromImage */
+    uint8_t patch[81];
+    for (int r = 0; r < 9; r++) memcpy(patch + 9*r, S->img + (size_t)(src_pos[i].y - H + r)*S->w + src_pos[i].x - H, 9);
+    int best = MAXSSD + 1; orc_int2 bp = dst_pos[i];
+    const int tlx = dst_pos[i].x - range, tly = dst_pos[i].y - range, brx = dst_pos[i].x + range, bry = dst_pos[i].y + range;
+    int top = tly; if (top < 0) top = 0; if (top >= D->h) top = D->h - 1;           /* :84-90 */
+    for (int c = D->lut[top]; c < D->ncorners; c++) {                                /* :93-107 */
+      const orc_int2 p = D->corners[c];
+      if (p.x < tlx || p.x > brx) continue;
+      if (p.y > bry) break;
+      int ssd;
+      if (!in_border(D, p.x, p.y, H)) ssd = MAXSSD + 1;
+      else { ssd = 0; for (int r = 0; r < 9; r++) for (int q = 0; q < 9; q++) { const int df = D->img[(size_t)(p.y - H + r)*D->w + p.x - H + q] - patch[9*r + q]; ssd += df*df; } }
+      if (ssd < best) { bp = p; best = ssd; }
+    }
+    if (out_ssd) out_ssd[i] = best;
+    if (best < MAXSSD) { out_pos[i] = bp; out_found[i] = 1; }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ tracker per-point path */
+static void m3v(const double* A, const double* v, double* o) {
+  const double a = A[0]*v[0] + A[1]*v[1] + A[2]*v[2], b = A[3]*v[0] + A[4]*v[1] + A[5]*v[2], c = A[6]*v[0] + A[7]*v[1] + A[8]*v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static void gen_field(int i, const double* p, double* o) {
+  o[0] = o[1] = o[2] = 0.0;
+  if (i < 3) { o[i] = 1.0; return; }
+  const int a = i - 3; o[(a+1)%3] = -p[(a+2)%3]; o[(a+2)%3] = p[(a+1)%3];
+}
+/* CVD::transform + sample [3P-memory]: incremental source position, bilinear sample in double,
+ * truncating conversion to byte; returns the number of destination pixels that fell outside */
+static int cvd_transform8(const olevel* in, uint8_t* out /*8x8*/, const double M[4], double inx, double iny, double outx, double outy) {
+  const int w = 8, h = 8, iw = in->w, ih = in->h;
+  const double across[2] = { M[0], M[2] }, down[2] = { M[1], M[3] };
+  double p0[2] = { inx - (M[0]*outx + M[1]*outy), iny - (M[2]*outx + M[3]*outy) };
+  double min_x = p0[0], min_y = p0[1], max_x = min_x, max_y = min_y;
+  if (across[0] < 0) min_x += w*across[0]; else max_x += w*across[0];
+  if (down[0] < 0) min_x += h*down[0]; else max_x += h*down[0];
+  if (across[1] < 0) min_y += w*across[1]; else max_y += w*across[1];
+  if (down[1] < 0) min_y += h*down[1]; else max_y += h*down[1];
+  const double cr[2] = { down[0] - w*across[0], down[1] - w*across[1] };
+  const int inside = (min_x >= 0 && min_y >= 0 && max_x < iw - 1 && max_y < ih - 1);
+  const double xb = iw - 1, yb = ih - 1;
+  int count = 0;
+  double p[2] = { p0[0], p0[1] };
+  for (int i = 0; i < h; ++i, p[0] += cr[0], p[1] += cr[1])
+    for (int j = 0; j < w; ++j, p[0] += across[0], p[1] += across[1]) {
+      if (inside || (0 <= p[0] && 0 <= p[1] && p[0] < xb && p[1] < yb)) {
+        const int lx = (int)p[0], ly = (int)p[1];
+        const double x = p[0] - lx, y = p[1] - ly;
+        const uint8_t* q = in->img + (size_t)ly*iw + lx;
+        const double v = (1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]);
+        out[i*8 + j] = (uint8_t)v;
+      } else { out[i*8 + j] = 0; ++count; }
+    }
+  return count;
+}
+/* PatchFinder::ZMSSDAtPoint scalar branch, PatchFinder.cc:511-664 */
+static int zmssd(const olevel* L, const uint8_t* T, int tsum, int tsumsq, int x, int y) {
+  const int MAXSSD = 8*8*250;
+  if (!in_border(L, x, y, 4)) return MAXSSD + 1;
+  int isum = 0, isumsq = 0, cross = 0;
+  for (int r = 0; r < 8; r++) { const uint8_t* ip = L->img + (size_t)(y - 4 + r)*L->w + x - 4; for (int c = 0; c < 8; c++) { const int n = ip[c]; isum += n; isumsq += n*n; cross += n*T[8*r + c]; } }
+  const int SA = tsum, SB = isum, N = 64;
+  return ((2*SA*SB - SA*SA - SB*SB)/N + isumsq + tsumsq - 2*cross);
+}
+static int inv3(const double* A, double* I) {
+  const double c00 = A[4]*A[8] - A[5]*A[7], c01 = A[5]*A[6] - A[3]*A[8], c02 = A[3]*A[7] - A[4]*A[6];
+  const double det = A[0]*c00 + A[1]*c01 + A[2]*c02;
+  const double id = 1.0/det;
+  I[0] = c00*id; I[1] = (A[2]*A[7] - A[1]*A[8])*id; I[2] = (A[1]*A[5] - A[2]*A[4])*id;
+  I[3] = c01*id; I[4] = (A[0]*A[8] - A[2]*A[6])*id; I[5] = (A[2]*A[3] - A[0]*A[5])*id;
+  I[6] = c02*id; I[7] = (A[1]*A[6] - A[0]*A[7])*id; I[8] = (A[0]*A[4] - A[1]*A[3])*id;
+  return det != 0;
+}
+
+int orc_track_search(orc_kf* target, const orc_camera* cam, const double bfw[12], const double cfb[12], int n,
+                     const orc_td_in* in, int range, int subpix_its, int exhaustive, orc_td_out* out) {
+  /* CamFromWorld = CamFromBase * BaseFromWorld */
+  double Rcw[9], tcw[3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rcw[3*i+j] = cfb[3*i]*bfw[j] + cfb[3*i+1]*bfw[3+j] + cfb[3*i+2]*bfw[6+j];
+  m3v(cfb, bfw + 9, tcw); tcw[0] += cfb[9]; tcw[1] += cfb[10]; tcw[2] += cfb[11];
+  for (int i = 0; i < n; i++) {
+    const orc_td_in* p = &in[i]; orc_td_out* o = &out[i];
+    memset(o, 0, sizeof *o); o->search_level = -1; o->score = 8*8*250 + 1;
+    /* TrackerData::Project, TrackerData.h:102-119 */
+    double xc[3]; m3v(Rcw, p->world_pos, xc); xc[0] += tcw[0]; xc[1] += tcw[1]; xc[2] += tcw[2];
+    const int invalid = orc_cam_project(cam, xc, o->image, o->cam_derivs);
+    if (invalid) continue;
+    if (o->image[0] < 0 || o->image[1] < 0 || o->image[0] > cam->image_size[0] || o->image[1] > cam->image_size[1]) continue;
+    o->in_image = 1;
+    /* CalcJacobian, TrackerData.h:155-175 */
+    double dT[3], dP[3]; orc_cam_sphere_deriv(xc, dT, dP);
+    { double xb[3]; m3v(bfw, p->world_pos, xb); xb[0] += bfw[9]; xb[1] += bfw[10]; xb[2] += bfw[11];
+      for (int m = 0; m < 6; m++) {
+        double mb[3], mc[3]; gen_field(m, xb, mb); m3v(cfb, mb, mc);
+        const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+        o->jacobian[m] = o->cam_derivs[0]*s0 + o->cam_derivs[1]*s1; o->jacobian[6 + m] = o->cam_derivs[2]*s0 + o->cam_derivs[3]*s1;
+      } }
+    /* PatchFinder::CalcSearchLevelAndWarpMatrix, PatchFinder.cc:69-122 */
+    double mr[3], md[3]; m3v(Rcw, p->pixel_right_w, mr); m3v(Rcw, p->pixel_down_w, md);
+    const double sr0 = dT[0]*mr[0] + dT[1]*mr[1] + dT[2]*mr[2], sr1 = dP[0]*mr[0] + dP[1]*mr[1] + dP[2]*mr[2];
+    const double sd0 = dT[0]*md[0] + dT[1]*md[1] + dT[2]*md[2], sd1 = dP[0]*md[0] + dP[1]*md[1] + dP[2]*md[2];
+    double* WI = o->warp_inverse;
+    WI[0] = o->cam_derivs[0]*sr0 + o->cam_derivs[1]*sr1; WI[2] = o->cam_derivs[2]*sr0 + o->cam_derivs[3]*sr1;   /* column 0 */
+    WI[1] = o->cam_derivs[0]*sd0 + o->cam_derivs[1]*sd1; WI[3] = o->cam_derivs[2]*sd0 + o->cam_derivs[3]*sd1;   /* column 1 */
+    double dDet = WI[0]*WI[3] - WI[1]*WI[2];
+    int level = 0;
+    while (dDet > 3 && level < ORC_LEVELS - 1) { level++; dDet *= 0.25; }
+    if (dDet > 3 || dDet < 0.5 || !isfinite(dDet)) { o->template_bad = 1; continue; }
+    o->search_level = level;
+    /* MakeTemplateCoarseCont, :135-182 (cache neutralised: always refresh) */
+    const int scale = 1 << level;
+    double m2[4];
+    { const double det = WI[0]*WI[3] - WI[1]*WI[2], id = 1.0/det;                         /* opts::M2Inverse, SmallMatrixOpts.h:67-79 */
+      m2[0] = WI[3]*id*scale; m2[3] = WI[0]*id*scale; m2[2] = -WI[2]*id*scale; m2[1] = -WI[1]*id*scale; }
+    const olevel* SL = &p->source_kf->lev[p->source_level];
+    const int outside = cvd_transform8(SL, o->templ, m2, p->center_x, p->center_y, 4, 4);
+    if (outside) { o->template_bad = 1; continue; }
+    int tsum = 0, tsumsq = 0;                                                                 /* MakeTemplateSums :209-224 */
+    for (int q = 0; q < 64; q++) { tsum += o->templ[q]; tsumsq += o->templ[q]*o->templ[q]; }
+    /* FindPatchCoarse, :229-355 */
+    const int bex = p->fixed || exhaustive;
+    int its = subpix_its; if (bex) its = 10;                                                  /* Tracker.cc:1326-1331 */
+    const olevel* L = &target->lev[level];
+    int px = (int)o->image[0], py = (int)o->image[1];                                         /* CVD::ir truncation, Tracker.cc:1334 */
+    px = px/scale; py = py/scale;                                                             /* ImageRef / int */
+    const unsigned nr = ((unsigned)range + scale - 1)/scale;
+    int top = py - (int)nr, bot1 = py + (int)nr + 1, left = px - (int)nr, right = px + (int)nr;
+    o->searched = 1;
+    const int MAXSSD = 8*8*250;
+    int best = MAXSSD + 1, bx = 0, by = 0, early = 0;
+    if (top < 0) top = 0;
+    if (top >= L->h) early = 1;
+    if (bot1 <= 0) early = 1;
+    if (left < 0) left = 0;
+    if (left >= L->w) early = 1;
+    if (early) { o->found = 0; continue; }
+    if (bex) {
+      for (int y = top; y < bot1 && y < L->h; y++) for (int x = left; x <= right && x < L->w; x++) {
+        if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+        const int s = zmssd(L, o->templ, tsum, tsumsq, x, y);
+        if (s < best) { bx = x; by = y; best = s; }
+      }
+    } else {
+      const int c0 = L->lut[top], c1 = (bot1 >= L->h) ? L->ncorners : L->lut[bot1];
+      for (int c = c0; c < c1; c++) {
+        const int x = L->corners[c].x, y = L->corners[c].y;
+        if (x < left || x > right) continue;
+        if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+        const int s = zmssd(L, o->templ, tsum, tsumsq, x, y);
+        if (s < best) { bx = x; by = y; best = s; }
+      }
+    }
+    o->score = best;
+    if (!(best < MAXSSD)) { o->found = 0; continue; }
+    o->found = 1; o->coarse_x = bx; o->coarse_y = by;
+    double coarse[2] = { (bx + 0.5)*scale - 0.5, (by + 0.5)*scale - 0.5 };                   /* LevelZeroPos */
+    o->sqrt_inv_noise = 1.0/scale;
+    o->found_pos[0] = coarse[0]; o->found_pos[1] = coarse[1];
+    if (its > 0) {
+      o->did_subpix = 1;
+      /* MakeSubPixTemplate, :362-390 */
+      double jx[36], jy[36], H[9] = {0,0,0,0,0,0,0,0,0};
+      for (int x = 1; x < 7; x++) for (int y = 1; y < 7; y++) {
+        const double gx = 0.5*(o->templ[8*y + x + 1] - o->templ[8*y + x - 1]);
+        const double gy = 0.5*(o->templ[8*(y + 1) + x] - o->templ[8*(y - 1) + x]);
+        jx[(y - 1)*6 + x - 1] = gx; jy[(y - 1)*6 + x - 1] = gy;
+        const double g[3] = { gx, gy, 1.0 };
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) H[3*a + b] += g[a]*g[b];
+      }
+      double Hinv[9]; inv3(H, Hinv);
+      double sp[2] = { coarse[0], coarse[1] }, mean = 0.0;
+      int converged = 0;
+      for (int it = 0; it < its && !converged; it++) {                                         /* IterateSubPixToConvergence :392-410 */
+        /* IterateSubPix :415-472 */
+        const double cx = (sp[0] + 0.5)/scale - 0.5, cy = (sp[1] + 0.5)/scale - 0.5;           /* LevelNPos */
+        const int rx = (int)round(cx), ry = (int)round(cy);
+        if (!in_border(L, rx, ry, 5)) { converged = -1; break; }
+        const double bxs = cx - 4, bys = cy - 4;
+        const double dX = bxs - floor(bxs), dY = bys - floor(bys);
+        const float fTL = (float)((1.0 - dX)*(1.0 - dY)), fTR = (float)(dX*(1.0 - dY)), fBL = (float)((1.0 - dX)*dY), fBR = (float)(dX*dY);
+        double acc[3] = {0, 0, 0};
+        for (int y = 1; y < 7; y++) {
+          const uint8_t* q = L->img + (size_t)((int)bys + y)*L->w + (int)bxs + 1;
+          for (int x = 1; x < 7; x++) {
+            float fPixel = fTL*q[0] + fTR*q[1] + fBL*q[L->w] + fBR*q[L->w + 1];
+            q++;
+            const double d = fPixel - o->templ[8*y + x] + mean;
+            acc[0] += d*jx[(y - 1)*6 + x - 1]; acc[1] += d*jy[(y - 1)*6 + x - 1]; acc[2] += d;
+          }
+        }
+        double up[3]; m3v(Hinv, acc, up);
+        sp[0] -= up[0]*scale; sp[1] -= up[1]*scale; mean -= up[2];
+        const double u2 = up[0]*up[0] + up[1]*up[1];
+        if (u2 < 0.03*0.03) converged = 1;
+      }
+      if (converged != 1) { o->found = 0; continue; }
+      o->found_pos[0] = sp[0]; o->found_pos[1] = sp[1];
+    }
+  }
+  return 0;
+}
+
+static int cmp_d(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
+/* Tracker::CalcPoseUpdate with the Tukey estimator and TooN WLS<6> [3P-memory], Tracker.cc:1386-1512 */
+int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sin,
+                          const double* J, double override_sigma, double mu[6], double* wout, double* sigma_out) {
+  double* e2 = (double*)malloc(sizeof(double)*(n + 1)); int ne = 0;
+  double* ex = (double*)malloc(sizeof(double)*(2*(size_t)n + 2));
+  for (int i = 0; i < n; i++) {
+    if (wout) wout[i] = 0;
+    if (!found[i]) continue;
+    ex[2*i] = sin[i]*(fpos[2*i] - ipos[2*i]); ex[2*i+1] = sin[i]*(fpos[2*i+1] - ipos[2*i+1]);
+    e2[ne++] = ex[2*i]*ex[2*i] + ex[2*i+1]*ex[2*i+1];
+  }
+  for (int k = 0; k < 6; k++) mu[k] = 0;
+  if (ne == 0) { free(e2); free(ex); if (sigma_out) *sigma_out = 0; return 0; }
+  double s2;
+  if (override_sigma > 0) s2 = override_sigma; else s2 = orc_tukey_sigma_squared(e2, ne);
+  if (sigma_out) *sigma_out = s2;
+  double C[36], v[6];
+  for (int a = 0; a < 36; a++) C[a] = 0; for (int a = 0; a < 6; a++) { C[7*a] = 100.0; v[a] = 0; }   /* add_prior(100) */
+  for (int i = 0; i < n; i++) {
+    if (!found[i]) continue;
+    const double err2 = ex[2*i]*ex[2*i] + ex[2*i+1]*ex[2*i+1];
+    const double w = orc_tukey_weight(err2, s2);
+    if (wout) wout[i] = w;
+    if (w == 0.0) continue;
+    for (int r = 0; r < 2; r++) {
+      double Jr[6]; for (int k = 0; k < 6; k++) Jr[k] = sin[i]*J[12*(size_t)i + 6*r + k];
+      const double m = ex[2*i + r];
+      for (int a = 0; a < 6; a++) { v[a] += w*m*Jr[a]; for (int b = 0; b < 6; b++) C[6*a + b] += w*Jr[a]*Jr[b]; }
+    }
+  }
+  /* Cholesky solve of the 6x6 */
+  double L[36]; memcpy(L, C, sizeof L);
+  for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) { double s = L[6*i + j]; for (int k = 0; k < j; k++) s -= L[6*i + k]*L[6*j + k]; L[6*i + j] = (i == j) ? sqrt(s) : s/L[6*j + j]; }
+  for (int i = 0; i < 6; i++) { double s = v[i]; for (int k = 0; k < i; k++) s -= L[6*i + k]*mu[k]; mu[i] = s/L[6*i + i]; }
+  for (int i = 5; i >= 0; i--) { double s = mu[i]; for (int k = i + 1; k < 6; k++) s -= L[6*k + i]*mu[k]; mu[i] = s/L[6*i + i]; }
+  free(e2); free(ex);
+  return 0;
+}

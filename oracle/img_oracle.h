@@ -1,0 +1,75 @@
+/*
+ * img_oracle.h -- CPU ORACLE for the KeyFrame / Tracker image path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ba_oracle.h): never linked into or called by the product
+ * library.  Plain-C restatement of
+ *   /root/reference/src/KeyFrame.cc:145-450, ShiTomasi.cc:34-63, MiniPatch.cc:34-122,
+ *   PatchFinder.cc:69-472,511-664, include/mcptam/TrackerData.h:102-185,
+ *   Tracker.cc:1386-1512, include/mcptam/LevelHelpers.h:55-98
+ * and of the libCVD / OpenCV / TooN primitives they call (halfSample, fast_corner_detect_10,
+ * fast_corner_score_10, fast_nonmax, transform, dilate, WLS<6>), restated from their published
+ * algorithms [3P-memory] as listed in SURVEY.md Appendix A.6/A.7.
+ *
+ * PARITY UNPINNED: the reference has no tests or fixtures for this path and libCVD/OpenCV/
+ * TooN are absent, so rounding conventions of halfSample / transform / fast_nonmax are
+ * restated from memory; each is a switch or is documented where it is restated.
+ */
+#ifndef MCPTAM_IMG_ORACLE_H
+#define MCPTAM_IMG_ORACLE_H
+#include <stdint.h>
+#include "ba_oracle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_LEVELS 4
+
+typedef struct orc_kf orc_kf;
+typedef struct orc_int2 { int x, y; } orc_int2;
+
+orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb);
+void    orc_kf_destroy(orc_kf*);
+int     orc_kf_make_lite(orc_kf*, const uint8_t* img, int stride, const uint8_t* const* masks);
+int     orc_kf_level_size(orc_kf*, int level, int* w, int* h);
+const uint8_t* orc_kf_image(orc_kf*, int level);
+int     orc_kf_num_corners(orc_kf*, int level);
+const orc_int2* orc_kf_corners(orc_kf*, int level);
+const int* orc_kf_row_lut(orc_kf*, int level);
+int     orc_kf_fast_thresh(orc_kf*, int level);
+const double* orc_kf_fast_frequency(orc_kf*, int level);
+int     orc_kf_make_rest(orc_kf*, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score);
+int     orc_kf_num_candidates(orc_kf*, int level);
+int     orc_kf_get_candidates(orc_kf*, int level, orc_int2* pos, double* score, int cap);
+
+/* primitives exposed for unit checks */
+int    orc_fast10_is_corner(const uint8_t* p, int stride, int b);
+int    orc_fast10_score(const uint8_t* p, int stride, int bstart);
+int    orc_fast_ring_sad_score(const uint8_t* p, int stride, int barrier);
+double orc_shi_tomasi(const uint8_t* img, int stride, int half, int x, int y);
+
+int orc_minipatch_find(orc_kf* src, orc_kf* dst, int level, int n, const orc_int2* src_pos,
+                       const orc_int2* dst_pos, int range, orc_int2* out_pos, uint8_t* out_found, int* out_ssd);
+
+typedef struct orc_td_in {
+  double world_pos[3], pixel_right_w[3], pixel_down_w[3];
+  const orc_kf* source_kf;
+  int source_level, center_x, center_y, fixed;
+} orc_td_in;
+typedef struct orc_td_out {
+  double image[2], cam_derivs[4], jacobian[12], found_pos[2], sqrt_inv_noise, warp_inverse[4];
+  int in_image, search_level, template_bad, searched, found, did_subpix, coarse_x, coarse_y, score;
+  uint8_t templ[64];
+} orc_td_out;
+
+int orc_track_search(orc_kf* target, const orc_camera* cam, const double base_from_world[12],
+                     const double cam_from_base[12], int n, const orc_td_in* in, int range,
+                     int subpix_its, int exhaustive, orc_td_out* out);
+int orc_track_pose_update(int n, const uint8_t* found, const double* found_pos, const double* image_pos,
+                          const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
+                          double mu[6], double* weights_out, double* sigma_sq_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

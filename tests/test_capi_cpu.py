@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libmcptam_hip.so does not export " + n
     assert set(chain_bundle.BA_SYMBOLS) == set(names)
+    from mcptam_amd import keyframe
+    img_names = [n for n in _declared("mcp_img.h")]
+    assert len(img_names) >= 16
+    for n in img_names:
+        assert hasattr(L, n), "libmcptam_hip.so does not export " + n
+    assert set(keyframe.IMG_SYMBOLS) == set(img_names)
 
 
 def test_create_fails_loudly_without_gpu():

@@ -1,0 +1,174 @@
+"""Parity of the HIP KeyFrame / Tracker image path (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from mcptam_amd import synth_img
+    return synth_img.make_tracking_scene()
+
+
+def _pair(w, h, **kw):
+    from mcptam_amd.keyframe import KeyFrame
+    from oracle import OracleKeyFrame
+    return KeyFrame(w, h, **kw), OracleKeyFrame(w, h, **kw)
+
+
+def _assert_lite_equal(g, o):
+    for l in range(4):
+        assert g.LevelSize(l) == o.LevelSize(l)
+        assert np.array_equal(g.Image(l), o.Image(l)), "pyramid level %d differs" % l
+        assert g.FastThresh(l) == o.FastThresh(l)
+        assert np.array_equal(g.FastFrequency(l), o.FastFrequency(l))
+        cg, co = g.Corners(l), o.Corners(l)
+        assert cg.shape == co.shape and np.array_equal(cg, co), "corner list/order differs at level %d" % l
+        assert np.array_equal(g.RowLUT(l), o.RowLUT(l))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(pavgb=True), dict(adaptive=False), dict(glare=True)])
+def test_make_keyframe_lite_bit_exact(gpu_required, scene, kw):
+    g, o = _pair(640, 480, **kw)
+    img = scene["imgA"].copy()
+    if kw.get("glare"):
+        img[100:140, 200:260] = 255          # a saturated blob to mask
+    g.MakeKeyFrame_Lite(img)
+    o.MakeKeyFrame_Lite(img)
+    _assert_lite_equal(g, o)
+    assert len(g.Corners(0)) > 500
+
+
+def test_make_keyframe_lite_with_masks_and_odd_stride(gpu_required, scene):
+    g, o = _pair(640, 480)
+    rng = np.random.default_rng(5)
+    masks = []
+    for l in range(4):
+        m = np.full((480 >> l, 640 >> l), 255, dtype=np.uint8)
+        m[: (100 >> l), :] = 0
+        m[rng.integers(0, 480 >> l, 50), rng.integers(0, 640 >> l, 50)] = 254     # "< 255" is masked out too
+        masks.append(m if l != 2 else None)
+    big = np.zeros((480, 700), dtype=np.uint8)
+    big[:, :640] = scene["imgB"]
+    view = big[:, :640]                      # row stride 700
+    g.MakeKeyFrame_Lite(np.ascontiguousarray(view), masks)
+    o.MakeKeyFrame_Lite(np.ascontiguousarray(view), masks)
+    _assert_lite_equal(g, o)
+    assert (g.Corners(0)[:, 1] >= 100).all()
+
+
+def test_flat_and_tiny_inputs(gpu_required):
+    g, o = _pair(64, 64)
+    img = np.full((64, 64), 77, dtype=np.uint8)
+    g.MakeKeyFrame_Lite(img)
+    o.MakeKeyFrame_Lite(img)
+    _assert_lite_equal(g, o)
+    assert len(g.Corners(0)) == 0
+
+
+def test_c5_size_frame(gpu_required):
+    """BASELINE config c5 frame size (1280x960)."""
+    from mcptam_amd import synth_img
+    sc = synth_img.make_tracking_scene(size=(1280, 960))
+    g, o = _pair(1280, 960)
+    g.MakeKeyFrame_Lite(sc["imgA"])
+    o.MakeKeyFrame_Lite(sc["imgA"])
+    _assert_lite_equal(g, o)
+
+
+@pytest.mark.parametrize("use_shi,use_percent,nm", [(False, True, 0), (True, True, 0), (True, False, 0), (False, True, 1)])
+def test_make_keyframe_rest_candidates(gpu_required, scene, use_shi, use_percent, nm):
+    g, o = _pair(640, 480)
+    g.MakeKeyFrame_Lite(scene["imgA"])
+    o.MakeKeyFrame_Lite(scene["imgA"])
+    g.MakeKeyFrame_Rest(use_shi, use_percent, 0.8, 70.0, nm)
+    o.MakeKeyFrame_Rest(use_shi, use_percent, 0.8, 70.0, nm)
+    for l in range(4):
+        pg, sg = g.Candidates(l)
+        po, so = o.Candidates(l)
+        assert np.array_equal(pg, po), "candidate set/order differs at level %d" % l
+        if use_shi:
+            assert np.allclose(sg, so, rtol=1e-12, atol=0)
+        else:
+            assert np.array_equal(sg, so)
+    assert len(g.Candidates(0)[0]) > 100
+
+
+def test_minipatch_find(gpu_required, scene):
+    from mcptam_amd.keyframe import minipatch_find
+    from oracle import oracle_minipatch_find
+    g, o = _pair(640, 480)
+    g2, o2 = _pair(640, 480)
+    g.MakeKeyFrame_Lite(scene["imgA"]); o.MakeKeyFrame_Lite(scene["imgA"])
+    g2.MakeKeyFrame_Lite(scene["imgB"]); o2.MakeKeyFrame_Lite(scene["imgB"])
+    for level, rng in ((0, 10), (1, 20), (2, 5)):
+        pos = o.Corners(level)[::7][:300]
+        pos = np.concatenate([pos, [[1, 1], [639 >> level, 479 >> level]]]).astype(np.int32)     # border cases
+        pg, fg, sg = minipatch_find(g, g2, level, pos, pos, rng)
+        po, fo, so = oracle_minipatch_find(o, o2, level, pos, pos, rng)
+        assert np.array_equal(fg, fo) and np.array_equal(pg, po) and np.array_equal(sg, so)
+    assert fg.sum() > 0
+
+
+def _points(scene, g, o):
+    from mcptam_amd import synth_img
+    g.MakeKeyFrame_Rest()
+    o.MakeKeyFrame_Rest()
+    return synth_img.make_map_points(scene["cam"], g, o, scene["poseA"], scene["depth"])
+
+
+INT_FIELDS = ("in_image", "search_level", "template_bad", "searched", "found", "did_subpix", "coarse_x", "coarse_y", "score")
+
+
+@pytest.mark.parametrize("rng,its,exh", [(10, 8, False), (30, 0, False), (5, 3, True)])
+def test_track_search_matches_oracle(gpu_required, scene, rng, its, exh):
+    from mcptam_amd.keyframe import track_search
+    from oracle import oracle_track_search
+    gA, oA = _pair(640, 480)
+    gB, oB = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    gB.MakeKeyFrame_Lite(scene["imgB"]); oB.MakeKeyFrame_Lite(scene["imgB"])
+    pts = _points(scene, gA, oA)
+    if exh:
+        pts = pts[:120]
+    pts[3]["fixed"] = 1                                     # calibration-style point: exhaustive + 10 sub-pixel iterations
+    pts.append(dict(pts[0], world_pos=np.array([0.0, 0.0, -5.0])))     # behind the camera: not in image
+    I = (np.eye(3), np.zeros(3))
+    cfb = (np.eye(3), np.array([0.02, 0.0, 0.0]))
+    RB, tB = scene["poseB"]
+    bfw = (RB, tB - cfb[1])
+    og = track_search(gB, scene["cam"], bfw, cfb, pts, rng, its, exh)
+    oo = oracle_track_search(oB, scene["cam"], bfw, cfb, pts, rng, its, exh)
+    for f in INT_FIELDS:
+        assert np.array_equal(og[f], oo[f]), f
+    assert np.array_equal(og["templ"], oo["templ"])
+    for f in ("image", "cam_derivs", "jacobian", "warp_inverse", "sqrt_inv_noise"):
+        assert np.allclose(og[f], oo[f], rtol=1e-11, atol=1e-12), f
+    assert np.allclose(og["found_pos"], oo["found_pos"], rtol=0, atol=1e-9)
+    assert og["found"].sum() > 0.5 * len(pts) or exh
+    assert og["in_image"][-1] == 0
+
+
+def test_pose_update_matches_oracle(gpu_required, scene):
+    from mcptam_amd.keyframe import track_pose_update, track_search
+    from oracle import oracle_track_pose_update
+    gA, oA = _pair(640, 480)
+    gB, oB = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    gB.MakeKeyFrame_Lite(scene["imgB"])
+    pts = _points(scene, gA, oA)
+    I = (np.eye(3), np.zeros(3))
+    RB, tB = scene["poseB"]
+    out = track_search(gB, scene["cam"], (RB, tB + np.array([0.01, 0.0, 0.0])), I, pts, 10, 8)
+    for override in (-1.0, 16.0):
+        mg, wg, sg = track_pose_update(out["found"], out["found_pos"], out["image"], out["sqrt_inv_noise"], out["jacobian"], override)
+        mo, wo, so = oracle_track_pose_update(out["found"], out["found_pos"], out["image"], out["sqrt_inv_noise"], out["jacobian"], override)
+        assert abs(sg - so) <= 1e-13 * so
+        assert np.array_equal(wg == 0, wo == 0)             # same outlier set
+        assert np.allclose(wg, wo, rtol=1e-12, atol=0)
+        assert np.allclose(mg, mo, rtol=1e-9, atol=1e-13)
+    assert abs(mg[0] + 0.01) < 2e-3                          # the update undoes the 1 cm perturbation
+    none = np.zeros(len(pts), dtype=np.uint8)
+    mg, _, _ = track_pose_update(none, out["found_pos"], out["image"], out["sqrt_inv_noise"], out["jacobian"])
+    assert np.all(mg == 0)                                   # no measurements: zero update (Tracker.cc:1421-1422)
