@@ -274,6 +274,24 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
                    true_base_R=tR, true_base_t=tt, true_world=world)
 
 
+def merge_shards(shards):
+    """One Problem holding the points and measurements of all shards (same trajectory): the single-rank
+    equivalent of a sharded multi-GPU run."""
+    a = shards[0]
+    off, pt_x, pt_src, pt_fixed, ms_mkf, ms_cam, ms_pt, ms_uv, ms_level, tw = 0, [], [], [], [], [], [], [], [], []
+    for s in shards:
+        assert np.array_equal(s.base_R, a.base_R) and np.array_equal(s.base_t, a.base_t)
+        pt_x.append(s.pt_x); pt_src.append(s.pt_src); pt_fixed.append(s.pt_fixed)
+        ms_mkf.append(s.ms_mkf); ms_cam.append(s.ms_cam); ms_pt.append(s.ms_pt + off)
+        ms_uv.append(s.ms_uv); ms_level.append(s.ms_level); tw.append(s.true_world)
+        off += s.n_points
+    return Problem(cams=a.cams, mode=a.mode, n_mkf=a.n_mkf, base_R=a.base_R.copy(), base_t=a.base_t.copy(), base_fixed=a.base_fixed,
+                   cam_R=a.cam_R, cam_t=a.cam_t, pt_x=np.concatenate(pt_x), pt_src=np.concatenate(pt_src),
+                   pt_fixed=np.concatenate(pt_fixed), ms_mkf=np.concatenate(ms_mkf), ms_cam=np.concatenate(ms_cam),
+                   ms_pt=np.concatenate(ms_pt), ms_uv=np.concatenate(ms_uv), ms_level=np.concatenate(ms_level),
+                   true_base_R=a.true_base_R, true_base_t=a.true_base_t, true_world=np.concatenate(tw))
+
+
 # the BASELINE.json configurations (SURVEY.md 8 notation)
 CONFIGS = {
     "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3, n_fixed_mkf=2),  # 2 fixed KFs pin the monocular scale gauge
@@ -285,6 +303,7 @@ CONFIGS = {
 
 
 def make_config(name, **over):
+    """BASELINE configuration by name; keyword overrides go to make_problem."""
     kw = dict(CONFIGS[name])
     kw.update(over)
     return make_problem(**kw)

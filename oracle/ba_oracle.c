@@ -517,6 +517,7 @@ int orc_ba_jacobian(orc_ba* h, int m, double* J_obs, double* J_src, double* J_pt
   if (!h->prepared) orc_ba_prepare(h);
   double Jo[ORC_MAX_CHAIN][12], Js[ORC_MAX_CHAIN][12], Jp[6];
   memset(Jo, 0, sizeof Jo); memset(Js, 0, sizeof Js); memset(Jp, 0, sizeof Jp);
+  update_chains(h); compute_error(h, &h->meas[m]);      /* linearizeOplus uses _m2CamDerivs cached by computeError */
   int mask = linearize(h, &h->meas[m], Jo, Js, Jp);
   memcpy(J_obs, Jo, sizeof Jo); memcpy(J_src, Js, sizeof Js); memcpy(J_pt, Jp, sizeof Jp);
   return mask;

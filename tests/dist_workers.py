@@ -1,0 +1,69 @@
+"""Worker functions for the multi-process tests (importable by torch.multiprocessing.spawn)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return dist
+
+
+def hook_on_host_memory(rank, world, port, outdir):
+    """GlooAllReduce(host=True): the all-reduce hook contract on plain host buffers."""
+    dist = _init(rank, world, port)
+    from mcptam_amd.dist import GlooAllReduce
+    h = GlooAllReduce(host=True)
+    a = np.arange(1000, dtype=np.float64) * (rank + 1)
+    h(a.ctypes.data, a.size, 0)
+    b = np.array([float(rank == r) for r in range(world)])
+    h(b.ctypes.data, b.size, 0)
+    np.savez(os.path.join(outdir, "host_%d.npz" % rank), a=a, b=b, calls=h.calls)
+    dist.destroy_process_group()
+
+
+def sharded_solve_on_one_gpu(rank, world, port, outdir, cfg, iters):
+    """Every rank owns one shard of the map; poses replicated; reduced system summed through the hook."""
+    dist = _init(rank, world, port)
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import GlooAllReduce
+    from helpers import collect
+    p = synth.make_config(shard=rank, **cfg)
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, device=0)
+    ids = p.populate(b)
+    hook = GlooAllReduce(host=False)
+    b.SetAllReduce(hook, rank, world)
+    rc = b.Compute(iters)
+    R, t, X = collect(b, ids)
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in b.IterLogs()])
+    np.savez(os.path.join(outdir, "shard_%d.npz" % rank), rc=rc, R=R, t=t, X=X, logs=logs, sigma_sq=b.GetSigmaSquared(),
+             mean_chi2=b.GetMeanChiSquared(), calls=hook.calls, n_out=len(b.GetOutlierMeasurements()))
+    b.close()
+    dist.destroy_process_group()
+
+
+def rccl_hook_single_rank(rank, world, port, outdir):
+    """RcclAllReduce on a device buffer with a 1-rank nccl (= RCCL) group: staging copies, stream sync, collective."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from mcptam_amd.dist import RcclAllReduce
+    h = RcclAllReduce(torch.device("cuda", 0))
+    t = torch.arange(5000, dtype=torch.float64, device="cuda") * 0.5
+    h(t.data_ptr(), t.numel(), 0)
+    h(t.data_ptr() + 8 * 100, 50, 0)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, "rccl.npz"), t=t.cpu().numpy(), calls=h.calls)
+    dist.destroy_process_group()

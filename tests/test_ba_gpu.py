@@ -227,3 +227,46 @@ def test_point_seen_from_many_poses_uses_generic_path(gpu_required):
     gpu = run_bundle(_gpu(p.cams), p, 8)
     ref = run_bundle(_orc(p.cams), p, 8)
     compare_runs(gpu, ref)
+
+
+def test_two_rank_sharded_solve_equals_merged_single_rank(gpu_required):
+    """points/measurements sharded over ranks, poses replicated, reduced pose system summed with
+    the all-reduce hook.  Two processes share this GPU and reduce through gloo; the result must equal the
+    single-rank solve of the merged map."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    from mcptam_amd import synth
+    cfg = dict(name="c2", n_mkf=16, n_points=1200)
+    iters = 6
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.sharded_solve_on_one_gpu, args=(2, port, d, cfg, iters), nprocs=2, join=True)
+        r0, r1 = np.load(os.path.join(d, "shard_0.npz")), np.load(os.path.join(d, "shard_1.npz"))
+    merged = synth.merge_shards([synth.make_config(shard=0, **cfg), synth.make_config(shard=1, **cfg)])
+    ref = run_bundle(_gpu(merged.cams), merged, iters)
+    assert int(r0["rc"]) == int(r1["rc"]) == ref["rc"]
+    assert np.array_equal(r0["R"], r1["R"]) and np.array_equal(r0["t"], r1["t"])        # replicas stay bit-identical
+    assert rel_err(r0["R"], ref["R"]) < 1e-8 and rel_err(r0["t"], ref["t"]) < 1e-8
+    n0 = r0["X"].shape[0]
+    assert rel_err(r0["X"], ref["X"][:n0]) < 1e-8 and rel_err(r1["X"], ref["X"][n0:]) < 1e-8
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in ref["logs"]])
+    assert np.allclose(r0["logs"], logs, rtol=1e-9)
+    assert abs(float(r0["sigma_sq"]) - ref["sigma_sq"]) <= 1e-12 * ref["sigma_sq"]        # global median is exact
+    assert int(r0["n_out"]) + int(r1["n_out"]) == len(ref["outliers"])
+
+
+def test_rccl_hook_on_device_buffer(gpu_required):
+    """The production all-reduce hook (torch.distributed backend nccl == RCCL) on a 1-rank group."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.rccl_hook_single_rank, args=(1, port, d), nprocs=1, join=True)
+        r = np.load(os.path.join(d, "rccl.npz"))
+    assert np.array_equal(r["t"], np.arange(5000) * 0.5) and int(r["calls"]) == 2
