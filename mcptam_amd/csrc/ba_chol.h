@@ -14,6 +14,8 @@
 // A non-positive pivot (CHOLMOD failure in the reference == rejected LM trial) raises *fail.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
 
 namespace mcp {
 
@@ -27,16 +29,23 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// load a 32x32 tile (rows r0.., cols c0..) into LDS, zero outside [nrows) x [ncols)
-__device__ inline void chol_load_tile(const double* __restrict__ A, int ld, int nrows, int ncols, int r0, int c0,
-                                      double (*T)[CH_NB + 1]) {
+// 32x32 tile (rows r0.., cols c0..) -> 16 registers per lane (zero outside [nrows) x [ncols)); issuing the
+// global loads of ALL tiles of a step before the first LDS write keeps them in flight together (one memory
+// round trip per step instead of one per tile)
+__device__ inline void chol_load_tile_regs(const double* __restrict__ A, int ld, int nrows, int ncols, int r0, int c0, double* v) {
   const int lane = threadIdx.x;
   const int c = lane & 31, rb = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = 2*i + rb;
-    T[r][c] = (r0 + r < nrows && c0 + c < ncols) ? A[(size_t)(r0 + r)*ld + c0 + c] : 0.0;
+    v[i] = (r0 + r < nrows && c0 + c < ncols) ? A[(size_t)(r0 + r)*ld + c0 + c] : 0.0;
   }
+}
+__device__ inline void chol_regs_to_lds(const double* v, double (*T)[CH_NB + 1]) {
+  const int lane = threadIdx.x;
+  const int c = lane & 31, rb = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[2*i + rb][c] = v[i];
 }
 
 // acc(2x2 MFMA tiles, C/D layout) -= Pi * Pj^T over K = 32
@@ -74,9 +83,10 @@ __device__ inline void chol_acc_to_lds(double (*T)[CH_NB + 1], const chol_d4 acc
 }
 
 __global__ void __launch_bounds__(64)
-k_chol_step(double* __restrict__ S, int n, int nrows, int k, int* __restrict__ fail) {
-  const int ti = k + blockIdx.x, tj = k + blockIdx.y;
-  if (tj > ti) return;
+k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail) {
+  // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
+  const int packed = tiles[blockIdx.x];
+  const int ti = packed >> 16, tj = packed & 0xffff;
   __shared__ double Ta[CH_NB][CH_NB + 1];
   __shared__ double Tb[CH_NB][CH_NB + 1];
   __shared__ double Tc[CH_NB][CH_NB + 1];
@@ -86,14 +96,20 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, int* __restrict__ f
   const int r0 = ti*CH_NB, c0 = tj*CH_NB, k0 = k*CH_NB, p0 = (k - 1)*CH_NB;
   const bool panel = (tj == k), offdiag = (ti != k);
   // ---- all global loads up front: own tile, the two tiles of panel k-1, and (block column k) the diagonal tile
-  chol_load_tile(S, n, nrows, n, r0, c0, Tc);
-  if (k > 0) {
-    chol_load_tile(S, n, nrows, n, r0, p0, Ta);
-    chol_load_tile(S, n, nrows, n, c0, p0, Tb);
-  }
-  if (panel && offdiag) {
-    chol_load_tile(S, n, nrows, n, k0, k0, Td);
-    if (k > 0) chol_load_tile(S, n, nrows, n, k0, p0, Te);
+  {
+    double vc[16], va[16], vb[16], vd[16], ve[16];
+    chol_load_tile_regs(S, n, nrows, n, r0, c0, vc);
+    if (k > 0) {
+      chol_load_tile_regs(S, n, nrows, n, r0, p0, va);
+      chol_load_tile_regs(S, n, nrows, n, c0, p0, vb);
+    }
+    if (panel && offdiag) {
+      chol_load_tile_regs(S, n, nrows, n, k0, k0, vd);
+      if (k > 0) chol_load_tile_regs(S, n, nrows, n, k0, p0, ve);
+    }
+    chol_regs_to_lds(vc, Tc);
+    if (k > 0) { chol_regs_to_lds(va, Ta); chol_regs_to_lds(vb, Tb); }
+    if (panel && offdiag) { chol_regs_to_lds(vd, Td); if (k > 0) chol_regs_to_lds(ve, Te); }
   }
   __syncthreads();
   chol_d4 acc[2][2];
@@ -168,7 +184,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, int* __restrict__ f
 constexpr int CH_BACK_THREADS = 512;
 constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
 __global__ void __launch_bounds__(CH_BACK_THREADS)
-k_chol_back(const double* __restrict__ S, int n, double* __restrict__ xout) {
+k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   const int t = threadIdx.x;
   const double* y = S + (size_t)n*n;
@@ -197,7 +213,10 @@ k_chol_back(const double* __restrict__ S, int n, double* __restrict__ xout) {
       if (t < nbe) xs[k0 + t] = yv;
     }
     __syncthreads();
-    for (int c = t; c < k0; c += CH_BACK_THREADS) {
+    // y[c] -= sum_r L[k0+r][c] x[k0+r] over the structurally non-zero tiles of block row kb
+    const int l0 = row_start[kb], l1 = row_start[kb + 1];
+    for (int q = t; q < (l1 - l0)*CH_NB; q += CH_BACK_THREADS) {
+      const int c = row_tiles[l0 + q/CH_NB]*CH_NB + (q & (CH_NB - 1));
       double s = 0.0;
 #pragma unroll 8
       for (int r = 0; r < nbe; ++r) s += S[(size_t)(k0 + r)*n + c]*xs[k0 + r];
@@ -208,16 +227,69 @@ k_chol_back(const double* __restrict__ S, int n, double* __restrict__ xout) {
   for (int i = t; i < n; i += CH_BACK_THREADS) xout[i] = xs[i];
 }
 
+// Block-sparse execution plan (the job CHOLMOD's symbolic analysis does for the reference): which 32x32 tiles
+// of the lower triangle are structurally non-zero after fill-in, in the given (natural) pose order.
+struct CholPlan {
+  int n = 0, ntc = 0, ntr = 0;
+  std::vector<int> step_start, step_tiles;     // per step k: tiles to process, block column k first
+  std::vector<int> row_start, row_tiles;       // per block row: non-zero tile columns left of the diagonal
+  int* d_step_tiles = nullptr; int* d_row_start = nullptr; int* d_row_tiles = nullptr;
+  ~CholPlan() { release(); }
+  void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
+                   d_step_tiles = d_row_start = d_row_tiles = nullptr; }
+  // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
+  int build(int n_, const std::vector<unsigned char>& pattern) {
+    release();
+    n = n_; ntc = (n + CH_NB - 1)/CH_NB; ntr = (n + 1 + CH_NB - 1)/CH_NB;
+    std::vector<unsigned char> P((size_t)ntr*ntc, 0);
+    for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) P[(size_t)i*ntc + j] = pattern.empty() ? 1 : pattern[(size_t)i*ntc + j];
+    for (int i = 0; i < ntc; ++i) P[(size_t)i*ntc + i] = 1;
+    const int rhs_tile = n/CH_NB;                                  // the row tile holding the right-hand side: dense
+    for (int j = 0; j < ntc; ++j) P[(size_t)rhs_tile*ntc + j] = 1;
+    for (int k = 0; k < ntc; ++k) {                                // symbolic fill-in
+      std::vector<int> rows;
+      for (int i = k + 1; i < ntr; ++i) if (P[(size_t)i*ntc + k]) rows.push_back(i);
+      for (int a : rows) for (int b : rows) if (b <= a && b < ntc) P[(size_t)a*ntc + b] = 1;
+    }
+    step_start.assign(ntc + 1, 0); step_tiles.clear();
+    for (int k = 0; k < ntc; ++k) {
+      step_start[k] = (int)step_tiles.size();
+      for (int i = k; i < ntr; ++i) if (P[(size_t)i*ntc + k]) step_tiles.push_back((i << 16) | k);       // block column k (critical path) first
+      if (k > 0) {
+        std::vector<int> rows;
+        for (int i = k; i < ntr; ++i) if (P[(size_t)i*ntc + k - 1]) rows.push_back(i);
+        for (int a : rows) for (int b : rows) if (b <= a && b < ntc && b > k) step_tiles.push_back((a << 16) | b);
+        // tiles of block column k that panel k-1 does not touch were emitted above already (they only need the panel step)
+      }
+    }
+    step_start[ntc] = (int)step_tiles.size();
+    row_start.assign(ntc + 1, 0); row_tiles.clear();
+    for (int i = 0; i < ntc; ++i) { row_start[i] = (int)row_tiles.size(); for (int j = 0; j < i; ++j) if (P[(size_t)i*ntc + j]) row_tiles.push_back(j); }
+    row_start[ntc] = (int)row_tiles.size();
+    if (hipMalloc((void**)&d_step_tiles, sizeof(int)*std::max<size_t>(step_tiles.size(), 1)) != hipSuccess ||
+        hipMalloc((void**)&d_row_start, sizeof(int)*row_start.size()) != hipSuccess ||
+        hipMalloc((void**)&d_row_tiles, sizeof(int)*std::max<size_t>(row_tiles.size(), 1)) != hipSuccess) return -1;
+    if (!step_tiles.empty() && hipMemcpy(d_step_tiles, step_tiles.data(), sizeof(int)*step_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(d_row_start, row_start.data(), sizeof(int)*row_start.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (!row_tiles.empty() && hipMemcpy(d_row_tiles, row_tiles.data(), sizeof(int)*row_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+  }
+  size_t tile_updates() const { return step_tiles.size(); }
+};
+
 // factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
-inline void chol_factor(hipStream_t st, double* S, int n, int* fail) {
-  const int nrows = n + 1;
-  const int ntc = (n + CH_NB - 1)/CH_NB, ntr = (nrows + CH_NB - 1)/CH_NB;
-  for (int k = 0; k < ntc; ++k)
-    hipLaunchKernelGGL(k_chol_step, dim3(ntr - k, ntc - k), dim3(64), 0, st, S, n, nrows, k, fail);
+inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail) {
+  const int n = plan.n, nrows = n + 1;
+  for (int k = 0; k < plan.ntc; ++k) {
+    const int cnt = plan.step_start[k + 1] - plan.step_start[k];
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt), dim3(64), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail);
+  }
 }
 // row n: y -> x = L^-T y
-inline void chol_back(hipStream_t st, double* S, int n) {
-  hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n, S + (size_t)n*n);
+inline void chol_back(hipStream_t st, const CholPlan& plan, double* S) {
+  const int n = plan.n;
+  hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
+                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n);
 }
 
 }  // namespace mcp

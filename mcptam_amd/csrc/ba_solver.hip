@@ -142,6 +142,7 @@ struct mcp_ba {
   std::vector<Ev> evs; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
 
   DevProblem P;
+  CholPlan plan;                   // block-sparse structure of the reduced system
 
   ~mcp_ba() {
     if (h_res) (void)hipHostFree(h_res);
@@ -351,6 +352,21 @@ int mcp_ba::prepare() {
     g_sp0.push_back(nsp);
   }
   ngroup = (int)g_sp0.size() - 1;
+  // ---- tile occupancy of the reduced pose system: poses a, b interact iff some point touches both
+  if (np > 0) {
+    const int ntc = (np + CH_NB - 1)/CH_NB;
+    std::vector<unsigned char> pat((size_t)ntc*ntc, 0);
+    if (hook && world > 1) std::fill(pat.begin(), pat.end(), 1);         // other ranks' points are unknown here: dense
+    else for (int sp = 0; sp < nsp; ++sp) {
+      const std::vector<int>& q = sp_poses[sp];
+      for (int a : q) for (int b : q) {
+        if (a < b) continue;
+        const int ra0 = (6*a)/CH_NB, ra1 = (6*a + 5)/CH_NB, rb0 = (6*b)/CH_NB, rb1 = (6*b + 5)/CH_NB;
+        for (int ra = ra0; ra <= ra1; ++ra) for (int rb = rb0; rb <= rb1; ++rb) if (ra >= rb) pat[(size_t)ra*ntc + rb] = 1;
+      }
+    }
+    if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
+  }
   // local pose indices of slots and incidences
   std::vector<unsigned char> slot_lp(nslot + 1, 0), inc_lp(ninc + 1, 0);
   for (int gi = 0; gi < ngroup; ++gi) {
@@ -517,8 +533,8 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
   if (np && allreduce(d_red.p, n2 + 2*(size_t)np)) return -1;
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
   if (np) {
-    tic(ST_CHOL); chol_factor(st, S(), np, d_fail.p); toc();
-    tic(ST_SOLVE); chol_back(st, S(), np); toc();
+    tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p); toc();
+    tic(ST_SOLVE); chol_back(st, plan, S()); toc();
   }
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 3);
@@ -950,8 +966,10 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
   HIPCK(hipMemcpy(d.p, A, (size_t)n*n*8, hipMemcpyHostToDevice));
   HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
   HIPCK(hipMemset(f.p, 0, 16));
-  chol_factor(nullptr, d.p, n, f.p);
-  chol_back(nullptr, d.p, n);
+  CholPlan plan;
+  if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_dense_spd_solve: plan allocation failed"); return -1; }
+  chol_factor(nullptr, plan, d.p, f.p);
+  chol_back(nullptr, plan, d.p);
   int fl = 0;
   HIPCK(hipMemcpy(&fl, f.p, 4, hipMemcpyDeviceToHost));
   HIPCK(hipMemcpy(x, d.p + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
