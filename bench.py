@@ -23,6 +23,27 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
 
+def load_traffic():
+    """Per-kernel HBM traffic per launch from the committed PMC pass (scripts/collect_traffic.sh):
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_per_launch.json")
+    if not os.path.exists(path):
+        return {}
+    raw = json.load(open(path))
+    return {k.replace("void ", ""): (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 for k, v in raw.items()}
+
+
+STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ; count -1 = number of 32-column Cholesky steps
+    "linearize": [("mcp::k_linearize_group", 1), ("__amd_rocclr_fillBufferAligned", 1)],
+    "schur": [("mcp::k_schur_init", 1), ("mcp::k_schur_group", 1)],
+    "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
+    "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
+    "select": [("mcp::k_select_pass", 6), ("mcp::k_select_final", 1), ("mcp::k_sigma_from_median", 1)],
+    "cholesky": [("mcp::k_chol_step", -1)],
+    "tri_solve": [("mcp::k_chol_back", 1)],
+}
+
+
 def stage_rooflines(tm, M, N, np_, n_lin, n_trials):
     """Algorithmic bytes / flops per launch group (meas record 36 B, point 24 B,
     V+g 72 B, chi2 8 B) over the measured per-launch duration of each stage."""
@@ -44,6 +65,17 @@ def stage_rooflines(tm, M, N, np_, n_lin, n_trials):
             ach = flops / dur / 1e12
             out[name] = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
                              traffic=None, avg_ms=tm[key] / n_trials, launches=n_trials, flops_per_launch=flops)
+    traffic = load_traffic()
+    steps = (np_ + 31) // 32
+    for name, r in out.items():
+        t = 0.0
+        ok = bool(traffic)
+        for kname, cnt in STAGE_KERNELS.get(name, []):
+            if kname not in traffic:
+                ok = False
+                break
+            t += traffic[kname] * (steps if cnt < 0 else cnt)
+        r["traffic"] = t if ok else None
     return out
 
 
@@ -137,7 +169,8 @@ def main():
             r = dict(dom[1])
             r["kernel"] = dom[0]
             result["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms")}
-            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches")} for k, v in roofs.items()}}
+            result["roofline"]["traffic_source"] = "profiles/r01/pmc_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = (2*FETCH + WRITE)*1024 per launch, summed over the launches of the stage)"
+            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic")} for k, v in roofs.items()}}
     # CPU baseline: the oracle (a scalar single-thread port of the reference algorithm) on the same map
     if rank == 0 and world == 1 and args.cpu_iters > 0:
         from oracle import OracleBundle

@@ -58,7 +58,10 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   const int sp = P.g_sp0[grp] + lane;
   const bool valid = sp < P.g_sp0[grp + 1] && !P.sp_big[sp];
   // register accumulators of the first source-chain slot (the pose the point is expressed in)
-  double Uss[21], bs[6];
+  double Uss[21], bs[6], Wss[18];
+  int wss_inc = -1;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) Wss[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 21; ++i) Uss[i] = 0.0;
 #pragma unroll
@@ -154,17 +157,25 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
             for (int c = 0; c <= r; ++c) lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
         }
         if (lpt >= 0) {
-          double* Wb = W + 18*(size_t)P.slot_inc[s0 + ia];
-          if (P.slot_first[s0 + ia]) {
+          if (bit_a == 4) {          // the source pose's block collects one term per measurement: keep it in registers
+            wss_inc = P.slot_inc[s0 + ia];
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-              for (int c = 0; c < 3; ++c) Wb[3*r + c] = w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+              for (int c = 0; c < 3; ++c) Wss[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
           } else {
+            double* Wb = W + 18*(size_t)P.slot_inc[s0 + ia];
+            if (P.slot_first[s0 + ia]) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+              for (int r = 0; r < 6; ++r)
 #pragma unroll
-              for (int c = 0; c < 3; ++c) Wb[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+                for (int c = 0; c < 3; ++c) Wb[3*r + c] = w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Wb[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+            }
           }
         }
         int ib = ia + 1;
@@ -180,6 +191,16 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
       }
     }
     if (lpt >= 0) {
+      if (wss_inc >= 0) {
+        double* Wb = W + 18*(size_t)wss_inc;
+        if (P.inc_mixed[wss_inc]) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wb[k] += Wss[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wb[k] = Wss[k];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) V[6*(size_t)lpt + k] = Vp[k];
 #pragma unroll

@@ -58,6 +58,7 @@ struct DevProblem {
   const unsigned char* slot_lp;   // [nslot] local pose index of the slot inside its group
   const unsigned char* slot_first;// [nslot] 1: first contribution to its incidence (store), 0: accumulate
   const unsigned char* inc_lp;    // [ninc] local pose index of the incidence
+  const unsigned char* inc_mixed; // [ninc] 1: block fed both from registers (first source link) and through memory
 };
 constexpr int GRP_LMAX = 16;      // poses per group (6*16 = 96 local dof)
 constexpr int GRP_PTS = 64;       // points per group (one lane each in k_linearize_group)

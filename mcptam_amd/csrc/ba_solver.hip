@@ -110,7 +110,7 @@ struct mcp_ba {
   DevBuf<double> d_m_u, d_m_v, d_m_omega;
   DevBuf<int> d_slot_start, d_slot_unk, d_slot_inc, d_l_i0, d_l_i1, d_inc_unk, d_fl_point;
   DevBuf<int> d_sp_pt, d_sp_m, d_sp_i, d_m_sp, d_l_sp, d_g_sp0, d_g_pose;
-  DevBuf<unsigned char> d_sp_big, d_slot_lp, d_slot_first, d_inc_lp;
+  DevBuf<unsigned char> d_sp_big, d_slot_lp, d_slot_first, d_inc_lp, d_inc_mixed;
   int nsp = 0, ngroup = 0, nbig = 0;
   // state (double buffered: cur / trial)
   DevBuf<double> d_pose[2], d_pt[2], d_first[2], d_second[2], d_last[2], d_chi2[2];
@@ -290,6 +290,7 @@ int mcp_ba::prepare() {
   std::vector<int> sp_pt(nsp), sp_m(nsp + 1, 0), sp_i(nsp + 1, 0);
   std::vector<unsigned char> sp_big(nsp, 0);
   std::vector<std::vector<int>> sp_poses(nsp);       // distinct pose unknowns touched by the point
+  std::vector<unsigned char> inc_state;              // bit0: fed by a first-source-link slot, bit1: fed by another slot
   slot_unk.reserve((size_t)nmeas*2); slot_inc.reserve((size_t)nmeas*2); slot_first.reserve((size_t)nmeas*2); inc_unk.reserve((size_t)nfl*8);
   perm.assign(nmeas, 0);
   int j = 0;
@@ -313,10 +314,14 @@ int mcp_ba::prepare() {
         const int u = poses[c.v[b & 3]].unk;
         slot_unk.push_back(u);
         if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
+        // slot_first: first contribution to its W block among the slots that write it through memory (every slot but
+        // the first source link, whose block is kept in registers by k_linearize_group); inc_mixed: both kinds occur
         int inc = -1; unsigned char first = 0;
         if (lpt >= 0) {
           for (int t = ibase; t < (int)inc_unk.size(); ++t) if (inc_unk[t] == u) { inc = t; break; }
-          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); first = 1; }
+          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); inc_state.push_back(0); }
+          if (b == 4) inc_state[inc] |= 1;
+          else { if (!(inc_state[inc] & 2)) first = 1; inc_state[inc] |= 2; }
         }
         slot_inc.push_back(inc); slot_first.push_back(first);
       }
@@ -369,6 +374,8 @@ int mcp_ba::prepare() {
   }
   // local pose indices of slots and incidences
   std::vector<unsigned char> slot_lp(nslot + 1, 0), inc_lp(ninc + 1, 0);
+  std::vector<unsigned char> inc_mixed(ninc + 1, 0);
+  for (int i = 0; i < ninc; ++i) inc_mixed[i] = (inc_state[i] == 3);
   for (int gi = 0; gi < ngroup; ++gi) {
     const int* gp = &g_pose[(size_t)gi*GRP_LMAX];
     auto local = [&](int u) -> unsigned char { for (int k = 0; k < GRP_LMAX; ++k) if (gp[k] == u) return (unsigned char)k; return 0; };
@@ -394,7 +401,7 @@ int mcp_ba::prepare() {
       d_fl_point.upload(fl_point, st) || d_sp_pt.upload(sp_pt, st) || d_sp_m.upload(sp_m, st) || d_sp_i.upload(sp_i, st) ||
       d_sp_big.upload(sp_big, st) || d_m_sp.upload(m_sp, st) || d_l_sp.upload(l_sp, st) || d_g_sp0.upload(g_sp0, st) ||
       d_g_pose.upload(g_pose, st) || d_slot_lp.upload(slot_lp, st) || d_slot_first.upload(slot_first, st) ||
-      d_inc_lp.upload(inc_lp, st)) return -1;
+      d_inc_lp.upload(inc_lp, st) || d_inc_mixed.upload(inc_mixed, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < 2; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
@@ -420,7 +427,7 @@ int mcp_ba::prepare() {
   P.l_i0 = d_l_i0.p; P.l_i1 = d_l_i1.p; P.inc_unk = d_inc_unk.p; P.fl_point = d_fl_point.p; P.robust = robust;
   P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
-  P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p;
+  P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
   HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
   if (upload_state()) return -1;
   HIPCK(hipStreamSynchronize(st));

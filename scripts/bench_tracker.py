@@ -1,0 +1,63 @@
+"""Secondary benchmark: the per-frame Tracker path (BASELINE config c3: 4 x 640x480 pyramids + FAST-10 +
+PatchFinder search on ~1k tracked points + 10 pose iterations), GPU through the C ABI vs the CPU oracle."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
+    from mcptam_amd import synth_img
+    from mcptam_amd.keyframe import KeyFrame, track_pose_update, track_search
+    sc = synth_img.make_tracking_scene(size=size)
+    I = (np.eye(3), np.zeros(3))
+    src = [KeyFrame(*size) for _ in range(cams)]
+    from oracle import OracleKeyFrame, oracle_track_pose_update, oracle_track_search
+    osrc = [OracleKeyFrame(*size) for _ in range(cams)]
+    pts = []
+    for c in range(cams):
+        src[c].MakeKeyFrame_Lite(sc["imgA"]); src[c].MakeKeyFrame_Rest()
+        osrc[c].MakeKeyFrame_Lite(sc["imgA"]); osrc[c].MakeKeyFrame_Rest()
+        pts.append(synth_img.make_map_points(sc["cam"], src[c], osrc[c], sc["poseA"], sc["depth"], per_level=(100, 80, 50, 20)))
+    npts = sum(len(p) for p in pts)
+    cur = [KeyFrame(*size) for _ in range(cams)]
+
+    def gpu_frame():
+        found = 0
+        outs = []
+        for c in range(cams):
+            cur[c].MakeKeyFrame_Lite(sc["imgB"])
+            outs.append(track_search(cur[c], sc["cam"], sc["poseB"], I, pts[c], 10, 8))
+            found += int(outs[-1]["found"].sum())
+        o = np.concatenate(outs)
+        for it in range(10):
+            mu, w, s = track_pose_update(o["found"], o["found_pos"], o["image"], o["sqrt_inv_noise"], o["jacobian"], 16.0 if it > 5 else -1.0)
+        return found
+
+    gpu_frame()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        found = gpu_frame()
+    gdt = (time.perf_counter() - t0)/frames
+    ocur = [OracleKeyFrame(*size) for _ in range(cams)]
+    t0 = time.perf_counter()
+    for _ in range(cpu_frames):
+        outs = []
+        for c in range(cams):
+            ocur[c].MakeKeyFrame_Lite(sc["imgB"])
+            outs.append(oracle_track_search(ocur[c], sc["cam"], sc["poseB"], I, pts[c], 10, 8))
+        o = np.concatenate(outs)
+        for it in range(10):
+            oracle_track_pose_update(o["found"], o["found_pos"], o["image"], o["sqrt_inv_noise"], o["jacobian"], 16.0 if it > 5 else -1.0)
+    cdt = (time.perf_counter() - t0)/cpu_frames
+    px = cams*size[0]*size[1]
+    res = {"metric": "Tracker frames/s (c3: %d x %dx%d, %d tracked points/frame, 10 pose iterations)" % (cams, size[0], size[1], npts),
+           "gpu_frames_per_s": 1/gdt, "gpu_ms_per_frame": gdt*1e3, "found_per_frame": found,
+           "cpu_oracle_frames_per_s": 1/cdt, "cpu_cores": 1,
+           "algorithmic_bytes_per_frame": int(px*(1.64 + 1.33) + npts*1500),
+           "note": "host-driven: one make_lite + one track_search + 10 pose_update calls per camera/frame, images uploaded over PCIe each frame"}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
