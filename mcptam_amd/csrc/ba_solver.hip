@@ -220,6 +220,8 @@ struct mcp_ba {
 // ------------------------------------------------------------------------------------------
 int mcp_ba::prepare() {
   auto t0 = std::chrono::steady_clock::now();
+  auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
+  auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
   HIPCK(hipSetDevice(device));
   const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
   for (auto& p : poses) { p.active = 0; p.unk = -1; }
@@ -251,6 +253,7 @@ int mcp_ba::prepare() {
   nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
   if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
   if (!(hook && world > 1)) nfl_total = nfl;
+  lap("activity");
   // ---- measurements by point (add order kept inside a point)
   std::vector<int> cnt(npoint + 1, 0);
   for (const auto& m : meas) cnt[m.point + 1]++;
@@ -270,16 +273,28 @@ int mcp_ba::prepare() {
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pkey[a] < pkey[b]; });
   nsp = (int)order.size();
-  // per (obs chain, src chain) activity mask
+  // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
+  const size_t nch = chains.size();
+  const bool dense_table = nch <= 4096;
+  std::vector<unsigned short> mask_table(dense_table ? nch*nch : 0, 0xffff);
   std::map<std::pair<int, int>, unsigned short> mask_cache;
-  auto pair_mask = [&](int oc, int sc) -> unsigned short {
-    auto key = std::make_pair(oc, sc);
-    auto it = mask_cache.find(key);
-    if (it != mask_cache.end()) return it->second;
+  auto compute_mask = [&](int oc, int sc) -> unsigned short {
     unsigned short mk = 0;
     const HChain& o = chains[oc]; const HChain& s = chains[sc];
     for (int i = 0; i < o.len; ++i) if (!poses[o.v[i]].fixed && !move_together(o, s, i)) mk |= (1 << i);
     for (int i = 0; i < s.len; ++i) if (!poses[s.v[i]].fixed && !move_together(s, o, i)) mk |= (1 << (4 + i));
+    return mk;
+  };
+  auto pair_mask = [&](int oc, int sc) -> unsigned short {
+    if (dense_table) {
+      unsigned short& e = mask_table[(size_t)oc*nch + sc];
+      if (e == 0xffff) e = compute_mask(oc, sc);
+      return e;
+    }
+    auto key = std::make_pair(oc, sc);
+    auto it = mask_cache.find(key);
+    if (it != mask_cache.end()) return it->second;
+    const unsigned short mk = compute_mask(oc, sc);
     mask_cache[key] = mk; return mk;
   };
   std::vector<int> m_pt(nmeas), m_chain(nmeas), m_sp(nmeas), slot_start(nmeas + 1, 0), slot_unk, slot_inc;
@@ -332,6 +347,7 @@ int mcp_ba::prepare() {
   sp_m[nsp] = j; sp_i[nsp] = (int)inc_unk.size();
   slot_start[nmeas] = (int)slot_unk.size();
   ninc = (int)inc_unk.size(); nslot = (int)slot_unk.size();
+  lap("sort+slots");
   // ---- groups: consecutive points, <= GRP_PTS points and <= GRP_LMAX distinct poses
   std::vector<int> g_sp0, g_pose;
   nbig = 0;
@@ -357,15 +373,20 @@ int mcp_ba::prepare() {
     g_sp0.push_back(nsp);
   }
   ngroup = (int)g_sp0.size() - 1;
+  lap("groups");
   // ---- tile occupancy of the reduced pose system: poses a, b interact iff some point touches both
   if (np > 0) {
     const int ntc = (np + CH_NB - 1)/CH_NB;
     std::vector<unsigned char> pat((size_t)ntc*ntc, 0);
     if (hook && world > 1) std::fill(pat.begin(), pat.end(), 1);         // other ranks' points are unknown here: dense
-    else for (int sp = 0; sp < nsp; ++sp) {
-      const std::vector<int>& q = sp_poses[sp];
-      for (int a : q) for (int b : q) {
-        if (a < b) continue;
+    else {
+      std::vector<unsigned char> cov((size_t)nfp*nfp, 0);                  // pose-pair co-visibility, a >= b
+      for (int sp = 0; sp < nsp; ++sp) {
+        const std::vector<int>& q = sp_poses[sp];
+        for (int a : q) for (int b : q) if (a >= b) cov[(size_t)a*nfp + b] = 1;
+      }
+      for (int a = 0; a < nfp; ++a) for (int b = 0; b <= a; ++b) {
+        if (!cov[(size_t)a*nfp + b]) continue;
         const int ra0 = (6*a)/CH_NB, ra1 = (6*a + 5)/CH_NB, rb0 = (6*b)/CH_NB, rb1 = (6*b + 5)/CH_NB;
         for (int ra = ra0; ra <= ra1; ++ra) for (int rb = rb0; rb <= rb1; ++rb) if (ra >= rb) pat[(size_t)ra*ntc + rb] = 1;
       }
@@ -386,6 +407,7 @@ int mcp_ba::prepare() {
     }
   }
 
+  lap("pattern+plan");
   // upload
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*4), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
   std::vector<unsigned char> pt_fixed(npoint);
@@ -429,8 +451,10 @@ int mcp_ba::prepare() {
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
   P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
   HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
+  lap("alloc+upload");
   if (upload_state()) return -1;
   HIPCK(hipStreamSynchronize(st));
+  lap("state");
   dirty = false;
   timing.structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;

@@ -40,6 +40,9 @@ struct mcp_kf {
   int device = 0; hipStream_t st = nullptr;
   mcp_kf_params prm;
   Level lev[MCP_LEVELS];
+  // scratch reused across calls (no hipMalloc on the per-frame path)
+  Buf<DevTdIn> td_in; Buf<mcp_td_out> td_out;
+  Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f; Buf<int> mp_s;
   ~mcp_kf() { if (st) (void)hipStreamDestroy(st); }
   DevKfView view() const {
     DevKfView v;
@@ -200,7 +203,7 @@ int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int
   if (level < 0 || level >= MCP_LEVELS || n < 0) return img_fail("mcp_minipatch_find: bad arguments");
   if (n == 0) return 0;
   ICK(hipSetDevice(dst->device));
-  Buf<mcp_int2> dsp, ddp, dop; Buf<uint8_t> dfound; Buf<int> dssd;
+  Buf<mcp_int2>& dsp = dst->mp_a; Buf<mcp_int2>& ddp = dst->mp_b; Buf<mcp_int2>& dop = dst->mp_o; Buf<uint8_t>& dfound = dst->mp_f; Buf<int>& dssd = dst->mp_s;
   if (dsp.alloc(n) || ddp.alloc(n) || dop.alloc(n) || dfound.alloc(n) || dssd.alloc(n)) return -1;
   ICK(hipMemcpy(dsp.p, src_pos, sizeof(mcp_int2)*(size_t)n, hipMemcpyHostToDevice));
   ICK(hipMemcpy(ddp.p, dst_pos, sizeof(mcp_int2)*(size_t)n, hipMemcpyHostToDevice));
@@ -227,13 +230,13 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12]
     const Level& S = p.source_kf->lev[p.source_level];
     h[i].src_img = S.img.p; h[i].src_w = S.w; h[i].src_h = S.h; h[i].center_x = p.center_x; h[i].center_y = p.center_y; h[i].fixed = p.fixed;
   }
-  Buf<DevTdIn> din; Buf<mcp_td_out> dout;
+  Buf<DevTdIn>& din = target->td_in; Buf<mcp_td_out>& dout = target->td_out;
   if (din.alloc(n) || dout.alloc(n)) return -1;
-  ICK(hipMemcpy(din.p, h.data(), sizeof(DevTdIn)*(size_t)n, hipMemcpyHostToDevice));
+  ICK(hipMemcpyAsync(din.p, h.data(), sizeof(DevTdIn)*(size_t)n, hipMemcpyHostToDevice, target->st));
   Se3 B, C; std::memcpy(B.R, bfw, 72); std::memcpy(B.t, bfw + 9, 24); std::memcpy(C.R, cfb, 72); std::memcpy(C.t, cfb + 9, 24);
   hipLaunchKernelGGL(k_track_search, dim3(n), dim3(64), 0, target->st, target->view(), *cam, B, C, n, (const DevTdIn*)din.p, range, subpix_its, exhaustive, dout.p);
+  ICK(hipMemcpyAsync(out, dout.p, sizeof(mcp_td_out)*(size_t)n, hipMemcpyDeviceToHost, target->st));
   ICK(hipStreamSynchronize(target->st));
-  ICK(hipMemcpy(out, dout.p, sizeof(mcp_td_out)*(size_t)n, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -247,7 +250,12 @@ int mcp_track_pose_update(int n, const uint8_t* found, const double* fpos, const
   for (int i = 0; i < n; ++i) { slot[i] = ne; if (found[i]) ++ne; }
   if (wout) std::memset(wout, 0, sizeof(double)*(size_t)n);
   if (ne == 0) return 0;
-  Buf<uint8_t> dfound; Buf<double> dfp, dip, dsi, dJ, dex, de2, dsig, dmu, dw, dhist; Buf<int> dslot; Buf<SelState> dst;
+  // scratch kept across calls (the tracker calls this ~20 times per frame)
+  struct PoseScratch { Buf<uint8_t> dfound; Buf<double> dfp, dip, dsi, dJ, dex, de2, dsig, dmu, dw, dhist; Buf<int> dslot; Buf<SelState> dst; };
+  static thread_local PoseScratch ps;
+  Buf<uint8_t>& dfound = ps.dfound; Buf<double>& dfp = ps.dfp; Buf<double>& dip = ps.dip; Buf<double>& dsi = ps.dsi; Buf<double>& dJ = ps.dJ;
+  Buf<double>& dex = ps.dex; Buf<double>& de2 = ps.de2; Buf<double>& dsig = ps.dsig; Buf<double>& dmu = ps.dmu; Buf<double>& dw = ps.dw;
+  Buf<double>& dhist = ps.dhist; Buf<int>& dslot = ps.dslot; Buf<SelState>& dst = ps.dst;
   if (dfound.alloc(n) || dfp.alloc(2*(size_t)n) || dip.alloc(2*(size_t)n) || dsi.alloc(n) || dJ.alloc(12*(size_t)n) || dex.alloc(2*(size_t)n) ||
       de2.alloc(ne) || dsig.alloc(4) || dmu.alloc(8) || dw.alloc(n) || dhist.alloc((size_t)SEL_PASSES*SEL_BINS) || dslot.alloc(n) || dst.alloc(SEL_PASSES + 1)) return -1;
   ICK(hipMemcpy(dfound.p, found, (size_t)n, hipMemcpyHostToDevice));

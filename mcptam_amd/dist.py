@@ -42,20 +42,36 @@ class RcclAllReduce:
     def __call__(self, ptr, count, stream):
         torch = self.torch
         import torch.distributed as dist
-        if self.stage is None or self.stage.numel() < count:
-            self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device=self.device)
-        t = self.stage[:count]
-        nbytes = count * 8
-        if self.hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr), nbytes, hipMemcpyDeviceToDevice) != 0:
-            raise RuntimeError("hipMemcpy to staging failed")
-        self.hip.hipDeviceSynchronize()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize(self.device)
-        if self.hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(t.data_ptr()), nbytes, hipMemcpyDeviceToDevice) != 0:
-            raise RuntimeError("hipMemcpy from staging failed")
-        self.hip.hipDeviceSynchronize()
+        # zero-copy view of the library's device buffer (the solver stream has been synchronised by the caller)
+        try:
+            view = torch.as_tensor(_DevicePointer(ptr, count), device=self.device)
+        except Exception:
+            view = None
+        if view is not None and view.data_ptr() == ptr:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
+        else:       # staging fallback
+            if self.stage is None or self.stage.numel() < count:
+                self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device=self.device)
+            t = self.stage[:count]
+            nbytes = count * 8
+            if self.hip.hipMemcpy(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(ptr), nbytes, hipMemcpyDeviceToDevice) != 0:
+                raise RuntimeError("hipMemcpy to staging failed")
+            self.hip.hipDeviceSynchronize()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
+            if self.hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(t.data_ptr()), nbytes, hipMemcpyDeviceToDevice) != 0:
+                raise RuntimeError("hipMemcpy from staging failed")
+            self.hip.hipDeviceSynchronize()
         self.calls += 1
         self.elements += count
+
+
+class _DevicePointer:
+    """Minimal __cuda_array_interface__ carrier: lets torch alias `count` doubles at a raw device address."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
 
 
 class GlooAllReduce:
