@@ -102,15 +102,28 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from mcptam_amd import chain_bundle, synth
-    from mcptam_amd.dist import RcclAllReduce
+    from mcptam_amd.dist import RcclAllReduce, init_rccl_comm
 
     problem = synth.make_config(args.config, shard=rank)
-    hook = RcclAllReduce(dev) if world > 1 else None
+    # transport of the per-trial all-reduce: the library's own RCCL communicator on the solver stream; if that cannot
+    # be created, the torch.distributed (backend nccl = RCCL) hook
+    comm, hook, transport = None, None, "none"
+    if world > 1:
+        try:
+            comm = init_rccl_comm(rank, world, local_rank)
+            transport = "rccl (library communicator, stream-ordered)"
+        except Exception as exc:
+            if rank == 0:
+                print("bench: native RCCL communicator unavailable (%r); using the torch.distributed hook" % (exc,), file=sys.stderr)
+            hook = RcclAllReduce(dev)
+            transport = "rccl via torch.distributed hook"
 
     def fresh(profile=False):
         b = chain_bundle.ChainBundle(problem.cams, True, True, False, disable_convergence=True, device=local_rank, profile=profile)
         problem.populate(b)
-        if hook is not None:
+        if comm is not None:
+            b.SetComm(comm)
+        elif hook is not None:
             b.SetAllReduce(hook, rank, world)
         b.Prepare()          # structure + upload: the map is resident in HBM before the timed region
         return b
@@ -152,7 +165,7 @@ def main():
             "dtype": "f64", "data": "synthetic (seed %d, SURVEY.md 8(d) generator)" % synth.DEFAULT_SEED,
             "config": {"workload": "%s: %d cams, %d MKF, %d points, %d measurements per rank" % (
                 args.config, len(problem.cams), problem.n_mkf, problem.n_points, problem.n_meas),
-                "trials_per_iteration": trials / args.steps, "parallelism": "points sharded x%d, poses replicated" % world,
+                "trials_per_iteration": trials / args.steps, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
                 "chi2_first": chi_first, "chi2_last": chi_last},
         }
     # per-stage HIP-event timing of the same run shape (separate pass so the events do not perturb `value`)

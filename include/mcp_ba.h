@@ -151,6 +151,19 @@ int    mcp_ba_get_timing(mcp_ba*, mcp_ba_timing* out);
 typedef int (*mcp_allreduce_fn)(void* user, void* device_buf, size_t count, void* hip_stream);
 int mcp_ba_set_allreduce(mcp_ba*, mcp_allreduce_fn hook, void* user, int rank, int world_size);
 
+/* Native transport: an RCCL communicator over the GPUs of the node.  The all-reduces are enqueued on the
+ * solver's HIP stream (stream-ordered, no host round trip).  Bootstrap: rank 0 calls mcp_comm_unique_id and
+ * ships the MCP_COMM_ID_BYTES bytes to the other ranks by any means (torch.distributed, MPI, a file); every
+ * rank then calls mcp_comm_init on its own device.  One communicator serves any number of handles. */
+#define MCP_COMM_ID_BYTES 128
+typedef struct mcp_comm mcp_comm;
+int       mcp_comm_unique_id(void* id_out);
+mcp_comm* mcp_comm_init(const void* id, int rank, int world_size, int device);
+void      mcp_comm_destroy(mcp_comm*);
+int       mcp_ba_set_comm(mcp_ba*, mcp_comm*);
+/* SUM all-reduce of `count` doubles at a device pointer on the communicator (test hook) */
+int       mcp_comm_allreduce(mcp_comm*, void* device_buf, size_t count);
+
 /* ---- introspection used by the parity tests (no reference counterpart) ---- */
 /* structure build + upload without solving; returns the number of unknowns 6P+3N */
 int mcp_ba_prepare(mcp_ba*);

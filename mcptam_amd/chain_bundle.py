@@ -51,6 +51,7 @@ BA_SYMBOLS = [
     "mcp_ba_num_outliers", "mcp_ba_get_outliers", "mcp_ba_sigma_squared", "mcp_ba_mean_chi_squared", "mcp_ba_max_cov",
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
+    "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce",
 ]
 
 
@@ -90,6 +91,12 @@ def lib():
     L.mcp_ba_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.mcp_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_dense_spd_solve.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p]
+    L.mcp_comm_unique_id.argtypes = [ctypes.c_void_p]
+    L.mcp_comm_init.restype = ctypes.c_void_p
+    L.mcp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.mcp_comm_destroy.argtypes = [ctypes.c_void_p]
+    L.mcp_ba_set_comm.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.mcp_comm_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     _LIB = L
     return L
 
@@ -108,6 +115,37 @@ def _dp(a):
 
 def _ip(a):
     return a.ctypes.data_as(c_int_p)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (rank 0 creates it and ships the bytes to the other ranks)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    if lib().mcp_comm_unique_id(buf) != 0:
+        raise RuntimeError("mcp_comm_unique_id failed: " + last_error())
+    return bytes(buf.raw)
+
+
+class Comm:
+    """RCCL communicator over the GPUs of one node (include/mcp_ba.h mcp_comm_*)."""
+
+    def __init__(self, uid, rank, world_size, device=-1):
+        self._L = lib()
+        self._h = self._L.mcp_comm_init(ctypes.c_char_p(uid), int(rank), int(world_size), int(device))
+        if not self._h:
+            raise RuntimeError("mcp_comm_init failed: " + last_error())
+        self.rank, self.world_size = rank, world_size
+
+    def allreduce(self, device_ptr, count):
+        if self._L.mcp_comm_allreduce(self._h, ctypes.c_void_p(device_ptr), int(count)) != 0:
+            raise RuntimeError("mcp_comm_allreduce failed: " + last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mcp_comm_destroy(self._h)
+            self._h = None
 
 
 def dense_spd_solve(A, b):
@@ -267,6 +305,11 @@ class ChainBundle:
                 return 1
         self._hook = ALLREDUCE_FN(tramp) if fn is not None else ctypes.cast(None, ALLREDUCE_FN)
         self._check(self._L.mcp_ba_set_allreduce(self._h, self._hook, None, int(rank), int(world_size)), "SetAllReduce")
+
+    def SetComm(self, comm):
+        """Use a native RCCL communicator (stream-ordered all-reduces) instead of a host hook."""
+        self._comm = comm
+        self._check(self._L.mcp_ba_set_comm(self._h, comm._h if comm is not None else None), "SetComm")
 
     # ---- introspection for parity tests ----
     def Prepare(self):

@@ -191,10 +191,10 @@ k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* _
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// fixed-order final reduction of up to 4 partial arrays into out[0..3] (single block)
+// fixed-order final reduction of up to 3 partial arrays into out[off..off+2] (single block); out[off+3] = failure flag
 __global__ void __launch_bounds__(256)
 k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
-             double* __restrict__ out, int off) {
+             double* __restrict__ out, int off, const int* __restrict__ fail) {
   __shared__ double lds[4];
   const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
   for (int a = 0; a < 3; ++a) {
@@ -204,6 +204,7 @@ k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const d
     const double t = block_sum<256>(v, lds);
     if (threadIdx.x == 0) out[off + a] = t;
   }
+  if (fail && threadIdx.x == 0) out[off + 3] = (fail[0] != 0) ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------

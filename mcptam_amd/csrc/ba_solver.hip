@@ -22,6 +22,7 @@
 #include "ba_select.h"
 #include "ba_chol.h"
 #include "ba_group.h"
+#include "ba_comm.h"
 
 using namespace mcp;
 
@@ -136,6 +137,8 @@ struct mcp_ba {
 
   // multi-rank
   mcp_allreduce_fn hook = nullptr; void* hook_user = nullptr; int rank = 0, world = 1;
+  mcp_comm* comm = nullptr;        // native RCCL transport (takes precedence over the hook)
+  bool multi() const { return world > 1 && (hook || comm); }
 
   // profiling
   struct Ev { int stage; hipEvent_t a, b; };
@@ -196,8 +199,17 @@ struct mcp_ba {
     return true;
   }
 
-  int allreduce(double* buf, size_t count) {
-    if (!hook || world <= 1) return 0;
+  // SUM all-reduce of `count` doubles at `buf` over the ranks.  host_sync: the caller reads the result with a
+  // blocking copy next, so the stream-ordered RCCL path has to drain the stream first.
+  int allreduce(double* buf, size_t count, bool host_sync = false) {
+    if (world <= 1) return 0;
+    if (comm) {
+      const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, comm->comm, st);
+      if (rc != 0) { set_err(std::string("ncclAllReduce failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?")); return -1; }
+      if (host_sync) HIPCK(hipStreamSynchronize(st));
+      return 0;
+    }
+    if (!hook) return 0;
     HIPCK(hipStreamSynchronize(st));
     if (hook(hook_user, buf, count, (void*)st) != 0) { set_err("all-reduce hook failed"); return -1; }
     return 0;
@@ -233,7 +245,7 @@ int mcp_ba::prepare() {
     for (int k = 0; k < sc.len; ++k) poses[sc.v[k]].active = 1;
   }
   m_total = (double)nmeas;
-  if (hook && world > 1) {
+  if (multi()) {
     // ranks hold different measurement shards: agree on the active poses and the global count
     std::vector<double> flags(npose + 2);
     for (int i = 0; i < npose; ++i) flags[i] = poses[i].active;
@@ -242,7 +254,7 @@ int mcp_ba::prepare() {
     flags[npose + 1] = nfree;
     DevBuf<double> tmp;
     if (tmp.upload(flags, st)) return -1;
-    if (allreduce(tmp.p, flags.size())) return -1;
+    if (allreduce(tmp.p, flags.size(), true)) return -1;
     HIPCK(hipMemcpy(flags.data(), tmp.p, flags.size()*sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < npose; ++i) poses[i].active = flags[i] > 0;
     m_total = flags[npose]; nfl_total = flags[npose + 1];
@@ -252,7 +264,7 @@ int mcp_ba::prepare() {
   for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
   nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
   if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
-  if (!(hook && world > 1)) nfl_total = nfl;
+  if (!multi()) nfl_total = nfl;
   lap("activity");
   // ---- measurements by point (add order kept inside a point)
   std::vector<int> cnt(npoint + 1, 0);
@@ -378,7 +390,7 @@ int mcp_ba::prepare() {
   if (np > 0) {
     const int ntc = (np + CH_NB - 1)/CH_NB;
     std::vector<unsigned char> pat((size_t)ntc*ntc, 0);
-    if (hook && world > 1) std::fill(pat.begin(), pat.end(), 1);         // other ranks' points are unknown here: dense
+    if (multi()) std::fill(pat.begin(), pat.end(), 1);         // other ranks' points are unknown here: dense
     else {
       std::vector<unsigned char> cov((size_t)nfp*nfp, 0);                  // pose-pair co-visibility, a >= b
       for (int sp = 0; sp < nsp; ++sp) {
@@ -568,7 +580,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
     tic(ST_SOLVE); chol_back(st, plan, S()); toc();
   }
   tic(ST_UPDATE);
-  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 3);
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6);
   const int nbb = (nfl + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, d_Vinv.p,
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
@@ -578,13 +590,13 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
   launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
-                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0);
+                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p);
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
-  if (allreduce(d_res.p, 3)) return -1;
-  if (read_results(5)) return -1;
-  h_res[1] += h_res[3]; h_res[2] += h_res[4];
-  ok2 = (h_fail[0] == 0);
+  if (allreduce(d_res.p, 4)) return -1;          // robust chi2, point parts of the step statistics, failure flag (any rank)
+  if (read_results(8)) return -1;
+  h_res[1] += h_res[6]; h_res[2] += h_res[7];
+  ok2 = (h_res[3] == 0.0);
   timing.n_trials++;
   return 0;
 }
@@ -613,7 +625,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       tic(ST_EVAL);
       const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
       hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
-      hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0);
+      hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
       toc();
       if (allreduce(d_res.p, 1)) return -1;
       if (linearize()) return -1;
@@ -639,7 +651,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           if (world > 1) {   // max over ranks of the V diagonals (U is already global)
             std::vector<double> slots(world, 0.0); slots[rank] = md;
             HIPCK(hipMemcpyAsync(d_res.p + 16, slots.data(), world*sizeof(double), hipMemcpyHostToDevice, st));
-            if (allreduce(d_res.p + 16, world)) return -1;
+            if (allreduce(d_res.p + 16, world, true)) return -1;
             HIPCK(hipMemcpy(slots.data(), d_res.p + 16, world*sizeof(double), hipMemcpyDeviceToHost));
             for (double v : slots) md = std::max(md, v);
           }
@@ -671,7 +683,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           if (world > 1) {   // point parts are rank-local
             double v2[2] = { sl, sq };
             HIPCK(hipMemcpy(d_res.p + 16, v2, 16, hipMemcpyHostToDevice));
-            if (allreduce(d_res.p + 16, 2)) return -1;
+            if (allreduce(d_res.p + 16, 2, true)) return -1;
             HIPCK(hipMemcpy(v2, d_res.p + 16, 16, hipMemcpyDeviceToHost)); sl = v2[0]; sq = v2[1];
           }
           scale += sl; ss += sq;
@@ -741,7 +753,7 @@ int mcp_ba::final_stats(int nCounter) {
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
-  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
   if (allreduce(d_res.p, 1)) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
   if (read_results(13)) return -2;
@@ -931,7 +943,41 @@ int mcp_ba_get_timing(mcp_ba* h, mcp_ba_timing* out) { *out = h->timing; return 
 
 int mcp_ba_set_allreduce(mcp_ba* h, mcp_allreduce_fn hook, void* user, int rank, int world_size) {
   if (world_size < 1 || rank < 0 || rank >= world_size) { set_err("mcp_ba_set_allreduce: bad rank/world"); return -1; }
-  h->hook = hook; h->hook_user = user; h->rank = rank; h->world = hook ? world_size : 1; h->dirty = true;
+  h->hook = hook; h->hook_user = user; h->comm = nullptr; h->rank = hook ? rank : 0; h->world = hook ? world_size : 1; h->dirty = true;
+  return 0;
+}
+
+int mcp_comm_unique_id(void* id_out) {
+  if (!rccl().load()) { set_err("mcp_comm_unique_id: librccl not found"); return -1; }
+  RcclUniqueId id; std::memset(&id, 0, sizeof id);
+  const int rc = rccl().GetUniqueId(&id);
+  if (rc != 0) { set_err("ncclGetUniqueId failed"); return -1; }
+  std::memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+mcp_comm* mcp_comm_init(const void* id, int rank, int world_size, int device) {
+  if (!rccl().load()) { set_err("mcp_comm_init: librccl not found"); return nullptr; }
+  if (world_size < 1 || rank < 0 || rank >= world_size) { set_err("mcp_comm_init: bad rank/world"); return nullptr; }
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+  if (hipSetDevice(device) != hipSuccess) { set_err("mcp_comm_init: hipSetDevice failed"); return nullptr; }
+  RcclUniqueId uid; std::memcpy(&uid, id, sizeof uid);
+  mcp_comm* c = new mcp_comm(); c->rank = rank; c->world = world_size; c->device = device;
+  const int rc = rccl().CommInitRank(&c->comm, world_size, uid, rank);
+  if (rc != 0) { set_err(std::string("ncclCommInitRank failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?")); delete c; return nullptr; }
+  return c;
+}
+void mcp_comm_destroy(mcp_comm* c) { if (c) { if (c->comm) (void)rccl().CommDestroy(c->comm); delete c; } }
+int mcp_ba_set_comm(mcp_ba* h, mcp_comm* c) {
+  if (c && c->device != h->device) { set_err("mcp_ba_set_comm: communicator lives on another device"); return -1; }
+  h->comm = c; h->rank = c ? c->rank : 0; h->world = c ? c->world : 1; h->dirty = true;
+  return 0;
+}
+int mcp_comm_allreduce(mcp_comm* c, void* buf, size_t count) {
+  if (!c || !c->comm) { set_err("mcp_comm_allreduce: no communicator"); return -1; }
+  HIPCK(hipSetDevice(c->device));
+  const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, c->comm, nullptr);
+  if (rc != 0) { set_err("ncclAllReduce failed"); return -1; }
+  HIPCK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -966,7 +1012,7 @@ int mcp_ba_robust_chi2(mcp_ba* h, double* sigma_sq_raw, double* chi2_sum) {
   if (h->robust && h->median_sigma(h->cur)) return -1;
   const int nbe = (n + EVAL_BLOCK - 1)/EVAL_BLOCK;
   hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, h->st, n, h->robust, (const double*)h->d_chi2[h->cur].p, (const double*)h->d_sigma.p, h->d_part0.p);
-  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, h->st, nbe, (const double*)h->d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, h->d_res.p, 0);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, h->st, nbe, (const double*)h->d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, h->d_res.p, 0, (const int*)nullptr);
   if (h->allreduce(h->d_res.p, 1)) return -1;
   HIPCK(hipMemcpyAsync(h->d_res.p + 9, h->d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, h->st));
   if (h->read_results(13)) return -1;

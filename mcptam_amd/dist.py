@@ -101,3 +101,13 @@ class GlooAllReduce:
             if self.hip.hipMemcpy(ctypes.c_void_p(ptr), ctypes.c_void_p(buf.ctypes.data), count * 8, hipMemcpyHostToDevice) != 0:
                 raise RuntimeError("hipMemcpy H2D failed")
         self.calls += 1
+
+
+def init_rccl_comm(rank, world_size, device_index):
+    """Bootstrap the library's own RCCL communicator: rank 0 creates the unique id and broadcasts it over the
+    (already initialised) torch.distributed default group; every rank then joins on its device."""
+    import torch.distributed as dist
+    from .chain_bundle import Comm, comm_unique_id
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Comm(box[0], rank, world_size, device_index)

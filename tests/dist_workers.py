@@ -67,3 +67,29 @@ def rccl_hook_single_rank(rank, world, port, outdir):
     torch.cuda.synchronize()
     np.savez(os.path.join(outdir, "rccl.npz"), t=t.cpu().numpy(), calls=h.calls)
     dist.destroy_process_group()
+
+
+def native_rccl_single_rank(rank, world, port, outdir):
+    """The library's own RCCL communicator (dlopen'ed librccl, stream-ordered ncclAllReduce) with one rank:
+    bootstrap through torch.distributed, raw all-reduce, and a full solve with the communicator installed."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import init_rccl_comm
+    from helpers import collect
+    comm = init_rccl_comm(0, 1, 0)
+    t = torch.arange(4096, dtype=torch.float64, device="cuda") * 0.25
+    comm.allreduce(t.data_ptr(), t.numel())
+    p = synth.make_config("tiny")
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, device=0)
+    ids = p.populate(b)
+    b.SetComm(comm)
+    rc = b.Compute(8)
+    R, tt, X = collect(b, ids)
+    np.savez(os.path.join(outdir, "native.npz"), t=t.cpu().numpy(), rc=rc, R=R, tt=tt, X=X)
+    b.close(); comm.close()
+    dist.destroy_process_group()

@@ -270,3 +270,35 @@ def test_rccl_hook_on_device_buffer(gpu_required):
         mp.spawn(dist_workers.rccl_hook_single_rank, args=(1, port, d), nprocs=1, join=True)
         r = np.load(os.path.join(d, "rccl.npz"))
     assert np.array_equal(r["t"], np.arange(5000) * 0.5) and int(r["calls"]) == 2
+
+
+def test_c4_size_single_rank_properties(gpu_required):
+    """BASELINE config c4 map (4-cam, 500 MKF, 100k points, 800k measurements) on one GPU: the 2994-unknown reduced
+    system (94 block steps) converges to the noise-free ground truth."""
+    from mcptam_amd import synth
+    p = synth.make_config("c4", noise=False)
+    assert p.n_meas == 800000 and p.n_mkf == 500
+    g = _gpu(p.cams)
+    ids = p.populate(g)
+    rc = g.Compute(25)
+    assert rc > 0 and g.Converged()
+    R, t = g.GetPoses(ids["mkf"])
+    assert np.abs(R - p.true_base_R).max() < 1e-8 and np.abs(t - p.true_base_t).max() < 1e-7
+
+
+def test_native_rccl_communicator_single_rank(gpu_required):
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    from mcptam_amd import synth
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.native_rccl_single_rank, args=(1, port, d), nprocs=1, join=True)
+        r = np.load(os.path.join(d, "native.npz"))
+    assert np.array_equal(r["t"], np.arange(4096) * 0.25)
+    p = synth.make_config("tiny")
+    ref = run_bundle(_gpu(p.cams), p, 8)
+    assert int(r["rc"]) == ref["rc"]
+    assert rel_err(r["R"], ref["R"]) < 1e-9 and rel_err(r["X"], ref["X"]) < 1e-9
