@@ -1,0 +1,32 @@
+"""The C++ host-side mirror (include/mcptam_hip/ChainBundle.hpp) compiles with plain g++ against the C ABI and links
+against libmcptam_hip.so; on a GPU box the same program solves a small bundle."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp):
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(str(tmp), "chain_bundle_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "chain_bundle_smoke.cpp"),
+                           "-L", os.path.join(ROOT, "mcptam_amd"), "-lmcptam_hip", "-Wl,-rpath," + os.path.join(ROOT, "mcptam_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_links(tmp_path):
+    exe = _build(tmp_path)
+    out = subprocess.run([exe, "--link-only"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "linked" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_solves_on_gpu(tmp_path, gpu_required):
+    exe = _build(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
