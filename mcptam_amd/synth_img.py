@@ -78,3 +78,25 @@ def make_map_points(cam, kf, kf_oracle, pose, depth, per_level=(400, 300, 200, 1
             pts.append(dict(world_pos=Xw, pixel_right_w=R.T @ (right_p - cen_p), pixel_down_w=R.T @ (down_p - cen_p),
                             source_kf=kf, source_kf_oracle=kf_oracle, source_level=level, center=(int(c[0]), int(c[1])), fixed=0))
     return pts
+
+
+def hypothesis_point(cam, kf, kf_oracle, pose, center, level, scale_along_ray, normal_c=(0.0, 0.0, -1.0)):
+    """A hypothesised map point on the view ray of candidate `center` (level coordinates) of keyframe `kf`, `scale_along_ray`
+    metres from the camera -- what MapMakerServerBase::AddPointEpipolar builds for every step along the epipolar arc
+    (/root/reference/src/MapMakerServerBase.cc:724-760) before it hands the point to PatchFinder."""
+    R, t = pose
+    nrm = np.asarray(normal_c)
+    sc = 1 << level
+    c = np.asarray(center, dtype=np.float64)
+    cen = (c + 0.5) * sc - 0.5
+    right = cen + np.array([sc, 0.0])
+    down = cen + np.array([0.0, sc])
+    rc, rr, rd = cam.unproject(np.stack([cen, right, down]))
+    Xc = rc * scale_along_ray
+    Xw = R.T @ (Xc - t)
+    cam_height = abs(Xc @ nrm)
+    cen_p = rc * cam_height / abs(rc @ nrm)
+    right_p = rr * cam_height / abs(rr @ nrm)
+    down_p = rd * cam_height / abs(rd @ nrm)
+    return dict(world_pos=Xw, pixel_right_w=R.T @ (right_p - cen_p), pixel_down_w=R.T @ (down_p - cen_p),
+                source_kf=kf, source_kf_oracle=kf_oracle, source_level=level, center=(int(center[0]), int(center[1])), fixed=0)

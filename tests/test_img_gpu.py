@@ -121,6 +121,25 @@ def _points(scene, g, o):
 INT_FIELDS = ("in_image", "search_level", "template_bad", "searched", "found", "did_subpix", "coarse_x", "coarse_y", "score")
 
 
+def assert_track_equal(og, oo, max_ulp_cases=0.005):
+    """Integer outputs must be identical.  One documented exception (DESIGN.md 5): CVD::transform truncates the bilinear sample
+    to a byte, so in a FLAT image region (all four neighbours equal) the sample is an exact integer in exact arithmetic and the
+    last ulp of the source position decides between g and g-1; that position depends on atan(), whose last ulp differs between
+    glibc and the device math library.  Such points (a fraction of a percent) may differ by one grey level in a few template
+    pixels, with the ZMSSD score following; everything else must match exactly."""
+    n = len(og)
+    tdiff = np.abs(og["templ"].astype(int) - oo["templ"].astype(int))
+    assert tdiff.max() <= 1, "template bytes differ by more than one grey level"
+    touched = tdiff.max(axis=1) > 0
+    assert touched.sum() <= max(1, int(max_ulp_cases * n)), "too many templates differ: %d of %d" % (touched.sum(), n)
+    clean = ~touched
+    for f in INT_FIELDS:
+        assert np.array_equal(og[f][clean], oo[f][clean]), f
+    for f in ("in_image", "search_level", "template_bad", "searched"):
+        assert np.array_equal(og[f], oo[f]), f
+    return int(touched.sum())
+
+
 @pytest.mark.parametrize("rng,its,exh", [(10, 8, False), (30, 0, False), (5, 3, True)])
 def test_track_search_matches_oracle(gpu_required, scene, rng, its, exh):
     from mcptam_amd.keyframe import track_search
@@ -140,12 +159,12 @@ def test_track_search_matches_oracle(gpu_required, scene, rng, its, exh):
     bfw = (RB, tB - cfb[1])
     og = track_search(gB, scene["cam"], bfw, cfb, pts, rng, its, exh)
     oo = oracle_track_search(oB, scene["cam"], bfw, cfb, pts, rng, its, exh)
-    for f in INT_FIELDS:
-        assert np.array_equal(og[f], oo[f]), f
-    assert np.array_equal(og["templ"], oo["templ"])
-    for f in ("image", "cam_derivs", "jacobian", "warp_inverse", "sqrt_inv_noise"):
+    nt = assert_track_equal(og, oo)
+    clean = np.abs(og["templ"].astype(int) - oo["templ"].astype(int)).max(axis=1) == 0
+    for f in ("image", "cam_derivs", "jacobian", "warp_inverse"):
         assert np.allclose(og[f], oo[f], rtol=1e-11, atol=1e-12), f
-    assert np.allclose(og["found_pos"], oo["found_pos"], rtol=0, atol=1e-9)
+    assert np.allclose(og["sqrt_inv_noise"][clean], oo["sqrt_inv_noise"][clean], rtol=0, atol=0)
+    assert np.allclose(og["found_pos"][clean], oo["found_pos"][clean], rtol=0, atol=1e-9)
     assert og["found"].sum() > 0.5 * len(pts) or exh
     assert og["in_image"][-1] == 0
 
@@ -172,3 +191,45 @@ def test_pose_update_matches_oracle(gpu_required, scene):
     none = np.zeros(len(pts), dtype=np.uint8)
     mg, _, _ = track_pose_update(none, out["found_pos"], out["image"], out["sqrt_inv_noise"], out["jacobian"])
     assert np.all(mg == 0)                                   # no measurements: zero update (Tracker.cc:1421-1422)
+
+
+def test_epipolar_hypotheses_batch(gpu_required, scene):
+    """SURVEY.md 8(f)-1: the map-side PatchFinder caller (MapMakerServerBase::AddPointEpipolar, :724-781) hands one point per
+    depth hypothesis to PatchFinder with range 3 and no sub-pixel step -- the same batch entry serves it."""
+    from mcptam_amd import synth_img
+    from mcptam_amd.keyframe import track_search
+    from oracle import oracle_track_search
+    gA, oA = _pair(640, 480)
+    gB, oB = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    gB.MakeKeyFrame_Lite(scene["imgB"]); oB.MakeKeyFrame_Lite(scene["imgB"])
+    gA.MakeKeyFrame_Rest(); oA.MakeKeyFrame_Rest()
+    cand, _ = gA.Candidates(1)
+    cand = cand[::max(1, len(cand)//25)][:25]
+    true_scale = []
+    pts, owner = [], []
+    ray_scales = np.linspace(3.0, 12.0, 31)
+    for ci, c in enumerate(cand):
+        ray = scene["cam"].unproject(np.array([[(c[0] + 0.5)*2 - 0.5, (c[1] + 0.5)*2 - 0.5]]))[0]
+        true_scale.append(scene["depth"]/ray[2])
+        for s_ in ray_scales:
+            pts.append(synth_img.hypothesis_point(scene["cam"], gA, oA, scene["poseA"], c, 1, s_))
+            owner.append(ci)
+    I = (np.eye(3), np.zeros(3))
+    og = track_search(gB, scene["cam"], scene["poseB"], I, pts, 3, 0)
+    oo = oracle_track_search(oB, scene["cam"], scene["poseB"], I, pts, 3, 0)
+    assert_track_equal(og, oo)
+    owner = np.array(owner)
+    good = 0
+    for ci in range(len(cand)):
+        m = (owner == ci) & (og["found"] == 1)
+        if not m.any():
+            continue
+        idx = np.nonzero(m)[0]
+        best = idx[np.argmin(og["score"][idx])]
+        k_true = ci*len(ray_scales) + int(np.argmin(np.abs(ray_scales - true_scale[ci])))
+        lvl = 1 << int(og["search_level"][best])
+        pred = og["image"][k_true]/lvl                      # where the true 3-D point projects, at the search level
+        if abs(og["coarse_x"][best] - pred[0]) <= 3.5 and abs(og["coarse_y"][best] - pred[1]) <= 3.5:
+            good += 1
+    assert good >= 0.6*len(cand)          # the best-scoring hypothesis locks onto the corner of the true 3-D point
