@@ -404,6 +404,28 @@ __global__ void k_schur_init(int np, double lambda, const double* __restrict__ U
   }
 }
 
+// gather (pack = 1) / scatter (pack = 0) of the structurally non-zero 32x32 tiles of the reduced system plus its
+// two trailing vectors [rhs | bp] (2*np doubles) to / from a contiguous buffer: the payload of the per-trial all-reduce.
+// block b < ntiles handles tile b, block ntiles handles the vectors.  `src`/`dst` roles swap with `pack`.
+__global__ void __launch_bounds__(256)
+k_pack_tiles(const double* __restrict__ src, int np, const int* __restrict__ tiles, int ntiles, double* __restrict__ dst, int pack) {
+  const int b = blockIdx.x;
+  if (b == ntiles) {
+    const size_t off_full = (size_t)np*np, off_pack = (size_t)ntiles*1024;
+    for (int i = threadIdx.x; i < 2*np; i += 256) {
+      if (pack) dst[off_pack + i] = src[off_full + i]; else dst[off_full + i] = src[off_pack + i];
+    }
+    return;
+  }
+  const int ti = tiles[b] >> 16, tj = tiles[b] & 0xffff;
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int r = 32*ti + (e >> 5), c = 32*tj + (e & 31);
+    if (r < np && c < np) {
+      if (pack) dst[(size_t)b*1024 + e] = src[(size_t)r*np + c]; else dst[(size_t)r*np + c] = src[(size_t)b*1024 + e];
+    } else if (pack) dst[(size_t)b*1024 + e] = 0.0;
+  }
+}
+
 // inverse of the symmetric 3x3 (V + lambda I); returns false if not positive definite
 __device__ inline bool inv_sym3(const double* V6, double lambda, double* I6) {
   const double a = V6[0] + lambda, b = V6[1], c = V6[2], d = V6[3] + lambda, e = V6[4], f = V6[5] + lambda;

@@ -110,7 +110,8 @@ struct mcp_ba {
   DevBuf<unsigned short> d_m_mask;
   DevBuf<double> d_m_u, d_m_v, d_m_omega;
   DevBuf<int> d_slot_start, d_slot_unk, d_slot_inc, d_l_i0, d_l_i1, d_inc_unk, d_fl_point;
-  DevBuf<int> d_sp_pt, d_sp_m, d_sp_i, d_m_sp, d_l_sp, d_g_sp0, d_g_pose;
+  DevBuf<int> d_sp_pt, d_sp_m, d_sp_i, d_m_sp, d_l_sp, d_g_sp0, d_g_pose, d_red_tiles;
+  DevBuf<double> d_pack; int n_red_tiles = 0;
   DevBuf<unsigned char> d_sp_big, d_slot_lp, d_slot_first, d_inc_lp, d_inc_mixed;
   int nsp = 0, ngroup = 0, nbig = 0;
   // state (double buffered: cur / trial)
@@ -390,8 +391,7 @@ int mcp_ba::prepare() {
   if (np > 0) {
     const int ntc = (np + CH_NB - 1)/CH_NB;
     std::vector<unsigned char> pat((size_t)ntc*ntc, 0);
-    if (multi()) std::fill(pat.begin(), pat.end(), 1);         // other ranks' points are unknown here: dense
-    else {
+    {
       std::vector<unsigned char> cov((size_t)nfp*nfp, 0);                  // pose-pair co-visibility, a >= b
       for (int sp = 0; sp < nsp; ++sp) {
         const std::vector<int>& q = sp_poses[sp];
@@ -402,6 +402,21 @@ int mcp_ba::prepare() {
         const int ra0 = (6*a)/CH_NB, ra1 = (6*a + 5)/CH_NB, rb0 = (6*b)/CH_NB, rb1 = (6*b + 5)/CH_NB;
         for (int ra = ra0; ra <= ra1; ++ra) for (int rb = rb0; rb <= rb1; ++rb) if (ra >= rb) pat[(size_t)ra*ntc + rb] = 1;
       }
+    }
+    for (int i = 0; i < ntc; ++i) pat[(size_t)i*ntc + i] = 1;
+    if (multi()) {
+      // the union of every rank's co-visibility pattern: agreed once, used for the factorisation plan and for the
+      // packed all-reduce of the reduced system (only structurally non-zero tiles travel over xGMI)
+      std::vector<double> pd(pat.begin(), pat.end());
+      DevBuf<double> tmp;
+      if (tmp.upload(pd, st)) return -1;
+      if (allreduce(tmp.p, pd.size(), true)) return -1;
+      HIPCK(hipMemcpy(pd.data(), tmp.p, pd.size()*sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < pd.size(); ++i) pat[i] = pd[i] > 0;
+      std::vector<int> rt;
+      for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (pat[(size_t)i*ntc + j]) rt.push_back((i << 16) | j);
+      n_red_tiles = (int)rt.size();
+      if (d_red_tiles.upload(rt, st) || d_pack.alloc((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np)) return -1;
     }
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
   }
@@ -573,7 +588,13 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
   if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
   if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
   toc();
-  if (np && allreduce(d_red.p, n2 + 2*(size_t)np)) return -1;
+  if (np && multi()) {
+    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
+    const size_t npack = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1);
+    if (allreduce(d_pack.p, npack)) return -1;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0);
+  }
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
   if (np) {
     tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p); toc();
