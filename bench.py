@@ -115,6 +115,13 @@ def main():
         except Exception as exc:
             if rank == 0:
                 print("bench: native RCCL communicator unavailable (%r); using the torch.distributed hook" % (exc,), file=sys.stderr)
+        # every rank must use the same transport: fall back together if any rank could not join
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
             hook = RcclAllReduce(dev)
             transport = "rccl via torch.distributed hook"
 

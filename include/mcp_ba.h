@@ -85,6 +85,8 @@ typedef struct mcp_ba_timing {
   double structure_ms;    /* host: initializeOptimization analogue + upload */
   double eval_ms, select_ms, linearize_ms, schur_ms, cholesky_ms, solve_ms, update_ms;
   int    n_linearize, n_trials;
+  int    n_solves;        /* reduced systems built + factored (a solve may carry a second, speculative lambda) */
+  int    n_spec_hits;     /* trials served by such a speculative solve */
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);

@@ -38,7 +38,8 @@ class McpBaTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("structure_ms", ctypes.c_double), ("eval_ms", ctypes.c_double),
                 ("select_ms", ctypes.c_double), ("linearize_ms", ctypes.c_double), ("schur_ms", ctypes.c_double),
                 ("cholesky_ms", ctypes.c_double), ("solve_ms", ctypes.c_double), ("update_ms", ctypes.c_double),
-                ("n_linearize", ctypes.c_int), ("n_trials", ctypes.c_int)]
+                ("n_linearize", ctypes.c_int), ("n_trials", ctypes.c_int), ("n_solves", ctypes.c_int),
+                ("n_spec_hits", ctypes.c_int)]
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)

@@ -83,7 +83,8 @@ __device__ inline void chol_acc_to_lds(double (*T)[CH_NB + 1], const chol_d4 acc
 }
 
 __global__ void __launch_bounds__(64)
-k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail) {
+k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride) {
+  if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; }     // further systems of a multi-lambda batch
   // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
   const int packed = tiles[blockIdx.x];
   const int ti = packed >> 16, tj = packed & 0xffff;
@@ -184,7 +185,8 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
 constexpr int CH_BACK_THREADS = 512;
 constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
 __global__ void __launch_bounds__(CH_BACK_THREADS)
-k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout) {
+k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout, size_t sys_stride) {
+  if (blockIdx.x) { S += blockIdx.x*sys_stride; xout += blockIdx.x*sys_stride; }
   extern __shared__ __attribute__((aligned(16))) double xs[];
   const int t = threadIdx.x;
   const double* y = S + (size_t)n*n;
@@ -278,18 +280,19 @@ struct CholPlan {
 };
 
 // factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
-inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail) {
+// nsys > 1 factors further systems stored q*sys_stride doubles behind the first in the same launches (fail[q] is their flag)
+inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0) {
   const int n = plan.n, nrows = n + 1;
   for (int k = 0; k < plan.ntc; ++k) {
     const int cnt = plan.step_start[k + 1] - plan.step_start[k];
-    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt), dim3(64), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail);
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(64), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride);
   }
 }
 // row n: y -> x = L^-T y
-inline void chol_back(hipStream_t st, const CholPlan& plan, double* S) {
+inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0) {
   const int n = plan.n;
-  hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
-                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n);
+  hipLaunchKernelGGL(k_chol_back, dim3(nsys), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
+                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride);
 }
 
 }  // namespace mcp

@@ -265,7 +265,8 @@ typedef double sch_d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
               const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
-              double* __restrict__ rhs, int* __restrict__ fail) {
+              double* __restrict__ rhs, int* __restrict__ fail, SysBatch sb) {
+  if (blockIdx.y) { const int q = blockIdx.y; lambda = sb.lambda[q]; Vinv += q*sb.vstride; S += q*sb.sstride; rhs += q*sb.sstride; fail += q; }
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* Yd = lds;                            // [GRP_DOF][SCH_LD]
   double* Wd = lds + GRP_DOF*SCH_LD;           // [GRP_DOF][SCH_LD]

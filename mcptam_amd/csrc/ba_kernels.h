@@ -391,9 +391,18 @@ k_max_diag(int np, const double* __restrict__ U, int stride, int nfl, const doub
   if (threadIdx.x == 0) out[0] = t;
 }
 
+// A trial solve can carry speculative systems: the same linearisation damped with the lambdas the LM schedule will use
+// next if this trial (and the following ones) are rejected (lambda*ni, lambda*ni*2ni, ...).  Kernels that build or factor
+// the reduced system take the batch index q from blockIdx.y; system q lives q*sstride doubles behind system 0 in the
+// [S | rhs | bp] buffer, its V^-1 blocks q*vstride doubles behind in Vinv, its failure flag in fail[q].
+constexpr int MAX_SYS = 4;
+struct SysBatch { double lambda[MAX_SYS]; double lambda_init[MAX_SYS]; size_t sstride; size_t vstride; };
+
 // S = U (+ lambda on the diagonal), rhs = bp.   Lower triangle only is meaningful.
+// blockIdx.y selects the system of a two-lambda batch (SysBatch, below).
 __global__ void k_schur_init(int np, double lambda, const double* __restrict__ U, const double* __restrict__ bp,
-                             double* __restrict__ S, double* __restrict__ rhs) {
+                             double* __restrict__ S, double* __restrict__ rhs, SysBatch sb) {
+  if (blockIdx.y) { lambda = sb.lambda_init[blockIdx.y]; S += blockIdx.y*sb.sstride; rhs += blockIdx.y*sb.sstride; }
   const size_t n2 = (size_t)np*np;
   for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x*blockDim.x) {
     const int r = (int)(i / np), c = (int)(i % np);
@@ -408,7 +417,9 @@ __global__ void k_schur_init(int np, double lambda, const double* __restrict__ U
 // two trailing vectors [rhs | bp] (2*np doubles) to / from a contiguous buffer: the payload of the per-trial all-reduce.
 // block b < ntiles handles tile b, block ntiles handles the vectors.  `src`/`dst` roles swap with `pack`.
 __global__ void __launch_bounds__(256)
-k_pack_tiles(const double* __restrict__ src, int np, const int* __restrict__ tiles, int ntiles, double* __restrict__ dst, int pack) {
+k_pack_tiles(const double* __restrict__ src, int np, const int* __restrict__ tiles, int ntiles, double* __restrict__ dst, int pack,
+             size_t full_stride, size_t pack_stride) {
+  if (blockIdx.y) { src += blockIdx.y*(pack ? full_stride : pack_stride); dst += blockIdx.y*(pack ? pack_stride : full_stride); }
   const int b = blockIdx.x;
   if (b == ntiles) {
     const size_t off_full = (size_t)np*np, off_pack = (size_t)ntiles*1024;
@@ -443,7 +454,8 @@ __device__ inline bool inv_sym3(const double* V6, double lambda, double* I6) {
 __global__ void __launch_bounds__(256)
 k_schur(DevProblem P, int only_big, double lambda, const double* __restrict__ V, const double* __restrict__ g,
         const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
-        double* __restrict__ rhs, int* __restrict__ fail) {
+        double* __restrict__ rhs, int* __restrict__ fail, SysBatch sb) {
+  if (blockIdx.y) { const int q = blockIdx.y; lambda = sb.lambda[q]; Vinv += q*sb.vstride; S += q*sb.sstride; rhs += q*sb.sstride; fail += q; }
   const int l = blockIdx.x*4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (l >= P.nfl) return;

@@ -157,8 +157,14 @@ struct mcp_ba {
 
   double* U() { return d_lin.p; }
   double* bp() { return d_lin.p + (size_t)np*np; }
-  double* S() { return d_red.p; }
-  double* rhs() { return d_red.p + (size_t)np*np; }
+  // multi-lambda batch (ba_kernels.h SysBatch): systems 1.. are speculative solves for the next lambdas of the LM
+  // schedule.  S()/rhs()/Vinv() address the system the latest trial used.
+  size_t red_stride = 0, vinv_stride = 0, pack_stride = 0;
+  int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
+  int speculate = 3;                 // speculative systems per solve; MCP_BA_SPECULATE=0 turns them off
+  double* S() { return d_red.p + sys_cur*red_stride; }
+  double* rhs() { return S() + (size_t)np*np; }
+  double* Vinv() { return d_Vinv.p + sys_cur*vinv_stride; }
 
   hipEvent_t get_event() {
     if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
@@ -225,7 +231,7 @@ struct mcp_ba {
   int median_sigma(int which);
   int read_results(int count);
   int linearize();
-  int solve_trial(double lam, bool& ok2);
+  int solve_trial(double lam, bool& ok2, double ni = 0);
   int compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda);
   int final_stats(int nCounter);
 };
@@ -416,7 +422,8 @@ int mcp_ba::prepare() {
       std::vector<int> rt;
       for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (pat[(size_t)i*ntc + j]) rt.push_back((i << 16) | j);
       n_red_tiles = (int)rt.size();
-      if (d_red_tiles.upload(rt, st) || d_pack.alloc((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np)) return -1;
+      if (d_red_tiles.upload(rt, st) || d_pack.alloc(MAX_SYS*((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np))) return -1;
+      pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
     }
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
   }
@@ -457,8 +464,10 @@ int mcp_ba::prepare() {
         d_second[b].alloc(nc*4*9) || d_last[b].alloc(nc*12) || d_chi2[b].alloc(nmeas)) return -1;
   const size_t n2 = (size_t)np*np;
   const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
-  if (d_lin.alloc(n2 + np) || d_red.alloc(n2 + 2*(size_t)np) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
-      d_W.alloc((size_t)ninc*18) || d_Vinv.alloc((size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
+  red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
+  { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
+  if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
+      d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
@@ -544,13 +553,14 @@ int mcp_ba::median_sigma(int w) {
 }
 int mcp_ba::read_results(int count) {
   HIPCK(hipMemcpyAsync(h_res, d_res.p, count*sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCK(hipMemcpyAsync(h_fail, d_fail.p + sys_cur, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCK(hipStreamSynchronize(st));
   return 0;
 }
 
 // buildSystem at the current state (sigma block must be current)
 int mcp_ba::linearize() {
+  spec_ok = false;                   // a speculative solve belongs to the linearisation it was built from
   tic(ST_LIN);
   const size_t n2 = (size_t)np*np;
   HIPCK(hipMemsetAsync(d_lin.p, 0, (n2 + np)*sizeof(double), st));
@@ -573,37 +583,53 @@ int mcp_ba::linearize() {
 
 // one LM trial up to and including the evaluation of the trial state.
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
-int mcp_ba::solve_trial(double lam, bool& ok2) {
+int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const size_t n2 = (size_t)np*np;
   const int tr = cur ^ 1;
-  HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-  tic(ST_SCHUR);
-  if (np) {
-    // every rank contributes U_r - Schur_r (+ lambda I once, on rank 0), bp_r - W V^-1 g, and bp_r
-    const double lam_here = (rank == 0) ? lam : 0.0;
-    const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
-    hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, lam_here, U(), bp(), S(), rhs());
-    if (world > 1) HIPCK(hipMemcpyAsync(rhs() + np, bp(), np*sizeof(double), hipMemcpyDeviceToDevice, st));
-  }
-  if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
-  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
-  toc();
-  if (np && multi()) {
-    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
-    const size_t npack = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1);
-    if (allreduce(d_pack.p, npack)) return -1;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0);
+  if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
+    // an earlier trial of this iteration already built and solved this system speculatively
+    ++sys_cur;
+    timing.n_spec_hits++;
+  } else {
+    sys_cur = 0;
+    // the lambdas of the rejection branch of the LM schedule: lambda *= ni; ni *= 2 (same operations as compute())
+    const int nsys = (ni > 0) ? 1 + std::max(0, std::min(speculate, MAX_SYS - 1)) : 1;
+    SysBatch sb; std::memset(&sb, 0, sizeof sb);
+    sb.sstride = red_stride; sb.vstride = vinv_stride;
+    { double l = lam, f = ni; for (int q = 0; q < nsys; ++q) { batch_lambda[q] = sb.lambda[q] = l; sb.lambda_init[q] = (rank == 0) ? l : 0.0; l *= f; f *= 2; } }
+    batch_n = nsys;
+    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    tic(ST_SCHUR);
+    if (np) {
+      // every rank contributes U_r - Schur_r (+ lambda I once, on rank 0), bp_r - W V^-1 g, and bp_r
+      const double lam_here = (rank == 0) ? lam : 0.0;
+      const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
+      hipLaunchKernelGGL(k_schur_init, dim3(g, nsys), dim3(256), 0, st, np, lam_here, U(), bp(), S(), rhs(), sb);
+      if (world > 1) for (int q = 0; q < nsys; ++q)
+        HIPCK(hipMemcpyAsync(rhs() + q*red_stride + np, bp(), np*sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
+    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
+    toc();
+    if (np && multi()) {
+      // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
+      const size_t npack = pack_stride*nsys;
+      hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
+      if (allreduce(d_pack.p, npack)) return -1;
+      hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0, red_stride, pack_stride);
+    }
+    if (np) {
+      tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); toc();
+      tic(ST_SOLVE); chol_back(st, plan, S(), nsys, red_stride); toc();
+    }
+    spec_ok = (nsys > 1);
+    timing.n_solves++;
   }
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
-  if (np) {
-    tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p); toc();
-    tic(ST_SOLVE); chol_back(st, plan, S()); toc();
-  }
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6);
   const int nbb = (nfl + BS_BLOCK - 1)/BS_BLOCK;
-  if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, d_Vinv.p,
+  if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
   toc();
   tic(ST_EVAL);
@@ -611,7 +637,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2) {
   launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
-                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p);
+                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur);
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
   if (allreduce(d_res.p, 4)) return -1;          // robust chi2, point parts of the step statistics, failure flag (any rank)
@@ -683,7 +709,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       double rho = 0; int qmax = 0; int accepted = 0; double ss_last = 0; double trial_chi_raw = currentChi;
       do {
         bool ok2 = true;
-        if (solve_trial(lambda, ok2)) return -1;
+        if (solve_trial(lambda, ok2, ni)) return -1;
         double scale, ss;
         trial_chi_raw = h_res[0];
         if (ok2) {
@@ -804,14 +830,16 @@ int mcp_ba::final_stats(int nCounter) {
   // depth covariance only when fewer than 3 free poses (:1419); Hessian of the last buildSystem, no lambda
   if (nfp < 3 && nCounter > 0 && world == 1) {
     bool okm = true;
+    sys_cur = 0; spec_ok = false;
+    SysBatch sb; std::memset(&sb, 0, sizeof sb); sb.sstride = red_stride; sb.vstride = vinv_stride;
     HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
     const size_t n2 = (size_t)np*np;
     if (np) {
       const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
-      hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, 0.0, U(), bp(), S(), rhs());
+      hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, 0.0, U(), bp(), S(), rhs(), sb);
     }
-    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
-    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p);
+    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
+    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
     std::vector<double> Sh(n2 + 1), Sinv(n2 + 1, 0.0);
     if (np) HIPCK(hipMemcpyAsync(Sh.data(), S(), n2*8, hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
