@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 namespace mcp {
@@ -29,60 +30,121 @@ __device__ inline double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 32x32 tile (rows r0.., cols c0..) -> 16 registers per lane (zero outside [nrows) x [ncols)); issuing the
+constexpr int CH_STEP_THREADS = 256;    // 4 wavefronts load and multiply; wavefront 0 alone runs the panel factorisation
+
+// 32x32 tile (rows r0.., cols c0..) -> 4 registers per thread (zero outside [nrows) x [ncols)); issuing the
 // global loads of ALL tiles of a step before the first LDS write keeps them in flight together (one memory
 // round trip per step instead of one per tile)
 __device__ inline void chol_load_tile_regs(const double* __restrict__ A, int ld, int nrows, int ncols, int r0, int c0, double* v) {
-  const int lane = threadIdx.x;
-  const int c = lane & 31, rb = lane >> 5;
+  const int t = threadIdx.x;
+  const int c = t & 31, rb = t >> 5;          // rb 0..7
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = 2*i + rb;
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8*i + rb;
     v[i] = (r0 + r < nrows && c0 + c < ncols) ? A[(size_t)(r0 + r)*ld + c0 + c] : 0.0;
   }
 }
 __device__ inline void chol_regs_to_lds(const double* v, double (*T)[CH_NB + 1]) {
-  const int lane = threadIdx.x;
-  const int c = lane & 31, rb = lane >> 5;
+  const int t = threadIdx.x;
+  const int c = t & 31, rb = t >> 5;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) T[2*i + rb][c] = v[i];
+  for (int i = 0; i < 4; ++i) T[8*i + rb][c] = v[i];
 }
 
-// acc(2x2 MFMA tiles, C/D layout) -= Pi * Pj^T over K = 32
-__device__ inline void chol_tile_mma(double (*Pi)[CH_NB + 1], double (*Pj)[CH_NB + 1], chol_d4 acc[2][2]) {
-  const int lane = threadIdx.x;
-  const int i = lane & 15, kq = lane >> 4;
+// one 16x16 quadrant (bi, bj) per wavefront:  acc (C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15,
+// row = (lane >> 4) + 4*reg)  =  T[quadrant] - Pi[16 bi ..] Pj[16 bj ..]^T  over K = 32
+__device__ inline void chol_quadrant_update(double (*T)[CH_NB + 1], double (*Pi)[CH_NB + 1], double (*Pj)[CH_NB + 1], bool mma, chol_d4& acc) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bi = w >> 1, bj = w & 1;
+  const int c = lane & 15, rq = lane >> 4;
 #pragma unroll
-  for (int kk = 0; kk < CH_NB; kk += 4) {
-    const double a0 = -Pi[i][kk + kq], a1 = -Pi[16 + i][kk + kq];
-    const double b0 = Pj[i][kk + kq], b1 = Pj[16 + i][kk + kq];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  for (int g = 0; g < 4; ++g) acc[g] = T[16*bi + rq + 4*g][16*bj + c];
+  if (mma) {
+#pragma unroll
+    for (int kk = 0; kk < CH_NB; kk += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pi[16*bi + c][kk + rq], Pj[16*bj + c][kk + rq], acc, 0, 0, 0);
   }
 }
-// C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4*reg
-__device__ inline void chol_acc_from_lds(double (*T)[CH_NB + 1], chol_d4 acc[2][2]) {
-  const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
+__device__ inline void chol_quadrant_store(double (*T)[CH_NB + 1], const chol_d4& acc) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int bi = w >> 1, bj = w & 1;
+  const int c = lane & 15, rq = lane >> 4;
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[bi][bj][g] = T[16*bi + rq + 4*g][16*bj + c];
-}
-__device__ inline void chol_acc_to_lds(double (*T)[CH_NB + 1], const chol_d4 acc[2][2]) {
-  const int lane = threadIdx.x, c = lane & 15, rq = lane >> 4;
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) T[16*bi + rq + 4*g][16*bj + c] = acc[bi][bj][g];
+  for (int g = 0; g < 4; ++g) T[16*bi + rq + 4*g][16*bj + c] = acc[g];
 }
 
-__global__ void __launch_bounds__(64)
+// One pivot of the panel factorisation, software-pipelined with the next one.  Column J+1 is updated first and its
+// pivot's reciprocal square root (a chain of dependent instructions: v_rsq_f64 + one third-order refinement) is spread
+// over eight slots; each slot also carries an eighth of pivot J's remaining rank-1 updates (the v_readlane pairs of the
+// next eighth, the FMAs of the current one), which are independent of the chain and hide its latency.
+// sched_barrier pins the slot order.  On entry inv belongs to pivot J, on exit to pivot J+1.
+template <int J, int G> struct ChSlot {
+  static constexpr int lo = J + 2 + ((CH_NB - J - 2)*G)/8, hi = J + 2 + ((CH_NB - J - 2)*(G + 1))/8;
+  static __device__ inline void rl(const double* d, double* lc) {
+#pragma unroll
+#if defined(CHOL_ABL) && (CHOL_ABL == 2 || CHOL_ABL == 3)
+    for (int c = lo; c < hi; ++c) lc[c] = d[J];
+#else
+    for (int c = lo; c < hi; ++c) lc[c] = readlane_f64(d[J], c);
+#endif
+  }
+  static __device__ inline void fm(double* d, const double* lc) {
+#pragma unroll
+#if defined(CHOL_ABL) && CHOL_ABL == 1
+    for (int c = lo; c < hi; ++c) asm volatile("" :: "s"(lc[c]));
+#elif defined(CHOL_ABL) && CHOL_ABL == 3
+    for (int c = lo; c < hi; ++c) asm volatile("" :: "v"(lc[c]));
+#else
+    for (int c = lo; c < hi; ++c) d[c] -= d[J]*lc[c];          // entries above the diagonal: unused garbage
+#endif
+  }
+};
+#define CH_SB() __builtin_amdgcn_sched_barrier(0)
+template <int J>
+__device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad) {
+  double lc[CH_NB];                       // column J of L_kk, broadcast (uniform values)
+  d[J] *= inv;                            // lane J holds the pivot itself: pivot * rsqrt(pivot) = L_JJ
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J + 1 < CH_NB) {
+    // the next pivot, lane-locally: on lane J+1, d[J+1] - d[J]^2 is the updated diagonal entry
+    const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
+    const double l1 = readlane_f64(d[J], J + 1);
+    ChSlot<J, 0>::rl(d, lc);
+    CH_SB();
+    const double pn = readlane_f64(w, J + 1);
+    bad |= !(pn > 0.0);                    // off the critical path: a failed factorisation is flagged, its numbers are not used
+    ChSlot<J, 1>::rl(d, lc);
+    CH_SB();
+    // slot g: chain instruction, readlanes two slots ahead (a VALU write of an SGPR takes a while to reach a VALU reader), FMAs
+    const double y0 = __builtin_amdgcn_rsq(pn);
+    CH_SB(); ChSlot<J, 2>::rl(d, lc); CH_SB(); d[J + 1] -= d[J]*l1; ChSlot<J, 0>::fm(d, lc); CH_SB();
+    const double t = y0*(-pn);
+    CH_SB(); ChSlot<J, 3>::rl(d, lc); CH_SB(); ChSlot<J, 1>::fm(d, lc); CH_SB();
+    const double e = __builtin_fma(t, y0, 1.0);
+    CH_SB(); ChSlot<J, 4>::rl(d, lc); CH_SB(); ChSlot<J, 2>::fm(d, lc); CH_SB();
+    const double u = y0*e;
+    const double q = __builtin_fma(e, 0.375, 0.5);
+    CH_SB(); ChSlot<J, 5>::rl(d, lc); CH_SB(); ChSlot<J, 3>::fm(d, lc); CH_SB();
+    inv = __builtin_fma(u, q, y0);         // rsqrt(pn): v_rsq_f64 + one third-order correction
+    CH_SB(); ChSlot<J, 6>::rl(d, lc); CH_SB(); ChSlot<J, 4>::fm(d, lc); CH_SB();
+    ChSlot<J, 7>::rl(d, lc); CH_SB(); ChSlot<J, 5>::fm(d, lc); CH_SB();
+    ChSlot<J, 6>::fm(d, lc); ChSlot<J, 7>::fm(d, lc);
+    CH_SB();
+  }
+}
+#undef CH_SB
+template <int... Js>
+__device__ inline void chol_panel_pivots(double* d, double& inv, bool& bad, std::integer_sequence<int, Js...>) {
+  (chol_panel_pivot<Js>(d, inv, bad), ...);
+}
+
+#ifdef MCP_CHOL_PROF
+__device__ unsigned long long g_chol_prof[256*2*8];
+#define CHOL_STAMP(i) do { if (blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) g_chol_prof[(k*2 + blockIdx.x)*8 + (i)] = clock64(); } while (0)
+#else
+#define CHOL_STAMP(i) do {} while (0)
+#endif
+__global__ void __launch_bounds__(CH_STEP_THREADS)
 k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride) {
   if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; }     // further systems of a multi-lambda batch
   // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
@@ -96,9 +158,10 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   const int lane = threadIdx.x;
   const int r0 = ti*CH_NB, c0 = tj*CH_NB, k0 = k*CH_NB, p0 = (k - 1)*CH_NB;
   const bool panel = (tj == k), offdiag = (ti != k);
+  CHOL_STAMP(0);
   // ---- all global loads up front: own tile, the two tiles of panel k-1, and (block column k) the diagonal tile
   {
-    double vc[16], va[16], vb[16], vd[16], ve[16];
+    double vc[4], va[4], vb[4], vd[4], ve[4];
     chol_load_tile_regs(S, n, nrows, n, r0, c0, vc);
     if (k > 0) {
       chol_load_tile_regs(S, n, nrows, n, r0, p0, va);
@@ -113,27 +176,24 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     if (panel && offdiag) { chol_regs_to_lds(vd, Td); if (k > 0) chol_regs_to_lds(ve, Te); }
   }
   __syncthreads();
-  chol_d4 acc[2][2];
-  chol_acc_from_lds(Tc, acc);
-  if (k > 0) chol_tile_mma(Ta, Tb, acc);
-  chol_d4 dacc[2][2];
-  if (panel && offdiag) {
-    chol_acc_from_lds(Td, dacc);
-    if (k > 0) chol_tile_mma(Te, Te, dacc);
-  }
+  CHOL_STAMP(1);
+  chol_d4 acc, dacc;
+  chol_quadrant_update(Tc, Ta, Tb, k > 0, acc);
+  if (panel && offdiag) chol_quadrant_update(Td, Te, Te, k > 0, dacc);
+  chol_quadrant_store(Tc, acc);                 // each wavefront reads and writes only its own quadrant of Tc / Td
+  if (panel && offdiag) chol_quadrant_store(Td, dacc);
   __syncthreads();
-  chol_acc_to_lds(Tc, acc);
-  if (panel && offdiag) chol_acc_to_lds(Td, dacc);
-  __syncthreads();
+  CHOL_STAMP(2);
   if (!panel) {      // plain trailing tile: write back and leave
     const int c = lane & 31, rb = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = 2*i + rb;
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8*i + rb;
       if (r0 + r < nrows && c0 + c < n && (ti > tj || c <= r)) S[(size_t)(r0 + r)*n + c0 + c] = Tc[r][c];
     }
     return;
   }
+  if (lane >= 64) return;      // the panel factorisation is one wavefront's job (no barrier below this line)
   // ---- block column k: unblocked panel factorisation of [diagonal tile ; own tile], one row per lane.
   // lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the own tile (for the diagonal
   // block itself: only rows beyond the matrix, i.e. the right-hand-side row).  Applying the column operations
@@ -151,22 +211,11 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) d[c] = (use && c < nbe) ? Tc[rr][c] : 0.0;
   }
-  bool bad = false;
-#pragma unroll
-  for (int j = 0; j < CH_NB; ++j) {
-    double piv = readlane_f64(d[j], j);
-    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-    const double inv = rsqrt(piv);
-    d[j] = (lane == j) ? piv*inv : d[j]*inv;
-    // broadcast column j of L_kk (independent v_readlane pairs), then the rank-1 update of the remaining columns
-    double lc[CH_NB];
-#pragma unroll
-    for (int c = j + 1; c < CH_NB; ++c) lc[c] = readlane_f64(d[j], c);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = j + 1; c < CH_NB; ++c) d[c] -= d[j]*lc[c];    // entries above the diagonal: unused garbage
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  const double piv0 = readlane_f64(d[0], 0);
+  bool bad = !(piv0 > 0.0);
+  double inv = rsqrt(piv0);
+  chol_panel_pivots(d, inv, bad, std::make_integer_sequence<int, CH_NB>());
+  CHOL_STAMP(3);
   if (bad && lane == 0) atomicOr(fail, 2);
   if (!low) {
     if (!offdiag && lane < nbe) {
@@ -179,6 +228,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) if (c < nbe) p[c] = d[c];
   }
+  CHOL_STAMP(4);
 }
 
 // backward substitution L^T x = y (y = row n of the augmented matrix); single workgroup.
@@ -285,7 +335,7 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
   const int n = plan.n, nrows = n + 1;
   for (int k = 0; k < plan.ntc; ++k) {
     const int cnt = plan.step_start[k + 1] - plan.step_start[k];
-    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(64), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride);
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride);
   }
 }
 // row n: y -> x = L^-T y

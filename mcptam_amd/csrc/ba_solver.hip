@@ -1094,7 +1094,34 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
   HIPCK(hipMemset(f.p, 0, 16));
   CholPlan plan;
   if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_dense_spd_solve: plan allocation failed"); return -1; }
+#ifdef MCP_CHOL_PROF
+  {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    chol_factor(nullptr, plan, d.p, f.p);      // warm
+    HIPCK(hipMemcpy(d.p, A, (size_t)n*n*8, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
+    HIPCK(hipMemset(f.p, 0, 16));
+    hipEventRecord(e0, nullptr);
+  }
+#endif
   chol_factor(nullptr, plan, d.p, f.p);
+#ifdef MCP_CHOL_PROF
+  {
+    hipEvent_t e1; hipEventCreate(&e1); hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
+    std::vector<unsigned long long> pr(256*2*8);
+    hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_chol_prof), pr.size()*8);
+    const int ntc = plan.ntc;
+    double acc[2][4] = {{0}}; double gap = 0; int cnt = 0;
+    for (int k = 2; k + 2 < ntc; ++k) for (int b2 = 0; b2 < 2; ++b2) {
+      const unsigned long long* q = &pr[(k*2 + b2)*8];
+      for (int i = 0; i < 4; ++i) acc[b2][i] += (double)(q[i + 1] - q[i]);
+      if (b2 == 1) { gap += (double)(pr[((k + 1)*2 + 1)*8] - q[4]); ++cnt; }
+    }
+    fprintf(stderr, "[chol prof] n=%d steps=%d clock64 ticks per phase (avg over %d steps)\n", n, ntc, cnt);
+    for (int b2 = 0; b2 < 2; ++b2) fprintf(stderr, "  block %d: load %.0f  mfma %.0f  panel %.0f  store %.0f\n", b2, acc[b2][0]/cnt, acc[b2][1]/cnt, acc[b2][2]/cnt, acc[b2][3]/cnt);
+    fprintf(stderr, "  end(k) -> start(k+1) gap %.0f ticks; total first->last %.0f ticks\n", gap/cnt, (double)(pr[((ntc - 3)*2 + 1)*8] - pr[(2*2 + 1)*8]));
+  }
+#endif
   chol_back(nullptr, plan, d.p);
   int fl = 0;
   HIPCK(hipMemcpy(&fl, f.p, 4, hipMemcpyDeviceToHost));
