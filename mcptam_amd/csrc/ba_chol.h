@@ -73,69 +73,69 @@ __device__ inline void chol_quadrant_store(double (*T)[CH_NB + 1], const chol_d4
   for (int g = 0; g < 4; ++g) T[16*bi + rq + 4*g][16*bj + c] = acc[g];
 }
 
-// One pivot of the panel factorisation, software-pipelined with the next one.  Column J+1 is updated first and its
-// pivot's reciprocal square root (a chain of dependent instructions: v_rsq_f64 + one third-order refinement) is spread
-// over eight slots; each slot also carries an eighth of pivot J's remaining rank-1 updates (the v_readlane pairs of the
-// next eighth, the FMAs of the current one), which are independent of the chain and hide its latency.
-// sched_barrier pins the slot order.  On entry inv belongs to pivot J, on exit to pivot J+1.
-template <int J, int G> struct ChSlot {
-  static constexpr int lo = J + 2 + ((CH_NB - J - 2)*G)/8, hi = J + 2 + ((CH_NB - J - 2)*(G + 1))/8;
-  static __device__ inline void rl(const double* d, double* lc) {
+// ---- panel factorisation: one row per lane, columns in registers, software-pipelined over the pivots -------------
+// Column K of L (final after the scaling at pivot K) updates the columns to its right in two ways:
+//   * fast path, at pivot K, for columns K+1 and K+2: the two multipliers are fetched with v_readlane.  This is
+//     what the next pivot's critical path needs (its diagonal entry, then its reciprocal square root: v_rsq_f64 +
+//     one third-order correction, a chain of dependent fp64 instructions);
+//   * bulk, at pivot K+1, for columns >= K+3: the lanes of the diagonal tile write column K to LDS and every lane
+//     reads the multipliers back with broadcast ds_read (uniform address, no VALU issue slots -- a v_readlane
+//     pair per multiplier costs as much issue time as the fp64 FMA it feeds).  The reads are issued at pivot K and
+//     consumed one pivot later, interleaved with the dependency chain of pivot K+1, so neither the LDS round trip
+//     nor the chain latency is exposed.
+// Every d[c] still receives its updates in column order, so the arithmetic is that of the plain right-looking loop.
+#define CH_SB() __builtin_amdgcn_sched_barrier(0)
+template <int K, int G> struct ChBulk {        // group G (of 6) of the bulk update by column K: columns [lo, hi)
+  static constexpr int n = (CH_NB - K - 3 > 0) ? CH_NB - K - 3 : 0;
+  static constexpr int lo = K + 3 + (n*G)/6, hi = K + 3 + (n*(G + 1))/6;
+  static __device__ inline void fm(double* d, const double* m) {
 #pragma unroll
-#if defined(CHOL_ABL) && (CHOL_ABL == 2 || CHOL_ABL == 3)
-    for (int c = lo; c < hi; ++c) lc[c] = d[J];
-#else
-    for (int c = lo; c < hi; ++c) lc[c] = readlane_f64(d[J], c);
-#endif
-  }
-  static __device__ inline void fm(double* d, const double* lc) {
-#pragma unroll
-#if defined(CHOL_ABL) && CHOL_ABL == 1
-    for (int c = lo; c < hi; ++c) asm volatile("" :: "s"(lc[c]));
-#elif defined(CHOL_ABL) && CHOL_ABL == 3
-    for (int c = lo; c < hi; ++c) asm volatile("" :: "v"(lc[c]));
-#else
-    for (int c = lo; c < hi; ++c) d[c] -= d[J]*lc[c];          // entries above the diagonal: unused garbage
-#endif
+    for (int c = lo; c < hi; ++c) d[c] -= d[K]*m[c];          // entries above the diagonal: unused garbage
   }
 };
-#define CH_SB() __builtin_amdgcn_sched_barrier(0)
 template <int J>
-__device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad) {
-  double lc[CH_NB];                       // column J of L_kk, broadcast (uniform values)
-  d[J] *= inv;                            // lane J holds the pivot itself: pivot * rsqrt(pivot) = L_JJ
-  __builtin_amdgcn_sched_barrier(0);
+__device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf) {
+  double* cur = (J & 1) ? mO : mE;          // multipliers of column J (requested here, used at pivot J+1)
+  double* prev = (J & 1) ? mE : mO;         // multipliers of column J-1
+  d[J] *= inv;                              // lane J holds the pivot itself: pivot * rsqrt(pivot) = L_JJ
+  if constexpr (J + 3 < CH_NB) colbuf[threadIdx.x] = d[J];
+  CH_SB();
   if constexpr (J + 1 < CH_NB) {
     // the next pivot, lane-locally: on lane J+1, d[J+1] - d[J]^2 is the updated diagonal entry
     const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
     const double l1 = readlane_f64(d[J], J + 1);
-    ChSlot<J, 0>::rl(d, lc);
-    CH_SB();
+    double l2 = 0.0;
+    if constexpr (J + 2 < CH_NB) l2 = readlane_f64(d[J], J + 2);
     const double pn = readlane_f64(w, J + 1);
-    bad |= !(pn > 0.0);                    // off the critical path: a failed factorisation is flagged, its numbers are not used
-    ChSlot<J, 1>::rl(d, lc);
+    bad |= !(pn > 0.0);                     // off the critical path: a failed factorisation is flagged, its numbers are not used
+    if constexpr (J + 3 < CH_NB) {
+#pragma unroll
+      for (int c = J + 3; c < CH_NB; ++c) cur[c] = colbuf[c];
+    }
     CH_SB();
-    // slot g: chain instruction, readlanes two slots ahead (a VALU write of an SGPR takes a while to reach a VALU reader), FMAs
     const double y0 = __builtin_amdgcn_rsq(pn);
-    CH_SB(); ChSlot<J, 2>::rl(d, lc); CH_SB(); d[J + 1] -= d[J]*l1; ChSlot<J, 0>::fm(d, lc); CH_SB();
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 0>::fm(d, prev); CH_SB();
     const double t = y0*(-pn);
-    CH_SB(); ChSlot<J, 3>::rl(d, lc); CH_SB(); ChSlot<J, 1>::fm(d, lc); CH_SB();
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 1>::fm(d, prev); CH_SB();
     const double e = __builtin_fma(t, y0, 1.0);
-    CH_SB(); ChSlot<J, 4>::rl(d, lc); CH_SB(); ChSlot<J, 2>::fm(d, lc); CH_SB();
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 2>::fm(d, prev); CH_SB();
     const double u = y0*e;
     const double q = __builtin_fma(e, 0.375, 0.5);
-    CH_SB(); ChSlot<J, 5>::rl(d, lc); CH_SB(); ChSlot<J, 3>::fm(d, lc); CH_SB();
-    inv = __builtin_fma(u, q, y0);         // rsqrt(pn): v_rsq_f64 + one third-order correction
-    CH_SB(); ChSlot<J, 6>::rl(d, lc); CH_SB(); ChSlot<J, 4>::fm(d, lc); CH_SB();
-    ChSlot<J, 7>::rl(d, lc); CH_SB(); ChSlot<J, 5>::fm(d, lc); CH_SB();
-    ChSlot<J, 6>::fm(d, lc); ChSlot<J, 7>::fm(d, lc);
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 3>::fm(d, prev); CH_SB();
+    inv = __builtin_fma(u, q, y0);          // rsqrt(pn)
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 4>::fm(d, prev); CH_SB();
+    d[J + 1] -= d[J]*l1;
+    if constexpr (J >= 1) ChBulk<J - 1, 5>::fm(d, prev);
+    CH_SB();
+    if constexpr (J + 2 < CH_NB) d[J + 2] -= d[J]*l2;      // after the bulk update of d[J+2] by column J-1 (group 0)
     CH_SB();
   }
 }
 #undef CH_SB
 template <int... Js>
-__device__ inline void chol_panel_pivots(double* d, double& inv, bool& bad, std::integer_sequence<int, Js...>) {
-  (chol_panel_pivot<Js>(d, inv, bad), ...);
+__device__ inline void chol_panel_pivots(double* d, double& inv, bool& bad, double* colbuf, std::integer_sequence<int, Js...>) {
+  double mE[CH_NB], mO[CH_NB];
+  (chol_panel_pivot<Js>(d, inv, bad, mE, mO, colbuf), ...);
 }
 
 #ifdef MCP_CHOL_PROF
@@ -214,7 +214,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   const double piv0 = readlane_f64(d[0], 0);
   bool bad = !(piv0 > 0.0);
   double inv = rsqrt(piv0);
-  chol_panel_pivots(d, inv, bad, std::make_integer_sequence<int, CH_NB>());
+  chol_panel_pivots(d, inv, bad, &Ta[0][0], std::make_integer_sequence<int, CH_NB>());     // Ta is free now: column buffer
   CHOL_STAMP(3);
   if (bad && lane == 0) atomicOr(fail, 2);
   if (!low) {
