@@ -83,6 +83,8 @@ class Problem:
     true_base_R: np.ndarray = None
     true_base_t: np.ndarray = None
     true_world: np.ndarray = None   # (N,3)
+    rel_R: np.ndarray = None        # (C,3,3) calib mode: Cam_c-from-Cam_0 (initial, perturbed); entry 0 is the identity
+    rel_t: np.ndarray = None        # (C,3)
     ids: dict = field(default_factory=dict)
 
     @property
@@ -108,6 +110,15 @@ class Problem:
                 if k == 0:
                     for c in range(C):
                         cam_id[c] = bundle.AddPose(self.cam_R[c], self.cam_t[c], True)
+        elif self.mode == "calib":
+            # BundleAdjusterCalib.cc:118-146: the free relative camera poses first (the first camera is the identity
+            # and is skipped), then one pose per MKF = the first KeyFrame's CamFromWorld
+            for c in range(1, C):
+                cam_id[c] = bundle.AddPose(self.rel_R[c], self.rel_t[c], False)
+            for k in range(P):
+                R = self.cam_R[0] @ self.base_R[k]
+                t = self.cam_R[0] @ self.base_t[k] + self.cam_t[0]
+                mkf_id[k] = bundle.AddPose(R, t, bool(self.base_fixed[k]))
         else:
             # BundleAdjusterSingle.cc:76-101: one pose per KeyFrame = CamFromWorld
             assert C == 1
@@ -127,6 +138,13 @@ class Problem:
             elif self.mode == "multi":
                 chains[i] = (mkf_id[self.pt_src[i, 0]], cam_id[self.pt_src[i, 1]])
                 chain_len[i] = 2
+            elif self.mode == "calib":
+                # BundleAdjusterCalib.cc:169-173: chain {MKF} for the first camera, {MKF, relative pose} otherwise
+                chains[i, 0] = mkf_id[self.pt_src[i, 0]]
+                chain_len[i] = 1
+                if self.pt_src[i, 1] > 0:
+                    chains[i, 1] = cam_id[self.pt_src[i, 1]]
+                    chain_len[i] = 2
             else:
                 chains[i, 0] = mkf_id[self.pt_src[i, 0]]
                 chain_len[i] = 1
@@ -141,6 +159,10 @@ class Problem:
         mch[:, 0] = mkf_id[self.ms_mkf]
         if self.mode == "multi":
             mch[:, 1] = cam_id[self.ms_cam]
+        elif self.mode == "calib":              # BundleAdjusterCalib.cc:190-196
+            rel = self.ms_cam > 0
+            mch[rel, 1] = cam_id[self.ms_cam[rel]]
+            mlen[rel] = 2
         sig = (4.0 ** self.ms_level).astype(np.float64)     # LevelScale^2, BundleAdjusterMulti.cc:196
         if batch and hasattr(bundle, "AddMeasBatch"):
             bundle.AddMeasBatch(mch, mlen, pt_id[self.ms_pt], self.ms_uv, sig, self.ms_cam.astype(np.int32))
@@ -268,7 +290,17 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
             base_t[k] = R @ tt[k] + t
         pt_x = x_rel * (1.0 + rng.normal(size=(N, 1)) * depth_sigma)
     pt_x[pt_fixed] = world[pt_fixed]
-    return Problem(cams=cams, mode=mode, n_mkf=n_mkf, base_R=base_R, base_t=base_t, base_fixed=base_fixed,
+    rel_R = rel_t = None
+    if mode == "calib":
+        # relative camera poses Cam_c-from-Cam_0 = CamFromBase_c * CamFromBase_0^-1, the unknowns of the calibration
+        rel_R = np.array([cam_R[c] @ cam_R[0].T for c in range(n_cams)])
+        rel_t = np.array([cam_t[c] - rel_R[c] @ cam_t[0] for c in range(n_cams)])
+        if perturb:
+            for c in range(1, n_cams):
+                xi = np.concatenate([rng_pose.normal(size=3) * pose_sigma[0], rng_pose.normal(size=3) * math.radians(pose_sigma[1])])
+                R, t = se3_exp(xi)
+                rel_R[c], rel_t[c] = R @ rel_R[c], R @ rel_t[c] + t
+    return Problem(rel_R=rel_R, rel_t=rel_t, cams=cams, mode=mode, n_mkf=n_mkf, base_R=base_R, base_t=base_t, base_fixed=base_fixed,
                    cam_R=cam_R, cam_t=cam_t, pt_x=pt_x, pt_src=pt_src, pt_fixed=pt_fixed,
                    ms_mkf=ms_mkf, ms_cam=ms_cam, ms_pt=ms_pt, ms_uv=ms_uv, ms_level=ms_level,
                    true_base_R=tR, true_base_t=tt, true_world=world)
@@ -295,6 +327,9 @@ def merge_shards(shards):
 # the BASELINE.json configurations (SURVEY.md 8 notation)
 CONFIGS = {
     "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3, n_fixed_mkf=2),  # 2 fixed KFs pin the monocular scale gauge
+    # calibration-phase shapes (BundleAdjusterCalib): free relative camera poses shared by every MKF, fixed board points
+    "calib": dict(n_cams=3, n_mkf=12, n_points=600, per_point=6, mode="calib", arc_step=0.3, n_fixed_points=120,
+                  outlier_frac=0.0),      # board corners: no gross outliers (fixed-point measurements are never down-weighted)
     "c2": dict(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi"),
     "metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi"),
     "c4": dict(n_cams=4, n_mkf=500, n_points=100000, per_point=8, mode="multi"),

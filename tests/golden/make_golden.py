@@ -56,5 +56,6 @@ def img_fixture():
 if __name__ == "__main__":
     ba_fixture("tiny", 12)
     ba_fixture("c1", 12)
+    ba_fixture("calib", 10)
     img_fixture()
     print("golden fixtures written to", HERE)

@@ -6,7 +6,8 @@ def run_bundle(bundle, problem, n_iter=None, **kw):
     ids = problem.populate(bundle)
     rc = bundle.Compute(n_iter) if n_iter is not None else bundle.Compute()
     R, t, X = collect(bundle, ids)
-    return dict(rc=rc, converged=bundle.Converged(), total_iterations=bundle.TotalIterations(),
+    cam = [bundle.GetPose(int(i)) if i > 0 else (None, None) for i in ids["cam"]]
+    return dict(cam_R=[a for a, _ in cam], cam_t=[b for _, b in cam], rc=rc, converged=bundle.Converged(), total_iterations=bundle.TotalIterations(),
                 sigma_sq=bundle.GetSigmaSquared(), mean_chi2=bundle.GetMeanChiSquared(), max_cov=bundle.GetMaxCov(),
                 lam=bundle.GetLambda(), logs=bundle.IterLogs(), outliers=bundle.GetOutlierMeasurements(),
                 R=R, t=t, X=X, ids=ids)

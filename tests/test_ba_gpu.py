@@ -229,6 +229,37 @@ def test_point_seen_from_many_poses_uses_generic_path(gpu_required):
     compare_runs(gpu, ref)
 
 
+def test_calibration_chain_shapes(gpu_required):
+    """BundleAdjusterCalib's problem (src/BundleAdjusterCalib.cc:118-219): free relative camera poses that sit as the
+    *second* link of every chain of that camera (a dense block row of the reduced system), chains of length 1 for the
+    first camera, fixed board points on a world chain, Compute(abort, 10)."""
+    from mcptam_amd import synth
+    p = synth.make_config("calib")
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    for lam in (1e-3, 10.0):
+        xg = g.DebugSolve(lam)
+        rc, xs, xd = o.DebugSolve(lam)
+        assert rc == 0 and rel_err(xg, xs) < 1e-7
+    gpu = run_bundle(_gpu(p.cams), p, 10)
+    ref = run_bundle(_orc(p.cams), p, 10)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0
+    # the calibrated relative poses (what CalibrateAndUpdate writes back) agree, and moved towards the truth
+    for c in range(1, len(p.cams)):
+        Rg, tg = _pose(gpu, p, c)
+        Rr, tr = _pose(ref, p, c)
+        assert rel_err(Rg, Rr) < 1e-6 and rel_err(tg, tr) < 1e-6
+        Rt = p.cam_R[c] @ p.cam_R[0].T
+        tt = p.cam_t[c] - Rt @ p.cam_t[0]
+        assert np.abs(tg - tt).max() < 0.25 * np.abs(p.rel_t[c] - tt).max()
+
+
+def _pose(run, p, c):
+    return run["cam_R"][c], run["cam_t"][c]
+
+
 def test_two_rank_sharded_solve_equals_merged_single_rank(gpu_required):
     """points/measurements sharded over ranks, poses replicated, reduced pose system summed with
     the all-reduce hook.  Two processes share this GPU and reduce through gloo; the result must equal the
@@ -302,3 +333,29 @@ def test_native_rccl_communicator_single_rank(gpu_required):
     ref = run_bundle(_gpu(p.cams), p, 8)
     assert int(r["rc"]) == ref["rc"]
     assert rel_err(r["R"], ref["R"]) < 1e-9 and rel_err(r["X"], ref["X"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1", "calib"])
+def test_gpu_matches_committed_golden_fixture(gpu_required, name):
+    """The HIP path against the committed expected outputs (tests/golden/ba_*.npz, written by
+    tests/golden/make_golden.py): no oracle build involved."""
+    import os
+    from mcptam_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_%s.npz" % name))
+    p = synth.make_config(name)
+    b = _gpu(p.cams)
+    p.populate(b)
+    b.Prepare()
+    chi2, _ = b.Eval(p.n_meas)
+    assert rel_err(chi2, g["chi2_init"]) < 1e-10
+    csum, sig = b.DebugRobustChi2()
+    assert abs(sig - float(g["sigma_sq_init"])) <= 1e-12 * float(g["sigma_sq_init"])
+    assert abs(csum - float(g["robust_chi2_init"])) <= 1e-11 * float(g["robust_chi2_init"])
+    r = run_bundle(_gpu(p.cams), p, int(g["iters"]))
+    assert r["rc"] == int(g["rc"])
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in r["logs"]])
+    assert np.array_equal(logs[:, 4:], g["logs"][:, 4:])                     # same LM accept/reject sequence
+    assert np.allclose(logs[:, :4], g["logs"][:, :4], rtol=1e-6, atol=0)
+    assert rel_err(r["R"], g["R"]) < 1e-6 and rel_err(r["t"], g["t"]) < 1e-6 and rel_err(r["X"], g["X"]) < 1e-6
+    assert np.array_equal(np.array(r["outliers"], dtype=np.int32).reshape(-1, 3), g["outliers"])
+    assert abs(r["sigma_sq"] - float(g["sigma_sq"])) <= 1e-6 * float(g["sigma_sq"])

@@ -233,3 +233,27 @@ def test_epipolar_hypotheses_batch(gpu_required, scene):
         if abs(og["coarse_x"][best] - pred[0]) <= 3.5 and abs(og["coarse_y"][best] - pred[1]) <= 3.5:
             good += 1
     assert good >= 0.6*len(cand)          # the best-scoring hypothesis locks onto the corner of the true 3-D point
+
+
+def test_gpu_matches_committed_image_fixture(gpu_required):
+    """The HIP image path against the committed expected outputs (tests/golden/img_320.npz): bit-exact pyramid, corners,
+    row LUT, thresholds and candidates; the tracker batch with the documented flat-region tolerance."""
+    import os
+    from mcptam_amd import synth_img
+    from mcptam_amd.keyframe import KeyFrame, track_search
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "img_320.npz"))
+    A, B = KeyFrame(320, 240), KeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(g["imgA"])
+    B.MakeKeyFrame_Lite(g["imgB"])
+    A.MakeKeyFrame_Rest()
+    for l in range(4):
+        assert np.array_equal(A.Image(l), g["imgA_l%d" % l])
+        assert np.array_equal(A.Corners(l), g["cornersA%d" % l])
+        assert np.array_equal(A.RowLUT(l), g["lutA%d" % l])
+        assert A.FastThresh(l) == int(g["threshA%d" % l])
+        assert np.array_equal(A.Candidates(l)[0], g["candA%d" % l])
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    assert np.array_equal(sc["imgA"], g["imgA"])                               # the generator is deterministic
+    pts = synth_img.make_map_points(sc["cam"], A, A, sc["poseA"], sc["depth"], per_level=(120, 80, 40, 10))
+    out = track_search(B, sc["cam"], sc["poseB"], (np.eye(3), np.zeros(3)), pts, 10, 8)
+    assert_track_equal(out, g["track"])

@@ -177,7 +177,7 @@ def test_zmssd_identity_on_exact_template():
     assert np.linalg.norm(out["found_pos"][f] - out["image"][f], axis=1).max() < 0.6
 
 
-@pytest.mark.parametrize("name,iters", [("tiny", 12), ("c1", 12)])
+@pytest.mark.parametrize("name,iters", [("tiny", 12), ("c1", 12), ("calib", 10)])
 def test_oracle_matches_committed_ba_fixture(name, iters):
     from mcptam_amd import synth
     g = np.load(os.path.join(GOLD, "ba_%s.npz" % name))
