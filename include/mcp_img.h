@@ -63,11 +63,16 @@ int mcp_kf_get_row_lut(mcp_kf*, int level, int* out /* h */);
 int mcp_kf_fast_thresh(mcp_kf*, int level);
 int mcp_kf_get_fast_frequency(mcp_kf*, int level, double* out /* MCP_MAX_FAST_THRESH+1 */);
 
-/* KeyFrame::MakeKeyFrame_Rest, candidate part                         KeyFrame.cc:363-450
+/* frames held in the Level::imagePrev / vCornersPrev history (0..2, KeyFrame.h:147-148): every mcp_kf_make_lite on a handle
+ * that already holds a frame pushes that frame (device-resident) before overwriting it, KeyFrame.cc:152-199 */
+int mcp_kf_num_prev(mcp_kf*);
+
+/* KeyFrame::MakeKeyFrame_Rest, candidate part                         KeyFrame.cc:363-450, 456-527
  * use_shi: ssCandidateType ("shi" = 1 / "fast" = 0); use_percent: ssCandidateCriterion;
  * top_fraction = sdCandidateTopFraction (0.8); thresh = sdCandidateThresh (70).
  * nonmax_score: score used by CVD::fast_nonmax -- 0: FAST-10 binary-search score,
- * 1: the classic ring SAD corner_score (libCVD vintage dependent). */
+ * 1: the classic ring SAD corner_score (libCVD vintage dependent).
+ * When the handle holds history, the candidates are pruned by the back/forward MiniPatch stability test (:456-527). */
 int mcp_kf_make_rest(mcp_kf*, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score);
 int mcp_kf_num_candidates(mcp_kf*, int level);
 int mcp_kf_get_candidates(mcp_kf*, int level, mcp_int2* pos, double* score, int cap);

@@ -21,6 +21,7 @@ namespace {
 template <class T> struct Buf {
   T* p = nullptr; size_t n = 0;
   ~Buf() { if (p) (void)hipFree(p); }
+  void swap(Buf& o) { std::swap(p, o.p); std::swap(n, o.n); }
   int alloc(size_t c) { if (c == 0) c = 1; if (c <= n) return 0; if (p) (void)hipFree(p); p = nullptr; n = 0;
     if (hipMalloc((void**)&p, c*sizeof(T)) != hipSuccess) { mcp_set_error("hipMalloc failed"); return -1; } n = c; return 0; }
 };
@@ -33,6 +34,22 @@ struct Level {
   Buf<LevelInfo> info;
   bool has_mask = false;
   std::vector<mcp_int2> h_cand; std::vector<double> h_cand_score;
+  // Level::imagePrev / vCornersPrev (KeyFrame.h:147-148): the last NUM_PREV frames' level image, corners, row LUT and
+  // counts stay resident; [0] is the oldest.  Buffers rotate by pointer swap, nothing is copied.
+  static constexpr int NUM_PREV = 2;            // Level::snNumPrev, KeyFrame.cc:71
+  int nprev = 0;
+  Buf<uint8_t> pimg[NUM_PREV]; Buf<mcp_int2> pcorners[NUM_PREV]; Buf<int> plut[NUM_PREV]; Buf<LevelInfo> pinfo[NUM_PREV];
+  int alloc_frame() {
+    const size_t npx = (size_t)w*h;
+    if (img.alloc(npx) || corners.alloc(cap) || lut.alloc(h) || info.alloc(1)) return -1;
+    return 0;
+  }
+  int push_history() {                           // circular_buffer::push_back of the frame currently held
+    if (nprev == NUM_PREV) { pimg[0].swap(pimg[1]); pcorners[0].swap(pcorners[1]); plut[0].swap(plut[1]); pinfo[0].swap(pinfo[1]); --nprev; }
+    pimg[nprev].swap(img); pcorners[nprev].swap(corners); plut[nprev].swap(lut); pinfo[nprev].swap(info);
+    ++nprev;
+    return alloc_frame();                        // the dropped frame's buffers (or fresh ones) become the current frame
+  }
 };
 }  // namespace
 
@@ -42,7 +59,8 @@ struct mcp_kf {
   Level lev[MCP_LEVELS];
   // scratch reused across calls (no hipMalloc on the per-frame path)
   Buf<DevTdIn> td_in; Buf<mcp_td_out> td_out;
-  Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f; Buf<int> mp_s;
+  Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f, mp_f2; Buf<int> mp_s;
+  bool has_image = false;
   ~mcp_kf() { if (st) (void)hipStreamDestroy(st); }
   DevKfView view() const {
     DevKfView v;
@@ -81,6 +99,9 @@ int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* c
   ICK(hipSetDevice(k->device));
   hipStream_t st = k->st;
   static const int fixed_t[4] = { 10, 15, 15, 10 };
+  // the frame currently held moves into the history before it is overwritten, KeyFrame.cc:152-199
+  if (k->has_image) for (int l = 0; l < MCP_LEVELS; ++l) if (k->lev[l].push_history()) return -1;
+  k->has_image = true;
   for (int l = 0; l < MCP_LEVELS; ++l) {
     Level& L = k->lev[l];
     const size_t npx = (size_t)L.w*L.h;
@@ -187,8 +208,38 @@ int mcp_kf_make_rest(mcp_kf* k, int use_shi, int use_percent, double top_fractio
       for (int i = 0; i < inf.n_cand; ++i) if (sc[i] > thresh) { L.h_cand.push_back(pos[i]); L.h_cand_score.push_back(sc[i]); }
     }
   }
+  // stability pruning, KeyFrame.cc:456-527: every candidate is followed back to the oldest stored frame and forward again
+  // to the current one (MiniPatch, search radius 10 per stored frame); it survives if it lands within sqrt(2) pixels
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    Level& L = k->lev[l];
+    const int n = (int)L.h_cand.size();
+    if (L.nprev == 0 || n == 0) continue;
+    if (k->mp_a.alloc(n) || k->mp_b.alloc(n) || k->mp_o.alloc(n) || k->mp_f.alloc(n) || k->mp_f2.alloc(n) || k->mp_s.alloc(n)) return -1;
+    ICK(hipMemcpyAsync(k->mp_a.p, L.h_cand.data(), sizeof(mcp_int2)*(size_t)n, hipMemcpyHostToDevice, st));
+    const int range = L.nprev*10;
+    hipLaunchKernelGGL(k_minipatch, dim3(n), dim3(64), 0, st, (const uint8_t*)L.img.p, L.w, L.h, (const uint8_t*)L.pimg[0].p, L.w, L.h,
+                       (const mcp_int2*)L.pcorners[0].p, (const LevelInfo*)L.pinfo[0].p, (const int*)L.plut[0].p, n, (const mcp_int2*)k->mp_a.p, (const mcp_int2*)k->mp_a.p, range,
+                       k->mp_o.p, k->mp_f.p, k->mp_s.p);
+    hipLaunchKernelGGL(k_minipatch, dim3(n), dim3(64), 0, st, (const uint8_t*)L.pimg[0].p, L.w, L.h, (const uint8_t*)L.img.p, L.w, L.h,
+                       (const mcp_int2*)L.corners.p, (const LevelInfo*)L.info.p, (const int*)L.lut.p, n, (const mcp_int2*)k->mp_o.p, (const mcp_int2*)k->mp_o.p, range,
+                       k->mp_b.p, k->mp_f2.p, k->mp_s.p);
+    std::vector<mcp_int2> back(n); std::vector<uint8_t> f1(n), f2(n);
+    ICK(hipMemcpyAsync(back.data(), k->mp_b.p, sizeof(mcp_int2)*(size_t)n, hipMemcpyDeviceToHost, st));
+    ICK(hipMemcpyAsync(f1.data(), k->mp_f.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    ICK(hipMemcpyAsync(f2.data(), k->mp_f2.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    ICK(hipStreamSynchronize(st));
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!f1[i] || !f2[i]) continue;
+      const int dx = back[i].x - L.h_cand[i].x, dy = back[i].y - L.h_cand[i].y;
+      if (dx*dx + dy*dy > 2) continue;
+      L.h_cand[nk] = L.h_cand[i]; L.h_cand_score[nk] = L.h_cand_score[i]; ++nk;
+    }
+    L.h_cand.resize(nk); L.h_cand_score.resize(nk);
+  }
   return 0;
 }
+int mcp_kf_num_prev(mcp_kf* k) { return k->lev[0].nprev; }
 int mcp_kf_num_candidates(mcp_kf* k, int level) { if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level"); return (int)k->lev[level].h_cand.size(); }
 int mcp_kf_get_candidates(mcp_kf* k, int level, mcp_int2* pos, double* score, int cap) {
   if (level < 0 || level >= MCP_LEVELS) return img_fail("bad level");

@@ -42,7 +42,7 @@ assert TD_OUT_DTYPE.itemsize == ctypes.sizeof(TdOut)
 IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
-    "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
+    "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
 ]
 _BOUND = False
 
@@ -58,6 +58,7 @@ def lib():
         L.mcp_kf_level_size.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
         L.mcp_kf_get_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.mcp_kf_num_prev.argtypes = [ctypes.c_void_p]
         L.mcp_kf_get_corners.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.mcp_kf_get_row_lut.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p]
         L.mcp_kf_fast_thresh.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -113,6 +114,10 @@ class KeyFrame:
             arr = (ctypes.c_void_p * LEVELS)(*[None if m is None else m.ctypes.data for m in self._masks])
             mp = ctypes.cast(arr, ctypes.c_void_p)
         _chk(self._L.mcp_kf_make_lite(self._h, img.ctypes.data, img.strides[0], mp), "MakeKeyFrame_Lite")
+
+    def NumPrev(self):
+        """Frames held in the Level::imagePrev / vCornersPrev history (0..2)."""
+        return int(self._L.mcp_kf_num_prev(self._h))
 
     def LevelSize(self, level):
         w, h = ctypes.c_int(), ctypes.c_int()

@@ -226,6 +226,7 @@ def img_lib():
         L.orc_kf_image.restype = ctypes.c_void_p
         L.orc_kf_image.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_kf_num_prev.argtypes = [ctypes.c_void_p]
         L.orc_kf_corners.restype = ctypes.c_void_p
         L.orc_kf_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_kf_row_lut.restype = ctypes.c_void_p
@@ -269,6 +270,9 @@ class OracleKeyFrame:
             arr = (ctypes.c_void_p * 4)(*[None if m is None else m.ctypes.data for m in self._masks])
             mp = ctypes.cast(arr, ctypes.c_void_p)
         self._L.orc_kf_make_lite(self._h, img.ctypes.data, img.strides[0], mp)
+
+    def NumPrev(self):
+        return int(self._L.orc_kf_num_prev(self._h))
 
     def LevelSize(self, level):
         w, h = ctypes.c_int(), ctypes.c_int()

@@ -11,11 +11,14 @@
 
 #define MIN_FAST_THRESH 5      /* include/mcptam/KeyFrame.h:88 */
 #define MAX_FAST_THRESH 30     /* :89 */
+#define NUM_PREV 2              /* Level::snNumPrev, src/KeyFrame.cc:71 */
 
 typedef struct { int w, h; uint8_t* img; uint8_t* mask; int ncorners, ccorners; orc_int2* corners; int* lut;
                  int thresh; double freq[MAX_FAST_THRESH + 1];
-                 int ncand; orc_int2* cand; double* cand_score; } olevel;
-struct orc_kf { olevel lev[ORC_LEVELS]; int adaptive, glare, pavgb; };
+                 int ncand; orc_int2* cand; double* cand_score;
+                 /* Level::imagePrev / vCornersPrev: circular buffers of Level::snNumPrev = 2 (KeyFrame.cc:71, KeyFrame.h:124-125,147-148); [0] = oldest */
+                 int nprev; uint8_t* pimg[NUM_PREV]; orc_int2* pcorners[NUM_PREV]; int pncorners[NUM_PREV]; } olevel;
+struct orc_kf { olevel lev[ORC_LEVELS]; int adaptive, glare, pavgb, has_image; };
 
 orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb) {
   orc_kf* k = (orc_kf*)calloc(1, sizeof *k);
@@ -31,7 +34,8 @@ orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb) {
 }
 void orc_kf_destroy(orc_kf* k) {
   if (!k) return;
-  for (int l = 0; l < ORC_LEVELS; l++) { olevel* L = &k->lev[l]; free(L->img); free(L->mask); free(L->corners); free(L->lut); free(L->cand); free(L->cand_score); }
+  for (int l = 0; l < ORC_LEVELS; l++) { olevel* L = &k->lev[l]; free(L->img); free(L->mask); free(L->corners); free(L->lut); free(L->cand); free(L->cand_score);
+    for (int j = 0; j < NUM_PREV; j++) { free(L->pimg[j]); free(L->pcorners[j]); } }
   free(k);
 }
 
@@ -115,7 +119,23 @@ static void dilate5(const uint8_t* in, uint8_t* out, int w, int h) {
 }
 
 /* KeyFrame::MakeKeyFrame_Lite, KeyFrame.cc:145-360 */
+int orc_kf_num_prev(orc_kf* k) { return k->lev[0].nprev; }
 int orc_kf_make_lite(orc_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
+  /* the image and corners currently held move into the history buffers before they are overwritten, KeyFrame.cc:152-199 */
+  if (k->has_image) for (int l = 0; l < ORC_LEVELS; l++) {
+    olevel* L = &k->lev[l];
+    if (L->nprev == NUM_PREV) {              /* circular_buffer::push_back on a full buffer drops the oldest */
+      free(L->pimg[0]); free(L->pcorners[0]);
+      for (int j = 1; j < NUM_PREV; j++) { L->pimg[j-1] = L->pimg[j]; L->pcorners[j-1] = L->pcorners[j]; L->pncorners[j-1] = L->pncorners[j]; }
+      L->nprev--;
+    }
+    const size_t npx = (size_t)L->w*L->h;
+    L->pimg[L->nprev] = (uint8_t*)malloc(npx + 1); memcpy(L->pimg[L->nprev], L->img, npx);
+    L->pcorners[L->nprev] = (orc_int2*)malloc(sizeof(orc_int2)*(L->ncorners + 1)); memcpy(L->pcorners[L->nprev], L->corners, sizeof(orc_int2)*L->ncorners);
+    L->pncorners[L->nprev] = L->ncorners;
+    L->nprev++;
+  }
+  k->has_image = 1;
   for (int l = 0; l < ORC_LEVELS; l++) {
     olevel* L = &k->lev[l];
     if (l == 0) { for (int y = 0; y < L->h; y++) memcpy(L->img + (size_t)y*L->w, img + (size_t)y*stride, L->w); }
@@ -219,6 +239,7 @@ static int cmp_scored_desc(const void* a, const void* b) {       /* std::sort on
   return (x->p.x < y->p.x) - (x->p.x > y->p.x);
 }
 /* KeyFrame::MakeKeyFrame_Rest, candidate part, KeyFrame.cc:363-450 */
+static void prune_candidates(olevel* L);
 int orc_kf_make_rest(orc_kf* k, int use_shi, int use_percent, double top_fraction, double thresh, int nonmax_score) {
   for (int l = 0; l < ORC_LEVELS; l++) {
     olevel* L = &k->lev[l];
@@ -246,6 +267,7 @@ int orc_kf_make_rest(orc_kf* k, int use_shi, int use_percent, double top_fractio
       for (int i = 0; i < nv; i++) if (v[i].s > thresh) { L->cand[L->ncand] = v[i].p; L->cand_score[L->ncand++] = v[i].s; }
     }
     free(sc); free(mx); free(v);
+    prune_candidates(L);
   }
   return 0;
 }
@@ -253,6 +275,52 @@ int orc_kf_num_candidates(orc_kf* k, int l) { return k->lev[l].ncand; }
 int orc_kf_get_candidates(orc_kf* k, int l, orc_int2* pos, double* score, int cap) {
   const int n = k->lev[l].ncand < cap ? k->lev[l].ncand : cap;
   memcpy(pos, k->lev[l].cand, sizeof(orc_int2)*n); memcpy(score, k->lev[l].cand_score, sizeof(double)*n); return n;
+}
+
+/* MiniPatch::FindPatch without a row LUT (the form MakeKeyFrame_Rest uses, KeyFrame.cc:490,516): linear scan from the
+ * first corner at or below the top of the box, MiniPatch.cc:77-83,93-113.  `patch` = 9x9 template.  Returns found. */
+static int minipatch_scan(const uint8_t* patch, const uint8_t* dimg, int dw, int dh, const orc_int2* corners, int ncorners,
+                          orc_int2* pos, int range) {
+  const int H = 4, MAXSSD = 9999;
+  int best = MAXSSD + 1; orc_int2 bp = *pos;
+  const int tlx = pos->x - range, tly = pos->y - range, brx = pos->x + range, bry = pos->y + range;
+  int c = 0;
+  for (; c < ncorners; c++) if (corners[c].y >= tly) break;
+  for (; c < ncorners; c++) {
+    const orc_int2 p = corners[c];
+    if (p.x < tlx || p.x > brx) continue;
+    if (p.y > bry) break;
+    int ssd;
+    if (!(p.x >= H && p.y >= H && p.x < dw - H && p.y < dh - H)) ssd = MAXSSD + 1;
+    else { ssd = 0; for (int r = 0; r < 9; r++) for (int q = 0; q < 9; q++) { const int df = dimg[(size_t)(p.y - H + r)*dw + p.x - H + q] - patch[9*r + q]; ssd += df*df; } }
+    if (ssd < best) { bp = p; best = ssd; }
+  }
+  if (best < MAXSSD) { *pos = bp; return 1; }
+  return 0;
+}
+static void minipatch_sample(const uint8_t* img, int w, orc_int2 p, uint8_t* patch) {
+  for (int r = 0; r < 9; r++) memcpy(patch + 9*r, img + (size_t)(p.y - 4 + r)*w + p.x - 4, 9);
+}
+/* the stability pruning of MakeKeyFrame_Rest, KeyFrame.cc:456-527: follow each candidate back to the oldest stored frame
+ * and forward again to the current one; keep it if it lands within sqrt(2) pixels of where it started */
+static void prune_candidates(olevel* L) {
+  if (L->nprev == 0) return;
+  const int range = L->nprev*10;
+  int nk = 0;
+  for (int i = 0; i < L->ncand; i++) {
+    const orc_int2 cur = L->cand[i];
+    uint8_t patch[81];
+    minipatch_sample(L->img, L->w, cur, patch);
+    orc_int2 prev = cur;
+    if (!minipatch_scan(patch, L->pimg[0], L->w, L->h, L->pcorners[0], L->pncorners[0], &prev, range)) continue;
+    minipatch_sample(L->pimg[0], L->w, prev, patch);
+    orc_int2 next = prev;
+    if (!minipatch_scan(patch, L->img, L->w, L->h, L->corners, L->ncorners, &next, range)) continue;
+    const int dx = next.x - cur.x, dy = next.y - cur.y;
+    if (dx*dx + dy*dy > 2) continue;
+    L->cand[nk] = L->cand[i]; L->cand_score[nk] = L->cand_score[i]; nk++;
+  }
+  L->ncand = nk;
 }
 
 /* MiniPatch::SampleFromImage + FindPatch + SSDAtPoint, MiniPatch.cc:34-122 (half size 4, max SSD 9999) */

@@ -31,6 +31,7 @@ typedef struct orc_int2 { int x, y; } orc_int2;
 orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb);
 void    orc_kf_destroy(orc_kf*);
 int     orc_kf_make_lite(orc_kf*, const uint8_t* img, int stride, const uint8_t* const* masks);
+int     orc_kf_num_prev(orc_kf*);      /* frames held in Level::imagePrev (0..2) */
 int     orc_kf_level_size(orc_kf*, int level, int* w, int* h);
 const uint8_t* orc_kf_image(orc_kf*, int level);
 int     orc_kf_num_corners(orc_kf*, int level);

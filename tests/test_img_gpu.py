@@ -257,3 +257,30 @@ def test_gpu_matches_committed_image_fixture(gpu_required):
     pts = synth_img.make_map_points(sc["cam"], A, A, sc["poseA"], sc["depth"], per_level=(120, 80, 40, 10))
     out = track_search(B, sc["cam"], sc["poseB"], (np.eye(3), np.zeros(3)), pts, 10, 8)
     assert_track_equal(out, g["track"])
+
+
+def test_candidate_stability_pruning_with_history(gpu_required):
+    """MakeKeyFrame_Rest on a handle that has seen earlier frames (the tracker reuses one KeyFrame per camera): the
+    previous two frames stay resident (Level::imagePrev / vCornersPrev) and every candidate must survive the
+    back-and-forward MiniPatch walk, src/KeyFrame.cc:456-527.  Bit-exact candidate lists after 1, 2 and 3 pushes."""
+    from mcptam_amd import synth_img
+    g, o = _pair(640, 480)
+    sc = synth_img.make_tracking_scene()
+    frames = [sc["imgA"], sc["imgB"], np.roll(sc["imgB"], 2, axis=1), np.roll(sc["imgA"], -1, axis=0)]
+    survivors = []
+    for i, f in enumerate(frames):
+        g.MakeKeyFrame_Lite(f)
+        o.MakeKeyFrame_Lite(f)
+        assert g.NumPrev() == o.NumPrev() == min(i, 2)
+        _assert_lite_equal(g, o)
+        for kw in (dict(), dict(use_shi=True), dict(use_percent=False, thresh=70.0)):
+            g.MakeKeyFrame_Rest(**kw)
+            o.MakeKeyFrame_Rest(**kw)
+            for l in range(4):
+                pg, sg = g.Candidates(l)
+                po, so = o.Candidates(l)
+                assert np.array_equal(pg, po), (i, kw, l)
+                assert np.array_equal(sg, so)
+        survivors.append(sum(len(g.Candidates(l)[0]) for l in range(4)))
+    assert survivors[1] < survivors[0]            # the pruning removes unstable candidates once there is history
+    assert survivors[1] > 20

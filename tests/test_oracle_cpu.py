@@ -218,3 +218,33 @@ def test_synthetic_generator_and_sharding_are_deterministic():
         synth.make_config("tiny", n_mkf=3, per_point=5)                                       # impossible visibility
     m = synth.make_config("c2", n_mkf=12, n_points=400)
     assert m.n_meas == 8 * 400 and m.ms_pt.max() == 399
+
+
+def test_oracle_candidate_pruning_history_semantics():
+    """MakeKeyFrame_Rest's stability pruning (src/KeyFrame.cc:456-527) in the oracle: no history -> no pruning; an identical
+    previous frame -> every candidate walks back and forth onto itself; an unrelated previous frame -> (almost) nothing
+    survives; the history is a circular buffer of two frames and the walk targets the OLDEST one."""
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    img = sc["imgA"]
+    other = np.ascontiguousarray(synth_img.make_texture(seed=99, n=512)[100:340, 60:380]).astype(np.uint8)     # unrelated texture
+    k = OracleKeyFrame(320, 240)
+    k.MakeKeyFrame_Lite(img)
+    k.MakeKeyFrame_Rest()
+    base = [k.Candidates(l)[0].copy() for l in range(4)]
+    assert k.NumPrev() == 0 and sum(len(b) for b in base) > 50
+    k.MakeKeyFrame_Lite(img)                      # history = [img]
+    k.MakeKeyFrame_Rest()
+    assert k.NumPrev() == 1
+    for l in range(4):
+        assert np.array_equal(k.Candidates(l)[0], base[l])
+    k.MakeKeyFrame_Lite(other)                    # history = [img, img], current = other
+    k.MakeKeyFrame_Lite(img)                      # history = [img, other]: oldest is img -> everything survives
+    k.MakeKeyFrame_Rest()
+    assert k.NumPrev() == 2
+    for l in range(4):
+        assert np.array_equal(k.Candidates(l)[0], base[l])
+    k.MakeKeyFrame_Lite(img)                      # history = [other, img]: oldest is the unrelated frame
+    k.MakeKeyFrame_Rest()
+    assert sum(len(k.Candidates(l)[0]) for l in range(4)) < 0.2 * sum(len(b) for b in base)
