@@ -359,3 +359,30 @@ def test_gpu_matches_committed_golden_fixture(gpu_required, name):
     assert rel_err(r["R"], g["R"]) < 1e-6 and rel_err(r["t"], g["t"]) < 1e-6 and rel_err(r["X"], g["X"]) < 1e-6
     assert np.array_equal(np.array(r["outliers"], dtype=np.int32).reshape(-1, 3), g["outliers"])
     assert abs(r["sigma_sq"] - float(g["sigma_sq"])) <= 1e-6 * float(g["sigma_sq"])
+
+
+def test_replayed_map_dump_through_the_hip_path(gpu_required, tmp_path):
+    """A map in the reference's DumpToFile layout (src/MapMakerBase.cc:475-577) with the camera dump
+    (src/SystemBase.cc:166-215), loaded, populated in BundleAdjusterMulti order and adjusted on the GPU: same result
+    as the oracle on the same files."""
+    from mcptam_amd import map_io, synth
+    p = synth.make_config("c2", n_mkf=10, n_points=800)
+    names = ["camera%d" % (i + 1) for i in range(len(p.cams))]
+    map_io.dump_map(str(tmp_path / "map.dat"), map_io.map_from_problem(p, names), precision=17)
+    map_io.dump_cameras(str(tmp_path / "cameras.dat"), dict(zip(names, p.cams)), precision=17)
+    q = map_io.problem_from_map(map_io.load_map(str(tmp_path / "map.dat")), map_io.load_cameras(str(tmp_path / "cameras.dat")))
+    gpu = run_bundle(_gpu(q.cams), q, 8)
+    ref = run_bundle(_orc(q.cams), q, 8)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0 and gpu["outliers"] == ref["outliers"]
+    # and the adjusted map written back in the reference's own (6-digit) formatting still parses into the same map
+    out = map_io.map_from_problem(q, names, state=(gpu["R"], gpu["t"], _world_points(q, gpu)))
+    map_io.dump_map(str(tmp_path / "adjusted.dat"), out)
+    back = map_io.load_map(str(tmp_path / "adjusted.dat"))
+    assert np.allclose(back.mkf_pos, out.mkf_pos, rtol=1e-5, atol=1e-5) and len(back.ms_pt) == q.n_meas
+
+
+def _world_points(q, run):
+    R = np.einsum("nij,njk->nik", q.cam_R[q.pt_src[:, 1]], run["R"][q.pt_src[:, 0]])
+    t = np.einsum("nij,nj->ni", q.cam_R[q.pt_src[:, 1]], run["t"][q.pt_src[:, 0]]) + q.cam_t[q.pt_src[:, 1]]
+    return np.einsum("nji,nj->ni", R, run["X"] - t)
