@@ -283,19 +283,48 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = (sch_d4){0.0, 0.0, 0.0, 0.0};
   double racc = 0.0;                           // rhs entry t (t < GRP_DOF)
+  // The global reads of a chunk hang off two index hops (point -> incidence range -> local pose slot), a few
+  // microseconds of dependent latency.  They are issued one chunk ahead, into registers, and land in LDS after the
+  // matrix-core phase of the chunk before, so only the first chunk of a group pays for them.
+  const int pl = t >> 4, sub = t & 15;
+  double pw[6][3]; int prow[6];                // this thread's W rows of the next chunk (<= 16 incidences x 6 rows / 16 threads)
+  double pv[6], pg[3]; int plpt = -1;          // threads 0..15: V and g of the next chunk's points
+  auto prefetch = [&](int base) {
+    const int sp = base + pl;
+    int i0 = 0, cnt = 0;
+    if (sp < sp1 && !P.sp_big[sp]) { i0 = P.sp_i[sp]; cnt = (P.sp_i[sp + 1] - i0)*6; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int it = sub + 16*k;
+      prow[k] = -1;
+      if (it < cnt) {
+        const int inc = i0 + it/6, r = it%6;
+        const double* Wr = W + 18*(size_t)inc + 3*r;
+        pw[k][0] = Wr[0]; pw[k][1] = Wr[1]; pw[k][2] = Wr[2];
+        prow[k] = 6*P.inc_lp[inc] + r;
+      }
+    }
+    if (t < SCH_CHUNK) {
+      const int sq = base + t;
+      plpt = -1;
+      if (sq < sp1 && !P.sp_big[sq]) plpt = P.pt_unk[P.sp_pt[sq]];
+      if (plpt >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pv[k] = V[6*(size_t)plpt + k];
+        pg[0] = g[3*(size_t)plpt]; pg[1] = g[3*(size_t)plpt + 1]; pg[2] = g[3*(size_t)plpt + 2];
+      }
+    }
+  };
+  prefetch(sp0);
   for (int base = sp0; base < sp1; base += SCH_CHUNK) {
     for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
     if (t < SCH_CHUNK) {
-      const int sp = base + t;
       double I6[6] = {0, 0, 0, 0, 0, 0}; double g3[3] = {0, 0, 0};
-      if (sp < sp1 && !P.sp_big[sp]) {
-        const int lpt = P.pt_unk[P.sp_pt[sp]];
-        if (lpt >= 0) {
-          if (!inv_sym3(V + 6*(size_t)lpt, lambda, I6)) atomicOr(fail, 1);
+      if (plpt >= 0) {
+        if (!inv_sym3(pv, lambda, I6)) atomicOr(fail, 1);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) Vinv[6*(size_t)lpt + k] = I6[k];
-          g3[0] = g[3*(size_t)lpt]; g3[1] = g[3*(size_t)lpt + 1]; g3[2] = g[3*(size_t)lpt + 2];
-        }
+        for (int k = 0; k < 6; ++k) Vinv[6*(size_t)plpt + k] = I6[k];
+        g3[0] = pg[0]; g3[1] = pg[1]; g3[2] = pg[2];
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) Vi[6*t + k] = I6[k];
@@ -303,25 +332,20 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     }
     __syncthreads();
     {   // scatter W and Y = W V^-1 rows: 16 threads per point
-      const int pl = t >> 4, sub = t & 15;
-      const int sp = base + pl;
-      if (sp < sp1 && !P.sp_big[sp]) {
-        const int i0 = P.sp_i[sp], i1 = P.sp_i[sp + 1];
-        const double* I6 = Vi + 6*pl;
-        for (int it = sub; it < (i1 - i0)*6; it += 16) {
-          const int inc = i0 + it/6, r = it%6;
-          const double* Wr = W + 18*(size_t)inc + 3*r;
-          const double w0 = Wr[0], w1 = Wr[1], w2 = Wr[2];
-          const int row = 6*P.inc_lp[inc] + r;
-          double* wd = Wd + row*SCH_LD + 3*pl;
-          double* yd = Yd + row*SCH_LD + 3*pl;
-          wd[0] = w0; wd[1] = w1; wd[2] = w2;
-          yd[0] = w0*I6[0] + w1*I6[1] + w2*I6[2];
-          yd[1] = w0*I6[1] + w1*I6[3] + w2*I6[4];
-          yd[2] = w0*I6[2] + w1*I6[4] + w2*I6[5];
-        }
+      const double* I6 = Vi + 6*pl;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (prow[k] < 0) continue;
+        const double w0 = pw[k][0], w1 = pw[k][1], w2 = pw[k][2];
+        double* wd = Wd + prow[k]*SCH_LD + 3*pl;
+        double* yd = Yd + prow[k]*SCH_LD + 3*pl;
+        wd[0] = w0; wd[1] = w1; wd[2] = w2;
+        yd[0] = w0*I6[0] + w1*I6[1] + w2*I6[2];
+        yd[1] = w0*I6[1] + w1*I6[3] + w2*I6[4];
+        yd[2] = w0*I6[2] + w1*I6[4] + w2*I6[5];
       }
     }
+    if (base + SCH_CHUNK < sp1) prefetch(base + SCH_CHUNK);      // in flight during the matrix-core phase
     __syncthreads();
     // S_loc += Y W^T on the matrix cores; wave w owns the lower-triangular tile pairs w, w+4, ...
     {
