@@ -83,6 +83,24 @@ int mcp_kf_get_candidates(mcp_kf*, int level, mcp_int2* pos, double* score, int 
 int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int2* src_pos,
                        const mcp_int2* dst_pos, int range, mcp_int2* out_pos, uint8_t* out_found, int* out_ssd);
 
+/* ---- SmallBlurryImage / Relocaliser -------------------------------- src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121
+ * The 40x30 thumbnail of the frame the handle holds, its zero-mean Gaussian-blurred float template and gradient image
+ * (MakeFromKF + MakeJacs) live on the device with the keyframe (KeyFrame::mpSBI).  blur = 2.5 in the reference. */
+#define MCP_SBI_W 40
+#define MCP_SBI_H 30
+int mcp_kf_make_sbi(mcp_kf*, double blur);
+int mcp_kf_get_sbi(mcp_kf*, uint8_t* small_img /*1200 or NULL*/, float* templ /*1200 or NULL*/, float* jacs /*2400 (gx,gy) or NULL*/);
+/* Relocaliser::ScoreKFs: ZMSSD of cur against n candidate keyframes (NULL / SBI-less entries are skipped with a score of
+ * DBL_MAX); *best = index of the first smallest score or -1. */
+int mcp_sbi_score(mcp_kf* cur, int n, mcp_kf* const* cands, double* scores, int* best);
+/* SmallBlurryImage::IteratePosRelToTarget (ESM): se2 = { R00, R01, R10, R11, tx, ty }, *score = final sum of squares */
+int mcp_sbi_iterate(mcp_kf* cur, mcp_kf* target, int iterations, double se2[6], double* score);
+/* Tracker::CalcSBIRotation's per-camera step (src/Tracker.cc:1687-1720): every mcp_kf_make_sbi keeps the SBI it replaces as
+ * "last frame's"; this aligns the current one to it. */
+int mcp_sbi_iterate_last(mcp_kf*, int iterations, double se2[6], double* score);
+/* SmallBlurryImage::SE3fromSE2; the cameras are the 40x30 instances (TaylorCamera::SetImageSize(sirSize)) */
+int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cam_src, const mcp_camera* cam_target, double R[9]);
+
 /* one tracked map point as seen by Tracker::SearchForPoints */
 typedef struct mcp_td_in {
   double world_pos[3];          /* MapPoint::mv3WorldPos                                   */

@@ -6,6 +6,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <limits>
+#include <cmath>
 
 #include "../../include/mcp_img.h"
 #include "img_kernels.h"
@@ -61,6 +63,10 @@ struct mcp_kf {
   Buf<DevTdIn> td_in; Buf<mcp_td_out> td_out;
   Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f, mp_f2; Buf<int> mp_s;
   bool has_image = false;
+  // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
+  Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
+  Buf<uint8_t> sbi_last_small; Buf<float> sbi_last_templ, sbi_last_jacs; bool has_last_sbi = false;   // the SBI made before the current one (Tracker::mmpSBILastFrame)
+  Buf<const float*> sbi_ptrs; Buf<double> sbi_out;
   ~mcp_kf() { if (st) (void)hipStreamDestroy(st); }
   DevKfView view() const {
     DevKfView v;
@@ -265,6 +271,142 @@ int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int
   ICK(hipMemcpy(out_pos, dop.p, sizeof(mcp_int2)*(size_t)n, hipMemcpyDeviceToHost));
   ICK(hipMemcpy(out_found, dfound.p, (size_t)n, hipMemcpyDeviceToHost));
   if (out_ssd) ICK(hipMemcpy(out_ssd, dssd.p, sizeof(int)*(size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- SmallBlurryImage / Relocaliser --------------------------------------------------------------------------------
+// cv::resize's 8U INTER_LINEAR taps [3P-memory]: source coordinate (d+0.5)*scale-0.5 in float, clamped, 11-bit weights
+static void sbi_resize_coeffs(int src, int dst, int* idx, short* w0, short* w1) {
+  const double scale = (double)src/dst;
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)((d + 0.5)*scale - 0.5);
+    int s0 = (int)floorf(f);
+    f -= s0;
+    if (s0 < 0) { f = 0; s0 = 0; }
+    if (s0 >= src - 1) { f = 0; s0 = src - 1; }
+    idx[d] = s0;
+    w0[d] = (short)lrintf((1.f - f)*2048.f); w1[d] = (short)lrintf(f*2048.f);
+  }
+}
+int mcp_kf_make_sbi(mcp_kf* k, double blur) {
+  if (!k->has_image) return img_fail("mcp_kf_make_sbi: the handle holds no frame");
+  if (!(blur > 0)) return img_fail("mcp_kf_make_sbi: blur must be positive");
+  ICK(hipSetDevice(k->device));
+  if (k->has_sbi) {     // the previous SBI becomes "last frame's" (pointer swap), Tracker.cc: mmpSBILastFrame / mmpSBIThisFrame
+    k->sbi_last_small.swap(k->sbi_small); k->sbi_last_templ.swap(k->sbi_templ); k->sbi_last_jacs.swap(k->sbi_jacs);
+    k->has_last_sbi = true;
+  }
+  if (k->sbi_small.alloc(SBI_N) || k->sbi_templ.alloc(SBI_N) || k->sbi_jacs.alloc(2*SBI_N)) return -1;
+  SbiTables tb;
+  const Level& L = k->lev[0];
+  sbi_resize_coeffs(L.w, SBI_W, tb.xi, tb.xa, tb.xb);
+  sbi_resize_coeffs(L.h, SBI_H, tb.yi, tb.ya, tb.yb);
+  // CVD::convolveGaussian taps [3P-memory]: half size ceil(3 sigma), exp(-i^2/2 sigma^2), unit sum
+  tb.ks = std::min(31, (int)std::ceil(3.0*blur));
+  double sum = 1.0;
+  for (int i = 1; i <= tb.ks; ++i) sum += 2.0*std::exp(-(double)i*i/(2.0*blur*blur));
+  tb.k[0] = (float)(1.0/sum);
+  for (int i = 1; i < 32; ++i) tb.k[i] = (i <= tb.ks) ? (float)(std::exp(-(double)i*i/(2.0*blur*blur))/sum) : 0.f;
+  hipLaunchKernelGGL(k_sbi_make, dim3(1), dim3(256), 0, k->st, (const uint8_t*)L.img.p, L.w, L.h, tb, k->sbi_small.p, k->sbi_templ.p, k->sbi_jacs.p);
+  ICK(hipStreamSynchronize(k->st));
+  k->has_sbi = true;
+  return 0;
+}
+int mcp_kf_get_sbi(mcp_kf* k, uint8_t* small_img, float* templ, float* jacs) {
+  if (!k->has_sbi) return img_fail("mcp_kf_get_sbi: no SmallBlurryImage made");
+  ICK(hipSetDevice(k->device));
+  if (small_img) ICK(hipMemcpy(small_img, k->sbi_small.p, SBI_N, hipMemcpyDeviceToHost));
+  if (templ) ICK(hipMemcpy(templ, k->sbi_templ.p, SBI_N*sizeof(float), hipMemcpyDeviceToHost));
+  if (jacs) ICK(hipMemcpy(jacs, k->sbi_jacs.p, 2*SBI_N*sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+int mcp_sbi_score(mcp_kf* cur, int n, mcp_kf* const* cands, double* scores, int* best) {
+  if (!cur->has_sbi || n < 0) return img_fail("mcp_sbi_score: bad arguments");
+  *best = -1;
+  if (n == 0) return 0;
+  ICK(hipSetDevice(cur->device));
+  std::vector<const float*> ptrs(n);
+  for (int i = 0; i < n; ++i) ptrs[i] = (cands[i] && cands[i]->has_sbi) ? cands[i]->sbi_templ.p : nullptr;   // "KF doesn't have small blurry image! Skipping"
+  if (cur->sbi_ptrs.alloc(n) || cur->sbi_out.alloc(std::max(n, 8))) return -1;
+  ICK(hipMemcpyAsync(cur->sbi_ptrs.p, ptrs.data(), sizeof(float*)*(size_t)n, hipMemcpyHostToDevice, cur->st));
+  hipLaunchKernelGGL(k_sbi_score, dim3((n + 63)/64), dim3(64), 0, cur->st, (const float*)cur->sbi_templ.p, (const float* const*)cur->sbi_ptrs.p, n, cur->sbi_out.p);
+  ICK(hipMemcpyAsync(scores, cur->sbi_out.p, sizeof(double)*(size_t)n, hipMemcpyDeviceToHost, cur->st));
+  ICK(hipStreamSynchronize(cur->st));
+  double b = std::numeric_limits<double>::max();
+  for (int i = 0; i < n; ++i) if (ptrs[i] && scores[i] < b) { b = scores[i]; *best = i; }      // strict <: first smallest, Relocaliser.cc:113
+  return 0;
+}
+int mcp_sbi_iterate(mcp_kf* cur, mcp_kf* target, int iterations, double se2[6], double* score) {
+  if (!cur->has_sbi || !target->has_sbi || iterations < 0) return img_fail("mcp_sbi_iterate: both keyframes need a SmallBlurryImage with gradients");
+  ICK(hipSetDevice(cur->device));
+  if (cur->sbi_out.alloc(8)) return -1;
+  hipLaunchKernelGGL(k_sbi_iterate, dim3(1), dim3(256), 0, cur->st, (const float*)cur->sbi_templ.p, (const float*)target->sbi_templ.p, (const float*)target->sbi_jacs.p, iterations, cur->sbi_out.p);
+  double o[7];
+  ICK(hipMemcpyAsync(o, cur->sbi_out.p, sizeof o, hipMemcpyDeviceToHost, cur->st));
+  ICK(hipStreamSynchronize(cur->st));
+  std::memcpy(se2, o, 6*sizeof(double)); *score = o[6];
+  return 0;
+}
+// Tracker::CalcSBIRotation's alignment (Tracker.cc:1687-1720): this frame's SBI against the one made before it on this handle
+int mcp_sbi_iterate_last(mcp_kf* k, int iterations, double se2[6], double* score) {
+  if (!k->has_sbi || !k->has_last_sbi || iterations < 0) return img_fail("mcp_sbi_iterate_last: needs two consecutive SmallBlurryImages on the handle");
+  ICK(hipSetDevice(k->device));
+  if (k->sbi_out.alloc(8)) return -1;
+  hipLaunchKernelGGL(k_sbi_iterate, dim3(1), dim3(256), 0, k->st, (const float*)k->sbi_templ.p, (const float*)k->sbi_last_templ.p, (const float*)k->sbi_last_jacs.p, iterations, k->sbi_out.p);
+  double o[7];
+  ICK(hipMemcpyAsync(o, k->sbi_out.p, sizeof o, hipMemcpyDeviceToHost, k->st));
+  ICK(hipStreamSynchronize(k->st));
+  std::memcpy(se2, o, 6*sizeof(double)); *score = o[6];
+  return 0;
+}
+// SmallBlurryImage::SE3fromSE2 (:250-310): two points, three Gauss-Newton steps on SO3 -- control-plane arithmetic, run on the
+// host with the same camera functions the kernels use (ba_device.h is __host__ __device__)
+int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_camera* ct, double R[9]) {
+  if (!cs || !ct || cs->n_inv <= 0) return img_fail("mcp_sbi_se3_from_se2: bad camera");
+  const double c[2] = { SBI_W/2, SBI_H/2 };
+  const double off[2][2] = { { 5, 0 }, { -5, 0 } };
+  double turned[2][2], orig[2][3];
+  for (int i = 0; i < 2; ++i) {
+    turned[i][0] = c[0] + se2[0]*off[i][0] + se2[1]*off[i][1] + se2[4];
+    turned[i][1] = c[1] + se2[2]*off[i][0] + se2[3]*off[i][1] + se2[5];
+    // TaylorCamera::UnProject, TaylorCamera.cc:319-347
+    const double det = ct->affine[0]*ct->affine[3] - ct->affine[1]*ct->affine[2];
+    const double ai[4] = { ct->affine[3]/det, -ct->affine[1]/det, -ct->affine[2]/det, ct->affine[0]/det };
+    const double dx = c[0] + off[i][0] - ct->center[0], dy = c[1] + off[i][1] - ct->center[1];
+    const double x = ai[0]*dx + ai[1]*dy, y = ai[2]*dx + ai[3]*dy;
+    const double rho = std::sqrt(x*x + y*y);
+    const double p[5] = { ct->params[0], 0.0, ct->params[1], ct->params[2], ct->params[3] };
+    double z = p[4]; for (int q = 3; q >= 0; --q) z = z*rho + p[q];
+    const double n = std::sqrt(x*x + y*y + z*z);
+    orig[i][0] = x/n; orig[i][1] = y/n; orig[i][2] = z/n;
+  }
+  double so3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+  for (int it = 0; it < 3; ++it) {
+    double C[9] = { 10, 0, 0, 0, 10, 0, 0, 0, 10 }, v[3] = { 0, 0, 0 };
+    for (int i = 0; i < 2; ++i) {
+      double cam[3]; mat3_vec(so3, orig[i], cam);
+      Projection P; cam_project<true>(*cs, cam, P);
+      const double err[2] = { turned[i][0] - P.u, turned[i][1] - P.v };
+      double dT[3], dP[3]; cam_sphere_deriv(cam, dT, dP);
+      double J[2][3];
+      for (int m = 0; m < 3; ++m) {
+        double mot[3] = { 0, 0, 0 };
+        mot[(m + 1)%3] = -cam[(m + 2)%3]; mot[(m + 2)%3] = cam[(m + 1)%3];
+        const double sm[2] = { dT[0]*mot[0] + dT[1]*mot[1] + dT[2]*mot[2], dP[0]*mot[0] + dP[1]*mot[1] + dP[2]*mot[2] };
+        J[0][m] = P.D[0]*sm[0] + P.D[1]*sm[1]; J[1][m] = P.D[2]*sm[0] + P.D[3]*sm[1];
+      }
+      for (int r = 0; r < 2; ++r) for (int a = 0; a < 3; ++a) { v[a] += J[r][a]*err[r]; for (int b = 0; b < 3; ++b) C[3*a + b] += J[r][a]*J[r][b]; }
+    }
+    const double c00 = C[4]*C[8] - C[5]*C[7], c01 = C[5]*C[6] - C[3]*C[8], c02 = C[3]*C[7] - C[4]*C[6];
+    const double id = 1.0/(C[0]*c00 + C[1]*c01 + C[2]*c02);
+    const double Ci[9] = { c00*id, (C[2]*C[7] - C[1]*C[8])*id, (C[1]*C[5] - C[2]*C[4])*id,
+                           c01*id, (C[0]*C[8] - C[2]*C[6])*id, (C[2]*C[3] - C[0]*C[5])*id,
+                           c02*id, (C[1]*C[6] - C[0]*C[7])*id, (C[0]*C[4] - C[1]*C[3])*id };
+    double mu[3]; mat3_vec(Ci, v, mu);
+    double E[9], Rn[9]; so3_exp(mu, E); mat3_mul(E, so3, Rn);
+    std::memcpy(so3, Rn, sizeof Rn);
+  }
+  std::memcpy(R, so3, 9*sizeof(double));
   return 0;
 }
 

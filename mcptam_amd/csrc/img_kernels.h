@@ -595,4 +595,168 @@ __global__ void k_tukey_sigma(const double* __restrict__ med, double n, double o
   }
 }
 
+
+// ---- SmallBlurryImage / Relocaliser ------------------------------------------------------------------------------
+//   k_sbi_make     SmallBlurryImage::MakeFromKF + MakeJacs      src/SmallBlurryImage.cc:67-118
+//   k_sbi_score    Relocaliser::ScoreKFs (ZMSSD per candidate)  src/Relocaliser.cc:93-121, SmallBlurryImage.cc:122-134
+//   k_sbi_iterate  SmallBlurryImage::IteratePosRelToTarget      src/SmallBlurryImage.cc:139-245
+constexpr int SBI_W = 40, SBI_H = 30, SBI_N = SBI_W*SBI_H;
+struct SbiTables {               // cv::resize fixed-point taps and the Gaussian, built on the host once per handle / blur
+  int xi[SBI_W], yi[SBI_H]; short xa[SBI_W], xb[SBI_W], ya[SBI_H], yb[SBI_H];
+  float k[32]; int ks;
+};
+
+// one workgroup: resize (integer, as cv::resize 8U INTER_LINEAR), exact integer sum -> float mean, separable Gaussian in
+// float with the taps accumulated centre-first then outwards (zero outside the image), central differences
+__global__ void __launch_bounds__(256)
+k_sbi_make(const uint8_t* __restrict__ img, int iw, int ih, SbiTables tb, uint8_t* __restrict__ small_out,
+           float* __restrict__ templ_out, float* __restrict__ jacs_out) {
+  __shared__ float A[SBI_N], B[SBI_N];
+  __shared__ unsigned int red[4];
+  const int t = threadIdx.x;
+  unsigned int loc = 0;
+  for (int i = t; i < SBI_N; i += 256) {
+    const int y = i/SBI_W, x = i%SBI_W;
+    const uint8_t* r0 = img + (size_t)tb.yi[y]*iw; const uint8_t* r1 = img + (size_t)min(tb.yi[y] + 1, ih - 1)*iw;
+    const int x0 = tb.xi[x], x1 = min(x0 + 1, iw - 1);
+    const int h0 = r0[x0]*tb.xa[x] + r0[x1]*tb.xb[x], h1 = r1[x0]*tb.xa[x] + r1[x1]*tb.xb[x];
+    const int v = (((tb.ya[y]*(h0 >> 4)) >> 16) + ((tb.yb[y]*(h1 >> 4)) >> 16) + 2) >> 2;
+    const uint8_t b = (uint8_t)v;
+    small_out[i] = b; A[i] = (float)b; loc += b;
+  }
+  for (int o = 32; o > 0; o >>= 1) loc += __shfl_xor(loc, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = loc;
+  __syncthreads();
+  const unsigned int sum = red[0] + red[1] + red[2] + red[3];
+  const float mean = ((float)sum)/SBI_N;
+  for (int i = t; i < SBI_N; i += 256) A[i] = A[i] - mean;
+  __syncthreads();
+  for (int i = t; i < SBI_N; i += 256) {           // rows
+    const int y = i/SBI_W, x = i%SBI_W;
+    float a = A[i]*tb.k[0];
+    for (int q = 1; q <= tb.ks; ++q) { float p = 0.f; if (x - q >= 0) p += A[y*SBI_W + x - q]; if (x + q < SBI_W) p += A[y*SBI_W + x + q]; a += p*tb.k[q]; }
+    B[i] = a;
+  }
+  __syncthreads();
+  for (int i = t; i < SBI_N; i += 256) {           // columns
+    const int y = i/SBI_W, x = i%SBI_W;
+    float a = B[i]*tb.k[0];
+    for (int q = 1; q <= tb.ks; ++q) { float p = 0.f; if (y - q >= 0) p += B[(y - q)*SBI_W + x]; if (y + q < SBI_H) p += B[(y + q)*SBI_W + x]; a += p*tb.k[q]; }
+    A[i] = a; templ_out[i] = a;
+  }
+  __syncthreads();
+  for (int i = t; i < SBI_N; i += 256) {
+    const int y = i/SBI_W, x = i%SBI_W;
+    float gx = 0.f, gy = 0.f;
+    if (x >= 1 && y >= 1 && x < SBI_W - 1 && y < SBI_H - 1) { gx = A[i + 1] - A[i - 1]; gy = A[i + SBI_W] - A[i - SBI_W]; }
+    jacs_out[2*i] = gx; jacs_out[2*i + 1] = gy;
+  }
+}
+
+// one thread per candidate keyframe, raster-order double accumulation exactly as the scalar loop (so scores, and with them
+// the "first smallest" winner, are bit-identical); the 1200-float templates are a few kB each
+__global__ void __launch_bounds__(64)
+k_sbi_score(const float* __restrict__ cur, const float* const* __restrict__ cands, int n, double* __restrict__ scores) {
+  const int i = blockIdx.x*64 + threadIdx.x;
+  if (i >= n) return;
+  const float* o = cands[i];
+  if (!o) { scores[i] = 1.7976931348623157e308; return; }
+  double ssd = 0.0;
+  for (int p = 0; p < SBI_N; ++p) { const double d = cur[p] - o[p]; ssd += d*d; }
+  scores[i] = ssd;
+}
+
+// ESM alignment, all iterations in one launch (single workgroup): warp by closed-form source positions, 15 partial sums per
+// thread in double, fixed-order tree reduction, 4x4 LDL^T solve and SE2 update on thread 0
+__global__ void __launch_bounds__(256)
+k_sbi_iterate(const float* __restrict__ me, const float* __restrict__ ot_templ, const float* __restrict__ ot_jacs, int iterations,
+              double* __restrict__ out /* se2[6], score */) {
+  __shared__ float Tm[SBI_N], warped[SBI_N];
+  __shared__ double X[6], red[256][15 + 1], st[8];
+  const int t = threadIdx.x;
+  const int cx = SBI_W/2, cy = SBI_H/2;
+  for (int i = t; i < SBI_N; i += 256) Tm[i] = me[i];
+  if (t == 0) { st[0] = 1; st[1] = 0; st[2] = 0; st[3] = 1; st[4] = 0; st[5] = 0; st[6] = 0; st[7] = 0; }   // CtoC, mean offset, score
+  __syncthreads();
+  for (int it = 0; it < iterations; ++it) {
+    if (t == 0) {
+      // se2WfromC * se2CtoC * se2WfromC^-1 with WfromC = (I, centre)
+      const double R0 = st[0], R1 = st[1], R2 = st[2], R3 = st[3];
+      const double tx = st[4] + cx, ty = st[5] + cy;                      // WfromC * CtoC
+      X[0] = R0; X[1] = R1; X[2] = R2; X[3] = R3;
+      X[4] = R0*(-(double)cx) + R1*(-(double)cy) + tx; X[5] = R2*(-(double)cx) + R3*(-(double)cy) + ty;
+    }
+    __syncthreads();
+    const double xb = SBI_W - 1, yb = SBI_H - 1;
+    for (int i = t; i < SBI_N; i += 256) {
+      const int y = i/SBI_W, x = i%SBI_W;
+      const double px = X[4] + X[0]*x + X[1]*y, py = X[5] + X[2]*x + X[3]*y;
+      float v = -9e20f;
+      if (0 <= px && 0 <= py && px < xb && py < yb) {
+        const int lx = (int)px, ly = (int)py;
+        const double fx = px - lx, fy = py - ly;
+        const float* q = Tm + ly*SBI_W + lx;
+        v = (float)((1 - fy)*((1 - fx)*q[0] + fx*q[1]) + fy*((1 - fx)*q[SBI_W] + fx*q[SBI_W + 1]));
+      }
+      warped[i] = v;
+    }
+    __syncthreads();
+    double a[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) a[k] = 0.0;
+    const double moff = st[6];
+    for (int i = t; i < SBI_N; i += 256) {
+      const int y = i/SBI_W, x = i%SBI_W;
+      if (!(x >= 1 && y >= 1 && x < SBI_W - 1 && y < SBI_H - 1)) continue;
+      const float l = warped[i - 1], r = warped[i + 1], u = warped[i - SBI_W], d = warped[i + SBI_W], here = warped[i];
+      if (l + r + u + d + here < -9999.9) continue;
+      const double g0 = r - l, g1 = d - u;
+      const double s0 = 0.25*(g0 + (double)ot_jacs[2*i]), s1 = 0.25*(g1 + (double)ot_jacs[2*i + 1]);
+      const double J0 = s0, J1 = s1, J2 = -(y - cy)*s0 + (x - cx)*s1;
+      const double diff = (here - ot_templ[i]) + moff;
+      a[14] += diff*diff;
+      a[10] += diff*J0; a[11] += diff*J1; a[12] += diff*J2; a[13] += diff;
+      a[0] += J0*J0; a[1] += J1*J0; a[2] += J1*J1; a[3] += J2*J0; a[4] += J2*J1; a[5] += J2*J2; a[6] += J0; a[7] += J1; a[8] += J2; a[9] += 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) red[t][k] = a[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) red[t][k] += red[t + o][k];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const double* tri = red[0];
+      double A[16]; int v = 0;
+      for (int j = 0; j < 4; ++j) for (int i = 0; i <= j; ++i) { A[4*j + i] = A[4*i + j] = tri[v++]; }
+      const double b[4] = { red[0][10], red[0][11], red[0][12], red[0][13] };
+      double L[16], D[4], yv[4], upd[4];
+      for (int i = 0; i < 16; ++i) L[i] = 0.0;
+      for (int j = 0; j < 4; ++j) {
+        double dd = A[5*j];
+        for (int k = 0; k < j; ++k) dd -= L[4*j + k]*L[4*j + k]*D[k];
+        D[j] = dd;
+        for (int i = j + 1; i < 4; ++i) { double w = A[4*i + j]; for (int k = 0; k < j; ++k) w -= L[4*i + k]*L[4*j + k]*D[k]; L[4*i + j] = w/dd; }
+      }
+      for (int i = 0; i < 4; ++i) { double w = b[i]; for (int k = 0; k < i; ++k) w -= L[4*i + k]*yv[k]; yv[i] = w; }
+      for (int i = 0; i < 4; ++i) yv[i] /= D[i];
+      for (int i = 3; i >= 0; --i) { double w = yv[i]; for (int k = i + 1; k < 4; ++k) w -= L[4*k + i]*upd[k]; upd[i] = w; }
+      const double th = -upd[2], c = cos(th), s = sin(th);
+      const double U[6] = { c, -s, s, c, -upd[0], -upd[1] };
+      const double R0 = st[0], R1 = st[1], R2 = st[2], R3 = st[3];
+      const double n4 = R0*U[4] + R1*U[5] + st[4], n5 = R2*U[4] + R3*U[5] + st[5];
+      st[0] = R0*U[0] + R1*U[2]; st[1] = R0*U[1] + R1*U[3]; st[2] = R2*U[0] + R3*U[2]; st[3] = R2*U[1] + R3*U[3];
+      st[4] = n4; st[5] = n5;
+      st[6] -= upd[3];
+      st[7] = red[0][14];
+    }
+    __syncthreads();
+  }
+  if (t < 6) out[t] = st[t];
+  if (t == 6) out[6] = st[7];
+}
+
 }  // namespace mcp

@@ -43,6 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
+    "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -59,6 +60,12 @@ def lib():
         L.mcp_kf_get_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mcp_kf_num_prev.argtypes = [ctypes.c_void_p]
+        L.mcp_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        L.mcp_kf_get_sbi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_sbi_score.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_sbi_iterate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_sbi_iterate_last.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_sbi_se3_from_se2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mcp_kf_get_corners.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.mcp_kf_get_row_lut.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p]
         L.mcp_kf_fast_thresh.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -114,6 +121,25 @@ class KeyFrame:
             arr = (ctypes.c_void_p * LEVELS)(*[None if m is None else m.ctypes.data for m in self._masks])
             mp = ctypes.cast(arr, ctypes.c_void_p)
         _chk(self._L.mcp_kf_make_lite(self._h, img.ctypes.data, img.strides[0], mp), "MakeKeyFrame_Lite")
+
+    # ---- SmallBlurryImage (src/SmallBlurryImage.cc), KeyFrame::MakeSBI (src/KeyFrame.cc:539-545)
+    def MakeSBI(self, blur=2.5):
+        _chk(self._L.mcp_kf_make_sbi(self._h, float(blur)), "MakeSBI")
+
+    def SBI(self):
+        """(mimSmall u8 30x40, mimTemplate f32 30x40, mimImageJacs f32 30x40x2)"""
+        small = np.zeros((30, 40), dtype=np.uint8)
+        templ = np.zeros((30, 40), dtype=np.float32)
+        jacs = np.zeros((30, 40, 2), dtype=np.float32)
+        _chk(self._L.mcp_kf_get_sbi(self._h, small.ctypes.data, templ.ctypes.data, jacs.ctypes.data), "SBI")
+        return small, templ, jacs
+
+    def SBIRotationFromLast(self, iterations=6):
+        """IteratePosRelToTarget of this frame's SBI against the previous one on this handle (Tracker::CalcSBIRotation)."""
+        se2 = np.zeros(6)
+        sc = np.zeros(1)
+        _chk(self._L.mcp_sbi_iterate_last(self._h, int(iterations), se2.ctypes.data, sc.ctypes.data), "SBIRotationFromLast")
+        return se2[:4].reshape(2, 2).copy(), se2[4:].copy(), float(sc[0])
 
     def NumPrev(self):
         """Frames held in the Level::imagePrev / vCornersPrev history (0..2)."""
@@ -214,3 +240,30 @@ def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, ove
     s = ctypes.c_double(0)
     _chk(lib().mcp_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s)), "track_pose_update")
     return mu, w[:n], s.value
+
+
+def sbi_score(cur, cands):
+    """Relocaliser::ScoreKFs (src/Relocaliser.cc:93-121): (index of the first smallest ZMSSD or -1, scores)."""
+    n = len(cands)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[None if c is None else c._h for c in cands])
+    sc = np.zeros(max(n, 1))
+    best = ctypes.c_int(-1)
+    _chk(lib().mcp_sbi_score(cur._h, n, ctypes.cast(ptrs, ctypes.c_void_p), sc.ctypes.data, ctypes.byref(best)), "sbi_score")
+    return best.value, sc[:n]
+
+
+def sbi_iterate(cur, target, iterations=6):
+    """SmallBlurryImage::IteratePosRelToTarget: (R 2x2, t 2, final score)."""
+    se2 = np.zeros(6)
+    sc = np.zeros(1)
+    _chk(lib().mcp_sbi_iterate(cur._h, target._h, int(iterations), se2.ctypes.data, sc.ctypes.data), "sbi_iterate")
+    return se2[:4].reshape(2, 2).copy(), se2[4:].copy(), float(sc[0])
+
+
+def sbi_se3_from_se2(R2, t2, cam_src, cam_target):
+    """SmallBlurryImage::SE3fromSE2 with the 40x30 camera instances: 3x3 rotation."""
+    se2 = np.concatenate([np.asarray(R2, dtype=np.float64).ravel(), np.asarray(t2, dtype=np.float64)])
+    a, b = cam_src.to_struct(), cam_target.to_struct()
+    R = np.zeros(9)
+    _chk(lib().mcp_sbi_se3_from_se2(se2.ctypes.data, ctypes.byref(a), ctypes.byref(b), R.ctypes.data), "sbi_se3_from_se2")
+    return R.reshape(3, 3)

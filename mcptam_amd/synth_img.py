@@ -100,3 +100,20 @@ def hypothesis_point(cam, kf, kf_oracle, pose, center, level, scale_along_ray, n
     down_p = rd * cam_height / abs(rd @ nrm)
     return dict(world_pos=Xw, pixel_right_w=R.T @ (right_p - cen_p), pixel_down_w=R.T @ (down_p - cen_p),
                 source_kf=kf, source_kf_oracle=kf_oracle, source_level=level, center=(int(center[0]), int(center[1])), fixed=0)
+
+
+def make_smooth_scene(seed=5, size=(640, 480)):
+    """A frame with large-scale structure (what a SmallBlurryImage can see after 16:1 reduction): low-pass noise plus two
+    rectangles.  Returns (image, image rotated by 3 degrees and shifted, an unrelated frame)."""
+    w, h = size
+    out = []
+    for k in range(2):
+        rng = np.random.default_rng([seed, k])
+        base = ndimage.gaussian_filter(rng.normal(size=(h, w)), 30)
+        base = (base - base.min()) / (base.max() - base.min()) * 200 + 20
+        base[h // 5:h // 2, w // 4:w // 2] += 30
+        base[5 * h // 8:7 * h // 8, 5 * w // 8:7 * w // 8] -= 25
+        out.append(np.clip(base, 0, 255).astype(np.uint8))
+    rot = ndimage.rotate(out[0].astype(float), 3.0, reshape=False, order=1, mode="nearest")
+    rot = ndimage.shift(rot, (6, -9), order=1, mode="nearest").astype(np.uint8)
+    return out[0], rot, out[1]

@@ -247,6 +247,15 @@ def img_lib():
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.orc_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                             ctypes.c_double, c_double_p, c_double_p, c_double_p]
+        L.orc_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        for f in ("orc_kf_sbi_small", "orc_kf_sbi_template", "orc_kf_sbi_jacs"):
+            getattr(L, f).restype = ctypes.c_void_p
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.orc_sbi_zmssd.restype = ctypes.c_double
+        L.orc_sbi_zmssd.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_sbi_score.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_double_p]
+        L.orc_sbi_iterate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p]
+        L.orc_sbi_se3_from_se2.argtypes = [c_double_p, ctypes.c_void_p, ctypes.c_void_p, c_double_p]
         _IMG_BOUND = True
     return L
 
@@ -312,6 +321,44 @@ class OracleKeyFrame:
         sc = np.zeros(max(n, 1))
         n = self._L.orc_kf_get_candidates(self._h, level, pos.ctypes.data, _dp(sc), n)
         return pos[:n], sc[:n]
+
+
+    # ---- SmallBlurryImage (src/SmallBlurryImage.cc)
+    def MakeSBI(self, blur=2.5):
+        self._L.orc_kf_make_sbi(self._h, float(blur))
+
+    def SBI(self):
+        """(mimSmall u8 30x40, mimTemplate f32 30x40, mimImageJacs f32 30x40x2)"""
+        def arr(fn, ct, n):
+            return np.ctypeslib.as_array(ctypes.cast(fn(self._h), ctypes.POINTER(ct)), shape=(n,)).copy()
+        return (arr(self._L.orc_kf_sbi_small, ctypes.c_uint8, 1200).reshape(30, 40),
+                arr(self._L.orc_kf_sbi_template, ctypes.c_float, 1200).reshape(30, 40),
+                arr(self._L.orc_kf_sbi_jacs, ctypes.c_float, 2400).reshape(30, 40, 2))
+
+
+def oracle_sbi_score(cur, cands):
+    """Relocaliser::ScoreKFs: (best index or -1, scores)."""
+    n = len(cands)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[c._h for c in cands])
+    sc = np.zeros(max(n, 1))
+    best = img_lib().orc_sbi_score(cur._h, n, ctypes.cast(ptrs, ctypes.c_void_p), _dp(sc))
+    return best, sc[:n]
+
+
+def oracle_sbi_iterate(cur, target, iterations=6):
+    """SmallBlurryImage::IteratePosRelToTarget: (R 2x2, t 2, score)."""
+    se2 = np.zeros(6)
+    sc = np.zeros(1)
+    img_lib().orc_sbi_iterate(cur._h, target._h, int(iterations), _dp(se2), _dp(sc))
+    return se2[:4].reshape(2, 2).copy(), se2[4:].copy(), float(sc[0])
+
+
+def oracle_sbi_se3_from_se2(R2, t2, cam_src, cam_target):
+    se2 = np.concatenate([np.asarray(R2, dtype=np.float64).ravel(), np.asarray(t2, dtype=np.float64)])
+    a, b = cam_src.to_struct(), cam_target.to_struct()
+    R = np.zeros(9)
+    img_lib().orc_sbi_se3_from_se2(_dp(se2), ctypes.byref(a), ctypes.byref(b), _dp(R))
+    return R.reshape(3, 3)
 
 
 def oracle_minipatch_find(src, dst, level, src_pos, dst_pos, rng):

@@ -18,7 +18,9 @@ typedef struct { int w, h; uint8_t* img; uint8_t* mask; int ncorners, ccorners; 
                  int ncand; orc_int2* cand; double* cand_score;
                  /* Level::imagePrev / vCornersPrev: circular buffers of Level::snNumPrev = 2 (KeyFrame.cc:71, KeyFrame.h:124-125,147-148); [0] = oldest */
                  int nprev; uint8_t* pimg[NUM_PREV]; orc_int2* pcorners[NUM_PREV]; int pncorners[NUM_PREV]; } olevel;
-struct orc_kf { olevel lev[ORC_LEVELS]; int adaptive, glare, pavgb, has_image; };
+#define SBI_N (ORC_SBI_W*ORC_SBI_H)
+typedef struct { uint8_t small[SBI_N]; float templ[SBI_N]; float jacs[2*SBI_N]; } osbi;
+struct orc_kf { olevel lev[ORC_LEVELS]; int adaptive, glare, pavgb, has_image; osbi* sbi; };
 
 orc_kf* orc_kf_create(int w, int h, int adaptive, int glare, int pavgb) {
   orc_kf* k = (orc_kf*)calloc(1, sizeof *k);
@@ -36,6 +38,7 @@ void orc_kf_destroy(orc_kf* k) {
   if (!k) return;
   for (int l = 0; l < ORC_LEVELS; l++) { olevel* L = &k->lev[l]; free(L->img); free(L->mask); free(L->corners); free(L->lut); free(L->cand); free(L->cand_score);
     for (int j = 0; j < NUM_PREV; j++) { free(L->pimg[j]); free(L->pcorners[j]); } }
+  free(k->sbi);
   free(k);
 }
 
@@ -554,7 +557,8 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const
   if (override_sigma > 0) s2 = override_sigma; else s2 = orc_tukey_sigma_squared(e2, ne);
   if (sigma_out) *sigma_out = s2;
   double C[36], v[6];
-  for (int a = 0; a < 36; a++) C[a] = 0; for (int a = 0; a < 6; a++) { C[7*a] = 100.0; v[a] = 0; }   /* add_prior(100) */
+  for (int a = 0; a < 36; a++) C[a] = 0;
+  for (int a = 0; a < 6; a++) { C[7*a] = 100.0; v[a] = 0; }   /* add_prior(100) */
   for (int i = 0; i < n; i++) {
     if (!found[i]) continue;
     const double err2 = ex[2*i]*ex[2*i] + ex[2*i+1]*ex[2*i+1];
@@ -574,4 +578,231 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const
   for (int i = 5; i >= 0; i--) { double s = mu[i]; for (int k = i + 1; k < 6; k++) s -= L[6*k + i]*mu[k]; mu[i] = s/L[6*i + i]; }
   free(e2); free(ex);
   return 0;
+}
+
+
+/* ================================================================== SmallBlurryImage / Relocaliser */
+#include "ba_oracle.h"
+/* cv::resize(8U, INTER_LINEAR) [3P-memory, OpenCV imgproc resize.cpp]: source coordinate (dx+0.5)*scale-0.5 in float,
+ * clamped at the borders, 11-bit fixed-point weights (INTER_RESIZE_COEF_BITS), horizontal pass in int, vertical pass
+ * ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2. */
+static void resize_coeffs(int src, int dst, int* idx, short* w0, short* w1) {
+  const double scale = (double)src/dst;
+  for (int d = 0; d < dst; d++) {
+    float f = (float)((d + 0.5)*scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= src - 1) { f = 0; s = src - 1; }           /* the second tap is clamped to the last pixel with weight 0 */
+    idx[d] = s;
+    float a0 = (1.f - f)*2048.f, a1 = f*2048.f;
+    w0[d] = (short)lrintf(a0); w1[d] = (short)lrintf(a1);
+  }
+}
+static void resize_linear_u8(const uint8_t* in, int iw, int ih, uint8_t* out, int ow, int oh) {
+  int* xi = (int*)malloc(sizeof(int)*ow); short* xa = (short*)malloc(2*ow); short* xb = (short*)malloc(2*ow);
+  int* yi = (int*)malloc(sizeof(int)*oh); short* ya = (short*)malloc(2*oh); short* yb = (short*)malloc(2*oh);
+  resize_coeffs(iw, ow, xi, xa, xb); resize_coeffs(ih, oh, yi, ya, yb);
+  for (int y = 0; y < oh; y++) {
+    const uint8_t* r0 = in + (size_t)yi[y]*iw; const uint8_t* r1 = in + (size_t)(yi[y] + 1 < ih ? yi[y] + 1 : ih - 1)*iw;
+    for (int x = 0; x < ow; x++) {
+      const int x0 = xi[x], x1 = x0 + 1 < iw ? x0 + 1 : iw - 1;
+      const int h0 = r0[x0]*xa[x] + r0[x1]*xb[x], h1 = r1[x0]*xa[x] + r1[x1]*xb[x];
+      out[y*ow + x] = (uint8_t)((((ya[y]*(h0 >> 4)) >> 16) + ((yb[y]*(h1 >> 4)) >> 16) + 2) >> 2);
+    }
+  }
+  free(xi); free(xa); free(xb); free(yi); free(ya); free(yb);
+}
+/* CVD::convolveGaussian(Image<float>&, sigma) [3P-memory, cvd/convolution.h]: separable, kernel half-size
+ * ceil(3 sigma), taps exp(-i^2/(2 sigma^2)) normalised to unit sum, float accumulation (centre tap first, then the
+ * symmetric pairs outwards), samples outside the image contribute nothing; rows first, then columns, in place. */
+static int gauss_kernel(double sigma, float* k /* >= 32 */) {
+  int ks = (int)ceil(3.0*sigma); if (ks > 31) ks = 31;
+  double sum = 1.0;
+  for (int i = 1; i <= ks; i++) sum += 2.0*exp(-(double)i*i/(2.0*sigma*sigma));
+  k[0] = (float)(1.0/sum);
+  for (int i = 1; i <= ks; i++) k[i] = (float)(exp(-(double)i*i/(2.0*sigma*sigma))/sum);
+  return ks;
+}
+static void convolve_gaussian(float* I, int w, int h, double sigma) {
+  float k[32]; const int ks = gauss_kernel(sigma, k);
+  float* tmp = (float*)malloc(sizeof(float)*w*h);
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    float a = I[y*w + x]*k[0];
+    for (int i = 1; i <= ks; i++) { float p = 0.f; if (x - i >= 0) p += I[y*w + x - i]; if (x + i < w) p += I[y*w + x + i]; a += p*k[i]; }
+    tmp[y*w + x] = a;
+  }
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    float a = tmp[y*w + x]*k[0];
+    for (int i = 1; i <= ks; i++) { float p = 0.f; if (y - i >= 0) p += tmp[(y - i)*w + x]; if (y + i < h) p += tmp[(y + i)*w + x]; a += p*k[i]; }
+    I[y*w + x] = a;
+  }
+  free(tmp);
+}
+/* SmallBlurryImage::MakeFromKF + MakeJacs, SmallBlurryImage.cc:67-118 */
+int orc_kf_make_sbi(orc_kf* k, double blur) {
+  if (!k->sbi) k->sbi = (osbi*)calloc(1, sizeof(osbi));
+  osbi* s = k->sbi;
+  const int W = ORC_SBI_W, H = ORC_SBI_H;
+  resize_linear_u8(k->lev[0].img, k->lev[0].w, k->lev[0].h, s->small, W, H);                /* :76-79 */
+  unsigned int sum = 0;
+  for (int i = 0; i < SBI_N; i++) sum += s->small[i];                                         /* :81-85 */
+  const float mean = ((float)sum)/SBI_N;                                                      /* :87 */
+  for (int i = 0; i < SBI_N; i++) s->templ[i] = s->small[i] - mean;                            /* :89-92 */
+  convolve_gaussian(s->templ, W, H, blur);                                                    /* :94 */
+  for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {                                    /* MakeJacs :99-118, no 0.5 factor */
+    float gx = 0.f, gy = 0.f;
+    if (x >= 1 && y >= 1 && x < W - 1 && y < H - 1) { gx = s->templ[y*W + x + 1] - s->templ[y*W + x - 1]; gy = s->templ[(y + 1)*W + x] - s->templ[(y - 1)*W + x]; }
+    s->jacs[2*(y*W + x)] = gx; s->jacs[2*(y*W + x) + 1] = gy;
+  }
+  return 0;
+}
+const uint8_t* orc_kf_sbi_small(orc_kf* k) { return k->sbi ? k->sbi->small : NULL; }
+const float* orc_kf_sbi_template(orc_kf* k) { return k->sbi ? k->sbi->templ : NULL; }
+const float* orc_kf_sbi_jacs(orc_kf* k) { return k->sbi ? k->sbi->jacs : NULL; }
+/* SmallBlurryImage::ZMSSD, :122-134 */
+double orc_sbi_zmssd(orc_kf* a, orc_kf* b) {
+  double ssd = 0.0;
+  for (int i = 0; i < SBI_N; i++) { const double d = a->sbi->templ[i] - b->sbi->templ[i]; ssd += d*d; }
+  return ssd;
+}
+/* Relocaliser::ScoreKFs, Relocaliser.cc:93-121 (strict <: the first smallest wins) */
+int orc_sbi_score(orc_kf* cur, int n, orc_kf* const* cands, double* scores) {
+  double best = DBL_MAX; int bi = -1;
+  for (int i = 0; i < n; i++) {
+    if (!cands[i]->sbi) { scores[i] = DBL_MAX; continue; }
+    scores[i] = orc_sbi_zmssd(cur, cands[i]);
+    if (scores[i] < best) { best = scores[i]; bi = i; }
+  }
+  return bi;
+}
+/* CVD::transform on a float image with default value [3P-memory], as cvd_transform8 above */
+static void cvd_transform_f(const float* in, int iw, int ih, float* out, const double M[4], double inx, double iny, float defval) {
+  const int w = iw, h = ih;
+  const double across[2] = { M[0], M[2] }, down[2] = { M[1], M[3] };
+  double p0[2] = { inx, iny };                       /* outOrig = 0 */
+  const double cr[2] = { down[0] - w*across[0], down[1] - w*across[1] };
+  const double xb = iw - 1, yb = ih - 1;
+  double p[2] = { p0[0], p0[1] };
+  for (int i = 0; i < h; ++i, p[0] += cr[0], p[1] += cr[1])
+    for (int j = 0; j < w; ++j, p[0] += across[0], p[1] += across[1]) {
+      if (0 <= p[0] && 0 <= p[1] && p[0] < xb && p[1] < yb) {
+        const int lx = (int)p[0], ly = (int)p[1];
+        const double x = p[0] - lx, y = p[1] - ly;
+        const float* q = in + (size_t)ly*iw + lx;
+        out[i*w + j] = (float)((1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]));
+      } else out[i*w + j] = defval;
+    }
+}
+static void se2_mul(const double* A, const double* B, double* C) {     /* {R00,R01,R10,R11,tx,ty} */
+  const double r[6] = { A[0]*B[0] + A[1]*B[2], A[0]*B[1] + A[1]*B[3], A[2]*B[0] + A[3]*B[2], A[2]*B[1] + A[3]*B[3],
+                        A[0]*B[4] + A[1]*B[5] + A[4], A[2]*B[4] + A[3]*B[5] + A[5] };
+  memcpy(C, r, sizeof r);
+}
+static void se2_inv(const double* A, double* C) {
+  const double r[6] = { A[0], A[2], A[1], A[3], -(A[0]*A[4] + A[2]*A[5]), -(A[1]*A[4] + A[3]*A[5]) };
+  memcpy(C, r, sizeof r);
+}
+/* 4x4 SPD solve (TooN Cholesky<4>::backsub, LDL^T) */
+static void solve4(const double* A, const double* b, double* x) {
+  double L[16] = {0}, D[4];
+  for (int j = 0; j < 4; j++) {
+    double d = A[5*j];
+    for (int k = 0; k < j; k++) d -= L[4*j + k]*L[4*j + k]*D[k];
+    D[j] = d;
+    for (int i = j + 1; i < 4; i++) { double v = A[4*i + j]; for (int k = 0; k < j; k++) v -= L[4*i + k]*L[4*j + k]*D[k]; L[4*i + j] = v/d; }
+  }
+  double y[4];
+  for (int i = 0; i < 4; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[4*i + k]*y[k]; y[i] = v; }
+  for (int i = 0; i < 4; i++) y[i] /= D[i];
+  for (int i = 3; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 4; k++) v -= L[4*k + i]*x[k]; x[i] = v; }
+}
+/* SmallBlurryImage::IteratePosRelToTarget (ESM tracking), :139-245 */
+int orc_sbi_iterate(orc_kf* cur, orc_kf* target, int iterations, double se2[6], double* score) {
+  const int W = ORC_SBI_W, H = ORC_SBI_H;
+  const int cx = W/2, cy = H/2;
+  double CtoC[6] = { 1, 0, 0, 1, 0, 0 };
+  const double WfromC[6] = { 1, 0, 0, 1, (double)cx, (double)cy };
+  double WfromCinv[6]; se2_inv(WfromC, WfromCinv);
+  double mean_offset = 0.0, final_score = 0.0;
+  float warped[SBI_N];
+  const osbi* me = cur->sbi; const osbi* ot = target->sbi;
+  for (int it = 0; it < iterations; it++) {
+    final_score = 0.0;
+    double acc[4] = { 0, 0, 0, 0 }, tri[10] = { 0 };
+    double X[6], T1[6]; se2_mul(WfromC, CtoC, T1); se2_mul(T1, WfromCinv, X);
+    cvd_transform_f(me->templ, W, H, warped, X, X[4], X[5], -9e20f);
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+      if (!(x >= 1 && y >= 1 && x < W - 1 && y < H - 1)) continue;
+      const float l = warped[y*W + x - 1], r = warped[y*W + x + 1], u = warped[(y - 1)*W + x], d = warped[(y + 1)*W + x], here = warped[y*W + x];
+      if (l + r + u + d + here < -9999.9) continue;
+      const double g0 = r - l, g1 = d - u;                                   /* float differences, :189-190 */
+      const double s0 = 0.25*(g0 + (double)ot->jacs[2*(y*W + x)]), s1 = 0.25*(g1 + (double)ot->jacs[2*(y*W + x) + 1]);
+      const double J[4] = { s0, s1, -(y - cy)*s0 + (x - cx)*s1, 1.0 };
+      const double diff = (here - ot->templ[y*W + x]) + mean_offset;
+      final_score += diff*diff;
+      for (int a = 0; a < 4; a++) acc[a] += diff*J[a];
+      tri[0] += J[0]*J[0]; tri[1] += J[1]*J[0]; tri[2] += J[1]*J[1]; tri[3] += J[2]*J[0]; tri[4] += J[2]*J[1];
+      tri[5] += J[2]*J[2]; tri[6] += J[0]; tri[7] += J[1]; tri[8] += J[2]; tri[9] += 1.0;
+    }
+    double m4[16]; int v = 0;
+    for (int j = 0; j < 4; j++) for (int i = 0; i <= j; i++) { m4[4*j + i] = m4[4*i + j] = tri[v++]; }
+    double upd[4]; solve4(m4, acc, upd);
+    const double th = -upd[2];
+    const double U[6] = { cos(th), -sin(th), sin(th), cos(th), -upd[0], -upd[1] };
+    se2_mul(CtoC, U, CtoC);
+    mean_offset -= upd[3];
+  }
+  memcpy(se2, CtoC, sizeof CtoC);
+  *score = final_score;
+  return 0;
+}
+/* TaylorCamera::UnProject, TaylorCamera.cc:319-347 */
+static void cam_unproject(const orc_camera* c, const double uv[2], double out[3]) {
+  const double det = c->affine[0]*c->affine[3] - c->affine[1]*c->affine[2];
+  const double ai[4] = { c->affine[3]/det, -c->affine[1]/det, -c->affine[2]/det, c->affine[0]/det };
+  const double dx = uv[0] - c->center[0], dy = uv[1] - c->center[1];
+  const double x = ai[0]*dx + ai[1]*dy, y = ai[2]*dx + ai[3]*dy;
+  const double rho = sqrt(x*x + y*y);
+  const double p[5] = { c->params[0], 0.0, c->params[1], c->params[2], c->params[3] };
+  double z = p[4]; for (int i = 3; i >= 0; i--) z = z*rho + p[i];
+  const double n = sqrt(x*x + y*y + z*z);
+  out[0] = x/n; out[1] = y/n; out[2] = z/n;
+}
+/* SmallBlurryImage::SE3fromSE2, :250-310 (cameras already at SBI size) */
+void orc_sbi_se3_from_se2(const double se2[6], const orc_camera* cs, const orc_camera* ct, double R[9]) {
+  const double c[2] = { ORC_SBI_W/2, ORC_SBI_H/2 };
+  double turned[2][2], orig[2][3];
+  const double off[2][2] = { { 5, 0 }, { -5, 0 } };
+  for (int i = 0; i < 2; i++) {
+    turned[i][0] = c[0] + se2[0]*off[i][0] + se2[1]*off[i][1] + se2[4];
+    turned[i][1] = c[1] + se2[2]*off[i][0] + se2[3]*off[i][1] + se2[5];
+    const double px[2] = { c[0] + off[i][0], c[1] + off[i][1] };
+    cam_unproject(ct, px, orig[i]);
+  }
+  double so3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+  for (int it = 0; it < 3; it++) {
+    double C[9] = { 10, 0, 0, 0, 10, 0, 0, 0, 10 }, v[3] = { 0, 0, 0 };        /* add_prior(10) */
+    for (int i = 0; i < 2; i++) {
+      double cam[3]; m3v(so3, orig[i], cam);
+      double px[2], D[4]; orc_cam_project(cs, cam, px, D);
+      const double err[2] = { turned[i][0] - px[0], turned[i][1] - px[1] };
+      double dT[3], dP[3]; orc_cam_sphere_deriv(cam, dT, dP);
+      double J[2][3];
+      for (int m = 0; m < 3; m++) {
+        double mot[3] = { 0, 0, 0 };                                           /* SO3::generator_field(m, cam) = e_m x cam */
+        mot[(m + 1)%3] = -cam[(m + 2)%3]; mot[(m + 2)%3] = cam[(m + 1)%3];
+        const double sm[2] = { dT[0]*mot[0] + dT[1]*mot[1] + dT[2]*mot[2], dP[0]*mot[0] + dP[1]*mot[1] + dP[2]*mot[2] };
+        J[0][m] = D[0]*sm[0] + D[1]*sm[1]; J[1][m] = D[2]*sm[0] + D[3]*sm[1];
+      }
+      for (int r = 0; r < 2; r++) for (int a = 0; a < 3; a++) { v[a] += J[r][a]*err[r]; for (int b = 0; b < 3; b++) C[3*a + b] += J[r][a]*J[r][b]; }
+    }
+    double Ci[9]; inv3(C, Ci);
+    double mu[3]; m3v(Ci, v, mu);
+    double E[9]; orc_so3_exp(mu, E);
+    double Rn[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rn[3*a + b] = E[3*a]*so3[b] + E[3*a + 1]*so3[3 + b] + E[3*a + 2]*so3[6 + b];
+    memcpy(so3, Rn, sizeof Rn);
+  }
+  memcpy(R, so3, sizeof(double)*9);
 }

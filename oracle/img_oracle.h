@@ -70,6 +70,24 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* found_pos, 
                           const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
                           double mu[6], double* weights_out, double* sigma_sq_out);
 
+/* ---- SmallBlurryImage / Relocaliser (src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121) ----------------
+ * 40x30 thumbnail of level 0 (cv::resize INTER_LINEAR [3P-memory]), zero-mean float template blurred with
+ * CVD::convolveGaussian [3P-memory], gradient image, ZMSSD, ESM SE2 alignment, SE2 -> camera rotation. */
+#define ORC_SBI_W 40
+#define ORC_SBI_H 30
+int orc_kf_make_sbi(orc_kf*, double blur);             /* MakeFromKF + MakeJacs */
+const uint8_t* orc_kf_sbi_small(orc_kf*);              /* mimSmall, 1200 bytes */
+const float*   orc_kf_sbi_template(orc_kf*);           /* mimTemplate, 1200 floats */
+const float*   orc_kf_sbi_jacs(orc_kf*);               /* mimImageJacs, 1200 x (gx, gy) */
+double orc_sbi_zmssd(orc_kf* a, orc_kf* b);
+/* Relocaliser::ScoreKFs: best (first smallest) ZMSSD among n candidates; scores[n]; returns best index or -1 */
+int orc_sbi_score(orc_kf* cur, int n, orc_kf* const* cands, double* scores);
+/* IteratePosRelToTarget: se2 = { R00, R01, R10, R11, tx, ty } */
+int orc_sbi_iterate(orc_kf* cur, orc_kf* target, int iterations, double se2[6], double* score);
+/* SE3fromSE2 (cameras already at SBI size): rotation R (row-major) */
+struct orc_camera;
+void orc_sbi_se3_from_se2(const double se2[6], const struct orc_camera* cam_src, const struct orc_camera* cam_target, double R[9]);
+
 #ifdef __cplusplus
 }
 #endif

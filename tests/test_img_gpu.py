@@ -284,3 +284,75 @@ def test_candidate_stability_pruning_with_history(gpu_required):
         survivors.append(sum(len(g.Candidates(l)[0]) for l in range(4)))
     assert survivors[1] < survivors[0]            # the pruning removes unstable candidates once there is history
     assert survivors[1] > 20
+
+
+def _sbi_frames(scene):
+    from mcptam_amd import synth_img
+    return synth_img.make_smooth_scene()
+
+
+def test_small_blurry_image_bit_exact(gpu_required, scene):
+    """SmallBlurryImage::MakeFromKF + MakeJacs (src/SmallBlurryImage.cc:67-118): thumbnail bytes, float template and
+    gradient image identical to the oracle (integer resize, float Gaussian with the same tap order, contraction off)."""
+    for img in _sbi_frames(scene):
+        for blur in (2.5, 1.0):
+            g, o = _pair(640, 480)
+            g.MakeKeyFrame_Lite(img); o.MakeKeyFrame_Lite(img)
+            g.MakeSBI(blur); o.MakeSBI(blur)
+            sg, tg, jg = g.SBI()
+            so, to, jo = o.SBI()
+            assert np.array_equal(sg, so)
+            assert np.array_equal(tg, to), np.abs(tg - to).max()
+            assert np.array_equal(jg, jo)
+            assert abs(float(tg.mean())) < 0.1*float(tg.std()) and tg.std() > 1.0
+
+
+def test_relocaliser_scores_and_esm_alignment(gpu_required, scene):
+    """Relocaliser::ScoreKFs (bit-exact ZMSSD, first-smallest winner), IteratePosRelToTarget (ESM SE2, double sums in a
+    different but fixed order: 1e-9 relative) and SE3fromSE2, src/Relocaliser.cc:61-121, src/SmallBlurryImage.cc:139-310."""
+    from mcptam_amd.keyframe import sbi_iterate, sbi_score, sbi_se3_from_se2
+    from mcptam_amd.taylor_camera import TaylorCamera
+    from oracle import oracle_sbi_iterate, oracle_sbi_score, oracle_sbi_se3_from_se2
+    frames = _sbi_frames(scene)
+    G, O = [], []
+    for img in frames:
+        g, o = _pair(640, 480)
+        g.MakeKeyFrame_Lite(img); o.MakeKeyFrame_Lite(img)
+        g.MakeSBI(); o.MakeSBI()
+        G.append(g); O.append(o)
+    nosbi_g, nosbi_o = _pair(640, 480)
+    nosbi_g.MakeKeyFrame_Lite(frames[0]); nosbi_o.MakeKeyFrame_Lite(frames[0])
+    bg, sg = sbi_score(G[1], [G[2], nosbi_g, G[0], G[1], G[0]])
+    bo, so = oracle_sbi_score(O[1], [O[2], nosbi_o, O[0], O[1], O[0]])
+    assert bg == bo == 3 and np.array_equal(sg, so)                      # itself; the SBI-less keyframe is skipped (DBL_MAX)
+    bg, sg = sbi_score(G[1], [G[2], G[0], G[0]])
+    assert bg == 1 and sg[1] == sg[2] < sg[0]                            # ties: the first one wins
+    cam = TaylorCamera(scene["cam"].params, (640, 480), (640, 480), (40, 30))
+    for its in (1, 6, 10):
+        Rg, tg, scg = sbi_iterate(G[1], G[0], its)
+        Ro, to, sco = oracle_sbi_iterate(O[1], O[0], its)
+        assert np.allclose(Rg, Ro, rtol=0, atol=1e-9) and np.allclose(tg, to, rtol=0, atol=1e-8) and abs(scg - sco) <= 1e-8*sco
+        R3g = sbi_se3_from_se2(Rg, tg, cam, cam)
+        R3o = oracle_sbi_se3_from_se2(Ro, to, cam, cam)
+        assert np.allclose(R3g, R3o, rtol=0, atol=1e-9) and np.allclose(R3g @ R3g.T, np.eye(3), atol=1e-12)
+    ang = np.degrees(np.arctan2(Rg[1, 0], Rg[0, 0]))
+    assert 2.5 < abs(ang) < 3.8                                          # the 3 degree in-plane rotation is found
+    Rg, tg, scg = sbi_iterate(G[0], G[0], 6)
+    assert np.array_equal(Rg, np.eye(2)) and np.array_equal(tg, np.zeros(2)) and scg == 0.0
+
+
+def test_sbi_rotation_against_last_frame(gpu_required, scene):
+    """Tracker::CalcSBIRotation's per-camera step: MakeSBI keeps the previous SBI of the handle as 'last frame'."""
+    from mcptam_amd.keyframe import sbi_iterate
+    frames = _sbi_frames(scene)
+    a, b = _pair(640, 480)[0], _pair(640, 480)[0]
+    cur = _pair(640, 480)[0]
+    a.MakeKeyFrame_Lite(frames[0]); a.MakeSBI()
+    b.MakeKeyFrame_Lite(frames[1]); b.MakeSBI()
+    cur.MakeKeyFrame_Lite(frames[0]); cur.MakeSBI()
+    with pytest.raises(RuntimeError):
+        cur.SBIRotationFromLast()
+    cur.MakeKeyFrame_Lite(frames[1]); cur.MakeSBI()
+    R1, t1, s1 = cur.SBIRotationFromLast(6)
+    R2, t2, s2 = sbi_iterate(b, a, 6)
+    assert np.array_equal(R1, R2) and np.array_equal(t1, t2) and s1 == s2
