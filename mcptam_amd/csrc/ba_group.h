@@ -316,8 +316,10 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     }
   };
   prefetch(sp0);
+  // the staging arrays are zero-filled once; after each chunk every thread clears exactly the rows it wrote
+  for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
+  int orow[6];
   for (int base = sp0; base < sp1; base += SCH_CHUNK) {
-    for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
     if (t < SCH_CHUNK) {
       double I6[6] = {0, 0, 0, 0, 0, 0}; double g3[3] = {0, 0, 0};
       if (plpt >= 0) {
@@ -335,6 +337,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       const double* I6 = Vi + 6*pl;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
+        orow[k] = prow[k];
         if (prow[k] < 0) continue;
         const double w0 = pw[k][0], w1 = pw[k][1], w2 = pw[k][2];
         double* wd = Wd + prow[k]*SCH_LD + 3*pl;
@@ -374,6 +377,13 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       racc += s;
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (orow[k] < 0) continue;
+      double* wd = Wd + orow[k]*SCH_LD + 3*pl;
+      double* yd = Yd + orow[k]*SCH_LD + 3*pl;
+      wd[0] = 0.0; wd[1] = 0.0; wd[2] = 0.0; yd[0] = 0.0; yd[1] = 0.0; yd[2] = 0.0;
+    }
   }
   // flush: S -= S_loc (lower triangle in global order), rhs -= r_loc
   const int np = P.np;
