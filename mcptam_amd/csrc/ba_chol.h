@@ -231,9 +231,52 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   CHOL_STAMP(4);
 }
 
-// backward substitution L^T x = y (y = row n of the augmented matrix); single workgroup.
+// backward substitution L^T x = y (y = row n of the augmented matrix); one workgroup per system.
+// Wavefront 0 solves the 32x32 triangle of the step (diagonal tile prefetched into registers during the previous step's
+// update); the other 7 wavefronts spread the update y[c] -= sum_r L[k0+r][c] x[k0+r] over (column pair, 16-row slice) items --
+// one L2 round trip of 16 independent 16-byte loads per item (n = 6P is even, so column pairs are aligned) instead of a
+// 32-long walk per column -- and combine the slices with ds_add_f64 on the LDS copy of y.
 constexpr int CH_BACK_THREADS = 512;
+constexpr int CH_BACK_RG = 2;            // row slices per column
 constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
+// tiles of step kb into LDS, spread over `nth` threads (index `u`): Lt = L_kk (lower, unit-padded outside the matrix),
+// Tt = the tile below it, L[k0+32 .. ][k0 ..] (zero outside); coalesced row segments; load and LDS store are split so the
+// loads stay in flight during the update
+constexpr int CH_STAGE_PER = 5;                            // ceil(2*1024 / (CH_BACK_THREADS - 64))
+__device__ inline void chol_back_stage_load(const double* __restrict__ S, int n, int nblk, int kb, int u, int nth, double* v) {
+  const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
+  const int kb0 = k0 + CH_NB, nbb = (kb + 1 < nblk) ? min(CH_NB, n - kb0) : 0;
+#pragma unroll
+  for (int i = 0; i < CH_STAGE_PER; ++i) {
+    const int e = u + i*nth;
+    const int which = e >> 10, r = (e >> 5) & 31, c = e & 31;
+    v[i] = 0.0;
+    if (e < 2048) {
+      if (which == 0) v[i] = (r >= c && r < nbe && c < nbe) ? S[(size_t)(k0 + r)*n + k0 + c] : ((r == c) ? 1.0 : 0.0);
+      else v[i] = (r < nbb && c < nbe) ? S[(size_t)(kb0 + r)*n + k0 + c] : 0.0;
+    }
+  }
+}
+__device__ inline void chol_back_stage_store(int u, int nth, const double* v, double (*Lt)[CH_NB + 1], double (*Tt)[CH_NB + 1]) {
+#pragma unroll
+  for (int i = 0; i < CH_STAGE_PER; ++i) {
+    const int e = u + i*nth;
+    if (e < 2048) { if ((e >> 10) == 0) Lt[(e >> 5) & 31][e & 31] = v[i]; else Tt[(e >> 5) & 31][e & 31] = v[i]; }
+  }
+}
+#ifdef MCP_CHOL_PROF
+__device__ unsigned long long g_back_prof[256*2*8];
+#define BACK_STAMP(who, i) do { if (blockIdx.x == 0 && threadIdx.x == (who)*64) g_back_prof[(kb*2 + (who))*8 + (i)] = clock64(); } while (0)
+#else
+#define BACK_STAMP(who, i) do {} while (0)
+#endif
+// Time step kb: wavefront 0 (solver) first applies the one tile that links the block it solved in the previous step to
+// block kb (tile column in registers, x broadcast with v_readlane), then solves the 32x32 triangle; at the same time
+// the other 7 wavefronts subtract the PREVIOUS block's contribution from all column blocks further left, over
+// (column pair, 16-row slice) items -- one L2 round trip of 16 independent 16-byte loads per item (n = 6P is even, so
+// column pairs are aligned) -- combining the slices with ds_add_f64 on the LDS copy of y; they first stage the solver's
+// two tiles of the NEXT step in LDS.  One barrier per step; the solver touches neither global memory nor the
+// bulk update of the step before.
 __global__ void __launch_bounds__(CH_BACK_THREADS)
 k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout, size_t sys_stride) {
   if (blockIdx.x) { S += blockIdx.x*sys_stride; xout += blockIdx.x*sys_stride; }
@@ -241,17 +284,29 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
   const int t = threadIdx.x;
   const double* y = S + (size_t)n*n;
   for (int i = t; i < n; i += CH_BACK_THREADS) xs[i] = y[i];
-  __syncthreads();
   const int nblk = (n + CH_NB - 1)/CH_NB;
+  const bool solver = t < 64;
+  const int rr = t & 31;
+  __shared__ double Lt[2][CH_NB][CH_NB + 1], Tt[2][CH_NB][CH_NB + 1];     // tiles of the current / next step (by parity)
+  double xprev = 0.0;
+  if (t >= 64) {
+    double sv[CH_STAGE_PER];
+    chol_back_stage_load(S, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv);
+    chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(nblk - 1) & 1], Tt[(nblk - 1) & 1]);
+  }
+  __syncthreads();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
-    if (t < 64) {
-      const int rr = t & 31;
-      // column rr of L_kk: Lc[c] = L[k0+c][k0+rr], c >= rr
-      double Lc[CH_NB];
+    BACK_STAMP(0, 0); BACK_STAMP(1, 0);
+    if (solver) {
+      // column rr of L_kk and of the tile below it, staged in LDS by wavefront 1 during the previous step
+      double Lc[CH_NB], Tf[CH_NB];
 #pragma unroll
-      for (int c = 0; c < CH_NB; ++c) Lc[c] = (c >= rr && c < nbe && rr < nbe) ? S[(size_t)(k0 + c)*n + k0 + rr] : ((c == rr) ? 1.0 : 0.0);
+      for (int c = 0; c < CH_NB; ++c) { Lc[c] = Lt[kb & 1][c][rr]; Tf[c] = Tt[kb & 1][c][rr]; }
       double yv = (rr < nbe) ? xs[k0 + rr] : 0.0;
+      // contribution of the block solved in the previous step (Tf is zero in the first step)
+#pragma unroll
+      for (int r = 0; r < CH_NB; ++r) yv -= Tf[r]*readlane_f64(xprev, r);
       double dg = 1.0;
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) if (c == rr) dg = Lc[c];
@@ -263,18 +318,39 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
         else if (rr < c) yv -= Lc[c]*xc;
       }
       if (t < nbe) xs[k0 + t] = yv;
+      xprev = (rr < nbe) ? yv : 0.0;
+      BACK_STAMP(0, 1);
+    } else {
+      double sv[CH_STAGE_PER];
+      if (kb > 0) chol_back_stage_load(S, n, nblk, kb - 1, t - 64, CH_BACK_THREADS - 64, sv);      // in flight during the update
+      if (kb + 1 < nblk) {
+      // x of block kb+1 (solved in the previous step) against the structurally non-zero tiles of block row kb+1 left of tile kb
+      const int ub = kb + 1, u0 = ub*CH_NB, nbu = min(CH_NB, n - u0);
+      const int l0 = row_start[ub], l1 = row_start[ub + 1];
+      constexpr int RPI = CH_NB/CH_BACK_RG;                 // rows per item
+      const int items = (l1 - l0)*(CH_NB/2)*CH_BACK_RG;     // (tile, column pair, row slice)
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      for (int q = t - 64; q < items; q += CH_BACK_THREADS - 64) {
+        const int tile = row_tiles[l0 + q/((CH_NB/2)*CH_BACK_RG)];
+        if (tile == kb) continue;                           // the solver's tile
+        const int rem = q % ((CH_NB/2)*CH_BACK_RG);
+        const int rg = rem/(CH_NB/2), c = tile*CH_NB + 2*(rem % (CH_NB/2));
+        const int r0 = rg*RPI;
+        d2 v[RPI];
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) v[r] = (r0 + r < nbu) ? *reinterpret_cast<const d2*>(S + (size_t)(u0 + r0 + r)*n + c) : (d2){0.0, 0.0};
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) { const double xr = (r0 + r < nbu) ? xs[u0 + r0 + r] : 0.0; a0 += v[r][0]*xr; a1 += v[r][1]*xr; }
+        unsafeAtomicAdd(&xs[c], -a0);
+        unsafeAtomicAdd(&xs[c + 1], -a1);
+      }
+      }
+      if (kb > 0) chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(kb - 1) & 1], Tt[(kb - 1) & 1]);
     }
+    BACK_STAMP(0, 3); BACK_STAMP(1, 3);
     __syncthreads();
-    // y[c] -= sum_r L[k0+r][c] x[k0+r] over the structurally non-zero tiles of block row kb
-    const int l0 = row_start[kb], l1 = row_start[kb + 1];
-    for (int q = t; q < (l1 - l0)*CH_NB; q += CH_BACK_THREADS) {
-      const int c = row_tiles[l0 + q/CH_NB]*CH_NB + (q & (CH_NB - 1));
-      double s = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < nbe; ++r) s += S[(size_t)(k0 + r)*n + c]*xs[k0 + r];
-      xs[c] -= s;
-    }
-    __syncthreads();
+    BACK_STAMP(0, 4); BACK_STAMP(1, 4);
   }
   for (int i = t; i < n; i += CH_BACK_THREADS) xout[i] = xs[i];
 }
@@ -341,6 +417,8 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
 // row n: y -> x = L^-T y
 inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0) {
   const int n = plan.n;
+  static bool attr_set = false;      // x (up to CH_SOLVE_MAX doubles) + the staged tiles can exceed the default 64 KB of LDS
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SOLVE_MAX*(int)sizeof(double)); attr_set = true; }
   hipLaunchKernelGGL(k_chol_back, dim3(nsys), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
                      (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride);
 }

@@ -1123,6 +1123,21 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
   }
 #endif
   chol_back(nullptr, plan, d.p);
+#ifdef MCP_CHOL_PROF
+  {
+    HIPCK(hipDeviceSynchronize());
+    std::vector<unsigned long long> pr(256*2*8);
+    hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_back_prof), pr.size()*8);
+    const int ntc = plan.ntc; double sv = 0, rl = 0, sb_ = 0, up = 0, ub_ = 0; int cnt = 0;
+    for (int k = 2; k + 2 < ntc; ++k) {
+      const unsigned long long* a = &pr[(k*2 + 0)*8]; const unsigned long long* u = &pr[(k*2 + 1)*8];
+      sv += (double)(a[1] - a[0]); rl += (double)(a[3] - a[1]); sb_ += (double)(a[4] - a[3]);
+      up += (double)(u[3] - u[0]); ub_ += (double)(u[4] - u[3]); ++cnt;
+    }
+    fprintf(stderr, "[back prof] solver:  fast tile + solve %.0f  reload issue %.0f  barrier %.0f\n", sv/cnt, rl/cnt, sb_/cnt);
+    fprintf(stderr, "[back prof] updater: update %.0f  barrier %.0f\n", up/cnt, ub_/cnt);
+  }
+#endif
   int fl = 0;
   HIPCK(hipMemcpy(&fl, f.p, 4, hipMemcpyDeviceToHost));
   HIPCK(hipMemcpy(x, d.p + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
