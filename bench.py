@@ -24,7 +24,7 @@ FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8
 
 
 def load_traffic():
-    """Per-kernel HBM traffic per launch from the committed PMC pass (scripts/collect_traffic.sh):
+    """Per-kernel HBM traffic per launch from the committed PMC pass (scripts/gpu_final.sh + scripts/parse_traffic.py):
     bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes."""
     path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_per_launch.json")
     if not os.path.exists(path):
