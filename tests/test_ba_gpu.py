@@ -386,3 +386,26 @@ def _world_points(q, run):
     R = np.einsum("nij,njk->nik", q.cam_R[q.pt_src[:, 1]], run["R"][q.pt_src[:, 0]])
     t = np.einsum("nij,nj->ni", q.cam_R[q.pt_src[:, 1]], run["t"][q.pt_src[:, 0]]) + q.cam_t[q.pt_src[:, 1]]
     return np.einsum("nji,nj->ni", R, run["X"] - t)
+
+
+def test_speculative_solves_do_not_change_the_iteration(gpu_required, monkeypatch):
+    """A trial served by a speculative system (the next lambdas of the rejection branch factored alongside the current one,
+    DESIGN.md 4) must be indistinguishable from one solved on demand: same accept/reject sequence, same lambdas, same state."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=14, n_points=2000, pose_sigma=(0.2, 5.0), depth_sigma=0.2)     # rough start: rejected trials early on
+    runs = {}
+    for depth in ("0", "1", "3"):
+        monkeypatch.setenv("MCP_BA_SPECULATE", depth)
+        g = _gpu(p.cams, profile=True)
+        runs[depth] = run_bundle(g, p, 9)
+        runs[depth]["timing"] = g.Timing()
+    base = runs["0"]
+    assert base["timing"]["n_spec_hits"] == 0 and base["timing"]["n_solves"] == base["timing"]["n_trials"]
+    assert sum(l["trials"] for l in base["logs"]) > len(base["logs"])            # the run does contain rejected trials
+    for depth in ("1", "3"):
+        r = runs[depth]
+        assert r["timing"]["n_spec_hits"] > 0 and r["timing"]["n_solves"] + r["timing"]["n_spec_hits"] == r["timing"]["n_trials"]
+        assert [(l["trials"], l["accepted"]) for l in r["logs"]] == [(l["trials"], l["accepted"]) for l in base["logs"]]
+        assert np.allclose([l["lambda_end"] for l in r["logs"]], [l["lambda_end"] for l in base["logs"]], rtol=1e-9)
+        assert rel_err(r["R"], base["R"]) < 1e-9 and rel_err(r["t"], base["t"]) < 1e-9 and rel_err(r["X"], base["X"]) < 1e-9
+        assert r["outliers"] == base["outliers"]
