@@ -20,7 +20,11 @@ namespace mcp {
 __device__ inline int tri(int r, int c) { return r*(r + 1)/2 + c; }
 constexpr int GRP_TRI = GRP_DOF*(GRP_DOF + 1)/2;     // 4656
 
+#if defined(LIN_ABL) && LIN_ABL == 1
+__device__ inline void lds_add(double* p, double v) { if (v == 1.2345e-300) unsafeAtomicAdd(p, v); }     // timing ablation only
+#else
 __device__ inline void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+#endif
 
 // add w * Ja^T Jb (6x6) into the local tile at local poses (la, lb); la != lb or full symmetric handled by caller
 __device__ inline void tile_add_cross(double* Sl, int la, int lb, const double* Ja, const double* Jb, double w) {
@@ -44,6 +48,12 @@ __device__ inline void tile_add_cross(double* Sl, int la, int lb, const double* 
   }
 }
 
+#ifdef MCP_LIN_PROF      // in-kernel phase stamps (scripts/lin_prof.sh); compiled out of the product build
+__device__ unsigned long long g_lin_prof[8*8];
+#define LIN_STAMP(i) do { if ((blockIdx.x & 127) == 100 && blockIdx.x < 1024 && threadIdx.x == 0) g_lin_prof[(blockIdx.x >> 7)*8 + (i)] = clock64(); } while (0)
+#else
+#define LIN_STAMP(i) do {} while (0)
+#endif
 __global__ void __launch_bounds__(64)
 k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
                   const double* __restrict__ second, const double* __restrict__ sigma,
@@ -52,9 +62,11 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   __shared__ double Sl[GRP_TRI];
   __shared__ double bl[GRP_DOF];
   const int grp = blockIdx.x, lane = threadIdx.x;
+  LIN_STAMP(0);
   for (int i = lane; i < GRP_TRI; i += 64) Sl[i] = 0.0;
   for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
   __syncthreads();
+  LIN_STAMP(1);
   const int sp = P.g_sp0[grp] + lane;
   const bool valid = sp < P.g_sp0[grp + 1] && !P.sp_big[sp];
   // register accumulators of the first source-chain slot (the pose the point is expressed in)
@@ -88,6 +100,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     }
     double Vp[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
     const bool fixed_neg = P.pt_fixed[pt] && P.robust;
+    LIN_STAMP(2);
     for (int m = P.sp_m[sp]; m < P.sp_m[sp + 1]; ++m) {
       const int oc = P.m_chain[m], olen = P.chain_len[oc];
       const int mask = P.m_mask[m];
@@ -131,7 +144,11 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 #pragma unroll
         for (int c = 0; c < 3; ++c) gp[c] += -w*(Jp[c]*e0 + Jp[3+c]*e1);
       }
+#if defined(LIN_ABL) && LIN_ABL == 2
+      const int s0 = P.slot_start[m], ns = 0;                              // timing ablation only: no pose slots
+#else
       const int s0 = P.slot_start[m], ns = P.slot_start[m+1] - s0;
+#endif
       int ia = 0;
       for (int bit_a = 0; bit_a < 8 && ia < ns; ++bit_a) {
         if (!(mask & (1 << bit_a))) continue;
@@ -190,6 +207,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
         ++ia;
       }
     }
+    LIN_STAMP(3);
     if (lpt >= 0) {
       if (wss_inc >= 0) {
         double* Wb = W + 18*(size_t)wss_inc;
@@ -207,6 +225,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
       for (int k = 0; k < 3; ++k) g[3*(size_t)lpt + k] = gp[k];
     }
   }
+  LIN_STAMP(4);
   // segmented wave reduction of the source-pose accumulators, one LDS update per distinct pose
   unsigned long long todo = __ballot(ls >= 0);
   while (todo) {
@@ -238,6 +257,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     __syncthreads();
   }
   __syncthreads();
+  LIN_STAMP(5);
   // flush the local tile: one global atomic per touched entry
   const int* gp_ = P.g_pose + grp*GRP_LMAX;
   const int np = P.np;
@@ -254,6 +274,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
       if (v != 0.0) unsafeAtomicAdd(U + (size_t)(6*ur + r%6)*np + 6*gp_[c/6] + c%6, v);
     }
   }
+  LIN_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------

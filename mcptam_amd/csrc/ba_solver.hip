@@ -576,6 +576,16 @@ int mcp_ba::linearize() {
   if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), 0, st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
+#ifdef MCP_LIN_PROF
+  {
+    HIPCK(hipStreamSynchronize(st));
+    unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_lin_prof), sizeof pr);
+    double a[6] = {0}; int cnt = 0;
+    for (int b2 = 0; b2 < 6; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[6]) continue; for (int i2 = 0; i2 < 6; ++i2) a[i2] += (double)(q[i2 + 1] - q[i2]); ++cnt; }
+    if (cnt) fprintf(stderr, "[lin prof] zero %.0f  setup %.0f  measurements %.0f  V/g/W out %.0f  seg-reduce %.0f  flush %.0f  (cycles, %d groups)\n", a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, cnt);
+  }
+#endif
+
   toc();
   timing.n_linearize++;
   return 0;
