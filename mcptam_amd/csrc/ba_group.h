@@ -278,7 +278,9 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int SCH_CHUNK = 16;                 // points per MFMA chunk
+constexpr int SCH_CHUNK = 16;                 // points per MFMA chunk (8: more barriers, 5.8 -> 7.3 ms; 32: one workgroup per CU)
+constexpr int SCH_TPP = 256/SCH_CHUNK;        // threads per point in the scatter
+constexpr int SCH_EPT = (GRP_LMAX*6 + SCH_TPP - 1)/SCH_TPP;    // W rows per thread (<= 16 incidences x 6 rows per point)
 constexpr int SCH_K = 3*SCH_CHUNK;            // 48
 constexpr int SCH_LD = SCH_K + 1;             // LDS row stride (doubles)
 typedef double sch_d4 __attribute__((ext_vector_type(4)));
@@ -307,16 +309,16 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
   // The global reads of a chunk hang off two index hops (point -> incidence range -> local pose slot), a few
   // microseconds of dependent latency.  They are issued one chunk ahead, into registers, and land in LDS after the
   // matrix-core phase of the chunk before, so only the first chunk of a group pays for them.
-  const int pl = t >> 4, sub = t & 15;
-  double pw[6][3]; int prow[6];                // this thread's W rows of the next chunk (<= 16 incidences x 6 rows / 16 threads)
+  const int pl = t/SCH_TPP, sub = t%SCH_TPP;
+  double pw[SCH_EPT][3]; int prow[SCH_EPT];    // this thread's W rows of the next chunk
   double pv[6], pg[3]; int plpt = -1;          // threads 0..15: V and g of the next chunk's points
   auto prefetch = [&](int base) {
     const int sp = base + pl;
     int i0 = 0, cnt = 0;
     if (sp < sp1 && !P.sp_big[sp]) { i0 = P.sp_i[sp]; cnt = (P.sp_i[sp + 1] - i0)*6; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int it = sub + 16*k;
+    for (int k = 0; k < SCH_EPT; ++k) {
+      const int it = sub + SCH_TPP*k;
       prow[k] = -1;
       if (it < cnt) {
         const int inc = i0 + it/6, r = it%6;
@@ -339,7 +341,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
   prefetch(sp0);
   // the staging arrays are zero-filled once; after each chunk every thread clears exactly the rows it wrote
   for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
-  int orow[6];
+  int orow[SCH_EPT];
   for (int base = sp0; base < sp1; base += SCH_CHUNK) {
     if (t < SCH_CHUNK) {
       double I6[6] = {0, 0, 0, 0, 0, 0}; double g3[3] = {0, 0, 0};
@@ -357,7 +359,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     {   // scatter W and Y = W V^-1 rows: 16 threads per point
       const double* I6 = Vi + 6*pl;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 0; k < SCH_EPT; ++k) {
         orow[k] = prow[k];
         if (prow[k] < 0) continue;
         const double w0 = pw[k][0], w1 = pw[k][1], w2 = pw[k][2];
@@ -399,7 +401,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < SCH_EPT; ++k) {
       if (orow[k] < 0) continue;
       double* wd = Wd + orow[k]*SCH_LD + 3*pl;
       double* yd = Yd + orow[k]*SCH_LD + 3*pl;
