@@ -651,7 +651,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
   if (allreduce(d_res.p, 4)) return -1;          // robust chi2, point parts of the step statistics, failure flag (any rank)
-  if (read_results(8)) return -1;
+  if (read_results(29)) return -1;          // trial results [0..7] and, for compute(), the iteration-start block [24..28]
   h_res[1] += h_res[6]; h_res[2] += h_res[7];
   ok2 = (h_res[3] == 0.0);
   timing.n_trials++;
@@ -682,9 +682,13 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       tic(ST_EVAL);
       const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
       hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
-      hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
+      // iteration-start robust chi2 and the sigma block go to d_res[24..28]; they are read back together with the first
+      // trial's results (one host synchronisation less per iteration) -- except in the first iteration, whose lambda comes
+      // from the diagonal of the freshly built system
+      constexpr int RS = 24;
+      hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, RS, (const int*)nullptr);
       toc();
-      if (allreduce(d_res.p, 1)) return -1;
+      if (allreduce(d_res.p + RS, 1)) return -1;
       if (linearize()) return -1;
       if (it == 0 && !(user_lambda > 0)) {
         if (world > 1 && np) {     // the diagonal of U is a sum over ranks
@@ -695,12 +699,16 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         } else
           hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)U(), np + 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }
-      HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
-      if (read_results(13)) return -1;
-      double currentChi = h_res[0];
-      double tempChi = currentChi;
-      if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
-      lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
+      HIPCK(hipMemcpyAsync(d_res.p + RS + 1, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+      double currentChi = 0, tempChi = 0;
+      bool start_pending = true;
+      auto take_start = [&]() {
+        currentChi = tempChi = h_res[RS];
+        if (robust) { sigma_sq = h_res[RS + 1]; sigma_sq_lim = h_res[RS + 2]; }
+        lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
+        start_pending = false;
+      };
+      if (it == 0) { if (read_results(RS + 5)) return -1; take_start(); }
       if (it == 0) {
         if (user_lambda > 0) lambda = user_lambda;
         else {
@@ -720,6 +728,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       do {
         bool ok2 = true;
         if (solve_trial(lambda, ok2, ni)) return -1;
+        if (start_pending) take_start();
         double scale, ss;
         trial_chi_raw = h_res[0];
         if (ok2) {
