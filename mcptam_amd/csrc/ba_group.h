@@ -266,13 +266,18 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     const double v = bl[i];
     if (u >= 0 && v != 0.0) unsafeAtomicAdd(bp + 6*(size_t)u + i%6, v);
   }
-  for (int r = 0; r < GRP_DOF; ++r) {
-    const int ur = gp_[r/6];
-    if (ur < 0) break;
-    for (int c = lane; c <= r; c += 64) {
-      const double v = Sl[tri(r, c)];
-      if (v != 0.0) unsafeAtomicAdd(U + (size_t)(6*ur + r%6)*np + 6*gp_[c/6] + c%6, v);
-    }
+  // packed lower triangle walked flat (73 trips instead of 128 row-wise ones for a single wavefront)
+  int nrow = 0;
+  for (int i = 0; i < GRP_LMAX; ++i) if (gp_[i] >= 0) nrow = 6*(i + 1);
+  const int nent = nrow*(nrow + 1)/2;
+  for (int e = lane; e < nent; e += 64) {
+    const double v = Sl[e];
+    if (v == 0.0) continue;
+    int r = (int)((sqrtf(8.f*(float)e + 1.f) - 1.f)*0.5f);
+    while (r*(r + 1)/2 > e) --r;
+    while ((r + 1)*(r + 2)/2 <= e) ++r;
+    const int c = e - r*(r + 1)/2;
+    unsafeAtomicAdd(U + (size_t)(6*gp_[r/6] + r%6)*np + 6*gp_[c/6] + c%6, v);
   }
   LIN_STAMP(6);
 }
