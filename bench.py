@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--config", default="metric")
     ap.add_argument("--cpu-iters", type=int, default=8, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="all ranks on GPU 0 with a host-staged gloo all-reduce: exercises the multi-rank code path on a 1-GPU box; "
+                         "the printed value is NOT a valid measurement (config.debug says so)")
     args = ap.parse_args()
 
     import torch
@@ -101,20 +104,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.debug_single_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from mcptam_amd import chain_bundle, synth
-    from mcptam_amd.dist import RcclAllReduce, init_rccl_comm
+    from mcptam_amd.dist import GlooAllReduce, RcclAllReduce, init_rccl_comm
 
     problem = synth.make_config(args.config, shard=rank)
     # transport of the per-trial all-reduce: the library's own RCCL communicator on the solver stream; if that cannot
     # be created, the torch.distributed (backend nccl = RCCL) hook
     comm, hook, transport = None, None, "none"
-    if world > 1:
+    if world > 1 and args.debug_single_device:
+        hook = GlooAllReduce()
+        transport = "DEBUG: gloo, host-staged, all ranks on one GPU"
+    elif world > 1:
         try:
             comm = init_rccl_comm(rank, world, local_rank)
             transport = "rccl (library communicator, stream-ordered)"
@@ -164,7 +175,7 @@ def main():
     chi_first, chi_last = logs[0]["chi2_start"], logs[-1]["chi2_end"]
     b.close()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.debug_single_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -181,6 +192,8 @@ def main():
                 "trials_per_iteration": trials / args.steps, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
                 "chi2_first": chi_first, "chi2_last": chi_last},
         }
+        if args.debug_single_device:
+            result["config"]["debug"] = "all ranks share GPU 0, gloo transport: code-path check only, not a measurement"
     # per-stage HIP-event timing of the same run shape (separate pass so the events do not perturb `value`)
     if not args.no_roofline:
         bp = fresh(profile=True)
