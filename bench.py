@@ -189,7 +189,7 @@ def main():
             "dtype": "f64", "data": "synthetic (seed %d, SURVEY.md 8(d) generator)" % synth.DEFAULT_SEED,
             "config": {"workload": "%s: %d cams, %d MKF, %d points, %d measurements per rank" % (
                 args.config, len(problem.cams), problem.n_mkf, problem.n_points, problem.n_meas),
-                "trials_per_iteration": trials / args.steps, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
+                "trials_per_iteration": trials / args.steps, "trial_solves_per_s": world * trials / dt, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
                 "chi2_first": chi_first, "chi2_last": chi_last},
         }
         if args.debug_single_device:
