@@ -356,3 +356,35 @@ def test_sbi_rotation_against_last_frame(gpu_required, scene):
     R1, t1, s1 = cur.SBIRotationFromLast(6)
     R2, t2, s2 = sbi_iterate(b, a, 6)
     assert np.array_equal(R1, R2) and np.array_equal(t1, t2) and s1 == s2
+
+
+@pytest.mark.parametrize("w,h", [(642, 482), (322, 250), (64, 64)])
+def test_odd_sizes_and_degenerate_frames(gpu_required, w, h):
+    """Ragged / empty inputs: dimensions that do not halve evenly (level sizes are size/2 rounded down, KeyFrame.cc:189),
+    a black frame (no corners anywhere: empty lists, zero LUT, no candidates, nothing found), a saturated frame with
+    glare masking, a mask that removes everything, and a noise frame -- all identical to the oracle."""
+    rng = np.random.default_rng(w*1000 + h)
+    noise = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    blobs = np.zeros((h, w), dtype=np.uint8)
+    for _ in range(60):
+        x, y = int(rng.integers(4, w - 12)), int(rng.integers(4, h - 12))
+        blobs[y:y + int(rng.integers(3, 9)), x:x + int(rng.integers(3, 9))] = int(rng.integers(60, 255))
+    frames = [np.zeros((h, w), dtype=np.uint8), np.full((h, w), 255, dtype=np.uint8), noise, blobs]
+    for kw in (dict(), dict(glare=True)):
+        g, o = _pair(w, h, **kw)
+        for f in frames:
+            g.MakeKeyFrame_Lite(f); o.MakeKeyFrame_Lite(f)
+            _assert_lite_equal(g, o)
+            g.MakeKeyFrame_Rest(); o.MakeKeyFrame_Rest()
+            for l in range(4):
+                assert np.array_equal(g.Candidates(l)[0], o.Candidates(l)[0])
+    g, o = _pair(w, h)
+    zero_masks = [np.zeros((h >> l, w >> l), dtype=np.uint8) for l in range(4)]
+    g.MakeKeyFrame_Lite(blobs, zero_masks); o.MakeKeyFrame_Lite(blobs, zero_masks)
+    _assert_lite_equal(g, o)
+    assert all(len(g.Corners(l)) == 0 for l in range(4))
+    g.MakeKeyFrame_Lite(frames[0]); o.MakeKeyFrame_Lite(frames[0])
+    assert all(len(g.Corners(l)) == 0 for l in range(4)) and all(g.LevelSize(l) == (w >> l, h >> l) for l in range(4))
+    if w >= 320:
+        g.MakeSBI(); o.MakeSBI()
+        assert all(np.array_equal(a, b) for a, b in zip(g.SBI(), o.SBI()))

@@ -285,3 +285,58 @@ def test_oracle_small_blurry_image_properties():
     assert np.allclose(R3 @ R3.T, np.eye(3), atol=1e-12)
     w = np.degrees(np.arccos((np.trace(R3) - 1)/2))
     assert 0.5 < w < 20.0
+
+
+def test_oracle_long_chain_jacobians_sum_to_the_total_derivative():
+    """Chains of length 4 with a free link shared by the observer and the source chain: the per-slot analytic Jacobians
+    (src/ChainBundle.cc:485-586) of a vertex that sits in both chains must add up to the central-difference derivative with
+    respect to that vertex, and MoveTogether's structural zeros (:157-199) must be real zeros."""
+    from mcptam_amd import synth
+    from mcptam_amd.taylor_camera import TaylorCamera
+    rng = np.random.default_rng(11)
+    cam = TaylorCamera(synth.DEFAULT_CAM_PARAMS, (640, 480), (640, 480), (640, 480))
+
+    def rp(sr, st):
+        return synth.se3_exp(np.concatenate([rng.normal(size=3)*st, rng.normal(size=3)*sr]))
+
+    def mul(a, b):
+        return a[0] @ b[0], a[0] @ b[1] + a[1]
+
+    bases = [rp(0.15, 0.4) for _ in range(4)]
+    arm, mount, c0, c1 = rp(0.05, 0.05), rp(0.05, 0.05), rp(0.02, 0.02), rp(0.02, 0.1)
+    o = _orc([cam])
+    b_id = [o.AddPose(*bases[k], k == 0) for k in range(4)]
+    arm_id, mount_id = o.AddPose(*arm, False), o.AddPose(*mount, True)
+    cam_id = [o.AddPose(*c0, False), o.AddPose(*c1, True)]
+    cams2 = [c0, c1]
+    world = np.stack([rng.uniform(-2, 2, 40), rng.uniform(-1.5, 1.5, 40), rng.uniform(4, 9, 40)], axis=1)
+    meas = []
+    for i, X in enumerate(world):
+        k, c = i % 4, (i // 4) % 2
+        T = mul(cams2[c], mul(mount, mul(arm, bases[k])))
+        pid = o.AddPoint(T[0] @ X + T[1], [b_id[k], arm_id, mount_id, cam_id[c]], False)
+        for k2 in range(4):
+            for c2 in range(2):
+                T2 = mul(cams2[c2], mul(mount, mul(arm, bases[k2])))
+                uv, inv = cam.project((T2[0] @ X + T2[1])[None, :])
+                if not inv[0]:
+                    o.AddMeas([b_id[k2], arm_id, mount_id, cam_id[c2]], pid, uv[0] + 0.2, 1.0, 0)
+                    meas.append((k, c, k2, c2))
+    o.Prepare()
+    checked = 0
+    for m, (k, c, k2, c2) in enumerate(meas):
+        mask, jo, js, jp = o.Jacobian(m)
+        _, no, ns, npt = o.Jacobian(m, numeric=True, delta=1e-6)
+        scale = max(np.abs(no).max(), np.abs(ns).max(), np.abs(npt).max(), 1.0)
+        assert np.abs(jp - npt).max() < 1e-5*scale
+        if (k, c) == (k2, c2):                       # same chain on both sides: every pose link moves together
+            assert (mask & 0xff) == 0 and np.all(jo == 0) and np.all(js == 0)
+            continue
+        # link 0: different vertices on the two sides unless k == k2
+        if k != k2:
+            assert np.abs(jo[0] - no[0]).max() < 1e-5*scale and np.abs(js[0] - ns[0]).max() < 1e-5*scale
+        # link 1 (the arm) is the same vertex in both chains: the numeric derivative is the total one
+        assert np.abs(jo[1] + js[1] - no[1]).max() < 1e-5*scale
+        assert np.all(jo[2] == 0) and np.all(js[2] == 0)              # fixed mount
+        checked += 1
+    assert checked > 100
