@@ -498,9 +498,11 @@ k_schur(DevProblem P, int only_big, double lambda, const double* __restrict__ V,
 // pose update: T_trial = exp(x) * T_cur for free poses; pose part of sum x(lambda x + b) and sum x^2
 __global__ void __launch_bounds__(256)
 k_update_poses(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
-               const double* __restrict__ T_cur, double* __restrict__ T_trial, double* __restrict__ out /*[2]*/) {
+               const double* __restrict__ T_cur, double* __restrict__ T_trial, double* __restrict__ out /*[2]*/,
+               double* __restrict__ xp_keep /* copy of the pose update: the solver's x if this trial is accepted */) {
   __shared__ double lds[4];
   double sc = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < P.np; i += 256) xp_keep[i] = xp[i];
   for (int i = threadIdx.x; i < P.npose; i += 256) {
     const int u = P.pose_unk[i];
     if (u < 0) continue;

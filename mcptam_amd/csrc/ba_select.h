@@ -99,7 +99,7 @@ k_select_final(const double* __restrict__ hist, const SelState* __restrict__ sta
 // sigma block from the median (Huber::FindSigmaSquared + RobustKernelData::RecomputeNow limits,
 // MEstimator.h:194-204, ChainBundle.cc:822-830):  sig[0] raw sigma^2, [1] limited, [2] sqrt(limited), [3] median
 static __global__ void k_sigma_from_median(const double* __restrict__ med, double n_total, double min_sigma_sq,
-                                    double* __restrict__ sig) {
+                                    double* __restrict__ sig, double* __restrict__ sig_copy /* second destination or null */) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double m = med[0];
     double s = 1.4826*(1 + 5.0/(n_total*2 - 6))*sqrt(m);
@@ -107,6 +107,7 @@ static __global__ void k_sigma_from_median(const double* __restrict__ med, doubl
     const double s2 = s*s;
     const double lim = (s2 < min_sigma_sq) ? min_sigma_sq : s2;
     sig[0] = s2; sig[1] = lim; sig[2] = sqrt(lim); sig[3] = m;
+    if (sig_copy) { sig_copy[0] = s2; sig_copy[1] = lim; sig_copy[2] = sqrt(lim); sig_copy[3] = m; }
   }
 }
 

@@ -121,6 +121,7 @@ struct mcp_ba {
   DevBuf<double> d_lin;     // [U (np*np) | bp (np)]
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp copy (np)]   (the all-reduced block)
   DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
+  DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
   DevBuf<SelState> d_selstate;
   DevBuf<int> d_fail;
@@ -468,7 +469,7 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
   if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
-      d_xp_good.alloc(np) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
+      d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
   if (!h_res) HIPCK(hipHostMalloc((void**)&h_res, 32*sizeof(double)));
@@ -547,13 +548,13 @@ int mcp_ba::median_sigma(int w) {
   const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
   if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8)) return -1;
   hipLaunchKernelGGL(k_sigma_from_median, dim3(1), dim3(64), 0, st, d_res.p + 8, m_total,
-                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p);
+                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p, d_res.p + 25 /* compute()'s read-back block */);
   toc();
   return 0;
 }
 int mcp_ba::read_results(int count) {
+  // the failure flag of a trial travels inside the block (k_final_sums, d_res[3]): one copy, one wait
   HIPCK(hipMemcpyAsync(h_res, d_res.p, count*sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCK(hipMemcpyAsync(h_fail, d_fail.p + sys_cur, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCK(hipStreamSynchronize(st));
   return 0;
 }
@@ -637,7 +638,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   }
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
   tic(ST_UPDATE);
-  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6);
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   const int nbb = (nfl + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
@@ -699,7 +700,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         } else
           hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)U(), np + 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }
-      HIPCK(hipMemcpyAsync(d_res.p + RS + 1, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+      static_assert(RS + 1 == 25, "median_sigma() writes the sigma block to d_res + 25");
       double currentChi = 0, tempChi = 0;
       bool start_pending = true;
       auto take_start = [&]() {
@@ -733,8 +734,9 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         trial_chi_raw = h_res[0];
         if (ok2) {
           tempChi = h_res[0]; scale = h_res[1]; ss = h_res[2];
-          HIPCK(hipMemcpyAsync(d_xp_good.p, rhs(), std::max(np, 1)*sizeof(double), hipMemcpyDeviceToDevice, st));
-          if (nfl) HIPCK(hipMemcpyAsync(d_xl_good.p, d_xl.p, (size_t)nfl*3*sizeof(double), hipMemcpyDeviceToDevice, st));
+          // the solver's x of the last successful solve (what a later failed solve falls back on): swap, no copy
+          std::swap(d_xp_good.p, d_xp_cand.p); std::swap(d_xp_good.n, d_xp_cand.n);
+          std::swap(d_xl_good.p, d_xl.p); std::swap(d_xl_good.n, d_xl.n);
         } else {
           // CHOLMOD-failure analogue: the solver's x keeps its previous content [g2o]; recompute the
           // scale terms from it with the current lambda and b
