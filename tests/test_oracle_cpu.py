@@ -340,3 +340,56 @@ def test_oracle_long_chain_jacobians_sum_to_the_total_derivative():
         assert np.all(jo[2] == 0) and np.all(js[2] == 0)              # fixed mount
         checked += 1
     assert checked > 100
+
+
+def test_oracle_fixed_point_is_a_stationary_point_of_an_independent_cost():
+    """Independent pin of the residual model: the non-robust adjustment must stop where the gradient of
+    sum_m Omega_m |z_m - pi(CamFromBase * BaseFromWorld * X)|^2, coded here in numpy with world-coordinate points and its
+    own SE3 perturbations (so no Jacobian, chain helper or point parameterisation of the oracle is reused), vanishes."""
+    from mcptam_amd import synth
+    p = synth.make_config("tiny", outlier_frac=0.0)
+    o = _orc(p.cams, robust=False, tukey=False)
+    r = run_bundle(o, p, 80)
+    assert r["converged"] and r["rc"] > 0
+    cam = p.cams[0]
+    free = np.nonzero(~p.base_fixed)[0]
+    # state at the solution: poses from the bundle, points back in world coordinates through their source chain
+    R, t, Xs = r["R"], r["t"], r["X"]
+    omega = 1.0 / 2.0 ** p.ms_level                           # Omega = I / sqrt(sigma^2) = I / 2^level, ChainBundle.cc:1244-1245
+    Xw = None
+
+    def world_of(Rb, tb, Xrel):
+        sR = np.einsum("nij,njk->nik", p.cam_R[p.pt_src[:, 1]], Rb[p.pt_src[:, 0]])
+        st = np.einsum("nij,nj->ni", p.cam_R[p.pt_src[:, 1]], tb[p.pt_src[:, 0]]) + p.cam_t[p.pt_src[:, 1]]
+        return np.einsum("nji,nj->ni", sR, Xrel - st)
+
+    def cost(Rb, tb, Xb, dpose, dX):
+        Rk, tk = Rb.copy(), tb.copy()
+        for a, k in enumerate(free):
+            E = synth.se3_exp(dpose[6*a:6*a + 6])
+            Rk[k], tk[k] = E[0] @ Rb[k], E[0] @ tb[k] + E[1]
+        X = Xb + dX.reshape(-1, 3)
+        xb = np.einsum("mij,mj->mi", Rk[p.ms_mkf], X[p.ms_pt]) + tk[p.ms_mkf]
+        xc = np.einsum("mij,mj->mi", p.cam_R[p.ms_cam], xb) + p.cam_t[p.ms_cam]
+        uv, _ = cam.project(xc)
+        e = p.ms_uv - uv
+        return float((omega * (e * e).sum(axis=1)).sum())
+
+    n1, n2 = 6*len(free), 3*p.n_points
+
+    def grad(Rb, tb, Xb, idx):
+        g = np.zeros(len(idx))
+        h = 1e-6
+        for q, i in enumerate(idx):
+            d = np.zeros(n1 + n2); d[i] = h
+            g[q] = (cost(Rb, tb, Xb, d[:n1], d[n1:]) - cost(Rb, tb, Xb, -d[:n1], -d[n1:]))/(2*h)
+        return g
+
+    Xw = world_of(R, t, Xs)
+    c0 = cost(R, t, Xw, np.zeros(n1), np.zeros(n2))
+    assert abs(c0 - r["logs"][-1]["chi2_end"]) <= 1e-9*c0      # the same cost, computed independently
+    g_end = grad(R, t, Xw, range(n1 + n2))
+    X0 = world_of(p.base_R, p.base_t, p.pt_x)
+    assert abs(cost(p.base_R, p.base_t, X0, np.zeros(n1), np.zeros(n2)) - r["logs"][0]["chi2_start"]) <= 1e-9*r["logs"][0]["chi2_start"]
+    g_start = grad(p.base_R, p.base_t, X0, range(n1))
+    assert np.abs(g_end).max() < 1e-2 and np.abs(g_end).max() < 1e-6*np.abs(g_start).max(), (np.abs(g_end).max(), np.abs(g_start).max())
