@@ -393,3 +393,37 @@ def test_oracle_fixed_point_is_a_stationary_point_of_an_independent_cost():
     assert abs(cost(p.base_R, p.base_t, X0, np.zeros(n1), np.zeros(n2)) - r["logs"][0]["chi2_start"]) <= 1e-9*r["logs"][0]["chi2_start"]
     g_start = grad(p.base_R, p.base_t, X0, range(n1))
     assert np.abs(g_end).max() < 1e-2 and np.abs(g_end).max() < 1e-6*np.abs(g_start).max(), (np.abs(g_end).max(), np.abs(g_start).max())
+
+
+def test_fast10_detector_against_the_textbook_definition():
+    """Independent pin of the corner detector: Rosten's FAST-10 stated directly from its definition (16-pixel Bresenham ring of
+    radius 3, a corner if >= 10 contiguous ring pixels are all brighter than centre + t or all darker than centre - t,
+    3-pixel border skipped, raster order) in numpy, against the oracle's level-0 corner list with the fixed thresholds."""
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame
+    ring = [(0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3)]
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    img = sc["imgA"]
+    h, w = img.shape
+    t = 10                                                     # fixed level-0 threshold when adaptive thresholds are off
+    I = img.astype(np.int32)
+    c = I[3:h - 3, 3:w - 3]
+    br = np.stack([I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] > c + t for dx, dy in ring])      # (16, H, W)
+    dk = np.stack([I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] < c - t for dx, dy in ring])
+
+    def has_run(b):
+        out = np.zeros(b.shape[1:], dtype=bool)
+        for s in range(16):
+            m = np.ones(b.shape[1:], dtype=bool)
+            for j in range(10):
+                m &= b[(s + j) % 16]
+            out |= m
+        return out
+
+    corner = has_run(br) | has_run(dk)
+    ys, xs = np.nonzero(corner)
+    expect = np.stack([xs + 3, ys + 3], axis=1).astype(np.int32)                               # raster order
+    k = OracleKeyFrame(w, h, adaptive=False)
+    k.MakeKeyFrame_Lite(img)
+    got = k.Corners(0)
+    assert len(expect) > 200 and np.array_equal(got, expect)
