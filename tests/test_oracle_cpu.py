@@ -427,3 +427,43 @@ def test_fast10_detector_against_the_textbook_definition():
     k.MakeKeyFrame_Lite(img)
     got = k.Corners(0)
     assert len(expect) > 200 and np.array_equal(got, expect)
+
+
+def test_pose_update_against_numpy_weighted_least_squares():
+    """Tracker::CalcPoseUpdate (src/Tracker.cc:1386-1512) restated with numpy: covariance-scaled errors, Tukey sigma^2 from
+    the [size/2] order statistic (MEstimator.h:109-124) or the override, squared-root weights, prior 100 I, normal equations
+    solved with numpy.linalg -- against the oracle's WLS<6> restatement; also the all-missing and all-outlier cases."""
+    from oracle import oracle_track_pose_update
+    rng = np.random.default_rng(21)
+    n = 500
+    found = (rng.random(n) < 0.8).astype(np.uint8)
+    J = rng.normal(size=(n, 2, 6)) * np.array([300, 300, 300, 200, 200, 200])
+    mu_true = np.array([0.01, -0.02, 0.005, 0.002, -0.001, 0.003])
+    img = rng.uniform(0, 640, size=(n, 2))
+    fnd = img + np.einsum("nij,j->ni", J, mu_true) + rng.normal(size=(n, 2)) * 0.5
+    bad = rng.random(n) < 0.1
+    fnd[bad] += rng.normal(size=(bad.sum(), 2)) * 40.0
+    sinv = 1.0 / 2.0 ** rng.integers(0, 4, n)
+    for override in (-1.0, 16.0, 1.0):
+        mu, w, s2 = oracle_track_pose_update(found, fnd, img, sinv, J.reshape(n, 12), override)
+        f = found.astype(bool)
+        e = sinv[f, None] * (fnd[f] - img[f])
+        e2 = (e * e).sum(axis=1)
+        if override > 0:
+            sig2 = override
+        else:
+            med = np.sort(e2)[len(e2) // 2]
+            sig2 = (4.6851 * 1.4826 * (1 + 5.0 / (len(e2) * 2 - 6)) * np.sqrt(med)) ** 2
+        assert abs(s2 - sig2) <= 1e-12 * sig2
+        wt = np.where(e2 > sig2, 0.0, (1.0 - e2 / sig2) ** 2)
+        assert np.allclose(w[f], wt, rtol=1e-13, atol=0) and np.all(w[~f] == 0)
+        A = 100.0 * np.eye(6)
+        b = np.zeros(6)
+        Jf = sinv[f, None, None] * J[f]
+        for r in range(2):
+            A += np.einsum("n,ni,nj->ij", wt, Jf[:, r, :], Jf[:, r, :])
+            b += np.einsum("n,ni,n->i", wt, Jf[:, r, :], e[:, r])
+        assert np.allclose(mu, np.linalg.solve(A, b), rtol=1e-10, atol=1e-14)
+    assert np.abs(mu - mu_true).max() < 5e-3
+    mu, w, s2 = oracle_track_pose_update(np.zeros(n, dtype=np.uint8), fnd, img, sinv, J.reshape(n, 12))
+    assert np.all(mu == 0)                                                   # no valid measurements: null update (:1420-1421)
