@@ -467,3 +467,50 @@ def test_pose_update_against_numpy_weighted_least_squares():
     assert np.abs(mu - mu_true).max() < 5e-3
     mu, w, s2 = oracle_track_pose_update(np.zeros(n, dtype=np.uint8), fnd, img, sinv, J.reshape(n, 12))
     assert np.all(mu == 0)                                                   # no valid measurements: null update (:1420-1421)
+
+
+def test_adaptive_fast_threshold_against_numpy():
+    """The adaptive threshold of MakeKeyFrame_Lite (src/KeyFrame.cc:259-315) restated in numpy on top of the textbook
+    FAST-10 definition: score = largest t at which the pixel is still a corner, cumulative histogram over t = 5..30, knee =
+    first t whose (central / one-sided) derivative exceeds -(w h)/500, corners kept at score >= t -- frequency table,
+    threshold and corner list of every pyramid level must equal the oracle's."""
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame
+    ring = [(0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3)]
+
+    def corners_at(I, t):
+        h, w = I.shape
+        c = I[3:h - 3, 3:w - 3]
+        out = np.zeros(c.shape, dtype=bool)
+        for sign in (1, -1):
+            b = np.stack([sign*(I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] - c) > t for dx, dy in ring])
+            for s in range(16):
+                m = np.ones(c.shape, dtype=bool)
+                for j in range(10):
+                    m &= b[(s + j) % 16]
+                out |= m
+        return out
+
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    k = OracleKeyFrame(320, 240)
+    k.MakeKeyFrame_Lite(sc["imgA"])
+    for l in range(4):
+        I = k.Image(l).astype(np.int32)
+        h, w = I.shape
+        score = np.full((h - 6, w - 6), -1, dtype=np.int32)
+        for t in range(5, 32):                                  # score >= t  <=>  corner at threshold t
+            score[corners_at(I, t)] = t
+        freq = np.zeros(31)
+        for t in range(5, 31):
+            freq[t] = (score >= t).sum()
+        assert np.array_equal(k.FastFrequency(l)[5:31], freq[5:31]), l
+        target = -1.0*(w*h)/500.0
+        thresh = 5
+        for t in range(5, 31):
+            d = freq[t + 1] - freq[t] if t == 5 else (freq[t] - freq[t - 1] if t == 30 else (freq[t + 1] - freq[t - 1])/2.0)
+            thresh = t
+            if d > target:
+                break
+        assert k.FastThresh(l) == thresh, (l, k.FastThresh(l), thresh)
+        ys, xs = np.nonzero(score >= thresh)
+        assert np.array_equal(k.Corners(l), np.stack([xs + 3, ys + 3], axis=1).astype(np.int32)), l
