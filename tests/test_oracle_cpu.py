@@ -514,3 +514,30 @@ def test_adaptive_fast_threshold_against_numpy():
         assert k.FastThresh(l) == thresh, (l, k.FastThresh(l), thresh)
         ys, xs = np.nonzero(score >= thresh)
         assert np.array_equal(k.Corners(l), np.stack([xs + 3, ys + 3], axis=1).astype(np.int32)), l
+
+
+def test_robust_chi2_and_adaptive_sigma_against_numpy():
+    """RobustKernelData::RecomputeNow + RobustKernelAdaptive::robustify (src/ChainBundle.cc:810-897) from the per-measurement
+    chi2: sigma^2 = (1.345 * 1.4826 * (1 + 5/(2M - 6)))^2 * median|chi2| with the [M/2] element, floored at
+    sdMinMEstimatorSigma^2 = 0.25 (:1136,1148), Huber on chi2 (inlier |chi2|, outlier 2 sigma sqrt(chi2) - sigma^2), and the
+    negated chi2 of fixed points (:401-417) counting with weight one."""
+    from mcptam_amd import synth
+    for cfg, kw in (("tiny", {}), ("c1", dict(n_fixed_points=40)), ("tiny", dict(noise=False, perturb=False))):
+        p = synth.make_config(cfg, **kw)
+        o = _orc(p.cams)
+        p.populate(o)
+        o.Prepare()
+        chi2, err = o.Eval()
+        fixed = p.pt_fixed[p.ms_pt]
+        omega = 1.0 / 2.0 ** p.ms_level
+        # Eval reports measurements in the order they were added; chi2 = e^T Omega e, negated for fixed points
+        assert np.allclose(np.abs(chi2), omega * (err * err).sum(axis=1), rtol=1e-13, atol=1e-300)
+        assert np.all(chi2[fixed] <= 0) and np.all(chi2[~fixed] >= 0)
+        M = len(chi2)
+        med = np.sort(np.abs(chi2))[M // 2]
+        s2_raw = (1.345 * 1.4826 * (1 + 5.0 / (2 * M - 6)) * np.sqrt(med)) ** 2
+        s2 = max(s2_raw, 0.25)
+        rho = np.where(chi2 <= s2, np.abs(chi2), 2 * np.sqrt(s2) * np.sqrt(np.abs(chi2)) - s2)
+        total, sig_raw = o.DebugRobustChi2()
+        assert abs(sig_raw - s2_raw) <= 1e-12 * max(s2_raw, 1e-300)
+        assert abs(total - rho.sum()) <= 1e-11 * max(rho.sum(), 1e-300)
