@@ -541,3 +541,55 @@ def test_robust_chi2_and_adaptive_sigma_against_numpy():
         total, sig_raw = o.DebugRobustChi2()
         assert abs(sig_raw - s2_raw) <= 1e-12 * max(s2_raw, 1e-300)
         assert abs(total - rho.sum()) <= 1e-11 * max(rho.sum(), 1e-300)
+
+
+def test_tracker_jacobian_and_warp_against_finite_differences():
+    """TrackerData::Project/CalcJacobian (include/mcptam/TrackerData.h:102-185) and PatchFinder::CalcSearchLevelAndWarpMatrix
+    (src/PatchFinder.cc:69-122) against central differences of the independent Python camera: the 2x6 Jacobian is
+    d project(CamFromBase exp(d) BaseFromWorld x) / d d, the warp columns are d project / d x_cam applied to the rotated
+    pixel-right / pixel-down vectors, the search level follows from the determinant rule."""
+    from mcptam_amd import synth, synth_img
+    from oracle import OracleKeyFrame, oracle_track_search
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    cam = sc["cam"]
+    A, B = OracleKeyFrame(320, 240), OracleKeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"]); A.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(cam, A, A, sc["poseA"], sc["depth"], per_level=(60, 40, 20, 10))
+    cfb = (synth.so3_exp(np.array([0.02, -0.03, 0.05])), np.array([0.03, -0.01, 0.02]))
+    RB, tB = sc["poseB"]
+    bfw = (cfb[0].T @ RB, cfb[0].T @ (tB - cfb[1]))                 # CamFromBase * BaseFromWorld = poseB
+    out = oracle_track_search(B, cam, bfw, cfb, pts, 0, 0)
+
+    def proj(x):
+        return cam.project(np.asarray(x)[None, :])[0][0]
+
+    checked = 0
+    for i, p in enumerate(pts):
+        if not out["in_image"][i]:
+            continue
+        xb = bfw[0] @ p["world_pos"] + bfw[1]
+        xc = cfb[0] @ xb + cfb[1]
+        assert np.allclose(out["image"][i], proj(xc), atol=1e-9)
+        h = 1e-6
+        Jn = np.zeros((2, 6))
+        for m in range(6):
+            d = np.zeros(6); d[m] = h
+            Ep, Em = synth.se3_exp(d), synth.se3_exp(-d)
+            Jn[:, m] = (proj(cfb[0] @ (Ep[0] @ xb + Ep[1]) + cfb[1]) - proj(cfb[0] @ (Em[0] @ xb + Em[1]) + cfb[1]))/(2*h)
+        J = out["jacobian"][i].reshape(2, 6)
+        assert np.abs(J - Jn).max() < 1e-5*max(np.abs(Jn).max(), 1.0)
+        Jx = np.stack([(proj(xc + h*e) - proj(xc - h*e))/(2*h) for e in np.eye(3)], axis=1)       # d(u,v)/d x_cam
+        Rcw = cfb[0] @ bfw[0]
+        Wn = np.stack([Jx @ (Rcw @ p["pixel_right_w"]), Jx @ (Rcw @ p["pixel_down_w"])], axis=1)
+        W = out["warp_inverse"][i].reshape(2, 2)
+        assert np.abs(W - Wn).max() < 1e-5*max(np.abs(Wn).max(), 1.0)
+        det, lvl = np.linalg.det(Wn), 0
+        while det > 3 and lvl < 3:
+            lvl += 1; det *= 0.25
+        if abs(det - 3) > 1e-3 and abs(det - 0.5) > 1e-3:           # away from the decision boundaries
+            bad = det > 3 or det < 0.5
+            assert bool(out["template_bad"][i]) == bad or out["template_bad"][i]      # a template can also be bad for leaving the source image
+            if not bad:
+                assert out["search_level"][i] == lvl
+        checked += 1
+    assert checked > 80
