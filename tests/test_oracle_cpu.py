@@ -653,3 +653,36 @@ def test_image_primitives_against_numpy():
         if found[i]:
             assert tuple(pos[i]) == bp and ssd[i] == best
     assert found.sum() > 5
+
+
+def test_coarse_template_against_numpy_bilinear_warp():
+    """PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:135-182): the 8x8 template is the source keyframe level
+    resampled at centre + M ((x, y) - (4, 4)) with M = inverse(warp) * 2^level.  Restated with closed-form positions and a
+    numpy bilinear sample; CVD::transform accumulates the position incrementally and truncates to a byte, so individual
+    pixels may differ by one grey level -- nothing more, and almost nowhere."""
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame, oracle_track_search
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    cam = sc["cam"]
+    A, B = OracleKeyFrame(320, 240), OracleKeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"]); A.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(cam, A, A, sc["poseA"], sc["depth"], per_level=(80, 50, 30, 10))
+    out = oracle_track_search(B, cam, sc["poseB"], (np.eye(3), np.zeros(3)), pts, 0, 0)
+    imgs = [A.Image(l).astype(np.float64) for l in range(4)]
+    tot = diff = 0
+    for i, p in enumerate(pts):
+        if not out["in_image"][i] or out["template_bad"][i] or out["search_level"][i] < 0:
+            continue
+        W = out["warp_inverse"][i].reshape(2, 2)
+        M = np.linalg.inv(W) * (1 << int(out["search_level"][i]))
+        I = imgs[p["source_level"]]
+        gx, gy = np.meshgrid(np.arange(8) - 4.0, np.arange(8) - 4.0)
+        px = p["center"][0] + M[0, 0]*gx + M[0, 1]*gy
+        py = p["center"][1] + M[1, 0]*gx + M[1, 1]*gy
+        lx, ly = np.floor(px).astype(int), np.floor(py).astype(int)
+        fx, fy = px - lx, py - ly
+        v = (1 - fy)*((1 - fx)*I[ly, lx] + fx*I[ly, lx + 1]) + fy*((1 - fx)*I[ly + 1, lx] + fx*I[ly + 1, lx + 1])
+        d = np.abs(np.floor(v + 1e-9).astype(int) - out["templ"][i].reshape(8, 8).astype(int))
+        assert d.max() <= 1
+        tot += 64; diff += int((d > 0).sum())
+    assert tot > 64*80 and diff <= 0.01*tot
