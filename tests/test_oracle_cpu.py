@@ -686,3 +686,56 @@ def test_coarse_template_against_numpy_bilinear_warp():
         assert d.max() <= 1
         tot += 64; diff += int((d > 0).sum())
     assert tot > 64*80 and diff <= 0.01*tot
+
+
+def test_coarse_zmssd_search_against_numpy():
+    """PatchFinder::FindPatchCoarse + ZMSSDAtPoint (src/PatchFinder.cc:229-355, 511-664) restated with numpy/Python ints:
+    level-scaled centre and radius, FAST corners of the search level inside the circle, zero-mean SSD
+    (2 SA SB - SA^2 - SB^2)/64 + sum I^2 + sum T^2 - 2 sum I T with C integer division, strict < keeps the first best,
+    accepted below 8*8*250 -- best corner, score and found flag of every tracked point."""
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame, oracle_track_search
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    cam = sc["cam"]
+    A, B = OracleKeyFrame(320, 240), OracleKeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"]); A.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(cam, A, A, sc["poseA"], sc["depth"], per_level=(80, 50, 30, 10))
+    rng_px = 10
+    out = oracle_track_search(B, cam, sc["poseB"], (np.eye(3), np.zeros(3)), pts, rng_px, 0)
+    imgs = [B.Image(l).astype(np.int64) for l in range(4)]
+    cors = [B.Corners(l) for l in range(4)]
+    MAXSSD = 8*8*250
+    nfound = 0
+    for i in range(len(pts)):
+        if not out["searched"][i]:
+            continue
+        L = int(out["search_level"][i])
+        s = 1 << L
+        T = out["templ"][i].astype(np.int64).reshape(8, 8)
+        SA, TT = int(T.sum()), int((T*T).sum())
+        px, py = int(out["image"][i][0])//s, int(out["image"][i][1])//s          # CVD::ir truncates; positions are positive
+        r = (rng_px + s - 1)//s
+        I = imgs[L]
+        h, w = I.shape
+        best, bp = MAXSSD + 1, None
+        for (cx, cy) in cors[L]:
+            if cy < max(py - r, 0) or cy > py + r or cx < max(px - r, 0) or cx > px + r:
+                continue
+            if (px - cx)**2 + (py - cy)**2 > r*r:
+                continue
+            if not (4 <= cx < w - 4 and 4 <= cy < h - 4):
+                ssd = MAXSSD + 1
+            else:
+                P = I[cy - 4:cy + 4, cx - 4:cx + 4]
+                SB = int(P.sum())
+                num = 2*SA*SB - SA*SA - SB*SB
+                q = abs(num)//64 * (1 if num >= 0 else -1)                            # C integer division
+                ssd = q + int((P*P).sum()) + TT - 2*int((P*T).sum())
+            if ssd < best:
+                best, bp = ssd, (int(cx), int(cy))
+        assert int(out["score"][i]) == best, (i, out["score"][i], best)
+        assert bool(out["found"][i]) == (best < MAXSSD)
+        if out["found"][i]:
+            assert (int(out["coarse_x"][i]), int(out["coarse_y"][i])) == bp
+            nfound += 1
+    assert nfound > 60
