@@ -219,7 +219,9 @@ def _pose12(R, t):
 
 
 def track_search(target, cam, base_from_world, cam_from_base, points, rng, subpix_its, exhaustive=False):
-    arr = pack_points(points, lambda kf: kf._h)
+    """`points`: list of point dicts, or the ctypes array `pack_points` made from one (map points do not change from
+    frame to frame: a caller packs them once)."""
+    arr = points if isinstance(points, ctypes.Array) else pack_points(points, lambda kf: kf._h)
     out = np.zeros(len(points), dtype=TD_OUT_DTYPE)
     cs = cam.to_struct()
     b, c = _pose12(*base_from_world), _pose12(*cam_from_base)
