@@ -83,6 +83,25 @@ int mcp_kf_get_candidates(mcp_kf*, int level, mcp_int2* pos, double* score, int 
 int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int2* src_pos,
                        const mcp_int2* dst_pos, int range, mcp_int2* out_pos, uint8_t* out_found, int* out_ssd);
 
+/* The Gauss-Newton pose iterations of Tracker::TrackMap in one call (src/Tracker.cc:775-838, 1038-1075).  Per iteration i:
+ * nonlinear[i] != 0 -> PoseUpdateStep (found points are re-projected unless i == 0, CalcJacobian), else PoseUpdateStepLinear
+ * (LinearUpdate with the previous update); then CalcPoseUpdate with override_sigma[i] (<= 0: Tukey sigma^2 from the
+ * median -- the caller applies the "no override up to iteration 5" rule) and BaseFromWorld <- exp(mu) BaseFromWorld.
+ * Points of all cameras go in one array; image / cam_derivs are updated in place, weights_last (may be NULL) receives the
+ * Tukey weights of the last iteration (0 = outlier, as bMarkOutliers counts them). */
+typedef struct mcp_pose_point {
+  double world_pos[3];
+  double found_pos[2];
+  double sqrt_inv_noise;
+  double image[2];
+  double cam_derivs[4];
+  int    cam;
+  int    found;
+} mcp_pose_point;
+int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cam_from_base /* ncam x 12 */,
+                          double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                          double mu_last[6], double* weights_last);
+
 /* ---- SmallBlurryImage / Relocaliser -------------------------------- src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121
  * The 40x30 thumbnail of the frame the handle holds, its zero-mean Gaussian-blurred float template and gradient image
  * (MakeFromKF + MakeJacs) live on the device with the keyframe (KeyFrame::mpSBI).  blur = 2.5 in the reference. */

@@ -274,6 +274,35 @@ int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int
   return 0;
 }
 
+int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
+                          const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last) {
+  for (int k = 0; k < 6; ++k) mu_last[k] = 0;
+  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb) return img_fail("mcp_track_pose_refine: bad arguments");
+  if (n == 0 || n_iter == 0) return 0;
+  for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine: camera index out of range");
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine: no HIP device");
+  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<mcp_camera> dc; Buf<double> dcfb, dbfw, dov, dJ, dex, de2, dmu, dw; Buf<uint8_t> dnl; };
+  static thread_local RefineScratch rs;
+  if (rs.dp.alloc(n) || rs.dc.alloc(ncam) || rs.dcfb.alloc(12*(size_t)ncam) || rs.dbfw.alloc(12) || rs.dov.alloc(n_iter) || rs.dJ.alloc(12*(size_t)n) ||
+      rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n) || rs.dmu.alloc(8) || rs.dw.alloc(n) || rs.dnl.alloc(n_iter)) return -1;
+  hipStream_t st = nullptr;
+  ICK(hipMemcpyAsync(rs.dp.p, pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dc.p, cams, sizeof(mcp_camera)*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dcfb.p, cfb, 96*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dbfw.p, bfw, 96, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dov.p, override_sigma, 8*(size_t)n_iter, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dnl.p, nonlinear, (size_t)n_iter, hipMemcpyHostToDevice, st));
+  ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
+  hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, (const mcp_camera*)rs.dc.p, (const double*)rs.dcfb.p, rs.dbfw.p, n_iter,
+                     (const uint8_t*)rs.dnl.p, (const double*)rs.dov.p, rs.dJ.p, rs.dex.p, rs.de2.p, rs.dmu.p, rs.dw.p);
+  ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(bfw, rs.dbfw.p, 96, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(mu_last, rs.dmu.p, 48, hipMemcpyDeviceToHost, st));
+  if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+  ICK(hipStreamSynchronize(st));
+  return 0;
+}
+
 // ---- SmallBlurryImage / Relocaliser --------------------------------------------------------------------------------
 // cv::resize's 8U INTER_LINEAR taps [3P-memory]: source coordinate (d+0.5)*scale-0.5 in float, clamped, 11-bit weights
 static void sbi_resize_coeffs(int src, int dst, int* idx, short* w0, short* w1) {

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ba_device.h"
+#include "ba_select.h"
 #include "../../include/mcp_img.h"
 
 namespace mcp {
@@ -757,6 +758,163 @@ k_sbi_iterate(const float* __restrict__ me, const float* __restrict__ ot_templ, 
   }
   if (t < 6) out[t] = st[t];
   if (t == 6) out[6] = st[7];
+}
+
+
+// ---- the ten Gauss-Newton pose iterations of Tracker::TrackMap in one launch ----------------------------------------
+//   src/Tracker.cc:775-838 (PoseUpdateStep / PoseUpdateStepLinear), 1038-1075 (schedule), 1386-1512 (CalcPoseUpdate)
+// One workgroup; the points stay on the device between iterations (image position, camera derivatives, 2x6 Jacobian), so
+// an iteration costs a few barriers instead of a host round trip:  re-project or linear update -> covariance-scaled
+// errors -> exact Tukey median by an in-LDS radix select -> weights, 27 partial sums per thread, fixed-order reduction ->
+// 6x6 Cholesky and exp(mu) on thread 0.
+constexpr int PR_THREADS = 1024;
+__global__ void __launch_bounds__(PR_THREADS)
+k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
+              double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
+              double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out) {
+  __shared__ unsigned int hist[2048];
+  __shared__ unsigned int part[64];
+  __shared__ double red[PR_THREADS/64][28];
+  __shared__ double pose[12], v6[6];
+  __shared__ unsigned long long sel_prefix, sel_k;
+  __shared__ int nf_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 12) pose[t] = bfw_io[t];
+  if (t < 6) v6[t] = 0.0;
+  __syncthreads();
+  for (int it = 0; it < n_iter; ++it) {
+    const bool nl = nonlinear[it] != 0;
+    int nf_loc = 0;
+    for (int i = t; i < n; i += PR_THREADS) {
+      mcp_pose_point& p = pts[i];
+      if (!p.found) continue;
+      ++nf_loc;
+      double* Ji = J + 12*(size_t)i;
+      if (nl) {
+        const double* cfb = cfb_all + 12*(size_t)p.cam;
+        double xb[3], xc[3];
+        mat3_vec(pose, p.world_pos, xb); xb[0] += pose[9]; xb[1] += pose[10]; xb[2] += pose[11];
+        mat3_vec(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+        if (it != 0) {
+          Projection pr; cam_project<true>(cams[p.cam], xc, pr);
+          p.image[0] = pr.u; p.image[1] = pr.v; p.cam_derivs[0] = pr.D[0]; p.cam_derivs[1] = pr.D[1]; p.cam_derivs[2] = pr.D[2]; p.cam_derivs[3] = pr.D[3];
+        }
+        double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb, mb, mc);
+          const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+          Ji[m] = p.cam_derivs[0]*s0 + p.cam_derivs[1]*s1; Ji[6 + m] = p.cam_derivs[2]*s0 + p.cam_derivs[3]*s1;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { double a = 0.0; for (int k = 0; k < 6; ++k) a += Ji[6*r + k]*v6[k]; p.image[r] += a; }
+      }
+      const double e0 = p.sqrt_inv_noise*(p.found_pos[0] - p.image[0]), e1 = p.sqrt_inv_noise*(p.found_pos[1] - p.image[1]);
+      ex[2*(size_t)i] = e0; ex[2*(size_t)i + 1] = e1; e2s[i] = e0*e0 + e1*e1;
+    }
+    // number of found points (constant over the iterations, recomputed for simplicity)
+    for (int o = 32; o > 0; o >>= 1) nf_loc += __shfl_xor(nf_loc, o, 64);
+    if (t == 0) nf_s = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&nf_s, nf_loc);
+    __syncthreads();
+    const int nf = nf_s;
+    if (nf == 0) { if (t < 6) { v6[t] = 0.0; } __syncthreads(); continue; }           // no valid measurements: null update
+    double s2 = override_sigma[it];
+    if (!(s2 > 0)) {
+      // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select in LDS
+      if (t == 0) { sel_prefix = 0ull; sel_k = (unsigned long long)(nf/2); }
+      __syncthreads();
+      for (int pass = 0; pass < SEL_PASSES; ++pass) {
+        const int sh = sel_shift(pass);
+        const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+        const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+        for (int b = t; b < 2048; b += PR_THREADS) hist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = sel_prefix;
+        for (int i = t; i < n; i += PR_THREADS) {
+          if (!pts[i].found) continue;
+          const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(e2s[i]));
+          if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
+        __syncthreads();
+        if (t == 0) {
+          unsigned long long k = sel_k, acc = 0; int c = 0;
+          for (; c < 64; ++c) { if (acc + part[c] > k) break; acc += part[c]; }
+          if (c == 64) c = 63;
+          int b = 32*c;
+          for (; b < 32*c + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
+          if (b >= 32*c + 32) b = 32*c + 31;
+          sel_prefix = prefix | ((unsigned long long)b << sh);
+          sel_k = k - acc;
+        }
+        __syncthreads();
+      }
+      const double med = __longlong_as_double((long long)sel_prefix);
+      double sg = 1.4826*(1 + 5.0/(nf*2 - 6))*sqrt(med);
+      sg = 4.6851*sg;
+      s2 = sg*sg;
+    }
+    // weighted normal equations: 21 + 6 partial sums per thread
+    double a[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a[k] = 0.0;
+    const bool last = (it == n_iter - 1);
+    for (int i = t; i < n; i += PR_THREADS) {
+      const mcp_pose_point& p = pts[i];
+      if (!p.found) { if (last && w_out) w_out[i] = 0.0; continue; }
+      const double err2 = e2s[i];
+      double sq = (err2 > s2) ? 0.0 : 1.0 - (err2/s2);
+      const double w = sq*sq;
+      if (last && w_out) w_out[i] = w;
+      if (w == 0.0) continue;
+      const double* Ji = J + 12*(size_t)i;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double Jr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jr[k] = p.sqrt_inv_noise*Ji[6*r + k];
+        const double m = ex[2*(size_t)i + r];
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          a[21 + x] += w*m*Jr[x];
+#pragma unroll
+          for (int y = 0; y <= x; ++y) { a[q] += w*Jr[x]*Jr[y]; ++q; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { double v = a[k]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[k] = v; }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) red[wave][k] = a[k];
+    }
+    __syncthreads();
+    if (t == 0) {
+      double C[36], v[6], mu[6];
+      int q = 0;
+      for (int x = 0; x < 6; ++x) for (int y = 0; y <= x; ++y) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][q]; C[6*x + y] = C[6*y + x] = sum; ++q; }
+      for (int x = 0; x < 6; ++x) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][21 + x]; v[x] = sum; C[7*x] += 100.0; }    // add_prior(100)
+      for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = (i == j) ? sqrt(sum) : sum/C[6*j + j]; }
+      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum/C[6*i + i]; }
+      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum/C[6*i + i]; }
+      Se3 E, T, R;
+      se3_exp(mu, E);
+      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
+      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
+      se3_compose(E, T, R);
+      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
+      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
+      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+    }
+    __syncthreads();
+  }
+  if (t < 12) bfw_io[t] = pose[t];
+  if (t < 6) mu_out[t] = v6[t];
 }
 
 }  // namespace mcp

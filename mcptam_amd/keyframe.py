@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_track_pose_refine", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -60,6 +60,8 @@ def lib():
         L.mcp_kf_get_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.mcp_kf_num_prev.argtypes = [ctypes.c_void_p]
+        L.mcp_track_pose_refine.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mcp_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
         L.mcp_kf_get_sbi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mcp_sbi_score.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -269,3 +271,46 @@ def sbi_se3_from_se2(R2, t2, cam_src, cam_target):
     R = np.zeros(9)
     _chk(lib().mcp_sbi_se3_from_se2(se2.ctypes.data, ctypes.byref(a), ctypes.byref(b), R.ctypes.data), "sbi_se3_from_se2")
     return R.reshape(3, 3)
+
+
+POSE_POINT_DTYPE = np.dtype([("world_pos", "f8", 3), ("found_pos", "f8", 2), ("sqrt_inv_noise", "f8"), ("image", "f8", 2),
+                             ("cam_derivs", "f8", 4), ("cam", "i4"), ("found", "i4")], align=True)
+
+# Tracker::TrackMap's fine-stage schedule (src/Tracker.cc:1063-1075, 800-803): full re-projection at iterations 0, 4 and 9,
+# linear updates in between, the 16.0 override only beyond iteration 5
+FINE_NONLINEAR = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 1], dtype=np.uint8)
+FINE_OVERRIDE = np.array([0, 0, 0, 0, 0, 0, 16.0, 16.0, 16.0, 16.0])
+
+
+def pose_points(world_pos, td_out, cam_index):
+    """The mcp_pose_point records of one camera from its map points' world positions and a track_search result."""
+    n = len(td_out)
+    p = np.zeros(n, dtype=POSE_POINT_DTYPE)
+    p["world_pos"] = world_pos
+    for f in ("found_pos", "sqrt_inv_noise", "image", "cam_derivs", "found"):
+        p[f] = td_out[f]
+    p["cam"] = cam_index
+    return p
+
+
+def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, structs):
+    pts = np.ascontiguousarray(pts, dtype=POSE_POINT_DTYPE).copy()
+    n, ncam, nit = len(pts), len(cams), len(nonlinear)
+    carr = (structs * ncam)(*[c.to_struct() for c in cams])
+    cfb = np.ascontiguousarray(np.stack([_pose12(*T) for T in cam_from_base]))
+    bfw = _pose12(*base_from_world).copy()
+    nl = np.ascontiguousarray(nonlinear, dtype=np.uint8)
+    ov = np.ascontiguousarray(override_sigma, dtype=np.float64)
+    mu = np.zeros(6)
+    w = np.zeros(max(n, 1))
+    rc = fn(n, pts.ctypes.data, ncam, ctypes.cast(carr, ctypes.c_void_p), cfb.ctypes.data, bfw.ctypes.data, nit, nl.ctypes.data, ov.ctypes.data,
+            mu.ctypes.data, w.ctypes.data)
+    return rc, (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), mu, w[:n], pts
+
+
+def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE):
+    """All Gauss-Newton pose iterations of one frame in one device launch.  Returns (BaseFromWorld (R, t), last update,
+    last Tukey weights, points with their final image positions)."""
+    rc, pose, mu, w, out = _refine(lib().mcp_track_pose_refine, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
+    _chk(rc, "track_pose_refine")
+    return pose, mu, w, out

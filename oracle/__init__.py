@@ -248,6 +248,8 @@ def img_lib():
         L.orc_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                             ctypes.c_double, c_double_p, c_double_p, c_double_p]
         L.orc_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        L.orc_track_pose_refine.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         for f in ("orc_kf_sbi_small", "orc_kf_sbi_template", "orc_kf_sbi_jacs"):
             getattr(L, f).restype = ctypes.c_void_p
             getattr(L, f).argtypes = [ctypes.c_void_p]
@@ -403,3 +405,13 @@ def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobi
     s = ctypes.c_double(0)
     img_lib().orc_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s))
     return mu, w[:n], s.value
+
+
+def oracle_track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=None, override_sigma=None):
+    """CPU restatement of Tracker::TrackMap's pose iterations (same signature as mcptam_amd.keyframe.track_pose_refine)."""
+    from mcptam_amd import keyframe as kf
+    from mcptam_amd.taylor_camera import McpCamera
+    nonlinear = kf.FINE_NONLINEAR if nonlinear is None else nonlinear
+    override_sigma = kf.FINE_OVERRIDE if override_sigma is None else override_sigma
+    rc, pose, mu, w, out = kf._refine(img_lib().orc_track_pose_refine, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
+    return pose, mu, w, out

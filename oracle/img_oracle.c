@@ -806,3 +806,50 @@ void orc_sbi_se3_from_se2(const double se2[6], const orc_camera* cs, const orc_c
   }
   memcpy(R, so3, sizeof(double)*9);
 }
+
+
+/* ================================================================== Tracker::TrackMap pose iterations */
+int orc_track_pose_refine(int n, orc_pose_point* pts, int ncam, const orc_camera* cams, const double* cfb_all,
+                          double bfw[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                          double mu_last[6], double* weights_last) {
+  uint8_t* found = (uint8_t*)malloc(n + 1);
+  double* fpos = (double*)malloc(sizeof(double)*(2*(size_t)n + 2)); double* ipos = (double*)malloc(sizeof(double)*(2*(size_t)n + 2));
+  double* sinv = (double*)malloc(sizeof(double)*(n + 1)); double* J = (double*)calloc(12*(size_t)n + 12, sizeof(double));
+  double v6[6] = { 0, 0, 0, 0, 0, 0 };
+  for (int i = 0; i < n; i++) { found[i] = (uint8_t)(pts[i].found != 0); fpos[2*i] = pts[i].found_pos[0]; fpos[2*i+1] = pts[i].found_pos[1]; sinv[i] = pts[i].sqrt_inv_noise; }
+  (void)ncam;
+  for (int it = 0; it < n_iter; it++) {
+    if (nonlinear[it]) {                                    /* PoseUpdateStep, :775-812 */
+      for (int i = 0; i < n; i++) {
+        orc_pose_point* p = &pts[i];
+        if (!p->found) continue;
+        const double* cfb = cfb_all + 12*(size_t)p->cam;
+        double xb[3]; m3v(bfw, p->world_pos, xb); xb[0] += bfw[9]; xb[1] += bfw[10]; xb[2] += bfw[11];
+        double xc[3]; m3v(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+        if (it != 0) orc_cam_project(&cams[p->cam], xc, p->image, p->cam_derivs);          /* ProjectAndDerivs, :783-790 */
+        double dT[3], dP[3]; orc_cam_sphere_deriv(xc, dT, dP);                                /* CalcJacobian, TrackerData.h:152-176 */
+        for (int m = 0; m < 6; m++) {
+          double mb[3], mc[3]; gen_field(m, xb, mb); m3v(cfb, mb, mc);
+          const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+          J[12*(size_t)i + m] = p->cam_derivs[0]*s0 + p->cam_derivs[1]*s1; J[12*(size_t)i + 6 + m] = p->cam_derivs[2]*s0 + p->cam_derivs[3]*s1;
+        }
+      }
+    } else {                                                /* PoseUpdateStepLinear, :815-838: mv2Image += J v6 */
+      for (int i = 0; i < n; i++) {
+        if (!pts[i].found) continue;
+        for (int r = 0; r < 2; r++) { double a = 0; for (int k = 0; k < 6; k++) a += J[12*(size_t)i + 6*r + k]*v6[k]; pts[i].image[r] += a; }
+      }
+    }
+    for (int i = 0; i < n; i++) { ipos[2*i] = pts[i].image[0]; ipos[2*i+1] = pts[i].image[1]; }
+    double s2;
+    orc_track_pose_update(n, found, fpos, ipos, sinv, J, override_sigma[it], v6, (it == n_iter - 1) ? weights_last : NULL, &s2);
+    double E[9], et[3]; orc_se3_exp(v6, E, et);            /* mse3BaseFromWorld = exp(v6) * mse3BaseFromWorld */
+    double nb[12];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) nb[3*a + b] = E[3*a]*bfw[b] + E[3*a+1]*bfw[3+b] + E[3*a+2]*bfw[6+b];
+    m3v(E, bfw + 9, nb + 9); nb[9] += et[0]; nb[10] += et[1]; nb[11] += et[2];
+    memcpy(bfw, nb, sizeof nb);
+  }
+  memcpy(mu_last, v6, sizeof v6);
+  free(found); free(fpos); free(ipos); free(sinv); free(J);
+  return 0;
+}

@@ -70,6 +70,22 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* found_pos, 
                           const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
                           double mu[6], double* weights_out, double* sigma_sq_out);
 
+/* The ten Gauss-Newton pose iterations of Tracker::TrackMap (src/Tracker.cc:775-838, 1038-1075): per iteration either
+ * PoseUpdateStep (re-project the found points unless it is iteration 0, CalcJacobian, CalcPoseUpdate, BaseFromWorld <-
+ * exp(mu) BaseFromWorld) or PoseUpdateStepLinear (LinearUpdate with the previous mu instead of re-projection). */
+typedef struct orc_pose_point {
+  double world_pos[3];      /* MapPoint::mv3WorldPos */
+  double found_pos[2];      /* TrackerData::mv2Found */
+  double sqrt_inv_noise;    /* mdSqrtInvNoise */
+  double image[2];          /* mv2Image: in = projection from the search stage, out = after the last iteration */
+  double cam_derivs[4];     /* mm2CamDerivs, same */
+  int cam;                  /* index into cams / cam_from_base */
+  int found;                /* mbFound */
+} orc_pose_point;
+int orc_track_pose_refine(int n, orc_pose_point* pts, int ncam, const struct orc_camera* cams, const double* cam_from_base /* ncam x 12 */,
+                          double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                          double mu_last[6], double* weights_last);
+
 /* ---- SmallBlurryImage / Relocaliser (src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121) ----------------
  * 40x30 thumbnail of level 0 (cv::resize INTER_LINEAR [3P-memory]), zero-mean float template blurred with
  * CVD::convolveGaussian [3P-memory], gradient image, ZMSSD, ESM SE2 alignment, SE2 -> camera rotation. */

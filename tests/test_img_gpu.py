@@ -388,3 +388,27 @@ def test_odd_sizes_and_degenerate_frames(gpu_required, w, h):
     if w >= 320:
         g.MakeSBI(); o.MakeSBI()
         assert all(np.array_equal(a, b) for a, b in zip(g.SBI(), o.SBI()))
+
+
+def test_pose_refine_matches_oracle(gpu_required):
+    """mcp_track_pose_refine: the ten Gauss-Newton pose iterations of Tracker::TrackMap in one launch (re-projection at
+    iterations 0, 4, 9, linear updates in between, Tukey sigma from the exact median, 16.0 override beyond iteration 5)
+    against the oracle: pose, last update, weights, final image positions; also a coarse-stage schedule and no-found input."""
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_refine
+    from oracle import oracle_track_pose_refine
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    f = recs["found"] != 0
+    schedules = [(None, None), (np.ones(10, dtype=np.uint8), np.full(10, 1.0)), (np.array([1, 0, 1], dtype=np.uint8), np.zeros(3))]
+    for nl, ov in schedules:
+        kw = {} if nl is None else dict(nonlinear=nl, override_sigma=ov)
+        pg, mg, wg, og = track_pose_refine(recs, [cam, cam], cfbs, bfw, **kw)
+        po, mo, wo, oo = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw, **kw)
+        assert np.allclose(pg[0], po[0], rtol=0, atol=1e-10) and np.allclose(pg[1], po[1], rtol=0, atol=1e-10)
+        assert np.allclose(mg, mo, rtol=0, atol=1e-10)
+        assert np.allclose(wg, wo, rtol=0, atol=1e-8) and np.array_equal(wg == 0, wo == 0)
+        assert np.allclose(og["image"][f], oo["image"][f], rtol=0, atol=1e-8) and np.allclose(og["cam_derivs"][f], oo["cam_derivs"][f], rtol=1e-10, atol=1e-8)
+        assert np.array_equal(og["image"][~f], recs["image"][~f])
+    none = recs.copy(); none["found"] = 0
+    pg, mg, wg, og = track_pose_refine(none, [cam, cam], cfbs, bfw)
+    assert np.all(mg == 0) and np.array_equal(pg[0], bfw[0]) and np.all(wg == 0)

@@ -739,3 +739,79 @@ def test_coarse_zmssd_search_against_numpy():
             assert (int(out["coarse_x"][i]), int(out["coarse_y"][i])) == bp
             nfound += 1
     assert nfound > 60
+
+
+def _refine_scene():
+    from mcptam_amd import synth, synth_img
+    from mcptam_amd.keyframe import pose_points
+    from oracle import OracleKeyFrame, oracle_track_search
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    cam = sc["cam"]
+    A, B = OracleKeyFrame(320, 240), OracleKeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"]); A.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(cam, A, A, sc["poseA"], sc["depth"], per_level=(150, 80, 40, 10))
+    cfbs = [(np.eye(3), np.zeros(3)), (synth.so3_exp(np.array([0.0, 0.02, 0.0])), np.array([0.01, 0.0, 0.0]))]
+    RB, tB = sc["poseB"]
+    # a slightly wrong starting pose: the iterations have something to do
+    dR, dt = synth.se3_exp(np.array([0.004, -0.003, 0.002, 0.001, -0.0015, 0.0008]))
+    bfw = (dR @ RB, dR @ tB + dt)
+    recs = []
+    for c, cfb in enumerate(cfbs):
+        b2 = (cfb[0].T @ bfw[0], cfb[0].T @ (bfw[1] - cfb[1])) if c else bfw       # same CamFromWorld for both "cameras"
+        out = oracle_track_search(B, cam, b2 if c == 0 else bfw, cfb if c else cfbs[0], pts, 10, 8) if c == 0 else \
+            oracle_track_search(B, cam, bfw, cfb, pts[::2], 10, 8)
+        wp = np.array([p["world_pos"] for p in (pts if c == 0 else pts[::2])])
+        recs.append(pose_points(wp, out, c))
+    return cam, cfbs, bfw, np.concatenate(recs)
+
+
+def test_pose_refine_equals_the_iteration_loop_spelled_out():
+    """orc_track_pose_refine against Tracker::TrackMap's loop written out in Python on top of pieces pinned elsewhere:
+    PoseUpdateStep / PoseUpdateStepLinear (src/Tracker.cc:775-838) with the fine-stage schedule (:1063-1075)."""
+    from mcptam_amd import synth
+    from mcptam_amd.keyframe import FINE_NONLINEAR, FINE_OVERRIDE
+    from oracle import oracle_track_pose_refine, oracle_track_pose_update
+    cam, cfbs, bfw, recs = _refine_scene()
+    assert recs["found"].sum() > 150
+    pose, mu, w, out = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw)
+    # the same, step by step
+    R, t = bfw
+    img = recs["image"].copy()
+    D = recs["cam_derivs"].copy()
+    J = np.zeros((len(recs), 12))
+    f = recs["found"] != 0
+    v6 = np.zeros(6)
+
+    def gen(m, p):
+        e = np.zeros(3)
+        if m < 3:
+            e[m] = 1.0
+            return e
+        a = np.zeros(3); a[m - 3] = 1.0
+        return np.cross(a, p)
+
+    for i in np.nonzero(f)[0]:                       # iteration 0: CalcJacobian with the search-stage projection
+        cR, ct = cfbs[recs["cam"][i]]
+        xb = R @ recs["world_pos"][i] + t
+        xc = cR @ xb + ct
+        n2 = xc[0]**2 + xc[1]**2
+        n_ = np.sqrt(n2)
+        dT = np.array([-xc[2]*xc[0], -xc[2]*xc[1], n2])/(n_*(n2 + xc[2]**2))
+        dP = np.array([-xc[1], xc[0], 0.0])/n2
+        Dm = D[i].reshape(2, 2)
+        for m in range(6):
+            mc = cR @ gen(m, xb)
+            J[i, m], J[i, 6 + m] = Dm @ np.array([dT @ mc, dP @ mc])
+    for it in range(4):                              # iterations 1..3 are linear updates
+        if it:
+            img[f] += np.einsum("nrk,k->nr", J[f].reshape(-1, 2, 6), v6)
+        v6, ww, s2 = oracle_track_pose_update(recs["found"].astype(np.uint8), recs["found_pos"], img, recs["sqrt_inv_noise"], J, FINE_OVERRIDE[it])
+        E = synth.se3_exp(v6)
+        R, t = E[0] @ R, E[0] @ t + E[1]
+    # four iterations (one non-linear, three linear) reproduced exactly by a refine call with the truncated schedule
+    pose4, mu4, w4, out4 = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw, FINE_NONLINEAR[:4], FINE_OVERRIDE[:4])
+    assert np.allclose(pose4[0], R, atol=1e-12) and np.allclose(pose4[1], t, atol=1e-12) and np.allclose(mu4, v6, atol=1e-13)
+    assert np.allclose(out4["image"][f], img[f], atol=1e-9)
+    # and the full schedule converges: the last update is tiny and the pose is close to the true one
+    assert np.abs(mu).max() < 1e-3 * max(np.abs(mu4).max(), 1e-3) or np.abs(mu).max() < 1e-5
+    assert (w[f] > 0).mean() > 0.7 and np.all(w[~f] == 0)
