@@ -63,11 +63,12 @@ struct mcp_kf {
   Buf<DevTdIn> td_in; Buf<mcp_td_out> td_out;
   Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f, mp_f2; Buf<int> mp_s;
   bool has_image = false;
+  LevelInfo* h_info = nullptr;      // pinned: the four levels' bookkeeping, read back with the frame (one wait per frame)
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
   Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
   Buf<uint8_t> sbi_last_small; Buf<float> sbi_last_templ, sbi_last_jacs; bool has_last_sbi = false;   // the SBI made before the current one (Tracker::mmpSBILastFrame)
   Buf<const float*> sbi_ptrs; Buf<double> sbi_out;
-  ~mcp_kf() { if (st) (void)hipStreamDestroy(st); }
+  ~mcp_kf() { if (st) (void)hipStreamDestroy(st); if (h_info) (void)hipHostFree(h_info); }
   DevKfView view() const {
     DevKfView v;
     for (int l = 0; l < MCP_LEVELS; ++l) { v.img[l] = lev[l].img.p; v.w[l] = lev[l].w; v.h[l] = lev[l].h; v.corners[l] = lev[l].corners.p; v.lut[l] = lev[l].lut.p; v.info[l] = lev[l].info.p; }
@@ -142,11 +143,10 @@ int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* c
     }
     hipLaunchKernelGGL(k_row_lut, dim3((L.h + 63)/64), dim3(64), 0, st, (const mcp_int2*)L.corners.p, (const LevelInfo*)L.info.p, L.h, L.lut.p);
   }
+  if (!k->h_info) ICK(hipHostMalloc((void**)&k->h_info, MCP_LEVELS*sizeof(LevelInfo)));
+  for (int l = 0; l < MCP_LEVELS; ++l) ICK(hipMemcpyAsync(k->h_info + l, k->lev[l].info.p, sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
-  for (int l = 0; l < MCP_LEVELS; ++l) {
-    LevelInfo inf; ICK(hipMemcpy(&inf, k->lev[l].info.p, sizeof inf, hipMemcpyDeviceToHost));
-    if (inf.overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
-  }
+  for (int l = 0; l < MCP_LEVELS; ++l) if (k->h_info[l].overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
   return 0;
 }
 
