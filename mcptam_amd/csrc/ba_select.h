@@ -111,4 +111,89 @@ static __global__ void k_sigma_from_median(const double* __restrict__ med, doubl
   }
 }
 
+
+// ---- short form for a single GPU: two histogram passes over the whole array, then the few elements that share the
+// selected 22-bit prefix are gathered and the remaining 42 bits are resolved by one workgroup in LDS (4 launches in place
+// of 8; the launches, not the bytes, are what a 400k-element selection costs).
+constexpr int SEL_GATHER_CAP = 1 << 16;
+
+// derive state[2] from pass 1 (as k_select_pass(pass = 2) would) and gather |x| of the matching elements
+static __global__ void __launch_bounds__(SEL_BLOCK)
+k_select_gather(int n, const double* __restrict__ x, const double* __restrict__ hist, SelState* __restrict__ state,
+                unsigned int* __restrict__ cnt, double* __restrict__ vals) {
+  __shared__ unsigned long long sc[SEL_BLOCK + 2];
+  const SelState prev = state[1];
+  int bin; unsigned long long kin;
+  sel_find_bin(hist + (size_t)SEL_BINS, 1 << sel_nbits(1), prev.k, bin, kin, sc);
+  SelState st;
+  st.prefix = prev.prefix | ((unsigned long long)bin << sel_shift(1));
+  st.k = kin;
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[2] = st;
+  const unsigned long long himask = ~0ull << sel_shift(1);
+  for (size_t i = blockIdx.x*(size_t)SEL_BLOCK + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x*SEL_BLOCK) {
+    const double a = fabs(x[i]);
+    const unsigned long long key = (unsigned long long)__double_as_longlong(a);
+    if ((key & himask) == st.prefix) {
+      const unsigned int idx = atomicAdd(cnt, 1u);
+      if (idx < (unsigned int)SEL_GATHER_CAP) vals[idx] = a;
+    }
+  }
+}
+
+// one workgroup: passes 2..5 over the gathered candidates (or, if they overflowed the buffer -- tens of thousands of
+// values equal in their top 22 bits -- over the original array with the prefix filter), then the sigma block
+static __global__ void __launch_bounds__(1024)
+k_select_small(int n, const double* __restrict__ x, const unsigned int* __restrict__ cnt, const double* __restrict__ vals,
+               const SelState* __restrict__ state, double n_total, double min_sigma_sq, double* __restrict__ med_out,
+               double* __restrict__ sig, double* __restrict__ sig_copy) {
+  __shared__ unsigned int hist[SEL_BINS];
+  __shared__ unsigned int part[64];
+  __shared__ unsigned long long s_prefix, s_k;
+  const int t = threadIdx.x;
+  const unsigned int c = cnt[0];
+  const bool overflow = c > (unsigned int)SEL_GATHER_CAP;
+  const double* src = overflow ? x : vals;
+  const int m = overflow ? n : (int)c;
+  if (t == 0) { s_prefix = state[2].prefix; s_k = state[2].k; }
+  __syncthreads();
+  for (int pass = 2; pass < SEL_PASSES; ++pass) {
+    const int sh = sel_shift(pass);
+    const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+    const unsigned long long himask = ~0ull << sel_shift(pass - 1);
+    for (int b = t; b < SEL_BINS; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    for (int i = t; i < m; i += 1024) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(src[i]));
+      if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
+    }
+    __syncthreads();
+    if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long k = s_k, acc = 0; int cc = 0;
+      for (; cc < 64; ++cc) { if (acc + part[cc] > k) break; acc += part[cc]; }
+      if (cc == 64) cc = 63;
+      int b = 32*cc;
+      for (; b < 32*cc + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
+      if (b >= 32*cc + 32) b = 32*cc + 31;
+      s_prefix = prefix | ((unsigned long long)b << sh);
+      s_k = k - acc;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double md = __longlong_as_double((long long)s_prefix);
+    med_out[0] = md;
+    if (sig) {
+      double s = 1.4826*(1 + 5.0/(n_total*2 - 6))*sqrt(md);
+      s = 1.345*s;
+      const double s2 = s*s;
+      const double lim = (s2 < min_sigma_sq) ? min_sigma_sq : s2;
+      sig[0] = s2; sig[1] = lim; sig[2] = sqrt(lim); sig[3] = md;
+      if (sig_copy) { sig_copy[0] = s2; sig_copy[1] = lim; sig_copy[2] = sqrt(lim); sig_copy[3] = md; }
+    }
+  }
+}
+
 }  // namespace mcp

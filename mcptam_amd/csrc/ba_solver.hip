@@ -121,6 +121,7 @@ struct mcp_ba {
   DevBuf<double> d_lin;     // [U (np*np) | bp (np)]
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp copy (np)]   (the all-reduced block)
   DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
+  DevBuf<double> d_selvals;     // candidates of the single-GPU selection (SEL_GATHER_CAP)
   DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
   DevBuf<SelState> d_selstate;
@@ -228,7 +229,7 @@ struct mcp_ba {
   int download_state();
   void launch_chains(int which);
   void launch_eval(int which, bool sum, double* err_out);
-  int select_kth(const double* x, int n, unsigned long long k, double* out_dev);
+  int select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma = false);
   int median_sigma(int which);
   int read_results(int count);
   int linearize();
@@ -469,7 +470,7 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
   if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
-      d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
+      d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
   if (!h_res) HIPCK(hipHostMalloc((void**)&h_res, 32*sizeof(double)));
@@ -532,9 +533,20 @@ void mcp_ba::launch_eval(int w, bool sum, double* err_out) {
 }
 
 // exact k-th smallest |x| (global over ranks when a hook is installed); result left at out_dev[0]
-int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out_dev) {
-  HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
+int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma) {
   const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
+  if (world == 1) {
+    // single GPU: two full histogram passes, gather, one-workgroup finish (which also writes the Huber sigma block if asked)
+    HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)(2*SEL_BINS + 1)*sizeof(double), st));        // two histograms + the gather counter behind them
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(d_hist.p + 2*SEL_BINS);
+    for (int p = 0; p < 2; ++p) hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
+    hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, (const double*)d_hist.p, d_selstate.p, cnt, d_selvals.p);
+    hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_selvals.p, (const SelState*)d_selstate.p,
+                       m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma, out_dev, huber_sigma ? d_sigma.p : (double*)nullptr,
+                       huber_sigma ? d_res.p + 25 : (double*)nullptr);
+    return 0;
+  }
+  HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
   for (int p = 0; p < SEL_PASSES; ++p) {
     hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
     if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
@@ -546,9 +558,10 @@ int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out
 int mcp_ba::median_sigma(int w) {
   tic(ST_SELECT);
   const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
-  if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8)) return -1;
-  hipLaunchKernelGGL(k_sigma_from_median, dim3(1), dim3(64), 0, st, d_res.p + 8, m_total,
-                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p, d_res.p + 25 /* compute()'s read-back block */);
+  if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8, true)) return -1;
+  if (world > 1)       // (the single-GPU path writes the sigma block in its last kernel)
+    hipLaunchKernelGGL(k_sigma_from_median, dim3(1), dim3(64), 0, st, d_res.p + 8, m_total,
+                       prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p, d_res.p + 25 /* compute()'s read-back block */);
   toc();
   return 0;
 }
