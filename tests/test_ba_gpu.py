@@ -86,7 +86,8 @@ def test_dense_cholesky_solve_matches_numpy(gpu_required, n):
     b = rng.normal(size=n)
     x = dense_spd_solve(np.tril(A), b)          # only the lower triangle is read
     ref = np.linalg.solve(A, b)
-    assert rel_err(x, ref) < 1e-11
+    err = rel_err(x, ref)
+    assert err < 1e-11, (n, err, int(np.argmax(np.abs(x - ref))))
     with pytest.raises(RuntimeError):
         dense_spd_solve(-A, b)                  # not positive definite -> loud failure
 
