@@ -38,7 +38,7 @@ STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ;
     "schur": [("mcp::k_schur_init", 1), ("mcp::k_schur_group", 1)],
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
-    "select": [("mcp::k_select_pass", 6), ("mcp::k_select_final", 1), ("mcp::k_sigma_from_median", 1)],
+    "select": [("mcp::k_select_pass", 2), ("mcp::k_select_gather", 1), ("mcp::k_select_small", 1)],
     "cholesky": [("mcp::k_chol_step", -1)],
     "tri_solve": [("mcp::k_chol_back", 1)],
 }
