@@ -154,6 +154,7 @@ struct mcp_ba {
     if (h_res) (void)hipHostFree(h_res);
     if (h_fail) (void)hipHostFree(h_fail);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -164,6 +165,8 @@ struct mcp_ba {
   size_t red_stride = 0, vinv_stride = 0, pack_stride = 0;
   int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
   int speculate = 3;                 // speculative systems per solve; MCP_BA_SPECULATE=0 turns them off
+  int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
+  hipGraphExec_t chol_exec[MAX_SYS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double* S() { return d_red.p + sys_cur*red_stride; }
   double* rhs() { return S() + (size_t)np*np; }
   double* Vinv() { return d_Vinv.p + sys_cur*vinv_stride; }
@@ -468,6 +471,8 @@ int mcp_ba::prepare() {
   const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
   red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
+  { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
+  for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
   if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
@@ -643,8 +648,25 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0, red_stride, pack_stride);
     }
     if (np) {
-      tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); toc();
-      tic(ST_SOLVE); chol_back(st, plan, S(), nsys, red_stride); toc();
+      if (use_graph && !prm.profile) {
+        // the ~40 dependent launches of one factorisation + back-substitution replayed from a captured graph
+        // (arguments never change between solves: same buffers, same plan); one graph per batch width
+        if (!chol_exec[nsys]) {
+          hipGraph_t g = nullptr;
+          if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            chol_factor(st, plan, d_red.p, d_fail.p, nsys, red_stride);
+            chol_back(st, plan, d_red.p, nsys, red_stride);
+            if (hipStreamEndCapture(st, &g) != hipSuccess || !g || hipGraphInstantiate(&chol_exec[nsys], g, nullptr, nullptr, 0) != hipSuccess) { chol_exec[nsys] = nullptr; use_graph = 0; }
+            if (g) (void)hipGraphDestroy(g);
+          } else use_graph = 0;
+          (void)hipGetLastError();
+        }
+        if (chol_exec[nsys]) HIPCK(hipGraphLaunch(chol_exec[nsys], st));
+        else { chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); chol_back(st, plan, S(), nsys, red_stride); }
+      } else {
+        tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); toc();
+        tic(ST_SOLVE); chol_back(st, plan, S(), nsys, red_stride); toc();
+      }
     }
     spec_ok = (nsys > 1);
     timing.n_solves++;
