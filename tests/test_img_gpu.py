@@ -412,3 +412,36 @@ def test_pose_refine_matches_oracle(gpu_required):
     none = recs.copy(); none["found"] = 0
     pg, mg, wg, og = track_pose_refine(none, [cam, cam], cfbs, bfw)
     assert np.all(mg == 0) and np.array_equal(pg[0], bfw[0]) and np.all(wg == 0)
+
+
+def test_c5_frame_size_1280x960(gpu_required):
+    """BASELINE config c5 (8-camera 1280x960 rig, one camera per GPU): one camera's frame through the whole per-frame path at
+    that size -- pyramid, corners, LUT, candidates bit-exact; the tracked-point batch with the documented tolerance; pose
+    iterations."""
+    from mcptam_amd import synth_img
+    from mcptam_amd.keyframe import pose_points, track_pose_refine, track_search
+    from oracle import oracle_track_pose_refine, oracle_track_search
+    sc = synth_img.make_tracking_scene(size=(1280, 960))
+    gA, oA = _pair(1280, 960)
+    gB, oB = _pair(1280, 960)
+    gA.MakeKeyFrame_Lite(sc["imgA"]); oA.MakeKeyFrame_Lite(sc["imgA"])
+    gB.MakeKeyFrame_Lite(sc["imgB"]); oB.MakeKeyFrame_Lite(sc["imgB"])
+    _assert_lite_equal(gA, oA)
+    _assert_lite_equal(gB, oB)
+    assert len(gA.Corners(0)) > 2000 and gA.LevelSize(3) == (160, 120)
+    gA.MakeKeyFrame_Rest(); oA.MakeKeyFrame_Rest()
+    for l in range(4):
+        assert np.array_equal(gA.Candidates(l)[0], oA.Candidates(l)[0])
+    from mcptam_amd import synth_img as si
+    pts = si.make_map_points(sc["cam"], gA, oA, sc["poseA"], sc["depth"], per_level=(500, 300, 150, 50))
+    I = (np.eye(3), np.zeros(3))
+    og = track_search(gB, sc["cam"], sc["poseB"], I, pts, 10, 8)
+    oo = oracle_track_search(oB, sc["cam"], sc["poseB"], I, pts, 10, 8)
+    assert_track_equal(og, oo)
+    assert og["found"].sum() > 0.2*len(pts)       # twice the pixel motion of the 640x480 scene at the same search radius
+    wp = np.array([p["world_pos"] for p in pts])
+    pg, mg, wg, _ = track_pose_refine(pose_points(wp, og, 0), [sc["cam"]], [I], sc["poseB"])
+    po, mo, wo, _ = oracle_track_pose_refine(pose_points(wp, oo, 0), [sc["cam"]], [I], sc["poseB"])
+    clean = np.abs(og["templ"].astype(int) - oo["templ"].astype(int)).max(axis=1) == 0
+    if clean.all() and np.array_equal(og["found"], oo["found"]):
+        assert np.allclose(pg[0], po[0], atol=1e-9) and np.allclose(pg[1], po[1], atol=1e-9)
