@@ -339,8 +339,12 @@ int mcp_ba::prepare() {
     const int ibase = (int)inc_unk.size();
     sp_pt[sp] = pt; sp_m[sp] = j; sp_i[sp] = ibase;
     std::vector<int>& q = sp_poses[sp];
-    for (int k = cnt[pt]; k < cnt[pt + 1]; ++k, ++j) {
-      const int mi = by_point[k];
+    // Measurements of a point are stored rotated by the point's position: neighbouring points (= neighbouring lanes of
+    // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
+    // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
+    const int nm_pt = cnt[pt + 1] - cnt[pt];
+    for (int kk = 0; kk < nm_pt; ++kk, ++j) {
+      const int mi = by_point[cnt[pt] + (kk + sp) % nm_pt];
       const HMeas& m = meas[mi];
       perm[j] = mi;
       m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega; m_sp[j] = sp;
