@@ -173,7 +173,11 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 #pragma unroll
             for (int c = 0; c <= r; ++c) lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
         }
+#if defined(LIN_ABL) && LIN_ABL == 3
+        if (false) {                 // timing ablation only: no W blocks
+#else
         if (lpt >= 0) {
+#endif
           if (bit_a == 4) {          // the source pose's block collects one term per measurement: keep it in registers
             wss_inc = P.slot_inc[s0 + ia];
 #pragma unroll
