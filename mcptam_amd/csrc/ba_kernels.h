@@ -523,6 +523,7 @@ k_update_poses(DevProblem P, double lambda, const double* __restrict__ xp, const
 }
 
 constexpr int BS_BLOCK = 256;
+constexpr int BS_TPP = 4;          // threads per point in k_backsub
 // back-substitution for the points + oplus; partial sums of x(lambda x + b) and x^2
 __global__ void __launch_bounds__(BS_BLOCK)
 k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ g,
@@ -530,17 +531,25 @@ k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const doub
           double* __restrict__ pt_trial, double* __restrict__ xl, double* __restrict__ part_scale,
           double* __restrict__ part_ss) {
   __shared__ double lds[BS_BLOCK/64];
-  const int l = blockIdx.x*BS_BLOCK + threadIdx.x;
+  // BS_TPP threads per point share its incidences (each walk is a chain of dependent index -> pose-update loads), partial
+  // sums are combined with a fixed shuffle tree
+  const int l = (blockIdx.x*BS_BLOCK + threadIdx.x)/BS_TPP, q = threadIdx.x & (BS_TPP - 1);
   double sc = 0.0, ss = 0.0;
-  if (l < P.nfl) {
-    const double b0 = g[3*(size_t)l], b1 = g[3*(size_t)l+1], b2 = g[3*(size_t)l+2];
-    double t0 = b0, t1 = b1, t2 = b2;
+  const bool valid = l < P.nfl;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  if (valid) {
     const int i0 = P.l_i0[l], i1 = P.l_i1[l];
-    for (int i = i0; i < i1; ++i) {
+    for (int i = i0 + q; i < i1; i += BS_TPP) {
       const double* Wa = W + 18*(size_t)i; const double* xa = xp + 6*(size_t)P.inc_unk[i];
 #pragma unroll
       for (int r = 0; r < 6; ++r) { t0 -= Wa[3*r]*xa[r]; t1 -= Wa[3*r+1]*xa[r]; t2 -= Wa[3*r+2]*xa[r]; }
     }
+  }
+#pragma unroll
+  for (int o = 1; o < BS_TPP; o <<= 1) { t0 += __shfl_xor(t0, o, 64); t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+  if (valid && q == 0) {
+    const double b0 = g[3*(size_t)l], b1 = g[3*(size_t)l+1], b2 = g[3*(size_t)l+2];
+    t0 += b0; t1 += b1; t2 += b2;
     const double* I6 = Vinv + 6*(size_t)l;
     const double d[3] = { I6[0]*t0 + I6[1]*t1 + I6[2]*t2, I6[1]*t0 + I6[3]*t1 + I6[4]*t2, I6[2]*t0 + I6[4]*t1 + I6[5]*t2 };
     xl[3*(size_t)l] = d[0]; xl[3*(size_t)l+1] = d[1]; xl[3*(size_t)l+2] = d[2];

@@ -678,7 +678,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const double* bp_glob = (world > 1) ? rhs() + np : bp();
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
-  const int nbb = (nfl + BS_BLOCK - 1)/BS_BLOCK;
+  const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
   toc();
