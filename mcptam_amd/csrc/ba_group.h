@@ -292,7 +292,18 @@ constexpr int SCH_TPP = 256/SCH_CHUNK;        // threads per point in the scatte
 constexpr int SCH_EPT = (GRP_LMAX*6 + SCH_TPP - 1)/SCH_TPP;    // W rows per thread (<= 16 incidences x 6 rows per point)
 constexpr int SCH_K = 3*SCH_CHUNK;            // 48
 constexpr int SCH_LD = SCH_K + 1;             // LDS row stride (doubles)
+constexpr int SCH_NCH = GRP_PTS/SCH_CHUNK;    // chunks per group
 typedef double sch_d4 __attribute__((ext_vector_type(4)));
+#ifdef MCP_SCH_PROF
+__device__ unsigned long long g_sch_prof[8*8];
+#define SCH_T0() unsigned long long sch_t = clock64(), sch_a[8] = {0,0,0,0,0,0,0,0}
+#define SCH_LAP(i) do { const unsigned long long n_ = clock64(); sch_a[i] += n_ - sch_t; sch_t = n_; } while (0)
+#define SCH_OUT() do { if ((blockIdx.x & 127) == 100 && blockIdx.x < 1024 && blockIdx.y == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_sch_prof[(blockIdx.x >> 7)*8 + i_] = sch_a[i_]; } while (0)
+#else
+#define SCH_T0() do {} while (0)
+#define SCH_LAP(i) do {} while (0)
+#define SCH_OUT() do {} while (0)
+#endif
 
 __global__ void __launch_bounds__(256)
 k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
@@ -314,17 +325,28 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
   sch_d4 acc[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = (sch_d4){0.0, 0.0, 0.0, 0.0};
-  double racc = 0.0;                           // rhs entry t (t < GRP_DOF)
-  // The global reads of a chunk hang off two index hops (point -> incidence range -> local pose slot), a few
-  // microseconds of dependent latency.  They are issued one chunk ahead, into registers, and land in LDS after the
-  // matrix-core phase of the chunk before, so only the first chunk of a group pays for them.
+  double racc = 0.0;                           // half of rhs entry t % GRP_DOF (t < 2*GRP_DOF)
+  SCH_T0();
+  // The global reads of a chunk hang off index hops (point -> incidence range / free-point index).  Those of all
+  // chunks are resolved in the prologue (one exposed round trip per group instead of one per chunk); the W / V / g
+  // reads are then issued one chunk ahead, into registers, and land in LDS after the matrix-core phase of the chunk
+  // before, so only the first chunk of a group waits for them.
   const int pl = t/SCH_TPP, sub = t%SCH_TPP;
+  int ci0[SCH_NCH], ccnt[SCH_NCH], cpt[SCH_NCH];
+#pragma unroll
+  for (int c = 0; c < SCH_NCH; ++c) {
+    const int sp = sp0 + c*SCH_CHUNK + pl;
+    ci0[c] = 0; ccnt[c] = 0; cpt[c] = -1;
+    if (sp < sp1 && !P.sp_big[sp]) { ci0[c] = P.sp_i[sp]; ccnt[c] = (P.sp_i[sp + 1] - ci0[c])*6; }
+    if (t < SCH_CHUNK) {
+      const int sq = sp0 + c*SCH_CHUNK + t;
+      if (sq < sp1 && !P.sp_big[sq]) cpt[c] = P.pt_unk[P.sp_pt[sq]];
+    }
+  }
   double pw[SCH_EPT][3]; int prow[SCH_EPT];    // this thread's W rows of the next chunk
   double pv[6], pg[3]; int plpt = -1;          // threads 0..15: V and g of the next chunk's points
-  auto prefetch = [&](int base) {
-    const int sp = base + pl;
-    int i0 = 0, cnt = 0;
-    if (sp < sp1 && !P.sp_big[sp]) { i0 = P.sp_i[sp]; cnt = (P.sp_i[sp + 1] - i0)*6; }
+  auto prefetch = [&]() {                      // the next chunk not fetched yet: entry 0 of the index queues
+    const int i0 = ci0[0], cnt = ccnt[0];
 #pragma unroll
     for (int k = 0; k < SCH_EPT; ++k) {
       const int it = sub + SCH_TPP*k;
@@ -337,20 +359,22 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       }
     }
     if (t < SCH_CHUNK) {
-      const int sq = base + t;
-      plpt = -1;
-      if (sq < sp1 && !P.sp_big[sq]) plpt = P.pt_unk[P.sp_pt[sq]];
+      plpt = cpt[0];
       if (plpt >= 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pv[k] = V[6*(size_t)plpt + k];
         pg[0] = g[3*(size_t)plpt]; pg[1] = g[3*(size_t)plpt + 1]; pg[2] = g[3*(size_t)plpt + 2];
       }
     }
+#pragma unroll
+    for (int c = 0; c + 1 < SCH_NCH; ++c) { ci0[c] = ci0[c + 1]; ccnt[c] = ccnt[c + 1]; cpt[c] = cpt[c + 1]; }
+    ccnt[SCH_NCH - 1] = 0; cpt[SCH_NCH - 1] = -1;
   };
-  prefetch(sp0);
+  prefetch();
   // the staging arrays are zero-filled once; after each chunk every thread clears exactly the rows it wrote
   for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
   int orow[SCH_EPT];
+  SCH_LAP(0);
   for (int base = sp0; base < sp1; base += SCH_CHUNK) {
     if (t < SCH_CHUNK) {
       double I6[6] = {0, 0, 0, 0, 0, 0}; double g3[3] = {0, 0, 0};
@@ -365,6 +389,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       gl[3*t] = g3[0]; gl[3*t + 1] = g3[1]; gl[3*t + 2] = g3[2];
     }
     __syncthreads();
+    SCH_LAP(1);
     {   // scatter W and Y = W V^-1 rows: 16 threads per point
       const double* I6 = Vi + 6*pl;
 #pragma unroll
@@ -380,10 +405,12 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
         yd[2] = w0*I6[2] + w1*I6[4] + w2*I6[5];
       }
     }
-    if (base + SCH_CHUNK < sp1) prefetch(base + SCH_CHUNK);      // in flight during the matrix-core phase
+    SCH_LAP(2);
+    if (base + SCH_CHUNK < sp1) prefetch();      // in flight during the matrix-core phase
     __syncthreads();
-    // S_loc += Y W^T on the matrix cores; wave w owns the lower-triangular tile pairs w, w+4, ...
-    {
+    SCH_LAP(3);
+    // S_loc += Y W^T on the matrix cores
+    {   // wave w owns the lower-triangular tile pairs w, w+4, ...
       const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
@@ -401,13 +428,16 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
         }
       }
     }
-    if (t < GRP_DOF) {
-      const double* yr = Yd + t*SCH_LD;
+    SCH_LAP(4);
+    if (t < 2*GRP_DOF) {                        // two threads per row, 24 columns each; both add to rhs at the flush
+      const int row = (t < GRP_DOF) ? t : t - GRP_DOF, k0 = (t < GRP_DOF) ? 0 : SCH_K/2;
+      const double* yr = Yd + row*SCH_LD + k0;
       double s = 0.0;
 #pragma unroll 8
-      for (int k = 0; k < SCH_K; ++k) s += yr[k]*gl[k];
+      for (int k = 0; k < SCH_K/2; ++k) s += yr[k]*gl[k0 + k];
       racc += s;
     }
+    SCH_LAP(5);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SCH_EPT; ++k) {
@@ -416,12 +446,14 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       double* yd = Yd + orow[k]*SCH_LD + 3*pl;
       wd[0] = 0.0; wd[1] = 0.0; wd[2] = 0.0; yd[0] = 0.0; yd[1] = 0.0; yd[2] = 0.0;
     }
+    SCH_LAP(6);
   }
   // flush: S -= S_loc (lower triangle in global order), rhs -= r_loc
   const int np = P.np;
-  if (t < GRP_DOF) {
-    const int u = gp_[t/6];
-    if (u >= 0 && racc != 0.0) unsafeAtomicAdd(rhs + 6*(size_t)u + t%6, -racc);
+  if (t < 2*GRP_DOF) {
+    const int row = (t < GRP_DOF) ? t : t - GRP_DOF;
+    const int u = gp_[row/6];
+    if (u >= 0 && racc != 0.0) unsafeAtomicAdd(rhs + 6*(size_t)u + row%6, -racc);
   }
   {
     const int col_l = lane & 15, rq = lane >> 4;
@@ -445,6 +477,8 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
       }
     }
   }
+  SCH_LAP(7);
+  SCH_OUT();
 }
 constexpr size_t SCH_LDS_BYTES = (size_t)(2*GRP_DOF*SCH_LD + SCH_CHUNK*6 + SCH_K)*sizeof(double);
 

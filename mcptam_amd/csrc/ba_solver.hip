@@ -644,6 +644,16 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
     if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
     toc();
+#ifdef MCP_SCH_PROF
+    {
+      HIPCK(hipStreamSynchronize(st));
+      unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sch_prof), sizeof pr);
+      double a[8] = {0}; int cnt = 0;
+      for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[7]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
+      if (cnt) fprintf(stderr, "[sch prof] prologue %.0f  inverse+barrier %.0f  scatter %.0f  prefetch+barrier %.0f  mfma %.0f  rhs %.0f  barrier+clear %.0f  flush %.0f  (cycles, %d groups)\n",
+                       a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, a[6]/cnt, a[7]/cnt, cnt);
+    }
+#endif
     if (np && multi()) {
       // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
       const size_t npack = pack_stride*nsys;
