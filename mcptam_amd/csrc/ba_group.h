@@ -293,6 +293,12 @@ constexpr int SCH_EPT = (GRP_LMAX*6 + SCH_TPP - 1)/SCH_TPP;    // W rows per thr
 constexpr int SCH_K = 3*SCH_CHUNK;            // 48
 constexpr int SCH_LD = SCH_K + 1;             // LDS row stride (doubles)
 constexpr int SCH_NCH = GRP_PTS/SCH_CHUNK;    // chunks per group
+#ifndef SCH_Z
+#define SCH_Z 1       // 1: stage Z = W L only (V^-1 = L L^T), S -= Z Z^T;  0: stage W and Y = W V^-1, S -= Y W^T
+#endif
+#ifndef SCH_WAVES
+#define SCH_WAVES 3   // wavefronts per SIMD the register allocation aims at (3: 168 VGPRs + 104 B of scratch, three workgroups per CU: 5.34 -> 5.06 ms)
+#endif
 typedef double sch_d4 __attribute__((ext_vector_type(4)));
 #ifdef MCP_SCH_PROF
 __device__ unsigned long long g_sch_prof[8*8];
@@ -305,14 +311,14 @@ __device__ unsigned long long g_sch_prof[8*8];
 #define SCH_OUT() do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCH_WAVES, SCH_WAVES)))
 k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
               const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
               double* __restrict__ rhs, int* __restrict__ fail, SysBatch sb) {
   if (blockIdx.y) { const int q = blockIdx.y; lambda = sb.lambda[q]; Vinv += q*sb.vstride; S += q*sb.sstride; rhs += q*sb.sstride; fail += q; }
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* Yd = lds;                            // [GRP_DOF][SCH_LD]
-  double* Wd = lds + GRP_DOF*SCH_LD;           // [GRP_DOF][SCH_LD]
+  double* Yd = lds;                            // [GRP_DOF][SCH_LD]   (SCH_Z: Z, the only staging array)
+  double* Wd = lds + (SCH_Z ? 0 : GRP_DOF*SCH_LD);     // [GRP_DOF][SCH_LD]
   double* Vi = Wd + GRP_DOF*SCH_LD;            // [SCH_CHUNK][6]
   double* gl = Vi + SCH_CHUNK*6;               // [SCH_K]
   const int grp = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -372,7 +378,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
   };
   prefetch();
   // the staging arrays are zero-filled once; after each chunk every thread clears exactly the rows it wrote
-  for (int i = t; i < 2*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
+  for (int i = t; i < (SCH_Z ? 1 : 2)*GRP_DOF*SCH_LD; i += 256) lds[i] = 0.0;
   int orow[SCH_EPT];
   SCH_LAP(0);
   for (int base = sp0; base < sp1; base += SCH_CHUNK) {
@@ -383,6 +389,19 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
 #pragma unroll
         for (int k = 0; k < 6; ++k) Vinv[6*(size_t)plpt + k] = I6[k];
         g3[0] = pg[0]; g3[1] = pg[1]; g3[2] = pg[2];
+#if SCH_Z
+        // V^-1 = L L^T (3x3 Cholesky; a failed inverse is flagged above, its factor is zeroed rather than NaN):
+        // I6 <- (l00, l10, l20, l11, l21, l22), g3 <- L^T g, so that W V^-1 W^T = Z Z^T and W V^-1 g = Z (L^T g)
+        const double l00 = I6[0] > 0.0 ? sqrt(I6[0]) : 0.0, r00 = l00 > 0.0 ? 1.0/l00 : 0.0;
+        const double l10 = I6[1]*r00, l20 = I6[2]*r00;
+        const double d11 = I6[3] - l10*l10;
+        const double l11 = d11 > 0.0 ? sqrt(d11) : 0.0, r11 = l11 > 0.0 ? 1.0/l11 : 0.0;
+        const double l21 = (I6[4] - l20*l10)*r11;
+        const double d22 = I6[5] - l20*l20 - l21*l21;
+        const double l22 = d22 > 0.0 ? sqrt(d22) : 0.0;
+        I6[0] = l00; I6[1] = l10; I6[2] = l20; I6[3] = l11; I6[4] = l21; I6[5] = l22;
+        g3[0] = l00*pg[0] + l10*pg[1] + l20*pg[2]; g3[1] = l11*pg[1] + l21*pg[2]; g3[2] = l22*pg[2];
+#endif
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) Vi[6*t + k] = I6[k];
@@ -397,12 +416,18 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
         orow[k] = prow[k];
         if (prow[k] < 0) continue;
         const double w0 = pw[k][0], w1 = pw[k][1], w2 = pw[k][2];
-        double* wd = Wd + prow[k]*SCH_LD + 3*pl;
         double* yd = Yd + prow[k]*SCH_LD + 3*pl;
+#if SCH_Z
+        yd[0] = w0*I6[0] + w1*I6[1] + w2*I6[2];
+        yd[1] = w1*I6[3] + w2*I6[4];
+        yd[2] = w2*I6[5];
+#else
+        double* wd = Wd + prow[k]*SCH_LD + 3*pl;
         wd[0] = w0; wd[1] = w1; wd[2] = w2;
         yd[0] = w0*I6[0] + w1*I6[1] + w2*I6[2];
         yd[1] = w0*I6[1] + w1*I6[3] + w2*I6[4];
         yd[2] = w0*I6[2] + w1*I6[4] + w2*I6[5];
+#endif
       }
     }
     SCH_LAP(2);
@@ -442,9 +467,12 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
 #pragma unroll
     for (int k = 0; k < SCH_EPT; ++k) {
       if (orow[k] < 0) continue;
-      double* wd = Wd + orow[k]*SCH_LD + 3*pl;
       double* yd = Yd + orow[k]*SCH_LD + 3*pl;
-      wd[0] = 0.0; wd[1] = 0.0; wd[2] = 0.0; yd[0] = 0.0; yd[1] = 0.0; yd[2] = 0.0;
+      yd[0] = 0.0; yd[1] = 0.0; yd[2] = 0.0;
+#if !SCH_Z
+      double* wd = Wd + orow[k]*SCH_LD + 3*pl;
+      wd[0] = 0.0; wd[1] = 0.0; wd[2] = 0.0;
+#endif
     }
     SCH_LAP(6);
   }
@@ -480,6 +508,6 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
   SCH_LAP(7);
   SCH_OUT();
 }
-constexpr size_t SCH_LDS_BYTES = (size_t)(2*GRP_DOF*SCH_LD + SCH_CHUNK*6 + SCH_K)*sizeof(double);
+constexpr size_t SCH_LDS_BYTES = (size_t)((SCH_Z ? 1 : 2)*GRP_DOF*SCH_LD + SCH_CHUNK*6 + SCH_K)*sizeof(double);
 
 }  // namespace mcp
