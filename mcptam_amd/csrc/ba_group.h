@@ -287,7 +287,10 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int SCH_CHUNK = 16;                 // points per MFMA chunk (8: more barriers, 5.8 -> 7.3 ms; 32: one workgroup per CU)
+#ifndef SCH_CHUNK_PTS
+#define SCH_CHUNK_PTS 16
+#endif
+constexpr int SCH_CHUNK = SCH_CHUNK_PTS;                 // points per MFMA chunk (8: more barriers, 5.8 -> 7.3 ms; 32: one workgroup per CU)
 constexpr int SCH_TPP = 256/SCH_CHUNK;        // threads per point in the scatter
 constexpr int SCH_EPT = (GRP_LMAX*6 + SCH_TPP - 1)/SCH_TPP;    // W rows per thread (<= 16 incidences x 6 rows per point)
 constexpr int SCH_K = 3*SCH_CHUNK;            // 48
