@@ -140,20 +140,55 @@ k_select_gather(int n, const double* __restrict__ x, const double* __restrict__ 
   }
 }
 
+// ---- multi-rank short form: two all-reduced histogram passes, then every rank writes the elements that share the selected
+// 22-bit prefix into its own slot of a (ranks x cap) table; summing the zero-filled tables over the ranks gathers them, and
+// every rank finishes locally with k_select_small (3 collectives in place of 6).  The all-reduced histogram tells every rank
+// the same global candidate count; beyond `cap` the table is abandoned and the remaining histogram passes run instead.
+static __global__ void __launch_bounds__(SEL_BLOCK)
+k_select_gather_slot(int n, const double* __restrict__ x, const double* __restrict__ hist, SelState* __restrict__ state,
+                     unsigned int* __restrict__ cnt, double* __restrict__ slot_vals, int cap, double* __restrict__ flag /* rank 0; else null */) {
+  __shared__ unsigned long long sc[SEL_BLOCK + 2];
+  const SelState prev = state[1];
+  int bin; unsigned long long kin;
+  sel_find_bin(hist + (size_t)SEL_BINS, 1 << sel_nbits(1), prev.k, bin, kin, sc);
+  SelState st;
+  st.prefix = prev.prefix | ((unsigned long long)bin << sel_shift(1));
+  st.k = kin;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state[2] = st;
+    if (flag) flag[0] = (hist[SEL_BINS + bin] > (double)cap) ? 1.0 : 0.0;
+  }
+  const unsigned long long himask = ~0ull << sel_shift(1);
+  for (size_t i = blockIdx.x*(size_t)SEL_BLOCK + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x*SEL_BLOCK) {
+    const double a = fabs(x[i]);
+    const unsigned long long key = (unsigned long long)__double_as_longlong(a);
+    if ((key & himask) == st.prefix) {
+      const unsigned int idx = atomicAdd(cnt, 1u);
+      if (idx < (unsigned int)cap) slot_vals[idx] = a;
+    }
+  }
+}
+static __global__ void k_select_publish(const unsigned int* __restrict__ cnt, int cap, double* __restrict__ count_slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) count_slot[0] = (double)min(cnt[0], (unsigned int)cap);
+}
+
 // one workgroup: passes 2..5 over the gathered candidates (or, if they overflowed the buffer -- tens of thousands of
 // values equal in their top 22 bits -- over the original array with the prefix filter), then the sigma block
 static __global__ void __launch_bounds__(1024)
 k_select_small(int n, const double* __restrict__ x, const unsigned int* __restrict__ cnt, const double* __restrict__ vals,
                const SelState* __restrict__ state, double n_total, double min_sigma_sq, double* __restrict__ med_out,
-               double* __restrict__ sig, double* __restrict__ sig_copy) {
+               double* __restrict__ sig, double* __restrict__ sig_copy,
+               const double* __restrict__ slot_counts = nullptr, int nslot = 0, int slot_cap = 0) {
   __shared__ unsigned int hist[SEL_BINS];
   __shared__ unsigned int part[64];
   __shared__ unsigned long long s_prefix, s_k;
   const int t = threadIdx.x;
-  const unsigned int c = cnt[0];
-  const bool overflow = c > (unsigned int)SEL_GATHER_CAP;
+  // slot mode (multi-rank, k_select_gather_slot): vals is an nslot x slot_cap table, slot r holds slot_counts[r] candidates
+  const bool slots = slot_counts != nullptr;
+  const unsigned int c = slots ? 0u : cnt[0];
+  const bool overflow = !slots && c > (unsigned int)SEL_GATHER_CAP;
   const double* src = overflow ? x : vals;
-  const int m = overflow ? n : (int)c;
+  const int m = slots ? nslot*slot_cap : (overflow ? n : (int)c);
   if (t == 0) { s_prefix = state[2].prefix; s_k = state[2].k; }
   __syncthreads();
   for (int pass = 2; pass < SEL_PASSES; ++pass) {
@@ -164,6 +199,7 @@ k_select_small(int n, const double* __restrict__ x, const unsigned int* __restri
     __syncthreads();
     const unsigned long long prefix = s_prefix;
     for (int i = t; i < m; i += 1024) {
+      if (slots && (double)(i % slot_cap) >= slot_counts[i/slot_cap]) continue;
       const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(src[i]));
       if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
     }

@@ -122,6 +122,8 @@ struct mcp_ba {
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp copy (np)]   (the all-reduced block)
   DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
   DevBuf<double> d_selvals;     // candidates of the single-GPU selection (SEL_GATHER_CAP)
+  DevBuf<double> d_seltab;      // multi-rank selection: [world x sel_cap candidates][overflow flag][world counts][gather counter]
+  int sel_cap = 4096;           // candidates per rank slot (MCP_BA_SELECT_CAP)
   DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
   DevBuf<SelState> d_selstate;
@@ -163,6 +165,7 @@ struct mcp_ba {
   // multi-lambda batch (ba_kernels.h SysBatch): systems 1.. are speculative solves for the next lambdas of the LM
   // schedule.  S()/rhs()/Vinv() address the system the latest trial used.
   size_t red_stride = 0, vinv_stride = 0, pack_stride = 0;
+  bool start_rides = false;        // the iteration-start chi2 still has to be summed over the ranks
   int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
   int speculate = 3;                 // speculative systems per solve; MCP_BA_SPECULATE=0 turns them off
   int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
@@ -476,6 +479,8 @@ int mcp_ba::prepare() {
   red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
+  { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
+  if (world > 1 && d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
   if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
@@ -555,8 +560,30 @@ int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out
                        huber_sigma ? d_res.p + 25 : (double*)nullptr);
     return 0;
   }
+  // several ranks: two all-reduced histogram passes, then the few candidates of every rank are gathered through a
+  // zero-filled (ranks x sel_cap) table summed over the ranks, and each rank finishes locally: 3 collectives
   HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
-  for (int p = 0; p < SEL_PASSES; ++p) {
+  const size_t tab = (size_t)world*sel_cap;              // [tab] overflow flag, [tab+1 .. tab+world] counts, [tab+world+1] gather counter
+  HIPCK(hipMemsetAsync(d_seltab.p, 0, (tab + world + 2)*sizeof(double), st));
+  for (int p = 0; p < 2; ++p) {
+    hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
+    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
+  }
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(d_seltab.p + tab + world + 1);
+  hipLaunchKernelGGL(k_select_gather_slot, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, (const double*)d_hist.p, d_selstate.p, cnt,
+                     d_seltab.p + (size_t)rank*sel_cap, sel_cap, rank == 0 ? d_seltab.p + tab : (double*)nullptr);
+  hipLaunchKernelGGL(k_select_publish, dim3(1), dim3(64), 0, st, (const unsigned int*)cnt, sel_cap, d_seltab.p + tab + 1 + rank);
+  if (allreduce(d_seltab.p, tab + 1 + world)) return -1;
+  // the flag is the same on every rank (it is derived from the all-reduced histogram), so all ranks take the same branch
+  HIPCK(hipMemcpyAsync(h_res + 30, d_seltab.p + tab, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCK(hipStreamSynchronize(st));
+  if (h_res[30] == 0.0) {
+    hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_seltab.p, (const SelState*)d_selstate.p,
+                       m_total, 0.0, out_dev, (double*)nullptr, (double*)nullptr, (const double*)(d_seltab.p + tab + 1), world, sel_cap);
+    return 0;
+  }
+  // more candidates than the table holds (tens of thousands of values equal in their top 22 bits): the remaining digits by histogram
+  for (int p = 2; p < SEL_PASSES; ++p) {
     hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
     if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
   }
@@ -700,7 +727,14 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
                      nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur);
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
-  if (allreduce(d_res.p, 4)) return -1;          // robust chi2, point parts of the step statistics, failure flag (any rank)
+  // robust chi2, point parts of the step statistics, failure flag (any rank); on the first trial of an iteration also the
+  // iteration-start robust chi2 (moved next to them for the occasion, and back)
+  if (start_rides) {
+    HIPCK(hipMemcpyAsync(d_res.p + 4, d_res.p + 24, sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (allreduce(d_res.p, 5)) return -1;
+    HIPCK(hipMemcpyAsync(d_res.p + 24, d_res.p + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
+    start_rides = false;
+  } else if (allreduce(d_res.p, 4)) return -1;
   if (read_results(29)) return -1;          // trial results [0..7] and, for compute(), the iteration-start block [24..28]
   h_res[1] += h_res[6]; h_res[2] += h_res[7];
   ok2 = (h_res[3] == 0.0);
@@ -738,7 +772,10 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       constexpr int RS = 24;
       hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, RS, (const int*)nullptr);
       toc();
-      if (allreduce(d_res.p + RS, 1)) return -1;
+      // several ranks: the sum over the ranks rides on the first trial's all-reduce (d_res[0..3] + d_res[4], see solve_trial);
+      // the first iteration needs it before its first trial
+      if (it == 0) { if (allreduce(d_res.p + RS, 1)) return -1; }
+      start_rides = (it > 0 && world > 1);
       if (linearize()) return -1;
       if (it == 0 && !(user_lambda > 0)) {
         if (world > 1 && np) {     // the diagonal of U is a sum over ranks
