@@ -815,3 +815,119 @@ def test_pose_refine_equals_the_iteration_loop_spelled_out():
     # and the full schedule converges: the last update is tiny and the pose is close to the true one
     assert np.abs(mu).max() < 1e-3 * max(np.abs(mu4).max(), 1e-3) or np.abs(mu).max() < 1e-5
     assert (w[f] > 0).mean() > 0.7 and np.all(w[~f] == 0)
+
+
+@pytest.mark.parametrize("over,iters,user_lambda", [({}, 6, -1.0), (dict(pose_sigma=(0.12, 1.0), depth_sigma=0.05, seed=2), 8, 1e-8)])
+def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user_lambda):
+    """Independent pin of the whole non-robust adjustment loop: residuals coded in numpy from the measurement model, the
+    vertex updates of VertexPoseSE3 / VertexRelPoint::oplusImpl (src/ChainBundle.cc:82-86, 237-281) restated in numpy,
+    Jacobians by central differences through those updates, one dense (H + lambda I) x = b solve per trial and the
+    Levenberg-Marquardt schedule of g2o's OptimizationAlgorithmLevenberg as ChainBundle drives it (tau = 1e-5, rho with the
+    1e-3 guard, lambda *= max(1/3, min(2/3, 1 - (2 rho - 1)^3)) on success, lambda *= ni, ni *= 2 on failure).  Nothing of the
+    oracle's Jacobians, block assembly, Schur complement or Cholesky is reused; the per-iteration log must agree.  The second
+    case starts further away with a tiny user lambda, so that one iteration rejects seven trials in a row (the lambda *= ni
+    branch).  (Starts so far off that points land beyond ~100 degrees from the optical axis are not usable here: there the
+    reference's analytic projection derivatives, which the oracle follows, differ from the numeric ones.)"""
+    from mcptam_amd import synth
+    p = synth.make_config("tiny", outlier_frac=0.0, **over)
+    o = _orc(p.cams, robust=False, tukey=False)
+    o.DisableConvergence(True)
+    from helpers import collect
+    ids = p.populate(o)
+    rc = o.Compute(iters, user_lambda)
+    R_, t_, X_ = collect(o, ids)
+    r = dict(rc=rc, logs=o.IterLogs(), R=R_, t=t_, X=X_)
+    if over:
+        assert max(l["trials"] for l in r["logs"]) > 5
+    assert r["rc"] == iters
+    cam = p.cams[0]
+    free = np.nonzero(~p.base_fixed)[0]
+    assert not np.any(p.pt_fixed)
+    omega = 1.0 / 2.0 ** p.ms_level
+    W = np.repeat(omega, 2)
+
+    def so3(w):
+        return synth.se3_exp(np.concatenate([np.zeros(3), w]))[0]
+
+    def point_oplus(X, U):
+        out = np.empty_like(X)
+        for j in range(len(X)):
+            x, u = X[j], U[j]
+            rho = 1.0/np.linalg.norm(x)
+            d = x*rho
+            ax = np.array([d[1], -d[0], 0.0])
+            nrm = np.linalg.norm(ax)
+            Rp = so3(ax/nrm*np.arcsin(nrm))
+            v = Rp.T @ so3(np.array([u[0], u[1], 0.0])) @ Rp @ d
+            out[j] = v/(rho + u[2])
+        return out
+
+    def pose_oplus(Rb, tb, u):
+        Rk, tk = Rb.copy(), tb.copy()
+        for a, k in enumerate(free):
+            E = synth.se3_exp(u[6*a:6*a + 6])
+            Rk[k], tk[k] = E[0] @ Rb[k], E[0] @ tb[k] + E[1]
+        return Rk, tk
+
+    def residual(Rb, tb, Xrel):
+        # relative point -> world through its source chain, world -> pixel through the observer chain
+        sR = np.einsum("nij,njk->nik", p.cam_R[p.pt_src[:, 1]], Rb[p.pt_src[:, 0]])
+        st = np.einsum("nij,nj->ni", p.cam_R[p.pt_src[:, 1]], tb[p.pt_src[:, 0]]) + p.cam_t[p.pt_src[:, 1]]
+        Xw = np.einsum("nji,nj->ni", sR, Xrel - st)
+        xb = np.einsum("mij,mj->mi", Rb[p.ms_mkf], Xw[p.ms_pt]) + tb[p.ms_mkf]
+        xc = np.einsum("mij,mj->mi", p.cam_R[p.ms_cam], xb) + p.cam_t[p.ms_cam]
+        uv, _ = cam.project(xc)
+        return (p.ms_uv - uv).reshape(-1)
+
+    n1, n2 = 6*len(free), 3*p.n_points
+    h = 1e-6
+
+    def jacobian(Rb, tb, Xrel):
+        J = np.zeros((2*p.n_meas, n1 + n2))
+        for i in range(n1):
+            u = np.zeros(n1); u[i] = h
+            J[:, i] = (residual(*pose_oplus(Rb, tb, u), Xrel) - residual(*pose_oplus(Rb, tb, -u), Xrel))/(2*h)
+        rows = np.arange(2*p.n_meas)
+        cols = n1 + 3*np.repeat(p.ms_pt, 2)
+        for d in range(3):                   # a residual depends on one point only: perturb all points at once
+            U = np.zeros((p.n_points, 3)); U[:, d] = h
+            col = (residual(Rb, tb, point_oplus(Xrel, U)) - residual(Rb, tb, point_oplus(Xrel, -U)))/(2*h)
+            J[rows, cols + d] = col
+        return J
+
+    Rb, tb, Xrel = p.base_R.copy(), p.base_t.copy(), p.pt_x.copy()
+    lam, ni = None, 2.0
+    for it in range(iters):
+        lg = r["logs"][it]
+        e = residual(Rb, tb, Xrel)
+        chi = float((W*e*e).sum())
+        assert abs(chi - lg["chi2_start"]) <= (1e-7 if user_lambda < 0 else 1e-4)*chi, (it, chi, lg)
+        J = jacobian(Rb, tb, Xrel)
+        H = J.T @ (W[:, None]*J)
+        b = -J.T @ (W*e)
+        if it == 0:
+            lam, ni = (user_lambda if user_lambda > 0 else 1e-5*np.abs(np.diag(H)).max()), 2.0
+        trials, accepted, rho = 0, 0, 0.0
+        while True:
+            x = np.linalg.solve(H + lam*np.eye(n1 + n2), b)
+            Rn, tn = pose_oplus(Rb, tb, x[:n1])
+            Xn = point_oplus(Xrel, x[n1:].reshape(-1, 3))
+            en = residual(Rn, tn, Xn)
+            chin = float((W*en*en).sum())
+            rho = (chi - chin)/(float(x @ (lam*x + b)) + 1e-3)
+            if rho > 0 and np.isfinite(chin):
+                alpha = min(1.0 - (2*rho - 1)**3, 2.0/3.0)
+                lam *= max(1.0/3.0, alpha); ni = 2.0
+                Rb, tb, Xrel, chi, accepted = Rn, tn, Xn, chin, 1
+            else:
+                lam *= ni; ni *= 2; accepted = 0
+            trials += 1
+            if not (rho < 0 and trials < 100):
+                break
+        assert trials == lg["trials"] and accepted == lg["accepted"], (it, trials, accepted, lg)
+        # the nearly undamped first step of the second case (lambda = 1e-8 on a gauge-deficient system) amplifies the
+        # 1e-10 error of the central differences: looser there
+        tol = 1e-6 if user_lambda < 0 else 1e-4
+        assert abs(lam - lg["lambda_end"]) <= 10*tol*lam, (it, lam, lg)
+        assert abs(chi - lg["chi2_end"]) <= tol*max(chi, 1e-9), (it, chi, lg)
+    assert rel_err(Rb, r["R"]) < tol and rel_err(tb, r["t"]) < tol and rel_err(Xrel, r["X"]) < tol
