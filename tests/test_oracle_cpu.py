@@ -819,7 +819,8 @@ def test_pose_refine_equals_the_iteration_loop_spelled_out():
 
 @pytest.mark.parametrize("over,iters,user_lambda,robust", [({}, 6, -1.0, False),
                                                           (dict(pose_sigma=(0.12, 1.0), depth_sigma=0.05, seed=2), 8, 1e-8, False),
-                                                          (dict(outlier_frac=0.05), 6, -1.0, True)])
+                                                          (dict(outlier_frac=0.05), 6, -1.0, True),
+                                                          (dict(n_mkf=3, per_point=3, outlier_frac=0.05), 5, -1.0, True)])
 def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user_lambda, robust):
     """Independent pin of the whole non-robust adjustment loop: residuals coded in numpy from the measurement model, the
     vertex updates of VertexPoseSE3 / VertexRelPoint::oplusImpl (src/ChainBundle.cc:82-86, 237-281) restated in numpy,
@@ -831,16 +832,19 @@ def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user
     branch).  (Starts so far off that points land beyond ~100 degrees from the optical axis are not usable here: there the
     reference's analytic projection derivatives, which the oracle follows, differ from the numeric ones.)  The third case
     has 5 % outliers and the adaptive Huber kernel on: sigma^2 from the median chi2 at every iteration start
-    (RobustKernelData::RecomputeNow), first-order weights rho' in H and b, sum of rho as the cost the LM compares."""
+    (RobustKernelData::RecomputeNow), first-order weights rho' in H and b, sum of rho as the cost the LM compares.  The
+    fourth case has two free poses, so BundleAdjust's epilogue also runs (src/ChainBundle.cc:1368-1448): the Tukey outlier
+    list at the final state and GetMaxCov = the [N/2] element of the points' depth variances (H^-1)_22, H being the
+    undamped system of the last iteration."""
     from mcptam_amd import synth
     p = synth.make_config("tiny", **dict(dict(outlier_frac=0.0), **over))
-    o = _orc(p.cams, robust=robust, tukey=False)
+    o = _orc(p.cams, robust=robust, tukey=robust)
     o.DisableConvergence(True)
     from helpers import collect
     ids = p.populate(o)
     rc = o.Compute(iters, user_lambda)
     R_, t_, X_ = collect(o, ids)
-    r = dict(rc=rc, logs=o.IterLogs(), R=R_, t=t_, X=X_)
+    r = dict(rc=rc, logs=o.IterLogs(), R=R_, t=t_, X=X_, outliers=o.GetOutlierMeasurements(), max_cov=o.GetMaxCov())
     if user_lambda > 0:
         assert max(l["trials"] for l in r["logs"]) > 5
     assert r["rc"] == iters
@@ -928,6 +932,7 @@ def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user
         assert abs(chi - lg["chi2_start"]) <= (1e-4 if user_lambda > 0 else (1e-5 if robust else 1e-7))*chi, (it, chi, lg)
         J = jacobian(Rb, tb, Xrel)
         H = J.T @ (Wr[:, None]*J)
+        H_last = H
         b = -J.T @ (Wr*e)
         if it == 0:
             lam, ni = (user_lambda if user_lambda > 0 else 1e-5*np.abs(np.diag(H)).max()), 2.0
@@ -957,3 +962,16 @@ def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user
     # (points with a single down-weighted ray are loose along their depth: their tolerance is wider)
     assert rel_err(Rb, r["R"]) < tol and rel_err(tb, r["t"]) < tol and rel_err(Xrel, r["X"]) < 10*tol
     assert (n_down > 0) == robust
+    if robust:
+        c = omega*(residual(Rb, tb, Xrel).reshape(-1, 2)**2).sum(axis=1)
+        t2 = max((4.6851*1.4826*(1 + 5.0/(2*M - 6)))**2*np.sort(c)[M//2], 0.25)
+        margin = np.abs(c - t2) > 1e-4*t2                       # (a measurement exactly on the threshold could go either way)
+        mine = sorted((int(ids["point"][p.ms_pt[m]]), int(ids["mkf"][p.ms_mkf[m]]), int(p.ms_cam[m])) for m in range(M) if c[m] >= t2 and margin[m])
+        sure = {(int(ids["point"][p.ms_pt[m]]), int(ids["mkf"][p.ms_mkf[m]]), int(p.ms_cam[m])) for m in range(M) if not margin[m]}
+        assert sorted(t for t in r["outliers"] if t not in sure) == mine and len(mine) > 0
+    if len(free) < 3:
+        cov = np.linalg.inv(H_last)
+        c22 = np.sort(np.array([cov[n1 + 3*j + 2, n1 + 3*j + 2] for j in range(p.n_points)]))
+        assert abs(c22[p.n_points//2] - r["max_cov"]) <= 1e-5*r["max_cov"] and r["max_cov"] > 0
+    else:
+        assert r["max_cov"] == 0
