@@ -975,3 +975,47 @@ def test_lm_trajectory_against_an_independent_dense_numeric_lm(over, iters, user
         assert abs(c22[p.n_points//2] - r["max_cov"]) <= 1e-5*r["max_cov"] and r["max_cov"] > 0
     else:
         assert r["max_cov"] == 0
+
+
+@pytest.mark.parametrize("use_shi,use_percent", [(False, True), (True, True), (False, False), (True, False)])
+def test_keyframe_rest_candidates_against_numpy(use_shi, use_percent):
+    """KeyFrame::MakeKeyFrame_Rest, candidate part (src/KeyFrame.cc:363-450), on a first frame (no history, so no pruning):
+    fast_nonmax over the level's corners (a corner survives unless one of its 8 neighbours is a corner with a strictly
+    greater score), the 10-pixel border, the FAST or Shi-Tomasi score, then either the best `fraction` of them (descending
+    score, ties by descending (y, x)) or those above a threshold -- stated with a score image and a 3x3 maximum filter."""
+    import ctypes
+    from scipy import ndimage
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame, img_lib
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    k = OracleKeyFrame(320, 240)
+    k.MakeKeyFrame_Lite(sc["imgA"])
+    frac, thresh = 0.8, (35.0 if not use_shi else 40.0)
+    k.MakeKeyFrame_Rest(use_shi=use_shi, use_percent=use_percent, top_fraction=frac, thresh=thresh)
+    L = img_lib()
+    L.orc_shi_tomasi.restype = ctypes.c_double
+    total = 0
+    for l in range(4):
+        I = np.ascontiguousarray(k.Image(l))
+        h, w = I.shape
+        cor, b = k.Corners(l), k.FastThresh(l)
+        score = np.full((h, w), -1, dtype=np.int64)
+        for (x, y) in cor:
+            score[y, x] = L.orc_fast10_score(ctypes.c_void_p(I.ctypes.data + int(y)*w + int(x)), w, b)
+        assert np.all(score[cor[:, 1], cor[:, 0]] >= b)                # a detected corner passes at least its own threshold
+        neigh = ndimage.maximum_filter(score, size=3, mode="constant", cval=-1)
+        keep = [(int(x), int(y)) for (x, y) in cor if neigh[y, x] <= score[y, x]]          # raster order
+        keep = [(x, y) for (x, y) in keep if 10 <= x < w - 10 and 10 <= y < h - 10]
+        if use_shi:
+            val = [L.orc_shi_tomasi(ctypes.c_void_p(I.ctypes.data), w, 3, x, y) for (x, y) in keep]
+        else:
+            val = [float(score[y, x]) for (x, y) in keep]
+        if use_percent:
+            order = sorted(range(len(keep)), key=lambda i: (-val[i], -keep[i][1], -keep[i][0]))[:int(len(keep)*frac)]
+        else:
+            order = [i for i in range(len(keep)) if val[i] > thresh]
+        pos, got = k.Candidates(l)
+        assert [tuple(p) for p in pos] == [keep[i] for i in order]
+        assert np.array_equal(got, np.array([val[i] for i in order]))
+        total += len(order)
+    assert total > 30
