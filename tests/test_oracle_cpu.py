@@ -1086,3 +1086,52 @@ def test_subpixel_refinement_against_numpy():
             n_fail += 1
     assert n_conv > 60
     assert np.median(err_f) < 0.6*np.median(err_c), (np.median(err_f), np.median(err_c))
+
+
+def test_glare_and_internal_masks_against_scipy():
+    """KeyFrame::MakeKeyFrame_Lite's masking (src/KeyFrame.cc:214-243, 302-315): the glare mask is the level image dilated
+    five times with OpenCV's 5x5 elliptical element and thresholded at 245 (saturated neighbourhoods are masked out), ANDed
+    with the camera's internal mask; a corner survives only where the mask is 255.  The corner statistics (frequency table,
+    knee threshold) are taken before masking, so they must equal those of the unmasked run."""
+    from scipy import ndimage
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    img = sc["imgA"].copy()
+    rng = np.random.default_rng(5)
+    for _ in range(6):                                   # saturated blobs (lamps)
+        cx, cy, r = rng.integers(30, 290), rng.integers(30, 210), rng.integers(4, 14)
+        yy, xx = np.mgrid[0:240, 0:320]
+        img[(xx - cx)**2 + (yy - cy)**2 <= r*r] = 255
+    masks = []
+    for l in range(4):
+        h, w = 240 >> l, 320 >> l
+        m = np.full((h, w), 255, dtype=np.uint8)
+        m[:, : w//5] = 0                                 # the rig occludes the left fifth of the image
+        m[h//2:h//2 + 3, :] = 128                        # anything below 255 masks
+        masks.append(m)
+    plain = OracleKeyFrame(320, 240)
+    plain.MakeKeyFrame_Lite(img)
+    both = OracleKeyFrame(320, 240, glare=True)
+    both.MakeKeyFrame_Lite(img, masks)
+    glare_only = OracleKeyFrame(320, 240, glare=True)
+    glare_only.MakeKeyFrame_Lite(img)
+    EL = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], dtype=bool)
+    dropped = 0
+    for l in range(4):
+        I = plain.Image(l)
+        assert np.array_equal(both.Image(l), I)
+        d = I
+        for _ in range(5):
+            d = ndimage.grey_dilation(d, footprint=EL, mode="constant", cval=0)
+        g = np.where(d > 245, 0, 255).astype(np.uint8)
+        cor = plain.Corners(l)
+        for kf, m in ((glare_only, g), (both, masks[l] & g)):
+            assert kf.FastThresh(l) == plain.FastThresh(l) and np.array_equal(kf.FastFrequency(l), plain.FastFrequency(l))
+            want = cor[m[cor[:, 1], cor[:, 0]] == 255]
+            assert np.array_equal(kf.Corners(l), want)
+            got = kf.Corners(l)
+            assert np.array_equal(kf.RowLUT(l), np.searchsorted(got[:, 1], np.arange(I.shape[0]), side="left"))
+        dropped += len(cor) - len(both.Corners(l))
+        assert (g == 0).any() or l == 3
+    assert dropped > 20
