@@ -27,6 +27,17 @@ constexpr int CH_NB = 32;
 #ifndef MCP_CHOL_SIDE_DIAG
 #define MCP_CHOL_SIDE_DIAG 0
 #endif
+#if MCP_CHOL_SIDE_DIAG      // extra kernel parameters / arguments of the variant; nothing in the default build
+#define CH_DIAG_PARAMS(cv) , cv double* __restrict__ Dg /* [systems][block columns][32 x 32] factored diagonal tiles */, size_t diag_stride
+#define CH_DIAG_ARGS(plan) , plan.d_diag, plan.diag_stride
+#define CH_DIAG_OFFSET(b) Dg += (b)*diag_stride
+#define CH_BACK_DG , Dg, diag_stride
+#else
+#define CH_DIAG_PARAMS(cv)
+#define CH_DIAG_ARGS(plan)
+#define CH_DIAG_OFFSET(b) ((void)0)
+#define CH_BACK_DG
+#endif
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
 
 __device__ inline double readlane_f64(double v, int lane) {
@@ -151,9 +162,8 @@ __device__ unsigned long long g_chol_prof[256*2*8];
 #define CHOL_STAMP(i) do {} while (0)
 #endif
 __global__ void __launch_bounds__(CH_STEP_THREADS)
-k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride,
-            double* __restrict__ Dg /* [systems][block columns][32 x 32] factored diagonal tiles (MCP_CHOL_SIDE_DIAG) */, size_t diag_stride) {
-  if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; Dg += blockIdx.y*diag_stride; }     // further systems of a multi-lambda batch
+k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride CH_DIAG_PARAMS()) {
+  if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; CH_DIAG_OFFSET(blockIdx.y); }     // further systems of a multi-lambda batch
   // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
   const int packed = tiles[blockIdx.x];
   const int ti = packed >> 16, tj = packed & 0xffff;
@@ -254,7 +264,7 @@ constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
 // Tt = the tile below it, L[k0+32 .. ][k0 ..] (zero outside); coalesced row segments; load and LDS store are split so the
 // loads stay in flight during the update
 constexpr int CH_STAGE_PER = 5;                            // ceil(2*1024 / (CH_BACK_THREADS - 64))
-__device__ inline void chol_back_stage_load(const double* __restrict__ S, const double* __restrict__ Dg, int n, int nblk, int kb, int u, int nth, double* v) {
+__device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG_PARAMS(const), int n, int nblk, int kb, int u, int nth, double* v) {
   const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
   const int kb0 = k0 + CH_NB, nbb = (kb + 1 < nblk) ? min(CH_NB, n - kb0) : 0;
 #pragma unroll
@@ -293,9 +303,8 @@ __device__ unsigned long long g_back_prof[256*2*8];
 // two tiles of the NEXT step in LDS.  One barrier per step; the solver touches neither global memory nor the
 // bulk update of the step before.
 __global__ void __launch_bounds__(CH_BACK_THREADS)
-k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout, size_t sys_stride,
-            const double* __restrict__ Dg, size_t diag_stride) {
-  if (blockIdx.x) { S += blockIdx.x*sys_stride; xout += blockIdx.x*sys_stride; Dg += blockIdx.x*diag_stride; }
+k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_start, const int* __restrict__ row_tiles, double* __restrict__ xout, size_t sys_stride CH_DIAG_PARAMS(const)) {
+  if (blockIdx.x) { S += blockIdx.x*sys_stride; xout += blockIdx.x*sys_stride; CH_DIAG_OFFSET(blockIdx.x); }
   extern __shared__ __attribute__((aligned(16))) double xs[];
   const int t = threadIdx.x;
   const double* y = S + (size_t)n*n;
@@ -307,7 +316,7 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
   double xprev = 0.0;
   if (t >= 64) {
     double sv[CH_STAGE_PER];
-    chol_back_stage_load(S, Dg, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv);
+    chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv);
     chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(nblk - 1) & 1], Tt[(nblk - 1) & 1]);
   }
   __syncthreads();
@@ -338,7 +347,7 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
       BACK_STAMP(0, 1);
     } else {
       double sv[CH_STAGE_PER];
-      if (kb > 0) chol_back_stage_load(S, Dg, n, nblk, kb - 1, t - 64, CH_BACK_THREADS - 64, sv);      // in flight during the update
+      if (kb > 0) chol_back_stage_load(S CH_BACK_DG, n, nblk, kb - 1, t - 64, CH_BACK_THREADS - 64, sv);      // in flight during the update
       if (kb + 1 < nblk) {
       // x of block kb+1 (solved in the previous step) against the structurally non-zero tiles of block row kb+1 left of tile kb
       const int ub = kb + 1, u0 = ub*CH_NB, nbu = min(CH_NB, n - u0);
@@ -378,11 +387,16 @@ struct CholPlan {
   std::vector<int> step_start, step_tiles;     // per step k: tiles to process, block column k first
   std::vector<int> row_start, row_tiles;       // per block row: non-zero tile columns left of the diagonal
   int* d_step_tiles = nullptr; int* d_row_start = nullptr; int* d_row_tiles = nullptr;
-  double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles (MCP_CHOL_SIDE_DIAG)
+#if MCP_CHOL_SIDE_DIAG
+  double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
+#endif
   ~CholPlan() { release(); }
   void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
+#if MCP_CHOL_SIDE_DIAG
                    if (d_diag) (void)hipFree(d_diag);
-                   d_step_tiles = d_row_start = d_row_tiles = nullptr; d_diag = nullptr; }
+                   d_diag = nullptr;
+#endif
+                   d_step_tiles = d_row_start = d_row_tiles = nullptr; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
   int build(int n_, const std::vector<unsigned char>& pattern) {
     release();
@@ -433,7 +447,7 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
   const int n = plan.n, nrows = n + 1;
   for (int k = 0; k < plan.ntc; ++k) {
     const int cnt = plan.step_start[k + 1] - plan.step_start[k];
-    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride, plan.d_diag, plan.diag_stride);
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride CH_DIAG_ARGS(plan));
   }
 }
 // row n: y -> x = L^-T y
@@ -442,7 +456,7 @@ inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys 
   static bool attr_set = false;      // x (up to CH_SOLVE_MAX doubles) + the staged tiles can exceed the default 64 KB of LDS
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SOLVE_MAX*(int)sizeof(double)); attr_set = true; }
   hipLaunchKernelGGL(k_chol_back, dim3(nsys), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
-                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride, (const double*)plan.d_diag, plan.diag_stride);
+                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride CH_DIAG_ARGS(plan));
 }
 
 }  // namespace mcp
