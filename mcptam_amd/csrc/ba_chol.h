@@ -155,6 +155,96 @@ __device__ inline void chol_panel_pivots(double* d, double& inv, bool& bad, doub
   (chol_panel_pivot<Js>(d, inv, bad, mE, mO, colbuf), ...);
 }
 
+// ---- variant: the panel split over two wavefronts by column halves (-DMCP_CHOL_PANEL2=1, off until it has
+// been run on the hardware).  Both wavefronts hold the same 64 rows (diagonal tile + own tile); wavefront A owns columns
+// [0, 16), wavefront B columns [16, 32).  A factors pivots 0..15 exactly as above but only updates its own columns, and
+// publishes every finished column J (all 64 lanes) in slot J of an LDS ring, then raises `ready` to J + 1.  B applies the
+// rank-1 update of each published column to its 16 columns (own-row value x multiplier of the diagonal lane, both from the
+// ring) and then factors pivots 16..31 with the same pipelined code.  Every d[c] still receives its updates in column order.
+#ifndef MCP_CHOL_PANEL2
+#define MCP_CHOL_PANEL2 0
+#endif
+#if MCP_CHOL_PANEL2
+constexpr int CH_HALF = CH_NB/2;
+#define CH_SB() __builtin_amdgcn_sched_barrier(0)
+template <int K, int G, int CEND> struct ChBulk2 {        // group G (of 6) of the bulk update by column K: columns [lo, hi) below CEND
+  static constexpr int n = (CEND - K - 3 > 0) ? CEND - K - 3 : 0;
+  static constexpr int lo = K + 3 + (n*G)/6, hi = K + 3 + (n*(G + 1))/6;
+  template <int J0> static __device__ inline void fm(double* d, const double* m /* indexed from J0 */) {
+#pragma unroll
+    for (int c = lo; c < hi; ++c) d[c] -= d[K]*m[c - J0];
+  }
+};
+// pivot J of the column range [J0, CEND); `col` = where column J is published (64 doubles: a ring slot for A, one buffer for B)
+template <int J, int J0, int CEND, bool PUBLISH_ALL>
+__device__ inline void chol_panel2_pivot(double* d, double& inv, bool& bad, double* mE, double* mO, double* col, int ln, int* ready) {
+  double* cur = (J & 1) ? mO : mE;
+  double* prev = (J & 1) ? mE : mO;
+  d[J] *= inv;
+  if constexpr (PUBLISH_ALL || J + 3 < CEND) col[ln] = d[J];
+  if constexpr (PUBLISH_ALL) {
+    __asm__ volatile("" ::: "memory");        // DS operations of one wavefront execute in order: the column lands before the counter
+    __hip_atomic_store(ready, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  CH_SB();
+  if constexpr (J + 1 < CEND) {
+    const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
+    const double l1 = readlane_f64(d[J], J + 1);
+    double l2 = 0.0;
+    if constexpr (J + 2 < CEND) l2 = readlane_f64(d[J], J + 2);
+    const double pn = readlane_f64(w, J + 1);
+    bad |= !(pn > 0.0);
+    if constexpr (J + 3 < CEND) {
+#pragma unroll
+      for (int c = J + 3; c < CEND; ++c) cur[c - J0] = col[c];
+    }
+    CH_SB();
+    const double y0 = __builtin_amdgcn_rsq(pn);
+    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 0, CEND>::template fm<J0>(d, prev); CH_SB();
+    const double t = y0*(-pn);
+    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 1, CEND>::template fm<J0>(d, prev); CH_SB();
+    const double e = __builtin_fma(t, y0, 1.0);
+    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 2, CEND>::template fm<J0>(d, prev); CH_SB();
+    const double u = y0*e;
+    const double q = __builtin_fma(e, 0.375, 0.5);
+    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 3, CEND>::template fm<J0>(d, prev); CH_SB();
+    inv = __builtin_fma(u, q, y0);
+    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 4, CEND>::template fm<J0>(d, prev); CH_SB();
+    d[J + 1] -= d[J]*l1;
+    if constexpr (J > J0) ChBulk2<J - 1, 5, CEND>::template fm<J0>(d, prev);
+    CH_SB();
+    if constexpr (J + 2 < CEND) d[J + 2] -= d[J]*l2;
+    CH_SB();
+  }
+}
+#undef CH_SB
+template <int... Js>      // wavefront A: pivots 0 .. CH_HALF-1, ring slot J = ring + 64 J
+__device__ inline void chol_panel2_first(double* d, double& inv, bool& bad, double* ring, int ln, int* ready, std::integer_sequence<int, Js...>) {
+  double mE[CH_HALF], mO[CH_HALF];
+  (chol_panel2_pivot<Js, 0, CH_HALF, true>(d, inv, bad, mE, mO, ring + 64*Js, ln, ready), ...);
+}
+template <int... Js>      // wavefront B: pivots CH_HALF .. CH_NB-1 (Js = 0 .. CH_HALF-1 offsets)
+__device__ inline void chol_panel2_second(double* d, double& inv, bool& bad, double* colbuf, int ln, std::integer_sequence<int, Js...>) {
+  double mE[CH_HALF], mO[CH_HALF];
+  (chol_panel2_pivot<CH_HALF + Js, CH_HALF, CH_NB, false>(d, inv, bad, mE, mO, colbuf, ln, nullptr), ...);
+}
+template <int J>          // wavefront B: rank-1 update of columns [CH_HALF, CH_NB) by the published column J
+__device__ inline void chol_panel2_consume_one(double* d, const double* ring, int ln, int* ready) {
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= J) __builtin_amdgcn_s_sleep(1);
+  __asm__ volatile("" ::: "memory");
+  const double* col = ring + 64*J;
+  const double x = col[ln];
+#pragma unroll
+  for (int c = CH_HALF; c < CH_NB; ++c) d[c] -= x*col[c];
+#pragma unroll
+  for (int c = CH_HALF; c < CH_NB; ++c) __asm__ volatile("" : "+v"(d[c]));      // finish this column's update before waiting for the next
+}
+template <int... Js>
+__device__ inline void chol_panel2_consume(double* d, const double* ring, int ln, int* ready, std::integer_sequence<int, Js...>) {
+  (chol_panel2_consume_one<Js>(d, ring, ln, ready), ...);
+}
+#endif
+
 #ifdef MCP_CHOL_PROF
 __device__ unsigned long long g_chol_prof[256*2*8];
 #define CHOL_STAMP(i) do { if (blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) g_chol_prof[(k*2 + blockIdx.x)*8 + (i)] = clock64(); } while (0)
@@ -172,6 +262,10 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   __shared__ double Tc[CH_NB][CH_NB + 1];
   __shared__ double Td[CH_NB][CH_NB + 1];
   __shared__ double Te[CH_NB][CH_NB + 1];
+#if MCP_CHOL_PANEL2
+  __shared__ int panel_ready;                      // columns published by wavefront A of the panel (reset before the first barrier)
+  if (threadIdx.x == 0) panel_ready = 0;
+#endif
   const int lane = threadIdx.x;
   const int r0 = ti*CH_NB, c0 = tj*CH_NB, k0 = k*CH_NB, p0 = (k - 1)*CH_NB;
   const bool panel = (tj == k), offdiag = (ti != k);
@@ -210,6 +304,65 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     }
     return;
   }
+#if MCP_CHOL_PANEL2
+  if (lane >= 128) return;     // two wavefronts share the panel factorisation (no barrier below this line)
+  const int wv = __builtin_amdgcn_readfirstlane(lane >> 6), ln = lane & 63;      // wavefront-uniform: a scalar branch below
+  double (*Tdiag)[CH_NB + 1] = offdiag ? Td : Tc;
+  const int nbe = min(CH_NB, n - k0);
+  const int rr = ln & 31;
+  const bool low = ln >= 32;
+  double d[CH_NB];                     // only this wavefront's half is ever loaded, updated and stored
+  auto load_half = [&](auto c0_) {
+    constexpr int C0 = decltype(c0_)::value;
+    if (!low) {
+#pragma unroll
+      for (int c = C0; c < C0 + CH_HALF; ++c) d[c] = (c <= rr && rr < nbe && c < nbe) ? Tdiag[rr][c] : ((c == rr) ? 1.0 : 0.0);
+    } else {
+      const bool use = offdiag || rr >= nbe;
+#pragma unroll
+      for (int c = C0; c < C0 + CH_HALF; ++c) d[c] = (use && c < nbe) ? Tc[rr][c] : 0.0;
+    }
+  };
+  auto store_half = [&](auto c0_) {
+    constexpr int C0 = decltype(c0_)::value;
+    if (!low) {
+      if (!offdiag && ln < nbe) {
+#if MCP_CHOL_SIDE_DIAG
+        double* p = Dg + (size_t)k*(CH_NB*CH_NB) + ln*CH_NB;
+#else
+        double* p = S + (size_t)(k0 + ln)*n + k0;
+#endif
+#pragma unroll
+        for (int c = C0; c < C0 + CH_HALF; ++c) if (c <= ln) p[c] = d[c];
+      }
+    } else if (r0 + rr < nrows && (offdiag || rr >= nbe)) {
+      double* p = S + (size_t)(r0 + rr)*n + k0;
+#pragma unroll
+      for (int c = C0; c < C0 + CH_HALF; ++c) if (c < nbe) p[c] = d[c];
+    }
+  };
+  double* ring = &Ta[0][0];            // Ta is free now: CH_HALF slots of 64 doubles (1024 <= 32*33)
+  int* ready = &panel_ready;
+  bool bad = false;
+  if (wv == 0) {
+    load_half(std::integral_constant<int, 0>());
+    const double piv0 = readlane_f64(d[0], 0);
+    bad = !(piv0 > 0.0);
+    double inv = rsqrt(piv0);
+    chol_panel2_first(d, inv, bad, ring, ln, ready, std::make_integer_sequence<int, CH_HALF>());
+    CHOL_STAMP(3);
+    store_half(std::integral_constant<int, 0>());
+  } else {
+    load_half(std::integral_constant<int, CH_HALF>());
+    chol_panel2_consume(d, ring, ln, ready, std::make_integer_sequence<int, CH_HALF>());
+    const double pivh = readlane_f64(d[CH_HALF], CH_HALF);
+    bad = !(pivh > 0.0);
+    double inv = rsqrt(pivh);
+    chol_panel2_second(d, inv, bad, &Tb[0][0], ln, std::make_integer_sequence<int, CH_HALF>());      // Tb is free as well
+    store_half(std::integral_constant<int, CH_HALF>());
+  }
+  if (bad && ln == 0) atomicOr(fail, 2);
+#else
   if (lane >= 64) return;      // the panel factorisation is one wavefront's job (no barrier below this line)
   // ---- block column k: unblocked panel factorisation of [diagonal tile ; own tile], one row per lane.
   // lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the own tile (for the diagonal
@@ -249,6 +402,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) if (c < nbe) p[c] = d[c];
   }
+#endif
   CHOL_STAMP(4);
 }
 
