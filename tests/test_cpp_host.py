@@ -8,11 +8,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp):
+def _build(tmp, name="chain_bundle_smoke"):
     import __graft_entry__ as g
     g.build()
-    exe = os.path.join(str(tmp), "chain_bundle_smoke")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "chain_bundle_smoke.cpp"),
+    exe = os.path.join(str(tmp), name)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
                            "-L", os.path.join(ROOT, "mcptam_amd"), "-lmcptam_hip", "-Wl,-rpath," + os.path.join(ROOT, "mcptam_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
@@ -30,3 +30,12 @@ def test_cpp_mirror_solves_on_gpu(tmp_path, gpu_required):
     exe = _build(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cpp_keyframe_mirror_compiles_and_links(tmp_path):
+    """include/mcptam_hip/KeyFrame.hpp (KeyFrame / Level, SmallBlurryImage, Relocaliser scoring, MiniPatch and the tracker's
+    per-point entry points): every member is instantiated by tests/cpp/keyframe_link.cpp and must link against the C ABI."""
+    exe = _build(tmp_path, "keyframe_link")
+    out = subprocess.run([exe, "--link-only"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "linked" in out.stdout
