@@ -19,14 +19,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ROUND = "r02"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
 
+TRAFFIC_FILE = os.path.join("profiles", ROUND, "pmc_traffic_per_launch.json")
+
+
 def load_traffic():
-    """Per-kernel HBM traffic per launch from the committed PMC pass (scripts/gpu_final.sh + scripts/parse_traffic.py):
-    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is doubled on gfx950 as MI355X_MICROARCH.md prescribes."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_per_launch.json")
+    """Per-kernel HBM traffic per launch from THIS round's PMC pass (scripts/gpu_final.sh: two separate `rocprofv3 --pmc`
+    runs of this file, parsed by scripts/parse_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE is
+    doubled on gfx950 as MI355X_MICROARCH.md prescribes.  The file records the kernel set it was taken with; if a kernel
+    of the current build is missing from it (a stale file) the stage's traffic is reported as null, never guessed."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     if not os.path.exists(path):
         return {}
     raw = json.load(open(path))
@@ -34,8 +40,8 @@ def load_traffic():
 
 
 STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ; count -1 = number of 32-column Cholesky steps
-    "linearize": [("mcp::k_linearize_group", 1), ("__amd_rocclr_fillBufferAligned", 1)],
-    "schur": [("mcp::k_schur_init", 1), ("mcp::k_schur_group", 1)],
+    "linearize": [("mcp::k_linearize_group", 1)],
+    "schur": [("mcp::k_schur_group", 1), ("mcp::k_assemble", 1)],
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
     "select": [("mcp::k_select_pass", 2), ("mcp::k_select_gather", 1), ("mcp::k_select_small", 1)],
@@ -82,6 +88,35 @@ def stage_rooflines(tm, M, N, np_, n_lin, n_trials, n_solves):
                 break
             t += traffic[kname] * (steps if cnt < 0 else cnt)
         r["traffic"] = t if ok else None
+    return out
+
+
+def parity_against_oracle(problem, chain_bundle, device, gpu_logs, o, oids, n):
+    """Iteration log of the timed GPU run against the oracle's over the oracle's n iterations (trial counts, accept/reject,
+    chi2, lambda), and the state of a GPU run stopped after the same n iterations against the oracle's state."""
+    import numpy as np
+    olog = o.IterLogs()
+    m = min(n, len(gpu_logs), len(olog))
+    flips, dchi, dlam = 0, 0.0, 0.0
+    for g, r in zip(gpu_logs[:m], olog[:m]):
+        if g["trials"] != r["trials"] or g["accepted"] != r["accepted"]:
+            flips += 1
+            break
+        dchi = max(dchi, abs(g["chi2_start"] - r["chi2_start"]) / abs(r["chi2_start"]), abs(g["chi2_end"] - r["chi2_end"]) / abs(r["chi2_end"]))
+        dlam = max(dlam, abs(g["lambda_end"] - r["lambda_end"]) / abs(r["lambda_end"]))
+    b = chain_bundle.ChainBundle(problem.cams, True, True, False, disable_convergence=True, device=device)
+    ids = problem.populate(b)
+    b.Compute(n)
+    Rg, tg = b.GetPoses(ids["mkf"])
+    Xg = b.GetPoints(ids["point"])
+    b.close()
+    Ro = np.array([o.GetPose(int(i))[0] for i in oids["mkf"]])
+    to = np.array([o.GetPose(int(i))[1] for i in oids["mkf"]])
+    Xo = np.array([o.GetPoint(int(i)) for i in oids["point"]])
+    rel = lambda a, c: float(np.abs(a - c).max() / np.abs(c).max())
+    out = {"iterations_compared": m, "branch_flips": flips, "max_rel_chi2": dchi, "max_rel_lambda": dlam,
+           "state_rel_err": {"pose_R": rel(Rg, Ro), "pose_t": rel(tg, to), "points": rel(Xg, Xo)}, "tolerance": 1e-6}
+    out["ok"] = bool(flips == 0 and dchi < 1e-7 and dlam < 1e-6 and max(out["state_rel_err"].values()) < 1e-6)
     return out
 
 
@@ -142,14 +177,24 @@ def main():
             hook = RcclAllReduce(dev)
             transport = "rccl via torch.distributed hook"
 
+    setup_ms = {}
+
     def fresh(profile=False):
         b = chain_bundle.ChainBundle(problem.cams, True, True, False, disable_convergence=True, device=local_rank, profile=profile)
+        t0 = time.perf_counter()
         problem.populate(b)
+        t1 = time.perf_counter()
         if comm is not None:
             b.SetComm(comm)
         elif hook is not None:
             b.SetAllReduce(hook, rank, world)
         b.Prepare()          # structure + upload: the map is resident in HBM before the timed region
+        t2 = time.perf_counter()
+        # what a BundleAdjust() call pays once before its first LM iteration (the reference builds a fresh ChainBundle per
+        # call, BundleAdjusterMulti.cc:75): populate = the AddPose/AddPoint/AddMeas replay through the C ABI (batched
+        # entries, from Python here), prepare = symbolic structure on the host + upload over PCIe
+        setup_ms["populate_ms"] = (t1 - t0) * 1e3
+        setup_ms["prepare_ms"] = (t2 - t1) * 1e3
         return b
 
     def barrier():
@@ -190,7 +235,9 @@ def main():
             "config": {"workload": "%s: %d cams, %d MKF, %d points, %d measurements per rank" % (
                 args.config, len(problem.cams), problem.n_mkf, problem.n_points, problem.n_meas),
                 "trials_per_iteration": trials / args.steps, "trial_solves_per_s": world * trials / dt, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
-                "chi2_first": chi_first, "chi2_last": chi_last},
+                "chi2_first": chi_first, "chi2_last": chi_last,
+                "setup_outside_timed_region": dict(setup_ms, note="once per BundleAdjust call: C-ABI replay of the map (populate) and "
+                                                   "host structure build + PCIe upload (prepare); not part of `value`")},
         }
         if args.debug_single_device:
             result["config"]["debug"] = "all ranks share GPU 0, gloo transport: code-path check only, not a measurement"
@@ -208,24 +255,27 @@ def main():
             r = dict(dom[1])
             r["kernel"] = dom[0]
             result["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_ms")}
-            result["roofline"]["traffic_source"] = "profiles/r01/pmc_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = (2*FETCH + WRITE)*1024 per launch, summed over the launches of the stage)"
+            result["roofline"]["traffic_source"] = (TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command; bytes = (2*FETCH + WRITE)*1024 "
+                                                    "per launch, summed over the launches of the stage)") if r.get("traffic") is not None else "no PMC pass of this round's kernels in " + TRAFFIC_FILE
             result["config"]["reduced_system_solves"] = tm["n_solves"]
             result["config"]["trials_served_speculatively"] = tm["n_spec_hits"]
             result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic")} for k, v in roofs.items()}}
-    # CPU baseline: the oracle (a scalar single-thread port of the reference algorithm) on the same map
+    # CPU baseline: the oracle (a scalar single-thread port of the reference algorithm) on the same map; its iteration log
+    # doubles as the parity check of the GPU run that was just timed
     if rank == 0 and world == 1 and args.cpu_iters > 0:
         from oracle import OracleBundle
         o = OracleBundle(problem.cams, True, True, False)
         o.DisableConvergence(True)
-        problem.populate(o)
+        oids = problem.populate(o)
         o.Prepare()
         t0 = time.perf_counter()
         rc = o.Compute(args.cpu_iters)
         cdt = time.perf_counter() - t0
         result["cpu_baseline"] = {"value": rc / cdt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
-                                  "sample": "%d LM iterations of the same %d-measurement map (oracle/ba_oracle.c, gcc -O2, 1 thread; "
-                                            "the reference's g2o+CHOLMOD stack cannot be built here)" % (rc, problem.n_meas),
+                                  "sample": "%d LM iterations of the same %d-measurement map (oracle/ba_oracle.c: Schur + dense Cholesky, "
+                                            "1 thread; the reference's g2o+CHOLMOD stack cannot be built here)" % (rc, problem.n_meas),
                                   "host_cores_available": os.cpu_count()}
+        result["parity_at_metric"] = parity_against_oracle(problem, chain_bundle, local_rank, logs, o, oids, rc)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -120,8 +120,11 @@ int mcp_ba_add_measurements(mcp_ba*, int count, const int* chains, int stride,
                             const double* sigma_sq, const int* cam_index);
 
 /* int ChainBundle::Compute(bool* pAbortSignal, int nNumIter, double dUserLambda) :1305-1451
- * n_iter <= 0 selects params.max_iterations.  Return value as the reference: number of
- * outer iterations run (>0), 0 = aborted before any step, -1 = failure. */
+ * n_iter < 0 selects params.max_iterations; n_iter == 0 runs no iteration (g2o optimize(0)), which the reference
+ * reports as -1 unless the abort flag is up.  Return value as the reference: number of outer iterations run (>0),
+ * 0 = aborted before any step, -1 = no iteration could be run (:1355-1366).  MCP_BA_ERR_RUNTIME (-2) is NOT a
+ * reference outcome: a HIP / RCCL call failed (mcp_last_error() says which), the state was not written back. */
+#define MCP_BA_ERR_RUNTIME (-2)
 int mcp_ba_compute(mcp_ba*, volatile unsigned char* abort_flag, int n_iter, double user_lambda);
 
 int    mcp_ba_converged(mcp_ba*);                 /* Converged()          ChainBundle.h:146 */
@@ -181,6 +184,14 @@ int mcp_ba_debug_solve(mcp_ba*, double lambda, double* x_out);
 /* dense SPD solve A x = b (row-major n x n, lower triangle read) with the reduced-system
  * Cholesky kernels; returns -1 if A is not positive definite.  n <= 6144. */
 int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x);
+/* reproducibility check of the factorisation kernels: solves (A + q I) x_q = b for q = 0..nsys-1 (nsys <= 4) in one
+ * batched launch chain, `reps` times from the same device-resident input; x (nsys*n) receives the first repetition's
+ * solutions and *n_mismatch the number of later repetitions whose solutions differ from it in any bit. */
+int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int reps, double* x, int* n_mismatch);
+/* the reduced pose system the solver would factor at the current state for `lambda`: S (np*np, row-major, lower
+ * triangle meaningful inside the tiles of the factorisation plan, other entries 0), rhs (np) and J^T r (np) behind it;
+ * np = 6 * free poses.  Returns np (buffers may be NULL to query it), < 0 on error. */
+int mcp_ba_debug_system(mcp_ba*, double lambda, double* S_rhs_b_out);
 
 #ifdef __cplusplus
 }

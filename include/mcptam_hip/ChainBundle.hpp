@@ -50,7 +50,9 @@ class ChainBundle {
   /// returns the number of outer iterations run (>0), 0 = aborted before any step, -1 = failure
   int Compute(bool* pAbortSignal, int nNumIter = snMaxIterations, double dUserLambda = -1) {
     static_assert(sizeof(bool) == 1, "the abort flag is shared as one byte");
-    return mcp_ba_compute(mpHandle, reinterpret_cast<volatile unsigned char*>(pAbortSignal), nNumIter, dUserLambda);
+    const int rc = mcp_ba_compute(mpHandle, reinterpret_cast<volatile unsigned char*>(pAbortSignal), nNumIter, dUserLambda);
+    if (rc == MCP_BA_ERR_RUNTIME) throw std::runtime_error(mcp_last_error());      // device failure, not a BA outcome
+    return rc;
   }
   bool Converged() { return mcp_ba_converged(mpHandle) != 0; }
   int TotalIterations() { return mcp_ba_total_iterations(mpHandle); }

@@ -52,6 +52,7 @@ BA_SYMBOLS = [
     "mcp_ba_num_outliers", "mcp_ba_get_outliers", "mcp_ba_sigma_squared", "mcp_ba_mean_chi_squared", "mcp_ba_max_cov",
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
+    "mcp_dense_spd_stress", "mcp_ba_debug_system",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce",
 ]
 
@@ -92,6 +93,8 @@ def lib():
     L.mcp_ba_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.mcp_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_dense_spd_solve.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p]
+    L.mcp_dense_spd_stress.argtypes = [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_int)]
+    L.mcp_ba_debug_system.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_comm_unique_id.argtypes = [ctypes.c_void_p]
     L.mcp_comm_init.restype = ctypes.c_void_p
     L.mcp_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -157,6 +160,18 @@ def dense_spd_solve(A, b):
     if lib().mcp_dense_spd_solve(_dp(A), A.shape[0], _dp(b), _dp(x)) != 0:
         raise RuntimeError("mcp_dense_spd_solve failed: " + last_error())
     return x
+
+
+def dense_spd_stress(A, b, nsys=1, reps=10):
+    """(A + q I) x_q = b for q < nsys, `reps` times from the same device-resident input (test hook).
+    Returns (x of the first repetition as (nsys, n), number of repetitions that differed from it in any bit)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros((nsys, A.shape[0]))
+    bad = ctypes.c_int(0)
+    if lib().mcp_dense_spd_stress(_dp(A), A.shape[0], _dp(b), int(nsys), int(reps), _dp(x), ctypes.byref(bad)) != 0:
+        raise RuntimeError("mcp_dense_spd_stress failed: " + last_error())
+    return x, bad.value
 
 
 class ChainBundle:
@@ -230,10 +245,23 @@ class ChainBundle:
         self._check(self._L.mcp_ba_add_measurements(self._h, uv.shape[0], _ip(chains), chains.shape[1], _ip(chain_len),
                                                     _ip(point_ids), _dp(uv), _dp(sigma_sq), _ip(cam_index)), "AddMeasBatch")
 
+    def DebugSystem(self, lam):
+        """(S, rhs, J^T r) of the reduced pose system at the current state (test hook, mcp_ba_debug_system)."""
+        n = self._L.mcp_ba_debug_system(self._h, float(lam), None)
+        if n < 0:
+            raise RuntimeError("mcp_ba_debug_system: " + last_error())
+        out = np.zeros(n * n + 2 * n)
+        if self._L.mcp_ba_debug_system(self._h, float(lam), _dp(out)) < 0:
+            raise RuntimeError("mcp_ba_debug_system: " + last_error())
+        return out[:n * n].reshape(n, n), out[n * n:n * n + n], out[n * n + n:]
+
     def Compute(self, n_iter=None, user_lambda=-1.0):
         """int Compute(bool* pAbortSignal, int nNumIter, double dUserLambda); the abort flag is self.abort."""
         n = self.snMaxIterations if n_iter is None else int(n_iter)
-        return self._L.mcp_ba_compute(self._h, ctypes.byref(self.abort), n, float(user_lambda))
+        rc = self._L.mcp_ba_compute(self._h, ctypes.byref(self.abort), n, float(user_lambda))
+        if rc == -2:        # MCP_BA_ERR_RUNTIME: a HIP / RCCL call failed -- not one of the reference's outcomes
+            raise RuntimeError("mcp_ba_compute: " + last_error())
+        return rc
 
     def Converged(self):
         return bool(self._L.mcp_ba_converged(self._h))

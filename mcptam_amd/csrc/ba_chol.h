@@ -21,23 +21,13 @@
 namespace mcp {
 
 constexpr int CH_NB = 32;
-// 1: the diagonal workgroup of launch k writes L_kk to a side array of diagonal tiles (read by k_chol_back) instead of over
-// tile (k,k), which the other workgroups of block column k load in the same launch.  Off until it has been
-// run on the hardware.
-#ifndef MCP_CHOL_SIDE_DIAG
-#define MCP_CHOL_SIDE_DIAG 0
-#endif
-#if MCP_CHOL_SIDE_DIAG      // extra kernel parameters / arguments of the variant; nothing in the default build
+// The diagonal workgroup of launch k writes L_kk to a side array of diagonal tiles (Dg, read by k_chol_back) instead of over
+// tile (k,k): the other workgroups of block column k load tile (k,k) in the same launch, and nothing orders a store
+// against those loads inside a launch.  Tile (k,k) of S therefore stays untouched (pre-factorisation values) for good.
 #define CH_DIAG_PARAMS(cv) , cv double* __restrict__ Dg /* [systems][block columns][32 x 32] factored diagonal tiles */, size_t diag_stride
 #define CH_DIAG_ARGS(plan) , plan.d_diag, plan.diag_stride
 #define CH_DIAG_OFFSET(b) Dg += (b)*diag_stride
 #define CH_BACK_DG , Dg, diag_stride
-#else
-#define CH_DIAG_PARAMS(cv)
-#define CH_DIAG_ARGS(plan)
-#define CH_DIAG_OFFSET(b) ((void)0)
-#define CH_BACK_DG
-#endif
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
 
 __device__ inline double readlane_f64(double v, int lane) {
@@ -327,11 +317,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     constexpr int C0 = decltype(c0_)::value;
     if (!low) {
       if (!offdiag && ln < nbe) {
-#if MCP_CHOL_SIDE_DIAG
         double* p = Dg + (size_t)k*(CH_NB*CH_NB) + ln*CH_NB;
-#else
-        double* p = S + (size_t)(k0 + ln)*n + k0;
-#endif
 #pragma unroll
         for (int c = C0; c < C0 + CH_HALF; ++c) if (c <= ln) p[c] = d[c];
       }
@@ -389,11 +375,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   if (bad && lane == 0) atomicOr(fail, 2);
   if (!low) {
     if (!offdiag && lane < nbe) {
-#if MCP_CHOL_SIDE_DIAG
       double* p = Dg + (size_t)k*(CH_NB*CH_NB) + lane*CH_NB;
-#else
-      double* p = S + (size_t)(k0 + lane)*n + k0;
-#endif
 #pragma unroll
       for (int c = 0; c < CH_NB; ++c) if (c <= lane) p[c] = d[c];
     }
@@ -410,7 +392,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
 // Wavefront 0 solves the 32x32 triangle of the step (diagonal tile prefetched into registers during the previous step's
 // update); the other 7 wavefronts spread the update y[c] -= sum_r L[k0+r][c] x[k0+r] over (column pair, 16-row slice) items --
 // one L2 round trip of 16 independent 16-byte loads per item (n = 6P is even, so column pairs are aligned) instead of a
-// 32-long walk per column -- and combine the slices with ds_add_f64 on the LDS copy of y.
+// 32-long walk per column -- and combine the two slices of a column pair by a lane shuffle (fixed order, no atomics).
 constexpr int CH_BACK_THREADS = 512;
 constexpr int CH_BACK_RG = 2;            // row slices per column
 constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
@@ -427,11 +409,7 @@ __device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG
     const int which = e >> 10, r = (e >> 5) & 31, c = e & 31;
     v[i] = 0.0;
     if (e < 2048) {
-#if MCP_CHOL_SIDE_DIAG
       if (which == 0) v[i] = (r >= c && r < nbe && c < nbe) ? Dg[(size_t)kb*(CH_NB*CH_NB) + r*CH_NB + c] : ((r == c) ? 1.0 : 0.0);
-#else
-      if (which == 0) v[i] = (r >= c && r < nbe && c < nbe) ? S[(size_t)(k0 + r)*n + k0 + c] : ((r == c) ? 1.0 : 0.0);
-#endif
       else v[i] = (r < nbb && c < nbe) ? S[(size_t)(kb0 + r)*n + k0 + c] : 0.0;
     }
   }
@@ -453,7 +431,7 @@ __device__ unsigned long long g_back_prof[256*2*8];
 // block kb (tile column in registers, x broadcast with v_readlane), then solves the 32x32 triangle; at the same time
 // the other 7 wavefronts subtract the PREVIOUS block's contribution from all column blocks further left, over
 // (column pair, 16-row slice) items -- one L2 round trip of 16 independent 16-byte loads per item (n = 6P is even, so
-// column pairs are aligned) -- combining the slices with ds_add_f64 on the LDS copy of y; they first stage the solver's
+// column pairs are aligned) -- combining the two slices of a column pair by a lane shuffle; they first stage the solver's
 // two tiles of the NEXT step in LDS.  One barrier per step; the solver touches neither global memory nor the
 // bulk update of the step before.
 __global__ void __launch_bounds__(CH_BACK_THREADS)
@@ -513,7 +491,7 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
         const int tile = row_tiles[l0 + q/((CH_NB/2)*CH_BACK_RG)];
         if (tile == kb) continue;                           // the solver's tile
         const int rem = q % ((CH_NB/2)*CH_BACK_RG);
-        const int rg = rem/(CH_NB/2), c = tile*CH_NB + 2*(rem % (CH_NB/2));
+        const int rg = rem & (CH_BACK_RG - 1), c = tile*CH_NB + 2*(rem/CH_BACK_RG);     // the row slices of a column pair sit in neighbouring lanes
         const int r0 = rg*RPI;
         d2 v[RPI];
 #pragma unroll
@@ -521,8 +499,11 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int r = 0; r < RPI; ++r) { const double xr = (r0 + r < nbu) ? xs[u0 + r0 + r] : 0.0; a0 += v[r][0]*xr; a1 += v[r][1]*xr; }
-        unsafeAtomicAdd(&xs[c], -a0);
-        unsafeAtomicAdd(&xs[c + 1], -a1);
+        // fixed-order combination of the two slices (lanes 2i, 2i+1: same tile, same column pair; the loop bounds are even, so
+        // both are active together); one lane owns the column pair in this step -- no atomics, reproducible
+        static_assert(CH_BACK_RG == 2 && ((CH_BACK_THREADS - 64) % 2) == 0, "slice pairing");
+        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+        if (rg == 0) { xs[c] -= a0; xs[c + 1] -= a1; }
       }
       }
       if (kb > 0) chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(kb - 1) & 1], Tt[(kb - 1) & 1]);
@@ -540,16 +521,13 @@ struct CholPlan {
   int n = 0, ntc = 0, ntr = 0;
   std::vector<int> step_start, step_tiles;     // per step k: tiles to process, block column k first
   std::vector<int> row_start, row_tiles;       // per block row: non-zero tile columns left of the diagonal
+  std::vector<int> all_tiles;                  // every tile of the plan after fill-in, incl. the right-hand-side row (ti << 16 | tj)
   int* d_step_tiles = nullptr; int* d_row_start = nullptr; int* d_row_tiles = nullptr;
-#if MCP_CHOL_SIDE_DIAG
   double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
-#endif
   ~CholPlan() { release(); }
   void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
-#if MCP_CHOL_SIDE_DIAG
                    if (d_diag) (void)hipFree(d_diag);
                    d_diag = nullptr;
-#endif
                    d_step_tiles = d_row_start = d_row_tiles = nullptr; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
   int build(int n_, const std::vector<unsigned char>& pattern) {
@@ -565,6 +543,8 @@ struct CholPlan {
       for (int i = k + 1; i < ntr; ++i) if (P[(size_t)i*ntc + k]) rows.push_back(i);
       for (int a : rows) for (int b : rows) if (b <= a && b < ntc) P[(size_t)a*ntc + b] = 1;
     }
+    all_tiles.clear();
+    for (int i = 0; i < ntr; ++i) for (int j = 0; j < ntc && j <= i; ++j) if (P[(size_t)i*ntc + j]) all_tiles.push_back((i << 16) | j);
     step_start.assign(ntc + 1, 0); step_tiles.clear();
     for (int k = 0; k < ntc; ++k) {
       step_start[k] = (int)step_tiles.size();
@@ -585,10 +565,8 @@ struct CholPlan {
         hipMalloc((void**)&d_row_tiles, sizeof(int)*std::max<size_t>(row_tiles.size(), 1)) != hipSuccess) return -1;
     if (!step_tiles.empty() && hipMemcpy(d_step_tiles, step_tiles.data(), sizeof(int)*step_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (hipMemcpy(d_row_start, row_start.data(), sizeof(int)*row_start.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
-#if MCP_CHOL_SIDE_DIAG
     diag_stride = (size_t)std::max(ntc, 1)*CH_NB*CH_NB;
     if (hipMalloc((void**)&d_diag, sizeof(double)*diag_stride*max_sys) != hipSuccess) return -1;
-#endif
     if (!row_tiles.empty() && hipMemcpy(d_row_tiles, row_tiles.data(), sizeof(int)*row_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     return 0;
   }

@@ -11,6 +11,12 @@
 //                       and flushed once per group.
 //   k_schur_group     : S -= W V^-1 W^T as a dense zero-filled (96 x 3*16)(3*16 x 96) product
 //                       per 16-point chunk on the fp64 matrix cores (v_mfma_f64_16x16x4).
+//   k_assemble        : the reduced system, tile by tile, from the groups' staged blocks.
+//
+// Fixed-order accumulation (hard part 2): a group never adds into the global system.  It writes the
+// structurally non-zero 6x6 blocks of its local tile (which local pose pairs those are is known at Prepare()) to its own
+// slots of a staging array, and k_assemble builds every entry of S as the sum of its staged contributions in ascending
+// group order -- one writer per entry, no atomics, bit-identical from run to run.
 #pragma once
 #include "ba_kernels.h"
 
@@ -19,6 +25,24 @@ namespace mcp {
 // packed lower-triangular index of the local tile
 __device__ inline int tri(int r, int c) { return r*(r + 1)/2 + c; }
 constexpr int GRP_TRI = GRP_DOF*(GRP_DOF + 1)/2;     // 4656
+
+// Flush of a group's local tile (packed lower triangle in LDS) and local right-hand side to the group's staging slots:
+// block `slot` of the group is the 6x6 block (la, lb), la >= lb, of the local tile, row-major, rows = pose la (for
+// la == lb only the lower triangle is meaningful; the upper entries are written as zeros).  Consecutive threads write
+// consecutive doubles.  NT = threads of the workgroup.
+template <int NT>
+__device__ inline void flush_group_blocks(const double* Sl, const double* bl, int grp, const int* __restrict__ g_blk0,
+                                          const unsigned char* __restrict__ blk_pair, double* __restrict__ st_blocks,
+                                          double* __restrict__ st_rhs) {
+  const int b0 = g_blk0[grp], nb = g_blk0[grp + 1] - b0;
+  for (int e = threadIdx.x; e < nb*36; e += NT) {
+    const int slot = e/36, w = e - 36*slot;
+    const int pr = blk_pair[b0 + slot], la = pr >> 4, lb = pr & 15;
+    const int r = w/6, c = w - 6*r;
+    st_blocks[(size_t)(b0 + slot)*36 + w] = (la == lb && c > r) ? 0.0 : Sl[tri(6*la + r, 6*lb + c)];
+  }
+  for (int i = threadIdx.x; i < GRP_DOF; i += NT) st_rhs[(size_t)grp*GRP_DOF + i] = bl[i];
+}
 
 #if defined(LIN_ABL) && LIN_ABL == 1
 __device__ inline void lds_add(double* p, double v) { if (v == 1.2345e-300) unsafeAtomicAdd(p, v); }     // timing ablation only
@@ -57,8 +81,8 @@ __device__ unsigned long long g_lin_prof[8*8];
 __global__ void __launch_bounds__(64)
 k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
                   const double* __restrict__ second, const double* __restrict__ sigma,
-                  double* __restrict__ U, double* __restrict__ bp, double* __restrict__ V,
-                  double* __restrict__ g, double* __restrict__ W) {
+                  double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
+                  double* __restrict__ V, double* __restrict__ g, double* __restrict__ W) {
   __shared__ double Sl[GRP_TRI];
   __shared__ double bl[GRP_DOF];
   const int grp = blockIdx.x, lane = threadIdx.x;
@@ -262,27 +286,8 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   }
   __syncthreads();
   LIN_STAMP(5);
-  // flush the local tile: one global atomic per touched entry
-  const int* gp_ = P.g_pose + grp*GRP_LMAX;
-  const int np = P.np;
-  for (int i = lane; i < GRP_DOF; i += 64) {
-    const int u = gp_[i/6];
-    const double v = bl[i];
-    if (u >= 0 && v != 0.0) unsafeAtomicAdd(bp + 6*(size_t)u + i%6, v);
-  }
-  // packed lower triangle walked flat (73 trips instead of 128 row-wise ones for a single wavefront)
-  int nrow = 0;
-  for (int i = 0; i < GRP_LMAX; ++i) if (gp_[i] >= 0) nrow = 6*(i + 1);
-  const int nent = nrow*(nrow + 1)/2;
-  for (int e = lane; e < nent; e += 64) {
-    const double v = Sl[e];
-    if (v == 0.0) continue;
-    int r = (int)((sqrtf(8.f*(float)e + 1.f) - 1.f)*0.5f);
-    while (r*(r + 1)/2 > e) --r;
-    while ((r + 1)*(r + 2)/2 <= e) ++r;
-    const int c = e - r*(r + 1)/2;
-    unsafeAtomicAdd(U + (size_t)(6*gp_[r/6] + r%6)*np + 6*gp_[c/6] + c%6, v);
-  }
+  // flush the local tile to the group's staging slots (k_assemble sums them in group order)
+  flush_group_blocks<64>(Sl, bl, grp, P.g_blk0, P.blk_pair, stU, stb);
   LIN_STAMP(6);
 }
 
@@ -316,9 +321,9 @@ __device__ unsigned long long g_sch_prof[8*8];
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCH_WAVES, SCH_WAVES)))
 k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const double* __restrict__ g,
-              const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ S,
-              double* __restrict__ rhs, int* __restrict__ fail, SysBatch sb) {
-  if (blockIdx.y) { const int q = blockIdx.y; lambda = sb.lambda[q]; Vinv += q*sb.vstride; S += q*sb.sstride; rhs += q*sb.sstride; fail += q; }
+              const double* __restrict__ W, double* __restrict__ Vinv, double* __restrict__ stS /* staged blocks of W V^-1 W^T */,
+              double* __restrict__ str /* staged W V^-1 g */, int* __restrict__ fail, SysBatch sb) {
+  if (blockIdx.y) { const int q = blockIdx.y; lambda = sb.lambda[q]; Vinv += q*sb.vstride; stS += q*sb.ststride; str += q*sb.strstride; fail += q; }
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* Yd = lds;                            // [GRP_DOF][SCH_LD]   (SCH_Z: Z, the only staging array)
   double* Wd = lds + (SCH_Z ? 0 : GRP_DOF*SCH_LD);     // [GRP_DOF][SCH_LD]
@@ -479,14 +484,13 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     }
     SCH_LAP(6);
   }
-  // flush: S -= S_loc (lower triangle in global order), rhs -= r_loc
-  const int np = P.np;
-  if (t < 2*GRP_DOF) {
-    const int row = (t < GRP_DOF) ? t : t - GRP_DOF;
-    const int u = gp_[row/6];
-    if (u >= 0 && racc != 0.0) unsafeAtomicAdd(rhs + 6*(size_t)u + row%6, -racc);
-  }
+  // flush: the local product goes through LDS (the staging array is free now: packed lower triangle, 4656 <= 96 x 49
+  // doubles; the local rhs in the V^-1 scratch) to the group's staging slots; k_assemble subtracts it from the system
+  __syncthreads();
   {
+    double* Sl = lds;
+    double* rl = Vi;                              // [GRP_DOF] = SCH_CHUNK*6 doubles
+    static_assert(SCH_CHUNK*6 >= GRP_DOF && GRP_DOF*SCH_LD >= GRP_TRI, "flush scratch");
     const int col_l = lane & 15, rq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -499,18 +503,89 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int r = 16*tr + rq + 4*gq, c = 16*tc + col_l;
-          const double v = a[gq];
-          if (c <= r && r < 6*npl && v != 0.0) {
-            const int ur = gp_[r/6], uc = gp_[c/6];
-            unsafeAtomicAdd(S + (size_t)(6*ur + r%6)*np + 6*uc + c%6, -v);
-          }
+          if (c <= r) Sl[tri(r, c)] = a[gq];
         }
       }
     }
+    // rows of 16-row tiles that were not computed (beyond the group's poses) are never read by the flush
+    if (t < GRP_DOF) rl[t] = racc;
+    __syncthreads();
+    if (t >= GRP_DOF && t < 2*GRP_DOF) rl[t - GRP_DOF] += racc;      // fixed order: first half + second half
+    __syncthreads();
+    flush_group_blocks<256>(Sl, rl, grp, P.g_blk0, P.blk_pair, stS, str);
   }
   SCH_LAP(7);
   SCH_OUT();
 }
+// ------------------------------------------------------------------------------------------
+// Assembly of the reduced system from the staged group blocks.  One writer per entry:
+//   S_q(6a+r, 6b+c) = sum_g U_g - sum_g (W V^-1 W^T)_{g,q}  (+ lambda_q on the diagonal),   g ascending,
+//   rhs_q(6a+r)     = sum_g b_g - sum_g (W V^-1 g)_{g,q},
+// over the groups that stage a block for the pose pair (a, b) / the pose a.  Every entry of every tile of the
+// factorisation plan is written (structural zeros and fill-in tiles included), so S needs no clearing between solves.
+struct AsmPlan {
+  int nfp;                        // free poses
+  int ntiles;                     // tiles of the factorisation plan incl. the right-hand-side row (ti << 16 | tj)
+  const int* tiles;
+  const int* pair_id;             // [nfp*nfp] (a, b), a >= b  ->  pair index or -1
+  const int* pr_start;            // [npairs+1] CSR over pairs: staged block indices, ascending group
+  const int* pr_src;
+  const int* po_start;            // [nfp+1] CSR over poses: staged rhs slots (group*GRP_LMAX + local pose), ascending group
+  const int* po_src;
+};
+
+__global__ void __launch_bounds__(256)
+k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ stb,
+           const double* __restrict__ stS, const double* __restrict__ str,
+           const double* __restrict__ Ubig /* dense np x np + np contributions of the points outside the groups, or null */,
+           double* __restrict__ S, SysBatch sb) {
+  const int q = blockIdx.y;
+  S += q*sb.sstride; stS += q*sb.ststride; str += q*sb.strstride;
+  const double lam = sb.lambda_init[q];
+  const int packed = A.tiles[blockIdx.x];
+  const int ti = packed >> 16, tj = packed & 0xffff;
+  const size_t n2 = (size_t)np*np;
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int row = 32*ti + (e >> 5), col = 32*tj + (e & 31);
+    if (col >= np || row > np) continue;
+    if (row == np) {                       // right-hand side (row n of the augmented matrix) and, behind it, the plain J^T r
+      const int a = col/6, r = col - 6*a;
+      double b = 0.0, sr = 0.0;
+      for (int k = A.po_start[a]; k < A.po_start[a + 1]; ++k) { const size_t o = (size_t)A.po_src[k]*6 + r; b += stb[o]; sr += str[o]; }
+      if (Ubig) b += Ubig[n2 + col];
+      S[n2 + col] = b - sr;
+      S[n2 + np + col] = b;
+      continue;
+    }
+    double v = 0.0;
+    if (col <= row) {                      // (the upper part of a diagonal tile is never read: zero)
+      const int a = row/6, r = row - 6*a, b = col/6, c = col - 6*b;
+      const int pid = A.pair_id[(size_t)a*A.nfp + b];
+      double u = 0.0, w = 0.0;
+      if (pid >= 0) {
+        const int o = r*6 + c;
+        for (int k = A.pr_start[pid]; k < A.pr_start[pid + 1]; ++k) { const size_t off = (size_t)A.pr_src[k]*36 + o; u += stU[off]; w += stS[off]; }
+      }
+      v = u - w;
+      if (Ubig) v += Ubig[(size_t)row*np + col];
+      if (row == col) v += lam;
+    }
+    S[(size_t)row*np + col] = v;
+  }
+}
+
+// diagonal of the pose part of J^T J (for computeLambdaInit [g2o]): d[6a+r] = sum_g U_g(6a+r, 6a+r)
+__global__ void k_udiag(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ Ubig, double* __restrict__ d) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const int a = i/6, r = i - 6*a;
+  const int pid = A.pair_id[(size_t)a*A.nfp + a];
+  double u = 0.0;
+  if (pid >= 0) for (int k = A.pr_start[pid]; k < A.pr_start[pid + 1]; ++k) u += stU[(size_t)A.pr_src[k]*36 + 7*r];
+  if (Ubig) u += Ubig[(size_t)i*np + i];
+  d[i] = u;
+}
+
 constexpr size_t SCH_LDS_BYTES = (size_t)((SCH_Z ? 1 : 2)*GRP_DOF*SCH_LD + SCH_CHUNK*6 + SCH_K)*sizeof(double);
 
 }  // namespace mcp

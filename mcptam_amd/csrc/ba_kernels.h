@@ -59,6 +59,9 @@ struct DevProblem {
   const unsigned char* slot_first;// [nslot] 1: first contribution to its incidence (store), 0: accumulate
   const unsigned char* inc_lp;    // [ninc] local pose index of the incidence
   const unsigned char* inc_mixed; // [ninc] 1: block fed both from registers (first source link) and through memory
+  // staging of the groups' local tiles (ba_group.h): group g owns the 6x6 blocks [g_blk0[g], g_blk0[g+1])
+  const int* g_blk0;              // [ngroup+1]
+  const unsigned char* blk_pair;  // [nblk] local pose pair of the block, la << 4 | lb (la >= lb)
 };
 constexpr int GRP_LMAX = 16;      // poses per group (6*16 = 96 local dof)
 constexpr int GRP_PTS = 64;       // points per group (one lane each in k_linearize_group)
@@ -374,10 +377,6 @@ k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const d
 }
 
 // max |diag| of U and V  (computeLambdaInit [g2o])
-__global__ void k_extract_diag(int np, const double* __restrict__ U, double* __restrict__ d) {
-  const int i = blockIdx.x*blockDim.x + threadIdx.x;
-  if (i < np) d[i] = U[(size_t)i*np + i];
-}
 __global__ void __launch_bounds__(256)
 k_max_diag(int np, const double* __restrict__ U, int stride, int nfl, const double* __restrict__ V, double* out) {
   __shared__ double lds[4];
@@ -396,22 +395,8 @@ k_max_diag(int np, const double* __restrict__ U, int stride, int nfl, const doub
 // the reduced system take the batch index q from blockIdx.y; system q lives q*sstride doubles behind system 0 in the
 // [S | rhs | bp] buffer, its V^-1 blocks q*vstride doubles behind in Vinv, its failure flag in fail[q].
 constexpr int MAX_SYS = 4;
-struct SysBatch { double lambda[MAX_SYS]; double lambda_init[MAX_SYS]; size_t sstride; size_t vstride; };
-
-// S = U (+ lambda on the diagonal), rhs = bp.   Lower triangle only is meaningful.
-// blockIdx.y selects the system of a two-lambda batch (SysBatch, below).
-__global__ void k_schur_init(int np, double lambda, const double* __restrict__ U, const double* __restrict__ bp,
-                             double* __restrict__ S, double* __restrict__ rhs, SysBatch sb) {
-  if (blockIdx.y) { lambda = sb.lambda_init[blockIdx.y]; S += blockIdx.y*sb.sstride; rhs += blockIdx.y*sb.sstride; }
-  const size_t n2 = (size_t)np*np;
-  for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x*blockDim.x) {
-    const int r = (int)(i / np), c = (int)(i % np);
-    double v = U[i];
-    if (r == c) v += lambda;
-    S[i] = v;
-    if (c == 0) rhs[r] = bp[r];
-  }
-}
+struct SysBatch { double lambda[MAX_SYS]; double lambda_init[MAX_SYS]; size_t sstride; size_t vstride;
+                  size_t ststride, strstride; /* per-system strides of the staged Schur blocks / local right-hand sides */ };
 
 // gather (pack = 1) / scatter (pack = 0) of the structurally non-zero 32x32 tiles of the reduced system plus its
 // two trailing vectors [rhs | bp] (2*np doubles) to / from a contiguous buffer: the payload of the per-trial all-reduce.

@@ -18,6 +18,14 @@ constexpr int SEL_BLOCK = 256;
 
 struct SelState { unsigned long long prefix; unsigned long long k; };
 
+// Denominator of the small-sample factor 1 + 5/(2n - 6) of Huber/Tukey::FindSigmaSquared (include/mcptam/MEstimator.h:121,201).
+// The reference evaluates `vErrorSquared.size()*2 - 6` in size_t, so it wraps for n = 1, 2 (factor ~ 1) and is 0 for n = 3
+// (sigma = inf); reproduced here in 64-bit unsigned arithmetic.
+__host__ __device__ inline double mest_denom(double n) {
+  const unsigned long long u = (unsigned long long)n*2ull - 6ull;
+  return (double)u;
+}
+
 __host__ __device__ inline int sel_shift(int pass) { return pass < 5 ? 64 - SEL_BITS*(pass + 1) : 0; }
 __host__ __device__ inline int sel_nbits(int pass) { return pass < 5 ? SEL_BITS : 9; }
 
@@ -102,7 +110,7 @@ static __global__ void k_sigma_from_median(const double* __restrict__ med, doubl
                                     double* __restrict__ sig, double* __restrict__ sig_copy /* second destination or null */) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const double m = med[0];
-    double s = 1.4826*(1 + 5.0/(n_total*2 - 6))*sqrt(m);
+    double s = 1.4826*(1 + 5.0/mest_denom(n_total))*sqrt(m);
     s = 1.345*s;
     const double s2 = s*s;
     const double lim = (s2 < min_sigma_sq) ? min_sigma_sq : s2;
@@ -222,7 +230,7 @@ k_select_small(int n, const double* __restrict__ x, const unsigned int* __restri
     const double md = __longlong_as_double((long long)s_prefix);
     med_out[0] = md;
     if (sig) {
-      double s = 1.4826*(1 + 5.0/(n_total*2 - 6))*sqrt(md);
+      double s = 1.4826*(1 + 5.0/mest_denom(n_total))*sqrt(md);
       s = 1.345*s;
       const double s2 = s*s;
       const double lim = (s2 < min_sigma_sq) ? min_sigma_sq : s2;

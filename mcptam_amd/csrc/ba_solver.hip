@@ -31,8 +31,11 @@ static void set_err(const std::string& s) { g_err = s; }
 extern "C" const char* mcp_last_error(void) { return g_err.c_str(); }
 void mcp_set_error(const char* s) { g_err = s; }      // shared with img_api.hip
 
+// MCP_ERR_RUNTIME (-2): HIP / RCCL failure.  Kept apart from -1, which mcp_ba_compute also uses for the reference's
+// legitimate "no iteration ran" outcome (ChainBundle.cc:1355-1366); the wrappers raise on -2.
+constexpr int MCP_ERR_RUNTIME = -2;
 #define HIPCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-  set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
+  set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return MCP_ERR_RUNTIME; } } while (0)
 #define HIPCKV(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
   set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
 
@@ -118,8 +121,14 @@ struct mcp_ba {
   DevBuf<double> d_pose[2], d_pt[2], d_first[2], d_second[2], d_last[2], d_chi2[2];
   int cur = 0;
   // system
-  DevBuf<double> d_lin;     // [U (np*np) | bp (np)]
-  DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp copy (np)]   (the all-reduced block)
+  DevBuf<double> d_ubig;    // [U (np*np) | bp (np)] contributions of the points outside the groups (> GRP_LMAX poses); only if nbig
+  DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp = J^T r (np)]   (the all-reduced block)
+  // staged local tiles of the groups and the assembly plan (ba_group.h: fixed-order accumulation)
+  DevBuf<double> d_stU, d_stb, d_stS, d_str, d_udiag;
+  DevBuf<int> d_g_blk0, d_asm_tiles, d_pair_id, d_pr_start, d_pr_src, d_po_start, d_po_src;
+  DevBuf<unsigned char> d_blk_pair;
+  size_t nstage = 0;        // staged 6x6 blocks over all groups
+  AsmPlan A;
   DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
   DevBuf<double> d_selvals;     // candidates of the single-GPU selection (SEL_GATHER_CAP)
   DevBuf<double> d_seltab;      // multi-rank selection: [world x sel_cap candidates][overflow flag][world counts][gather counter]
@@ -160,8 +169,8 @@ struct mcp_ba {
     if (st) (void)hipStreamDestroy(st);
   }
 
-  double* U() { return d_lin.p; }
-  double* bp() { return d_lin.p + (size_t)np*np; }
+  double* Ubig() { return nbig ? d_ubig.p : nullptr; }
+  double* bp() { return rhs() + np; }            // J^T r of the current linearisation (written by k_assemble behind every system's rhs)
   // multi-lambda batch (ba_kernels.h SysBatch): systems 1.. are speculative solves for the next lambdas of the LM
   // schedule.  S()/rhs()/Vinv() address the system the latest trial used.
   size_t red_stride = 0, vinv_stride = 0, pack_stride = 0;
@@ -239,6 +248,7 @@ struct mcp_ba {
   int median_sigma(int which);
   int read_results(int count);
   int linearize();
+  int build_system(int nsys, SysBatch& sb);
   int solve_trial(double lam, bool& ok2, double ni = 0);
   int compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda);
   int final_stats(int nCounter);
@@ -438,7 +448,7 @@ int mcp_ba::prepare() {
       pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
     }
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
-  }
+  } else plan.all_tiles.clear();
   // local pose indices of slots and incidences
   std::vector<unsigned char> slot_lp(nslot + 1, 0), inc_lp(ninc + 1, 0);
   std::vector<unsigned char> inc_mixed(ninc + 1, 0);
@@ -451,6 +461,49 @@ int mcp_ba::prepare() {
       for (int s2 = slot_start[sp_m[sp]]; s2 < slot_start[sp_m[sp + 1]]; ++s2) slot_lp[s2] = local(slot_unk[s2]);
       for (int i2 = sp_i[sp]; i2 < sp_i[sp + 1]; ++i2) inc_lp[i2] = local(inc_unk[i2]);
     }
+  }
+
+  // ---- fixed-order assembly plan (ba_group.h): which local pose pairs every group stages, and for every global pose
+  // pair / pose the list of staged slots in ascending group order
+  std::vector<int> g_blk0(ngroup + 1, 0), pair_id((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1), pr_start, pr_src, po_start(nfp + 1, 0), po_src;
+  std::vector<unsigned char> blk_pair;
+  {
+    std::vector<std::array<int, 2>> blk_ab;                            // global pose pair (a >= b) of every staged block
+    auto ltri = [](int r, int c) { return r*(r + 1)/2 + c; };
+    for (int gi = 0; gi < ngroup; ++gi) {
+      const int* gp = &g_pose[(size_t)gi*GRP_LMAX];
+      unsigned char cov[GRP_LMAX*(GRP_LMAX + 1)/2] = {0};
+      for (int sp = g_sp0[gi]; sp < g_sp0[gi + 1]; ++sp) {
+        if (sp_big[sp]) continue;
+        int loc[GRP_LMAX]; int nl = 0;
+        for (int u : sp_poses[sp]) for (int k = 0; k < GRP_LMAX; ++k) if (gp[k] == u) { loc[nl++] = k; break; }
+        for (int x = 0; x < nl; ++x) for (int y = 0; y < nl; ++y) if (loc[x] >= loc[y]) cov[ltri(loc[x], loc[y])] = 1;
+      }
+      g_blk0[gi] = (int)blk_pair.size();
+      for (int la = 0; la < GRP_LMAX; ++la) for (int lb = 0; lb <= la; ++lb) if (cov[ltri(la, lb)]) {
+        blk_pair.push_back((unsigned char)((la << 4) | lb));
+        blk_ab.push_back({gp[la], gp[lb]});                            // g_pose is ascending: gp[la] >= gp[lb]
+      }
+      for (int k = 0; k < GRP_LMAX; ++k) if (gp[k] >= 0) po_start[gp[k] + 1]++;
+    }
+    g_blk0[ngroup] = (int)blk_pair.size();
+    nstage = blk_pair.size();
+    int npairs = 0;
+    std::vector<int> cnt_pair;
+    for (const auto& ab : blk_ab) {
+      int& id = pair_id[(size_t)ab[0]*nfp + ab[1]];
+      if (id < 0) { id = npairs++; cnt_pair.push_back(0); }
+      cnt_pair[id]++;
+    }
+    pr_start.assign(npairs + 1, 0);
+    for (int i = 0; i < npairs; ++i) pr_start[i + 1] = pr_start[i] + cnt_pair[i];
+    pr_src.assign(nstage, 0);
+    { std::vector<int> pos(pr_start.begin(), pr_start.end() - 1);
+      for (size_t k = 0; k < blk_ab.size(); ++k) pr_src[pos[pair_id[(size_t)blk_ab[k][0]*nfp + blk_ab[k][1]]]++] = (int)k; }     // blocks are numbered group by group
+    for (int a = 0; a < nfp; ++a) po_start[a + 1] += po_start[a];
+    po_src.assign(po_start[nfp], 0);
+    { std::vector<int> pos(po_start.begin(), po_start.end() - 1);
+      for (int gi = 0; gi < ngroup; ++gi) for (int k = 0; k < GRP_LMAX; ++k) { const int u = g_pose[(size_t)gi*GRP_LMAX + k]; if (u >= 0) po_src[pos[u]++] = gi*GRP_LMAX + k; } }
   }
 
   lap("pattern+plan");
@@ -469,7 +522,9 @@ int mcp_ba::prepare() {
       d_fl_point.upload(fl_point, st) || d_sp_pt.upload(sp_pt, st) || d_sp_m.upload(sp_m, st) || d_sp_i.upload(sp_i, st) ||
       d_sp_big.upload(sp_big, st) || d_m_sp.upload(m_sp, st) || d_l_sp.upload(l_sp, st) || d_g_sp0.upload(g_sp0, st) ||
       d_g_pose.upload(g_pose, st) || d_slot_lp.upload(slot_lp, st) || d_slot_first.upload(slot_first, st) ||
-      d_inc_lp.upload(inc_lp, st) || d_inc_mixed.upload(inc_mixed, st)) return -1;
+      d_inc_lp.upload(inc_lp, st) || d_inc_mixed.upload(inc_mixed, st) ||
+      d_g_blk0.upload(g_blk0, st) || d_blk_pair.upload(blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(pair_id, st) ||
+      d_pr_start.upload(pr_start, st) || d_pr_src.upload(pr_src, st) || d_po_start.upload(po_start, st) || d_po_src.upload(po_src, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < 2; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
@@ -482,7 +537,8 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (world > 1 && d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
-  if (d_lin.alloc(n2 + np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
+  if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)ngroup*GRP_DOF) || d_stS.alloc(MAX_SYS*nstage*36) ||
+      d_str.alloc(MAX_SYS*(size_t)ngroup*GRP_DOF) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
@@ -502,6 +558,11 @@ int mcp_ba::prepare() {
   P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
   P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
+  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p;
+  A.nfp = nfp; A.ntiles = (int)plan.all_tiles.size(); A.tiles = d_asm_tiles.p; A.pair_id = d_pair_id.p;
+  A.pr_start = d_pr_start.p; A.pr_src = d_pr_src.p; A.po_start = d_po_start.p; A.po_src = d_po_src.p;
+  // the staging arrays of a group that stages nothing for a slot are never read; slots are always fully written
+  // before k_assemble runs, so they need no clearing either
   HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
   lap("alloc+upload");
   if (upload_state()) return -1;
@@ -613,19 +674,19 @@ int mcp_ba::linearize() {
   spec_ok = false;                   // a speculative solve belongs to the linearisation it was built from
   tic(ST_LIN);
   const size_t n2 = (size_t)np*np;
-  HIPCK(hipMemsetAsync(d_lin.p, 0, (n2 + np)*sizeof(double), st));
-  if (nbig) {      // points that touch more than GRP_LMAX poses go through the generic atomic path
+  if (nbig) {      // points that touch more than GRP_LMAX poses go through the generic atomic path into their own dense block
+    HIPCK(hipMemsetAsync(d_ubig.p, 0, (n2 + np)*sizeof(double), st));
     if (nfl) {
       HIPCK(hipMemsetAsync(d_V.p, 0, (size_t)nfl*6*sizeof(double), st));
       HIPCK(hipMemsetAsync(d_g.p, 0, (size_t)nfl*3*sizeof(double), st));
     }
     if (ninc) HIPCK(hipMemsetAsync(d_W.p, 0, (size_t)ninc*18*sizeof(double), st));
-    hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
+    if (P.nmeas) hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
   }
   if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), 0, st, P,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, U(), bp(), d_V.p, d_g.p, d_W.p);
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
 #ifdef MCP_LIN_PROF
   {
     HIPCK(hipStreamSynchronize(st));
@@ -641,10 +702,44 @@ int mcp_ba::linearize() {
   return 0;
 }
 
+// The reduced system(s) of the current linearisation for the lambdas of `sb`: every rank contributes U_r - Schur_r
+// (+ lambda I once, on rank 0: sb.lambda_init), bp_r - W V^-1 g and bp_r; summed over the ranks when there are several.
+int mcp_ba::build_system(int nsys, SysBatch& sb) {
+  sb.sstride = red_stride; sb.vstride = vinv_stride; sb.ststride = nstage*36; sb.strstride = (size_t)ngroup*GRP_DOF;
+  HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+  tic(ST_SCHUR);
+  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, d_Vinv.p, d_stS.p, d_str.p, d_fail.p, sb);
+  else if (ngroup && nstage) {      // no free point: nothing is eliminated, the staged Schur blocks are zero
+    HIPCK(hipMemsetAsync(d_stS.p, 0, (size_t)nsys*nstage*36*sizeof(double), st));
+    HIPCK(hipMemsetAsync(d_str.p, 0, (size_t)nsys*ngroup*GRP_DOF*sizeof(double), st));
+  }
+  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
+                             (const double*)d_stS.p, (const double*)d_str.p, (const double*)Ubig(), d_red.p, sb);
+  if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, st, P, 1, sb.lambda[0], d_V.p, d_g.p, d_W.p, d_Vinv.p, d_red.p, d_red.p + (size_t)np*np, d_fail.p, sb);
+  toc();
+#ifdef MCP_SCH_PROF
+  {
+    HIPCK(hipStreamSynchronize(st));
+    unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sch_prof), sizeof pr);
+    double a[8] = {0}; int cnt = 0;
+    for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[7]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
+    if (cnt) fprintf(stderr, "[sch prof] prologue %.0f  inverse+barrier %.0f  scatter %.0f  prefetch+barrier %.0f  mfma %.0f  rhs %.0f  barrier+clear %.0f  flush %.0f  (cycles, %d groups)\n",
+                     a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, a[6]/cnt, a[7]/cnt, cnt);
+  }
+#endif
+  if (np && multi()) {
+    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
+    const size_t npack = pack_stride*nsys;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
+    if (allreduce(d_pack.p, npack)) return -1;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0, red_stride, pack_stride);
+  }
+  return 0;
+}
+
 // one LM trial up to and including the evaluation of the trial state.
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
-  const size_t n2 = (size_t)np*np;
   const int tr = cur ^ 1;
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
     // an earlier trial of this iteration already built and solved this system speculatively
@@ -655,39 +750,9 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     // the lambdas of the rejection branch of the LM schedule: lambda *= ni; ni *= 2 (same operations as compute())
     const int nsys = (ni > 0) ? 1 + std::max(0, std::min(speculate, MAX_SYS - 1)) : 1;
     SysBatch sb; std::memset(&sb, 0, sizeof sb);
-    sb.sstride = red_stride; sb.vstride = vinv_stride;
     { double l = lam, f = ni; for (int q = 0; q < nsys; ++q) { batch_lambda[q] = sb.lambda[q] = l; sb.lambda_init[q] = (rank == 0) ? l : 0.0; l *= f; f *= 2; } }
     batch_n = nsys;
-    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-    tic(ST_SCHUR);
-    if (np) {
-      // every rank contributes U_r - Schur_r (+ lambda I once, on rank 0), bp_r - W V^-1 g, and bp_r
-      const double lam_here = (rank == 0) ? lam : 0.0;
-      const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
-      hipLaunchKernelGGL(k_schur_init, dim3(g, nsys), dim3(256), 0, st, np, lam_here, U(), bp(), S(), rhs(), sb);
-      if (world > 1) for (int q = 0; q < nsys; ++q)
-        HIPCK(hipMemcpyAsync(rhs() + q*red_stride + np, bp(), np*sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
-    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, st, P, 1, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
-    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, lam, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
-    toc();
-#ifdef MCP_SCH_PROF
-    {
-      HIPCK(hipStreamSynchronize(st));
-      unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sch_prof), sizeof pr);
-      double a[8] = {0}; int cnt = 0;
-      for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[7]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
-      if (cnt) fprintf(stderr, "[sch prof] prologue %.0f  inverse+barrier %.0f  scatter %.0f  prefetch+barrier %.0f  mfma %.0f  rhs %.0f  barrier+clear %.0f  flush %.0f  (cycles, %d groups)\n",
-                       a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, a[6]/cnt, a[7]/cnt, cnt);
-    }
-#endif
-    if (np && multi()) {
-      // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
-      const size_t npack = pack_stride*nsys;
-      hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
-      if (allreduce(d_pack.p, npack)) return -1;
-      hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0, red_stride, pack_stride);
-    }
+    if (build_system(nsys, sb)) return -1;
     if (np) {
       if (use_graph && !prm.profile) {
         // the ~40 dependent launches of one factorisation + back-substitution replayed from a captured graph
@@ -712,7 +777,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     spec_ok = (nsys > 1);
     timing.n_solves++;
   }
-  const double* bp_glob = (world > 1) ? rhs() + np : bp();
+  const double* bp_glob = bp();
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
@@ -747,25 +812,27 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   HIPCK(hipSetDevice(device));
   std::memset(&timing, 0, sizeof timing);
   evs.clear(); ev_used = 0;
-  if (n_iter <= 0) n_iter = prm.max_iterations;
+  if (n_iter < 0) n_iter = prm.max_iterations;      // 0 runs nothing, as g2o optimize(0) (-> -1 unless externally aborted)
   auto terminate = [&]() { return abort_flag && *abort_flag; };
   // Initialize(), ChainBundle.cc:1284-1298
   outliers.clear(); logs.clear();
   int conv_mag = 0, conv_res = 0;
-  if (dirty) { if (prepare()) return -1; }
+  if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
   converged = 0; total_iterations = 0;
   int nCounter = 0;
-  if (nx == 0 || P.nmeas == 0) { nCounter = -1; if (P.nmeas) { launch_chains(cur); launch_eval(cur, false, nullptr); } }
+  // emptiness is decided on the GLOBAL totals: a rank whose shard holds no measurement (or no free point) still runs every
+  // kernel with zero-size inputs and joins every collective, or the other ranks would wait in them for ever
+  if (nx_total() == 0 || m_total == 0) { nCounter = -1; if (P.nmeas) { launch_chains(cur); launch_eval(cur, false, nullptr); } }
   else {
     tic(ST_EVAL); launch_chains(cur); launch_eval(cur, false, nullptr); toc();
     double ni = 2; bool ok = true; int cj = 0;
     for (int it = 0; it < n_iter && !terminate() && ok; ++it) {
       mcp_ba_iter_log lg; std::memset(&lg, 0, sizeof lg);
       // preIteration + first robustify: sigma^2 from |chi2| at the iteration-start state
-      if (robust) { if (median_sigma(cur)) return -1; }
+      if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
       const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-      hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+      if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
       // iteration-start robust chi2 and the sigma block go to d_res[24..28]; they are read back together with the first
       // trial's results (one host synchronisation less per iteration) -- except in the first iteration, whose lambda comes
       // from the diagonal of the freshly built system
@@ -774,17 +841,15 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       toc();
       // several ranks: the sum over the ranks rides on the first trial's all-reduce (d_res[0..3] + d_res[4], see solve_trial);
       // the first iteration needs it before its first trial
-      if (it == 0) { if (allreduce(d_res.p + RS, 1)) return -1; }
+      if (it == 0) { if (allreduce(d_res.p + RS, 1)) return MCP_ERR_RUNTIME; }
       start_rides = (it > 0 && world > 1);
-      if (linearize()) return -1;
+      if (linearize()) return MCP_ERR_RUNTIME;
       if (it == 0 && !(user_lambda > 0)) {
-        if (world > 1 && np) {     // the diagonal of U is a sum over ranks
-          hipLaunchKernelGGL(k_extract_diag, dim3((np + 255)/256), dim3(256), 0, st, np, (const double*)U(), d_xp_good.p);
-          if (allreduce(d_xp_good.p, np)) return -1;
-          hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_xp_good.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
-          HIPCK(hipMemsetAsync(d_xp_good.p, 0, np*sizeof(double), st));
-        } else
-          hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)U(), np + 1, nfl, (const double*)d_V.p, d_res.p + 5);
+        // computeLambdaInit [g2o]: 1e-5 * max |H_jj| over the pose and point diagonals; the pose diagonal is summed from
+        // the staged blocks (and over the ranks), the point diagonals are rank-local (maximum over ranks taken below)
+        if (np) hipLaunchKernelGGL(k_udiag, dim3((np + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
+        if (world > 1 && np) { if (allreduce(d_udiag.p, np)) return MCP_ERR_RUNTIME; }
+        hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_udiag.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }
       static_assert(RS + 1 == 25, "median_sigma() writes the sigma block to d_res + 25");
       double currentChi = 0, tempChi = 0;
@@ -795,7 +860,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
         start_pending = false;
       };
-      if (it == 0) { if (read_results(RS + 5)) return -1; take_start(); }
+      if (it == 0) { if (read_results(RS + 5)) return MCP_ERR_RUNTIME; take_start(); }
       if (it == 0) {
         if (user_lambda > 0) lambda = user_lambda;
         else {
@@ -803,7 +868,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           if (world > 1) {   // max over ranks of the V diagonals (U is already global)
             std::vector<double> slots(world, 0.0); slots[rank] = md;
             HIPCK(hipMemcpyAsync(d_res.p + 16, slots.data(), world*sizeof(double), hipMemcpyHostToDevice, st));
-            if (allreduce(d_res.p + 16, world, true)) return -1;
+            if (allreduce(d_res.p + 16, world, true)) return MCP_ERR_RUNTIME;
             HIPCK(hipMemcpy(slots.data(), d_res.p + 16, world*sizeof(double), hipMemcpyDeviceToHost));
             for (double v : slots) md = std::max(md, v);
           }
@@ -814,7 +879,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       double rho = 0; int qmax = 0; int accepted = 0; double ss_last = 0; double trial_chi_raw = currentChi;
       do {
         bool ok2 = true;
-        if (solve_trial(lambda, ok2, ni)) return -1;
+        if (solve_trial(lambda, ok2, ni)) return MCP_ERR_RUNTIME;
         if (start_pending) take_start();
         double scale, ss;
         trial_chi_raw = h_res[0];
@@ -829,7 +894,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           tempChi = DBL_MAX;
           scale = 0; ss = 0;
           std::vector<double> xp(np), xl((size_t)nfl*3), bpv(np), gv((size_t)nfl*3);
-          if (np) { HIPCK(hipMemcpy(xp.data(), d_xp_good.p, (size_t)np*8, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(bpv.data(), (world > 1) ? rhs() + np : bp(), (size_t)np*8, hipMemcpyDeviceToHost)); }
+          if (np) { HIPCK(hipMemcpy(xp.data(), d_xp_good.p, (size_t)np*8, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(bpv.data(), bp(), (size_t)np*8, hipMemcpyDeviceToHost)); }
           if (nfl) { HIPCK(hipMemcpy(xl.data(), d_xl_good.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(gv.data(), d_g.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); }
           for (int j = 0; j < np; ++j) { scale += xp[j]*(lambda*xp[j] + bpv[j]); ss += xp[j]*xp[j]; }
           double sl = 0, sq = 0;
@@ -837,7 +902,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           if (world > 1) {   // point parts are rank-local
             double v2[2] = { sl, sq };
             HIPCK(hipMemcpy(d_res.p + 16, v2, 16, hipMemcpyHostToDevice));
-            if (allreduce(d_res.p + 16, 2, true)) return -1;
+            if (allreduce(d_res.p + 16, 2, true)) return MCP_ERR_RUNTIME;
             HIPCK(hipMemcpy(v2, d_res.p + 16, 16, hipMemcpyDeviceToHost)); sl = v2[0]; sq = v2[1];
           }
           scale += sl; ss += sq;
@@ -881,14 +946,13 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     nCounter = cj;
   }
   int rc = final_stats(nCounter);
-  if (rc != -2) {
-    converged = (conv_mag || conv_res);
-    bool external_abort = terminate() && !converged;
-    if (nCounter == 0 && !external_abort) rc = -1;
-    else if (nCounter == 0 && terminate()) rc = 0;
-    else rc = nCounter;
-  } else rc = -1;
-  if (download_state()) return -1;
+  if (rc == MCP_ERR_RUNTIME) return rc;
+  converged = (conv_mag || conv_res);
+  bool external_abort = terminate() && !converged;
+  if (nCounter == 0 && !external_abort) rc = -1;
+  else if (nCounter == 0 && terminate()) rc = 0;
+  else rc = nCounter;
+  if (download_state()) return MCP_ERR_RUNTIME;
   // stage timings
   if (prm.profile) {
     (void)hipStreamSynchronize(st);
@@ -903,10 +967,10 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
 
 // ChainBundle.cc:1339-1345 (final sigma^2), :1368-1399 (Tukey outliers), :1401-1448 (depth covariance)
 int mcp_ba::final_stats(int nCounter) {
-  if (P.nmeas == 0 || dirty) { max_cov = 0; return 0; }
+  if (m_total == 0 || dirty) { max_cov = 0; return 0; }
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
   if (allreduce(d_res.p, 1)) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -916,12 +980,12 @@ int mcp_ba::final_stats(int nCounter) {
   const double median = h_res[12];
   if (nCounter == 0) return 0;
   if (tukey) {
-    double s = 1.4826*(1 + 5.0/(m_total*2 - 6))*std::sqrt(median);     // Tukey::FindSigmaSquared, MEstimator.h:109-124
+    double s = 1.4826*(1 + 5.0/mest_denom(m_total))*std::sqrt(median);     // Tukey::FindSigmaSquared, MEstimator.h:109-124
     s = 4.6851*s;
     double s2 = s*s;
     const double mins = prm.min_mestimator_sigma*prm.min_mestimator_sigma;
     if (s2 < mins) s2 = mins;
-    hipLaunchKernelGGL(k_tukey_flags, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, s2, d_flags.p);
+    if (P.nmeas) hipLaunchKernelGGL(k_tukey_flags, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, s2, d_flags.p);
     std::vector<unsigned char> fl(P.nmeas);
     HIPCK(hipMemcpyAsync(fl.data(), d_flags.p, P.nmeas, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
@@ -935,23 +999,21 @@ int mcp_ba::final_stats(int nCounter) {
     }
   }
   // depth covariance only when fewer than 3 free poses (:1419); Hessian of the last buildSystem, no lambda
-  if (nfp < 3 && nCounter > 0 && world == 1) {
+  if (nfp < 3 && nCounter > 0) {
+    // (several ranks: S is the all-reduced system, every rank inverts it, the point covariances are rank-local and their
+    // median is the global order statistic -- same collectives on every rank, nfp and nfl_total are global)
     bool okm = true;
     sys_cur = 0; spec_ok = false;
-    SysBatch sb; std::memset(&sb, 0, sizeof sb); sb.sstride = red_stride; sb.vstride = vinv_stride;
-    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    SysBatch sb; std::memset(&sb, 0, sizeof sb);
+    if (build_system(1, sb)) return -2;
     const size_t n2 = (size_t)np*np;
-    if (np) {
-      const int g = (int)std::min<size_t>(2048, (n2 + 255)/256);
-      hipLaunchKernelGGL(k_schur_init, dim3(g), dim3(256), 0, st, np, 0.0, U(), bp(), S(), rhs(), sb);
-    }
-    if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4), dim3(256), 0, st, P, 1, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
-    if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup), dim3(256), SCH_LDS_BYTES, st, P, 0.0, d_V.p, d_g.p, d_W.p, d_Vinv.p, S(), rhs(), d_fail.p, sb);
+    hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, 0, (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)d_fail.p);
+    if (allreduce(d_res.p + 3, 1)) return -2;
     std::vector<double> Sh(n2 + 1), Sinv(n2 + 1, 0.0);
     if (np) HIPCK(hipMemcpyAsync(Sh.data(), S(), n2*8, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(h_fail, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(h_res + 3, d_res.p + 3, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
-    if (h_fail[0]) okm = false;
+    if (h_res[3] != 0.0) okm = false;
     if (okm && np) {
       // <= 12x12 control-plane inverse on the host (lower triangle of S is valid)
       std::vector<double> L(n2, 0.0);
@@ -969,13 +1031,12 @@ int mcp_ba::final_stats(int nCounter) {
       }
     }
     if (okm) {
-      if (nfl > 0) {
+      if (nfl_total > 0) {
         DevBuf<double> dSinv;
         std::vector<double> tmp(Sinv.begin(), Sinv.begin() + std::max<size_t>(n2, 1));
         if (dSinv.upload(tmp, st)) return -2;
-        hipLaunchKernelGGL(k_point_cov22, dim3((nfl + 63)/64), dim3(64), 0, st, P, (const double*)d_Vinv.p, (const double*)d_W.p, (const double*)dSinv.p, d_cov.p);
-        const double m_keep = m_total; (void)m_keep;
-        if (select_kth(d_cov.p, nfl, (unsigned long long)(nfl/2), d_res.p + 8)) return -2;
+        if (nfl) hipLaunchKernelGGL(k_point_cov22, dim3((nfl + 63)/64), dim3(64), 0, st, P, (const double*)d_Vinv.p, (const double*)d_W.p, (const double*)dSinv.p, d_cov.p);
+        if (select_kth(d_cov.p, nfl, (unsigned long long)(nfl_total/2), d_res.p + 8)) return -2;
         HIPCK(hipMemcpyAsync(h_res, d_res.p + 8, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
         max_cov = h_res[0];
@@ -1188,6 +1249,68 @@ int mcp_ba_debug_solve(mcp_ba* h, double lambda, double* x_out) {
   if (!ok2) { set_err("mcp_ba_debug_solve: system not positive definite"); return -1; }
   if (h->np) HIPCK(hipMemcpy(x_out, h->rhs(), (size_t)h->np*8, hipMemcpyDeviceToHost));
   if (h->nfl) HIPCK(hipMemcpy(x_out + h->np, h->d_xl.p, (size_t)h->nfl*24, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mcp_ba_debug_system(mcp_ba* h, double lambda, double* out) {
+  if (h->dirty && h->prepare()) return -1;
+  if (!out) return h->np;
+  if (h->m_total == 0 || h->nx_total() == 0) { set_err("mcp_ba_debug_system: empty problem"); return -1; }
+  h->launch_chains(h->cur);
+  h->launch_eval(h->cur, false, nullptr);
+  if (h->robust && h->median_sigma(h->cur)) return -1;
+  if (h->linearize()) return -1;
+  h->sys_cur = 0; h->spec_ok = false;
+  SysBatch sb; std::memset(&sb, 0, sizeof sb);
+  sb.lambda[0] = lambda; sb.lambda_init[0] = (h->rank == 0) ? lambda : 0.0;
+  if (h->build_system(1, sb)) return -1;
+  const size_t n2 = (size_t)h->np*h->np;
+  // the entries outside the plan's tiles are never written by the assembly: report them as zeros
+  std::vector<double> full(n2 + 2*(size_t)h->np, 0.0), dev(n2 + 2*(size_t)h->np);
+  HIPCK(hipMemcpyAsync(dev.data(), h->d_red.p, dev.size()*8, hipMemcpyDeviceToHost, h->st));
+  HIPCK(hipStreamSynchronize(h->st));
+  for (int tpk : h->plan.all_tiles) {
+    const int ti = tpk >> 16, tj = tpk & 0xffff;
+    for (int r = 32*ti; r < std::min(32*ti + 32, h->np); ++r) for (int c = 32*tj; c < std::min(32*tj + 32, h->np); ++c) full[(size_t)r*h->np + c] = dev[(size_t)r*h->np + c];
+  }
+  for (int i = 0; i < 2*h->np; ++i) full[n2 + i] = dev[n2 + i];
+  std::memcpy(out, full.data(), full.size()*8);
+  return h->np;
+}
+
+// reproducibility of the factorisation + back-substitution chain (test hook): see mcp_ba.h
+int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int reps, double* x, int* n_mismatch) {
+  if (n <= 0 || n > CH_SOLVE_MAX || nsys < 1 || nsys > MAX_SYS || reps < 1) { set_err("mcp_dense_spd_stress: bad arguments"); return -1; }
+  const size_t stride = (size_t)n*n + n;
+  DevBuf<double> pristine, work; DevBuf<int> f;
+  if (pristine.alloc(stride*nsys) || work.alloc(stride*nsys) || f.alloc(4)) return -1;
+  {
+    std::vector<double> host(stride);
+    for (int q = 0; q < nsys; ++q) {
+      std::memcpy(host.data(), A, (size_t)n*n*8);
+      for (int i = 0; i < n; ++i) host[(size_t)i*n + i] += (double)q;
+      std::memcpy(host.data() + (size_t)n*n, b, (size_t)n*8);
+      HIPCK(hipMemcpy(pristine.p + q*stride, host.data(), stride*8, hipMemcpyHostToDevice));
+    }
+  }
+  CholPlan plan;
+  if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_dense_spd_stress: plan allocation failed"); return -1; }
+  std::vector<double> first((size_t)nsys*n), cur((size_t)nsys*n);
+  int bad = 0, fl[4] = {0, 0, 0, 0};
+  for (int rep = 0; rep < reps; ++rep) {
+    HIPCK(hipMemcpyAsync(work.p, pristine.p, stride*nsys*8, hipMemcpyDeviceToDevice, nullptr));
+    HIPCK(hipMemsetAsync(f.p, 0, 16, nullptr));
+    chol_factor(nullptr, plan, work.p, f.p, nsys, stride);
+    chol_back(nullptr, plan, work.p, nsys, stride);
+    std::vector<double>& dst = rep ? cur : first;
+    for (int q = 0; q < nsys; ++q) HIPCK(hipMemcpyAsync(dst.data() + (size_t)q*n, work.p + q*stride + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost, nullptr));
+    HIPCK(hipMemcpyAsync(fl, f.p, 16, hipMemcpyDeviceToHost, nullptr));
+    HIPCK(hipStreamSynchronize(nullptr));
+    for (int q = 0; q < nsys; ++q) if (fl[q]) { set_err("mcp_dense_spd_stress: matrix not positive definite"); return -1; }
+    if (rep && std::memcmp(first.data(), cur.data(), first.size()*8) != 0) ++bad;
+  }
+  std::memcpy(x, first.data(), first.size()*8);
+  if (n_mismatch) *n_mismatch = bad;
   return 0;
 }
 

@@ -592,7 +592,7 @@ k_pose_solve(int n, const uint8_t* __restrict__ found, const double* __restrict_
 __global__ void k_tukey_sigma(const double* __restrict__ med, double n, double override_sigma, double* __restrict__ sig) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     if (override_sigma > 0) sig[0] = override_sigma;
-    else { double s = 1.4826*(1 + 5.0/(n*2 - 6))*sqrt(med[0]); s = 4.6851*s; sig[0] = s*s; }
+    else { double s = 1.4826*(1 + 5.0/mest_denom((double)n))*sqrt(med[0]); s = 4.6851*s; sig[0] = s*s; }
   }
 }
 
@@ -854,7 +854,7 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
         __syncthreads();
       }
       const double med = __longlong_as_double((long long)sel_prefix);
-      double sg = 1.4826*(1 + 5.0/(nf*2 - 6))*sqrt(med);
+      double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
       sg = 4.6851*sg;
       s2 = sg*sg;
     }

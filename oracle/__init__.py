@@ -58,6 +58,7 @@ def lib():
         L.orc_ba_jacobian.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p, c_double_p]
         L.orc_ba_numeric_jacobian.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p, c_double_p]
         L.orc_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p, c_double_p]
+        L.orc_ba_debug_system.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
         L.orc_ba_debug_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p]
         L.orc_ba_debug_robust_chi2.restype = ctypes.c_double
         L.orc_cam_project.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, c_double_p]
@@ -197,6 +198,14 @@ class OracleBundle:
         xd = np.zeros(n)
         rc = self._L.orc_ba_debug_solve(self._h, float(lam), _dp(xs), _dp(xd))
         return rc, xs, xd
+
+    def DebugSystem(self, lam):
+        """(S, rhs, pose part of J^T r) of the reduced pose system at the current state."""
+        n = self._L.orc_ba_debug_system(self._h, float(lam), None)
+        out = np.zeros(n * n + 2 * n)
+        if self._L.orc_ba_debug_system(self._h, float(lam), _dp(out)) < 0:
+            raise RuntimeError("orc_ba_debug_system: a point block is not positive definite")
+        return out[:n * n].reshape(n, n), out[n * n:n * n + n], out[n * n + n:]
 
     def DebugRobustChi2(self):
         s = ctypes.c_double(0)

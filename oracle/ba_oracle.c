@@ -216,7 +216,7 @@ static int cmp_double(const void* a, const void* b) {
 double orc_huber_sigma_squared(double* v, int n) {
   qsort(v, n, sizeof(double), cmp_double);
   const double med = v[n/2];
-  double dSigma = 1.4826 * (1 + 5.0/(n*2 - 6)) * sqrt(med);
+  double dSigma = 1.4826 * (1 + 5.0/(double)((unsigned long long)n*2ull - 6ull)) * sqrt(med);
   dSigma = 1.345 * dSigma;
   return dSigma*dSigma;
 }
@@ -224,7 +224,7 @@ double orc_huber_sigma_squared(double* v, int n) {
 double orc_tukey_sigma_squared(double* v, int n) {
   qsort(v, n, sizeof(double), cmp_double);
   const double med = v[n/2];
-  double dSigma = 1.4826 * (1 + 5.0/(n*2 - 6)) * sqrt(med);
+  double dSigma = 1.4826 * (1 + 5.0/(double)((unsigned long long)n*2ull - 6ull)) * sqrt(med);
   dSigma = 4.6851 * dSigma;
   return dSigma*dSigma;
 }
@@ -694,18 +694,16 @@ static int inv3_spd(const double* A, double* I) {
 }
 
 /* (H + lambda I) x = b with the points eliminated first.  returns 0 ok, -1 = not SPD (ok2=false) */
-static int solve_system(orc_ba* h, double lambda, double* x) {
+/* points eliminated: S = Hpp + lambda I - sum W (V + lambda I)^-1 W^T, r = bp - sum W (V + lambda I)^-1 g  (Vinv: nfl x 9) */
+static int reduce_system(orc_ba* h, double lambda, double* S, double* r, double* Vinv) {
   const int np = h->np;
-  double* S = h->S; double* r = (double*)malloc(sizeof(double)*(np + 1));
   memcpy(S, h->Hpp, sizeof(double)*(size_t)np*np); memcpy(r, h->bp, sizeof(double)*np);
   for (int i = 0; i < np; i++) S[(size_t)i*np + i] += lambda;
-  double* Vinv = (double*)malloc(sizeof(double)*((size_t)h->nfl*9 + 1));
-  int fail = 0;
-  for (int l = 0; l < h->nfl && !fail; l++) {
+  for (int l = 0; l < h->nfl; l++) {
     const opoint* p = &h->points[h->fl_point[l]];
     double Vl[9]; memcpy(Vl, h->V + 9*(size_t)l, 72); Vl[0] += lambda; Vl[4] += lambda; Vl[8] += lambda;
     double* Vi = Vinv + 9*(size_t)l;
-    if (inv3_spd(Vl, Vi)) { fail = 1; break; }
+    if (inv3_spd(Vl, Vi)) return -1;
     const double* g = h->g + 3*(size_t)l;
     for (int a = 0; a < p->in; a++) {
       const double* Wa = h->W + 18*(size_t)(p->is + a); const int ua = h->inc_pose[p->is + a];
@@ -720,6 +718,13 @@ static int solve_system(orc_ba* h, double lambda, double* x) {
       }
     }
   }
+  return 0;
+}
+static int solve_system(orc_ba* h, double lambda, double* x) {
+  const int np = h->np;
+  double* S = h->S; double* r = (double*)malloc(sizeof(double)*(np + 1));
+  double* Vinv = (double*)malloc(sizeof(double)*((size_t)h->nfl*9 + 1));
+  int fail = reduce_system(h, lambda, S, r, Vinv) ? 1 : 0;
   if (!fail && np > 0 && chol_dense(S, np)) fail = 1;
   if (!fail) {
     if (np > 0) chol_solve(S, np, r);
@@ -769,6 +774,19 @@ int orc_ba_debug_solve(orc_ba* h, double lambda, double* x_schur, double* x_dens
   if (!rc) chol_solve(H, n, x_dense);
   free(H);
   return rc;
+}
+/* the reduced pose system at the current state: out = [S (np x np, full symmetric) | rhs (np) | J^T r of the poses (np)] */
+int orc_ba_debug_system(orc_ba* h, double lambda, double* out) {
+  if (!h->prepared) orc_ba_prepare(h);
+  const int np = h->np;
+  if (!out) return np;
+  compute_active_errors(h); h->need_recompute = 1; (void)active_robust_chi2(h);
+  build_system(h);
+  double* Vinv = (double*)malloc(sizeof(double)*((size_t)h->nfl*9 + 1));
+  const int rc = reduce_system(h, lambda, out, out + (size_t)np*np, Vinv);
+  free(Vinv);
+  memcpy(out + (size_t)np*np + np, h->bp, sizeof(double)*np);
+  return rc ? -1 : np;
 }
 double orc_ba_debug_robust_chi2(orc_ba* h, double* sigma_sq_raw) {
   if (!h->prepared) orc_ba_prepare(h);

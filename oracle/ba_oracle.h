@@ -102,6 +102,9 @@ int  orc_ba_numeric_jacobian(orc_ba*, int m, double delta, double* J_obs, double
  * points-first block elimination (what compute uses) and one dense Cholesky of the whole
  * un-marginalised system.  x arrays have orc_ba_prepare() entries.  returns 0 on success */
 int  orc_ba_debug_solve(orc_ba*, double lambda, double* x_schur, double* x_dense);
+/* reduced pose system at the current state: out = [S (np*np, symmetric) | rhs (np) | pose part of J^T r (np)]; returns np
+ * (out may be NULL to query it), -1 if a point block is not positive definite */
+int  orc_ba_debug_system(orc_ba*, double lambda, double* out);
 /* robust chi2 sum at current state with freshly recomputed sigma */
 double orc_ba_debug_robust_chi2(orc_ba*, double* sigma_sq_raw);
 
