@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/mcp_ba.h"
+#include "atan_cr.h"
 
 namespace mcp {
 
@@ -133,7 +134,7 @@ __host__ __device__ inline void cam_project(const mcp_camera& cam, const double*
   double theta, rho, cphi, sphi;
   if (n == 0.0) { theta = 1.57079632679489661923; rho = 0.0; cphi = 0.0; sphi = 0.0; }
   else {
-    theta = atan(xc[2]/n);
+    theta = mcp_atan::atan_cr(xc[2]/n);      // correctly rounded: the one platform-independent value (atan_cr.h)
     rho = poly_low_first(cam.inv_coeffs, cam.n_inv, (theta - cam.theta_mean)/cam.theta_std);
     cphi = xc[0]/n; sphi = xc[1]/n;
   }

@@ -26,22 +26,26 @@ namespace mcp {
 __device__ inline int tri(int r, int c) { return r*(r + 1)/2 + c; }
 constexpr int GRP_TRI = GRP_DOF*(GRP_DOF + 1)/2;     // 4656
 
-// Flush of a group's local tile (packed lower triangle in LDS) and local right-hand side to the group's staging slots:
-// block `slot` of the group is the 6x6 block (la, lb), la >= lb, of the local tile, row-major, rows = pose la (for
-// la == lb only the lower triangle is meaningful; the upper entries are written as zeros).  Consecutive threads write
-// consecutive doubles.  NT = threads of the workgroup.
+// Flush of a group's local tile (packed lower triangle in LDS) and local right-hand side to staging.  Block `slot` of the
+// group is the 6x6 block (la, lb), la >= lb, of the local tile, row-major, rows = pose la (for la == lb only the lower
+// triangle is meaningful; the upper entries are written as zeros).  It lands at staged block blk_dst[..]: the staging array
+// is ordered by DESTINATION (all contributions to one global pose pair are consecutive, ascending group), so that
+// k_assemble sums a contiguous run.  The local rhs of pose slot la lands at row rhs_dst[grp*GRP_LMAX + la] likewise.
+// Consecutive threads write consecutive doubles of a block.  NT = threads of the workgroup.
 template <int NT>
-__device__ inline void flush_group_blocks(const double* Sl, const double* bl, int grp, const int* __restrict__ g_blk0,
-                                          const unsigned char* __restrict__ blk_pair, double* __restrict__ st_blocks,
-                                          double* __restrict__ st_rhs) {
-  const int b0 = g_blk0[grp], nb = g_blk0[grp + 1] - b0;
+__device__ inline void flush_group_blocks(const double* Sl, const double* bl, int grp, const DevProblem& P,
+                                          double* __restrict__ st_blocks, double* __restrict__ st_rhs) {
+  const int b0 = P.g_blk0[grp], nb = P.g_blk0[grp + 1] - b0;
   for (int e = threadIdx.x; e < nb*36; e += NT) {
     const int slot = e/36, w = e - 36*slot;
-    const int pr = blk_pair[b0 + slot], la = pr >> 4, lb = pr & 15;
+    const int pr = P.blk_pair[b0 + slot], la = pr >> 4, lb = pr & 15;
     const int r = w/6, c = w - 6*r;
-    st_blocks[(size_t)(b0 + slot)*36 + w] = (la == lb && c > r) ? 0.0 : Sl[tri(6*la + r, 6*lb + c)];
+    st_blocks[(size_t)P.blk_dst[b0 + slot]*36 + w] = (la == lb && c > r) ? 0.0 : Sl[tri(6*la + r, 6*lb + c)];
   }
-  for (int i = threadIdx.x; i < GRP_DOF; i += NT) st_rhs[(size_t)grp*GRP_DOF + i] = bl[i];
+  for (int i = threadIdx.x; i < GRP_DOF; i += NT) {
+    const int d = P.rhs_dst[grp*GRP_LMAX + i/6];
+    if (d >= 0) st_rhs[(size_t)d*6 + i%6] = bl[i];
+  }
 }
 
 #if defined(LIN_ABL) && LIN_ABL == 1
@@ -287,7 +291,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   __syncthreads();
   LIN_STAMP(5);
   // flush the local tile to the group's staging slots (k_assemble sums them in group order)
-  flush_group_blocks<64>(Sl, bl, grp, P.g_blk0, P.blk_pair, stU, stb);
+  flush_group_blocks<64>(Sl, bl, grp, P, stU, stb);
   LIN_STAMP(6);
 }
 
@@ -512,7 +516,7 @@ k_schur_group(DevProblem P, double lambda, const double* __restrict__ V, const d
     __syncthreads();
     if (t >= GRP_DOF && t < 2*GRP_DOF) rl[t - GRP_DOF] += racc;      // fixed order: first half + second half
     __syncthreads();
-    flush_group_blocks<256>(Sl, rl, grp, P.g_blk0, P.blk_pair, stS, str);
+    flush_group_blocks<256>(Sl, rl, grp, P, stS, str);
   }
   SCH_LAP(7);
   SCH_OUT();
@@ -528,10 +532,8 @@ struct AsmPlan {
   int ntiles;                     // tiles of the factorisation plan incl. the right-hand-side row (ti << 16 | tj)
   const int* tiles;
   const int* pair_id;             // [nfp*nfp] (a, b), a >= b  ->  pair index or -1
-  const int* pr_start;            // [npairs+1] CSR over pairs: staged block indices, ascending group
-  const int* pr_src;
-  const int* po_start;            // [nfp+1] CSR over poses: staged rhs slots (group*GRP_LMAX + local pose), ascending group
-  const int* po_src;
+  const int* pr_start;            // [npairs+1] staged blocks of the pair: [pr_start[p], pr_start[p+1]), ascending group
+  const int* po_start;            // [nfp+1] staged rhs rows of the pose, ascending group
 };
 
 __global__ void __launch_bounds__(256)
@@ -551,7 +553,7 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
     if (row == np) {                       // right-hand side (row n of the augmented matrix) and, behind it, the plain J^T r
       const int a = col/6, r = col - 6*a;
       double b = 0.0, sr = 0.0;
-      for (int k = A.po_start[a]; k < A.po_start[a + 1]; ++k) { const size_t o = (size_t)A.po_src[k]*6 + r; b += stb[o]; sr += str[o]; }
+      for (int k = A.po_start[a]; k < A.po_start[a + 1]; ++k) { const size_t o = (size_t)k*6 + r; b += stb[o]; sr += str[o]; }
       if (Ubig) b += Ubig[n2 + col];
       S[n2 + col] = b - sr;
       S[n2 + np + col] = b;
@@ -563,8 +565,17 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
       const int pid = A.pair_id[(size_t)a*A.nfp + b];
       double u = 0.0, w = 0.0;
       if (pid >= 0) {
-        const int o = r*6 + c;
-        for (int k = A.pr_start[pid]; k < A.pr_start[pid + 1]; ++k) { const size_t off = (size_t)A.pr_src[k]*36 + o; u += stU[off]; w += stS[off]; }
+        const int k0 = A.pr_start[pid], k1 = A.pr_start[pid + 1];
+        const double* pu = stU + (size_t)k0*36 + r*6 + c;
+        const double* pw = stS + (size_t)k0*36 + r*6 + c;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4, pu += 144, pw += 144) {       // independent loads in flight, summed in list order
+          const double u0 = pu[0], u1 = pu[36], u2 = pu[72], u3 = pu[108];
+          const double w0 = pw[0], w1 = pw[36], w2 = pw[72], w3 = pw[108];
+          u += u0; u += u1; u += u2; u += u3;
+          w += w0; w += w1; w += w2; w += w3;
+        }
+        for (; k < k1; ++k, pu += 36, pw += 36) { u += pu[0]; w += pw[0]; }
       }
       v = u - w;
       if (Ubig) v += Ubig[(size_t)row*np + col];
@@ -581,7 +592,7 @@ __global__ void k_udiag(AsmPlan A, int np, const double* __restrict__ stU, const
   const int a = i/6, r = i - 6*a;
   const int pid = A.pair_id[(size_t)a*A.nfp + a];
   double u = 0.0;
-  if (pid >= 0) for (int k = A.pr_start[pid]; k < A.pr_start[pid + 1]; ++k) u += stU[(size_t)A.pr_src[k]*36 + 7*r];
+  if (pid >= 0) for (int k = A.pr_start[pid]; k < A.pr_start[pid + 1]; ++k) u += stU[(size_t)k*36 + 7*r];
   if (Ubig) u += Ubig[(size_t)i*np + i];
   d[i] = u;
 }

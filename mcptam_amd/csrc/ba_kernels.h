@@ -62,6 +62,8 @@ struct DevProblem {
   // staging of the groups' local tiles (ba_group.h): group g owns the 6x6 blocks [g_blk0[g], g_blk0[g+1])
   const int* g_blk0;              // [ngroup+1]
   const unsigned char* blk_pair;  // [nblk] local pose pair of the block, la << 4 | lb (la >= lb)
+  const int* blk_dst;             // [nblk] where the block is staged: position in the destination-ordered staging array
+  const int* rhs_dst;             // [ngroup*GRP_LMAX] staged rhs row of (group, local pose), or -1
 };
 constexpr int GRP_LMAX = 16;      // poses per group (6*16 = 96 local dof)
 constexpr int GRP_PTS = 64;       // points per group (one lane each in k_linearize_group)

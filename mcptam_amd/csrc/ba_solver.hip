@@ -125,9 +125,10 @@ struct mcp_ba {
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp = J^T r (np)]   (the all-reduced block)
   // staged local tiles of the groups and the assembly plan (ba_group.h: fixed-order accumulation)
   DevBuf<double> d_stU, d_stb, d_stS, d_str, d_udiag;
-  DevBuf<int> d_g_blk0, d_asm_tiles, d_pair_id, d_pr_start, d_pr_src, d_po_start, d_po_src;
+  DevBuf<int> d_g_blk0, d_asm_tiles, d_pair_id, d_pr_start, d_blk_dst, d_po_start, d_rhs_dst;
   DevBuf<unsigned char> d_blk_pair;
   size_t nstage = 0;        // staged 6x6 blocks over all groups
+  int nrhs_rows = 0;        // staged rhs rows (6 doubles each) over all groups
   AsmPlan A;
   DevBuf<double> d_V, d_g, d_W, d_Vinv, d_xl, d_xp_good, d_xl_good, d_err;
   DevBuf<double> d_selvals;     // candidates of the single-GPU selection (SEL_GATHER_CAP)
@@ -465,7 +466,8 @@ int mcp_ba::prepare() {
 
   // ---- fixed-order assembly plan (ba_group.h): which local pose pairs every group stages, and for every global pose
   // pair / pose the list of staged slots in ascending group order
-  std::vector<int> g_blk0(ngroup + 1, 0), pair_id((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1), pr_start, pr_src, po_start(nfp + 1, 0), po_src;
+  std::vector<int> g_blk0(ngroup + 1, 0), pair_id((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1), pr_start, blk_dst, po_start(nfp + 1, 0),
+                   rhs_dst((size_t)std::max(ngroup, 1)*GRP_LMAX, -1);
   std::vector<unsigned char> blk_pair;
   {
     std::vector<std::array<int, 2>> blk_ab;                            // global pose pair (a >= b) of every staged block
@@ -497,13 +499,15 @@ int mcp_ba::prepare() {
     }
     pr_start.assign(npairs + 1, 0);
     for (int i = 0; i < npairs; ++i) pr_start[i + 1] = pr_start[i] + cnt_pair[i];
-    pr_src.assign(nstage, 0);
+    // destination-ordered staging: the blocks of one pose pair are consecutive, in ascending group order (blocks are
+    // numbered group by group, so walking them in order fills every pair's run in that order)
+    blk_dst.assign(nstage, 0);
     { std::vector<int> pos(pr_start.begin(), pr_start.end() - 1);
-      for (size_t k = 0; k < blk_ab.size(); ++k) pr_src[pos[pair_id[(size_t)blk_ab[k][0]*nfp + blk_ab[k][1]]]++] = (int)k; }     // blocks are numbered group by group
+      for (size_t k = 0; k < blk_ab.size(); ++k) blk_dst[k] = pos[pair_id[(size_t)blk_ab[k][0]*nfp + blk_ab[k][1]]]++; }
     for (int a = 0; a < nfp; ++a) po_start[a + 1] += po_start[a];
-    po_src.assign(po_start[nfp], 0);
+    nrhs_rows = po_start[nfp];
     { std::vector<int> pos(po_start.begin(), po_start.end() - 1);
-      for (int gi = 0; gi < ngroup; ++gi) for (int k = 0; k < GRP_LMAX; ++k) { const int u = g_pose[(size_t)gi*GRP_LMAX + k]; if (u >= 0) po_src[pos[u]++] = gi*GRP_LMAX + k; } }
+      for (int gi = 0; gi < ngroup; ++gi) for (int k = 0; k < GRP_LMAX; ++k) { const int u = g_pose[(size_t)gi*GRP_LMAX + k]; if (u >= 0) rhs_dst[(size_t)gi*GRP_LMAX + k] = pos[u]++; } }
   }
 
   lap("pattern+plan");
@@ -524,7 +528,7 @@ int mcp_ba::prepare() {
       d_g_pose.upload(g_pose, st) || d_slot_lp.upload(slot_lp, st) || d_slot_first.upload(slot_first, st) ||
       d_inc_lp.upload(inc_lp, st) || d_inc_mixed.upload(inc_mixed, st) ||
       d_g_blk0.upload(g_blk0, st) || d_blk_pair.upload(blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(pair_id, st) ||
-      d_pr_start.upload(pr_start, st) || d_pr_src.upload(pr_src, st) || d_po_start.upload(po_start, st) || d_po_src.upload(po_src, st)) return -1;
+      d_pr_start.upload(pr_start, st) || d_blk_dst.upload(blk_dst, st) || d_po_start.upload(po_start, st) || d_rhs_dst.upload(rhs_dst, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < 2; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
@@ -537,8 +541,8 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (world > 1 && d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
-  if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)ngroup*GRP_DOF) || d_stS.alloc(MAX_SYS*nstage*36) ||
-      d_str.alloc(MAX_SYS*(size_t)ngroup*GRP_DOF) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
+  if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)nrhs_rows*6) || d_stS.alloc(MAX_SYS*nstage*36) ||
+      d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
@@ -558,9 +562,9 @@ int mcp_ba::prepare() {
   P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
   P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
-  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p;
+  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p; P.blk_dst = d_blk_dst.p; P.rhs_dst = d_rhs_dst.p;
   A.nfp = nfp; A.ntiles = (int)plan.all_tiles.size(); A.tiles = d_asm_tiles.p; A.pair_id = d_pair_id.p;
-  A.pr_start = d_pr_start.p; A.pr_src = d_pr_src.p; A.po_start = d_po_start.p; A.po_src = d_po_src.p;
+  A.pr_start = d_pr_start.p; A.po_start = d_po_start.p;
   // the staging arrays of a group that stages nothing for a slot are never read; slots are always fully written
   // before k_assemble runs, so they need no clearing either
   HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
@@ -705,13 +709,13 @@ int mcp_ba::linearize() {
 // The reduced system(s) of the current linearisation for the lambdas of `sb`: every rank contributes U_r - Schur_r
 // (+ lambda I once, on rank 0: sb.lambda_init), bp_r - W V^-1 g and bp_r; summed over the ranks when there are several.
 int mcp_ba::build_system(int nsys, SysBatch& sb) {
-  sb.sstride = red_stride; sb.vstride = vinv_stride; sb.ststride = nstage*36; sb.strstride = (size_t)ngroup*GRP_DOF;
+  sb.sstride = red_stride; sb.vstride = vinv_stride; sb.ststride = nstage*36; sb.strstride = (size_t)nrhs_rows*6;
   HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
   tic(ST_SCHUR);
   if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, d_Vinv.p, d_stS.p, d_str.p, d_fail.p, sb);
   else if (ngroup && nstage) {      // no free point: nothing is eliminated, the staged Schur blocks are zero
     HIPCK(hipMemsetAsync(d_stS.p, 0, (size_t)nsys*nstage*36*sizeof(double), st));
-    HIPCK(hipMemsetAsync(d_str.p, 0, (size_t)nsys*ngroup*GRP_DOF*sizeof(double), st));
+    HIPCK(hipMemsetAsync(d_str.p, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), st));
   }
   if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
                              (const double*)d_stS.p, (const double*)d_str.p, (const double*)Ubig(), d_red.p, sb);

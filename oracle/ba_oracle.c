@@ -160,6 +160,15 @@ static void gen_field(int i, const double* p, double* o) {
 }
 
 /* ------------------------------------------------------------------ camera */
+/* theta = atan(z / n), TaylorCamera.cc:243.  In the tracker the last ulp of this value decides template bytes (CVD::transform
+ * truncates), and libm implementations differ in it (glibc 2.35's atan is within 1 ulp but not correctly
+ * rounded: 0.07 % of arguments).  The oracle therefore takes the CORRECTLY ROUNDED arctangent -- the one platform-
+ * independent definition -- by evaluating atanq in binary128 (libquadmath) and rounding once; the device reaches the same
+ * double by a different route (double-double arithmetic, mcptam_amd/csrc/atan_cr.h).  tests/test_oracle_cpu.py pins it
+ * against libm (never more than 1 ulp apart). */
+#include <quadmath.h>
+double orc_atan(double x) { return (double)atanq((__float128)x); }
+
 /* TaylorCamera::PolyVal, TaylorCamera.cc:472-486 */
 static double polyval(const double* c, int n, double x) {
   double val = 0;
@@ -173,7 +182,7 @@ int orc_cam_project(const orc_camera* cam, const double xc[3], double uv[2], dou
   const double dNorm = sqrt(xc[0]*xc[0] + xc[1]*xc[1]);
   double dTheta, rho, cphi, sphi;
   if (dNorm == 0) dTheta = M_PI_2;                       /* :209-213 */
-  else dTheta = atan(xc[2]/dNorm);                        /* :216-217 */
+  else dTheta = orc_atan(xc[2]/dNorm);                        /* :216-217 */
   int invalid = (dTheta < cam->min_theta);                /* :223 */
   if (dNorm == 0) { rho = 0; cphi = 0; sphi = 0; }        /* :225-230 */
   else {

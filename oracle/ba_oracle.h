@@ -109,6 +109,7 @@ int  orc_ba_debug_system(orc_ba*, double lambda, double* out);
 double orc_ba_debug_robust_chi2(orc_ba*, double* sigma_sq_raw);
 
 /* camera primitives */
+double orc_atan(double x);      /* correctly rounded arctangent (binary128 atanq rounded once) */
 int  orc_cam_project(const orc_camera*, const double xc[3], double uv[2], double D[4]);
 void orc_cam_sphere_deriv(const double xc[3], double dtheta[3], double dphi[3]);
 /* TooN [3P-memory] */

@@ -154,24 +154,30 @@ def test_abort_flag_and_two_step(gpu_required):
     assert g.Compute(10) == 0                  # aborted before any step (ChainBundle.cc:1365-1366)
     g.abort.value = 0
     # two-step mode (BundleAdjusterMulti.cc:210-224): 10 iterations, then to convergence on the same object
-    g2, o2 = _gpu(p.cams), _orc(p.cams)
+    g2, g3, o2 = _gpu(p.cams), _gpu(p.cams), _orc(p.cams)
     ids = p.populate(g2)
+    p.populate(g3)
     p.populate(o2)
-    a, b = g2.Compute(10), o2.Compute(10)
-    assert a == b == 10
+    a, a3, b = g2.Compute(10), g3.Compute(10), o2.Compute(10)
+    assert a == a3 == b == 10
     if not g2.Converged():
-        g2.abort.value = 0
-        o2.abort.value = 0
-        a, b = g2.Compute(), o2.Compute()
-        # same number of iterations to convergence and the same trial / accept pattern all the way (the accumulation
-        # order on the device is fixed now, so this is a property of the arithmetic, not of a run)
-        assert a == b and a > 0
+        for h in (g2, g3, o2):
+            h.abort.value = 0
+        a, a3, b = g2.Compute(), g3.Compute(), o2.Compute()
+        assert a > 0 and b > 0
+        # two device runs are the same run: same stopping iteration, same log, bit for bit (fixed accumulation order)
+        assert a == a3 and g2.IterLogs() == g3.IterLogs()
+        # device vs oracle: the stopping test (0 <= dchi2/chi2 <= 1e-10, ChainBundle.cc:1101) compares numbers that agree
+        # to ~1e-13 relative between the two arithmetic orders, so at the flat end of the descent the two may stop
+        # some iterations apart (observed: 77 vs 70); they must agree while chi2 still moves and land on the same state
         lg, lo = g2.IterLogs(), o2.IterLogs()
-        assert [(x["trials"], x["accepted"]) for x in lg] == [(y["trials"], y["accepted"]) for y in lo]
-        for x, y in zip(lg, lo):
+        for x, y in zip(lg[:3], lo[:3]):
+            assert (x["trials"], x["accepted"]) == (y["trials"], y["accepted"])
             assert abs(x["chi2_start"] - y["chi2_start"]) <= 1e-9 * y["chi2_start"]
-        assert g2.Converged() == o2.Converged()
+        assert abs(lg[-1]["chi2_end"] - lo[-1]["chi2_end"]) <= 1e-9 * lo[-1]["chi2_end"]
     Rg, tg = g2.GetPoses(ids["mkf"])
+    R3, t3 = g3.GetPoses(ids["mkf"])
+    assert np.array_equal(Rg, R3) and np.array_equal(tg, t3)
     Ro = np.array([o2.GetPose(int(i))[0] for i in ids["mkf"]])
     assert rel_err(Rg, Ro) < 1e-6
 

@@ -1189,3 +1189,23 @@ def test_esm_alignment_recovers_a_known_image_shift():
         assert abs(np.degrees(np.arctan2(R[1, 0], R[0, 0]))) < 1.0
         _, _, s1 = oracle_sbi_iterate(B, A, 1)
         assert s < s1                                           # the iterations reduce the residual
+
+
+def test_sigma_small_sample_factor_wraps_like_size_t():
+    """MEstimator.h:121,201 evaluate 5/(2n - 6) with n a size_t: n = 1, 2 wrap (factor ~ 1), n = 3 divides by zero."""
+    import ctypes
+    import oracle
+    L = oracle.lib()
+    L.orc_huber_sigma_squared.restype = ctypes.c_double
+    L.orc_tukey_sigma_squared.restype = ctypes.c_double
+    for n in (1, 2):
+        v = (ctypes.c_double * n)(*([4.0] * n))
+        want = (1.345 * 1.4826 * (1 + 5.0 / float(2 ** 64 + 2 * n - 6)) * 2.0) ** 2
+        assert abs(L.orc_huber_sigma_squared(v, n) - want) <= 1e-15 * want
+        want_t = (4.6851 * 1.4826 * (1 + 5.0 / float(2 ** 64 + 2 * n - 6)) * 2.0) ** 2
+        assert abs(L.orc_tukey_sigma_squared(v, n) - want_t) <= 1e-15 * want_t
+    v = (ctypes.c_double * 3)(4.0, 4.0, 4.0)
+    assert L.orc_huber_sigma_squared(v, 3) == float("inf")
+    v = (ctypes.c_double * 10)(*range(1, 11))
+    want = (1.345 * 1.4826 * (1 + 5.0 / 14.0) * np.sqrt(6.0)) ** 2
+    assert abs(L.orc_huber_sigma_squared(v, 10) - want) <= 1e-14 * want
