@@ -24,8 +24,10 @@ class OrcIterLog(ctypes.Structure):
 
 
 def build(force=False):
+    if os.environ.get("ORC_LIB"):          # bench.py: the -O3 -march=native -fopenmp build made on the measuring box (`make native`)
+        return os.environ["ORC_LIB"]
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ba_oracle.c", "ba_oracle.h", "img_oracle.c", "img_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ba_oracle.c", "ba_oracle.h", "img_oracle.c", "img_oracle.h", "ba_baseline.inc", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -40,6 +42,8 @@ def lib():
         L.orc_ba_destroy.argtypes = [ctypes.c_void_p]
         L.orc_ba_set_limits.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.orc_ba_disable_convergence.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_ba_set_solver.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.orc_ba_threads.argtypes = [ctypes.c_void_p]
         L.orc_ba_add_pose.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int]
         L.orc_ba_add_point.argtypes = [ctypes.c_void_p, c_double_p, c_int_p, ctypes.c_int, ctypes.c_int]
         L.orc_ba_add_meas.argtypes = [ctypes.c_void_p, c_int_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_double, ctypes.c_int]
@@ -100,6 +104,12 @@ class OracleBundle:
 
     def SetLimits(self, max_trials=100, pct_limit=1e-10, rms_limit=1e-10, min_sigma=0.5):
         self._L.orc_ba_set_limits(self._h, max_trials, pct_limit, rms_limit, min_sigma)
+
+    def SetSolver(self, solver, threads=1):
+        """CPU-baseline variants (oracle/ba_baseline.inc): 0 = the oracle proper, 1 = A sparse L D L^T of the un-marginalised
+        system (1 thread), 2 = B Schur + OpenMP.  Returns the thread count in effect (1 without OpenMP in the loaded build)."""
+        self._L.orc_ba_set_solver(self._h, int(solver), int(threads))
+        return self._L.orc_ba_threads(self._h)
 
     def DisableConvergence(self, disable=True):
         self._L.orc_ba_disable_convergence(self._h, int(disable))

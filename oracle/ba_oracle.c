@@ -65,7 +65,20 @@ struct orc_ba {
   int* outliers; int noutliers, coutliers;
   orc_iter_log* logs; int nlogs, clogs;
   double last_chi2_action;
+
+  /* CPU-baseline variants (ba_baseline.inc): 0 = the oracle proper (Schur, dense Cholesky, 1 thread), 1 = A (sparse
+   * L D L^T of the un-marginalised system, 1 thread), 2 = B (Schur, OpenMP) */
+  int solver, threads; void* sparse; void* par;
 };
+
+static void baseline_free(orc_ba* h);
+static int solve_system_sparse(orc_ba* h, double lambda, double* x);
+static int solve_system_par(orc_ba* h, double lambda, double* x);
+static void build_system_par(orc_ba* h);
+static void compute_active_errors_par(orc_ba* h);
+static double active_robust_chi2_par(orc_ba* h);
+static void apply_update_par(orc_ba* h, const double* x);
+static double select_kth(double* v, int n, int k);
 
 /* ------------------------------------------------------------------ small math */
 static void m3mul(const double* A, const double* B, double* C) {
@@ -260,6 +273,7 @@ orc_ba* orc_ba_create(const orc_camera* cams, int ncam, int use_robust, int use_
   return h;
 }
 static void free_structure(orc_ba* h) {
+  baseline_free(h);
   free(h->pt_meas); free(h->inc_pose); free(h->fl_point); free(h->fp_pose);
   free(h->Hpp); free(h->bp); free(h->V); free(h->g); free(h->W); free(h->S); free(h->x); free(h->ball);
   h->pt_meas = h->inc_pose = h->fl_point = h->fp_pose = NULL;
@@ -395,6 +409,7 @@ static double meas_chi2(const orc_ba* h, const omeas* m) {
 }
 /* g2o computeActiveErrors + UpdateHelpersAction (:925-947) */
 static void compute_active_errors(orc_ba* h) {
+  if (h->solver == 2) { compute_active_errors_par(h); return; }
   update_chains(h);
   for (int i = 0; i < h->nmeas; i++) compute_error(h, &h->meas[i]);
 }
@@ -403,7 +418,12 @@ static void recompute_sigma(orc_ba* h) {
   h->need_recompute = 0;
   double* v = (double*)malloc(sizeof(double)*(h->nmeas > 0 ? h->nmeas : 1));
   for (int i = 0; i < h->nmeas; i++) v[i] = fabs(meas_chi2(h, &h->meas[i]));
-  double s = orc_huber_sigma_squared(v, h->nmeas);
+  double s;
+  if (h->solver == 2 && h->nmeas > 0) {     /* baseline B: the same element [n/2] by quick-select instead of a full sort */
+    const int n = h->nmeas;
+    double dSigma = 1.4826 * (1 + 5.0/(double)((unsigned long long)n*2ull - 6ull)) * sqrt(select_kth(v, n, n/2));
+    dSigma = 1.345 * dSigma; s = dSigma*dSigma;
+  } else s = orc_huber_sigma_squared(v, h->nmeas);
   free(v);
   h->sigma_sq = s; h->sigma_sq_lim = s;
   const double mins = h->min_sigma*h->min_sigma;                  /* :1148 */
@@ -419,6 +439,7 @@ static void robustify(orc_ba* h, double e2, double rho[3]) {
 }
 /* g2o SparseOptimizer::activeRobustChi2 [3P-memory] */
 static double active_robust_chi2(orc_ba* h) {
+  if (h->solver == 2) return active_robust_chi2_par(h);
   double chi = 0.0, rho[3];
   for (int i = 0; i < h->nmeas; i++) {
     const double c = meas_chi2(h, &h->meas[i]);
@@ -635,6 +656,7 @@ static int find_inc(const orc_ba* h, const opoint* p, int unk) {
 /* g2o BlockSolver::buildSystem + BaseMultiEdge::constructQuadraticForm [3P-memory]:
  * H += Ji^T (rho' Omega) Jj, b += -Ji^T (rho' Omega) e over the free vertices of each edge. */
 static void build_system(orc_ba* h) {
+  if (h->solver == 2) { build_system_par(h); return; }
   const int np = h->np;
   memset(h->Hpp, 0, sizeof(double)*(size_t)np*np); memset(h->bp, 0, sizeof(double)*np);
   memset(h->V, 0, sizeof(double)*(size_t)h->nfl*9); memset(h->g, 0, sizeof(double)*(size_t)h->nfl*3);
@@ -730,6 +752,8 @@ static int reduce_system(orc_ba* h, double lambda, double* S, double* r, double*
   return 0;
 }
 static int solve_system(orc_ba* h, double lambda, double* x) {
+  if (h->solver == 1) return solve_system_sparse(h, lambda, x);
+  if (h->solver == 2) return solve_system_par(h, lambda, x);
   const int np = h->np;
   double* S = h->S; double* r = (double*)malloc(sizeof(double)*(np + 1));
   double* Vinv = (double*)malloc(sizeof(double)*((size_t)h->nfl*9 + 1));
@@ -823,6 +847,7 @@ static void pop_state(orc_ba* h) {
   for (int i = 0; i < h->nfl; i++) { opoint* p = &h->points[h->fl_point[i]]; memcpy(p->x, p->xbak, 24); }
 }
 static void apply_update(orc_ba* h, const double* x) {
+  if (h->solver == 2) { apply_update_par(h, x); return; }
   for (int i = 0; i < h->nfp; i++) pose_oplus(&h->poses[h->fp_pose[i]].T, x + 6*i);
   for (int i = 0; i < h->nfl; i++) point_oplus(h->points[h->fl_point[i]].x, x + h->np + 3*(size_t)i);
 }
@@ -1014,3 +1039,5 @@ int orc_ba_num_iter_logs(orc_ba* h) { return h->nlogs; }
 int orc_ba_get_iter_logs(orc_ba* h, orc_iter_log* out, int cap) {
   int n = h->nlogs < cap ? h->nlogs : cap; memcpy(out, h->logs, sizeof(orc_iter_log)*(size_t)n); return n;
 }
+
+#include "ba_baseline.inc"

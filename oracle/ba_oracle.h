@@ -63,6 +63,11 @@ void    orc_ba_destroy(orc_ba*);
 void orc_ba_set_limits(orc_ba*, int max_trials, double pct_limit, double rms_limit, double min_sigma);
 /* when nonzero the convergence actions never fire (timing runs) */
 void orc_ba_disable_convergence(orc_ba*, int disable);
+/* CPU-baseline variants for bench.py (ba_baseline.inc): solver 0 = the oracle proper, 1 = A "reference-shaped" (sparse
+ * L D L^T of the un-marginalised system, one thread), 2 = B "best CPU" (Schur, OpenMP over `threads`) */
+void orc_ba_set_solver(orc_ba*, int solver, int threads);
+int  orc_ba_threads(orc_ba*);
+int  orc_built_with_openmp(void);
 
 int  orc_ba_add_pose (orc_ba*, const double R[9], const double t[3], int fixed);
 int  orc_ba_add_point(orc_ba*, const double x[3], const int* chain, int n, int fixed);

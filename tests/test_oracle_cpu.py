@@ -1209,3 +1209,21 @@ def test_sigma_small_sample_factor_wraps_like_size_t():
     v = (ctypes.c_double * 10)(*range(1, 11))
     want = (1.345 * 1.4826 * (1 + 5.0 / 14.0) * np.sqrt(6.0)) ** 2
     assert abs(L.orc_huber_sigma_squared(v, 10) - want) <= 1e-14 * want
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_cpu_baseline_variants_reproduce_the_oracle(solver):
+    """bench.py's CPU baselines (oracle/ba_baseline.inc: A = sparse L D L^T of the un-marginalised system, B = Schur with
+    per-thread block accumulators and a tiled Cholesky) run the same LM iterations as the oracle proper."""
+    from helpers import compare_runs, run_bundle
+    from mcptam_amd import synth
+    from oracle import OracleBundle
+    p = synth.make_config("c2", n_mkf=10, n_points=800)
+    runs = []
+    for s in (0, solver):
+        o = OracleBundle(p.cams, True, True, False)
+        o.SetSolver(s, 4)
+        runs.append(run_bundle(o, p, 6))
+    rep = compare_runs(runs[1], runs[0], tol_state=1e-10)
+    assert rep["branch_flips"] == 0
+    assert runs[0]["outliers"] == runs[1]["outliers"]
