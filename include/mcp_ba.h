@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MCP_MAX_CHAIN 4      /* longest pose chain accepted (reference uses 1 and 2) */
+#define MCP_MAX_CHAIN 8      /* longest pose chain accepted (the reference's adapters build chains of 1 and 2 poses) */
 #define MCP_MAX_INV   31     /* MAX_INV_DEGREE+1, include/mcptam/TaylorCamera.h:74 */
 
 /* The already-fitted TaylorCamera, i.e. the state after TaylorCamera::RefreshParams
@@ -49,8 +49,9 @@ typedef struct mcp_camera {
   double max_rho;        /* mdMaxRho                                    :147     */
   double theta_mean;     /* mdThetaMean                                 :551-565 */
   double theta_std;      /* mdThetaStd                                  :569     */
-  int    n_inv;          /* number of inverse polynomial coefficients; 0 (= the reference's
-                            Newton fallback, :161-176) is rejected                  */
+  int    n_inv;          /* number of inverse polynomial coefficients (mbUsingInversePoly); 0 = the reference's
+                            Newton fallback (:161-176, 258-270): inv_coeffs[0..1] then hold the linear
+                            inverse model mv2LinearInvCoeffs that seeds FindRootWithNewton (:293-315)    */
   int    pad_;
   double inv_coeffs[MCP_MAX_INV];   /* mvxPolyInvCoeffs, x^0 first       :157     */
 } mcp_camera;

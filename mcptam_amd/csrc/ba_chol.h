@@ -15,15 +15,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
 namespace mcp {
 
 constexpr int CH_NB = 32;
-// The diagonal workgroup of launch k writes L_kk to a side array of diagonal tiles (Dg, read by k_chol_back) instead of over
-// tile (k,k): the other workgroups of block column k load tile (k,k) in the same launch, and nothing orders a store
-// against those loads inside a launch.  Tile (k,k) of S therefore stays untouched (pre-factorisation values) for good.
+// The diagonal workgroup of launch k writes its result (L_kk^-T, all the back-substitution needs of the tile) to a side array
+// of diagonal tiles (Dg, read by k_chol_back) instead of over tile (k,k): the other workgroups of block column k load tile
+// (k,k) in the same launch, and nothing orders a store against those loads inside a launch.  Tile (k,k) of S therefore
+// stays untouched (pre-factorisation values) for good.
 #define CH_DIAG_PARAMS(cv) , cv double* __restrict__ Dg /* [systems][block columns][32 x 32] factored diagonal tiles */, size_t diag_stride
 #define CH_DIAG_ARGS(plan) , plan.d_diag, plan.diag_stride
 #define CH_DIAG_OFFSET(b) Dg += (b)*diag_stride
@@ -96,8 +98,10 @@ template <int K, int G> struct ChBulk {        // group G (of 6) of the bulk upd
   static constexpr int n = (CH_NB - K - 3 > 0) ? CH_NB - K - 3 : 0;
   static constexpr int lo = K + 3 + (n*G)/6, hi = K + 3 + (n*(G + 1))/6;
   static __device__ inline void fm(double* d, const double* m) {
+#if !defined(CH_ABL)
 #pragma unroll
     for (int c = lo; c < hi; ++c) d[c] -= d[K]*m[c];          // entries above the diagonal: unused garbage
+#endif
   }
 };
 template <int J>
@@ -105,7 +109,9 @@ __device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad, doubl
   double* cur = (J & 1) ? mO : mE;          // multipliers of column J (requested here, used at pivot J+1)
   double* prev = (J & 1) ? mE : mO;         // multipliers of column J-1
   d[J] *= inv;                              // lane J holds the pivot itself: pivot * rsqrt(pivot) = L_JJ
+#if !defined(CH_ABL) || CH_ABL < 2
   if constexpr (J + 3 < CH_NB) colbuf[threadIdx.x] = d[J];
+#endif
   CH_SB();
   if constexpr (J + 1 < CH_NB) {
     // the next pivot, lane-locally: on lane J+1, d[J+1] - d[J]^2 is the updated diagonal entry
@@ -115,10 +121,12 @@ __device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad, doubl
     if constexpr (J + 2 < CH_NB) l2 = readlane_f64(d[J], J + 2);
     const double pn = readlane_f64(w, J + 1);
     bad |= !(pn > 0.0);                     // off the critical path: a failed factorisation is flagged, its numbers are not used
+#if !defined(CH_ABL) || CH_ABL < 2
     if constexpr (J + 3 < CH_NB) {
 #pragma unroll
       for (int c = J + 3; c < CH_NB; ++c) cur[c] = colbuf[c];
     }
+#endif
     CH_SB();
     const double y0 = __builtin_amdgcn_rsq(pn);
     CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 0>::fm(d, prev); CH_SB();
@@ -145,96 +153,6 @@ __device__ inline void chol_panel_pivots(double* d, double& inv, bool& bad, doub
   (chol_panel_pivot<Js>(d, inv, bad, mE, mO, colbuf), ...);
 }
 
-// ---- variant: the panel split over two wavefronts by column halves (-DMCP_CHOL_PANEL2=1, off until it has
-// been run on the hardware).  Both wavefronts hold the same 64 rows (diagonal tile + own tile); wavefront A owns columns
-// [0, 16), wavefront B columns [16, 32).  A factors pivots 0..15 exactly as above but only updates its own columns, and
-// publishes every finished column J (all 64 lanes) in slot J of an LDS ring, then raises `ready` to J + 1.  B applies the
-// rank-1 update of each published column to its 16 columns (own-row value x multiplier of the diagonal lane, both from the
-// ring) and then factors pivots 16..31 with the same pipelined code.  Every d[c] still receives its updates in column order.
-#ifndef MCP_CHOL_PANEL2
-#define MCP_CHOL_PANEL2 0
-#endif
-#if MCP_CHOL_PANEL2
-constexpr int CH_HALF = CH_NB/2;
-#define CH_SB() __builtin_amdgcn_sched_barrier(0)
-template <int K, int G, int CEND> struct ChBulk2 {        // group G (of 6) of the bulk update by column K: columns [lo, hi) below CEND
-  static constexpr int n = (CEND - K - 3 > 0) ? CEND - K - 3 : 0;
-  static constexpr int lo = K + 3 + (n*G)/6, hi = K + 3 + (n*(G + 1))/6;
-  template <int J0> static __device__ inline void fm(double* d, const double* m /* indexed from J0 */) {
-#pragma unroll
-    for (int c = lo; c < hi; ++c) d[c] -= d[K]*m[c - J0];
-  }
-};
-// pivot J of the column range [J0, CEND); `col` = where column J is published (64 doubles: a ring slot for A, one buffer for B)
-template <int J, int J0, int CEND, bool PUBLISH_ALL>
-__device__ inline void chol_panel2_pivot(double* d, double& inv, bool& bad, double* mE, double* mO, double* col, int ln, int* ready) {
-  double* cur = (J & 1) ? mO : mE;
-  double* prev = (J & 1) ? mE : mO;
-  d[J] *= inv;
-  if constexpr (PUBLISH_ALL || J + 3 < CEND) col[ln] = d[J];
-  if constexpr (PUBLISH_ALL) {
-    __asm__ volatile("" ::: "memory");        // DS operations of one wavefront execute in order: the column lands before the counter
-    __hip_atomic_store(ready, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  CH_SB();
-  if constexpr (J + 1 < CEND) {
-    const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
-    const double l1 = readlane_f64(d[J], J + 1);
-    double l2 = 0.0;
-    if constexpr (J + 2 < CEND) l2 = readlane_f64(d[J], J + 2);
-    const double pn = readlane_f64(w, J + 1);
-    bad |= !(pn > 0.0);
-    if constexpr (J + 3 < CEND) {
-#pragma unroll
-      for (int c = J + 3; c < CEND; ++c) cur[c - J0] = col[c];
-    }
-    CH_SB();
-    const double y0 = __builtin_amdgcn_rsq(pn);
-    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 0, CEND>::template fm<J0>(d, prev); CH_SB();
-    const double t = y0*(-pn);
-    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 1, CEND>::template fm<J0>(d, prev); CH_SB();
-    const double e = __builtin_fma(t, y0, 1.0);
-    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 2, CEND>::template fm<J0>(d, prev); CH_SB();
-    const double u = y0*e;
-    const double q = __builtin_fma(e, 0.375, 0.5);
-    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 3, CEND>::template fm<J0>(d, prev); CH_SB();
-    inv = __builtin_fma(u, q, y0);
-    CH_SB(); if constexpr (J > J0) ChBulk2<J - 1, 4, CEND>::template fm<J0>(d, prev); CH_SB();
-    d[J + 1] -= d[J]*l1;
-    if constexpr (J > J0) ChBulk2<J - 1, 5, CEND>::template fm<J0>(d, prev);
-    CH_SB();
-    if constexpr (J + 2 < CEND) d[J + 2] -= d[J]*l2;
-    CH_SB();
-  }
-}
-#undef CH_SB
-template <int... Js>      // wavefront A: pivots 0 .. CH_HALF-1, ring slot J = ring + 64 J
-__device__ inline void chol_panel2_first(double* d, double& inv, bool& bad, double* ring, int ln, int* ready, std::integer_sequence<int, Js...>) {
-  double mE[CH_HALF], mO[CH_HALF];
-  (chol_panel2_pivot<Js, 0, CH_HALF, true>(d, inv, bad, mE, mO, ring + 64*Js, ln, ready), ...);
-}
-template <int... Js>      // wavefront B: pivots CH_HALF .. CH_NB-1 (Js = 0 .. CH_HALF-1 offsets)
-__device__ inline void chol_panel2_second(double* d, double& inv, bool& bad, double* colbuf, int ln, std::integer_sequence<int, Js...>) {
-  double mE[CH_HALF], mO[CH_HALF];
-  (chol_panel2_pivot<CH_HALF + Js, CH_HALF, CH_NB, false>(d, inv, bad, mE, mO, colbuf, ln, nullptr), ...);
-}
-template <int J>          // wavefront B: rank-1 update of columns [CH_HALF, CH_NB) by the published column J
-__device__ inline void chol_panel2_consume_one(double* d, const double* ring, int ln, int* ready) {
-  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= J) __builtin_amdgcn_s_sleep(1);
-  __asm__ volatile("" ::: "memory");
-  const double* col = ring + 64*J;
-  const double x = col[ln];
-#pragma unroll
-  for (int c = CH_HALF; c < CH_NB; ++c) d[c] -= x*col[c];
-#pragma unroll
-  for (int c = CH_HALF; c < CH_NB; ++c) __asm__ volatile("" : "+v"(d[c]));      // finish this column's update before waiting for the next
-}
-template <int... Js>
-__device__ inline void chol_panel2_consume(double* d, const double* ring, int ln, int* ready, std::integer_sequence<int, Js...>) {
-  (chol_panel2_consume_one<Js>(d, ring, ln, ready), ...);
-}
-#endif
-
 #ifdef MCP_CHOL_PROF
 __device__ unsigned long long g_chol_prof[256*2*8];
 #define CHOL_STAMP(i) do { if (blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) g_chol_prof[(k*2 + blockIdx.x)*8 + (i)] = clock64(); } while (0)
@@ -252,10 +170,6 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   __shared__ double Tc[CH_NB][CH_NB + 1];
   __shared__ double Td[CH_NB][CH_NB + 1];
   __shared__ double Te[CH_NB][CH_NB + 1];
-#if MCP_CHOL_PANEL2
-  __shared__ int panel_ready;                      // columns published by wavefront A of the panel (reset before the first barrier)
-  if (threadIdx.x == 0) panel_ready = 0;
-#endif
   const int lane = threadIdx.x;
   const int r0 = ti*CH_NB, c0 = tj*CH_NB, k0 = k*CH_NB, p0 = (k - 1)*CH_NB;
   const bool panel = (tj == k), offdiag = (ti != k);
@@ -294,61 +208,6 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     }
     return;
   }
-#if MCP_CHOL_PANEL2
-  if (lane >= 128) return;     // two wavefronts share the panel factorisation (no barrier below this line)
-  const int wv = __builtin_amdgcn_readfirstlane(lane >> 6), ln = lane & 63;      // wavefront-uniform: a scalar branch below
-  double (*Tdiag)[CH_NB + 1] = offdiag ? Td : Tc;
-  const int nbe = min(CH_NB, n - k0);
-  const int rr = ln & 31;
-  const bool low = ln >= 32;
-  double d[CH_NB];                     // only this wavefront's half is ever loaded, updated and stored
-  auto load_half = [&](auto c0_) {
-    constexpr int C0 = decltype(c0_)::value;
-    if (!low) {
-#pragma unroll
-      for (int c = C0; c < C0 + CH_HALF; ++c) d[c] = (c <= rr && rr < nbe && c < nbe) ? Tdiag[rr][c] : ((c == rr) ? 1.0 : 0.0);
-    } else {
-      const bool use = offdiag || rr >= nbe;
-#pragma unroll
-      for (int c = C0; c < C0 + CH_HALF; ++c) d[c] = (use && c < nbe) ? Tc[rr][c] : 0.0;
-    }
-  };
-  auto store_half = [&](auto c0_) {
-    constexpr int C0 = decltype(c0_)::value;
-    if (!low) {
-      if (!offdiag && ln < nbe) {
-        double* p = Dg + (size_t)k*(CH_NB*CH_NB) + ln*CH_NB;
-#pragma unroll
-        for (int c = C0; c < C0 + CH_HALF; ++c) if (c <= ln) p[c] = d[c];
-      }
-    } else if (r0 + rr < nrows && (offdiag || rr >= nbe)) {
-      double* p = S + (size_t)(r0 + rr)*n + k0;
-#pragma unroll
-      for (int c = C0; c < C0 + CH_HALF; ++c) if (c < nbe) p[c] = d[c];
-    }
-  };
-  double* ring = &Ta[0][0];            // Ta is free now: CH_HALF slots of 64 doubles (1024 <= 32*33)
-  int* ready = &panel_ready;
-  bool bad = false;
-  if (wv == 0) {
-    load_half(std::integral_constant<int, 0>());
-    const double piv0 = readlane_f64(d[0], 0);
-    bad = !(piv0 > 0.0);
-    double inv = rsqrt(piv0);
-    chol_panel2_first(d, inv, bad, ring, ln, ready, std::make_integer_sequence<int, CH_HALF>());
-    CHOL_STAMP(3);
-    store_half(std::integral_constant<int, 0>());
-  } else {
-    load_half(std::integral_constant<int, CH_HALF>());
-    chol_panel2_consume(d, ring, ln, ready, std::make_integer_sequence<int, CH_HALF>());
-    const double pivh = readlane_f64(d[CH_HALF], CH_HALF);
-    bad = !(pivh > 0.0);
-    double inv = rsqrt(pivh);
-    chol_panel2_second(d, inv, bad, &Tb[0][0], ln, std::make_integer_sequence<int, CH_HALF>());      // Tb is free as well
-    store_half(std::integral_constant<int, CH_HALF>());
-  }
-  if (bad && ln == 0) atomicOr(fail, 2);
-#else
   if (lane >= 64) return;      // the panel factorisation is one wavefront's job (no barrier below this line)
   // ---- block column k: unblocked panel factorisation of [diagonal tile ; own tile], one row per lane.
   // lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the own tile (for the diagonal
@@ -362,10 +221,15 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   if (!low) {
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) d[c] = (c <= rr && rr < nbe && c < nbe) ? Tdiag[rr][c] : ((c == rr) ? 1.0 : 0.0);
-  } else {
-    const bool use = offdiag || rr >= nbe;
+  } else if (offdiag || rr >= nbe) {
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) d[c] = (use && c < nbe) ? Tc[rr][c] : 0.0;
+    for (int c = 0; c < CH_NB; ++c) d[c] = (c < nbe) ? Tc[rr][c] : 0.0;
+  } else {
+    // diagonal workgroup: its lower lanes are free (the tile's rows sit in lanes 0..31), so they carry the identity through the
+    // same column operations and come out as I L_kk^-T -- lane 32 + r ends with row r of L_kk^-T = column r of L_kk^-1, which
+    // is all the back-substitution needs of this tile (a 32 x 32 matrix-vector product instead of a 32-pivot triangular solve)
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) d[c] = (c == rr) ? 1.0 : 0.0;
   }
   const double piv0 = readlane_f64(d[0], 0);
   bool bad = !(piv0 > 0.0);
@@ -374,29 +238,29 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   CHOL_STAMP(3);
   if (bad && lane == 0) atomicOr(fail, 2);
   if (!low) {
-    if (!offdiag && lane < nbe) {
-      double* p = Dg + (size_t)k*(CH_NB*CH_NB) + lane*CH_NB;
+    // (L_kk itself is not stored: the forward substitution rides on the factorisation as the augmented row, the backward
+    // one uses the inverse below; the other tiles of block column k already hold X = C L_kk^-T)
+  } else if (!offdiag && rr < nbe) {
+    double* p = Dg + (size_t)k*(CH_NB*CH_NB) + rr*CH_NB;        // row rr of L_kk^-T (upper triangular)
 #pragma unroll
-      for (int c = 0; c < CH_NB; ++c) if (c <= lane) p[c] = d[c];
-    }
+    for (int c = 0; c < CH_NB; ++c) if (c >= rr && c < nbe) p[c] = d[c];
   } else if (r0 + rr < nrows && (offdiag || rr >= nbe)) {
     double* p = S + (size_t)(r0 + rr)*n + k0;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) if (c < nbe) p[c] = d[c];
   }
-#endif
   CHOL_STAMP(4);
 }
 
 // backward substitution L^T x = y (y = row n of the augmented matrix); one workgroup per system.
-// Wavefront 0 solves the 32x32 triangle of the step (diagonal tile prefetched into registers during the previous step's
-// update); the other 7 wavefronts spread the update y[c] -= sum_r L[k0+r][c] x[k0+r] over (column pair, 16-row slice) items --
+// Wavefront 0 multiplies by L_kk^-T of the step (a by-product of the factorisation; tile prefetched into registers during the
+// previous step's update); the other 7 wavefronts spread the update y[c] -= sum_r L[k0+r][c] x[k0+r] over (column pair, 16-row slice) items --
 // one L2 round trip of 16 independent 16-byte loads per item (n = 6P is even, so column pairs are aligned) instead of a
 // 32-long walk per column -- and combine the two slices of a column pair by a lane shuffle (fixed order, no atomics).
 constexpr int CH_BACK_THREADS = 512;
 constexpr int CH_BACK_RG = 2;            // row slices per column
 constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
-// tiles of step kb into LDS, spread over `nth` threads (index `u`): Lt = L_kk (lower, unit-padded outside the matrix),
+// tiles of step kb into LDS, spread over `nth` threads (index `u`): Lt = L_kk^-T (upper, unit-padded outside the matrix),
 // Tt = the tile below it, L[k0+32 .. ][k0 ..] (zero outside); coalesced row segments; load and LDS store are split so the
 // loads stay in flight during the update
 constexpr int CH_STAGE_PER = 5;                            // ceil(2*1024 / (CH_BACK_THREADS - 64))
@@ -409,7 +273,7 @@ __device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG
     const int which = e >> 10, r = (e >> 5) & 31, c = e & 31;
     v[i] = 0.0;
     if (e < 2048) {
-      if (which == 0) v[i] = (r >= c && r < nbe && c < nbe) ? Dg[(size_t)kb*(CH_NB*CH_NB) + r*CH_NB + c] : ((r == c) ? 1.0 : 0.0);
+      if (which == 0) v[i] = (c >= r && r < nbe && c < nbe) ? Dg[(size_t)kb*(CH_NB*CH_NB) + r*CH_NB + c] : ((r == c) ? 1.0 : 0.0);   // L_kk^-T, upper
       else v[i] = (r < nbb && c < nbe) ? S[(size_t)(kb0 + r)*n + k0 + c] : 0.0;
     }
   }
@@ -445,68 +309,105 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
   const bool solver = t < 64;
   const int rr = t & 31;
   __shared__ double Lt[2][CH_NB][CH_NB + 1], Tt[2][CH_NB][CH_NB + 1];     // tiles of the current / next step (by parity)
+  // the block-row index of the plan, staged once: every step would otherwise start with two dependent global index reads
+  constexpr int RT_CAP = 4096;
+  __shared__ int rs_l[CH_SOLVE_MAX/CH_NB + 2], rt_l[RT_CAP];
+  const int n_rt = row_start[nblk];
+  for (int i = t; i <= nblk; i += CH_BACK_THREADS) rs_l[i] = row_start[i];
+  if (n_rt <= RT_CAP) for (int i = t; i < n_rt; i += CH_BACK_THREADS) rt_l[i] = row_tiles[i];
+  const int* rt = (n_rt <= RT_CAP) ? rt_l : row_tiles;
   double xprev = 0.0;
+  // the solver's two tiles travel global -> registers -> LDS two steps ahead of their use: loaded during step j+2, stored to
+  // LDS at the start of step j+1 (into the buffer of the other parity), read by the solver in step j
+  double sv[CH_STAGE_PER];
   if (t >= 64) {
-    double sv[CH_STAGE_PER];
     chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv);
     chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(nblk - 1) & 1], Tt[(nblk - 1) & 1]);
+    if (nblk > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 2, t - 64, CH_BACK_THREADS - 64, sv);
   }
   __syncthreads();
+  // updaters: (tile, column pair, row slice) items of block row ub against x of block ub; item q of a thread's first round is
+  // PREFETCHED one step ahead (the L values do not depend on x), so the cold-miss latency of a step's loads hides behind the
+  // solver's work of the step before
+  constexpr int RPI = CH_NB/CH_BACK_RG;                 // rows per item
+  constexpr int IPT = (CH_NB/2)*CH_BACK_RG;             // items per tile
+  constexpr int NUP = CH_BACK_THREADS - 64;             // updater threads
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 pv[RPI]; int p_c = -1, p_rg = 0;
+  // issue the loads of item q of block row ub, skipping tile `skip` (the solver's own tile of the step that consumes them)
+  auto load_item = [&](int ub, int q, int skip, d2* v, int& c_out, int& rg_out) {
+    c_out = -1;
+    const int l0 = rs_l[ub], items = (rs_l[ub + 1] - l0)*IPT;
+    if (q >= items) return;
+    const int tile = rt[l0 + q/IPT];
+    if (tile == skip) return;
+    const int rem = q % IPT;
+    const int rg = rem & (CH_BACK_RG - 1), c = tile*CH_NB + 2*(rem/CH_BACK_RG);     // the row slices of a column pair sit in neighbouring lanes
+    const int u0 = ub*CH_NB, nbu = min(CH_NB, n - u0), r0 = rg*RPI;
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) v[r] = (r0 + r < nbu) ? *reinterpret_cast<const d2*>(S + (size_t)(u0 + r0 + r)*n + c) : (d2){0.0, 0.0};
+    c_out = c; rg_out = rg;
+  };
+  // both lanes of a slice pair (2i, 2i+1: same tile, same column pair) are active together: the item counts are even
+  auto apply_item = [&](int ub, const d2* v, int c, int rg) {
+    const int u0 = ub*CH_NB, nbu = min(CH_NB, n - u0), r0 = rg*RPI;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) { const double xr = (r0 + r < nbu) ? xs[u0 + r0 + r] : 0.0; a0 += v[r][0]*xr; a1 += v[r][1]*xr; }
+    // fixed-order combination of the two slices; one lane owns the column pair in this step -- no atomics, reproducible
+    static_assert(CH_BACK_RG == 2 && (NUP % 2) == 0, "slice pairing");
+    a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+    if (rg == 0) { xs[c] -= a0; xs[c + 1] -= a1; }
+  };
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
     BACK_STAMP(0, 0); BACK_STAMP(1, 0);
     if (solver) {
-      // column rr of L_kk and of the tile below it, staged in LDS by wavefront 1 during the previous step
-      double Lc[CH_NB], Tf[CH_NB];
-#pragma unroll
-      for (int c = 0; c < CH_NB; ++c) { Lc[c] = Lt[kb & 1][c][rr]; Tf[c] = Tt[kb & 1][c][rr]; }
+      // column rr of the tile below and row rr of L_kk^-T, staged in LDS by the updaters during the previous step; consumed in
+      // halves of 16 so that the solver's live registers stay below the updaters' (the kernel's allocation is the maximum)
       double yv = (rr < nbe) ? xs[k0 + rr] : 0.0;
-      // contribution of the block solved in the previous step (Tf is zero in the first step)
+      // contribution of the block solved in the previous step (the tile below is zero in the first step)
 #pragma unroll
-      for (int r = 0; r < CH_NB; ++r) yv -= Tf[r]*readlane_f64(xprev, r);
-      double dg = 1.0;
+      for (int h = 0; h < CH_NB; h += 16) {
+        double Tf[16];
 #pragma unroll
-      for (int c = 0; c < CH_NB; ++c) if (c == rr) dg = Lc[c];
-      const double rinv = 1.0/dg;
+        for (int r = 0; r < 16; ++r) Tf[r] = Tt[kb & 1][h + r][rr];
 #pragma unroll
-      for (int c = CH_NB - 1; c >= 0; --c) {
-        const double xc = readlane_f64(yv, c)*readlane_f64(rinv, c);
-        if (rr == c) yv = xc;
-        else if (rr < c) yv -= Lc[c]*xc;
+        for (int r = 0; r < 16; ++r) yv -= Tf[r]*readlane_f64(xprev, h + r);
+      }
+      // x = L_kk^-T y with the tile's inverse (a by-product of the factorisation, k_chol_step): x[rr] = sum_c (L^-T)[rr][c] y[c]
+      {
+        double xa = 0.0, xb = 0.0;
+#pragma unroll
+        for (int h = 0; h < CH_NB; h += 16) {
+          double Lc[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) Lc[c] = Lt[kb & 1][rr][h + c];
+#pragma unroll
+          for (int c = 0; c < 16; c += 2) { xa += Lc[c]*readlane_f64(yv, h + c); xb += Lc[c + 1]*readlane_f64(yv, h + c + 1); }
+        }
+        yv = xa + xb;
       }
       if (t < nbe) xs[k0 + t] = yv;
       xprev = (rr < nbe) ? yv : 0.0;
       BACK_STAMP(0, 1);
     } else {
-      double sv[CH_STAGE_PER];
-      if (kb > 0) chol_back_stage_load(S CH_BACK_DG, n, nblk, kb - 1, t - 64, CH_BACK_THREADS - 64, sv);      // in flight during the update
+      if (kb > 0) chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(kb - 1) & 1], Tt[(kb - 1) & 1]);      // tiles of step kb-1 (loaded a step ago)
+      if (kb > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, kb - 2, t - 64, CH_BACK_THREADS - 64, sv);           // tiles of step kb-2: a full step to land
       if (kb + 1 < nblk) {
-      // x of block kb+1 (solved in the previous step) against the structurally non-zero tiles of block row kb+1 left of tile kb
-      const int ub = kb + 1, u0 = ub*CH_NB, nbu = min(CH_NB, n - u0);
-      const int l0 = row_start[ub], l1 = row_start[ub + 1];
-      constexpr int RPI = CH_NB/CH_BACK_RG;                 // rows per item
-      const int items = (l1 - l0)*(CH_NB/2)*CH_BACK_RG;     // (tile, column pair, row slice)
-      typedef double d2 __attribute__((ext_vector_type(2)));
-      for (int q = t - 64; q < items; q += CH_BACK_THREADS - 64) {
-        const int tile = row_tiles[l0 + q/((CH_NB/2)*CH_BACK_RG)];
-        if (tile == kb) continue;                           // the solver's tile
-        const int rem = q % ((CH_NB/2)*CH_BACK_RG);
-        const int rg = rem & (CH_BACK_RG - 1), c = tile*CH_NB + 2*(rem/CH_BACK_RG);     // the row slices of a column pair sit in neighbouring lanes
-        const int r0 = rg*RPI;
-        d2 v[RPI];
-#pragma unroll
-        for (int r = 0; r < RPI; ++r) v[r] = (r0 + r < nbu) ? *reinterpret_cast<const d2*>(S + (size_t)(u0 + r0 + r)*n + c) : (d2){0.0, 0.0};
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPI; ++r) { const double xr = (r0 + r < nbu) ? xs[u0 + r0 + r] : 0.0; a0 += v[r][0]*xr; a1 += v[r][1]*xr; }
-        // fixed-order combination of the two slices (lanes 2i, 2i+1: same tile, same column pair; the loop bounds are even, so
-        // both are active together); one lane owns the column pair in this step -- no atomics, reproducible
-        static_assert(CH_BACK_RG == 2 && ((CH_BACK_THREADS - 64) % 2) == 0, "slice pairing");
-        a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
-        if (rg == 0) { xs[c] -= a0; xs[c + 1] -= a1; }
+        // x of block kb+1 (solved in the previous step) against the structurally non-zero tiles of block row kb+1 left of tile kb
+        const int ub = kb + 1;
+        if (p_c >= 0) apply_item(ub, pv, p_c, p_rg);                         // first round: prefetched during the previous step
+        const int items = (rs_l[ub + 1] - rs_l[ub])*IPT;
+        for (int q = t - 64 + NUP; q < items; q += NUP) {                    // further rounds (long block rows): loaded here
+          d2 v[RPI]; int c, rg;
+          load_item(ub, q, kb, v, c, rg);
+          if (c >= 0) apply_item(ub, v, c, rg);
+        }
       }
-      }
-      if (kb > 0) chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(kb - 1) & 1], Tt[(kb - 1) & 1]);
+      // block row kb is consumed in the next step (against tile kb-1 the solver handles itself): fetch its first round now
+      p_c = -1;
+      if (kb > 0) load_item(kb, t - 64, kb - 1, pv, p_c, p_rg);
     }
     BACK_STAMP(0, 3); BACK_STAMP(1, 3);
     __syncthreads();
@@ -522,12 +423,14 @@ struct CholPlan {
   std::vector<int> step_start, step_tiles;     // per step k: tiles to process, block column k first
   std::vector<int> row_start, row_tiles;       // per block row: non-zero tile columns left of the diagonal
   std::vector<int> all_tiles;                  // every tile of the plan after fill-in, incl. the right-hand-side row (ti << 16 | tj)
+  int* d_all_tiles = nullptr;
   int* d_step_tiles = nullptr; int* d_row_start = nullptr; int* d_row_tiles = nullptr;
   double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
   ~CholPlan() { release(); }
   void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
                    if (d_diag) (void)hipFree(d_diag);
-                   d_diag = nullptr;
+                   if (d_all_tiles) (void)hipFree(d_all_tiles);
+                   d_diag = nullptr; d_all_tiles = nullptr;
                    d_step_tiles = d_row_start = d_row_tiles = nullptr; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
   int build(int n_, const std::vector<unsigned char>& pattern) {
@@ -568,6 +471,8 @@ struct CholPlan {
     diag_stride = (size_t)std::max(ntc, 1)*CH_NB*CH_NB;
     if (hipMalloc((void**)&d_diag, sizeof(double)*diag_stride*max_sys) != hipSuccess) return -1;
     if (!row_tiles.empty() && hipMemcpy(d_row_tiles, row_tiles.data(), sizeof(int)*row_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d_all_tiles, sizeof(int)*std::max<size_t>(all_tiles.size(), 1)) != hipSuccess) return -1;
+    if (!all_tiles.empty() && hipMemcpy(d_all_tiles, all_tiles.data(), sizeof(int)*all_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     return 0;
   }
   size_t tile_updates() const { return step_tiles.size(); }

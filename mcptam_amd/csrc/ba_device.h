@@ -135,7 +135,26 @@ __host__ __device__ inline void cam_project(const mcp_camera& cam, const double*
   if (n == 0.0) { theta = 1.57079632679489661923; rho = 0.0; cphi = 0.0; sphi = 0.0; }
   else {
     theta = mcp_atan::atan_cr(xc[2]/n);      // correctly rounded: the one platform-independent value (atan_cr.h)
-    rho = poly_low_first(cam.inv_coeffs, cam.n_inv, (theta - cam.theta_mean)/cam.theta_std);
+    const double ts = (theta - cam.theta_mean)/cam.theta_std;
+    if (cam.n_inv > 0) rho = poly_low_first(cam.inv_coeffs, cam.n_inv, ts);
+    else {
+      // no usable inverse polynomial: linear inverse model, then FindRootWithNewton on a0 + (a1 - tan theta) rho + a2 rho^2 +
+      // a3 rho^3 + a4 rho^4 (a1 = 0) until the step is below 0.01 (src/TaylorCamera.cc:258-270, 293-315; at most 50 steps,
+      // where the reference asserts)
+      const double a0 = cam.params[0], a2 = cam.params[1], a3 = cam.params[2], a4 = cam.params[3];
+      const double tt = xc[2]/n;
+      double prev = poly_low_first(cam.inv_coeffs, 2, ts);
+      rho = prev;
+      for (int it = 0; it < 50; ++it) {
+        // PolyVal's order of operations (Horner, x^0 last)
+        const double f = (((a4*prev + a3)*prev + a2)*prev + (0.0 - tt))*prev + a0;
+        const double fp = ((4.0*a4*prev + 3.0*a3)*prev + 2.0*a2)*prev + (0.0 - tt);
+        rho = prev - f/fp;
+        const double err = fabs(rho - prev);
+        prev = rho;
+        if (!(err > 0.01)) break;
+      }
+    }
     cphi = xc[0]/n; sphi = xc[1]/n;
   }
   const double d0 = cphi*rho, d1 = sphi*rho;

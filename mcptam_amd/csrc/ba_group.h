@@ -113,7 +113,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     const int lpt = P.pt_unk[pt];
     const double x[3] = { pt_x[3*(size_t)pt], pt_x[3*(size_t)pt+1], pt_x[3*(size_t)pt+2] };
     Se3 Ts;
-    load_se3(first + 12*(size_t)(sc*4 + slen - 1), Ts);
+    load_se3(first + 12*(size_t)(sc*MAXC + slen - 1), Ts);
     double xw[3];
     se3_apply_inv(Ts, x, xw);
     // point frame (shared by all measurements of the point)
@@ -132,9 +132,9 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     for (int m = P.sp_m[sp]; m < P.sp_m[sp + 1]; ++m) {
       const int oc = P.m_chain[m], olen = P.chain_len[oc];
       const int mask = P.m_mask[m];
-      if ((mask & 0xff) == 0 && lpt < 0) continue;
+      if (mask == 0 && lpt < 0) continue;
       Se3 To;
-      load_se3(first + 12*(size_t)(oc*4 + olen - 1), To);
+      load_se3(first + 12*(size_t)(oc*MAXC + olen - 1), To);
       double xc[3];
       se3_apply(To, xw, xc);
       Projection pr;
@@ -178,13 +178,13 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
       const int s0 = P.slot_start[m], ns = P.slot_start[m+1] - s0;
 #endif
       int ia = 0;
-      for (int bit_a = 0; bit_a < 8 && ia < ns; ++bit_a) {
+      for (int bit_a = 0; bit_a < 2*MAXC && ia < ns; ++bit_a) {
         if (!(mask & (1 << bit_a))) continue;
         SlotGeom sa; double Ja[12];
-        make_slot(bit_a >> 2, bit_a & 3, A, xw, first, second, oc, sc, To.R, sa);
+        make_slot(bit_a >> MAXC_LOG, bit_a & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sa);
         slot_jacobian(sa, Ja);
         const int la = P.slot_lp[s0 + ia];
-        if (bit_a == 4) {            // first source link: private accumulators, reduced across the wave below
+        if (bit_a == MAXC) {            // first source link: private accumulators, reduced across the wave below
           ls = la;
 #pragma unroll
           for (int r = 0; r < 6; ++r) bs[r] += -w*(Ja[r]*e0 + Ja[6+r]*e1);
@@ -206,7 +206,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 #else
         if (lpt >= 0) {
 #endif
-          if (bit_a == 4) {          // the source pose's block collects one term per measurement: keep it in registers
+          if (bit_a == MAXC) {          // the source pose's block collects one term per measurement: keep it in registers
             wss_inc = P.slot_inc[s0 + ia];
 #pragma unroll
             for (int r = 0; r < 6; ++r)
@@ -228,10 +228,10 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
           }
         }
         int ib = ia + 1;
-        for (int bit_b = bit_a + 1; bit_b < 8 && ib < ns; ++bit_b) {
+        for (int bit_b = bit_a + 1; bit_b < 2*MAXC && ib < ns; ++bit_b) {
           if (!(mask & (1 << bit_b))) continue;
           SlotGeom sb; double Jb[12];
-          make_slot(bit_b >> 2, bit_b & 3, A, xw, first, second, oc, sc, To.R, sb);
+          make_slot(bit_b >> MAXC_LOG, bit_b & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sb);
           slot_jacobian(sb, Jb);
           tile_add_cross(Sl, la, P.slot_lp[s0 + ib], Ja, Jb, w);
           ++ib;

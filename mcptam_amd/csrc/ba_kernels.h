@@ -22,7 +22,7 @@ struct DevProblem {
   // chains
   int nchain;
   const int* chain_len;       // [nchain]
-  const int* chain_pose;      // [nchain*4] pose array index
+  const int* chain_pose;      // [nchain*MAXC] pose array index
   // poses
   int npose;
   const int* pose_unk;        // [npose] unknown index or -1
@@ -65,6 +65,9 @@ struct DevProblem {
   const int* blk_dst;             // [nblk] where the block is staged: position in the destination-ordered staging array
   const int* rhs_dst;             // [ngroup*GRP_LMAX] staged rhs row of (group, local pose), or -1
 };
+constexpr int MAXC = MCP_MAX_CHAIN;             // links per pose chain; per-chain arrays are strided by it
+constexpr int MAXC_LOG = 3;
+static_assert((1 << MAXC_LOG) == MAXC && 2*MAXC <= 16, "m_mask is 16 bits: observer links in bits [0, MAXC), source links in [MAXC, 2 MAXC)");
 constexpr int GRP_LMAX = 16;      // poses per group (6*16 = 96 local dof)
 constexpr int GRP_PTS = 64;       // points per group (one lane each in k_linearize_group)
 constexpr int GRP_DOF = 6*GRP_LMAX;
@@ -77,12 +80,12 @@ __global__ void k_chains(DevProblem P, const double* __restrict__ pose_T, double
   const int len = P.chain_len[c];
   Se3 acc; se3_identity(acc);
   for (int i = 0; i < len; ++i) {
-    Se3 v; const double* p = pose_T + 12*(size_t)P.chain_pose[c*4+i];
+    Se3 v; const double* p = pose_T + 12*(size_t)P.chain_pose[c*MAXC+i];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v.R[k] = p[k];
     v.t[0] = p[9]; v.t[1] = p[10]; v.t[2] = p[11];
     se3_compose(v, acc, acc);
-    double* o = first + 12*(size_t)(c*4+i);
+    double* o = first + 12*(size_t)(c*MAXC+i);
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k] = acc.R[k];
     o[9] = acc.t[0]; o[10] = acc.t[1]; o[11] = acc.t[2];
@@ -95,10 +98,10 @@ __global__ void k_chains(DevProblem P, const double* __restrict__ pose_T, double
   }
   double Rc[9] = {1,0,0, 0,1,0, 0,0,1};
   for (int i = len - 1; i >= 0; --i) {
-    double* o = second + 9*(size_t)(c*4+i);
+    double* o = second + 9*(size_t)(c*MAXC+i);
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k] = Rc[k];
-    mat3_mul(Rc, pose_T + 12*(size_t)P.chain_pose[c*4+i], Rc);
+    mat3_mul(Rc, pose_T + 12*(size_t)P.chain_pose[c*MAXC+i], Rc);
   }
 }
 
@@ -232,9 +235,9 @@ __device__ inline void make_slot(int side, int link, const double* A /*2x3*/, co
                                  const double* Robs_last, SlotGeom& s) {
   Se3 F;
   if (side == 0) {
-    load_se3(first + 12*(size_t)(oc*4+link), F);
+    load_se3(first + 12*(size_t)(oc*MAXC+link), F);
     se3_apply(F, xw, s.base);
-    const double* R2 = second + 9*(size_t)(oc*4+link);
+    const double* R2 = second + 9*(size_t)(oc*MAXC+link);
     // B = A * R2
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -242,7 +245,7 @@ __device__ inline void make_slot(int side, int link, const double* A /*2x3*/, co
       for (int c = 0; c < 3; ++c) s.B[3*r+c] = A[3*r]*R2[c] + A[3*r+1]*R2[3+c] + A[3*r+2]*R2[6+c];
     s.sign = 1.0;
   } else {
-    load_se3(first + 12*(size_t)(sc*4+link), F);
+    load_se3(first + 12*(size_t)(sc*MAXC+link), F);
     se3_apply(F, xw, s.base);
     double Rrel[9];
     mat3_mul_t(Robs_last, F.R, Rrel);          // R(T_obs * T_src_i^-1)
@@ -269,10 +272,10 @@ k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const d
   const int olen = P.chain_len[oc], slen = P.chain_len[sc];
   const int mask = P.m_mask[m];
   const int lpt = P.pt_unk[pt];
-  if ((mask & 0xff) == 0 && lpt < 0) return;
+  if (mask == 0 && lpt < 0) return;
   Se3 Ts, To;
-  load_se3(first + 12*(size_t)(sc*4 + slen - 1), Ts);
-  load_se3(first + 12*(size_t)(oc*4 + olen - 1), To);
+  load_se3(first + 12*(size_t)(sc*MAXC + slen - 1), Ts);
+  load_se3(first + 12*(size_t)(oc*MAXC + olen - 1), To);
   const double x[3] = { pt_x[3*(size_t)pt], pt_x[3*(size_t)pt+1], pt_x[3*(size_t)pt+2] };
   double xw[3], xc[3];
   se3_apply_inv(Ts, x, xw);
@@ -331,10 +334,10 @@ k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const d
   const int s0 = P.slot_start[m], ns = P.slot_start[m+1] - s0;
   const int np = P.np;
   int ia = 0;
-  for (int bit_a = 0; bit_a < 8 && ia < ns; ++bit_a) {
+  for (int bit_a = 0; bit_a < 2*MAXC && ia < ns; ++bit_a) {
     if (!(mask & (1 << bit_a))) continue;
     SlotGeom sa; double Ja[12];
-    make_slot(bit_a >> 2, bit_a & 3, A, xw, first, second, oc, sc, To.R, sa);
+    make_slot(bit_a >> MAXC_LOG, bit_a & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sa);
     slot_jacobian(sa, Ja);
     const int ua = P.slot_unk[s0 + ia];
     double* b = bp + 6*(size_t)ua;
@@ -355,10 +358,10 @@ k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const d
     }
     // cross blocks with later slots
     int ib = ia + 1;
-    for (int bit_b = bit_a + 1; bit_b < 8 && ib < ns; ++bit_b) {
+    for (int bit_b = bit_a + 1; bit_b < 2*MAXC && ib < ns; ++bit_b) {
       if (!(mask & (1 << bit_b))) continue;
       SlotGeom sb; double Jb[12];
-      make_slot(bit_b >> 2, bit_b & 3, A, xw, first, second, oc, sc, To.R, sb);
+      make_slot(bit_b >> MAXC_LOG, bit_b & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sb);
       slot_jacobian(sb, Jb);
       const int ub = P.slot_unk[s0 + ib];
       if (ua > ub) {

@@ -76,7 +76,7 @@ template <class T> struct DevBuf {
 struct HPose { int id; int fixed; double T[12]; int unk; int active; };
 struct HPoint { int id; int fixed; double x[3]; int chain; int unk; int active; };
 struct HMeas { int chain, point, cam; double u, v, omega; };
-struct HChain { int len; int v[4]; };
+struct HChain { int len; int v[MCP_MAX_CHAIN]; };
 
 enum Stage { ST_EVAL = 0, ST_SELECT, ST_LIN, ST_SCHUR, ST_CHOL, ST_SOLVE, ST_UPDATE, ST_N };
 
@@ -93,7 +93,7 @@ struct mcp_ba {
   std::vector<HPoint> points;
   std::vector<HMeas> meas;
   std::vector<HChain> chains;
-  std::map<std::array<int, 5>, int> chain_map;
+  std::map<std::array<int, 1 + MCP_MAX_CHAIN>, int> chain_map;
   std::vector<int> id_kind, id_index;   // by id; kind 1 pose, 2 point
   int next_id = 1;
   bool dirty = true;
@@ -177,7 +177,7 @@ struct mcp_ba {
   size_t red_stride = 0, vinv_stride = 0, pack_stride = 0;
   bool start_rides = false;        // the iteration-start chi2 still has to be summed over the ranks
   int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
-  int speculate = 3;                 // speculative systems per solve; MCP_BA_SPECULATE=0 turns them off
+  int speculate = 3;                 // speculative systems per solve at most; MCP_BA_SPECULATE=0 turns them off
   int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
   hipGraphExec_t chol_exec[MAX_SYS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double* S() { return d_red.p + sys_cur*red_stride; }
@@ -198,14 +198,14 @@ struct mcp_ba {
   }
   int find_chain(const int* ids, int n) {
     if (n < 1 || n > MCP_MAX_CHAIN) return -1;
-    std::array<int, 5> key{n, -1, -1, -1, -1};
+    std::array<int, 1 + MCP_MAX_CHAIN> key; key.fill(-1); key[0] = n;
     for (int i = 0; i < n; ++i) {
       if (ids[i] <= 0 || ids[i] >= next_id || id_kind[ids[i]] != 1) return -1;
       key[1 + i] = id_index[ids[i]];
     }
     auto it = chain_map.find(key);
     if (it != chain_map.end()) return it->second;
-    HChain c; c.len = n; for (int i = 0; i < 4; ++i) c.v[i] = (i < n) ? key[1 + i] : 0;
+    HChain c; c.len = n; for (int i = 0; i < MCP_MAX_CHAIN; ++i) c.v[i] = (i < n) ? key[1 + i] : 0;
     chains.push_back(c);
     int idx = (int)chains.size() - 1; chain_map[key] = idx; return idx;
   }
@@ -320,7 +320,7 @@ int mcp_ba::prepare() {
     unsigned short mk = 0;
     const HChain& o = chains[oc]; const HChain& s = chains[sc];
     for (int i = 0; i < o.len; ++i) if (!poses[o.v[i]].fixed && !move_together(o, s, i)) mk |= (1 << i);
-    for (int i = 0; i < s.len; ++i) if (!poses[s.v[i]].fixed && !move_together(s, o, i)) mk |= (1 << (4 + i));
+    for (int i = 0; i < s.len; ++i) if (!poses[s.v[i]].fixed && !move_together(s, o, i)) mk |= (1 << (MAXC + i));
     return mk;
   };
   auto pair_mask = [&](int oc, int sc) -> unsigned short {
@@ -365,10 +365,10 @@ int mcp_ba::prepare() {
       const unsigned short mk = pair_mask(m.chain, points[pt].chain);
       m_mask[j] = mk;
       slot_start[j] = (int)slot_unk.size();
-      for (int b = 0; b < 8; ++b) {
+      for (int b = 0; b < 2*MAXC; ++b) {
         if (!(mk & (1 << b))) continue;
-        const HChain& c = (b < 4) ? chains[m.chain] : chains[points[pt].chain];
-        const int u = poses[c.v[b & 3]].unk;
+        const HChain& c = (b < MAXC) ? chains[m.chain] : chains[points[pt].chain];
+        const int u = poses[c.v[b & (MAXC - 1)]].unk;
         slot_unk.push_back(u);
         if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
         // slot_first: first contribution to its W block among the slots that write it through memory (every slot but
@@ -377,7 +377,7 @@ int mcp_ba::prepare() {
         if (lpt >= 0) {
           for (int t = ibase; t < (int)inc_unk.size(); ++t) if (inc_unk[t] == u) { inc = t; break; }
           if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); inc_state.push_back(0); }
-          if (b == 4) inc_state[inc] |= 1;
+          if (b == MAXC) inc_state[inc] |= 1;
           else { if (!(inc_state[inc] & 2)) first = 1; inc_state[inc] |= 2; }
         }
         slot_inc.push_back(inc); slot_first.push_back(first);
@@ -512,9 +512,9 @@ int mcp_ba::prepare() {
 
   lap("pattern+plan");
   // upload
-  std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*4), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
+  std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
   std::vector<unsigned char> pt_fixed(npoint);
-  for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < 4; ++i) chain_pose[c*4 + i] = chains[c].v[i]; }
+  for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
   for (int i = 0; i < npose; ++i) pose_unk[i] = poses[i].unk;
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
   if (d_cams.upload(cams, st) || d_chain_len.upload(chain_len, st) || d_chain_pose.upload(chain_pose, st) ||
@@ -531,8 +531,8 @@ int mcp_ba::prepare() {
       d_pr_start.upload(pr_start, st) || d_blk_dst.upload(blk_dst, st) || d_po_start.upload(po_start, st) || d_rhs_dst.upload(rhs_dst, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < 2; ++b)
-    if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*4*12) ||
-        d_second[b].alloc(nc*4*9) || d_last[b].alloc(nc*12) || d_chi2[b].alloc(nmeas)) return -1;
+    if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*MAXC*12) ||
+        d_second[b].alloc(nc*MAXC*9) || d_last[b].alloc(nc*12) || d_chi2[b].alloc(nmeas)) return -1;
   const size_t n2 = (size_t)np*np;
   const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
   red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
@@ -1057,7 +1057,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
                       const mcp_ba_params* params) {
   if (!cams || ncam <= 0 || ncam > 255) { set_err("mcp_ba_create: need 1..255 cameras"); return nullptr; }
   for (int i = 0; i < ncam; ++i)
-    if (cams[i].n_inv <= 0 || cams[i].n_inv > MCP_MAX_INV) { set_err("mcp_ba_create: camera without inverse polynomial (Newton fallback unsupported)"); return nullptr; }
+    if (cams[i].n_inv < 0 || cams[i].n_inv > MCP_MAX_INV) { set_err("mcp_ba_create: bad inverse polynomial length"); return nullptr; }      // 0 = Newton mode
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_err("mcp_ba_create: no HIP device available (the HIP path has no CPU fallback)"); return nullptr; }
   mcp_ba_params p;
@@ -1327,7 +1327,15 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
   HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
   HIPCK(hipMemset(f.p, 0, 16));
   CholPlan plan;
-  if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_dense_spd_solve: plan allocation failed"); return -1; }
+  std::vector<unsigned char> pattern;
+#ifdef MCP_CHOL_PROF
+  if (const char* e = getenv("MCP_CHOL_TEST_BAND")) {      // profiling only: a banded + bordered tile pattern like a loop trajectory's (results are not checked)
+    const int bw = atoi(e), ntc = (n + CH_NB - 1)/CH_NB;
+    pattern.assign((size_t)ntc*ntc, 0);
+    for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (i - j <= bw || i >= ntc - bw) pattern[(size_t)i*ntc + j] = 1;
+  }
+#endif
+  if (plan.build(n, pattern)) { set_err("mcp_dense_spd_solve: plan allocation failed"); return -1; }
 #ifdef MCP_CHOL_PROF
   {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

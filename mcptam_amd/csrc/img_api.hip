@@ -391,7 +391,7 @@ int mcp_sbi_iterate_last(mcp_kf* k, int iterations, double se2[6], double* score
 // SmallBlurryImage::SE3fromSE2 (:250-310): two points, three Gauss-Newton steps on SO3 -- control-plane arithmetic, run on the
 // host with the same camera functions the kernels use (ba_device.h is __host__ __device__)
 int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_camera* ct, double R[9]) {
-  if (!cs || !ct || cs->n_inv <= 0) return img_fail("mcp_sbi_se3_from_se2: bad camera");
+  if (!cs || !ct || cs->n_inv < 0) return img_fail("mcp_sbi_se3_from_se2: bad camera");
   const double c[2] = { SBI_W/2, SBI_H/2 };
   const double off[2][2] = { { 5, 0 }, { -5, 0 } };
   double turned[2][2], orig[2][3];
@@ -441,7 +441,7 @@ int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_ca
 
 int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12], const double cfb[12], int n, const mcp_td_in* in,
                      int range, int subpix_its, int exhaustive, mcp_td_out* out) {
-  if (n < 0 || !cam || cam->n_inv <= 0) return img_fail("mcp_track_search: bad arguments");
+  if (n < 0 || !cam || cam->n_inv < 0) return img_fail("mcp_track_search: bad arguments");
   if (n == 0) return 0;
   ICK(hipSetDevice(target->device));
   std::vector<DevTdIn> h(n);

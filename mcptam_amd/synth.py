@@ -189,7 +189,7 @@ def make_rig(n_cams, lever=0.1):
 def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", seed=DEFAULT_SEED,
                  radius=5.0, arc_step=None, pixel_sigma=0.5, outlier_frac=0.02, pose_sigma=(0.02, 0.5),
                  depth_sigma=0.05, n_fixed_points=0, cam_params=DEFAULT_CAM_PARAMS, image_size=(640, 480),
-                 noise=True, perturb=True, k_near=12, n_fixed_mkf=1, shard=0):
+                 noise=True, perturb=True, k_near=12, n_fixed_mkf=1, shard=0, newton_camera=False):
     """SURVEY.md 8(d) generator.  Returns a Problem with exactly n_points points and
     per_point*n_points measurements.
 
@@ -198,7 +198,8 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
     of the map)."""
     rng = np.random.default_rng([seed, 1 + shard])      # points, measurements, noise
     rng_pose = np.random.default_rng([seed, 0])        # pose perturbation: identical on every shard
-    cam = TaylorCamera(cam_params, image_size, image_size, image_size)
+    # newton_camera: the camera model without a usable inverse polynomial (linear inverse + Newton, TaylorCamera.cc:159-176)
+    cam = TaylorCamera(cam_params, image_size, image_size, image_size, force_newton=newton_camera)
     cams = [cam] * n_cams
     cam_R, cam_t = make_rig(n_cams)
     # trajectory: loop (or arc) of radius `radius` with sinusoidal height

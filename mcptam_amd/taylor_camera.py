@@ -44,7 +44,10 @@ def polyval_low_first(coeffs, x):
 
 
 class TaylorCamera:
-    def __init__(self, params9, calib_size, fullscale_size, image_size):
+    def __init__(self, params9, calib_size, fullscale_size, image_size, force_newton=False):
+        # force_newton: behave as if no inverse polynomial of degree <= 30 met the 1e-4 limit, i.e. the reference's slow path
+        # (TaylorCamera.cc:159-176): a linear inverse model as the starting point + Newton's method on the forward polynomial
+        self.force_newton = bool(force_newton)
         self.params = np.asarray(params9, dtype=np.float64).copy()
         self.calib_size = np.asarray(calib_size, dtype=np.float64)
         self.fullscale_size = np.asarray(fullscale_size, dtype=np.float64)
@@ -63,11 +66,14 @@ class TaylorCamera:
         self.largest_radius = math.sqrt(float(corner @ corner))                 # :146
         self.max_rho = 1.0 * self.largest_radius                                # :149
         self.min_theta = math.atan(float(polyval_low_first(self.poly, self.max_rho)) / self.max_rho)  # :154
-        inv = self.find_inv_poly_using_roots(-1, 1e-4)                          # :159
+        inv = None if self.force_newton else self.find_inv_poly_using_roots(-1, 1e-4)   # :159
+        self.using_inverse_poly = inv is not None
         if inv is None:
-            raise ValueError("TaylorCamera: no inverse polynomial of degree <= %d within 1e-4 "
-                             "(the reference falls back to Newton's method, TaylorCamera.cc:161-176; "
-                             "that mode is not supported by the HIP path)" % MAX_INV_DEGREE)
+            # :161-176: linear inverse model (degree-1 fit; it also refreshes theta mean / std) and the derivative of the
+            # forward polynomial for Newton's method
+            self.linear_inv_coeffs = self.find_inv_poly_using_roots(1, 0.1)
+            self.poly_deriv = self.poly[1:] * np.arange(1, 5)
+            inv = self.linear_inv_coeffs
         self.inv_coeffs = inv
         self.affine = np.array([[scale[0] * p[6], scale[1] * p[7]],
                                 [scale[0] * p[8], scale[1] * 1.0]])             # :183-186
@@ -124,13 +130,33 @@ class TaylorCamera:
         safe = np.where(norm == 0, 1.0, norm)
         theta = np.where(norm == 0, math.pi / 2, np.arctan(xc[:, 2] / safe))
         invalid = theta < self.min_theta
-        rho = np.where(norm == 0, 0.0, polyval_low_first(self.inv_coeffs, (theta - self.theta_mean) / self.theta_std))
+        rho = polyval_low_first(self.inv_coeffs, (theta - self.theta_mean) / self.theta_std)
+        if not self.using_inverse_poly:
+            rho = self._newton(xc[:, 2] / safe, rho)
+        rho = np.where(norm == 0, 0.0, rho)
         cphi = np.where(norm == 0, 0.0, xc[:, 0] / safe)
         sphi = np.where(norm == 0, 0.0, xc[:, 1] / safe)
         d = np.stack([cphi * rho, sphi * rho], axis=1)
         uv = d @ self.affine.T + self.center
         invalid |= ~((uv[:, 0] >= 0) & (uv[:, 0] < self.image_size[0]) & (uv[:, 1] >= 0) & (uv[:, 1] < self.image_size[1]))
         return uv, invalid
+
+    # TaylorCamera::FindRootWithNewton, TaylorCamera.cc:293-315 (error limit 0.01, at most 50 iterations, TaylorCamera.h:267)
+    def _newton(self, tan_theta, rho0):
+        rho = np.array(rho0, dtype=np.float64)
+        active = np.ones(rho.shape, dtype=bool)
+        for _ in range(50):
+            c1 = self.poly[1] - tan_theta
+            f = (((self.poly[4] * rho + self.poly[3]) * rho + self.poly[2]) * rho + c1) * rho + self.poly[0]
+            d0 = self.poly_deriv[0] - tan_theta
+            fp = ((self.poly_deriv[3] * rho + self.poly_deriv[2]) * rho + self.poly_deriv[1]) * rho + d0
+            new = rho - f / fp
+            err = np.abs(new - rho)
+            rho = np.where(active, new, rho)
+            active &= err > 0.01
+            if not active.any():
+                break
+        return rho
 
     # TaylorCamera::UnProject, TaylorCamera.cc:319-347
     def unproject(self, uv):
@@ -152,7 +178,8 @@ class TaylorCamera:
         s.theta_mean, s.theta_std = self.theta_mean, self.theta_std
         if len(self.inv_coeffs) > 31:
             raise ValueError("inverse polynomial too long")
-        s.n_inv = len(self.inv_coeffs)
+        # n_inv == 0 selects the Newton mode; inv_coeffs[0..1] then hold the linear inverse model (mv2LinearInvCoeffs)
+        s.n_inv = len(self.inv_coeffs) if self.using_inverse_poly else 0
         for i, c in enumerate(self.inv_coeffs):
             s.inv_coeffs[i] = c
         return s

@@ -87,6 +87,17 @@ def _ip(a):
     return a.ctypes.data_as(c_int_p)
 
 
+def cam_project(cam, xc):
+    """orc_cam_project: (uv, D (2x2 projection derivatives, row-major), invalid flag) of a camera-frame point."""
+    import numpy as np
+    st = cam.to_struct()
+    xc = np.ascontiguousarray(xc, dtype=np.float64)
+    uv = np.zeros(2)
+    D = np.zeros(4)
+    inv = lib().orc_cam_project(ctypes.byref(st), _dp(xc), _dp(uv), _dp(D))
+    return uv, D.reshape(2, 2), bool(inv)
+
+
 class OracleBundle:
     """ChainBundle-shaped wrapper over the oracle (same surface as mcptam_amd.ChainBundle)."""
 
@@ -192,9 +203,11 @@ class OracleBundle:
         self._L.orc_ba_eval(self._h, _dp(chi2), _dp(err))
         return chi2, err
 
+    MAX_CHAIN = 8        # ORC_MAX_CHAIN: the Jacobian mask has observer links in bits [0, 8), source links in [8, 16), the point in bit 16
+
     def Jacobian(self, m, numeric=False, delta=1e-6):
-        jo = np.zeros((4, 2, 6))
-        js = np.zeros((4, 2, 6))
+        jo = np.zeros((self.MAX_CHAIN, 2, 6))
+        js = np.zeros((self.MAX_CHAIN, 2, 6))
         jp = np.zeros((2, 3))
         if numeric:
             mask = self._L.orc_ba_numeric_jacobian(self._h, int(m), float(delta), _dp(jo), _dp(js), _dp(jp))

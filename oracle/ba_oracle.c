@@ -199,7 +199,20 @@ int orc_cam_project(const orc_camera* cam, const double xc[3], double uv[2], dou
   int invalid = (dTheta < cam->min_theta);                /* :223 */
   if (dNorm == 0) { rho = 0; cphi = 0; sphi = 0; }        /* :225-230 */
   else {
-    rho = polyval(cam->inv_coeffs, cam->n_inv, (dTheta - cam->theta_mean)/cam->theta_std); /* :261-262 */
+    if (cam->n_inv > 0) rho = polyval(cam->inv_coeffs, cam->n_inv, (dTheta - cam->theta_mean)/cam->theta_std); /* :261-262 */
+    else {                                                /* :263-268 + FindRootWithNewton :293-315 (dErrorLimit 0.01, nMaxIter 50) */
+      const double dTanTheta = xc[2]/dNorm;
+      double c5[5] = { cam->params[0], 0 - dTanTheta, cam->params[1], cam->params[2], cam->params[3] };
+      double d4[4] = { 0 - dTanTheta, 2*cam->params[1], 3*cam->params[2], 4*cam->params[3] };
+      double prev = polyval(cam->inv_coeffs, 2, (dTheta - cam->theta_mean)/cam->theta_std);
+      rho = prev;
+      for (int i = 0; i < 50; i++) {
+        rho = prev - polyval(c5, 5, prev)/polyval(d4, 4, prev);
+        const double dError = fabs(rho - prev);             /* abs(double) [3P-memory: resolves to std::abs through TooN] */
+        prev = rho;
+        if (!(dError > 0.01)) break;
+      }
+    }
     cphi = xc[0]/dNorm; sphi = xc[1]/dNorm;               /* :271-272 */
   }
   const double dc0 = cphi*rho, dc1 = sphi*rho;            /* :279-280 */
@@ -520,7 +533,7 @@ static int linearize(const orc_ba* h, const omeas* m, double Jo[ORC_MAX_CHAIN][1
       Js[i][k]     = -1*(D[0]*s0 + D[1]*s1);
       Js[i][6 + k] = -1*(D[2]*s0 + D[3]*s1);
     }
-    mask |= 1 << (4 + i);
+    mask |= 1 << (ORC_MAX_CHAIN + i);
   }
   if (!p->fixed) {                                                       /* :589-684 */
     double Rp[9], dir[3], rho;
@@ -538,7 +551,7 @@ static int linearize(const orc_ba* h, const omeas* m, double Jo[ORC_MAX_CHAIN][1
       Jp[k]     = -1*(D[0]*s0 + D[1]*s1);                                /* :676-682 */
       Jp[3 + k] = -1*(D[2]*s0 + D[3]*s1);
     }
-    mask |= 1 << 8;
+    mask |= 1 << (2*ORC_MAX_CHAIN);
   }
   return mask;
 }
@@ -579,7 +592,7 @@ int orc_ba_numeric_jacobian(orc_ba* h, int mi, double delta, double* J_obs, doub
         J[i*12 + d]     = scalar*(ep[0] - m->e[0]);
         J[i*12 + 6 + d] = scalar*(ep[1] - m->e[1]);
       }
-      mask |= 1 << (side*4 + i);
+      mask |= 1 << (side*ORC_MAX_CHAIN + i);
     }
   }
   if (!p->fixed) {
@@ -592,7 +605,7 @@ int orc_ba_numeric_jacobian(orc_ba* h, int mi, double delta, double* J_obs, doub
       memcpy(p->x, bak, 24);
       J_pt[d] = scalar*(ep[0] - m->e[0]); J_pt[3 + d] = scalar*(ep[1] - m->e[1]);
     }
-    mask |= 1 << 8;
+    mask |= 1 << (2*ORC_MAX_CHAIN);
   }
   update_chains(h); compute_error(h, m);
   return mask;
@@ -671,7 +684,7 @@ static void build_system(orc_ba* h) {
     /* slots */
     const double* J[2*ORC_MAX_CHAIN]; int U[2*ORC_MAX_CHAIN]; int ns = 0;
     for (int i = 0; i < oc->len; i++) if (mask & (1 << i)) { J[ns] = Jo[i]; U[ns++] = h->poses[oc->v[i]].unk; }
-    for (int i = 0; i < sc->len; i++) if (mask & (1 << (4+i))) { J[ns] = Js[i]; U[ns++] = h->poses[sc->v[i]].unk; }
+    for (int i = 0; i < sc->len; i++) if (mask & (1 << (ORC_MAX_CHAIN+i))) { J[ns] = Js[i]; U[ns++] = h->poses[sc->v[i]].unk; }
     for (int a = 0; a < ns; a++) {
       double* b = h->bp + 6*U[a];
       for (int r = 0; r < 6; r++) b[r] += -w*(J[a][r]*m->e[0] + J[a][6+r]*m->e[1]);
@@ -683,7 +696,7 @@ static void build_system(orc_ba* h) {
         }
       }
     }
-    if (mask & (1 << 8)) {
+    if (mask & (1 << (2*ORC_MAX_CHAIN))) {
       double* V = h->V + 9*(size_t)p->unk; double* g = h->g + 3*(size_t)p->unk;
       for (int r = 0; r < 3; r++) {
         g[r] += -w*(Jp[r]*m->e[0] + Jp[3+r]*m->e[1]);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_CHAIN 4
+#define ORC_MAX_CHAIN 8
 #define ORC_MAX_INV   31
 
 /* Post-RefreshParams state of a TaylorCamera (TaylorCamera.cc:84-198). */

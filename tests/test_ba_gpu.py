@@ -419,10 +419,12 @@ def test_speculative_solves_do_not_change_the_iteration(gpu_required, monkeypatc
         assert r["outliers"] == base["outliers"]
 
 
-def test_four_link_chains_with_mixed_fixed_and_free_links(gpu_required):
-    """Generic pose chains (any length <= 4, any link fixed or free): chain {base_k, arm (free, shared by all),
-    mount (fixed), camera_c (c = 0 free, c = 1 fixed)}.  PoseChainHelper's first/second transforms, MoveTogether's structural
-    zeros and the Jacobians of inner links (src/ChainBundle.cc:120-199, 485-586) against the oracle."""
+@pytest.mark.parametrize("extra_links", [0, 2, 4])
+def test_long_chains_with_mixed_fixed_and_free_links(gpu_required, extra_links):
+    """Generic pose chains (the reference accepts any length, src/ChainBundle.cc:1220-1230; here up to MCP_MAX_CHAIN = 8, any
+    link fixed or free): chain {base_k, arm (free, shared by all), mount (fixed), [joints: free / fixed alternating],
+    camera_c (c = 0 free, c = 1 fixed)} -- 4, 6 and 8 links.  PoseChainHelper's first/second transforms, MoveTogether's
+    structural zeros and the Jacobians of inner links (src/ChainBundle.cc:120-199, 485-586) against the oracle."""
     from mcptam_amd import synth
     from mcptam_amd.taylor_camera import TaylorCamera
     rng = np.random.default_rng(11)
@@ -439,9 +441,13 @@ def test_four_link_chains_with_mixed_fixed_and_free_links(gpu_required):
     bases = [rand_pose(0.15, 0.4) for _ in range(nb)]
     arm, mount = rand_pose(0.05, 0.05), rand_pose(0.05, 0.05)
     cams2 = [rand_pose(0.02, 0.02), (synth.rot_z(0.3) @ np.eye(3), np.array([0.1, 0.0, 0.0]))]
+    joints = [rand_pose(0.03, 0.03) for _ in range(extra_links)]          # joint j is free for even j, fixed for odd j
 
     def chain_T(k, c):
-        return mul(cams2[c], mul(mount, mul(arm, bases[k])))
+        T = mul(mount, mul(arm, bases[k]))
+        for J in joints:
+            T = mul(J, T)
+        return mul(cams2[c], T)
 
     world = np.stack([rng.uniform(-2, 2, 400), rng.uniform(-1.5, 1.5, 400), rng.uniform(4, 9, 400)], axis=1)
 
@@ -456,13 +462,14 @@ def test_four_link_chains_with_mixed_fixed_and_free_links(gpu_required):
         b_id = [bundle.AddPose(*P(bases[k], 1 if k else 0), k == 0) for k in range(nb)]
         arm_id = bundle.AddPose(*P(arm, 1), False)
         mount_id = bundle.AddPose(*mount, True)
+        joint_id = [bundle.AddPose(*P(J, 0.5 if j % 2 == 0 else 0), j % 2 == 1) for j, J in enumerate(joints)]
         cam_id = [bundle.AddPose(*P(cams2[0], 1), False), bundle.AddPose(*cams2[1], True)]
         pts = []
         for i, X in enumerate(world):
             k, c = i % nb, (i // nb) % 2
             R, t = chain_T(k, c)
             x = (R @ X + t) * (1.0 + (0.03*pert.normal() if perturb else 0.0))
-            pts.append(bundle.AddPoint(x, [b_id[k], arm_id, mount_id, cam_id[c]], False))
+            pts.append(bundle.AddPoint(x, [b_id[k], arm_id, mount_id] + joint_id + [cam_id[c]], False))
         nm = 0
         for i, X in enumerate(world):
             for k in range(nb):
@@ -474,9 +481,9 @@ def test_four_link_chains_with_mixed_fixed_and_free_links(gpu_required):
                     if inv[0]:
                         continue
                     lvl = (i + k) % 3
-                    bundle.AddMeas([b_id[k], arm_id, mount_id, cam_id[c]], pts[i], uv[0] + 0.3*np.array([np.sin(i + k), np.cos(i*c + 1)]), 4.0**lvl, 0)
+                    bundle.AddMeas([b_id[k], arm_id, mount_id] + joint_id + [cam_id[c]], pts[i], uv[0] + 0.3*np.array([np.sin(i + k), np.cos(i*c + 1)]), 4.0**lvl, 0)
                     nm += 1
-        return b_id + [arm_id, cam_id[0]], pts, nm
+        return b_id + [arm_id, cam_id[0]] + joint_id[::2], pts, nm
 
     g, o = _gpu([cam]), _orc([cam])
     ids_g, pts_g, nm = build(g, True)
@@ -614,3 +621,23 @@ def test_zero_iterations_and_runtime_error_code(gpu_required):
     assert g.Compute(0) == -1
     g.abort.value = 1
     assert g.Compute(0) == 0
+
+
+@pytest.mark.parametrize("cfg,iters", [("tiny", 10), ("c2small", 8)])
+def test_newton_fallback_camera(gpu_required, cfg, iters):
+    """Cameras without an inverse polynomial (n_inv == 0): linear inverse model + FindRootWithNewton in the kernels
+    (TaylorCamera.cc:159-176, 258-270, 293-315)."""
+    from mcptam_amd import synth
+    kw = dict(newton_camera=True)
+    p = synth.make_config("c2", n_mkf=12, n_points=1500, **kw) if cfg == "c2small" else synth.make_config(cfg, **kw)
+    assert p.cams[0].to_struct().n_inv == 0
+    g, o = _gpu(p.cams), _orc(p.cams)
+    p.populate(g)
+    p.populate(o)
+    chi_g, err_g = g.Eval(p.n_meas)
+    chi_o, err_o = o.Eval()
+    assert rel_err(err_g, err_o) < 1e-9
+    gpu = run_bundle(_gpu(p.cams), p, iters)
+    ref = run_bundle(_orc(p.cams), p, iters)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0 and gpu["outliers"] == ref["outliers"]

@@ -437,3 +437,22 @@ def test_c5_frame_size_1280x960(gpu_required):
     clean = np.abs(og["templ"].astype(int) - oo["templ"].astype(int)).max(axis=1) == 0
     if clean.all() and np.array_equal(og["found"], oo["found"]):
         assert np.allclose(pg[0], po[0], atol=1e-9) and np.allclose(pg[1], po[1], atol=1e-9)
+
+
+def test_track_search_with_newton_fallback_camera(gpu_required, scene):
+    """The tracker's projection with a camera that has no inverse polynomial (n_inv == 0, TaylorCamera.cc:258-270)."""
+    from mcptam_amd.keyframe import track_search
+    from mcptam_amd.taylor_camera import TaylorCamera
+    from oracle import oracle_track_search
+    cam = TaylorCamera(scene["cam"].params, (640, 480), (640, 480), (640, 480), force_newton=True)
+    assert cam.to_struct().n_inv == 0
+    gA, oA = _pair(640, 480)
+    gB, oB = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    gB.MakeKeyFrame_Lite(scene["imgB"]); oB.MakeKeyFrame_Lite(scene["imgB"])
+    pts = _points(scene, gA, oA)[:300]
+    I = (np.eye(3), np.zeros(3))
+    og = track_search(gB, cam, scene["poseB"], I, pts, 10, 8, False)
+    oo = oracle_track_search(oB, cam, scene["poseB"], I, pts, 10, 8, False)
+    assert_track_equal(og, oo)
+    assert og["found"].sum() > 100

@@ -33,11 +33,11 @@ def test_analytic_jacobians_match_central_differences(cfg):
         mask2, jo2, js2, jp2 = o.Jacobian(m, numeric=True, delta=1e-6)
         # the analytic code zeroes blocks whose chains "move together"; the numeric code perturbs every free vertex
         scale = max(np.abs(jo2).max(), np.abs(js2).max(), np.abs(jp2).max(), 1e-9)
-        for a, b, bits in ((jo, jo2, 0), (js, js2, 4)):
-            for i in range(4):
+        for a, b, bits in ((jo, jo2, 0), (js, js2, o.MAX_CHAIN)):
+            for i in range(o.MAX_CHAIN):
                 if mask & (1 << (bits + i)):
                     worst = max(worst, np.abs(a[i] - b[i]).max() / scale)
-        if mask & 256:
+        if mask & (1 << (2 * o.MAX_CHAIN)):
             worst = max(worst, np.abs(jp - jp2).max() / scale)
     assert worst < 2e-5
 
@@ -55,7 +55,7 @@ def test_move_together_blocks_are_structurally_zero():
     for m in same[:10]:
         # populate() keeps add order == problem order
         mask, jo, js, jp = o.Jacobian(m)
-        assert not (mask & 1) and not (mask & 16)
+        assert not (mask & 1) and not (mask & (1 << o.MAX_CHAIN))
         _, jo2, js2, _ = o.Jacobian(m, numeric=True, delta=1e-6)
         assert np.abs(jo2[0] + js2[0]).max() < 1e-4 * max(np.abs(jo2[0]).max(), 1.0)
 
@@ -330,7 +330,7 @@ def test_oracle_long_chain_jacobians_sum_to_the_total_derivative():
         scale = max(np.abs(no).max(), np.abs(ns).max(), np.abs(npt).max(), 1.0)
         assert np.abs(jp - npt).max() < 1e-5*scale
         if (k, c) == (k2, c2):                       # same chain on both sides: every pose link moves together
-            assert (mask & 0xff) == 0 and np.all(jo == 0) and np.all(js == 0)
+            assert (mask & 0xffff) == 0 and np.all(jo == 0) and np.all(js == 0)
             continue
         # link 0: different vertices on the two sides unless k == k2
         if k != k2:
@@ -1227,3 +1227,26 @@ def test_cpu_baseline_variants_reproduce_the_oracle(solver):
     rep = compare_runs(runs[1], runs[0], tol_state=1e-10)
     assert rep["branch_flips"] == 0
     assert runs[0]["outliers"] == runs[1]["outliers"]
+
+
+def test_newton_fallback_camera_matches_the_inverse_polynomial_camera():
+    """TaylorCamera without a usable inverse polynomial (TaylorCamera.cc:159-176, 258-270): linear inverse model + Newton on the
+    forward polynomial.  Oracle vs the Python model, and both close to the inverse-polynomial camera (whose fit error is <= 1e-4)."""
+    import oracle
+    from mcptam_amd import synth
+    from mcptam_amd.taylor_camera import TaylorCamera
+    size = (640, 480)
+    cam_p = TaylorCamera(synth.DEFAULT_CAM_PARAMS, size, size, size)
+    cam_n = TaylorCamera(synth.DEFAULT_CAM_PARAMS, size, size, size, force_newton=True)
+    assert cam_n.to_struct().n_inv == 0 and cam_p.to_struct().n_inv > 2
+    rng = np.random.default_rng(3)
+    xc = rng.normal(size=(4000, 3)) * np.array([1.0, 1.0, 0.6]) + np.array([0, 0, 0.8])
+    uv_p, inv_p = cam_p.project(xc)
+    uv_n, inv_n = cam_n.project(xc)
+    ok = ~inv_p & ~inv_n
+    assert ok.sum() > 2000
+    assert np.abs(uv_p[ok] - uv_n[ok]).max() < 2e-2            # Newton stops at a 0.01 step; the polynomial fit is good to 1e-4
+    for i in np.flatnonzero(ok)[:500]:
+        uv, D, invalid = oracle.cam_project(cam_n, xc[i])
+        assert not invalid
+        assert np.abs(uv - uv_n[i]).max() < 1e-9
