@@ -338,6 +338,51 @@ CONFIGS = {
 }
 
 
+def recent_window(p, n_recent=3, newest=None):
+    """The local bundle BundleAdjusterBase::BundleAdjustRecent builds from a map (src/BundleAdjusterBase.cc:188-265): the newest
+    MKF and its `n_recent` closest MKFs, of which only the movable ones are kept (snRecentNum, :47), are adjusted; the points are
+    those measured from them by at least two KeyFrames; every other MKF that measures one of those points enters FIXED; the
+    measurements are all measurements of those points (BundleAdjusterMulti.cc:168-200).  Returns a new multi-mode Problem over
+    the MKFs involved (in map order) plus `window` = dict(mkf=map indices kept, adjust=map indices adjusted, points=map point
+    indices).  MKF distance is the distance between base origins (the reference takes the closest pair of KeyFrame centres)."""
+    assert p.mode == "multi"
+    newest = p.n_mkf - 1 if newest is None else int(newest)
+    centres = -np.einsum("kji,kj->ki", p.base_R, p.base_t)                     # -R^T t
+    d = np.linalg.norm(centres - centres[newest], axis=1)
+    d[newest] = np.inf
+    closest = np.argsort(d, kind="stable")[:n_recent]
+    adjust = {newest} | {int(k) for k in closest if not p.base_fixed[k]}
+    adj_mask = np.zeros(p.n_mkf, dtype=bool)
+    adj_mask[list(adjust)] = True
+    # points seen from the adjusted MKFs, measured by >= 2 KeyFrames overall
+    kf_key = p.ms_mkf.astype(np.int64) * len(p.cams) + p.ms_cam
+    per_point = np.zeros(p.n_points, dtype=np.int64)
+    uniq = np.unique(np.stack([p.ms_pt.astype(np.int64), kf_key], axis=1), axis=0)
+    np.add.at(per_point, uniq[:, 0], 1)
+    pts_mask = np.zeros(p.n_points, dtype=bool)
+    pts_mask[p.ms_pt[adj_mask[p.ms_mkf]]] = True
+    pts_mask &= per_point >= 2
+    ms_keep = pts_mask[p.ms_pt]
+    mkf_keep = np.zeros(p.n_mkf, dtype=bool)
+    mkf_keep[p.ms_mkf[ms_keep]] = True
+    mkf_keep[p.pt_src[pts_mask, 0]] = True
+    mkf_keep |= adj_mask
+    kmap = -np.ones(p.n_mkf, dtype=np.int64)
+    kmap[mkf_keep] = np.arange(mkf_keep.sum())
+    pmap = -np.ones(p.n_points, dtype=np.int64)
+    pmap[pts_mask] = np.arange(pts_mask.sum())
+    src = p.pt_src[pts_mask].copy()
+    src[:, 0] = kmap[src[:, 0]]
+    q = Problem(cams=p.cams, mode="multi", n_mkf=int(mkf_keep.sum()), base_R=p.base_R[mkf_keep].copy(), base_t=p.base_t[mkf_keep].copy(),
+                base_fixed=~adj_mask[mkf_keep], cam_R=p.cam_R, cam_t=p.cam_t, pt_x=p.pt_x[pts_mask].copy(), pt_src=src.astype(p.pt_src.dtype),
+                pt_fixed=p.pt_fixed[pts_mask].copy(), ms_mkf=kmap[p.ms_mkf[ms_keep]].astype(p.ms_mkf.dtype), ms_cam=p.ms_cam[ms_keep].copy(),
+                ms_pt=pmap[p.ms_pt[ms_keep]].astype(p.ms_pt.dtype), ms_uv=p.ms_uv[ms_keep].copy(), ms_level=p.ms_level[ms_keep].copy(),
+                true_base_R=None if p.true_base_R is None else p.true_base_R[mkf_keep], true_base_t=None if p.true_base_t is None else p.true_base_t[mkf_keep],
+                true_world=None if p.true_world is None else p.true_world[pts_mask])
+    q.window = dict(mkf=np.flatnonzero(mkf_keep), adjust=np.array(sorted(adjust)), points=np.flatnonzero(pts_mask))
+    return q
+
+
 def make_config(name, **over):
     """BASELINE configuration by name; keyword overrides go to make_problem."""
     kw = dict(CONFIGS[name])

@@ -1,0 +1,195 @@
+// Tracker_gpu.cc -- MI355X bodies of Tracker::SearchForPoints and Tracker::CalcPoseUpdate.
+//
+// Replace /root/reference/src/Tracker.cc:1297-1377 (SearchForPoints) and :1379-1512 (CalcPoseUpdate): delete those two member
+// functions there (or fence them with #ifndef MCPTAM_HIP) and add this file to the library's sources.  The tracker keeps all of its
+// control flow -- FindPVS, the level buckets, the 1000-patch budget, the shuffles, the coarse / fine stages, the motion model -- and
+// calls these two members exactly where it did (src/Tracker.cc:841-906, 1027-1075).  The per-point inner loops (TrackerData::Project /
+// CalcJacobian, PatchFinder::MakeTemplateCoarseCont / FindPatchCoarse / IterateSubPixToConvergence, the WLS accumulation) run as one
+// batched device call each.  Needs KeyFrame::mpDev (shim/KeyFrame_gpu.cc) and shim/CameraExport.h.
+#include <mcptam/Tracker.h>
+#include <mcptam/TrackerData.h>
+#include <mcptam/MapPoint.h>
+#include <mcptam/KeyFrame.h>
+#include <mcptam/LevelHelpers.h>
+#include <mcp_img.h>
+#include "CameraExport.h"
+#include <TooN/SVD.h>
+#include <ros/ros.h>
+
+using namespace TooN;
+
+
+namespace
+{
+void ToArray12(const SE3<>& se3, double a[12])
+{
+  const Matrix<3>& m3 = se3.get_rotation().get_matrix();
+  for(int i = 0; i < 3; ++i)
+  {
+    for(int j = 0; j < 3; ++j)
+      a[3*i + j] = m3(i, j);
+    a[9 + i] = se3.get_translation()[i];
+  }
+}
+}  // namespace
+
+// Find points in the image: one device call for the whole vector (include/mcp_img.h, mcp_track_search)
+int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, int nRange, int nSubPixIts, bool bExhaustive)
+{
+  if(vTD.empty())
+    return 0;
+
+  KeyFrame& kf = *mpCurrentMKF->mmpKeyFrames[cameraName];
+  ROS_ASSERT(kf.mpDev);
+
+  std::vector<mcp_td_in> vIn(vTD.size());
+  std::vector<mcp_td_out> vOut(vTD.size());
+  for(unsigned i = 0; i < vTD.size(); ++i)
+  {
+    MapPoint& point = vTD[i]->mPoint;
+    mcp_td_in& in = vIn[i];
+    for(int k = 0; k < 3; ++k)
+    {
+      in.world_pos[k] = point.mv3WorldPos[k];
+      in.pixel_right_w[k] = point.mv3PixelRight_W[k];
+      in.pixel_down_w[k] = point.mv3PixelDown_W[k];
+    }
+    ROS_ASSERT(point.mpPatchSourceKF && point.mpPatchSourceKF->mpDev);   // source pyramids stay resident on the device
+    in.source_kf = point.mpPatchSourceKF->mpDev;
+    in.source_level = point.mnSourceLevel;
+    in.center_x = point.mirCenter.x;
+    in.center_y = point.mirCenter.y;
+    in.fixed = point.mbFixed ? 1 : 0;
+  }
+
+  mcp_camera cam = mcptam_hip::CameraExport::Make(mmCameraModels[cameraName]);
+  double adBaseFromWorld[12], adCamFromBase[12];
+  ToArray12(mpCurrentMKF->mse3BaseFromWorld, adBaseFromWorld);
+  ToArray12(kf.mse3CamFromBase, adCamFromBase);
+
+  if(mcp_track_search(kf.mpDev, &cam, adBaseFromWorld, adCamFromBase, (int)vTD.size(), &vIn[0], nRange, nSubPixIts, bExhaustive ? 1 : 0, &vOut[0]) != 0)
+  {
+    ROS_FATAL_STREAM("Tracker::SearchForPoints: "<<mcp_last_error());
+    ros::shutdown();
+    return 0;
+  }
+
+  int nFound = 0;
+  for(unsigned i = 0; i < vTD.size(); ++i)
+  {
+    TrackerData& td = *vTD[i];
+    const mcp_td_out& out = vOut[i];
+
+    // the device re-derives the projection it searches around: identical to what FindPVS left in the TrackerData
+    td.mv2Image = makeVector(out.image[0], out.image[1]);
+    td.mm2CamDerivs(0, 0) = out.cam_derivs[0]; td.mm2CamDerivs(0, 1) = out.cam_derivs[1];
+    td.mm2CamDerivs(1, 0) = out.cam_derivs[2]; td.mm2CamDerivs(1, 1) = out.cam_derivs[3];
+    for(int r = 0; r < 2; ++r)
+      for(int c = 0; c < 6; ++c)
+        td.mm26Jacobian(r, c) = out.jacobian[6*r + c];
+    td.mnSearchLevel = out.search_level;
+
+    if(out.template_bad)   // PatchFinder::TemplateBad(): warp rejected or source footprint outside the source level
+    {
+      td.mbInImage = td.mbFound = false;
+      continue;
+    }
+    mmMeasAttemptedLevels[cameraName][out.search_level]++;
+
+    td.mbSearched = out.searched != 0;
+    td.mbFound = out.found != 0;
+    td.mbDidSubPix = out.did_subpix != 0;
+    if(!td.mbFound)
+      continue;     // not found in the coarse stage, or the sub-pixel iterations did not converge (counters as the reference nets them)
+
+    td.mdSqrtInvNoise = out.sqrt_inv_noise;   // 1 / LevelScale(search level)
+    td.mv2Found = makeVector(out.found_pos[0], out.found_pos[1]);
+    nFound++;
+    mmMeasFoundLevels[cameraName][out.search_level]++;
+  }
+  return nFound;
+}
+
+// Pose update from the found measurements: Tukey M-estimator + WLS<6> with prior 100 on the device (mcp_track_pose_update).
+// The device path implements the Tukey estimator, the tracker's default (Tracker::sMEstimatorName); the two others the reference
+// offers (Cauchy, Huber) are refused loudly rather than silently replaced.
+Vector<6> Tracker::CalcPoseUpdate(std::vector<TrackerDataPtrVector>& vIterationSets, double dOverrideSigma, bool bMarkOutliers)
+{
+  if(Tracker::sMEstimatorName != "Tukey")
+  {
+    ROS_FATAL_STREAM("Tracker: the MI355X pose update implements the Tukey M-estimator only (requested: "<<Tracker::sMEstimatorName<<")");
+    ros::shutdown();
+    return makeVector(0, 0, 0, 0, 0, 0);
+  }
+
+  std::vector<TrackerData*> vpTD;
+  for(unsigned i = 0; i < mvCurrCamNames.size(); ++i)
+    for(unsigned j = 0; j < vIterationSets[i].size(); ++j)
+      vpTD.push_back(vIterationSets[i][j].get());
+
+  const int n = (int)vpTD.size();
+  std::vector<uint8_t> vFound(n > 0 ? n : 1);
+  std::vector<double> vFoundPos(2*n + 2), vImagePos(2*n + 2), vSqrtInvNoise(n + 1), vJac(12*n + 12), vWeights(n + 1);
+  int nUsed = 0;
+  for(int i = 0; i < n; ++i)
+  {
+    TrackerData& td = *vpTD[i];
+    vFound[i] = td.mbFound ? 1 : 0;
+    if(!td.mbFound)
+      continue;
+    ++nUsed;
+    td.mv2Error_CovScaled = td.mdSqrtInvNoise * (td.mv2Found - td.mv2Image);
+    vFoundPos[2*i] = td.mv2Found[0]; vFoundPos[2*i + 1] = td.mv2Found[1];
+    vImagePos[2*i] = td.mv2Image[0]; vImagePos[2*i + 1] = td.mv2Image[1];
+    vSqrtInvNoise[i] = td.mdSqrtInvNoise;
+    for(int r = 0; r < 2; ++r)
+      for(int c = 0; c < 6; ++c)
+        vJac[12*i + 6*r + c] = td.mm26Jacobian(r, c);
+  }
+  if(nUsed == 0)
+    return makeVector(0, 0, 0, 0, 0, 0);
+
+  double adMu[6], dSigmaSquared = 0;
+  if(mcp_track_pose_update(n, &vFound[0], &vFoundPos[0], &vImagePos[0], &vSqrtInvNoise[0], &vJac[0], dOverrideSigma, adMu, &vWeights[0], &dSigmaSquared) != 0)
+  {
+    ROS_FATAL_STREAM("Tracker::CalcPoseUpdate: "<<mcp_last_error());
+    ros::shutdown();
+    return makeVector(0, 0, 0, 0, 0, 0);
+  }
+
+  // inlier / outlier bookkeeping of the marking iteration (src/Tracker.cc:1448-1487) and the covariance (:1500-1502)
+  mnNumInliers = 0;
+  Matrix<6> m6CInv = 100.0 * Identity;      // wls.add_prior(100)
+  for(int i = 0; i < n; ++i)
+  {
+    TrackerData& td = *vpTD[i];
+    if(!td.mbFound)
+    {
+      if(td.mbSearched && bMarkOutliers && !IsLost())
+        td.mPoint.mnMEstimatorOutlierCount++;
+      continue;
+    }
+    const double dWeight = vWeights[i];
+    if(dWeight == 0.0)
+    {
+      if(bMarkOutliers)
+        td.mPoint.mnMEstimatorOutlierCount++;
+      continue;
+    }
+    if(bMarkOutliers)
+    {
+      td.mPoint.mnMEstimatorInlierCount++;
+      mnNumInliers++;
+      // C^-1 += w J^T J with J = sqrt_inv_noise * Jacobian row (WLS::add_mJ twice)
+      for(int r = 0; r < 2; ++r)
+      {
+        const Vector<6> v6 = td.mdSqrtInvNoise * td.mm26Jacobian[r];
+        m6CInv += dWeight * v6.as_col() * v6.as_row();
+      }
+    }
+  }
+  if(bMarkOutliers)
+    mm6PoseCovariance = TooN::SVD<6>(m6CInv).get_pinv();
+
+  return makeVector(adMu[0], adMu[1], adMu[2], adMu[3], adMu[4], adMu[5]);
+}

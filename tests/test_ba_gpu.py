@@ -641,3 +641,18 @@ def test_newton_fallback_camera(gpu_required, cfg, iters):
     ref = run_bundle(_orc(p.cams), p, iters)
     rep = compare_runs(gpu, ref)
     assert rep["branch_flips"] == 0 and gpu["outliers"] == ref["outliers"]
+
+
+def test_recent_window_of_the_metric_map_matches_oracle(gpu_required):
+    """The bundle MCPTAM runs most: BundleAdjusterBase::BundleAdjustRecent (src/BundleAdjusterBase.cc:188-265) on the metric map --
+    the newest MKF and its movable neighbours free, every other MKF that sees their points fixed -- two-step as the map maker
+    calls it (10 iterations, then to convergence, BundleAdjusterMulti.cc:210-224 is per call; here one call of 10)."""
+    from mcptam_amd import synth
+    p = synth.recent_window(synth.make_config("metric"))
+    assert 2 <= (~p.base_fixed).sum() <= 4 and p.base_fixed.sum() >= 10 and p.n_meas > 10000
+    gpu = run_bundle(_gpu(p.cams), p, 10)
+    ref = run_bundle(_orc(p.cams), p, 10)
+    rep = compare_runs(gpu, ref)
+    assert rep["branch_flips"] == 0 and gpu["outliers"] == ref["outliers"]
+    assert abs(gpu["sigma_sq"] - ref["sigma_sq"]) <= 1e-9 * ref["sigma_sq"]
+    assert gpu["max_cov"] == 0.0 and ref["max_cov"] == 0.0          # three free poses: no marginals (:1419,1444-1448)

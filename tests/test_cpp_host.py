@@ -39,3 +39,14 @@ def test_cpp_keyframe_mirror_compiles_and_links(tmp_path):
     out = subprocess.run([exe, "--link-only"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "linked" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_keyframe_mirror_runs_on_gpu(tmp_path, gpu_required):
+    """The same program on a GPU box: pyramids / corners / LUTs of two KeyFrames fed the same frame agree, self-alignment of the
+    small blurry images is the identity, the relocaliser score is 0, MiniPatch matches sit at zero offset, the frame history
+    advances, and a pose update from perfect measurements is zero (tests/cpp/keyframe_link.cpp)."""
+    exe = _build(tmp_path, "keyframe_link")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "keyframe mirror ok" in out.stdout

@@ -1250,3 +1250,25 @@ def test_newton_fallback_camera_matches_the_inverse_polynomial_camera():
         uv, D, invalid = oracle.cam_project(cam_n, xc[i])
         assert not invalid
         assert np.abs(uv - uv_n[i]).max() < 1e-9
+
+
+def test_recent_window_selection():
+    """synth.recent_window = BundleAdjusterBase::BundleAdjustRecent's sets (src/BundleAdjusterBase.cc:188-265)."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=30, n_points=3000)
+    q = synth.recent_window(p)
+    w = q.window
+    assert 29 in w["adjust"] and len(w["adjust"]) <= 4 and not p.base_fixed[w["adjust"]].any()
+    assert set(np.flatnonzero(~q.base_fixed)) == {int(np.searchsorted(w["mkf"], a)) for a in w["adjust"]}
+    # every point of the window is measured from an adjusted MKF, and all its measurements came along
+    for i in (0, len(w["points"]) // 2, len(w["points"]) - 1):
+        gp = w["points"][i]
+        obs = p.ms_mkf[p.ms_pt == gp]
+        assert np.isin(obs, w["adjust"]).any()
+        assert (q.ms_pt == i).sum() == obs.size
+    # fixed MKFs are exactly the non-adjusted observers of those points
+    seen = np.unique(p.ms_mkf[np.isin(p.ms_pt, w["points"])])
+    assert set(w["mkf"]) == set(seen) | set(w["adjust"]) | set(p.pt_src[w["points"], 0])
+    o = _orc(q.cams)
+    q.populate(o)
+    assert o.Compute(5) == 5
