@@ -62,8 +62,9 @@ static int exercise(int w, int h) {
   const int n = 40;
   std::vector<uint8_t> found(n, 1); std::vector<double> fp(2*n), ip(2*n), sn(n, 1.0), J(12*n, 0.0), w6;
   for (int i = 0; i < n; ++i) { fp[2*i] = ip[2*i] = 10.0 + 3*i; fp[2*i+1] = ip[2*i+1] = 20.0 + i; for (int k = 0; k < 6; ++k) { J[12*i + k] = 1.0 + 0.1*k + 0.01*i; J[12*i + 6 + k] = 0.5 - 0.05*k + 0.02*i; } }
-  auto mu = mcptam_hip::CalcPoseUpdate(found, fp, ip, sn, J, -1.0, &w6);
+  auto mu = mcptam_hip::CalcPoseUpdate(found, fp, ip, sn, J, 1.0, &w6);      // (sigma^2 given: the median of all-zero errors would be 0)
   for (int k = 0; k < 6; ++k) CHECK(mu.first[k] == 0.0);
+  for (int i = 0; i < n; ++i) CHECK(w6[i] == 1.0);
   // still instantiated (their numerics are covered through ctypes in tests/test_img_gpu.py): the camera-dependent members
   mcp_camera cam; std::memset(&cam, 0, sizeof cam);
   const double T[12] = {1,0,0, 0,1,0, 0,0,1, 0,0,0};

@@ -51,6 +51,51 @@ def sharded_solve_on_one_gpu(rank, world, port, outdir, cfg, iters):
     dist.destroy_process_group()
 
 
+def _empty_copy(p):
+    """The same trajectory and cameras with no point and no measurement (a rank whose shard of the map is empty)."""
+    import copy
+    q = copy.copy(p)
+    for name in ("pt_x", "pt_src", "pt_fixed", "ms_mkf", "ms_cam", "ms_pt", "ms_uv", "ms_level"):
+        setattr(q, name, getattr(p, name)[:0])
+    q.true_world = None
+    return q
+
+
+def sharded_solve_with_an_empty_rank(rank, world, port, outdir, cfg, iters):
+    """Rank 0 holds the whole map, rank 1 nothing: rank 1 must still join every collective (no hang) and end with the same poses."""
+    dist = _init(rank, world, port)
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import GlooAllReduce
+    p = synth.make_config(shard=0, **cfg)
+    if rank == 1:
+        p = _empty_copy(p)
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, device=0)
+    ids = p.populate(b)
+    b.SetAllReduce(GlooAllReduce(host=False), rank, world)
+    rc = b.Compute(iters)
+    R, t = b.GetPoses(ids["mkf"])
+    np.savez(os.path.join(outdir, "empty_%d.npz" % rank), rc=rc, R=R, t=t, sigma_sq=b.GetSigmaSquared(), max_cov=b.GetMaxCov(),
+             trials=np.array([l["trials"] for l in b.IterLogs()]), n_out=len(b.GetOutlierMeasurements()))
+    b.close()
+    dist.destroy_process_group()
+
+
+def sharded_max_cov(rank, world, port, outdir, cfg, iters):
+    """Fewer than three free poses, points sharded over two ranks: GetMaxCov is the GLOBAL median of the depth covariances."""
+    dist = _init(rank, world, port)
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import GlooAllReduce
+    p = synth.make_config(shard=rank, **cfg)
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, device=0)
+    ids = p.populate(b)
+    b.SetAllReduce(GlooAllReduce(host=False), rank, world)
+    rc = b.Compute(iters)
+    R, t = b.GetPoses(ids["mkf"])
+    np.savez(os.path.join(outdir, "cov_%d.npz" % rank), rc=rc, R=R, t=t, max_cov=b.GetMaxCov())
+    b.close()
+    dist.destroy_process_group()
+
+
 def rccl_hook_single_rank(rank, world, port, outdir):
     """RcclAllReduce on a device buffer with a 1-rank nccl (= RCCL) group: staging copies, stream sync, collective."""
     import torch

@@ -656,3 +656,73 @@ def test_recent_window_of_the_metric_map_matches_oracle(gpu_required):
     assert rep["branch_flips"] == 0 and gpu["outliers"] == ref["outliers"]
     assert abs(gpu["sigma_sq"] - ref["sigma_sq"]) <= 1e-9 * ref["sigma_sq"]
     assert gpu["max_cov"] == 0.0 and ref["max_cov"] == 0.0          # three free poses: no marginals (:1419,1444-1448)
+
+
+def _spawn2(fn, *args):
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = tempfile.mkdtemp()
+    mp.spawn(fn, args=(2, port, d) + args, nprocs=2, join=True)
+    return d
+
+
+@pytest.mark.timeout(300)
+def test_rank_with_an_empty_shard_joins_every_collective(gpu_required):
+    """A rank whose shard holds no measurement must not take a local shortcut past the all-reduces (the other ranks would wait for
+    ever): emptiness is decided on the global totals.  Two ranks, rank 1 empty = the single-rank solve of rank 0's map."""
+    import os
+    import dist_workers
+    from mcptam_amd import synth
+    cfg = dict(name="c2", n_mkf=12, n_points=900)
+    d = _spawn2(dist_workers.sharded_solve_with_an_empty_rank, cfg, 5)
+    r0, r1 = np.load(os.path.join(d, "empty_0.npz")), np.load(os.path.join(d, "empty_1.npz"))
+    p = synth.make_config(shard=0, **cfg)
+    ref = run_bundle(_gpu(p.cams), p, 5)
+    assert int(r0["rc"]) == int(r1["rc"]) == ref["rc"] == 5
+    assert np.array_equal(r0["R"], r1["R"]) and np.array_equal(r0["t"], r1["t"])
+    assert rel_err(r0["R"], ref["R"]) < 1e-9 and rel_err(r0["t"], ref["t"]) < 1e-9
+    assert list(r0["trials"]) == [l["trials"] for l in ref["logs"]] == list(r1["trials"])
+    assert int(r0["n_out"]) == len(ref["outliers"]) and int(r1["n_out"]) == 0
+    assert abs(float(r1["sigma_sq"]) - ref["sigma_sq"]) <= 1e-12 * ref["sigma_sq"]
+
+
+@pytest.mark.timeout(300)
+def test_multi_rank_max_cov_is_the_global_median(gpu_required):
+    """ChainBundle.cc:1401-1448 with the points sharded: every rank inverts the all-reduced pose system, the depth covariances are
+    rank-local and their median is the global order statistic."""
+    import os
+    import dist_workers
+    from mcptam_amd import synth
+    cfg = dict(name="tiny", n_mkf=3, n_points=80, n_fixed_mkf=1, per_point=3)
+    d = _spawn2(dist_workers.sharded_max_cov, cfg, 8)
+    r0, r1 = np.load(os.path.join(d, "cov_0.npz")), np.load(os.path.join(d, "cov_1.npz"))
+    merged = synth.merge_shards([synth.make_config(shard=0, **cfg), synth.make_config(shard=1, **cfg)])
+    ref = run_bundle(_gpu(merged.cams), merged, 8)
+    assert int(r0["rc"]) == int(r1["rc"]) == ref["rc"]
+    assert ref["max_cov"] > 0
+    assert float(r0["max_cov"]) == float(r1["max_cov"])
+    assert abs(float(r0["max_cov"]) - ref["max_cov"]) <= 1e-8 * ref["max_cov"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_rank_path_end_to_end(gpu_required):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks on this box's
+    single GPU and the gloo transport (--debug-single-device): the multi-rank code path of the headline benchmark end to end."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "c2", "--cpu-iters", "0", "--debug-single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    assert "debug" in d["config"] and d["config"]["chi2_last"] < d["config"]["chi2_first"]
