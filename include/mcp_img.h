@@ -102,6 +102,15 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
                           double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
                           double mu_last[6], double* weights_last);
 
+/* The same pose iterations with the cameras spread over ranks (one camera per GPU, BASELINE config c5 / SURVEY.md 8(e)): every rank
+ * passes the points of ITS camera(s) and the same BaseFromWorld; per iteration the ranks exchange the squared errors (exact global
+ * Tukey median) and the 6x6 + 6 WLS accumulator through `allreduce` (SUM of doubles in place on a device buffer, the hook type of
+ * mcp_ba.h; e.g. RCCL over xGMI), so that every rank applies the identical update.  cap >= the largest n of any rank.  world = 1
+ * with allreduce = NULL runs the same kernels on one device. */
+int mcp_track_pose_refine_sharded(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cam_from_base /* ncam x 12 */,
+                                  double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                                  double mu_last[6], double* weights_last, mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap);
+
 /* ---- SmallBlurryImage / Relocaliser -------------------------------- src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121
  * The 40x30 thumbnail of the frame the handle holds, its zero-mean Gaussian-blurred float template and gradient image
  * (MakeFromKF + MakeJacs) live on the device with the keyframe (KeyFrame::mpSBI).  blur = 2.5 in the reference. */

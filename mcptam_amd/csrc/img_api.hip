@@ -303,6 +303,47 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
   return 0;
 }
 
+int mcp_track_pose_refine_sharded(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
+                                  const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last,
+                                  mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap) {
+  for (int k = 0; k < 6; ++k) mu_last[k] = 0;
+  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || world < 1 || rank < 0 || rank >= world || cap < n || cap < 1 || (world > 1 && !allreduce))
+    return img_fail("mcp_track_pose_refine_sharded: bad arguments");
+  for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine_sharded: camera index out of range");
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine_sharded: no HIP device");
+  if (n_iter == 0) return 0;      // (a rank without points still joins every collective below)
+  struct Scratch { Buf<mcp_pose_point> dp; Buf<mcp_camera> dc; Buf<double> dcfb, dpose, dv6, dJ, dex, de2, dtab, dacc, dw; Buf<unsigned int> dcnt; };
+  static thread_local Scratch rs;
+  const size_t tab = (size_t)world*cap;
+  if (rs.dp.alloc(std::max(n, 1)) || rs.dc.alloc(ncam) || rs.dcfb.alloc(12*(size_t)ncam) || rs.dpose.alloc(12) || rs.dv6.alloc(6) || rs.dJ.alloc(12*(size_t)std::max(n, 1)) ||
+      rs.dex.alloc(2*(size_t)std::max(n, 1)) || rs.de2.alloc(std::max(n, 1)) || rs.dtab.alloc(tab + world) || rs.dacc.alloc(28) || rs.dw.alloc(std::max(n, 1)) || rs.dcnt.alloc(1)) return -1;
+  hipStream_t st = nullptr;
+  if (n) ICK(hipMemcpyAsync(rs.dp.p, pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dc.p, cams, sizeof(mcp_camera)*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dcfb.p, cfb, 96*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dpose.p, bfw, 96, hipMemcpyHostToDevice, st));
+  ICK(hipMemsetAsync(rs.dv6.p, 0, 48, st));
+  ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)std::max(n, 1), st));
+  for (int it = 0; it < n_iter; ++it) {
+    ICK(hipMemsetAsync(rs.dtab.p, 0, (tab + world)*sizeof(double), st));
+    ICK(hipMemsetAsync(rs.dcnt.p, 0, sizeof(unsigned int), st));
+    if (n) hipLaunchKernelGGL(k_pr_project, dim3((n + 255)/256), dim3(256), 0, st, n, rs.dp.p, (const mcp_camera*)rs.dc.p, (const double*)rs.dcfb.p,
+                              (const double*)rs.dpose.p, (const double*)rs.dv6.p, it, (int)(nonlinear[it] != 0), rs.dJ.p, rs.dex.p, rs.de2.p,
+                              rs.dtab.p + (size_t)rank*cap, rs.dtab.p + tab + rank, rs.dcnt.p);
+    if (world > 1) { ICK(hipStreamSynchronize(st)); if (allreduce(user, rs.dtab.p, tab + world, (void*)st) != 0) return img_fail("mcp_track_pose_refine_sharded: all-reduce hook failed"); }
+    hipLaunchKernelGGL(k_pr_accum, dim3(1), dim3(1024), 0, st, n, (const mcp_pose_point*)rs.dp.p, (const double*)rs.dJ.p, (const double*)rs.dex.p, (const double*)rs.de2.p,
+                       (const double*)rs.dtab.p, (const double*)(rs.dtab.p + tab), world, cap, override_sigma[it], (int)(it == n_iter - 1), rs.dacc.p, rs.dw.p);
+    if (world > 1) { ICK(hipStreamSynchronize(st)); if (allreduce(user, rs.dacc.p, 27, (void*)st) != 0) return img_fail("mcp_track_pose_refine_sharded: all-reduce hook failed"); }
+    hipLaunchKernelGGL(k_pr_solve, dim3(1), dim3(64), 0, st, (const double*)rs.dacc.p, (const double*)(rs.dtab.p + tab), world, rs.dpose.p, rs.dv6.p);
+  }
+  if (n) ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(bfw, rs.dpose.p, 96, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(mu_last, rs.dv6.p, 48, hipMemcpyDeviceToHost, st));
+  if (weights_last && n) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+  ICK(hipStreamSynchronize(st));
+  return 0;
+}
+
 // ---- SmallBlurryImage / Relocaliser --------------------------------------------------------------------------------
 // cv::resize's 8U INTER_LINEAR taps [3P-memory]: source coordinate (d+0.5)*scale-0.5 in float, clamped, 11-bit weights
 static void sbi_resize_coeffs(int src, int dst, int* idx, short* w0, short* w1) {

@@ -917,4 +917,164 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
   if (t < 6) mu_out[t] = v6[t];
 }
 
+
+// ---- camera-per-rank pose refinement (BASELINE config c5): every rank holds the found points of its own
+// camera(s), the base pose is replicated.  One Gauss-Newton iteration of Tracker::TrackMap (src/Tracker.cc:1063-1075) =
+//   k_pr_project  : PoseUpdateStep / PoseUpdateStepLinear + the covariance-scaled errors; the rank's squared errors go, compacted,
+//                   into its own slot of a zero-filled (ranks x cap) table
+//   all-reduce #1 : SUM of the table = gather of every rank's squared errors (+ the per-rank counts)
+//   k_pr_accum    : Tukey sigma^2 from the exact [n/2] order statistic of ALL errors, then this rank's part of the WLS<6>
+//                   accumulator: 21 entries of C^-1, 6 of the vector
+//   all-reduce #2 : SUM of the 27 numbers
+//   k_pr_solve    : prior 100, 6x6 Cholesky, mu, BaseFromWorld <- exp(mu) BaseFromWorld -- the same on every rank
+__global__ void __launch_bounds__(256)
+k_pr_project(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
+             const double* __restrict__ pose, const double* __restrict__ v6, int it, int nl, double* __restrict__ J,
+             double* __restrict__ ex, double* __restrict__ e2s, double* __restrict__ slot /* cap */, double* __restrict__ count_slot,
+             unsigned int* __restrict__ counter) {
+  const int i = blockIdx.x*blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mcp_pose_point& p = pts[i];
+  if (!p.found) return;
+  double* Ji = J + 12*(size_t)i;
+  if (nl) {
+    const double* cfb = cfb_all + 12*(size_t)p.cam;
+    double xb[3], xc[3];
+    mat3_vec(pose, p.world_pos, xb); xb[0] += pose[9]; xb[1] += pose[10]; xb[2] += pose[11];
+    mat3_vec(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+    if (it != 0) {
+      Projection pr; cam_project<true>(cams[p.cam], xc, pr);
+      p.image[0] = pr.u; p.image[1] = pr.v; p.cam_derivs[0] = pr.D[0]; p.cam_derivs[1] = pr.D[1]; p.cam_derivs[2] = pr.D[2]; p.cam_derivs[3] = pr.D[3];
+    }
+    double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb, mb, mc);
+      const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+      Ji[m] = p.cam_derivs[0]*s0 + p.cam_derivs[1]*s1; Ji[6 + m] = p.cam_derivs[2]*s0 + p.cam_derivs[3]*s1;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { double a = 0.0; for (int k = 0; k < 6; ++k) a += Ji[6*r + k]*v6[k]; p.image[r] += a; }
+  }
+  const double e0 = p.sqrt_inv_noise*(p.found_pos[0] - p.image[0]), e1 = p.sqrt_inv_noise*(p.found_pos[1] - p.image[1]);
+  ex[2*(size_t)i] = e0; ex[2*(size_t)i + 1] = e1;
+  const double e2 = e0*e0 + e1*e1;
+  e2s[i] = e2;
+  const unsigned int k = atomicAdd(counter, 1u);      // position inside the slot is irrelevant to an order statistic
+  slot[k] = e2;
+  atomicAdd(count_slot, 1.0);                          // (integer-valued: exact in any order)
+}
+
+__global__ void __launch_bounds__(1024)
+k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restrict__ J, const double* __restrict__ ex, const double* __restrict__ e2s,
+           const double* __restrict__ table /* world x cap */, const double* __restrict__ counts /* world */, int world, int cap,
+           double override_sigma, int last, double* __restrict__ out27 /* [27] + [27] = total found */, double* __restrict__ w_out) {
+  __shared__ unsigned int hist[2048];
+  __shared__ unsigned int part[64];
+  __shared__ double red[16][28];
+  __shared__ unsigned long long sel_prefix, sel_k;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double nf_d = 0.0;
+  for (int r = 0; r < world; ++r) nf_d += counts[r];
+  const unsigned long long nf = (unsigned long long)nf_d;
+  if (nf == 0) { if (t < 28) out27[t] = 0.0; return; }
+  double s2 = override_sigma;
+  if (!(s2 > 0)) {
+    if (t == 0) { sel_prefix = 0ull; sel_k = nf/2; }
+    __syncthreads();
+    const int m = world*cap;
+    for (int pass = 0; pass < SEL_PASSES; ++pass) {
+      const int sh = sel_shift(pass);
+      const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+      const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+      for (int b = t; b < 2048; b += 1024) hist[b] = 0u;
+      __syncthreads();
+      const unsigned long long prefix = sel_prefix;
+      for (int i = t; i < m; i += 1024) {
+        if ((double)(i % cap) >= counts[i/cap]) continue;
+        const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(table[i]));
+        if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
+      }
+      __syncthreads();
+      if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
+      __syncthreads();
+      if (t == 0) {
+        unsigned long long k = sel_k, acc = 0; int c = 0;
+        for (; c < 64; ++c) { if (acc + part[c] > k) break; acc += part[c]; }
+        if (c == 64) c = 63;
+        int b = 32*c;
+        for (; b < 32*c + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
+        if (b >= 32*c + 32) b = 32*c + 31;
+        sel_prefix = prefix | ((unsigned long long)b << sh);
+        sel_k = k - acc;
+      }
+      __syncthreads();
+    }
+    const double med = __longlong_as_double((long long)sel_prefix);
+    double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
+    sg = 4.6851*sg;
+    s2 = sg*sg;
+  }
+  double a[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) a[k] = 0.0;
+  for (int i = t; i < n; i += 1024) {
+    const mcp_pose_point& p = pts[i];
+    if (!p.found) { if (last && w_out) w_out[i] = 0.0; continue; }
+    const double err2 = e2s[i];
+    const double sq = (err2 > s2) ? 0.0 : 1.0 - (err2/s2);
+    const double w = sq*sq;
+    if (last && w_out) w_out[i] = w;
+    if (w == 0.0) continue;
+    const double* Ji = J + 12*(size_t)i;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double Jr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jr[k] = p.sqrt_inv_noise*Ji[6*r + k];
+      const double mm = ex[2*(size_t)i + r];
+      int q = 0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+        a[21 + x] += w*mm*Jr[x];
+#pragma unroll
+        for (int y = 0; y <= x; ++y) { a[q] += w*Jr[x]*Jr[y]; ++q; }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) { double v = a[k]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[k] = v; }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[wave][k] = a[k];
+  }
+  __syncthreads();
+  if (t < 27) { double sum = 0.0; for (int wv = 0; wv < 16; ++wv) sum += red[wv][t]; out27[t] = sum; }
+  if (t == 27) out27[27] = 0.0;
+}
+
+// every rank: C^-1 (+ prior 100) mu = v, BaseFromWorld <- exp(mu) BaseFromWorld.  acc = the all-reduced 27 sums; nf_total = 0: null update.
+__global__ void k_pr_solve(const double* __restrict__ acc, const double* __restrict__ counts, int world, double* __restrict__ pose, double* __restrict__ v6) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double nf = 0.0;
+  for (int r = 0; r < world; ++r) nf += counts[r];
+  if (nf == 0.0) { for (int k = 0; k < 6; ++k) v6[k] = 0.0; return; }
+  double C[36], v[6], mu[6];
+  int q = 0;
+  for (int x = 0; x < 6; ++x) for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = acc[q]; ++q; }
+  for (int x = 0; x < 6; ++x) { v[x] = acc[21 + x]; C[7*x] += 100.0; }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = (i == j) ? sqrt(sum) : sum/C[6*j + j]; }
+  for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum/C[6*i + i]; }
+  for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum/C[6*i + i]; }
+  Se3 E, T, R;
+  se3_exp(mu, E);
+  for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
+  T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
+  se3_compose(E, T, R);
+  for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
+  pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
+  for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+}
+
 }  // namespace mcp

@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_track_pose_refine", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -62,6 +62,9 @@ def lib():
         L.mcp_kf_num_prev.argtypes = [ctypes.c_void_p]
         L.mcp_track_pose_refine.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_track_pose_refine_sharded.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    _cb.ALLREDUCE_FN, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.mcp_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
         L.mcp_kf_get_sbi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mcp_sbi_score.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -306,6 +309,28 @@ def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_s
     rc = fn(n, pts.ctypes.data, ncam, ctypes.cast(carr, ctypes.c_void_p), cfb.ctypes.data, bfw.ctypes.data, nit, nl.ctypes.data, ov.ctypes.data,
             mu.ctypes.data, w.ctypes.data)
     return rc, (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), mu, w[:n], pts
+
+
+def track_pose_refine_sharded(pts, cams, cam_from_base, base_from_world, allreduce=None, rank=0, world=1, cap=None,
+                              nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE):
+    """The pose iterations with the cameras spread over ranks (one camera per GPU, BASELINE config c5): `pts` are THIS rank's points,
+    `allreduce(device_ptr, count, stream)` an in-place SUM all-reduce of doubles (e.g. mcptam_amd.dist.RcclAllReduce / GlooAllReduce);
+    `cap` >= the largest point count of any rank.  Returns what track_pose_refine returns; the pose is the same on every rank."""
+    def tramp(_user, buf, count, stream):
+        try:
+            allreduce(int(buf), int(count), int(stream or 0))
+            return 0
+        except Exception as exc:      # never let an exception cross the C ABI
+            print("all-reduce hook raised:", repr(exc), flush=True)
+            return 1
+    hook = _cb.ALLREDUCE_FN(tramp) if allreduce is not None else ctypes.cast(None, _cb.ALLREDUCE_FN)
+    cap = max(len(pts), 1) if cap is None else int(cap)
+
+    def fn(n, p, ncam, carr, cfb, bfw, nit, nl, ov, mu, w):
+        return lib().mcp_track_pose_refine_sharded(n, p, ncam, carr, cfb, bfw, nit, nl, ov, mu, w, hook, None, int(rank), int(world), cap)
+    rc, pose, mu, w, out = _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
+    _chk(rc, "track_pose_refine_sharded")
+    return pose, mu, w, out
 
 
 def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE):

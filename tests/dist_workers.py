@@ -138,3 +138,19 @@ def native_rccl_single_rank(rank, world, port, outdir):
     np.savez(os.path.join(outdir, "native.npz"), t=t.cpu().numpy(), rc=rc, R=R, tt=tt, X=X)
     b.close(); comm.close()
     dist.destroy_process_group()
+
+
+def sharded_pose_refine(rank, world, port, outdir):
+    """One camera per rank: every rank refines the base pose from its own camera's points; the Tukey median and the 6x6 + 6
+    accumulator are exchanged per iteration (mcp_track_pose_refine_sharded)."""
+    dist = _init(rank, world, port)
+    import test_oracle_cpu as toc
+    from mcptam_amd.dist import GlooAllReduce
+    from mcptam_amd.keyframe import track_pose_refine_sharded
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    mine = recs[recs["cam"] == rank]
+    cap = int(max((recs["cam"] == r).sum() for r in range(world)))
+    hook = GlooAllReduce(host=False)
+    pose, mu, w, out = track_pose_refine_sharded(mine, [cam, cam], cfbs, bfw, allreduce=hook, rank=rank, world=world, cap=cap)
+    np.savez(os.path.join(outdir, "refine_%d.npz" % rank), R=pose[0], t=pose[1], mu=mu, w=w, image=out["image"], calls=hook.calls)
+    dist.destroy_process_group()

@@ -408,8 +408,7 @@ def test_pose_refine_matches_oracle(gpu_required):
 
 def test_c5_frame_size_1280x960(gpu_required):
     """BASELINE config c5 (8-camera 1280x960 rig, one camera per GPU): one camera's frame through the whole per-frame path at
-    that size -- pyramid, corners, LUT, candidates bit-exact; the tracked-point batch with the documented tolerance; pose
-    iterations."""
+    that size -- pyramid, corners, LUT, candidates bit-exact; the tracked-point batch bit-exact in its integer outputs; pose iterations."""
     from mcptam_amd import synth_img
     from mcptam_amd.keyframe import pose_points, track_pose_refine, track_search
     from oracle import oracle_track_pose_refine, oracle_track_search
@@ -434,9 +433,7 @@ def test_c5_frame_size_1280x960(gpu_required):
     wp = np.array([p["world_pos"] for p in pts])
     pg, mg, wg, _ = track_pose_refine(pose_points(wp, og, 0), [sc["cam"]], [I], sc["poseB"])
     po, mo, wo, _ = oracle_track_pose_refine(pose_points(wp, oo, 0), [sc["cam"]], [I], sc["poseB"])
-    clean = np.abs(og["templ"].astype(int) - oo["templ"].astype(int)).max(axis=1) == 0
-    if clean.all() and np.array_equal(og["found"], oo["found"]):
-        assert np.allclose(pg[0], po[0], atol=1e-9) and np.allclose(pg[1], po[1], atol=1e-9)
+    assert np.allclose(pg[0], po[0], atol=1e-9) and np.allclose(pg[1], po[1], atol=1e-9)
 
 
 def test_track_search_with_newton_fallback_camera(gpu_required, scene):
@@ -456,3 +453,31 @@ def test_track_search_with_newton_fallback_camera(gpu_required, scene):
     oo = oracle_track_search(oB, cam, scene["poseB"], I, pts, 10, 8, False)
     assert_track_equal(og, oo)
     assert og["found"].sum() > 100
+
+
+def test_camera_per_rank_pose_refine(gpu_required):
+    """BASELINE config c5's exchange: one camera per rank, per pose iteration an all-reduce of every rank's squared
+    errors (exact global Tukey median) and of the 6x6 + 6 WLS accumulator (src/Tracker.cc:1386-1512).  (a) one rank through the
+    sharded entry = the fused single-launch kernel; (b) two ranks (processes sharing this GPU, gloo transport), camera 0 / camera 1,
+    end on the same pose as the single-device refinement of all points, and both ranks hold identical poses."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_refine, track_pose_refine_sharded
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    assert set(np.unique(recs["cam"])) == {0, 1}
+    pg, mg, wg, og = track_pose_refine(recs, [cam, cam], cfbs, bfw)
+    p1, m1, w1, o1 = track_pose_refine_sharded(recs, [cam, cam], cfbs, bfw)
+    assert np.allclose(p1[0], pg[0], rtol=0, atol=1e-13) and np.allclose(p1[1], pg[1], rtol=0, atol=1e-13)
+    assert np.allclose(m1, mg, rtol=0, atol=1e-13) and np.allclose(w1, wg, rtol=0, atol=1e-12)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.sharded_pose_refine, args=(2, port, d), nprocs=2, join=True)
+        r0, r1 = np.load(os.path.join(d, "refine_0.npz")), np.load(os.path.join(d, "refine_1.npz"))
+    assert np.array_equal(r0["R"], r1["R"]) and np.array_equal(r0["t"], r1["t"]) and np.array_equal(r0["mu"], r1["mu"])
+    assert np.allclose(r0["R"], pg[0], rtol=0, atol=1e-11) and np.allclose(r0["t"], pg[1], rtol=0, atol=1e-11)
+    assert np.allclose(r0["w"], wg[recs["cam"] == 0], rtol=0, atol=1e-9) and np.allclose(r1["w"], wg[recs["cam"] == 1], rtol=0, atol=1e-9)
+    assert int(r0["calls"]) == 20                       # two collectives per iteration, ten iterations
