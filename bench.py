@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--config", default="metric")
     ap.add_argument("--cpu-iters", type=int, default=8, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tracker", action="store_true", help="skip the secondary Tracker line (BASELINE config c3) that is appended under `tracker_c3`")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="all ranks on GPU 0 with a host-staged gloo all-reduce: exercises the multi-rank code path on a 1-GPU box; "
                          "the printed value is NOT a valid measurement (config.debug says so)")
@@ -313,6 +314,14 @@ def main():
         result["cpu_baseline"] = base_a                 # the denominator SURVEY.md 8(d) names for the >= 10x target
         result["cpu_baseline_variants"] = variants
         result["speedup_vs_cpu"] = {k: result["value"] / v["value"] for k, v in variants.items()}
+    # secondary line: the per-frame Tracker path (BASELINE config c3), GPU through the C ABI next to the scalar CPU port
+    if rank == 0 and world == 1 and not args.no_tracker and args.cpu_iters > 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_tracker
+            result["tracker_c3"] = bench_tracker.main(frames=20, cpu_frames=2)
+        except Exception as exc:       # the headline line must not depend on the secondary one
+            result["tracker_c3"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -60,8 +60,11 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
            "cpu_oracle_frames_per_s": 1/cdt, "cpu_cores": 1,
            "algorithmic_bytes_per_frame": int(px*(1.64 + 1.33) + npts*1500),
            "note": "host-driven: one make_lite + one track_search per camera (one host thread and HIP stream per camera), then the 10 pose iterations in one mcp_track_pose_refine launch; images uploaded over PCIe each frame"}
-    print(json.dumps(res))
+    res["hbm_roofline"] = {"bound": "hbm", "achieved": res["algorithmic_bytes_per_frame"]/gdt/1e9, "peak": 8000.0, "unit": "GB/s",
+                           "frac": res["algorithmic_bytes_per_frame"]/gdt/1e9/8000.0}
+    res["speedup_vs_cpu_1thread"] = cdt/gdt
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(main()))
