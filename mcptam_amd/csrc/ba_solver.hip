@@ -7,6 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -196,18 +200,27 @@ struct mcp_ba {
     if ((int)id_kind.size() <= id) { id_kind.resize(id + 1024, 0); id_index.resize(id + 1024, 0); }
     id_kind[id] = kind; id_index[id] = index; return id;
   }
+  // last chain looked up: the adapters add measurements KeyFrame by KeyFrame (BundleAdjusterMulti.cc:168-200), so consecutive
+  // calls repeat the same pose chain and the ordered-map search is skipped for them
+  int last_chain_n = 0, last_chain_idx = -1; int last_chain_ids[MCP_MAX_CHAIN];
   int find_chain(const int* ids, int n) {
     if (n < 1 || n > MCP_MAX_CHAIN) return -1;
+    if (n == last_chain_n && last_chain_idx >= 0 && std::memcmp(ids, last_chain_ids, sizeof(int)*n) == 0) return last_chain_idx;
     std::array<int, 1 + MCP_MAX_CHAIN> key; key.fill(-1); key[0] = n;
     for (int i = 0; i < n; ++i) {
       if (ids[i] <= 0 || ids[i] >= next_id || id_kind[ids[i]] != 1) return -1;
       key[1 + i] = id_index[ids[i]];
     }
+    int idx;
     auto it = chain_map.find(key);
-    if (it != chain_map.end()) return it->second;
-    HChain c; c.len = n; for (int i = 0; i < MCP_MAX_CHAIN; ++i) c.v[i] = (i < n) ? key[1 + i] : 0;
-    chains.push_back(c);
-    int idx = (int)chains.size() - 1; chain_map[key] = idx; return idx;
+    if (it != chain_map.end()) idx = it->second;
+    else {
+      HChain c; c.len = n; for (int i = 0; i < MCP_MAX_CHAIN; ++i) c.v[i] = (i < n) ? key[1 + i] : 0;
+      chains.push_back(c);
+      idx = (int)chains.size() - 1; chain_map[key] = idx;
+    }
+    last_chain_n = n; last_chain_idx = idx; std::memcpy(last_chain_ids, ids, sizeof(int)*n);
+    return idx;
   }
   // PoseChainHelper::MoveTogether, ChainBundle.cc:157-199 (structural: evaluated once per chain pair)
   bool move_together(const HChain& a, const HChain& b, int depth) const {
@@ -314,8 +327,11 @@ int mcp_ba::prepare() {
   // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
   const size_t nch = chains.size();
   const bool dense_table = nch <= 4096;
-  std::vector<unsigned short> mask_table(dense_table ? nch*nch : 0, 0xffff);
+  // (entries are written concurrently by the structure threads below: every writer stores the same value, relaxed atomics)
+  std::unique_ptr<std::atomic<unsigned short>[]> mask_table(dense_table ? new std::atomic<unsigned short>[nch*nch] : nullptr);
+  if (dense_table) for (size_t i = 0; i < nch*nch; ++i) mask_table[i].store(0xffff, std::memory_order_relaxed);
   std::map<std::pair<int, int>, unsigned short> mask_cache;
+  std::mutex mask_mutex;
   auto compute_mask = [&](int oc, int sc) -> unsigned short {
     unsigned short mk = 0;
     const HChain& o = chains[oc]; const HChain& s = chains[sc];
@@ -325,10 +341,12 @@ int mcp_ba::prepare() {
   };
   auto pair_mask = [&](int oc, int sc) -> unsigned short {
     if (dense_table) {
-      unsigned short& e = mask_table[(size_t)oc*nch + sc];
-      if (e == 0xffff) e = compute_mask(oc, sc);
-      return e;
+      std::atomic<unsigned short>& e = mask_table[(size_t)oc*nch + sc];
+      unsigned short v = e.load(std::memory_order_relaxed);
+      if (v == 0xffff) { v = compute_mask(oc, sc); e.store(v, std::memory_order_relaxed); }
+      return v;
     }
+    std::lock_guard<std::mutex> lk(mask_mutex);
     auto key = std::make_pair(oc, sc);
     auto it = mask_cache.find(key);
     if (it != mask_cache.end()) return it->second;
@@ -344,49 +362,95 @@ int mcp_ba::prepare() {
   std::vector<unsigned char> sp_big(nsp, 0);
   std::vector<std::vector<int>> sp_poses(nsp);       // distinct pose unknowns touched by the point
   std::vector<unsigned char> inc_state;              // bit0: fed by a first-source-link slot, bit1: fed by another slot
-  slot_unk.reserve((size_t)nmeas*2); slot_inc.reserve((size_t)nmeas*2); slot_first.reserve((size_t)nmeas*2); inc_unk.reserve((size_t)nfl*8);
   perm.assign(nmeas, 0);
-  int j = 0;
-  for (int sp = 0; sp < nsp; ++sp) {
-    const int pt = order[sp];
-    const int lpt = points[pt].unk;
-    const int ibase = (int)inc_unk.size();
-    sp_pt[sp] = pt; sp_m[sp] = j; sp_i[sp] = ibase;
-    std::vector<int>& q = sp_poses[sp];
-    // Measurements of a point are stored rotated by the point's position: neighbouring points (= neighbouring lanes of
-    // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
-    // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
-    const int nm_pt = cnt[pt + 1] - cnt[pt];
-    for (int kk = 0; kk < nm_pt; ++kk, ++j) {
-      const int mi = by_point[cnt[pt] + (kk + sp) % nm_pt];
-      const HMeas& m = meas[mi];
-      perm[j] = mi;
-      m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega; m_sp[j] = sp;
-      const unsigned short mk = pair_mask(m.chain, points[pt].chain);
-      m_mask[j] = mk;
-      slot_start[j] = (int)slot_unk.size();
-      for (int b = 0; b < 2*MAXC; ++b) {
-        if (!(mk & (1 << b))) continue;
-        const HChain& c = (b < MAXC) ? chains[m.chain] : chains[points[pt].chain];
-        const int u = poses[c.v[b & (MAXC - 1)]].unk;
-        slot_unk.push_back(u);
-        if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
-        // slot_first: first contribution to its W block among the slots that write it through memory (every slot but
-        // the first source link, whose block is kept in registers by k_linearize_group); inc_mixed: both kinds occur
-        int inc = -1; unsigned char first = 0;
-        if (lpt >= 0) {
-          for (int t = ibase; t < (int)inc_unk.size(); ++t) if (inc_unk[t] == u) { inc = t; break; }
-          if (inc < 0) { inc = (int)inc_unk.size(); inc_unk.push_back(u); inc_state.push_back(0); }
-          if (b == MAXC) inc_state[inc] |= 1;
-          else { if (!(inc_state[inc] & 2)) first = 1; inc_state[inc] |= 2; }
+  // measurement ranges of the sorted points (prefix sum, serial and cheap); the per-point work below is independent per point
+  for (int sp = 0; sp < nsp; ++sp) sp_m[sp + 1] = sp_m[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]);
+  // The slot / incidence lists are built by a few host threads over contiguous ranges of sorted points, each into its own
+  // vectors (slot and incidence indices relative to the range), then concatenated with the offsets fixed up: the result is
+  // identical to a serial pass.
+  struct Chunk { int sp0, sp1; std::vector<int> slot_unk, slot_inc, inc_unk, slot_cnt; std::vector<unsigned char> slot_first, inc_state; std::vector<int> sp_ninc; };
+  const int nthr = (nsp >= 4096) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+  std::vector<Chunk> chunks(nthr);
+  auto build_chunk = [&](Chunk& C) {
+    C.slot_unk.reserve((size_t)(sp_m[C.sp1] - sp_m[C.sp0])*2); C.slot_inc.reserve(C.slot_unk.capacity()); C.slot_first.reserve(C.slot_unk.capacity());
+    C.sp_ninc.assign(C.sp1 - C.sp0, 0); C.slot_cnt.assign(sp_m[C.sp1] - sp_m[C.sp0], 0);
+    for (int sp = C.sp0; sp < C.sp1; ++sp) {
+      const int pt = order[sp];
+      const int lpt = points[pt].unk;
+      const int ibase = (int)C.inc_unk.size();
+      sp_pt[sp] = pt;
+      std::vector<int>& q = sp_poses[sp];
+      // Measurements of a point are stored rotated by the point's position: neighbouring points (= neighbouring lanes of
+      // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
+      // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
+      const int nm_pt = cnt[pt + 1] - cnt[pt];
+      int j = sp_m[sp];
+      for (int kk = 0; kk < nm_pt; ++kk, ++j) {
+        const int mi = by_point[cnt[pt] + (kk + sp) % nm_pt];
+        const HMeas& m = meas[mi];
+        perm[j] = mi;
+        m_pt[j] = pt; m_chain[j] = m.chain; m_cam[j] = (unsigned char)m.cam; m_u[j] = m.u; m_v[j] = m.v; m_om[j] = m.omega; m_sp[j] = sp;
+        const unsigned short mk = pair_mask(m.chain, points[pt].chain);
+        m_mask[j] = mk;
+        int nsl = 0;
+        for (int b = 0; b < 2*MAXC; ++b) {
+          if (!(mk & (1 << b))) continue;
+          const HChain& c = (b < MAXC) ? chains[m.chain] : chains[points[pt].chain];
+          const int u = poses[c.v[b & (MAXC - 1)]].unk;
+          C.slot_unk.push_back(u); ++nsl;
+          if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
+          // slot_first: first contribution to its W block among the slots that write it through memory (every slot but
+          // the first source link, whose block is kept in registers by k_linearize_group); inc_mixed: both kinds occur
+          int inc = -1; unsigned char first = 0;
+          if (lpt >= 0) {
+            for (int t = ibase; t < (int)C.inc_unk.size(); ++t) if (C.inc_unk[t] == u) { inc = t; break; }
+            if (inc < 0) { inc = (int)C.inc_unk.size(); C.inc_unk.push_back(u); C.inc_state.push_back(0); }
+            if (b == MAXC) C.inc_state[inc] |= 1;
+            else { if (!(C.inc_state[inc] & 2)) first = 1; C.inc_state[inc] |= 2; }
+          }
+          C.slot_inc.push_back(inc); C.slot_first.push_back(first);
         }
-        slot_inc.push_back(inc); slot_first.push_back(first);
+        C.slot_cnt[j - sp_m[C.sp0]] = nsl;
+      }
+      C.sp_ninc[sp - C.sp0] = (int)C.inc_unk.size() - ibase;
+      if ((int)q.size() > GRP_LMAX) sp_big[sp] = 1;
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t) {
+      // ranges balanced by measurement count
+      const long m0 = (long)nmeas*t/nthr, m1 = (long)nmeas*(t + 1)/nthr;
+      chunks[t].sp0 = (t == 0) ? 0 : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m0) - sp_m.begin());
+      chunks[t].sp1 = (t == nthr - 1) ? nsp : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m1) - sp_m.begin());
+    }
+    for (int t = 1; t < nthr; ++t) pool.emplace_back(build_chunk, std::ref(chunks[t]));
+    build_chunk(chunks[0]);
+    for (auto& th : pool) th.join();
+  }
+  {
+    size_t tot_slot = 0, tot_inc = 0;
+    for (const Chunk& C : chunks) { tot_slot += C.slot_unk.size(); tot_inc += C.inc_unk.size(); }
+    slot_unk.reserve(tot_slot); slot_inc.reserve(tot_slot); slot_first.reserve(tot_slot); inc_unk.reserve(tot_inc); inc_state.reserve(tot_inc);
+    for (const Chunk& C : chunks) {
+      const int ioff = (int)inc_unk.size();
+      int soff = (int)slot_unk.size();
+      for (int j = sp_m[C.sp0]; j < sp_m[C.sp1]; ++j) { slot_start[j] = soff; soff += C.slot_cnt[j - sp_m[C.sp0]]; }
+      slot_unk.insert(slot_unk.end(), C.slot_unk.begin(), C.slot_unk.end());
+      slot_first.insert(slot_first.end(), C.slot_first.begin(), C.slot_first.end());
+      for (int v : C.slot_inc) slot_inc.push_back(v < 0 ? -1 : v + ioff);
+      inc_unk.insert(inc_unk.end(), C.inc_unk.begin(), C.inc_unk.end());
+      inc_state.insert(inc_state.end(), C.inc_state.begin(), C.inc_state.end());
+      int ib = ioff;
+      for (int sp = C.sp0; sp < C.sp1; ++sp) {
+        sp_i[sp] = ib;
+        const int lpt = points[order[sp]].unk;
+        if (lpt >= 0) { l_i0[lpt] = ib; l_i1[lpt] = ib + C.sp_ninc[sp - C.sp0]; l_sp[lpt] = sp; }
+        ib += C.sp_ninc[sp - C.sp0];
       }
     }
-    if (lpt >= 0) { l_i0[lpt] = ibase; l_i1[lpt] = (int)inc_unk.size(); l_sp[lpt] = sp; }
-    if ((int)q.size() > GRP_LMAX) sp_big[sp] = 1;
   }
-  sp_m[nsp] = j; sp_i[nsp] = (int)inc_unk.size();
+  sp_i[nsp] = (int)inc_unk.size();
   slot_start[nmeas] = (int)slot_unk.size();
   ninc = (int)inc_unk.size(); nslot = (int)slot_unk.size();
   lap("sort+slots");
