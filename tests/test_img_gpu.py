@@ -481,3 +481,54 @@ def test_camera_per_rank_pose_refine(gpu_required):
     assert np.allclose(r0["R"], pg[0], rtol=0, atol=1e-11) and np.allclose(r0["t"], pg[1], rtol=0, atol=1e-11)
     assert np.allclose(r0["w"], wg[recs["cam"] == 0], rtol=0, atol=1e-9) and np.allclose(r1["w"], wg[recs["cam"] == 1], rtol=0, atol=1e-9)
     assert int(r0["calls"]) == 20                       # two collectives per iteration, ten iterations
+
+
+def test_c5_tracker_frames_and_window_ba_pipelined(gpu_required):
+    """BASELINE config c5's pipeline on one device: the per-frame tracker path (1280x960 pyramid + FAST + PatchFinder search + pose
+    iterations) keeps running while a windowed local bundle (BundleAdjustRecent shape) is being adjusted by another host thread --
+    every handle has its own HIP stream, nothing is shared.  Both must give exactly what they give alone."""
+    import threading
+    from mcptam_amd import synth, synth_img
+    from mcptam_amd.chain_bundle import ChainBundle
+    from mcptam_amd.keyframe import pose_points, track_pose_refine, track_search
+    from helpers import run_bundle
+    sc = synth_img.make_tracking_scene(size=(1280, 960))
+    gA, oA = _pair(1280, 960)
+    gA.MakeKeyFrame_Lite(sc["imgA"]); oA.MakeKeyFrame_Lite(sc["imgA"])
+    gA.MakeKeyFrame_Rest(); oA.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(sc["cam"], gA, oA, sc["poseA"], sc["depth"], per_level=(300, 200, 100, 40))
+    wp = np.array([p["world_pos"] for p in pts])
+    I = (np.eye(3), np.zeros(3))
+    from mcptam_amd.keyframe import KeyFrame
+
+    def frame(kf):
+        kf.MakeKeyFrame_Lite(sc["imgB"])
+        out = track_search(kf, sc["cam"], sc["poseB"], I, pts, 10, 8)
+        pose, mu, w, _ = track_pose_refine(pose_points(wp, out, 0), [sc["cam"]], [I], sc["poseB"])
+        return out, pose, mu
+
+    cur = KeyFrame(1280, 960)
+    ref_out, ref_pose, ref_mu = frame(cur)
+    win = synth.recent_window(synth.make_config("c2", n_mkf=40, n_points=6000))
+    ref_ba = run_bundle(ChainBundle(win.cams, True, True, False), win, 10)
+
+    result = {}
+
+    def ba_thread():
+        result["ba"] = [run_bundle(ChainBundle(win.cams, True, True, False), win, 10) for _ in range(3)]
+    th = threading.Thread(target=ba_thread)
+    th.start()
+    frames = []
+    while th.is_alive() or len(frames) < 5:
+        frames.append(frame(cur))
+        if len(frames) > 400:
+            break
+    th.join()
+    assert len(frames) >= 5
+    for out, pose, mu in frames:
+        assert np.array_equal(out["templ"], ref_out["templ"]) and np.array_equal(out["found"], ref_out["found"])
+        assert np.array_equal(out["found_pos"], ref_out["found_pos"])
+        assert np.array_equal(pose[0], ref_pose[0]) and np.array_equal(pose[1], ref_pose[1]) and np.array_equal(mu, ref_mu)
+    for r in result["ba"]:
+        assert r["rc"] == ref_ba["rc"] and r["logs"] == ref_ba["logs"]
+        assert np.array_equal(r["R"], ref_ba["R"]) and np.array_equal(r["t"], ref_ba["t"]) and np.array_equal(r["X"], ref_ba["X"])
