@@ -480,20 +480,25 @@ struct CholPlan {
 
 // factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
 // nsys > 1 factors further systems stored q*sys_stride doubles behind the first in the same launches (fail[q] is their flag)
-inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0) {
+// q0: index of the first of the nsys systems inside the batch buffers (S, fail and the diagonal side array are offset by it)
+inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
   const int n = plan.n, nrows = n + 1;
+  S += q0*sys_stride; fail += q0;
+  double* dg = plan.d_diag + q0*plan.diag_stride;
   for (int k = 0; k < plan.ntc; ++k) {
     const int cnt = plan.step_start[k + 1] - plan.step_start[k];
-    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride CH_DIAG_ARGS(plan));
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride, dg, plan.diag_stride);
   }
 }
 // row n: y -> x = L^-T y
-inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0) {
+inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
   const int n = plan.n;
+  S += q0*sys_stride;
+  const double* dg = plan.d_diag + q0*plan.diag_stride;
   static bool attr_set = false;      // x (up to CH_SOLVE_MAX doubles) + the staged tiles can exceed the default 64 KB of LDS
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SOLVE_MAX*(int)sizeof(double)); attr_set = true; }
   hipLaunchKernelGGL(k_chol_back, dim3(nsys), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
-                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride CH_DIAG_ARGS(plan));
+                     (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride, dg, plan.diag_stride);
 }
 
 }  // namespace mcp

@@ -89,6 +89,12 @@ enum Stage { ST_EVAL = 0, ST_SELECT, ST_LIN, ST_SCHUR, ST_CHOL, ST_SOLVE, ST_UPD
 struct mcp_ba {
   int device = 0;
   hipStream_t st = nullptr;
+  // second stream: the speculative systems of a solve are built and factored here while the main stream already factors the
+  // system the trial needs (both chains are latency-bound and overlap); ev_fork / ev_spec order the two
+  // (MCP_BA_OVERLAP: 0 = one stream, 1 = the speculative systems together on a second stream, 2 = system 1 on the second and
+  // systems 2.. on a third stream, so that the system the SECOND trial needs is ready as early as the first one's)
+  hipStream_t st2 = nullptr, st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_spec = nullptr, ev_spec3 = nullptr;
+  bool spec_pending = false, spec3_pending = false; int spec3_from = MAX_SYS; int overlap_spec = 1;
   std::vector<mcp_camera> cams;
   int robust = 1, tukey = 1, verbose = 0;
   mcp_ba_params prm;
@@ -171,7 +177,20 @@ struct mcp_ba {
     if (h_fail) (void)hipHostFree(h_fail);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
+    if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
+    if (st3) { (void)hipStreamSynchronize(st3); (void)hipStreamDestroy(st3); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_spec) (void)hipEventDestroy(ev_spec);
+    if (ev_spec3) (void)hipEventDestroy(ev_spec3);
     if (st) (void)hipStreamDestroy(st);
+  }
+  // everything the second stream still has in flight reads the current linearisation (W, V, g, staged blocks): the main stream
+  // must not overwrite any of it, nor consume a speculative solution, before that work is done
+  // q < 0: everything; otherwise only the stream that produces system q of the batch
+  int join_spec(int q = -1) {
+    if (spec_pending && (q < 0 || q < spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
+    if (spec3_pending && (q < 0 || q >= spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec3, 0)); spec3_pending = false; }
+    return 0;
   }
 
   double* Ubig() { return nbig ? d_ubig.p : nullptr; }
@@ -262,7 +281,7 @@ struct mcp_ba {
   int median_sigma(int which);
   int read_results(int count);
   int linearize();
-  int build_system(int nsys, SysBatch& sb);
+  int build_system(int nsys, SysBatch& sb, int q0 = 0, hipStream_t on = nullptr);
   int solve_trial(double lam, bool& ok2, double ni = 0);
   int compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda);
   int final_stats(int nCounter);
@@ -739,6 +758,7 @@ int mcp_ba::read_results(int count) {
 
 // buildSystem at the current state (sigma block must be current)
 int mcp_ba::linearize() {
+  if (join_spec()) return -1;        // the second stream may still be reading the previous linearisation
   spec_ok = false;                   // a speculative solve belongs to the linearisation it was built from
   tic(ST_LIN);
   const size_t n2 = (size_t)np*np;
@@ -772,22 +792,29 @@ int mcp_ba::linearize() {
 
 // The reduced system(s) of the current linearisation for the lambdas of `sb`: every rank contributes U_r - Schur_r
 // (+ lambda I once, on rank 0: sb.lambda_init), bp_r - W V^-1 g and bp_r; summed over the ranks when there are several.
-int mcp_ba::build_system(int nsys, SysBatch& sb) {
+int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
+  hipStream_t s = on ? on : st;
+  const bool main_stream = (s == st);
+  // the systems [q0, q0 + nsys) of the batch: a shifted copy of the lambda table, buffers offset by q0 system strides
+  SysBatch sb = sbfull;
+  for (int i = 0; i < nsys; ++i) { sb.lambda[i] = sbfull.lambda[q0 + i]; sb.lambda_init[i] = sbfull.lambda_init[q0 + i]; }
   sb.sstride = red_stride; sb.vstride = vinv_stride; sb.ststride = nstage*36; sb.strstride = (size_t)nrhs_rows*6;
-  HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-  tic(ST_SCHUR);
-  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, st, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, d_Vinv.p, d_stS.p, d_str.p, d_fail.p, sb);
+  sbfull.sstride = sb.sstride; sbfull.vstride = sb.vstride; sbfull.ststride = sb.ststride; sbfull.strstride = sb.strstride;
+  double* Sq = d_red.p + q0*red_stride; double* Vq = d_Vinv.p + q0*vinv_stride;
+  double* stSq = d_stS.p + q0*sb.ststride; double* strq = d_str.p + q0*sb.strstride; int* failq = d_fail.p + q0;
+  if (main_stream) tic(ST_SCHUR);
+  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, s, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, stSq, strq, failq, sb);
   else if (ngroup && nstage) {      // no free point: nothing is eliminated, the staged Schur blocks are zero
-    HIPCK(hipMemsetAsync(d_stS.p, 0, (size_t)nsys*nstage*36*sizeof(double), st));
-    HIPCK(hipMemsetAsync(d_str.p, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), st));
+    HIPCK(hipMemsetAsync(stSq, 0, (size_t)nsys*nstage*36*sizeof(double), s));
+    HIPCK(hipMemsetAsync(strq, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), s));
   }
-  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
-                             (const double*)d_stS.p, (const double*)d_str.p, (const double*)Ubig(), d_red.p, sb);
-  if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, st, P, 1, sb.lambda[0], d_V.p, d_g.p, d_W.p, d_Vinv.p, d_red.p, d_red.p + (size_t)np*np, d_fail.p, sb);
-  toc();
+  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(256), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
+                             (const double*)stSq, (const double*)strq, (const double*)Ubig(), Sq, sb);
+  if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, s, P, 1, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, Sq, Sq + (size_t)np*np, failq, sb);
+  if (main_stream) toc();
 #ifdef MCP_SCH_PROF
   {
-    HIPCK(hipStreamSynchronize(st));
+    HIPCK(hipStreamSynchronize(s));
     unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sch_prof), sizeof pr);
     double a[8] = {0}; int cnt = 0;
     for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[7]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
@@ -796,11 +823,11 @@ int mcp_ba::build_system(int nsys, SysBatch& sb) {
   }
 #endif
   if (np && multi()) {
-    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack
+    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack (main stream only: one communicator)
     const size_t npack = pack_stride*nsys;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_red.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)Sq, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
     if (allreduce(d_pack.p, npack)) return -1;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, d_red.p, 0, red_stride, pack_stride);
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, Sq, 0, red_stride, pack_stride);
   }
   return 0;
 }
@@ -810,7 +837,8 @@ int mcp_ba::build_system(int nsys, SysBatch& sb) {
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const int tr = cur ^ 1;
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
-    // an earlier trial of this iteration already built and solved this system speculatively
+    // an earlier trial of this iteration already built and solved this system speculatively (possibly on the second stream)
+    if (join_spec(sys_cur + 1)) return -1;
     ++sys_cur;
     timing.n_spec_hits++;
   } else {
@@ -820,6 +848,33 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     SysBatch sb; std::memset(&sb, 0, sizeof sb);
     { double l = lam, f = ni; for (int q = 0; q < nsys; ++q) { batch_lambda[q] = sb.lambda[q] = l; sb.lambda_init[q] = (rank == 0) ? l : 0.0; l *= f; f *= 2; } }
     batch_n = nsys;
+    if (join_spec()) return -1;            // (a re-solve inside an iteration: the previous batch's stragglers first)
+    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    const bool split = overlap_spec && nsys > 1 && np > 0 && !multi() && !use_graph && st2;
+    if (split) {
+      // system 0 -- the one this trial needs -- alone on the main stream; the speculative systems behind the fork on the second
+      // stream.  Same kernels on the same data as the batched path: the numbers do not depend on which stream produced them.
+      HIPCK(hipEventRecord(ev_fork, st));
+      if (build_system(1, sb, 0, st)) return -1;
+      tic(ST_CHOL); chol_factor(st, plan, d_red.p, d_fail.p, 1, red_stride, 0); toc();
+      tic(ST_SOLVE); chol_back(st, plan, d_red.p, 1, red_stride, 0); toc();
+      const int n2 = (overlap_spec >= 2 && nsys > 2 && st3) ? 1 : nsys - 1;       // systems on the second stream
+      HIPCK(hipStreamWaitEvent(st2, ev_fork, 0));
+      if (build_system(n2, sb, 1, st2)) return -1;
+      chol_factor(st2, plan, d_red.p, d_fail.p, n2, red_stride, 1);
+      chol_back(st2, plan, d_red.p, n2, red_stride, 1);
+      HIPCK(hipEventRecord(ev_spec, st2));
+      spec_pending = true; spec3_from = 1 + n2;
+      if (1 + n2 < nsys) {
+        const int n3 = nsys - 1 - n2;
+        HIPCK(hipStreamWaitEvent(st3, ev_fork, 0));
+        if (build_system(n3, sb, 1 + n2, st3)) return -1;
+        chol_factor(st3, plan, d_red.p, d_fail.p, n3, red_stride, 1 + n2);
+        chol_back(st3, plan, d_red.p, n3, red_stride, 1 + n2);
+        HIPCK(hipEventRecord(ev_spec3, st3));
+        spec3_pending = true;
+      }
+    } else {
     if (build_system(nsys, sb)) return -1;
     if (np) {
       if (use_graph && !prm.profile) {
@@ -841,6 +896,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
         tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); toc();
         tic(ST_SOLVE); chol_back(st, plan, S(), nsys, red_stride); toc();
       }
+    }
     }
     spec_ok = (nsys > 1);
     timing.n_solves++;
@@ -1013,6 +1069,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     }
     nCounter = cj;
   }
+  if (join_spec()) return MCP_ERR_RUNTIME;
   int rc = final_stats(nCounter);
   if (rc == MCP_ERR_RUNTIME) return rc;
   converged = (conv_mag || conv_res);
@@ -1073,6 +1130,8 @@ int mcp_ba::final_stats(int nCounter) {
     bool okm = true;
     sys_cur = 0; spec_ok = false;
     SysBatch sb; std::memset(&sb, 0, sizeof sb);
+    if (join_spec()) return -2;
+    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
     if (build_system(1, sb)) return -2;
     const size_t n2 = (size_t)np*np;
     hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, 0, (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)d_fail.p);
@@ -1139,6 +1198,11 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   std::memset(&h->timing, 0, sizeof h->timing);
   std::memset(&h->P, 0, sizeof h->P);
   if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
+  { const char* e = getenv("MCP_BA_OVERLAP"); if (e) h->overlap_spec = atoi(e); }
+  if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess)) { set_err("second stream / events could not be created"); delete h; return nullptr; }
   return h;
 }
 void mcp_ba_destroy(mcp_ba* h) { if (h) { (void)hipSetDevice(h->device); delete h; } }
@@ -1331,6 +1395,7 @@ int mcp_ba_debug_system(mcp_ba* h, double lambda, double* out) {
   h->sys_cur = 0; h->spec_ok = false;
   SysBatch sb; std::memset(&sb, 0, sizeof sb);
   sb.lambda[0] = lambda; sb.lambda_init[0] = (h->rank == 0) ? lambda : 0.0;
+  HIPCK(hipMemsetAsync(h->d_fail.p, 0, 4*sizeof(int), h->st));
   if (h->build_system(1, sb)) return -1;
   const size_t n2 = (size_t)h->np*h->np;
   // the entries outside the plan's tiles are never written by the assembly: report them as zeros
