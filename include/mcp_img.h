@@ -53,6 +53,15 @@ void    mcp_kf_destroy(mcp_kf*);
  * tightly packed mask of that level's size; a corner is kept only where mask == 255, :305). */
 int mcp_kf_make_lite(mcp_kf*, const uint8_t* img, int stride, const uint8_t* const* masks);
 
+/* The MakeKeyFrame_Lite loop over the cameras of a frame (Tracker::TrackFrame, src/Tracker.cc:303-318) as ONE submission:
+ * uploads + three kernel launches for all levels of all cameras + one wait.  kfs: ncam distinct handles on one device that
+ * share adaptive_thresh / half_sample_pavgb; imgs_on_device != 0: imgs[] are device pointers (a capture ring that already
+ * lives in HBM), nothing crosses PCIe.  masks: NULL, or per camera NULL / MCP_LEVELS pointers as in mcp_kf_make_lite.
+ * Results are those of ncam mcp_kf_make_lite calls, bit for bit. */
+#define MCP_MAX_FRAME_CAMS 8
+int mcp_kf_make_lite_batch(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                           const uint8_t* const* const* masks);
+
 /* read-back of what MakeKeyFrame_Lite leaves in Level (image, vCorners, vCornerRowLUT, nFastThresh,
  * vFastFrequency) */
 int mcp_kf_level_size(mcp_kf*, int level, int* w, int* h);
@@ -164,6 +173,11 @@ typedef struct mcp_td_out {
 int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double base_from_world[12],
                      const double cam_from_base[12], int n, const mcp_td_in* in, int range,
                      int subpix_its, int exhaustive, mcp_td_out* out);
+/* SearchForPoints for every camera of a frame in one launch (the per-camera loops of Tracker::TrackMap, src/Tracker.cc:985-1030):
+ * targets[c], cams[c], cam_from_base[12*c..], n[c] points in[c] -> out[c]; results equal ncam mcp_track_search calls. */
+int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double base_from_world[12],
+                           const double* cam_from_base /* ncam x 12 */, const int* n, const mcp_td_in* const* in,
+                           int range, int subpix_its, int exhaustive, mcp_td_out* const* out);
 
 /* Tracker::CalcPoseUpdate (Tukey M-estimator, WLS<6> with prior 100)   Tracker.cc:1386-1512
  * found[i] != 0 rows contribute.  override_sigma <= 0: Tukey sigma^2 from the median.

@@ -30,8 +30,9 @@ template <class T> struct Buf {
 struct Level {
   int w = 0, h = 0, cap = 0;
   Buf<uint8_t> img, mask, tmp_a, tmp_b;
-  Buf<mcp_int2> all_xy, corners, cand_pos;
-  Buf<int> all_score, lut, blk_cnt, score_img;
+  Buf<mcp_int2> corners, cand_pos;
+  Buf<uint8_t> score8;                             // FAST score per pixel at the detection threshold (0 = no corner), scratch of MakeKeyFrame_Lite
+  Buf<int> lut, rowcnt, blk_cnt, score_img;
   Buf<double> cand_score;
   Buf<LevelInfo> info;
   bool has_mask = false;
@@ -63,12 +64,16 @@ struct mcp_kf {
   Buf<DevTdIn> td_in; Buf<mcp_td_out> td_out;
   Buf<mcp_int2> mp_a, mp_b, mp_o; Buf<uint8_t> mp_f, mp_f2; Buf<int> mp_s;
   bool has_image = false;
-  LevelInfo* h_info = nullptr;      // pinned: the four levels' bookkeeping, read back with the frame (one wait per frame)
+  LevelInfo* h_info = nullptr;      // pinned, device-visible: the kernels leave the four levels' bookkeeping here (one wait per frame)
+  Buf<int> work;                    // threshold histogram + detected-corner count per level; k_row_compact leaves it zero again
+  bool work_dirty = true;
+  Buf<SearchCam> stab; Buf<DevTdIn> bt_in; Buf<mcp_td_out> bt_out;      // batched search: camera table + points of all cameras
+  hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
   Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
   Buf<uint8_t> sbi_last_small; Buf<float> sbi_last_templ, sbi_last_jacs; bool has_last_sbi = false;   // the SBI made before the current one (Tracker::mmpSBILastFrame)
   Buf<const float*> sbi_ptrs; Buf<double> sbi_out;
-  ~mcp_kf() { if (st) (void)hipStreamDestroy(st); if (h_info) (void)hipHostFree(h_info); }
+  ~mcp_kf() { if (st) (void)hipStreamDestroy(st); if (h_info) (void)hipHostFree(h_info); if (ev) (void)hipEventDestroy(ev); }
   DevKfView view() const {
     DevKfView v;
     for (int l = 0; l < MCP_LEVELS; ++l) { v.img[l] = lev[l].img.p; v.w[l] = lev[l].w; v.h[l] = lev[l].h; v.corners[l] = lev[l].corners.p; v.lut[l] = lev[l].lut.p; v.info[l] = lev[l].info.p; }
@@ -91,10 +96,13 @@ mcp_kf* mcp_kf_create(int w, int h, const mcp_kf_params* params) {
   if (hipSetDevice(dev) != hipSuccess) { mcp_set_error("hipSetDevice failed"); return nullptr; }
   mcp_kf* k = new mcp_kf(); k->device = dev; k->prm = p;
   if (hipStreamCreateWithFlags(&k->st, hipStreamNonBlocking) != hipSuccess) { mcp_set_error("hipStreamCreate failed"); delete k; return nullptr; }
+  if (hipEventCreateWithFlags(&k->ev, hipEventDisableTiming) != hipSuccess || hipHostMalloc((void**)&k->h_info, MCP_LEVELS*sizeof(LevelInfo)) != hipSuccess ||
+      k->work.alloc(FRAME_WORK_INTS)) { mcp_set_error("mcp_kf_create: allocation failed"); delete k; return nullptr; }
+  std::memset(k->h_info, 0, MCP_LEVELS*sizeof(LevelInfo));
   for (int l = 0; l < MCP_LEVELS; ++l) {
     Level& L = k->lev[l]; L.w = w >> l; L.h = h >> l; L.cap = std::max(1024, L.w*L.h/2);
-    const size_t npx = (size_t)L.w*L.h; const int nblk = (int)((npx + FAST_BLOCK - 1)/FAST_BLOCK) + (L.cap + FAST_BLOCK - 1)/FAST_BLOCK + 2;
-    if (L.img.alloc(npx) || L.mask.alloc(npx) || L.all_xy.alloc(L.cap) || L.all_score.alloc(L.cap) || L.corners.alloc(L.cap) ||
+    const size_t npx = (size_t)L.w*L.h; const int nblk = (L.cap + FAST_BLOCK - 1)/FAST_BLOCK + 2;
+    if (L.img.alloc(npx) || L.mask.alloc(npx) || L.score8.alloc(npx) || L.rowcnt.alloc(L.h) || L.corners.alloc(L.cap) ||
         L.lut.alloc(L.h) || L.blk_cnt.alloc(nblk) || L.info.alloc(1) || L.cand_pos.alloc(L.cap) || L.cand_score.alloc(L.cap)) { delete k; return nullptr; }
     (void)hipMemset(L.info.p, 0, sizeof(LevelInfo));
   }
@@ -102,52 +110,76 @@ mcp_kf* mcp_kf_create(int w, int h, const mcp_kf_params* params) {
 }
 void mcp_kf_destroy(mcp_kf* k) { if (k) { (void)hipSetDevice(k->device); delete k; } }
 
-int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
-  ICK(hipSetDevice(k->device));
-  hipStream_t st = k->st;
+// MakeKeyFrame_Lite of every camera of a frame in one submission (the loop of Tracker::TrackFrame, src/Tracker.cc:303-318): the
+// uploads, three launches for all levels of all cameras (k_pyr_fast, k_row_count, k_row_compact) and one wait.
+int mcp_kf_make_lite_batch(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                           const uint8_t* const* const* masks) {
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !kfs || !imgs || !strides) return img_fail("mcp_kf_make_lite_batch: bad arguments");
+  for (int c = 0; c < ncam; ++c) {
+    if (!kfs[c] || !imgs[c] || kfs[c]->device != kfs[0]->device) return img_fail("mcp_kf_make_lite_batch: keyframes must live on one device");
+    for (int d = 0; d < c; ++d) if (kfs[d] == kfs[c]) return img_fail("mcp_kf_make_lite_batch: a keyframe appears twice");
+  }
+  ICK(hipSetDevice(kfs[0]->device));
+  hipStream_t st = kfs[0]->st;
   static const int fixed_t[4] = { 10, 15, 15, 10 };
-  // the frame currently held moves into the history before it is overwritten, KeyFrame.cc:152-199
-  if (k->has_image) for (int l = 0; l < MCP_LEVELS; ++l) if (k->lev[l].push_history()) return -1;
-  k->has_image = true;
-  for (int l = 0; l < MCP_LEVELS; ++l) {
-    Level& L = k->lev[l];
-    const size_t npx = (size_t)L.w*L.h;
-    if (l == 0) ICK(hipMemcpy2DAsync(L.img.p, L.w, img, stride, L.w, L.h, hipMemcpyHostToDevice, st));
-    else {
-      const Level& Pv = k->lev[l - 1];
-      hipLaunchKernelGGL(k_half_sample, dim3((L.w + 31)/32, (L.h + 7)/8), dim3(32, 8), 0, st, (const uint8_t*)Pv.img.p, Pv.w, L.img.p, L.w, L.h, k->prm.half_sample_pavgb);
+  // launches are grouped by the settings a launch shares; a frame's cameras normally share all of them
+  for (int c = 1; c < ncam; ++c)
+    if (kfs[c]->prm.adaptive_thresh != kfs[0]->prm.adaptive_thresh || kfs[c]->prm.half_sample_pavgb != kfs[0]->prm.half_sample_pavgb)
+      return img_fail("mcp_kf_make_lite_batch: the keyframes of a batch must share adaptive_thresh and half_sample_pavgb");
+  FrameBatch B; std::memset(&B, 0, sizeof B);
+  B.ncam = ncam; B.adaptive = kfs[0]->prm.adaptive_thresh; B.pavgb = kfs[0]->prm.half_sample_pavgb;
+  for (int l = 0; l < MCP_LEVELS; ++l) B.detect_t[l] = B.adaptive ? MCP_MIN_FAST_THRESH : fixed_t[l];
+  int maxtiles = 0, maxh = 0; bool glare = false;
+  for (int c = 0; c < ncam; ++c) {
+    mcp_kf* k = kfs[c];
+    // the frame currently held moves into the history before it is overwritten, KeyFrame.cc:152-199
+    if (k->has_image) for (int l = 0; l < MCP_LEVELS; ++l) if (k->lev[l].push_history()) return -1;
+    k->has_image = true;
+    if (k->work_dirty) { ICK(hipMemsetAsync(k->work.p, 0, FRAME_WORK_INTS*sizeof(int), st)); }
+    k->work_dirty = true;                         // until k_row_compact of this frame has run to the end
+    FrameCam& C = B.c[c];
+    const Level& L0 = k->lev[0];
+    C.w = L0.w; C.h = L0.h; C.work = k->work.p; C.host_info = k->h_info;
+    if (imgs_on_device) { C.src = imgs[c]; C.src_stride = strides[c]; }
+    else { ICK(hipMemcpy2DAsync(L0.img.p, L0.w, imgs[c], strides[c], L0.w, L0.h, hipMemcpyHostToDevice, st)); C.src = L0.img.p; C.src_stride = L0.w; }
+    for (int l = 0; l < MCP_LEVELS; ++l) {
+      Level& L = k->lev[l];
+      C.img[l] = L.img.p; C.score[l] = L.score8.p; C.corners[l] = L.corners.p; C.lut[l] = L.lut.p; C.rowcnt[l] = L.rowcnt.p; C.info[l] = L.info.p; C.cap[l] = L.cap;
+      const uint8_t* m = masks && masks[c] ? masks[c][l] : nullptr;
+      if (m) ICK(hipMemcpyAsync(L.mask.p, m, (size_t)L.w*L.h, hipMemcpyHostToDevice, st));
+      C.mask[l] = (m || k->prm.glare_masking) ? L.mask.p : nullptr;
+      L.has_mask = C.mask[l] != nullptr;
     }
-    const uint8_t* internal = nullptr;
-    if (masks && masks[l]) { ICK(hipMemcpyAsync(L.mask.p, masks[l], npx, hipMemcpyHostToDevice, st)); internal = L.mask.p; }
-    const uint8_t* mask = internal;
-    if (k->prm.glare_masking) {
+    glare = glare || k->prm.glare_masking;
+    maxtiles = std::max(maxtiles, ((C.w + PYR_T - 1)/PYR_T)*((C.h + PYR_T - 1)/PYR_T)); maxh = std::max(maxh, C.h);
+  }
+  hipLaunchKernelGGL(k_pyr_fast, dim3(maxtiles, ncam), dim3(256), 0, st, B);
+  if (glare) for (int c = 0; c < ncam; ++c) {        // cv::dilate x5 of every level image, KeyFrame.cc:214-238 (needs the level images: after k_pyr_fast)
+    mcp_kf* k = kfs[c];
+    if (!k->prm.glare_masking) continue;
+    for (int l = 0; l < MCP_LEVELS; ++l) {
+      Level& L = k->lev[l];
+      const size_t npx = (size_t)L.w*L.h;
       if (L.tmp_a.alloc(npx) || L.tmp_b.alloc(npx)) return -1;
+      const uint8_t* internal = masks && masks[c] && masks[c][l] ? L.mask.p : nullptr;
       const uint8_t* src = L.img.p; uint8_t* a = L.tmp_a.p; uint8_t* b = L.tmp_b.p;
       for (int it = 0; it < 5; ++it) { hipLaunchKernelGGL(k_dilate5, dim3((L.w + 31)/32, (L.h + 7)/8), dim3(32, 8), 0, st, src, a, L.w, L.h); src = a; std::swap(a, b); }
       hipLaunchKernelGGL(k_glare_mask, dim3((unsigned)((npx + 255)/256)), dim3(256), 0, st, src, internal, L.mask.p, (int)npx);
-      mask = L.mask.p;
     }
-    L.has_mask = mask != nullptr;
-    ICK(hipMemsetAsync(L.info.p, 0, sizeof(LevelInfo), st));
-    const int nb = (int)((npx + FAST_BLOCK - 1)/FAST_BLOCK);
-    const int b = k->prm.adaptive_thresh ? MCP_MIN_FAST_THRESH : fixed_t[l];
-    hipLaunchKernelGGL(k_fast_count, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, L.blk_cnt.p);
-    if (k->prm.adaptive_thresh) {
-      hipLaunchKernelGGL(k_fast_write, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, (const int*)L.blk_cnt.p, L.cap, L.all_xy.p, L.all_score.p, L.info.p, 1);
-      const int nb2 = (L.cap + FAST_BLOCK - 1)/FAST_BLOCK;
-      int* cnt2 = L.blk_cnt.p + nb + 1;
-      hipLaunchKernelGGL(k_thresh_count, dim3(nb2), dim3(FAST_BLOCK), 0, st, (const mcp_int2*)L.all_xy.p, (const int*)L.all_score.p, mask, L.w, L.h, L.info.p, cnt2);
-      hipLaunchKernelGGL(k_thresh_write, dim3(nb2), dim3(FAST_BLOCK), 0, st, (const mcp_int2*)L.all_xy.p, (const int*)L.all_score.p, mask, L.w, L.info.p, (const int*)cnt2, L.corners.p);
-    } else {
-      hipLaunchKernelGGL(k_fast_write, dim3(nb), dim3(FAST_BLOCK), 0, st, (const uint8_t*)L.img.p, L.w, L.h, b, (const int*)L.blk_cnt.p, L.cap, L.corners.p, L.all_score.p, L.info.p, 0);
-    }
-    hipLaunchKernelGGL(k_row_lut, dim3((L.h + 63)/64), dim3(64), 0, st, (const mcp_int2*)L.corners.p, (const LevelInfo*)L.info.p, L.h, L.lut.p);
   }
-  if (!k->h_info) ICK(hipHostMalloc((void**)&k->h_info, MCP_LEVELS*sizeof(LevelInfo)));
-  for (int l = 0; l < MCP_LEVELS; ++l) ICK(hipMemcpyAsync(k->h_info + l, k->lev[l].info.p, sizeof(LevelInfo), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
+  ICK(hipGetLastError());
   ICK(hipStreamSynchronize(st));
-  for (int l = 0; l < MCP_LEVELS; ++l) if (k->h_info[l].overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
+  for (int c = 0; c < ncam; ++c) {
+    kfs[c]->work_dirty = false;
+    for (int l = 0; l < MCP_LEVELS; ++l) if (kfs[c]->h_info[l].overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
+  }
   return 0;
+}
+int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
+  mcp_kf* kfs[1] = { k }; const uint8_t* imgs[1] = { img }; const int strides[1] = { stride }; const uint8_t* const* ms[1] = { masks };
+  return mcp_kf_make_lite_batch(1, kfs, imgs, strides, 0, masks ? ms : nullptr);
 }
 
 static int get_info(mcp_kf* k, int level, LevelInfo* inf) {
@@ -500,6 +532,44 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12]
   hipLaunchKernelGGL(k_track_search, dim3(n), dim3(64), 0, target->st, target->view(), *cam, B, C, n, (const DevTdIn*)din.p, range, subpix_its, exhaustive, dout.p);
   ICK(hipMemcpyAsync(out, dout.p, sizeof(mcp_td_out)*(size_t)n, hipMemcpyDeviceToHost, target->st));
   ICK(hipStreamSynchronize(target->st));
+  return 0;
+}
+
+// SearchForPoints of every camera of a frame in one launch (the per-camera loops of Tracker::TrackMap, src/Tracker.cc:985-1030, 1299-1384)
+int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                           const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out) {
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
+  int total = 0, maxn = 0;
+  for (int c = 0; c < ncam; ++c) {
+    if (!targets[c] || n[c] < 0 || cams[c].n_inv < 0 || targets[c]->device != targets[0]->device) return img_fail("mcp_track_search_batch: bad arguments");
+    total += n[c]; maxn = std::max(maxn, n[c]);
+  }
+  if (total == 0) return 0;
+  mcp_kf* k0 = targets[0];
+  ICK(hipSetDevice(k0->device));
+  std::vector<SearchCam> tab(ncam); std::vector<DevTdIn> h(total);
+  int first = 0;
+  for (int c = 0; c < ncam; ++c) {
+    SearchCam& S = tab[c];
+    S.T = targets[c]->view(); S.cam = cams[c]; std::memcpy(S.cfb.R, cfb + 12*c, 72); std::memcpy(S.cfb.t, cfb + 12*c + 9, 24); S.n = n[c]; S.first = first;
+    for (int i = 0; i < n[c]; ++i) {
+      const mcp_td_in& p = in[c][i]; DevTdIn& d = h[first + i];
+      if (!p.source_kf || p.source_level < 0 || p.source_level >= MCP_LEVELS) return img_fail("mcp_track_search_batch: point without a resident source keyframe");
+      std::memcpy(d.world_pos, p.world_pos, 24); std::memcpy(d.pixel_right_w, p.pixel_right_w, 24); std::memcpy(d.pixel_down_w, p.pixel_down_w, 24);
+      const Level& Sl = p.source_kf->lev[p.source_level];
+      d.src_img = Sl.img.p; d.src_w = Sl.w; d.src_h = Sl.h; d.center_x = p.center_x; d.center_y = p.center_y; d.fixed = p.fixed;
+    }
+    first += n[c];
+  }
+  if (k0->stab.alloc(MCP_MAX_FRAME_CAMS) || k0->bt_in.alloc(total) || k0->bt_out.alloc(total)) return -1;
+  hipStream_t st = k0->st;
+  ICK(hipMemcpyAsync(k0->stab.p, tab.data(), sizeof(SearchCam)*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->bt_in.p, h.data(), sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
+  Se3 Bw; std::memcpy(Bw.R, bfw, 72); std::memcpy(Bw.t, bfw + 9, 24);
+  hipLaunchKernelGGL(k_track_search_batch, dim3(maxn, ncam), dim3(64), 0, st, (const SearchCam*)k0->stab.p, Bw, (const DevTdIn*)k0->bt_in.p, range, subpix_its, exhaustive, k0->bt_out.p);
+  for (int c = 0; c < ncam; ++c)
+    if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + tab[c].first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
+  ICK(hipStreamSynchronize(st));
   return 0;
 }
 

@@ -1,10 +1,9 @@
 // img_kernels.h -- HIP kernels of the KeyFrame / Tracker image path (gfx950).
 //
-//   k_half_sample            CVD::halfSample                         src/KeyFrame.cc:189-190
+//   k_pyr_fast               CVD::halfSample x3 + fast_corner_detect_10 + fast_corner_score_10 + vFastFrequency, all levels of
+//                            all cameras of a frame in one launch, LDS-tiled        src/KeyFrame.cc:189-190, 259-275
 //   k_dilate5 / k_glare_mask cv::dilate x5 + threshold + AND         :214-238
-//   k_fast_count / k_fast_write   fast_corner_detect_10 + fast_corner_score_10, raster-ordered   :259-262
-//   k_thresh_count / k_thresh_write   histogram knee + score/mask filter                  :264-315
-//   k_row_lut                vCornerRowLUT                            :346-355
+//   k_row_count / k_row_compact   histogram knee + score/mask filter, raster-ordered vCorners, vCornerRowLUT   :279-315, 346-355
 //   k_nonmax_* / k_candidates     fast_nonmax + FAST / Shi-Tomasi scores, border 10       :393-420
 //   k_minipatch              MiniPatch::FindPatch                     src/MiniPatch.cc:34-113
 //   k_track_search           TrackerData::Project/CalcJacobian + PatchFinder (warp, template,
@@ -29,17 +28,6 @@ struct LevelInfo {            // device-resident bookkeeping of one pyramid leve
   int hist[32];               // Level::vFastFrequency (cumulative)
   int overflow;
 };
-
-__global__ void k_half_sample(const uint8_t* __restrict__ in, int iw, uint8_t* __restrict__ out, int ow, int oh, int pavgb) {
-  const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y*blockDim.y + threadIdx.y;
-  if (x >= ow || y >= oh) return;
-  const uint8_t* p = in + (size_t)(2*y)*iw + 2*x;
-  const int a = p[0], b = p[1], c = p[iw], d = p[iw + 1];
-  int v;
-  if (pavgb) { const int v0 = (a + c + 1) >> 1, v1 = (b + d + 1) >> 1; v = (v0 + v1 + 1) >> 1; }
-  else v = (a + b + c + d)/4;
-  out[(size_t)y*ow + x] = (uint8_t)v;
-}
 
 __global__ void k_dilate5(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h) {
   const int x = blockIdx.x*blockDim.x + threadIdx.x, y = blockIdx.y*blockDim.y + threadIdx.y;
@@ -139,45 +127,10 @@ __device__ inline int block_prefix(const int* __restrict__ cnt, int b, int* lds)
   return t;
 }
 
-__global__ void __launch_bounds__(FAST_BLOCK)
-k_fast_count(const uint8_t* __restrict__ img, int w, int h, int b, int* __restrict__ blk_cnt) {
-  __shared__ int lds[FAST_BLOCK/64 + 1];
-  const int idx = blockIdx.x*FAST_BLOCK + threadIdx.x;
-  const int x = idx % w, y = idx / w;
-  bool corner = false;
-  if (y >= 3 && y < h - 3 && x >= 3 && x < w - 3) {
-    int r[16]; const uint8_t* p = img + (size_t)y*w + x;
-    fast_ring(p, w, r);
-    corner = fast10_corner(r, *p, b);
-  }
-  int tot; (void)block_rank(corner, &tot, lds);
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
-}
-__global__ void __launch_bounds__(FAST_BLOCK)
-k_fast_write(const uint8_t* __restrict__ img, int w, int h, int b, const int* __restrict__ blk_cnt, int cap,
-             mcp_int2* __restrict__ xy, int* __restrict__ score, LevelInfo* __restrict__ info, int do_hist) {
-  __shared__ int lds[FAST_BLOCK/64 + 1];
-  __shared__ int lh[32];
-  if (threadIdx.x < 32) lh[threadIdx.x] = 0;
-  const int off = block_prefix(blk_cnt, blockIdx.x, lds);
-  const int idx = blockIdx.x*FAST_BLOCK + threadIdx.x;
-  const int x = idx % w, y = idx / w;
-  bool corner = false; int sc = 0;
-  if (y >= 3 && y < h - 3 && x >= 3 && x < w - 3) {
-    int r[16]; const uint8_t* p = img + (size_t)y*w + x;
-    fast_ring(p, w, r);
-    corner = fast10_corner(r, *p, b);
-    if (corner) sc = fast10_score(r, *p);
-  }
-  int tot; const int rank = block_rank(corner, &tot, lds);
-  if (corner) {
-    const int o = off + rank;
-    if (o < cap) { xy[o].x = x; xy[o].y = y; score[o] = sc; } else info->overflow = 1;
-    if (do_hist) { const int top = min(sc, MCP_MAX_FAST_THRESH); for (int t = MCP_MIN_FAST_THRESH; t <= top; ++t) atomicAdd(&lh[t], 1); }
-  }
-  __syncthreads();
-  if (do_hist && threadIdx.x < 32 && lh[threadIdx.x]) atomicAdd(&info->hist[threadIdx.x], lh[threadIdx.x]);
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { info->n_all = min(off + tot, cap); if (!do_hist) { info->n_corners = min(off + tot, cap); info->thresh = b; } }
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
 // knee of the cumulative histogram (KeyFrame.cc:279-300)
 __device__ inline int knee_threshold(const int* hist, int w, int h) {
@@ -193,39 +146,176 @@ __device__ inline int knee_threshold(const int* hist, int w, int h) {
   }
   return th;
 }
-__global__ void __launch_bounds__(FAST_BLOCK)
-k_thresh_count(const mcp_int2* __restrict__ xy, const int* __restrict__ score, const uint8_t* __restrict__ mask, int w, int h,
-               LevelInfo* __restrict__ info, int* __restrict__ blk_cnt) {
-  __shared__ int lds[FAST_BLOCK/64 + 1];
-  __shared__ int th_s;
-  if (threadIdx.x == 0) { th_s = knee_threshold(info->hist, w, h); if (blockIdx.x == 0) info->thresh = th_s; }
+
+// ---- MakeKeyFrame_Lite in three launches for all levels of all cameras of a frame ----------------------
+// k_pyr_fast     one workgroup per 64x64 tile of level 0: the tile + a 24-pixel apron is staged in LDS, levels 1..3 are
+//                half-sampled LDS -> LDS (the apron shrinks to the 3 pixels FAST needs at level 3; values in the aprons are
+//                recomputed by the neighbouring tiles, bit for bit the same integers), every level's interior is written
+//                out once, FAST-10 + its score run on the LDS tiles and leave one score byte per pixel (0 = no corner at the
+//                detection threshold) and the cumulative threshold histogram (integer atomics: order-free).
+// k_row_count    threshold from the histogram knee (or the fixed one), kept corners per image row (one wavefront per row).
+// k_row_compact  exclusive prefix over the rows = vCornerRowLUT; the row's corners are written in x order at that offset, so
+//                vCorners comes out in raster order exactly as fast_corner_detect_10 + the filter loop produce it.
+constexpr int PYR_T = 64;                 // level-0 tile edge
+constexpr int PYR_A = 24;                 // level-0 apron = 3 << (MCP_LEVELS - 1)
+constexpr int PYR_R = PYR_T + 2*PYR_A;    // 112: staged region edge at level 0 (56, 28, 14 above)
+constexpr int FRAME_WORK_INTS = MCP_LEVELS*32 + MCP_LEVELS;      // histogram[level][32], corners detected[level]
+struct FrameCam {             // one camera of a frame: everything the three kernels touch
+  const uint8_t* src; int src_stride;           // level-0 pixels (device); == img[0] when the upload went straight there
+  int w, h;
+  uint8_t* img[MCP_LEVELS]; uint8_t* score[MCP_LEVELS]; const uint8_t* mask[MCP_LEVELS];
+  mcp_int2* corners[MCP_LEVELS]; int* lut[MCP_LEVELS]; int* rowcnt[MCP_LEVELS]; LevelInfo* info[MCP_LEVELS];
+  LevelInfo* host_info;                          // pinned, device-visible: the four levels' bookkeeping lands on the host with the frame
+  int* work; int cap[MCP_LEVELS];
+};
+struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; int detect_t[MCP_LEVELS]; };
+
+__global__ void __launch_bounds__(256)
+k_pyr_fast(const FrameBatch B) {
+  const FrameCam& C = B.c[blockIdx.y];
+  const int ntx = (C.w + PYR_T - 1)/PYR_T, nty = (C.h + PYR_T - 1)/PYR_T;
+  if ((int)blockIdx.x >= ntx*nty) return;
+  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t r0[PYR_R*PYR_R];
+  __shared__ __attribute__((aligned(16))) uint8_t r1[(PYR_R/2)*(PYR_R/2)];
+  __shared__ __attribute__((aligned(16))) uint8_t r2[(PYR_R/4)*(PYR_R/4)];
+  __shared__ __attribute__((aligned(16))) uint8_t r3[(PYR_R/8)*(PYR_R/8) + 4];
+  __shared__ int lh[MCP_LEVELS][32];
+  __shared__ int ln[MCP_LEVELS];
+  if (tid < MCP_LEVELS*32) (&lh[0][0])[tid] = 0;
+  if (tid < MCP_LEVELS) ln[tid] = 0;
+  // level 0: 112 rows of 28 words
+  {
+    const int ox = tx*PYR_T - PYR_A, oy = ty*PYR_T - PYR_A;
+    const bool al = ((((uintptr_t)C.src) | (uintptr_t)C.src_stride) & 3) == 0;
+    for (int i = tid; i < PYR_R*(PYR_R/4); i += 256) {
+      const int ry = i/(PYR_R/4), rx = (i % (PYR_R/4))*4, gy = oy + ry, gx = ox + rx;
+      uint32_t v = 0;
+      if (gy >= 0 && gy < C.h && gx + 3 >= 0 && gx < C.w) {
+        const uint8_t* row = C.src + (size_t)gy*C.src_stride;
+        if (al && gx >= 0 && gx + 3 < C.w) v = *(const uint32_t*)(row + gx);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (gx + q >= 0 && gx + q < C.w) v |= (uint32_t)row[gx + q] << (8*q);
+        }
+      }
+      *(uint32_t*)&r0[ry*PYR_R + rx] = v;
+    }
+  }
   __syncthreads();
-  const int i = blockIdx.x*FAST_BLOCK + threadIdx.x;
-  bool keep = false;
-  if (i < info->n_all) keep = (score[i] >= th_s) && (!mask || mask[(size_t)xy[i].y*w + xy[i].x] == 255);
-  int tot; (void)block_rank(keep, &tot, lds);
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+  uint8_t* const reg[MCP_LEVELS] = { r0, r1, r2, r3 };
+#pragma unroll
+  for (int l = 1; l < MCP_LEVELS; ++l) {
+    const int n = PYR_R >> l, wl = C.w >> l, hl = C.h >> l, ox = (tx*PYR_T - PYR_A) >> l, oy = (ty*PYR_T - PYR_A) >> l;     // arithmetic shift: the origin is a multiple of 8
+    const uint8_t* in = reg[l - 1]; uint8_t* out = reg[l]; const int ni = n*2;
+    for (int i = tid; i < n*n; i += 256) {
+      const int y = i / n, x = i % n, gx = ox + x, gy = oy + y;
+      int v = 0;
+      if (gx >= 0 && gx < wl && gy >= 0 && gy < hl) {
+        const int a = in[(2*y)*ni + 2*x], b = in[(2*y)*ni + 2*x + 1], c = in[(2*y + 1)*ni + 2*x], d = in[(2*y + 1)*ni + 2*x + 1];
+        if (B.pavgb) { const int v0 = (a + c + 1) >> 1, v1 = (b + d + 1) >> 1; v = (v0 + v1 + 1) >> 1; }
+        else v = (a + b + c + d)/4;
+      }
+      out[i] = (uint8_t)v;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int l = 0; l < MCP_LEVELS; ++l) {
+    const int n = PYR_R >> l, t = PYR_T >> l, a = PYR_A >> l, wl = C.w >> l, hl = C.h >> l, gx0 = (tx*PYR_T) >> l, gy0 = (ty*PYR_T) >> l;
+    const uint8_t* R = reg[l];
+    const bool write_img = l > 0 || C.src != C.img[0];
+    const int b = B.detect_t[l];
+    for (int i = tid; i < t*t; i += 256) {
+      const int ly = i / t, lx = i % t, gx = gx0 + lx, gy = gy0 + ly;
+      if (gx >= wl || gy >= hl) continue;
+      const uint8_t* p = R + (a + ly)*n + a + lx;
+      const int c = *p;
+      int sc = 0;
+      if (gy >= 3 && gy < hl - 3 && gx >= 3 && gx < wl - 3) {
+        int r[16]; fast_ring(p, n, r);
+        if (fast10_corner(r, c, b)) {
+          sc = fast10_score(r, c);
+          atomicAdd(&ln[l], 1);
+          if (B.adaptive) { const int top = min(sc, MCP_MAX_FAST_THRESH); for (int q = MCP_MIN_FAST_THRESH; q <= top; ++q) atomicAdd(&lh[l][q], 1); }
+        }
+      }
+      const size_t g = (size_t)gy*wl + gx;
+      C.score[l][g] = (uint8_t)sc;
+      if (write_img) C.img[l][g] = (uint8_t)c;
+    }
+  }
+  __syncthreads();
+  if (tid < MCP_LEVELS*32) { const int v = (&lh[0][0])[tid]; if (v) atomicAdd(&C.work[tid], v); }
+  if (tid < MCP_LEVELS && ln[tid]) atomicAdd(&C.work[MCP_LEVELS*32 + tid], ln[tid]);
 }
-__global__ void __launch_bounds__(FAST_BLOCK)
-k_thresh_write(const mcp_int2* __restrict__ xy, const int* __restrict__ score, const uint8_t* __restrict__ mask, int w,
-               LevelInfo* __restrict__ info, const int* __restrict__ blk_cnt, mcp_int2* __restrict__ out) {
-  __shared__ int lds[FAST_BLOCK/64 + 1];
-  const int th = info->thresh;
-  const int off = block_prefix(blk_cnt, blockIdx.x, lds);
-  const int i = blockIdx.x*FAST_BLOCK + threadIdx.x;
-  bool keep = false;
-  if (i < info->n_all) keep = (score[i] >= th) && (!mask || mask[(size_t)xy[i].y*w + xy[i].x] == 255);
-  int tot; const int rank = block_rank(keep, &tot, lds);
-  if (keep) out[off + rank] = xy[i];
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) info->n_corners = off + tot;
+
+__device__ inline bool corner_kept(const FrameCam& C, int l, int wl, int x, int y, int th, bool use_mask) {
+  const size_t g = (size_t)y*wl + x;
+  const int sc = C.score[l][g];
+  if (sc == 0 || sc < th) return false;
+  return !use_mask || C.mask[l][g] == 255;
 }
-// LUT[y] = index of the first corner with row >= y
-__global__ void k_row_lut(const mcp_int2* __restrict__ corners, const LevelInfo* __restrict__ info, int h, int* __restrict__ lut) {
-  const int y = blockIdx.x*blockDim.x + threadIdx.x;
-  if (y >= h) return;
-  int lo = 0, hi = info->n_corners;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (corners[mid].y < y) lo = mid + 1; else hi = mid; }
-  lut[y] = lo;
+__global__ void __launch_bounds__(256)
+k_row_count(const FrameBatch B) {
+  const int l = blockIdx.y; const FrameCam& C = B.c[blockIdx.z];
+  const int wl = C.w >> l, hl = C.h >> l, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x*4 >= hl) return;
+  __shared__ int th_s;
+  if (threadIdx.x == 0) th_s = B.adaptive ? knee_threshold(C.work + l*32, wl, hl) : B.detect_t[l];
+  __syncthreads();
+  const int th = th_s;
+  if (blockIdx.x == 0) {                        // the level's bookkeeping, completed by k_row_compact
+    LevelInfo* I = C.info[l];
+    if (threadIdx.x < 32) I->hist[threadIdx.x] = C.work[l*32 + threadIdx.x];
+    if (threadIdx.x == 0) { I->thresh = th; I->n_all = C.work[MCP_LEVELS*32 + l]; I->n_cand = 0; }
+  }
+  const int y = blockIdx.x*4 + wave;
+  if (y >= hl) return;
+  const bool use_mask = B.adaptive && C.mask[l] != nullptr;         // the fixed-threshold branch keeps every detected corner, KeyFrame.cc:318-343
+  int cnt = 0;
+  for (int x = lane; x < wl; x += 64) cnt += corner_kept(C, l, wl, x, y, th, use_mask) ? 1 : 0;
+  cnt = wave_sum_i(cnt);
+  if (lane == 0) C.rowcnt[l][y] = cnt;
+}
+__global__ void __launch_bounds__(256)
+k_row_compact(const FrameBatch B) {
+  const int l = blockIdx.y; const FrameCam& C = B.c[blockIdx.z];
+  const int wl = C.w >> l, hl = C.h >> l, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = blockIdx.x*4;
+  if (y0 >= hl) return;
+  __shared__ int part[4];
+  if (blockIdx.x == 0) {                        // the histogram accumulators are free again: leave them zero for the next frame
+    if (threadIdx.x < 32) C.work[l*32 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) C.work[MCP_LEVELS*32 + l] = 0;
+  }
+  int s = 0;
+  for (int i = threadIdx.x; i < y0; i += 256) s += C.rowcnt[l][i];
+  s = wave_sum_i(s);
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  int off = part[0] + part[1] + part[2] + part[3];
+  const int y = y0 + wave;
+  if (y >= hl) return;
+  for (int j = 0; j < wave; ++j) off += C.rowcnt[l][y0 + j];
+  const int th = C.info[l]->thresh;
+  const bool use_mask = B.adaptive && C.mask[l] != nullptr;
+  if (lane == 0) C.lut[l][y] = off;
+  int run = off;
+  for (int x0 = 0; x0 < wl; x0 += 64) {
+    const int x = x0 + lane;
+    const bool keep = x < wl && corner_kept(C, l, wl, x, y, th, use_mask);
+    const unsigned long long bal = __ballot(keep);
+    if (keep) { const int o = run + __popcll(bal & ((1ull << lane) - 1ull)); if (o < C.cap[l]) { C.corners[l][o].x = x; C.corners[l][o].y = y; } }
+    run += __popcll(bal);
+  }
+  if (y == hl - 1 && lane == 0) {
+    LevelInfo* I = C.info[l];
+    I->n_corners = min(run, C.cap[l]); I->overflow = run > C.cap[l];
+    LevelInfo* H = C.host_info + l;              // k_row_count's stores to *I are visible: it ran in the previous launch
+    H->n_all = I->n_all; H->n_corners = I->n_corners; H->thresh = I->thresh; H->n_cand = 0; H->overflow = I->overflow;
+    for (int q = 0; q < 32; ++q) H->hist[q] = I->hist[q];
+  }
 }
 
 // ---- MakeKeyFrame_Rest -----------------------------------------------------------------------
@@ -336,21 +426,10 @@ struct DevTdIn {
   int center_x, center_y, fixed;
 };
 
-__device__ inline int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
-__global__ void __launch_bounds__(64)
-k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTdIn* __restrict__ in, int range,
-               int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
-  __shared__ uint8_t tmpl[64];
-  __shared__ double dprod[3][36];
-  const int pi = blockIdx.x, lane = threadIdx.x;
-  if (pi >= n) return;
-  const DevTdIn& P = in[pi];
-  mcp_td_out& O = out[pi];
+// one tracked point, one wavefront
+__device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp_camera& cam, const Se3& bfw, const Se3& cfb, const DevTdIn& P, mcp_td_out& O,
+                                                   int range, int subpix_its, int exhaustive, uint8_t* tmpl, double (*dprod)[36], int lane) {
   const int MAXSSD = 8*8*250;
   // all lanes compute the (uniform) geometry redundantly
   Se3 cfw; se3_compose(cfb, bfw, cfw);
@@ -525,6 +604,27 @@ k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTd
     O.found = found; O.did_subpix = did_subpix; O.coarse_x = bx; O.coarse_y = by; O.score = best;
   }
   if (level < 0 || !in_image) O.templ[lane] = 0;
+}
+__global__ void __launch_bounds__(64)
+k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTdIn* __restrict__ in, int range,
+               int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
+  __shared__ uint8_t tmpl[64];
+  __shared__ double dprod[3][36];
+  const int pi = blockIdx.x;
+  if (pi >= n) return;
+  track_search_point(T, cam, bfw, cfb, in[pi], out[pi], range, subpix_its, exhaustive, tmpl, dprod, threadIdx.x);
+}
+// the cameras of a frame in one launch (blockIdx.y = camera); the per-camera views, models and poses sit in a device table
+struct SearchCam { DevKfView T; mcp_camera cam; Se3 cfb; int n, first; };
+__global__ void __launch_bounds__(64)
+k_track_search_batch(const SearchCam* __restrict__ tab, Se3 bfw, const DevTdIn* __restrict__ in, int range, int subpix_its, int exhaustive,
+                     mcp_td_out* __restrict__ out) {
+  __shared__ uint8_t tmpl[64];
+  __shared__ double dprod[3][36];
+  const SearchCam& S = tab[blockIdx.y];
+  const int pi = blockIdx.x;
+  if (pi >= S.n) return;
+  track_search_point(S.T, S.cam, bfw, S.cfb, in[S.first + pi], out[S.first + pi], range, subpix_its, exhaustive, tmpl, dprod, threadIdx.x);
 }
 
 // ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------

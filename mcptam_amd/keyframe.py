@@ -40,7 +40,7 @@ TD_OUT_DTYPE = np.dtype([("image", "f8", 2), ("cam_derivs", "f8", 4), ("jacobian
 assert TD_OUT_DTYPE.itemsize == ctypes.sizeof(TdOut)
 
 IMG_SYMBOLS = [
-    "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
+    "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_make_lite_batch", "mcp_track_search_batch", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
     "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
@@ -56,6 +56,9 @@ def lib():
         L.mcp_kf_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_destroy.argtypes = [ctypes.c_void_p]
         L.mcp_kf_make_lite.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_kf_make_lite_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_track_search_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_level_size.argtypes = [ctypes.c_void_p, ctypes.c_int, c_int_p, c_int_p]
         L.mcp_kf_get_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.mcp_kf_num_corners.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -190,6 +193,52 @@ class KeyFrame:
         sc = np.zeros(max(n, 1))
         n = _chk(self._L.mcp_kf_get_candidates(self._h, level, pos.ctypes.data, _dp(sc), n), "Candidates")
         return pos[:n], sc[:n]
+
+
+def make_lite_batch(kfs, imgs, masks=None, on_device=False, strides=None):
+    """MakeKeyFrame_Lite of all cameras of a frame in one submission (the loop of Tracker::TrackFrame, src/Tracker.cc:303-318).
+    imgs: one (h, w) uint8 array per camera, or -- on_device=True -- one device address per camera (an image ring that already
+    lives in HBM; `strides` = their row strides in bytes, default w)."""
+    n = len(kfs)
+    hs = (ctypes.c_void_p * n)(*[k._h for k in kfs])
+    if on_device:
+        ip = (ctypes.c_void_p * n)(*[int(a) for a in imgs])
+        st = (ctypes.c_int * n)(*[int(s_) for s_ in (strides or [k.w for k in kfs])])
+        keep = None
+    else:
+        keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in imgs]
+        for k, a in zip(kfs, keep):
+            assert a.shape == (k.h, k.w)
+        ip = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keep])
+        st = (ctypes.c_int * n)(*[a.strides[0] for a in keep])
+    mp = None
+    if masks is not None:
+        mkeep, rows = [], []
+        for m in masks:
+            if m is None:
+                rows.append(None)
+                continue
+            lv = [None if q is None else np.ascontiguousarray(q, dtype=np.uint8) for q in m]
+            mkeep.append(lv)
+            rows.append((ctypes.c_void_p * LEVELS)(*[None if q is None else q.ctypes.data for q in lv]))
+        mp = (ctypes.c_void_p * n)(*[None if r is None else ctypes.cast(r, ctypes.c_void_p) for r in rows])
+    _chk(lib().mcp_kf_make_lite_batch(n, hs, ip, st, int(on_device), mp), "make_lite_batch")
+
+
+def track_search_batch(targets, cams, base_from_world, cams_from_base, points, rng, subpix_its, exhaustive=False):
+    """SearchForPoints for all cameras of a frame in one launch; points[c]: list of point dicts or a packed ctypes array."""
+    n = len(targets)
+    arrs = [p if isinstance(p, ctypes.Array) else pack_points(p, lambda kf: kf._h) for p in points]
+    outs = [np.zeros(len(a), dtype=TD_OUT_DTYPE) for a in arrs]
+    hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
+    cs = (type(cams[0].to_struct()) * n)(*[c.to_struct() for c in cams])
+    b = _pose12(*base_from_world)
+    cfb = np.ascontiguousarray(np.concatenate([_pose12(*c) for c in cams_from_base]))
+    ns = (ctypes.c_int * n)(*[len(a) for a in arrs])
+    ins = (ctypes.c_void_p * n)(*[ctypes.cast(a, ctypes.c_void_p) for a in arrs])
+    ops = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    _chk(lib().mcp_track_search_batch(n, hs, cs, _dp(b), _dp(cfb), ns, ins, int(rng), int(subpix_its), int(exhaustive), ops), "track_search_batch")
+    return outs
 
 
 def minipatch_find(src, dst, level, src_pos, dst_pos, rng):

@@ -532,3 +532,63 @@ def test_c5_tracker_frames_and_window_ba_pipelined(gpu_required):
     for r in result["ba"]:
         assert r["rc"] == ref_ba["rc"] and r["logs"] == ref_ba["logs"]
         assert np.array_equal(r["R"], ref_ba["R"]) and np.array_equal(r["t"], ref_ba["t"]) and np.array_equal(r["X"], ref_ba["X"])
+
+
+def test_frame_batch_equals_per_camera_calls(gpu_required, scene):
+    """mcp_kf_make_lite_batch / mcp_track_search_batch: the cameras of a frame in one submission (different image sizes, one
+    camera masked, second frame so that the history rotates) give exactly what per-camera calls and the oracle give."""
+    from mcptam_amd import hip_rt
+    from mcptam_amd.keyframe import KeyFrame, make_lite_batch, track_search, track_search_batch
+    from oracle import OracleKeyFrame
+    sizes = [(640, 480), (642, 482), (322, 250), (640, 480)]
+    rng = np.random.default_rng(11)
+    imgs = []
+    for (w, h) in sizes:
+        base = np.zeros((h, w), dtype=np.uint8)
+        src = scene["imgA"] if len(imgs) != 3 else scene["imgB"]
+        base[:min(h, 480), :min(w, 640)] = src[:min(h, 480), :min(w, 640)]
+        imgs.append(base)
+    masks = [None, None, None, []]
+    for l in range(4):
+        m = np.full((480 >> l, 640 >> l), 255, dtype=np.uint8)
+        m[:, : (200 >> l)] = 0
+        masks[3].append(m)
+    kfs = [KeyFrame(w, h) for (w, h) in sizes]
+    oks = [OracleKeyFrame(w, h) for (w, h) in sizes]
+    for rep in range(2):
+        frame = [np.roll(a, 3*rep, axis=1) for a in imgs]
+        make_lite_batch(kfs, frame, masks)
+        for c, o in enumerate(oks):
+            o.MakeKeyFrame_Lite(frame[c], masks[c])
+            _assert_lite_equal(kfs[c], o)
+    assert kfs[0].NumPrev() == 1
+    assert (kfs[3].Corners(0)[:, 0] >= 200).all()
+    # the same frame from a device-resident ring (row stride 704), nothing uploaded by the call
+    ring = []
+    for c, (w, h) in enumerate(sizes):
+        padded = np.zeros((h, 704), dtype=np.uint8)
+        padded[:, :w] = np.roll(imgs[c], 3, axis=1)
+        ring.append(hip_rt.dev_alloc(padded.nbytes))
+        hip_rt.dev_upload(ring[c], padded)
+    kd = [KeyFrame(w, h) for (w, h) in sizes]
+    make_lite_batch(kd, ring, masks, on_device=True, strides=[704]*4)
+    for c in range(4):
+        _assert_lite_equal(kd[c], oks[c])
+    for r in ring:
+        hip_rt.dev_free(r)
+    # batched search == per-camera search
+    gA, oA = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    pts = _points(scene, gA, oA)
+    tg = [KeyFrame(640, 480) for _ in range(3)]
+    make_lite_batch(tg, [scene["imgB"], scene["imgA"], scene["imgB"]])
+    cfbs = [(np.eye(3), np.array([0.02*c, 0.0, 0.0])) for c in range(3)]
+    RB, tB = scene["poseB"]
+    bfw = (RB, tB)
+    lists = [pts, pts[:37], []]
+    outs = track_search_batch(tg, [scene["cam"]]*3, bfw, cfbs, lists, 10, 8)
+    for c in range(2):
+        single = track_search(tg[c], scene["cam"], bfw, cfbs[c], lists[c], 10, 8)
+        for f in single.dtype.names:
+            assert np.array_equal(single[f], outs[c][f], equal_nan=single[f].dtype.kind == "f"), f
+    assert len(outs[2]) == 0 and outs[0]["found"].sum() > 100
