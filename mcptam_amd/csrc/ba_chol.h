@@ -129,6 +129,17 @@ __device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad, doubl
 #endif
     CH_SB();
     const double y0 = __builtin_amdgcn_rsq(pn);
+#if defined(CH_RSQ2)
+    // second-order (Newton) correction, one dependent instruction shorter: g = pn y0, h = y0/2, r = 1/2 - g h, inv = y0 + y0 r
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 0>::fm(d, prev); CH_SB();
+    const double g = pn*y0;
+    const double h = 0.5*y0;
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 1>::fm(d, prev); if constexpr (J >= 1) ChBulk<J - 1, 2>::fm(d, prev); CH_SB();
+    const double r = __builtin_fma(-g, h, 0.5);
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 3>::fm(d, prev); CH_SB();
+    inv = __builtin_fma(y0, r, y0);
+    CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 4>::fm(d, prev); CH_SB();
+#else
     CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 0>::fm(d, prev); CH_SB();
     const double t = y0*(-pn);
     CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 1>::fm(d, prev); CH_SB();
@@ -139,6 +150,7 @@ __device__ inline void chol_panel_pivot(double* d, double& inv, bool& bad, doubl
     CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 3>::fm(d, prev); CH_SB();
     inv = __builtin_fma(u, q, y0);          // rsqrt(pn)
     CH_SB(); if constexpr (J >= 1) ChBulk<J - 1, 4>::fm(d, prev); CH_SB();
+#endif
     d[J + 1] -= d[J]*l1;
     if constexpr (J >= 1) ChBulk<J - 1, 5>::fm(d, prev);
     CH_SB();

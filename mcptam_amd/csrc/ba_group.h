@@ -48,31 +48,53 @@ __device__ inline void flush_group_blocks(const double* Sl, const double* bl, in
   }
 }
 
+// k_linearize_group keeps only the group's structurally non-zero blocks in LDS, in the order of the group's block list
+// (36 doubles per block, row-major, rows = the larger local pose; for a diagonal block only the lower triangle is ever
+// added to, the upper entries stay zero): the tile is the staging layout, so the flush is a straight copy, the LDS a group
+// needs is what its blocks need (22 blocks = 6 KB on average at the metric size instead of the 37 KB of the packed
+// 96 x 96 triangle), and more groups share a compute unit.  pslot[la*16 + lb] (la >= lb) = block slot of the local pair.
+template <int NT>
+__device__ inline void flush_compact_blocks(const double* Sc, const double* bl, int grp, const DevProblem& P,
+                                            double* __restrict__ st_blocks, double* __restrict__ st_rhs) {
+  const int b0 = P.g_blk0[grp], nb = P.g_blk0[grp + 1] - b0;
+  for (int e = threadIdx.x; e < nb*36; e += NT) {
+    const int slot = e/36, w = e - 36*slot;
+    st_blocks[(size_t)P.blk_dst[b0 + slot]*36 + w] = Sc[e];
+  }
+  for (int i = threadIdx.x; i < GRP_DOF; i += NT) {
+    const int d = P.rhs_dst[grp*GRP_LMAX + i/6];
+    if (d >= 0) st_rhs[(size_t)d*6 + i%6] = bl[i];
+  }
+}
+
 #if defined(LIN_ABL) && LIN_ABL == 1
 __device__ inline void lds_add(double* p, double v) { if (v == 1.2345e-300) unsafeAtomicAdd(p, v); }     // timing ablation only
 #else
 __device__ inline void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 #endif
 
-// add w * Ja^T Jb (6x6) into the local tile at local poses (la, lb); la != lb or full symmetric handled by caller
-__device__ inline void tile_add_cross(double* Sl, int la, int lb, const double* Ja, const double* Jb, double w) {
+// add w * Ja^T Jb (6x6) into the compact tile at local poses (la, lb)
+__device__ inline void tile_add_cross(double* Sc, const unsigned char* pslot, int la, int lb, const double* Ja, const double* Jb, double w) {
   // block rows belong to the larger local index (lower triangle)
   if (la > lb) {
+    double* B = Sc + 36*(int)pslot[16*la + lb];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lds_add(Sl + tri(6*la + r, 6*lb + c), w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c]));
+      for (int c = 0; c < 6; ++c) lds_add(B + 6*r + c, w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c]));
   } else if (lb > la) {
+    double* B = Sc + 36*(int)pslot[16*lb + la];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lds_add(Sl + tri(6*lb + r, 6*la + c), w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+      for (int c = 0; c < 6; ++c) lds_add(B + 6*r + c, w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
   } else {
+    double* B = Sc + 36*(int)pslot[17*la];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c)
-        lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+        lds_add(B + 6*r + c, w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
   }
 }
 
@@ -82,17 +104,29 @@ __device__ unsigned long long g_lin_prof[8*8];
 #else
 #define LIN_STAMP(i) do {} while (0)
 #endif
+#ifndef LIN_WAVES
+#define LIN_WAVES 0   // > 0: wavefronts per SIMD the register allocation is held to
+#endif
+#if LIN_WAVES > 0      // (the bound is a promise of at most 128 threads -- the launch has 64; with a one-wavefront bound the compiler ignores the occupancy request)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(LIN_WAVES, LIN_WAVES)))
+#else
 __global__ void __launch_bounds__(64)
+#endif
 k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
                   const double* __restrict__ second, const double* __restrict__ sigma,
                   double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
                   double* __restrict__ V, double* __restrict__ g, double* __restrict__ W) {
-  __shared__ double Sl[GRP_TRI];
+  extern __shared__ double Sc[];                 // the group's blocks, 36 doubles each (launch: 288 B x the largest block count of any group)
   __shared__ double bl[GRP_DOF];
+  __shared__ unsigned char pslot[GRP_LMAX*16];
   const int grp = blockIdx.x, lane = threadIdx.x;
   LIN_STAMP(0);
-  for (int i = lane; i < GRP_TRI; i += 64) Sl[i] = 0.0;
-  for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
+  {
+    const int b0 = P.g_blk0[grp], nb = P.g_blk0[grp + 1] - b0;
+    for (int i = lane; i < nb*36; i += 64) Sc[i] = 0.0;
+    for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
+    for (int i = lane; i < nb; i += 64) pslot[P.blk_pair[b0 + i]] = (unsigned char)i;      // (pairs outside the list are never looked up)
+  }
   __syncthreads();
   LIN_STAMP(1);
   const int sp = P.g_sp0[grp] + lane;
@@ -199,7 +233,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 #pragma unroll
           for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) lds_add(Sl + tri(6*la + r, 6*la + c), w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
+            for (int c = 0; c <= r; ++c) lds_add(Sc + 36*(int)pslot[17*la] + 6*r + c, w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
         }
 #if defined(LIN_ABL) && LIN_ABL == 3
         if (false) {                 // timing ablation only: no W blocks
@@ -233,7 +267,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
           SlotGeom sb; double Jb[12];
           make_slot(bit_b >> MAXC_LOG, bit_b & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sb);
           slot_jacobian(sb, Jb);
-          tile_add_cross(Sl, la, P.slot_lp[s0 + ib], Ja, Jb, w);
+          tile_add_cross(Sc, pslot, la, P.slot_lp[s0 + ib], Ja, Jb, w);
           ++ib;
         }
         ++ia;
@@ -281,7 +315,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) { Sl[tri(6*key + r, 6*key + c)] += vals[q]; ++q; }
+        for (int c = 0; c <= r; ++c) { Sc[36*(int)pslot[17*key] + 6*r + c] += vals[q]; ++q; }
 #pragma unroll
       for (int r = 0; r < 6; ++r) bl[6*key + r] += vals[21 + r];
     }
@@ -291,7 +325,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   __syncthreads();
   LIN_STAMP(5);
   // flush the local tile to the group's staging slots (k_assemble sums them in group order)
-  flush_group_blocks<64>(Sl, bl, grp, P, stU, stb);
+  flush_compact_blocks<64>(Sc, bl, grp, P, stU, stb);
   LIN_STAMP(6);
 }
 

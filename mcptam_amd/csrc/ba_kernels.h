@@ -200,9 +200,13 @@ k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* _
 }
 
 // fixed-order final reduction of up to 3 partial arrays into out[off..off+2] (single block); out[off+3] = failure flag
+// mail (may be null): device-visible pinned host memory.  The first mail_count entries of `out` are forwarded there, then the
+// ticket mail[MAIL_TICKET] is released at system scope -- the host polls the ticket instead of enqueueing a copy and waiting on
+// the stream (the LM accept/reject decision is one PCIe write away instead of a blit kernel + a stream wait).
+constexpr int MAIL_TICKET = 31;
 __global__ void __launch_bounds__(256)
 k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
-             double* __restrict__ out, int off, const int* __restrict__ fail) {
+             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0) {
   __shared__ double lds[4];
   const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
   for (int a = 0; a < 3; ++a) {
@@ -213,6 +217,13 @@ k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const d
     if (threadIdx.x == 0) out[off + a] = t;
   }
   if (fail && threadIdx.x == 0) out[off + 3] = (fail[0] != 0) ? 1.0 : 0.0;
+  if (mail) {
+    __syncthreads();                                 // thread 0's stores to `out` above; the other entries come from earlier kernels of the stream
+    for (int i = threadIdx.x; i < mail_count; i += 256) mail[i] = out[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(mail + MAIL_TICKET), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

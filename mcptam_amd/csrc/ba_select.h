@@ -29,6 +29,30 @@ __host__ __device__ inline double mest_denom(double n) {
 __host__ __device__ inline int sel_shift(int pass) { return pass < 5 ? 64 - SEL_BITS*(pass + 1) : 0; }
 __host__ __device__ inline int sel_nbits(int pass) { return pass < 5 ? SEL_BITS : 9; }
 
+// All NT threads of the block (thread order = bin order): `loc` = the count this thread owns.  Finds the thread whose span
+// holds rank k -- exclusive prefix <= k < inclusive prefix -- by a wavefront scan (lane shuffles) + one hop through LDS; a k
+// beyond the total is clamped to the last thread.  t_out / excl_out are uniform on return.  lds: NT/64 + 2 words.
+template <int NT>
+__device__ inline void block_find_rank(unsigned long long loc, unsigned long long k, int& t_out, unsigned long long& excl_out,
+                                       unsigned long long* lds) {
+  constexpr int NW = NT/64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+  if (lane == 63) lds[wave] = inc;
+  if (threadIdx.x == 0) lds[NW] = ~0ull;
+  __syncthreads();
+  unsigned long long base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { const unsigned long long v = lds[w]; if (w < wave) base += v; total += v; }
+  const unsigned long long incl = base + inc, excl = incl - loc;
+  if ((excl <= k && k < incl) || (k >= total && threadIdx.x == NT - 1)) { lds[NW] = (unsigned long long)threadIdx.x; lds[NW + 1] = excl; }
+  __syncthreads();
+  t_out = (int)lds[NW]; excl_out = lds[NW + 1];
+  __syncthreads();
+}
+
 // all threads of the block: locate the bin of `hist` (nbins doubles) holding rank k; returns via refs
 __device__ inline void sel_find_bin(const double* __restrict__ hist, int nbins, unsigned long long k,
                                     int& bin_out, unsigned long long& k_in, unsigned long long* lds /*SEL_BLOCK+2*/) {
@@ -36,28 +60,80 @@ __device__ inline void sel_find_bin(const double* __restrict__ hist, int nbins, 
   const int b0 = threadIdx.x*per;
   unsigned long long loc = 0;
   for (int i = 0; i < per; ++i) if (b0 + i < nbins) loc += (unsigned long long)hist[b0 + i];
-  lds[threadIdx.x] = loc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long acc = 0; int t = 0;
-    for (; t < SEL_BLOCK; ++t) { if (acc + lds[t] > k) break; acc += lds[t]; }
-    if (t == SEL_BLOCK) { t = SEL_BLOCK - 1; acc -= lds[t]; }      // k beyond the end: clamp to the last element
-    lds[SEL_BLOCK] = (unsigned long long)t; lds[SEL_BLOCK + 1] = acc;
-  }
-  __syncthreads();
-  const int t = (int)lds[SEL_BLOCK];
-  unsigned long long acc = lds[SEL_BLOCK + 1];
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  int t; unsigned long long acc;
+  block_find_rank<SEL_BLOCK>(loc, k, t, acc, lds);
+  if ((int)threadIdx.x == t) {        // the owner walks its own few bins
     int b = t*per; const int be = min(nbins, b + per);
     for (; b < be; ++b) { const unsigned long long c = (unsigned long long)hist[b]; if (acc + c > k) break; acc += c; }
     if (b >= be) b = be - 1;
-    lds[SEL_BLOCK] = (unsigned long long)b; lds[SEL_BLOCK + 1] = k - acc;
+    lds[0] = (unsigned long long)b; lds[1] = k - acc;
   }
   __syncthreads();
-  bin_out = (int)lds[SEL_BLOCK];
-  k_in = lds[SEL_BLOCK + 1];
+  bin_out = (int)lds[0];
+  k_in = lds[1];
   __syncthreads();
+}
+
+// 1024 threads, one digit histogram of SEL_BINS counters in LDS: the bin holding rank k, the rank inside it and the bin's count
+// (uniform on return).  sc: 1024/64 + 3 words.
+__device__ inline void lds_find_bin_1024(const unsigned int* hist, unsigned long long k, int& bin, unsigned long long& k_in, unsigned int& in_bin,
+                                         unsigned long long* sc) {
+  const int t = threadIdx.x;
+  const unsigned int h0 = hist[2*t], h1 = hist[2*t + 1];
+  int tt; unsigned long long acc;
+  block_find_rank<1024>((unsigned long long)h0 + h1, k, tt, acc, sc);
+  if (t == tt) {
+    int b = 2*t;
+    if (!(acc + h0 > k)) { acc += h0; b = 2*t + 1; }
+    sc[0] = (unsigned long long)b; sc[1] = k - acc; sc[2] = (b & 1) ? h1 : h0;
+  }
+  __syncthreads();
+  bin = (int)sc[0]; k_in = sc[1]; in_bin = (unsigned int)sc[2];
+  __syncthreads();
+}
+
+// One workgroup of 1024 threads: the rank-k element (bit pattern) among the keys keyfn(i, key) yields for i in [0, m), continuing
+// a most-significant-digit radix select at digit `pass0` with the bits above it fixed to `prefix0`.  Digit histograms live in
+// LDS; the bin search is a parallel scan; as soon as the selected bin holds a single key, that key is the answer and its
+// remaining bits are read off directly.  hist: SEL_BINS counters, sc: 1024/64 + 3 words, st: 2 words (all LDS).  Uniform result.
+template <class KeyFn>
+__device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long long k, int pass0, unsigned long long prefix0, KeyFn keyfn,
+                                                           unsigned int* hist, unsigned long long* sc, unsigned long long* st) {
+  const int t = threadIdx.x;
+  if (t == 0) { st[0] = prefix0; st[1] = k; }
+  __syncthreads();
+  for (int pass = pass0; pass < SEL_PASSES; ++pass) {
+    const int sh = sel_shift(pass);
+    const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+    const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+    for (int b = t; b < SEL_BINS; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = st[0];
+    for (int i = t; i < m; i += 1024) {
+      unsigned long long key;
+      if (!keyfn(i, key)) continue;
+      if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
+    }
+    __syncthreads();
+    int bin; unsigned long long kin; unsigned int in_bin;
+    lds_find_bin_1024(hist, st[1], bin, kin, in_bin, sc);
+    const unsigned long long np_ = prefix | ((unsigned long long)bin << sh);
+    if (in_bin == 1u && sh > 0) {
+      const unsigned long long hm2 = ~0ull << sh;
+      for (int i = t; i < m; i += 1024) {
+        unsigned long long key;
+        if (!keyfn(i, key)) continue;
+        if ((key & hm2) == np_) st[0] = key;
+      }
+      __syncthreads();
+      break;
+    }
+    if (t == 0) { st[0] = np_; st[1] = kin; }
+    __syncthreads();
+  }
+  const unsigned long long r = st[0];
+  __syncthreads();
+  return r;
 }
 
 // pass kernel: derive state[pass] from state[pass-1] and hist[pass-1], then histogram digit `pass`
@@ -188,8 +264,8 @@ k_select_small(int n, const double* __restrict__ x, const unsigned int* __restri
                double* __restrict__ sig, double* __restrict__ sig_copy,
                const double* __restrict__ slot_counts = nullptr, int nslot = 0, int slot_cap = 0) {
   __shared__ unsigned int hist[SEL_BINS];
-  __shared__ unsigned int part[64];
-  __shared__ unsigned long long s_prefix, s_k;
+  __shared__ unsigned long long sc[1024/64 + 3];
+  __shared__ unsigned long long s_st[2];
   const int t = threadIdx.x;
   // slot mode (multi-rank, k_select_gather_slot): vals is an nslot x slot_cap table, slot r holds slot_counts[r] candidates
   const bool slots = slot_counts != nullptr;
@@ -197,37 +273,12 @@ k_select_small(int n, const double* __restrict__ x, const unsigned int* __restri
   const bool overflow = !slots && c > (unsigned int)SEL_GATHER_CAP;
   const double* src = overflow ? x : vals;
   const int m = slots ? nslot*slot_cap : (overflow ? n : (int)c);
-  if (t == 0) { s_prefix = state[2].prefix; s_k = state[2].k; }
-  __syncthreads();
-  for (int pass = 2; pass < SEL_PASSES; ++pass) {
-    const int sh = sel_shift(pass);
-    const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
-    const unsigned long long himask = ~0ull << sel_shift(pass - 1);
-    for (int b = t; b < SEL_BINS; b += 1024) hist[b] = 0u;
-    __syncthreads();
-    const unsigned long long prefix = s_prefix;
-    for (int i = t; i < m; i += 1024) {
-      if (slots && (double)(i % slot_cap) >= slot_counts[i/slot_cap]) continue;
-      const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(src[i]));
-      if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
-    }
-    __syncthreads();
-    if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
-    __syncthreads();
-    if (t == 0) {
-      unsigned long long k = s_k, acc = 0; int cc = 0;
-      for (; cc < 64; ++cc) { if (acc + part[cc] > k) break; acc += part[cc]; }
-      if (cc == 64) cc = 63;
-      int b = 32*cc;
-      for (; b < 32*cc + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
-      if (b >= 32*cc + 32) b = 32*cc + 31;
-      s_prefix = prefix | ((unsigned long long)b << sh);
-      s_k = k - acc;
-    }
-    __syncthreads();
-  }
+  const unsigned long long sel = lds_radix_select_1024(m, state[2].k, 2, state[2].prefix, [&](int i, unsigned long long& key) {
+    if (slots && (double)(i % slot_cap) >= slot_counts[i/slot_cap]) return false;
+    key = (unsigned long long)__double_as_longlong(fabs(src[i]));
+    return true; }, hist, sc, s_st);
   if (t == 0) {
-    const double md = __longlong_as_double((long long)s_prefix);
+    const double md = __longlong_as_double((long long)sel);
     med_out[0] = md;
     if (sig) {
       double s = 1.4826*(1 + 5.0/mest_denom(n_total))*sqrt(md);

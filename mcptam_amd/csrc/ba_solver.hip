@@ -94,7 +94,7 @@ struct mcp_ba {
   // (MCP_BA_OVERLAP: 0 = one stream, 1 = the speculative systems together on a second stream, 2 = system 1 on the second and
   // systems 2.. on a third stream, so that the system the SECOND trial needs is ready as early as the first one's)
   hipStream_t st2 = nullptr, st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_spec = nullptr, ev_spec3 = nullptr;
-  bool spec_pending = false, spec3_pending = false; int spec3_from = MAX_SYS; int overlap_spec = 1;
+  bool spec_pending = false, spec3_pending = false; int spec2_from = 1, spec3_from = MAX_SYS; int overlap_spec = 1, main_sys = 1;
   std::vector<mcp_camera> cams;
   int robust = 1, tukey = 1, verbose = 0;
   mcp_ba_params prm;
@@ -137,6 +137,7 @@ struct mcp_ba {
   DevBuf<double> d_stU, d_stb, d_stS, d_str, d_udiag;
   DevBuf<int> d_g_blk0, d_asm_tiles, d_pair_id, d_pr_start, d_blk_dst, d_po_start, d_rhs_dst;
   DevBuf<unsigned char> d_blk_pair;
+  int grp_blk_max = 0;            // most staged blocks of any group (sizes the LDS tile of k_linearize_group)
   size_t nstage = 0;        // staged 6x6 blocks over all groups
   int nrhs_rows = 0;        // staged rhs rows (6 doubles each) over all groups
   AsmPlan A;
@@ -148,7 +149,8 @@ struct mcp_ba {
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
   DevBuf<SelState> d_selstate;
   DevBuf<int> d_fail;
-  double* h_res = nullptr;  // pinned
+  double* h_res = nullptr;  // pinned, device-visible; [32..63] is the mailbox k_final_sums writes (ticket at 32 + MAIL_TICKET)
+  unsigned long long mail_ticket = 0; int use_mailbox = 1; double* h_mail_dev = nullptr;
   int* h_fail = nullptr;    // pinned
 
   // robust data
@@ -188,7 +190,7 @@ struct mcp_ba {
   // must not overwrite any of it, nor consume a speculative solution, before that work is done
   // q < 0: everything; otherwise only the stream that produces system q of the batch
   int join_spec(int q = -1) {
-    if (spec_pending && (q < 0 || q < spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
+    if (spec_pending && (q < 0 || (q >= spec2_from && q < spec3_from))) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
     if (spec3_pending && (q < 0 || q >= spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec3, 0)); spec3_pending = false; }
     return 0;
   }
@@ -280,6 +282,7 @@ struct mcp_ba {
   int select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma = false);
   int median_sigma(int which);
   int read_results(int count);
+  int wait_mail(int count);
   int linearize();
   int build_system(int nsys, SysBatch& sb, int q0 = 0, hipStream_t on = nullptr);
   int solve_trial(double lam, bool& ok2, double ni = 0);
@@ -573,6 +576,8 @@ int mcp_ba::prepare() {
     }
     g_blk0[ngroup] = (int)blk_pair.size();
     nstage = blk_pair.size();
+    grp_blk_max = 0;
+    for (int gi = 0; gi < ngroup; ++gi) grp_blk_max = std::max(grp_blk_max, g_blk0[gi + 1] - g_blk0[gi]);
     int npairs = 0;
     std::vector<int> cnt_pair;
     for (const auto& ab : blk_ab) {
@@ -594,6 +599,7 @@ int mcp_ba::prepare() {
   }
 
   lap("pattern+plan");
+  if (trace) fprintf(stderr, "[mcp_ba prepare] %d groups, %zu staged blocks (%.1f per group, at most %d)\n", ngroup, nstage, ngroup ? (double)nstage/ngroup : 0.0, grp_blk_max);
   // upload
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
   std::vector<unsigned char> pt_fixed(npoint);
@@ -630,7 +636,7 @@ int mcp_ba::prepare() {
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
-  if (!h_res) HIPCK(hipHostMalloc((void**)&h_res, 32*sizeof(double)));
+  if (!h_res) { HIPCK(hipHostMalloc((void**)&h_res, 64*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); std::memset(h_res, 0, 64*sizeof(double)); void* dp = nullptr; HIPCK(hipHostGetDevicePointer(&dp, h_res, 0)); h_mail_dev = (double*)dp + 32; }
   if (!h_fail) HIPCK(hipHostMalloc((void**)&h_fail, 4*sizeof(int)));
   HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
   HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
@@ -749,6 +755,20 @@ int mcp_ba::median_sigma(int w) {
   toc();
   return 0;
 }
+// waits for the ticket of the trial's last kernel in the mailbox and takes the forwarded block from there
+int mcp_ba::wait_mail(int count) {
+  volatile unsigned long long* tk = (volatile unsigned long long*)(h_res + 32 + MAIL_TICKET);
+  for (unsigned long long spins = 0; __atomic_load_n(tk, __ATOMIC_ACQUIRE) != mail_ticket; ++spins) {
+    if ((spins & 0xfffff) == 0xfffff) {             // every ~million polls: has the stream died or drained without delivering?
+      const hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) { if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == mail_ticket) break; set_err("mailbox ticket never arrived"); return -1; }
+      if (e != hipErrorNotReady) { set_err(std::string("stream failed while waiting for a trial: ") + hipGetErrorString(e)); return -1; }
+    }
+    __builtin_ia32_pause();
+  }
+  std::memcpy(h_res, h_res + 32, count*sizeof(double));
+  return 0;
+}
 int mcp_ba::read_results(int count) {
   // the failure flag of a trial travels inside the block (k_final_sums, d_res[3]): one copy, one wait
   HIPCK(hipMemcpyAsync(h_res, d_res.p, count*sizeof(double), hipMemcpyDeviceToHost, st));
@@ -773,7 +793,7 @@ int mcp_ba::linearize() {
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
   }
   if (ngroup)
-    hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), 0, st, P,
+    hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
 #ifdef MCP_LIN_PROF
   {
@@ -836,6 +856,7 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const int tr = cur ^ 1;
+  int defer_n1 = 0, defer_n2 = 0, defer_nsys = 0;
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
     // an earlier trial of this iteration already built and solved this system speculatively (possibly on the second stream)
     if (join_spec(sys_cur + 1)) return -1;
@@ -854,26 +875,21 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (split) {
       // system 0 -- the one this trial needs -- alone on the main stream; the speculative systems behind the fork on the second
       // stream.  Same kernels on the same data as the batched path: the numbers do not depend on which stream produced them.
+      // main_sys systems stay on the main stream: 1 = only the trial's own; 2 = also the first speculative one, so that a second trial
+      // never waits for the other stream (its system comes out of the same launches as the first trial's)
+      const int n1 = std::min(std::max(main_sys, 1), nsys - 1);
       HIPCK(hipEventRecord(ev_fork, st));
-      if (build_system(1, sb, 0, st)) return -1;
-      tic(ST_CHOL); chol_factor(st, plan, d_red.p, d_fail.p, 1, red_stride, 0); toc();
-      tic(ST_SOLVE); chol_back(st, plan, d_red.p, 1, red_stride, 0); toc();
-      const int n2 = (overlap_spec >= 2 && nsys > 2 && st3) ? 1 : nsys - 1;       // systems on the second stream
+      if (build_system(n1, sb, 0, st)) return -1;
+      // host enqueue order: the other streams' Schur complements right away (they start at the fork on the device and run beside
+      // the main stream's), their factorisation chains only after this trial's own chain and tail (below) -- the main stream never
+      // runs dry behind the ~45 launches of another chain
+      defer_n2 = (overlap_spec >= 2 && nsys - n1 > 1 && st3) ? 1 : nsys - n1;       // systems on the second stream
       HIPCK(hipStreamWaitEvent(st2, ev_fork, 0));
-      if (build_system(n2, sb, 1, st2)) return -1;
-      chol_factor(st2, plan, d_red.p, d_fail.p, n2, red_stride, 1);
-      chol_back(st2, plan, d_red.p, n2, red_stride, 1);
-      HIPCK(hipEventRecord(ev_spec, st2));
-      spec_pending = true; spec3_from = 1 + n2;
-      if (1 + n2 < nsys) {
-        const int n3 = nsys - 1 - n2;
-        HIPCK(hipStreamWaitEvent(st3, ev_fork, 0));
-        if (build_system(n3, sb, 1 + n2, st3)) return -1;
-        chol_factor(st3, plan, d_red.p, d_fail.p, n3, red_stride, 1 + n2);
-        chol_back(st3, plan, d_red.p, n3, red_stride, 1 + n2);
-        HIPCK(hipEventRecord(ev_spec3, st3));
-        spec3_pending = true;
-      }
+      if (build_system(defer_n2, sb, n1, st2)) return -1;
+      if (n1 + defer_n2 < nsys) { HIPCK(hipStreamWaitEvent(st3, ev_fork, 0)); if (build_system(nsys - n1 - defer_n2, sb, n1 + defer_n2, st3)) return -1; }
+      tic(ST_CHOL); chol_factor(st, plan, d_red.p, d_fail.p, n1, red_stride, 0); toc();
+      tic(ST_SOLVE); chol_back(st, plan, d_red.p, n1, red_stride, 0); toc();
+      defer_n1 = n1; defer_nsys = nsys;
     } else {
     if (build_system(nsys, sb)) return -1;
     if (np) {
@@ -912,10 +928,35 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   launch_chains(tr);
   launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  const bool mailbox = use_mailbox && world == 1 && !prm.profile;
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
-                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur);
+                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
+                     mailbox ? h_mail_dev : (double*)nullptr, 29, ++mail_ticket);
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
+  if (defer_nsys) {
+    const int n2 = defer_n2;
+    chol_factor(st2, plan, d_red.p, d_fail.p, n2, red_stride, defer_n1);
+    chol_back(st2, plan, d_red.p, n2, red_stride, defer_n1);
+    HIPCK(hipEventRecord(ev_spec, st2));
+    spec_pending = true; spec2_from = defer_n1; spec3_from = defer_n1 + n2;
+    if (defer_n1 + n2 < defer_nsys) {
+      const int n3 = defer_nsys - defer_n1 - n2;
+      chol_factor(st3, plan, d_red.p, d_fail.p, n3, red_stride, defer_n1 + n2);
+      chol_back(st3, plan, d_red.p, n3, red_stride, defer_n1 + n2);
+      HIPCK(hipEventRecord(ev_spec3, st3));
+      spec3_pending = true;
+    }
+  }
+  if (mailbox) {
+    // one rank: nothing to reduce; the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
+    if (wait_mail(29)) return -1;
+    if (!nfl) h_res[1] = h_res[2] = 0.0;
+    h_res[1] += h_res[6]; h_res[2] += h_res[7];
+    ok2 = (h_res[3] == 0.0);
+    timing.n_trials++;
+    return 0;
+  }
   // robust chi2, point parts of the step statistics, failure flag (any rank); on the first trial of an iteration also the
   // iteration-start robust chi2 (moved next to them for the occasion, and back)
   if (start_rides) {
@@ -1199,6 +1240,8 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   std::memset(&h->P, 0, sizeof h->P);
   if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
   { const char* e = getenv("MCP_BA_OVERLAP"); if (e) h->overlap_spec = atoi(e); }
+  { const char* e = getenv("MCP_BA_MAILBOX"); if (e) h->use_mailbox = atoi(e); }
+  { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
   if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||

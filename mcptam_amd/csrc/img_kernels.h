@@ -873,10 +873,9 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
               double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
               double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out) {
   __shared__ unsigned int hist[2048];
-  __shared__ unsigned int part[64];
+  __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
   __shared__ double red[PR_THREADS/64][28];
-  __shared__ double pose[12], v6[6];
-  __shared__ unsigned long long sel_prefix, sel_k;
+  __shared__ double pose[12], v6[6], tot[27];
   __shared__ int nf_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 12) pose[t] = bfw_io[t];
@@ -924,35 +923,10 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
     double s2 = override_sigma[it];
     if (!(s2 > 0)) {
       // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select in LDS
-      if (t == 0) { sel_prefix = 0ull; sel_k = (unsigned long long)(nf/2); }
-      __syncthreads();
-      for (int pass = 0; pass < SEL_PASSES; ++pass) {
-        const int sh = sel_shift(pass);
-        const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
-        const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
-        for (int b = t; b < 2048; b += PR_THREADS) hist[b] = 0u;
-        __syncthreads();
-        const unsigned long long prefix = sel_prefix;
-        for (int i = t; i < n; i += PR_THREADS) {
-          if (!pts[i].found) continue;
-          const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(e2s[i]));
-          if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
-        }
-        __syncthreads();
-        if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
-        __syncthreads();
-        if (t == 0) {
-          unsigned long long k = sel_k, acc = 0; int c = 0;
-          for (; c < 64; ++c) { if (acc + part[c] > k) break; acc += part[c]; }
-          if (c == 64) c = 63;
-          int b = 32*c;
-          for (; b < 32*c + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
-          if (b >= 32*c + 32) b = 32*c + 31;
-          sel_prefix = prefix | ((unsigned long long)b << sh);
-          sel_k = k - acc;
-        }
-        __syncthreads();
-      }
+      const unsigned long long sel_prefix = lds_radix_select_1024(n, (unsigned long long)(nf/2), 0, 0ull, [&](int i, unsigned long long& key) {
+        if (!pts[i].found) return false;
+        key = (unsigned long long)__double_as_longlong(fabs(e2s[i]));
+        return true; }, hist, sel_sc, sel_st);
       const double med = __longlong_as_double((long long)sel_prefix);
       double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
       sg = 4.6851*sg;
@@ -994,14 +968,31 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
       for (int k = 0; k < 27; ++k) red[wave][k] = a[k];
     }
     __syncthreads();
+    if (t < 27) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][t]; tot[t] = sum; }      // the wavefronts' partials in wavefront order
+    __syncthreads();
     if (t == 0) {
-      double C[36], v[6], mu[6];
+      double C[36], v[6], mu[6], rd[6];
       int q = 0;
-      for (int x = 0; x < 6; ++x) for (int y = 0; y <= x; ++y) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][q]; C[6*x + y] = C[6*y + x] = sum; ++q; }
-      for (int x = 0; x < 6; ++x) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][21 + x]; v[x] = sum; C[7*x] += 100.0; }    // add_prior(100)
-      for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = (i == j) ? sqrt(sum) : sum/C[6*j + j]; }
-      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum/C[6*i + i]; }
-      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum/C[6*i + i]; }
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
+#pragma unroll
+      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
+      // 6x6 Cholesky; the divisions by a column's pivot share one reciprocal (a lane alone pays ~40 dependent instructions per fp64 division)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = C[7*j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
+        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
       Se3 E, T, R;
       se3_exp(mu, E);
       for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
@@ -1071,9 +1062,8 @@ k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restri
            const double* __restrict__ table /* world x cap */, const double* __restrict__ counts /* world */, int world, int cap,
            double override_sigma, int last, double* __restrict__ out27 /* [27] + [27] = total found */, double* __restrict__ w_out) {
   __shared__ unsigned int hist[2048];
-  __shared__ unsigned int part[64];
+  __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
   __shared__ double red[16][28];
-  __shared__ unsigned long long sel_prefix, sel_k;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double nf_d = 0.0;
   for (int r = 0; r < world; ++r) nf_d += counts[r];
@@ -1081,36 +1071,11 @@ k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restri
   if (nf == 0) { if (t < 28) out27[t] = 0.0; return; }
   double s2 = override_sigma;
   if (!(s2 > 0)) {
-    if (t == 0) { sel_prefix = 0ull; sel_k = nf/2; }
-    __syncthreads();
     const int m = world*cap;
-    for (int pass = 0; pass < SEL_PASSES; ++pass) {
-      const int sh = sel_shift(pass);
-      const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
-      const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
-      for (int b = t; b < 2048; b += 1024) hist[b] = 0u;
-      __syncthreads();
-      const unsigned long long prefix = sel_prefix;
-      for (int i = t; i < m; i += 1024) {
-        if ((double)(i % cap) >= counts[i/cap]) continue;
-        const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(table[i]));
-        if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
-      }
-      __syncthreads();
-      if (t < 64) { unsigned int a = 0; for (int b = 0; b < 32; ++b) a += hist[32*t + b]; part[t] = a; }
-      __syncthreads();
-      if (t == 0) {
-        unsigned long long k = sel_k, acc = 0; int c = 0;
-        for (; c < 64; ++c) { if (acc + part[c] > k) break; acc += part[c]; }
-        if (c == 64) c = 63;
-        int b = 32*c;
-        for (; b < 32*c + 32; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
-        if (b >= 32*c + 32) b = 32*c + 31;
-        sel_prefix = prefix | ((unsigned long long)b << sh);
-        sel_k = k - acc;
-      }
-      __syncthreads();
-    }
+    const unsigned long long sel_prefix = lds_radix_select_1024(m, nf/2, 0, 0ull, [&](int i, unsigned long long& key) {
+      if ((double)(i % cap) >= counts[i/cap]) return false;
+      key = (unsigned long long)__double_as_longlong(fabs(table[i]));
+      return true; }, hist, sel_sc, sel_st);
     const double med = __longlong_as_double((long long)sel_prefix);
     double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
     sg = 4.6851*sg;

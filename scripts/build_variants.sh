@@ -11,6 +11,8 @@ build() { name=$1; shift; /opt/rocm/bin/hipcc $FL "$@" -c -o /tmp/ba_$name.o ba_
 for v in "$@"; do
   case $v in
     panel2) build panel2 -DMCP_CHOL_PANEL2=1 & ;;          # panel split over two wavefronts by column halves
+    rsq2) build rsq2 -DCH_RSQ2=1 & ;;
+    lin2) build lin2 -DLIN_WAVES=2 & ;;                    # k_linearize_group held to 256 registers (two wavefronts per SIMD)                      # second-order rsqrt correction in the panel chain
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
