@@ -127,9 +127,20 @@ struct mcp_ba {
   DevBuf<double> d_pack; int n_red_tiles = 0;
   DevBuf<unsigned char> d_sp_big, d_slot_lp, d_slot_first, d_inc_lp, d_inc_mixed;
   int nsp = 0, ngroup = 0, nbig = 0;
-  // state (double buffered: cur / trial)
-  DevBuf<double> d_pose[2], d_pt[2], d_first[2], d_second[2], d_last[2], d_chi2[2];
-  int cur = 0;
+  // state: the current one + one candidate per system of a multi-lambda batch (trial q of an iteration writes candidate q;
+  // an accepted trial's candidate becomes current by index, nothing is copied)
+  static constexpr int NSTATE = 1 + MAX_SYS;
+  DevBuf<double> d_pose[NSTATE], d_pt[NSTATE], d_first[NSTATE], d_second[NSTATE], d_last[NSTATE], d_chi2[NSTATE];
+  int cur = 0, last_tr = 1;
+  int cand(int q) const { for (int s_ = 0, k = 0;; ++s_) { if (s_ == cur) continue; if (k == q) return s_; ++k; } }
+  // Speculative trial evaluation: the trials of an iteration differ only in lambda, so the step of every speculatively solved
+  // system is applied and evaluated (pose/point update, chains, residuals, robust sums) on the stream that solved it, right
+  // behind its back-substitution -- the host finds the result of a rejected trial's successor in its mailbox instead of
+  // launching five dependent kernels and waiting.  Same kernels on the same inputs as a trial run in sequence: same numbers.
+  DevBuf<double> d_sxp[MAX_SYS], d_sxl[MAX_SYS], d_sp0[MAX_SYS], d_sp1[MAX_SYS], d_sp2[MAX_SYS];
+  bool pre_run[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
+  hipEvent_t ev_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
+  int spec_trials = 1;             // MCP_BA_SPEC_TRIALS=0: trials strictly in sequence
   // system
   DevBuf<double> d_ubig;    // [U (np*np) | bp (np)] contributions of the points outside the groups (> GRP_LMAX poses); only if nbig
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp = J^T r (np)]   (the all-reduced block)
@@ -179,11 +190,13 @@ struct mcp_ba {
     if (h_fail) (void)hipHostFree(h_fail);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
+    for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) (void)hipGraphExecDestroy(chain_exec[q][r]);
     if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
     if (st3) { (void)hipStreamSynchronize(st3); (void)hipStreamDestroy(st3); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_spec) (void)hipEventDestroy(ev_spec);
     if (ev_spec3) (void)hipEventDestroy(ev_spec3);
+    for (int q = 0; q < MAX_SYS; ++q) if (ev_tr[q]) (void)hipEventDestroy(ev_tr[q]);
     if (st) (void)hipStreamDestroy(st);
   }
   // everything the second stream still has in flight reads the current linearisation (W, V, g, staged blocks): the main stream
@@ -205,6 +218,7 @@ struct mcp_ba {
   int speculate = 3;                 // speculative systems per solve at most; MCP_BA_SPECULATE=0 turns them off
   int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
   hipGraphExec_t chol_exec[MAX_SYS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t chain_exec[MAX_SYS + 1][MAX_SYS] = {};      // [systems][first system]: factorisation + back-substitution of a sub-batch, captured once
   double* S() { return d_red.p + sys_cur*red_stride; }
   double* rhs() { return S() + (size_t)np*np; }
   double* Vinv() { return d_Vinv.p + sys_cur*vinv_stride; }
@@ -282,7 +296,29 @@ struct mcp_ba {
   int select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma = false);
   int median_sigma(int which);
   int read_results(int count);
-  int wait_mail(int count);
+  int wait_mail(int q, unsigned long long ticket, int count);
+  int enqueue_spec_trial(hipStream_t s, int q);
+  int cancel_spec_trials();
+  int run_ahead(int q);
+  unsigned long long mail_ticket0 = 0;
+  int dbg_pre = 0; double dbg_wait_us[2] = {0, 0};
+  DevBuf<double>* last_xp = nullptr; DevBuf<double>* last_xl = nullptr;     // where the last trial left the solver's x (pose part, point part)
+  // MCP_BA_EVT=1: device time stamps (timing events) of the phases of every iteration on both streams, printed to stderr
+  int evt_debug = 0; std::vector<std::pair<const char*, hipEvent_t>> evt_log;
+  void mark(const char* what, hipStream_t s) { if (!evt_debug) return; hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; (void)hipEventRecord(e, s); evt_log.push_back({what, e}); }
+  void evt_flush() {
+    if (!evt_debug || evt_log.empty()) return;
+    (void)hipDeviceSynchronize();
+    size_t base = 0;
+    for (size_t i = 0; i < evt_log.size(); ++i) {
+      if (!std::strcmp(evt_log[i].first, "iter")) { base = i; fprintf(stderr, "\n[evt]"); }
+      float ms = 0; (void)hipEventElapsedTime(&ms, evt_log[base].second, evt_log[i].second); fprintf(stderr, " %s %.0f", evt_log[i].first, ms*1e3);
+    }
+    fprintf(stderr, "\n");
+    for (auto& pe : evt_log) (void)hipEventDestroy(pe.second);
+    evt_log.clear();
+  }
+  int solve_chain(hipStream_t s, int n, int q0);
   int linearize();
   int build_system(int nsys, SysBatch& sb, int q0 = 0, hipStream_t on = nullptr);
   int solve_trial(double lam, bool& ok2, double ni = 0);
@@ -619,7 +655,7 @@ int mcp_ba::prepare() {
       d_g_blk0.upload(g_blk0, st) || d_blk_pair.upload(blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(pair_id, st) ||
       d_pr_start.upload(pr_start, st) || d_blk_dst.upload(blk_dst, st) || d_po_start.upload(po_start, st) || d_rhs_dst.upload(rhs_dst, st)) return -1;
   const size_t nc = chains.size();
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < NSTATE; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*MAXC*12) ||
         d_second[b].alloc(nc*MAXC*9) || d_last[b].alloc(nc*12) || d_chi2[b].alloc(nmeas)) return -1;
   const size_t n2 = (size_t)np*np;
@@ -630,13 +666,21 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (world > 1 && d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
+  for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) { (void)hipGraphExecDestroy(chain_exec[q][r]); chain_exec[q][r] = nullptr; }
   if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)nrhs_rows*6) || d_stS.alloc(MAX_SYS*nstage*36) ||
       d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
-      d_part2.alloc(nblk) || d_res.alloc(32) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
+      d_part2.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
-  if (!h_res) { HIPCK(hipHostMalloc((void**)&h_res, 64*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); std::memset(h_res, 0, 64*sizeof(double)); void* dp = nullptr; HIPCK(hipHostGetDevicePointer(&dp, h_res, 0)); h_mail_dev = (double*)dp + 32; }
+  // pinned, device-visible: [0..31] read-back block, [32 + 32 q ..] mailbox of trial q (ticket at + MAIL_TICKET)
+  constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
+  if (!h_res) {
+    HIPCK(hipHostMalloc((void**)&h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); std::memset(h_res, 0, HRES*sizeof(double));
+    void* dp = nullptr; HIPCK(hipHostGetDevicePointer(&dp, h_res, 0)); h_mail_dev = (double*)dp + 32;
+  }
+  for (int q = 1; q < MAX_SYS; ++q)
+    if (d_sxp[q].alloc(np) || d_sxl[q].alloc((size_t)nfl*3) || d_sp0[q].alloc(nblk) || d_sp1[q].alloc(nblk) || d_sp2[q].alloc(nblk)) return -1;
   if (!h_fail) HIPCK(hipHostMalloc((void**)&h_fail, 4*sizeof(int)));
   HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
   HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
@@ -671,7 +715,7 @@ int mcp_ba::upload_state() {
   for (size_t i = 0; i < poses.size(); ++i) std::memcpy(&ps[i*12], poses[i].T, 96);
   for (size_t i = 0; i < points.size(); ++i) std::memcpy(&pt[i*3], points[i].x, 24);
   cur = 0;
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < NSTATE; ++b) {
     if (!ps.empty()) HIPCK(hipMemcpyAsync(d_pose[b].p, ps.data(), ps.size()*8, hipMemcpyHostToDevice, st));
     if (!pt.empty()) HIPCK(hipMemcpyAsync(d_pt[b].p, pt.data(), pt.size()*8, hipMemcpyHostToDevice, st));
   }
@@ -755,19 +799,60 @@ int mcp_ba::median_sigma(int w) {
   toc();
   return 0;
 }
-// waits for the ticket of the trial's last kernel in the mailbox and takes the forwarded block from there
-int mcp_ba::wait_mail(int count) {
-  volatile unsigned long long* tk = (volatile unsigned long long*)(h_res + 32 + MAIL_TICKET);
-  for (unsigned long long spins = 0; __atomic_load_n(tk, __ATOMIC_ACQUIRE) != mail_ticket; ++spins) {
+// waits for `ticket` in the mailbox of trial q (written by the trial's last kernel) and takes the forwarded block from there
+int mcp_ba::wait_mail(int q, unsigned long long ticket, int count) {
+  const auto w0 = std::chrono::steady_clock::now();
+  struct Acc { mcp_ba* h; int q; std::chrono::steady_clock::time_point t; ~Acc() { h->dbg_wait_us[q ? 1 : 0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } acc_{this, q, w0};
+  const double* box = h_res + 32 + 32*q;
+  volatile unsigned long long* tk = (volatile unsigned long long*)(box + MAIL_TICKET);
+  hipStream_t watched = (q == 0) ? st : st2;
+  for (unsigned long long spins = 0; __atomic_load_n(tk, __ATOMIC_ACQUIRE) != ticket; ++spins) {
     if ((spins & 0xfffff) == 0xfffff) {             // every ~million polls: has the stream died or drained without delivering?
-      const hipError_t e = hipStreamQuery(st);
-      if (e == hipSuccess) { if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == mail_ticket) break; set_err("mailbox ticket never arrived"); return -1; }
+      hipError_t e = hipStreamQuery(watched);
+      if (e == hipSuccess && q > 0 && st3) e = hipStreamQuery(st3);
+      if (e == hipSuccess) { if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == ticket) break; set_err("mailbox ticket never arrived"); return -1; }
       if (e != hipErrorNotReady) { set_err(std::string("stream failed while waiting for a trial: ") + hipGetErrorString(e)); return -1; }
     }
     __builtin_ia32_pause();
   }
-  std::memcpy(h_res, h_res + 32, count*sizeof(double));
+  std::memcpy(h_res, box, count*sizeof(double));
   return 0;
+}
+// the step of speculative system q applied and evaluated on stream s (which has just solved it): candidate state cand(q), its own
+// scratch, result block d_res[32 + 8 q ..] -> mailbox q.
+int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
+  const int slot = cand(q);
+  const double lam = batch_lambda[q];
+  double* Sq = d_red.p + q*red_stride; double* rhsq = Sq + (size_t)np*np;
+  double* resq = d_res.p + 32 + 8*q;
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
+  const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
+  if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, s, P, lam, (const double*)rhsq, (const double*)d_g.p, (const double*)d_W.p,
+                              (const double*)(d_Vinv.p + q*vinv_stride), (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
+  if (P.nchain) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
+                              (const double*)d_sigma.p, d_sp0[q].p);
+  pre_ticket[q] = ++mail_ticket;
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, s, nbe, (const double*)d_sp0[q].p, nbb, (const double*)(nfl ? d_sp1[q].p : nullptr),
+                     nbb, (const double*)(nfl ? d_sp2[q].p : nullptr), resq, 0, (const int*)d_fail.p + q, h_mail_dev + 32*q, 6, pre_ticket[q]);
+  HIPCK(hipEventRecord(ev_tr[q], s));
+  pre_run[q] = true;
+  return 0;
+}
+// the iteration has decided (or starts a new solve): a trial evaluated ahead that nobody asked for is simply never looked at
+// (at most one is in flight -- see run_ahead -- and it is done before the next linearisation wants its buffers)
+int mcp_ba::cancel_spec_trials() {
+  for (int q = 0; q < MAX_SYS; ++q) pre_run[q] = false;
+  return 0;
+}
+// One trial ahead: when the host turns to trial q - 1, the step of system q (if it was solved speculatively on another stream) is
+// applied and evaluated there already, so that a rejection of q - 1 finds q's result waiting.
+int mcp_ba::run_ahead(int q) {
+  if (!spec_trials || !use_mailbox || world != 1 || prm.profile) return 0;
+  if (!spec_pending && !spec3_pending && q >= spec2_from) { /* its stream has been joined already: still valid to use it */ }
+  if (q < spec2_from || q >= batch_n || pre_run[q]) return 0;
+  return enqueue_spec_trial(q >= spec3_from ? st3 : st2, q);
 }
 int mcp_ba::read_results(int count) {
   // the failure flag of a trial travels inside the block (k_final_sums, d_res[3]): one copy, one wait
@@ -778,7 +863,9 @@ int mcp_ba::read_results(int count) {
 
 // buildSystem at the current state (sigma block must be current)
 int mcp_ba::linearize() {
+  mark("lin_wait", st);
   if (join_spec()) return -1;        // the second stream may still be reading the previous linearisation
+  mark("lin_go", st);
   spec_ok = false;                   // a speculative solve belongs to the linearisation it was built from
   tic(ST_LIN);
   const size_t n2 = (size_t)np*np;
@@ -853,15 +940,53 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
 }
 
 // one LM trial up to and including the evaluation of the trial state.
+// factorisation + back-substitution of systems [q0, q0 + n) of the batch on stream s: ~40 dependent launches, or -- with
+// MCP_BA_GRAPH=1 -- one launch of a graph captured the first time this sub-batch shape occurs (same buffers, same plan every time).
+// With two chains in flight the host's enqueue rate decides when the second one can start; a graph hands it over at once.
+int mcp_ba::solve_chain(hipStream_t s, int n, int q0) {
+  if (use_graph && !prm.profile) {
+    hipGraphExec_t& ex = chain_exec[n][q0];
+    if (!ex) {
+      hipGraph_t g = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        chol_factor(s, plan, d_red.p, d_fail.p, n, red_stride, q0);
+        chol_back(s, plan, d_red.p, n, red_stride, q0);
+        if (hipStreamEndCapture(s, &g) != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { ex = nullptr; use_graph = 0; }
+        if (g) (void)hipGraphDestroy(g);
+      } else use_graph = 0;
+      (void)hipGetLastError();
+    }
+    if (ex) { HIPCK(hipGraphLaunch(ex, s)); return 0; }
+  }
+  chol_factor(s, plan, d_red.p, d_fail.p, n, red_stride, q0);
+  chol_back(s, plan, d_red.p, n, red_stride, q0);
+  return 0;
+}
+
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
-  const int tr = cur ^ 1;
   int defer_n1 = 0, defer_n2 = 0, defer_nsys = 0;
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
     // an earlier trial of this iteration already built and solved this system speculatively (possibly on the second stream)
-    if (join_spec(sys_cur + 1)) return -1;
     ++sys_cur;
     timing.n_spec_hits++;
+    if (pre_run[sys_cur]) {
+      // ... and its step has been applied and evaluated there as well: the result is in (or on its way to) the trial's mailbox
+      const int q = sys_cur;
+      last_tr = cand(q); last_xp = &d_sxp[q]; last_xl = &d_sxl[q];
+      if (run_ahead(q + 1)) return -1;
+      if (wait_mail(q, pre_ticket[q], 6)) return -1;
+      pre_run[q] = false;
+      HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));         // whatever the main stream does next with the trial's state comes after the kernels that made it
+      mark("pre_used", st);
+      ++dbg_pre;
+      if (!nfl) h_res[1] = h_res[2] = 0.0;
+      h_res[1] += h_res[4]; h_res[2] += h_res[5];
+      ok2 = (h_res[3] == 0.0);
+      timing.n_trials++;
+      return 0;
+    }
+    if (join_spec(sys_cur)) return -1;
   } else {
     sys_cur = 0;
     // the lambdas of the rejection branch of the LM schedule: lambda *= ni; ni *= 2 (same operations as compute())
@@ -869,9 +994,10 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     SysBatch sb; std::memset(&sb, 0, sizeof sb);
     { double l = lam, f = ni; for (int q = 0; q < nsys; ++q) { batch_lambda[q] = sb.lambda[q] = l; sb.lambda_init[q] = (rank == 0) ? l : 0.0; l *= f; f *= 2; } }
     batch_n = nsys;
-    if (join_spec()) return -1;            // (a re-solve inside an iteration: the previous batch's stragglers first)
+    if (cancel_spec_trials()) return -1;   // (a re-solve inside an iteration: nothing of the previous batch is wanted any more)
+    if (join_spec()) return -1;            // (... and its stragglers first)
     HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-    const bool split = overlap_spec && nsys > 1 && np > 0 && !multi() && !use_graph && st2;
+    const bool split = overlap_spec && nsys > 1 && np > 0 && !multi() && st2;
     if (split) {
       // system 0 -- the one this trial needs -- alone on the main stream; the speculative systems behind the fork on the second
       // stream.  Same kernels on the same data as the batched path: the numbers do not depend on which stream produced them.
@@ -879,16 +1005,23 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       // never waits for the other stream (its system comes out of the same launches as the first trial's)
       const int n1 = std::min(std::max(main_sys, 1), nsys - 1);
       HIPCK(hipEventRecord(ev_fork, st));
+      mark("fork", st);
       if (build_system(n1, sb, 0, st)) return -1;
+      mark("main_built", st);
       // host enqueue order: the other streams' Schur complements right away (they start at the fork on the device and run beside
       // the main stream's), their factorisation chains only after this trial's own chain and tail (below) -- the main stream never
       // runs dry behind the ~45 launches of another chain
       defer_n2 = (overlap_spec >= 2 && nsys - n1 > 1 && st3) ? 1 : nsys - n1;       // systems on the second stream
       HIPCK(hipStreamWaitEvent(st2, ev_fork, 0));
+      mark("spec_start", st2);
       if (build_system(defer_n2, sb, n1, st2)) return -1;
+      mark("spec_built", st2);
       if (n1 + defer_n2 < nsys) { HIPCK(hipStreamWaitEvent(st3, ev_fork, 0)); if (build_system(nsys - n1 - defer_n2, sb, n1 + defer_n2, st3)) return -1; }
-      tic(ST_CHOL); chol_factor(st, plan, d_red.p, d_fail.p, n1, red_stride, 0); toc();
-      tic(ST_SOLVE); chol_back(st, plan, d_red.p, n1, red_stride, 0); toc();
+      if (use_graph && !prm.profile) { if (solve_chain(st, n1, 0)) return -1; }
+      else {
+        tic(ST_CHOL); chol_factor(st, plan, d_red.p, d_fail.p, n1, red_stride, 0); toc();
+        tic(ST_SOLVE); chol_back(st, plan, d_red.p, n1, red_stride, 0); toc();
+      }
       defer_n1 = n1; defer_nsys = nsys;
     } else {
     if (build_system(nsys, sb)) return -1;
@@ -917,6 +1050,8 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     spec_ok = (nsys > 1);
     timing.n_solves++;
   }
+  mark("solved", st);
+  const int tr = cand(sys_cur); last_tr = tr; last_xp = &d_xp_cand; last_xl = &d_xl;
   const double* bp_glob = bp();
   tic(ST_UPDATE);
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
@@ -931,26 +1066,27 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const bool mailbox = use_mailbox && world == 1 && !prm.profile;
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
                      nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
-                     mailbox ? h_mail_dev : (double*)nullptr, 29, ++mail_ticket);
+                     mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0 = ++mail_ticket);
   toc();
   if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
+  mark("trial_end", st);
   if (defer_nsys) {
     const int n2 = defer_n2;
-    chol_factor(st2, plan, d_red.p, d_fail.p, n2, red_stride, defer_n1);
-    chol_back(st2, plan, d_red.p, n2, red_stride, defer_n1);
+    if (solve_chain(st2, n2, defer_n1)) return -1;
+    mark("spec_done", st2);
     HIPCK(hipEventRecord(ev_spec, st2));
     spec_pending = true; spec2_from = defer_n1; spec3_from = defer_n1 + n2;
     if (defer_n1 + n2 < defer_nsys) {
       const int n3 = defer_nsys - defer_n1 - n2;
-      chol_factor(st3, plan, d_red.p, d_fail.p, n3, red_stride, defer_n1 + n2);
-      chol_back(st3, plan, d_red.p, n3, red_stride, defer_n1 + n2);
+      if (solve_chain(st3, n3, defer_n1 + n2)) return -1;
       HIPCK(hipEventRecord(ev_spec3, st3));
       spec3_pending = true;
     }
   }
+  if (defer_nsys && run_ahead(1)) return -1;
   if (mailbox) {
     // one rank: nothing to reduce; the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
-    if (wait_mail(29)) return -1;
+    if (wait_mail(0, mail_ticket0, 29)) return -1;
     if (!nfl) h_res[1] = h_res[2] = 0.0;
     h_res[1] += h_res[6]; h_res[2] += h_res[7];
     ok2 = (h_res[3] == 0.0);
@@ -993,6 +1129,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     double ni = 2; bool ok = true; int cj = 0;
     for (int it = 0; it < n_iter && !terminate() && ok; ++it) {
       mcp_ba_iter_log lg; std::memset(&lg, 0, sizeof lg);
+      mark("iter", st);
       // preIteration + first robustify: sigma^2 from |chi2| at the iteration-start state
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
@@ -1051,8 +1188,8 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         if (ok2) {
           tempChi = h_res[0]; scale = h_res[1]; ss = h_res[2];
           // the solver's x of the last successful solve (what a later failed solve falls back on): swap, no copy
-          std::swap(d_xp_good.p, d_xp_cand.p); std::swap(d_xp_good.n, d_xp_cand.n);
-          std::swap(d_xl_good.p, d_xl.p); std::swap(d_xl_good.n, d_xl.n);
+          std::swap(d_xp_good.p, last_xp->p); std::swap(d_xp_good.n, last_xp->n);
+          std::swap(d_xl_good.p, last_xl->p); std::swap(d_xl_good.n, last_xl->n);
         } else {
           // CHOLMOD-failure analogue: the solver's x keeps its previous content [g2o]; recompute the
           // scale terms from it with the current lambda and b
@@ -1081,12 +1218,13 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           alpha = std::min(alpha, 2./3.);
           const double sf = std::max(1./3., alpha);
           lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
-          cur ^= 1;                                  // discardTop: the trial state becomes current
+          cur = last_tr;                             // discardTop: the trial state becomes current
         } else {
           lambda *= ni; ni *= 2; accepted = 0;       // pop: the current buffers were never touched
         }
         ++qmax;
       } while (rho < 0 && qmax < prm.max_trials_after_failure && !terminate());
+      if (cancel_spec_trials()) return MCP_ERR_RUNTIME;
       ok = !(qmax == prm.max_trials_after_failure || rho == 0);
       ++cj;
       // post-iteration actions
@@ -1111,6 +1249,8 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     nCounter = cj;
   }
   if (join_spec()) return MCP_ERR_RUNTIME;
+  if (evt_debug) { fprintf(stderr, "[evt] trials evaluated ahead and used: %d; host wait on mailbox: own trials %.0f us, ahead trials %.0f us\n", dbg_pre, dbg_wait_us[0], dbg_wait_us[1]); dbg_pre = 0; dbg_wait_us[0] = dbg_wait_us[1] = 0; }
+  evt_flush();
   int rc = final_stats(nCounter);
   if (rc == MCP_ERR_RUNTIME) return rc;
   converged = (conv_mag || conv_res);
@@ -1242,6 +1382,9 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_OVERLAP"); if (e) h->overlap_spec = atoi(e); }
   { const char* e = getenv("MCP_BA_MAILBOX"); if (e) h->use_mailbox = atoi(e); }
   { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
+  { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }
+  { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
+  for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
   if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
