@@ -9,3 +9,4 @@ cp gpurun_out/final_bench.json profiles/$ROUND/final_bench.json
 f=$(ls -t gpurun_out/prof_final/*/*kernel_stats.csv | head -1); cp "$f" profiles/$ROUND/final_bench_kernel_stats.csv
 cp gpurun_out/final_tests.log profiles/$ROUND/final_gpu_tests.log
 ls -la profiles/$ROUND
+[ -f gpurun_out/trk_kernel_stats.csv ] && cp gpurun_out/trk_kernel_stats.csv profiles/$ROUND/tracker_c3_kernel_stats.csv

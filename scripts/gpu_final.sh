@@ -20,3 +20,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 echo "stats rc=$?"; tail -1 $R/gpurun_out/prof_final.log | cut -c1-300
 cd $R
 timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/final_bench.json; tail -2 gpurun_out/final_bench.err
+bash $R/scripts/gpu_trk_prof.sh > gpurun_out/trk_prof_stdout.log 2>&1; tail -3 gpurun_out/trk_prof_stdout.log
