@@ -726,3 +726,22 @@ def test_bench_two_rank_path_end_to_end(gpu_required):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
     assert "debug" in d["config"] and d["config"]["chi2_last"] < d["config"]["chi2_first"]
+
+
+@pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
+                                 dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2")])
+def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
+    """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox and graph replay are
+    scheduling: the same kernels see the same inputs whichever of them is on, so iteration logs, poses and points are identical
+    to the default configuration's, bit for bit (the knobs are read when the handle is created)."""
+    from mcptam_amd import synth
+    p = synth.make_config("metric")
+    base = run_bundle(_gpu(p.cams, disable_convergence=True), p, 7)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = run_bundle(_gpu(p.cams, disable_convergence=True), p, 7)
+    assert base["rc"] == alt["rc"] == 7
+    assert sum(l["trials"] for l in base["logs"]) > 10, "the run must contain rejected trials for this to mean anything"
+    assert base["logs"] == alt["logs"]
+    assert np.array_equal(base["R"], alt["R"]) and np.array_equal(base["t"], alt["t"]) and np.array_equal(base["X"], alt["X"])
+    assert base["outliers"] == alt["outliers"] and base["sigma_sq"] == alt["sigma_sq"] and base["lam"] == alt["lam"]

@@ -592,3 +592,16 @@ def test_frame_batch_equals_per_camera_calls(gpu_required, scene):
         for f in single.dtype.names:
             assert np.array_equal(single[f], outs[c][f], equal_nan=single[f].dtype.kind == "f"), f
     assert len(outs[2]) == 0 and outs[0]["found"].sum() > 100
+
+
+def test_frame_batch_rejects_bad_arguments(gpu_required, scene):
+    from mcptam_amd.keyframe import KeyFrame, make_lite_batch
+    a, b = KeyFrame(640, 480), KeyFrame(640, 480, adaptive=False)
+    with pytest.raises(RuntimeError):
+        make_lite_batch([a, a], [scene["imgA"], scene["imgA"]])                 # one handle twice
+    with pytest.raises(RuntimeError):
+        make_lite_batch([a, b], [scene["imgA"], scene["imgA"]])                 # different threshold modes in one launch
+    with pytest.raises(RuntimeError):
+        make_lite_batch([KeyFrame(64, 64) for _ in range(9)], [np.zeros((64, 64), np.uint8)]*9)      # more than MCP_MAX_FRAME_CAMS
+    make_lite_batch([a], [scene["imgA"]])                                       # the handle is still usable afterwards
+    assert len(a.Corners(0)) > 500
