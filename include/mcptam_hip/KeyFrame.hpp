@@ -135,6 +135,28 @@ class KeyFrame {
 
   mcp_kf* handle() { return mpDev; }
 
+  // ---- the cameras of a frame in one submission (the per-camera loops of Tracker::TrackFrame, src/Tracker.cc:303-318, and of
+  // Tracker::TrackMap, :985-1030): results equal the per-camera calls bit for bit
+  /// MakeKeyFrame_Lite on every KeyFrame of `kfs` (<= MCP_MAX_FRAME_CAMS, one device); on_device: `ims` are device pointers
+  static void MakeKeyFrameLiteBatch(const std::vector<KeyFrame*>& kfs, const std::vector<const uint8_t*>& ims, const std::vector<int>& strides,
+                                    bool on_device = false, const std::vector<const uint8_t* const*>* masks = nullptr) {
+    std::vector<mcp_kf*> h; for (KeyFrame* k : kfs) h.push_back(k->mpDev);
+    check(mcp_kf_make_lite_batch((int)h.size(), h.data(), ims.data(), strides.data(), on_device ? 1 : 0, masks ? masks->data() : nullptr));
+  }
+  /// SearchForPoints of every camera against its KeyFrame in one launch; cams_from_base: 12 doubles per camera
+  static std::vector<std::vector<mcp_td_out>> SearchForPointsBatch(const std::vector<KeyFrame*>& kfs, const std::vector<mcp_camera>& cams,
+                                                                    const double base_from_world[12], const std::vector<double>& cams_from_base,
+                                                                    const std::vector<std::vector<mcp_td_in>>& vTD, int nRange, int nSubPixIts,
+                                                                    bool bExhaustive = false) {
+    const int nc = (int)kfs.size();
+    std::vector<mcp_kf*> h; std::vector<int> n; std::vector<const mcp_td_in*> in; std::vector<mcp_td_out*> op;
+    std::vector<std::vector<mcp_td_out>> out(nc);
+    for (int c = 0; c < nc; ++c) { h.push_back(kfs[c]->mpDev); n.push_back((int)vTD[c].size()); in.push_back(vTD[c].data()); out[c].resize(vTD[c].size() + 1); op.push_back(out[c].data()); }
+    check(mcp_track_search_batch(nc, h.data(), cams.data(), base_from_world, cams_from_base.data(), n.data(), in.data(), nRange, nSubPixIts, bExhaustive, op.data()));
+    for (int c = 0; c < nc; ++c) out[c].resize(vTD[c].size());
+    return out;
+  }
+
  private:
   static void check(int rc) { if (rc < 0) throw std::runtime_error(mcp_last_error()); }
   mcp_kf* mpDev = nullptr;

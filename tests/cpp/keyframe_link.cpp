@@ -1,6 +1,7 @@
 // C++ caller of the image/tracker boundary through mcptam_hip::KeyFrame (include/mcptam_hip/KeyFrame.hpp).
 // `--link-only`: every member is instantiated and every C-ABI symbol it uses must resolve (CPU container; on a box without a
 // gfx950 device the constructor throws, which is the documented behaviour -- there is no CPU fallback).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -74,6 +75,25 @@ static int exercise(int w, int h) {
   std::vector<mcp_pose_point> pts; double bfw[12]; std::memcpy(bfw, T, sizeof T);
   auto mu2 = mcptam_hip::TrackMapPoseIterations(pts, { cam }, std::vector<double>(T, T + 12), bfw, { 1 }, { -1.0 });
   (void)mu2; (void)&KeyFrame::SE3fromSE2;
+  // the cameras of a frame in one submission: identical to the per-camera calls; and what the submission costs a native caller
+  {
+    KeyFrame c1(w, h), c2(w, h), c3(w, h), c4(w, h);
+    std::vector<KeyFrame*> kfs = { &c1, &c2, &c3, &c4 };
+    KeyFrame::MakeKeyFrameLiteBatch(kfs, { img.data(), img.data(), img.data(), img.data() }, { w, w, w, w });
+    for (KeyFrame* k : kfs) for (int l = 0; l < MCP_LEVELS; ++l) {
+      mcptam_hip::Level X = k->GetLevel(l), Y = b.GetLevel(l);
+      CHECK(X.image == Y.image && X.vCorners.size() == Y.vCorners.size() && X.nFastThresh == Y.nFastThresh && X.vCornerRowLUT == Y.vCornerRowLUT);
+      for (size_t i = 0; i < X.vCorners.size(); ++i) CHECK(X.vCorners[i].x == Y.vCorners[i].x && X.vCorners[i].y == Y.vCorners[i].y);
+    }
+    std::vector<std::vector<mcp_td_in>> none(4);
+    auto outs = KeyFrame::SearchForPointsBatch(kfs, { cam, cam, cam, cam }, T, std::vector<double>(48, 0.0), none, 10, 8);
+    CHECK(outs.size() == 4 && outs[0].empty());
+    const int reps = 50;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) KeyFrame::MakeKeyFrameLiteBatch(kfs, { img.data(), img.data(), img.data(), img.data() }, { w, w, w, w });
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()/reps;
+    std::printf("native MakeKeyFrame_Lite of 4 cameras %dx%d in one submission (upload included): %.0f us\n", w, h, us);
+  }
   std::printf("keyframe mirror ok: %zu corners, %zu patches matched\n", total_corners, pm.size());
   return 0;
 }
@@ -83,6 +103,6 @@ int main(int argc, char** argv) {
     std::printf("linked: %d gfx950 device(s) visible\n", mcp_device_count());
     return (void*)&exercise ? 0 : 1;
   }
-  try { return exercise(320, 240); }
+  try { const int rc = exercise(320, 240); return rc ? rc : exercise(640, 480); }
   catch (const std::exception& e) { std::printf("failed: %s\n", e.what()); return 2; }
 }

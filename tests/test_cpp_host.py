@@ -49,4 +49,5 @@ def test_cpp_keyframe_mirror_runs_on_gpu(tmp_path, gpu_required):
     exe = _build(tmp_path, "keyframe_link")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "keyframe mirror ok" in out.stdout
+    assert out.stdout.count("keyframe mirror ok") == 2 and "one submission" in out.stdout       # 320x240 and 640x480, batch entries included
+    print(out.stdout)
