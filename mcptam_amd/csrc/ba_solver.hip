@@ -138,7 +138,7 @@ struct mcp_ba {
   // behind its back-substitution -- the host finds the result of a rejected trial's successor in its mailbox instead of
   // launching five dependent kernels and waiting.  Same kernels on the same inputs as a trial run in sequence: same numbers.
   DevBuf<double> d_sxp[MAX_SYS], d_sxl[MAX_SYS], d_sp0[MAX_SYS], d_sp1[MAX_SYS], d_sp2[MAX_SYS];
-  bool pre_run[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
+  bool pre_run[MAX_SYS] = {false, false, false, false}, ahead_enq[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
   hipEvent_t ev_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
   int spec_trials = 1;             // MCP_BA_SPEC_TRIALS=0: trials strictly in sequence
   // system
@@ -205,6 +205,10 @@ struct mcp_ba {
   int join_spec(int q = -1) {
     if (spec_pending && (q < 0 || (q >= spec2_from && q < spec3_from))) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
     if (spec3_pending && (q < 0 || q >= spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec3, 0)); spec3_pending = false; }
+    // a full join also covers the trials evaluated ahead on those streams (enqueued after ev_spec was recorded): whatever the main
+    // stream does next -- the next linearisation overwrites W, g, V; the next iteration's trials reuse the candidate states -- is
+    // ordered behind them, used or not
+    if (q < 0) for (int k = 0; k < MAX_SYS; ++k) if (ahead_enq[k]) { HIPCK(hipStreamWaitEvent(st, ev_tr[k], 0)); ahead_enq[k] = false; }
     return 0;
   }
 
@@ -837,7 +841,7 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, s, nbe, (const double*)d_sp0[q].p, nbb, (const double*)(nfl ? d_sp1[q].p : nullptr),
                      nbb, (const double*)(nfl ? d_sp2[q].p : nullptr), resq, 0, (const int*)d_fail.p + q, h_mail_dev + 32*q, 6, pre_ticket[q]);
   HIPCK(hipEventRecord(ev_tr[q], s));
-  pre_run[q] = true;
+  pre_run[q] = true; ahead_enq[q] = true;
   return 0;
 }
 // the iteration has decided (or starts a new solve): a trial evaluated ahead that nobody asked for is simply never looked at
