@@ -161,7 +161,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="metric")
     ap.add_argument("--cpu-iters", type=int, default=8, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -240,12 +240,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup: W untimed LM iterations (code objects, allocations, clocks)
-    if args.warmup > 0:
-        b = fresh()
-        b.Compute(args.warmup)
-        b.close()
+    # warmup: W untimed LM iterations (code objects, allocations, clocks) on a second handle, run AFTER the timed handle has been
+    # populated and prepared (60 ms of host work during which the device would idle and clock down) and right before the timed region
+    bw = fresh() if args.warmup > 0 else None
     b = fresh()
+    if bw is not None:
+        bw.Compute(args.warmup)
+        bw.close()
     barrier()
     t0 = time.perf_counter()
     rc = b.Compute(args.steps)
