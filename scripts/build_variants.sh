@@ -13,6 +13,8 @@ for v in "$@"; do
     panel2) build panel2 -DMCP_CHOL_PANEL2=1 & ;;          # panel split over two wavefronts by column halves
     rsq2) build rsq2 -DCH_RSQ2=1 & ;;
     lin2) build lin2 -DLIN_WAVES=2 & ;;
+    sch4) build sch4 -DSCH_WAVES=4 & ;;                    # k_schur_group held to 128 registers: four workgroups per CU (1024 slots >= 785 groups)
+    sch2) build sch2 -DSCH_WAVES=2 & ;;
     linabl3) build linabl3 -DLIN_ABL=3 & ;;                # timing ablation: no W block stores in k_linearize_group (results wrong)
     proflin) build proflin -DMCP_LIN_PROF & ;;             # phase stamps of k_linearize_group
     proflin2) build proflin2 -DMCP_LIN_PROF -DLIN_WAVES=2 & ;;                    # k_linearize_group held to 256 registers (two wavefronts per SIMD)                      # second-order rsqrt correction in the panel chain
