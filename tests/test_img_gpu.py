@@ -605,3 +605,65 @@ def test_frame_batch_rejects_bad_arguments(gpu_required, scene):
         make_lite_batch([KeyFrame(64, 64) for _ in range(9)], [np.zeros((64, 64), np.uint8)]*9)      # more than MCP_MAX_FRAME_CAMS
     make_lite_batch([a], [scene["imgA"]])                                       # the handle is still usable afterwards
     assert len(a.Corners(0)) > 500
+
+
+def test_c5_eight_camera_frame_in_one_submission_beside_window_ba(gpu_required):
+    """BASELINE config c5 at its stated size on one device: the eight 1280x960 cameras of a frame go through
+    mcp_kf_make_lite_batch (three launches), mcp_track_search_batch (one launch) and the ten pose iterations, frame after frame,
+    while another host thread adjusts a BundleAdjustRecent-shaped window.  Every frame must equal the per-camera reference and
+    the oracle's pyramid / corners; every window solve must equal the solve run alone."""
+    import threading
+    from mcptam_amd import synth, synth_img
+    from mcptam_amd.chain_bundle import ChainBundle
+    from mcptam_amd.keyframe import KeyFrame, make_lite_batch, pose_points, track_pose_refine, track_search, track_search_batch, pack_points
+    from helpers import run_bundle
+    ncam = 8
+    sc = synth_img.make_tracking_scene(size=(1280, 960))
+    gA, oA = _pair(1280, 960)
+    gA.MakeKeyFrame_Lite(sc["imgA"]); oA.MakeKeyFrame_Lite(sc["imgA"])
+    gA.MakeKeyFrame_Rest(); oA.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(sc["cam"], gA, oA, sc["poseA"], sc["depth"], per_level=(200, 120, 60, 20))
+    wp = np.array([p["world_pos"] for p in pts])
+    packed = pack_points(pts, lambda kf: kf._h)
+    cfbs = [(np.eye(3), np.array([0.01*c, 0.0, 0.0])) for c in range(ncam)]
+    # per-camera reference (single-camera entries) and the oracle's view of the frame
+    oB = _pair(1280, 960)[1]
+    oB.MakeKeyFrame_Lite(sc["imgB"])
+    single = KeyFrame(1280, 960)
+    single.MakeKeyFrame_Lite(sc["imgB"])
+    _assert_lite_equal(single, oB)
+    ref_out = [track_search(single, sc["cam"], sc["poseB"], cfbs[c], packed, 10, 8) for c in range(ncam)]
+    ref_pose, ref_mu, _, _ = track_pose_refine(np.concatenate([pose_points(wp, ref_out[c], c) for c in range(ncam)]), [sc["cam"]]*ncam, cfbs, sc["poseB"])
+    cur = [KeyFrame(1280, 960) for _ in range(ncam)]
+
+    def frame():
+        make_lite_batch(cur, [sc["imgB"]]*ncam)
+        outs = track_search_batch(cur, [sc["cam"]]*ncam, sc["poseB"], cfbs, [packed]*ncam, 10, 8)
+        pose, mu, w, _ = track_pose_refine(np.concatenate([pose_points(wp, outs[c], c) for c in range(ncam)]), [sc["cam"]]*ncam, cfbs, sc["poseB"])
+        return outs, pose, mu
+
+    win = synth.recent_window(synth.make_config("c2", n_mkf=40, n_points=6000))
+    ref_ba = run_bundle(ChainBundle(win.cams, True, True, False), win, 10)
+    result = {}
+
+    def ba_thread():
+        result["ba"] = [run_bundle(ChainBundle(win.cams, True, True, False), win, 10) for _ in range(3)]
+    th = threading.Thread(target=ba_thread)
+    th.start()
+    frames = []
+    while th.is_alive() or len(frames) < 3:
+        frames.append(frame())
+        if len(frames) > 200:
+            break
+    th.join()
+    for c in range(ncam):
+        _assert_lite_equal(cur[c], oB)
+    for outs, pose, mu in frames:
+        for c in range(ncam):
+            for f in ("templ", "found", "found_pos", "score", "coarse_x", "coarse_y"):
+                assert np.array_equal(outs[c][f], ref_out[c][f]), (c, f)
+        assert np.array_equal(pose[0], ref_pose[0]) and np.array_equal(pose[1], ref_pose[1]) and np.array_equal(mu, ref_mu)
+    assert sum(int(o_["found"].sum()) for o_ in frames[0][0]) > 8*80
+    for r in result["ba"]:
+        assert r["rc"] == ref_ba["rc"] and r["logs"] == ref_ba["logs"]
+        assert np.array_equal(r["R"], ref_ba["R"]) and np.array_equal(r["t"], ref_ba["t"]) and np.array_equal(r["X"], ref_ba["X"])
