@@ -186,6 +186,10 @@ struct mcp_ba {
   CholPlan plan;                   // block-sparse structure of the reduced system
 
   ~mcp_ba() {
+    // nothing of this handle may still be running when its mailbox goes back to the host allocator (a trial evaluated ahead writes there)
+    if (st) (void)hipStreamSynchronize(st);
+    if (st2) (void)hipStreamSynchronize(st2);
+    if (st3) (void)hipStreamSynchronize(st3);
     if (h_res) (void)hipHostFree(h_res);
     if (h_fail) (void)hipHostFree(h_fail);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
