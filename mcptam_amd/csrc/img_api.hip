@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -313,25 +314,41 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
   if (n == 0 || n_iter == 0) return 0;
   for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine: camera index out of range");
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine: no HIP device");
-  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<mcp_camera> dc; Buf<double> dcfb, dbfw, dov, dJ, dex, de2, dmu, dw; Buf<uint8_t> dnl; };
+  // device scratch, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d | pad 6 d |
+  // override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back in
+  // one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
+  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; std::vector<uint8_t> hblk; };
   static thread_local RefineScratch rs;
-  if (rs.dp.alloc(n) || rs.dc.alloc(ncam) || rs.dcfb.alloc(12*(size_t)ncam) || rs.dbfw.alloc(12) || rs.dov.alloc(n_iter) || rs.dJ.alloc(12*(size_t)n) ||
-      rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n) || rs.dmu.alloc(8) || rs.dw.alloc(n) || rs.dnl.alloc(n_iter)) return -1;
+  const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam;
+  const size_t o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam, blk = ((o_nl + (size_t)n_iter + 15)/16)*16;
+  static const int use_regs = [] { const char* e = getenv("MCP_TRACK_REFINE_REGS"); return e ? atoi(e) : 1; }();
+  static const bool regs_ok = hipFuncSetAttribute((const void*)k_pose_refine_regs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12*PRR_THREADS*PRR_PPT*sizeof(double))) == hipSuccess;
+  const bool regs = use_regs && regs_ok && n <= PRR_THREADS*PRR_PPT;          // the points fit the register-resident kernel
+  if (rs.dp.alloc(n) || rs.dblk.alloc(blk) || rs.dw.alloc(n)) return -1;
+  if (!regs && (rs.dJ.alloc(12*(size_t)n) || rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n))) return -1;
+  rs.hblk.assign(blk, 0);
+  std::memcpy(rs.hblk.data(), bfw, 96);
+  std::memcpy(rs.hblk.data() + o_ov, override_sigma, 8*(size_t)n_iter);
+  std::memcpy(rs.hblk.data() + o_cfb, cfb, 96*(size_t)ncam);
+  std::memcpy(rs.hblk.data() + o_cam, cams, sizeof(mcp_camera)*(size_t)ncam);
+  std::memcpy(rs.hblk.data() + o_nl, nonlinear, (size_t)n_iter);
   hipStream_t st = nullptr;
   ICK(hipMemcpyAsync(rs.dp.p, pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dc.p, cams, sizeof(mcp_camera)*(size_t)ncam, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dcfb.p, cfb, 96*(size_t)ncam, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dbfw.p, bfw, 96, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dov.p, override_sigma, 8*(size_t)n_iter, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dnl.p, nonlinear, (size_t)n_iter, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), blk, hipMemcpyHostToDevice, st));
   ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
-  hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, (const mcp_camera*)rs.dc.p, (const double*)rs.dcfb.p, rs.dbfw.p, n_iter,
-                     (const uint8_t*)rs.dnl.p, (const double*)rs.dov.p, rs.dJ.p, rs.dex.p, rs.de2.p, rs.dmu.p, rs.dw.p);
+  double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
+  const double* d_ov = reinterpret_cast<const double*>(rs.dblk.p + o_ov); const double* d_cfb = reinterpret_cast<const double*>(rs.dblk.p + o_cfb);
+  const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
+  if (regs)
+    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), (size_t)12*PRR_THREADS*PRR_PPT*sizeof(double), st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p);
+  else
+    hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p);
+  double back[18];
   ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
-  ICK(hipMemcpyAsync(bfw, rs.dbfw.p, 96, hipMemcpyDeviceToHost, st));
-  ICK(hipMemcpyAsync(mu_last, rs.dmu.p, 48, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
   if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
+  std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48);
   return 0;
 }
 

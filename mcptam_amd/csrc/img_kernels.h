@@ -1009,6 +1009,221 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 }
 
 
+// ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
+// One workgroup of 256 threads = one wavefront per SIMD, so a thread may keep 512 registers: its four points' found position,
+// noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips
+// inside an iteration (world position and camera model are re-read only by the re-projecting iterations), four-wavefront barriers,
+// the Tukey median selected from the register-held squared errors.  Same arithmetic per point as k_pose_refine; the order of the
+// 27 sums differs (4 points per thread, 4 wavefronts), i.e. results agree to rounding, the median exactly.
+constexpr int PRR_THREADS = 256, PRR_PPT = 4;
+__global__ void __launch_bounds__(PRR_THREADS)
+k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
+                   double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
+                   double* __restrict__ mu_out, double* __restrict__ w_out) {
+  constexpr int NT = PRR_THREADS, NW = NT/64, BPT = SEL_BINS/NT;
+  __shared__ unsigned int hist[SEL_BINS];
+  __shared__ unsigned long long sc[NW + 3], sst[2];
+  __shared__ double red[NW][28];
+  __shared__ double pose[12], v6[6], tot[27];
+  __shared__ int nf_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  bool fnd[PRR_PPT]; int camk[PRR_PPT];
+  double fpos[PRR_PPT][2], sinv[PRR_PPT], img[PRR_PPT][2], cd[PRR_PPT][4], ex[PRR_PPT][2], e2[PRR_PPT];
+  extern __shared__ double Jl[];                 // [12][NT*PPT]: a point's 2x6 Jacobian, one column of 12 per point (lane-consecutive: no bank conflicts)
+  constexpr int JS = PRR_THREADS*PRR_PPT;
+  int nf_loc = 0;
+#pragma unroll
+  for (int k = 0; k < PRR_PPT; ++k) {
+    const int i = t + k*NT;
+    fnd[k] = false; camk[k] = 0; sinv[k] = 0.0; e2[k] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { fpos[k][q] = 0.0; img[k][q] = 0.0; ex[k][q] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cd[k][q] = 0.0;
+    if (i < n) {
+      const mcp_pose_point& p = pts[i];
+      fnd[k] = p.found != 0; camk[k] = p.cam; sinv[k] = p.sqrt_inv_noise;
+      fpos[k][0] = p.found_pos[0]; fpos[k][1] = p.found_pos[1]; img[k][0] = p.image[0]; img[k][1] = p.image[1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cd[k][q] = p.cam_derivs[q];
+      nf_loc += fnd[k] ? 1 : 0;
+    }
+  }
+  if (t < 12) pose[t] = bfw_io[t];
+  if (t < 6) v6[t] = 0.0;
+  if (t == 0) nf_s = 0;
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nf_loc += __shfl_xor(nf_loc, o, 64);
+  if (lane == 0) atomicAdd(&nf_s, nf_loc);
+  __syncthreads();
+  const int nf = nf_s;
+  for (int it = 0; it < n_iter; ++it) {
+    if (nf == 0) { if (t < 6) v6[t] = 0.0; __syncthreads(); continue; }           // no valid measurements: null update
+    const bool nl = nonlinear[it] != 0;
+#pragma unroll
+    for (int k = 0; k < PRR_PPT; ++k) {
+      if (!fnd[k]) continue;
+      const int i = t + k*NT;
+      if (nl) {
+        const double* cfb = cfb_all + 12*(size_t)camk[k];
+        const double wp[3] = { pts[i].world_pos[0], pts[i].world_pos[1], pts[i].world_pos[2] };
+        double xb[3], xc[3];
+        mat3_vec(pose, wp, xb); xb[0] += pose[9]; xb[1] += pose[10]; xb[2] += pose[11];
+        mat3_vec(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+        if (it != 0) {
+          Projection pr; cam_project<true>(cams[camk[k]], xc, pr);
+          img[k][0] = pr.u; img[k][1] = pr.v; cd[k][0] = pr.D[0]; cd[k][1] = pr.D[1]; cd[k][2] = pr.D[2]; cd[k][3] = pr.D[3];
+        }
+        double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb, mb, mc);
+          const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+          Jl[m*JS + i] = cd[k][0]*s0 + cd[k][1]*s1; Jl[(6 + m)*JS + i] = cd[k][2]*s0 + cd[k][3]*s1;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { double a = 0.0; for (int q = 0; q < 6; ++q) a += Jl[(6*r + q)*JS + i]*v6[q]; img[k][r] += a; }
+      }
+      ex[k][0] = sinv[k]*(fpos[k][0] - img[k][0]); ex[k][1] = sinv[k]*(fpos[k][1] - img[k][1]);
+      e2[k] = ex[k][0]*ex[k][0] + ex[k][1]*ex[k][1];
+    }
+    double s2 = override_sigma[it];
+    if (!(s2 > 0)) {
+      // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select over the register-held keys
+      unsigned long long key[PRR_PPT];
+#pragma unroll
+      for (int k = 0; k < PRR_PPT; ++k) key[k] = (unsigned long long)__double_as_longlong(fabs(e2[k]));
+      if (t == 0) { sst[0] = 0ull; sst[1] = (unsigned long long)(nf/2); }
+      __syncthreads();
+      for (int pass = 0; pass < SEL_PASSES; ++pass) {
+        const int sh = sel_shift(pass);
+        const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+        const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+        for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = sst[0];
+#pragma unroll
+        for (int k = 0; k < PRR_PPT; ++k) if (fnd[k] && (key[k] & himask) == prefix) atomicAdd(&hist[(unsigned int)(key[k] >> sh) & dmask], 1u);
+        __syncthreads();
+        unsigned int hb[BPT]; unsigned long long loc = 0;
+#pragma unroll
+        for (int b = 0; b < BPT; ++b) { hb[b] = hist[BPT*t + b]; loc += hb[b]; }
+        int tt; unsigned long long acc;
+        block_find_rank<NT>(loc, sst[1], tt, acc, sc);
+        if (t == tt) {
+          const unsigned long long kk = sst[1];
+          int b = 0;
+#pragma unroll
+          for (int q = 0; q < BPT - 1; ++q) if (b == q && !(acc + hb[q] > kk)) { acc += hb[q]; b = q + 1; }
+          sc[0] = (unsigned long long)(BPT*t + b); sc[1] = kk - acc; sc[2] = hb[0];
+#pragma unroll
+          for (int q = 1; q < BPT; ++q) if (b == q) sc[2] = hb[q];
+        }
+        __syncthreads();
+        const unsigned long long np_ = prefix | (sc[0] << sh);
+        const unsigned long long kin = sc[1]; const unsigned int in_bin = (unsigned int)sc[2];
+        __syncthreads();
+        if (in_bin == 1u && sh > 0) {                 // one candidate left: it is the element
+          const unsigned long long hm2 = ~0ull << sh;
+#pragma unroll
+          for (int k = 0; k < PRR_PPT; ++k) if (fnd[k] && (key[k] & hm2) == np_) sst[0] = key[k];
+          __syncthreads();
+          break;
+        }
+        if (t == 0) { sst[0] = np_; sst[1] = kin; }
+        __syncthreads();
+      }
+      const double med = __longlong_as_double((long long)sst[0]);
+      double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
+      sg = 4.6851*sg;
+      s2 = sg*sg;
+    }
+    // weighted normal equations: 21 + 6 partial sums per thread
+    double a[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) a[q] = 0.0;
+    const bool last = (it == n_iter - 1);
+#pragma unroll
+    for (int k = 0; k < PRR_PPT; ++k) {
+      const int i = t + k*NT;
+      if (!fnd[k]) { if (last && w_out && i < n) w_out[i] = 0.0; continue; }
+      const double sq = (e2[k] > s2) ? 0.0 : 1.0 - (e2[k]/s2);
+      const double w = sq*sq;
+      if (last && w_out) w_out[i] = w;
+      if (w == 0.0) continue;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double Jr[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jr[q] = sinv[k]*Jl[(6*r + q)*JS + i];
+        const double m = ex[k][r];
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          a[21 + x] += w*m*Jr[x];
+#pragma unroll
+          for (int y = 0; y <= x; ++y) { a[q] += w*Jr[x]*Jr[y]; ++q; }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 27; ++q) { double v = a[q]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[q] = v; }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) red[wave][q] = a[q];
+    }
+    __syncthreads();
+    if (t < 27) { double sum = 0.0; for (int wv = 0; wv < NW; ++wv) sum += red[wv][t]; tot[t] = sum; }
+    __syncthreads();
+    if (t == 0) {
+      double C[36], v[6], mu[6], rd[6];
+      int q = 0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
+#pragma unroll
+      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = C[7*j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
+        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
+      Se3 E, T, R;
+      se3_exp(mu, E);
+      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
+      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
+      se3_compose(E, T, R);
+      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
+      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
+      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < PRR_PPT; ++k) {
+    const int i = t + k*NT;
+    if (i < n && fnd[k]) {
+      pts[i].image[0] = img[k][0]; pts[i].image[1] = img[k][1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pts[i].cam_derivs[q] = cd[k][q];
+    }
+  }
+  if (t < 12) bfw_io[t] = pose[t];
+  if (t < 6) mu_out[t] = v6[t];
+}
+
+
 // ---- camera-per-rank pose refinement (BASELINE config c5): every rank holds the found points of its own
 // camera(s), the base pose is replicated.  One Gauss-Newton iteration of Tracker::TrackMap (src/Tracker.cc:1063-1075) =
 //   k_pr_project  : PoseUpdateStep / PoseUpdateStepLinear + the covariance-scaled errors; the rank's squared errors go, compacted,
