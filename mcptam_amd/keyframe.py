@@ -231,9 +231,9 @@ def track_search_batch(targets, cams, base_from_world, cams_from_base, points, r
     arrs = [p if isinstance(p, ctypes.Array) else pack_points(p, lambda kf: kf._h) for p in points]
     outs = [np.zeros(len(a), dtype=TD_OUT_DTYPE) for a in arrs]
     hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
-    cs = (type(cams[0].to_struct()) * n)(*[c.to_struct() for c in cams])
+    cs = cams if isinstance(cams, ctypes.Array) else (type(cams[0].to_struct()) * n)(*[c.to_struct() for c in cams])
     b = _pose12(*base_from_world)
-    cfb = np.ascontiguousarray(np.concatenate([_pose12(*c) for c in cams_from_base]))
+    cfb = np.ascontiguousarray(cams_from_base.reshape(-1)) if isinstance(cams_from_base, np.ndarray) else np.ascontiguousarray(np.concatenate([_pose12(*c) for c in cams_from_base]))
     ns = (ctypes.c_int * n)(*[len(a) for a in arrs])
     ins = (ctypes.c_void_p * n)(*[ctypes.cast(a, ctypes.c_void_p) for a in arrs])
     ops = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
@@ -345,11 +345,26 @@ def pose_points(world_pos, td_out, cam_index):
     return p
 
 
+def pose_points_frame(world_pos_per_cam, td_outs):
+    """pose_points of all cameras of a frame in one array (camera index = position in the lists)."""
+    n = [len(o) for o in td_outs]
+    p = np.zeros(sum(n), dtype=POSE_POINT_DTYPE)
+    o0 = 0
+    for c, (wp, o) in enumerate(zip(world_pos_per_cam, td_outs)):
+        q = p[o0:o0 + n[c]]
+        q["world_pos"] = wp
+        for f in ("found_pos", "sqrt_inv_noise", "image", "cam_derivs", "found"):
+            q[f] = o[f]
+        q["cam"] = c
+        o0 += n[c]
+    return p
+
+
 def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, structs):
     pts = np.ascontiguousarray(pts, dtype=POSE_POINT_DTYPE).copy()
     n, ncam, nit = len(pts), len(cams), len(nonlinear)
-    carr = (structs * ncam)(*[c.to_struct() for c in cams])
-    cfb = np.ascontiguousarray(np.stack([_pose12(*T) for T in cam_from_base]))
+    carr = cams if isinstance(cams, ctypes.Array) else (structs * ncam)(*[c.to_struct() for c in cams])      # (a caller with fixed cameras marshals them once: taylor_camera.camera_array)
+    cfb = cam_from_base if isinstance(cam_from_base, np.ndarray) and cam_from_base.ndim == 2 else np.ascontiguousarray(np.stack([_pose12(*T) for T in cam_from_base]))
     bfw = _pose12(*base_from_world).copy()
     nl = np.ascontiguousarray(nonlinear, dtype=np.uint8)
     ov = np.ascontiguousarray(override_sigma, dtype=np.float64)
