@@ -152,7 +152,8 @@ __device__ inline int knee_threshold(const int* hist, int w, int h) {
 //                half-sampled LDS -> LDS (the apron shrinks to the 3 pixels FAST needs at level 3; values in the aprons are
 //                recomputed by the neighbouring tiles, bit for bit the same integers), every level's interior is written
 //                out once, FAST-10 + its score run on the LDS tiles and leave one score byte per pixel (0 = no corner at the
-//                detection threshold) and the cumulative threshold histogram (integer atomics: order-free).
+//                detection threshold) and the per-score corner counts (integer atomics: order-free; k_row_count sums them into the cumulative
+//                threshold histogram).
 // k_row_count    threshold from the histogram knee (or the fixed one), kept corners per image row (one wavefront per row).
 // k_row_compact  exclusive prefix over the rows = vCornerRowLUT; the row's corners are written in x order at that offset, so
 //                vCorners comes out in raster order exactly as fast_corner_detect_10 + the filter loop produce it.
@@ -182,6 +183,8 @@ k_pyr_fast(const FrameBatch B) {
   __shared__ __attribute__((aligned(16))) uint8_t r3[(PYR_R/8)*(PYR_R/8) + 4];
   __shared__ int lh[MCP_LEVELS][32];
   __shared__ int ln[MCP_LEVELS];
+  __shared__ unsigned short queue[PYR_T*PYR_T];
+  __shared__ int qn;
   if (tid < MCP_LEVELS*32) (&lh[0][0])[tid] = 0;
   if (tid < MCP_LEVELS) ln[tid] = 0;
   // level 0: 112 rows of 28 words
@@ -226,24 +229,37 @@ k_pyr_fast(const FrameBatch B) {
     const uint8_t* R = reg[l];
     const bool write_img = l > 0 || C.src != C.img[0];
     const int b = B.detect_t[l];
+    // detection: every pixel; the corners (a few per cent) are queued by tile position and scored afterwards with all lanes busy --
+    // scoring inside this loop would make a whole wavefront pay for fast10_score whenever one of its 64 pixels is a corner
+    if (tid == 0) qn = 0;
+    __syncthreads();
     for (int i = tid; i < t*t; i += 256) {
       const int ly = i / t, lx = i % t, gx = gx0 + lx, gy = gy0 + ly;
       if (gx >= wl || gy >= hl) continue;
       const uint8_t* p = R + (a + ly)*n + a + lx;
       const int c = *p;
-      int sc = 0;
+      bool corner = false;
       if (gy >= 3 && gy < hl - 3 && gx >= 3 && gx < wl - 3) {
         int r[16]; fast_ring(p, n, r);
-        if (fast10_corner(r, c, b)) {
-          sc = fast10_score(r, c);
-          atomicAdd(&ln[l], 1);
-          if (B.adaptive) { const int top = min(sc, MCP_MAX_FAST_THRESH); for (int q = MCP_MIN_FAST_THRESH; q <= top; ++q) atomicAdd(&lh[l][q], 1); }
-        }
+        corner = fast10_corner(r, c, b);
       }
       const size_t g = (size_t)gy*wl + gx;
-      C.score[l][g] = (uint8_t)sc;
+      if (corner) queue[atomicAdd(&qn, 1)] = (unsigned short)i;      // (order is irrelevant: scores go to their pixel, the counts are sums)
+      else C.score[l][g] = 0;
       if (write_img) C.img[l][g] = (uint8_t)c;
     }
+    __syncthreads();
+    const int nq = qn;
+    for (int j = tid; j < nq; j += 256) {
+      const int i = queue[j], ly = i / t, lx = i % t;
+      const uint8_t* p = R + (a + ly)*n + a + lx;
+      int r[16]; fast_ring(p, n, r);
+      const int sc = fast10_score(r, *p);
+      C.score[l][(size_t)(gy0 + ly)*wl + gx0 + lx] = (uint8_t)sc;
+      if (B.adaptive) atomicAdd(&lh[l][min(sc, MCP_MAX_FAST_THRESH)], 1);       // raw count per (capped) score; k_row_count turns it into the cumulative vFastFrequency
+    }
+    if (tid == 0) ln[l] = nq;
+    __syncthreads();
   }
   __syncthreads();
   if (tid < MCP_LEVELS*32) { const int v = (&lh[0][0])[tid]; if (v) atomicAdd(&C.work[tid], v); }
@@ -262,12 +278,20 @@ k_row_count(const FrameBatch B) {
   const int wl = C.w >> l, hl = C.h >> l, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x*4 >= hl) return;
   __shared__ int th_s;
-  if (threadIdx.x == 0) th_s = B.adaptive ? knee_threshold(C.work + l*32, wl, hl) : B.detect_t[l];
+  __shared__ int cum[32];
+  // vFastFrequency[t] = corners whose score reaches t (KeyFrame.cc:264-275) = suffix sum of the raw counts per capped score
+  if (threadIdx.x < 32) {
+    int c = 0;
+    if ((int)threadIdx.x >= MCP_MIN_FAST_THRESH) for (int q = threadIdx.x; q <= MCP_MAX_FAST_THRESH; ++q) c += C.work[l*32 + q];
+    cum[threadIdx.x] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) th_s = B.adaptive ? knee_threshold(cum, wl, hl) : B.detect_t[l];
   __syncthreads();
   const int th = th_s;
   if (blockIdx.x == 0) {                        // the level's bookkeeping, completed by k_row_compact
     LevelInfo* I = C.info[l];
-    if (threadIdx.x < 32) I->hist[threadIdx.x] = C.work[l*32 + threadIdx.x];
+    if (threadIdx.x < 32) I->hist[threadIdx.x] = cum[threadIdx.x];
     if (threadIdx.x == 0) { I->thresh = th; I->n_all = C.work[MCP_LEVELS*32 + l]; I->n_cand = 0; }
   }
   const int y = blockIdx.x*4 + wave;
