@@ -584,8 +584,16 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
   ICK(hipMemcpyAsync(k0->bt_in.p, h.data(), sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
   Se3 Bw; std::memcpy(Bw.R, bfw, 72); std::memcpy(Bw.t, bfw + 9, 24);
   hipLaunchKernelGGL(k_track_search_batch, dim3(maxn, ncam), dim3(64), 0, st, (const SearchCam*)k0->stab.p, Bw, (const DevTdIn*)k0->bt_in.p, range, subpix_its, exhaustive, k0->bt_out.p);
-  for (int c = 0; c < ncam; ++c)
-    if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + tab[c].first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
+  // one copy when the caller's per-camera result arrays are the slices of one array (they are laid out like the device buffer)
+  bool contiguous = true;
+  { mcp_td_out* expect = nullptr;
+    for (int c = 0; c < ncam; ++c) { if (!n[c]) continue; if (expect && out[c] != expect) contiguous = false; expect = out[c] + n[c]; } }
+  if (contiguous) {
+    int c0 = 0; while (c0 < ncam && !n[c0]) ++c0;
+    ICK(hipMemcpyAsync(out[c0], k0->bt_out.p, sizeof(mcp_td_out)*(size_t)total, hipMemcpyDeviceToHost, st));
+  } else
+    for (int c = 0; c < ncam; ++c)
+      if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + tab[c].first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
   return 0;
 }

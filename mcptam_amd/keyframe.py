@@ -229,14 +229,17 @@ def track_search_batch(targets, cams, base_from_world, cams_from_base, points, r
     """SearchForPoints for all cameras of a frame in one launch; points[c]: list of point dicts or a packed ctypes array."""
     n = len(targets)
     arrs = [p if isinstance(p, ctypes.Array) else pack_points(p, lambda kf: kf._h) for p in points]
-    outs = [np.zeros(len(a), dtype=TD_OUT_DTYPE) for a in arrs]
+    lens = [len(a) for a in arrs]
+    whole = np.zeros(sum(lens), dtype=TD_OUT_DTYPE)              # one array, one device-to-host copy; the per-camera results are its slices
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(int)
+    outs = [whole[offs[c]:offs[c + 1]] for c in range(n)]
     hs = (ctypes.c_void_p * n)(*[t._h for t in targets])
     cs = cams if isinstance(cams, ctypes.Array) else (type(cams[0].to_struct()) * n)(*[c.to_struct() for c in cams])
     b = _pose12(*base_from_world)
     cfb = np.ascontiguousarray(cams_from_base.reshape(-1)) if isinstance(cams_from_base, np.ndarray) else np.ascontiguousarray(np.concatenate([_pose12(*c) for c in cams_from_base]))
     ns = (ctypes.c_int * n)(*[len(a) for a in arrs])
     ins = (ctypes.c_void_p * n)(*[ctypes.cast(a, ctypes.c_void_p) for a in arrs])
-    ops = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ops = (ctypes.c_void_p * n)(*[whole.ctypes.data + int(offs[c])*TD_OUT_DTYPE.itemsize for c in range(n)])
     _chk(lib().mcp_track_search_batch(n, hs, cs, _dp(b), _dp(cfb), ns, ins, int(rng), int(subpix_its), int(exhaustive), ops), "track_search_batch")
     return outs
 
