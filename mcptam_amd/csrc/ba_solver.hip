@@ -10,6 +10,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <cfloat>
 #include <chrono>
@@ -76,6 +77,28 @@ template <class T> struct DevBuf {
     return 0;
   }
 };
+
+// cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container often sees all of the
+// host's logical CPUs in hardware_concurrency() while being allowed a fraction of them)
+static int usable_cores() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set; CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n > 0 ? n : c, c); }
+  auto quota = [](const char* path, bool v2) -> double {
+    FILE* f = std::fopen(path, "r"); if (!f) return 0.0;
+    char a[64] = {0}, b[64] = {0}; double q = 0.0;
+    if (v2) { if (std::fscanf(f, "%63s %63s", a, b) == 2 && std::strcmp(a, "max") != 0 && std::atof(b) > 0) q = std::atof(a)/std::atof(b); }
+    else if (std::fscanf(f, "%63s", a) == 1 && std::atof(a) > 0) {
+      FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      if (g) { if (std::fscanf(g, "%63s", b) == 1 && std::atof(b) > 0) q = std::atof(a)/std::atof(b); std::fclose(g); }
+    }
+    std::fclose(f); return q;
+  };
+  double q = quota("/sys/fs/cgroup/cpu.max", true);
+  if (q <= 0.0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+  if (q > 0.0) n = std::min(n, std::max(1, (int)(q + 0.5)));
+  return std::max(n, 1);
+}
 
 struct HPose { int id; int fixed; double T[12]; int unk; int active; };
 struct HPoint { int id; int fixed; double x[3]; int chain; int unk; int active; };
@@ -435,7 +458,7 @@ int mcp_ba::prepare() {
   // vectors (slot and incidence indices relative to the range), then concatenated with the offsets fixed up: the result is
   // identical to a serial pass.
   struct Chunk { int sp0, sp1; std::vector<int> slot_unk, slot_inc, inc_unk, slot_cnt; std::vector<unsigned char> slot_first, inc_state; std::vector<int> sp_ninc; };
-  const int nthr = (nsp >= 4096) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+  const int nthr = (nsp >= 4096) ? std::max(1, std::min(16, usable_cores())) : 1;
   std::vector<Chunk> chunks(nthr);
   auto build_chunk = [&](Chunk& C) {
     C.slot_unk.reserve((size_t)(sp_m[C.sp1] - sp_m[C.sp0])*2); C.slot_inc.reserve(C.slot_unk.capacity()); C.slot_first.reserve(C.slot_unk.capacity());
@@ -450,6 +473,8 @@ int mcp_ba::prepare() {
       // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
       // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
       const int nm_pt = cnt[pt + 1] - cnt[pt];
+      // (the measurements of a point are scattered over the add-order array: fetch the next point's while this one is worked on)
+      if (sp + 1 < C.sp1) { const int pn = order[sp + 1]; for (int e = cnt[pn]; e < cnt[pn + 1]; ++e) __builtin_prefetch(&meas[by_point[e]], 0, 1); }
       int j = sp_m[sp];
       for (int kk = 0; kk < nm_pt; ++kk, ++j) {
         const int mi = by_point[cnt[pt] + (kk + sp) % nm_pt];
@@ -490,9 +515,11 @@ int mcp_ba::prepare() {
       chunks[t].sp0 = (t == 0) ? 0 : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m0) - sp_m.begin());
       chunks[t].sp1 = (t == nthr - 1) ? nsp : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m1) - sp_m.begin());
     }
+    lap("  by point, order");
     for (int t = 1; t < nthr; ++t) pool.emplace_back(build_chunk, std::ref(chunks[t]));
     build_chunk(chunks[0]);
     for (auto& th : pool) th.join();
+    lap("  slot threads");
   }
   {
     size_t tot_slot = 0, tot_inc = 0;
@@ -578,7 +605,9 @@ int mcp_ba::prepare() {
       if (d_red_tiles.upload(rt, st) || d_pack.alloc(MAX_SYS*((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np))) return -1;
       pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
     }
+    lap("  covisibility");
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
+    lap("  symbolic plan");
   } else plan.all_tiles.clear();
   // local pose indices of slots and incidences
   std::vector<unsigned char> slot_lp(nslot + 1, 0), inc_lp(ninc + 1, 0);
@@ -594,6 +623,7 @@ int mcp_ba::prepare() {
     }
   }
 
+  lap("  local indices");
   // ---- fixed-order assembly plan (ba_group.h): which local pose pairs every group stages, and for every global pose
   // pair / pose the list of staged slots in ascending group order
   std::vector<int> g_blk0(ngroup + 1, 0), pair_id((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1), pr_start, blk_dst, po_start(nfp + 1, 0),
