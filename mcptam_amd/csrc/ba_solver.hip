@@ -125,6 +125,7 @@ struct mcp_ba {
   std::vector<HPose> poses;
   std::vector<HPoint> points;
   std::vector<HMeas> meas;
+  std::vector<int> meas_point;      // meas[i].point, compact: the bucketing by point at Prepare() reads 4 bytes per measurement instead of 40
   std::vector<HChain> chains;
   std::map<std::array<int, 1 + MCP_MAX_CHAIN>, int> chain_map;
   std::vector<int> id_kind, id_index;   // by id; kind 1 pose, 2 point
@@ -396,11 +397,11 @@ int mcp_ba::prepare() {
   lap("activity");
   // ---- measurements by point (add order kept inside a point)
   std::vector<int> cnt(npoint + 1, 0);
-  for (const auto& m : meas) cnt[m.point + 1]++;
+  for (int i = 0; i < nmeas; ++i) cnt[meas_point[i] + 1]++;
   for (int i = 0; i < npoint; ++i) cnt[i + 1] += cnt[i];
   std::vector<int> by_point(nmeas);
   { std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-    for (int i = 0; i < nmeas; ++i) by_point[pos[meas[i].point]++] = i; }
+    for (int i = 0; i < nmeas; ++i) by_point[pos[meas_point[i]]++] = i; }
   // ---- point order: by the first free pose of the chain the point is expressed in
   std::vector<int> order;
   order.reserve(npoint);
@@ -1454,7 +1455,7 @@ int mcp_ba_add_meas(mcp_ba* h, const int* chain, int n, int point_id, const doub
   if (c < 0) { set_err("mcp_ba_add_meas: bad chain"); return -1; }
   HMeas m; m.chain = c; m.point = h->id_index[point_id]; m.cam = cam_index; m.u = uv[0]; m.v = uv[1];
   m.omega = 1/std::sqrt(sigma_sq);                    // information = I / sqrt(sigma^2), ChainBundle.cc:1244-1245
-  h->meas.push_back(m); h->dirty = true;
+  h->meas.push_back(m); h->meas_point.push_back(m.point); h->dirty = true;
   return 0;
 }
 int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, int stride, const int* chain_len,
@@ -1468,7 +1469,7 @@ int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, 
 }
 int mcp_ba_add_measurements(mcp_ba* h, int count, const int* chains, int stride, const int* chain_len, const int* point_ids,
                             const double* uv, const double* sigma_sq, const int* cam_index) {
-  h->meas.reserve(h->meas.size() + count);
+  h->meas.reserve(h->meas.size() + count); h->meas_point.reserve(h->meas_point.size() + count);
   for (int i = 0; i < count; ++i)
     if (mcp_ba_add_meas(h, chains + (size_t)stride*i, chain_len[i], point_ids[i], uv + 2*(size_t)i, sigma_sq[i], cam_index[i])) return -1;
   return 0;
