@@ -343,6 +343,15 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
     hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), (size_t)12*PRR_THREADS*PRR_PPT*sizeof(double), st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p);
   else
     hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p);
+#ifdef MCP_PRR_PROF
+  if (regs) {
+    ICK(hipStreamSynchronize(st));
+    unsigned long long pr[16*8]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prr_prof), sizeof pr);
+    for (int it = 0; it < n_iter && it < 16; ++it) { const unsigned long long* q = pr + 8*it;
+      fprintf(stderr, "[prr prof] it %d%s: points %llu  select %llu  accumulate+reduce %llu  solve %llu  barrier %llu  (cycles)\n", it, nonlinear[it] ? " (re-projection)" : "",
+              q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4]); }
+  }
+#endif
   double back[18];
   ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
   ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));

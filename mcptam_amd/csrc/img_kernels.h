@@ -1033,6 +1033,29 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 }
 
 
+// Sum of v[0..31] over the 64 lanes of a wavefront, entry by entry, as a reduce-scatter butterfly: on return lanes 2i and 2i + 1 hold
+// the total of entry idx = i (= lane >> 1).  At offset 32, 16, 8, 4, 2 a lane keeps the half of its entries its lane bit selects and
+// receives the partner's contribution to them (16 + 8 + 4 + 2 + 1 exchanges), the last exchange (offset 1) completes the sum.
+template <int N>
+__device__ inline void wave_rs_step(const double* in, double* out, int lane, int off) {
+  const bool up = (lane & off) != 0;
+#pragma unroll
+  for (int j = 0; j < N/2; ++j) {
+    const double keep = up ? in[j + N/2] : in[j], send = up ? in[j] : in[j + N/2];
+    out[j] = keep + __shfl_xor(send, off, 64);
+  }
+}
+__device__ inline double wave_reduce_scatter32(const double (&v)[32], int lane, int& idx) {
+  double a16[16], a8[8], a4[4], a2[2], a1[1];
+  wave_rs_step<32>(v, a16, lane, 32);
+  wave_rs_step<16>(a16, a8, lane, 16);
+  wave_rs_step<8>(a8, a4, lane, 8);
+  wave_rs_step<4>(a4, a2, lane, 4);
+  wave_rs_step<2>(a2, a1, lane, 2);
+  idx = (lane >> 1) & 31;
+  return a1[0] + __shfl_xor(a1[0], 1, 64);
+}
+
 // ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
 // One workgroup of 256 threads = one wavefront per SIMD, so a thread may keep 512 registers: its four points' found position,
 // noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips
@@ -1040,17 +1063,25 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 // the Tukey median selected from the register-held squared errors.  Same arithmetic per point as k_pose_refine; the order of the
 // 27 sums differs (4 points per thread, 4 wavefronts), i.e. results agree to rounding, the median exactly.
 constexpr int PRR_THREADS = 256, PRR_PPT = 4;
+#ifdef MCP_PRR_PROF
+__device__ unsigned long long g_prr_prof[16*8];
+#define PRR_STAMP(i) do { if (threadIdx.x == 0 && it < 16) g_prr_prof[it*8 + (i)] = clock64(); } while (0)
+#else
+#define PRR_STAMP(i) do {} while (0)
+#endif
 __global__ void __launch_bounds__(PRR_THREADS)
 k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
                    double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
                    double* __restrict__ mu_out, double* __restrict__ w_out) {
   constexpr int NT = PRR_THREADS, NW = NT/64, BPT = SEL_BINS/NT;
   __shared__ unsigned int hist[SEL_BINS];
-  __shared__ unsigned long long sc[NW + 3], sst[2];
+  __shared__ unsigned int wtot[NW], sres[3];
+  __shared__ unsigned long long skey;
   __shared__ double red[NW][28];
   __shared__ double pose[12], v6[6], tot[27];
   __shared__ int nf_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;          // every digit pass leaves it zero again
   bool fnd[PRR_PPT]; int camk[PRR_PPT];
   double fpos[PRR_PPT][2], sinv[PRR_PPT], img[PRR_PPT][2], cd[PRR_PPT][4], ex[PRR_PPT][2], e2[PRR_PPT];
   extern __shared__ double Jl[];                 // [12][NT*PPT]: a point's 2x6 Jacobian, one column of 12 per point (lane-consecutive: no bank conflicts)
@@ -1085,6 +1116,7 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
   for (int it = 0; it < n_iter; ++it) {
     if (nf == 0) { if (t < 6) v6[t] = 0.0; __syncthreads(); continue; }           // no valid measurements: null update
     const bool nl = nonlinear[it] != 0;
+    PRR_STAMP(0);
 #pragma unroll
     for (int k = 0; k < PRR_PPT; ++k) {
       if (!fnd[k]) continue;
@@ -1113,57 +1145,61 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
       ex[k][0] = sinv[k]*(fpos[k][0] - img[k][0]); ex[k][1] = sinv[k]*(fpos[k][1] - img[k][1]);
       e2[k] = ex[k][0]*ex[k][0] + ex[k][1]*ex[k][1];
     }
+    PRR_STAMP(1);
     double s2 = override_sigma[it];
     if (!(s2 > 0)) {
-      // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select over the register-held keys
+      // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select over the register-held keys.
+      // Three barriers per digit: the histogram's owner threads read and clear their bins in one go (it is zero again for the
+      // next digit), counts are scanned in 32 bits, prefix and rank travel in registers.
       unsigned long long key[PRR_PPT];
 #pragma unroll
       for (int k = 0; k < PRR_PPT; ++k) key[k] = (unsigned long long)__double_as_longlong(fabs(e2[k]));
-      if (t == 0) { sst[0] = 0ull; sst[1] = (unsigned long long)(nf/2); }
-      __syncthreads();
+      unsigned long long prefix = 0ull; unsigned int kk = (unsigned int)(nf/2);
       for (int pass = 0; pass < SEL_PASSES; ++pass) {
         const int sh = sel_shift(pass);
         const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
         const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
-        for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;
-        __syncthreads();
-        const unsigned long long prefix = sst[0];
 #pragma unroll
         for (int k = 0; k < PRR_PPT; ++k) if (fnd[k] && (key[k] & himask) == prefix) atomicAdd(&hist[(unsigned int)(key[k] >> sh) & dmask], 1u);
         __syncthreads();
-        unsigned int hb[BPT]; unsigned long long loc = 0;
+        unsigned int hb[BPT], loc = 0;
 #pragma unroll
-        for (int b = 0; b < BPT; ++b) { hb[b] = hist[BPT*t + b]; loc += hb[b]; }
-        int tt; unsigned long long acc;
-        block_find_rank<NT>(loc, sst[1], tt, acc, sc);
-        if (t == tt) {
-          const unsigned long long kk = sst[1];
-          int b = 0;
+        for (int b = 0; b < BPT; ++b) { hb[b] = hist[BPT*t + b]; hist[BPT*t + b] = 0u; loc += hb[b]; }
+        unsigned int inc = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        unsigned int base = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) if (w < wave) base += wtot[w];
+        const unsigned int incl = base + inc, excl = incl - loc;
+        if (excl <= kk && kk < incl) {
+          unsigned int acc = excl; int b = 0;
 #pragma unroll
           for (int q = 0; q < BPT - 1; ++q) if (b == q && !(acc + hb[q] > kk)) { acc += hb[q]; b = q + 1; }
-          sc[0] = (unsigned long long)(BPT*t + b); sc[1] = kk - acc; sc[2] = hb[0];
+          unsigned int inb = hb[0];
 #pragma unroll
-          for (int q = 1; q < BPT; ++q) if (b == q) sc[2] = hb[q];
+          for (int q = 1; q < BPT; ++q) if (b == q) inb = hb[q];
+          sres[0] = (unsigned int)(BPT*t + b); sres[1] = kk - acc; sres[2] = inb;
         }
         __syncthreads();
-        const unsigned long long np_ = prefix | (sc[0] << sh);
-        const unsigned long long kin = sc[1]; const unsigned int in_bin = (unsigned int)sc[2];
-        __syncthreads();
-        if (in_bin == 1u && sh > 0) {                 // one candidate left: it is the element
+        prefix |= (unsigned long long)sres[0] << sh; kk = sres[1];
+        if (sres[2] == 1u && sh > 0) {                 // one candidate left: it is the element
           const unsigned long long hm2 = ~0ull << sh;
 #pragma unroll
-          for (int k = 0; k < PRR_PPT; ++k) if (fnd[k] && (key[k] & hm2) == np_) sst[0] = key[k];
+          for (int k = 0; k < PRR_PPT; ++k) if (fnd[k] && (key[k] & hm2) == prefix) skey = key[k];
           __syncthreads();
+          prefix = skey;
           break;
         }
-        if (t == 0) { sst[0] = np_; sst[1] = kin; }
-        __syncthreads();
       }
-      const double med = __longlong_as_double((long long)sst[0]);
+      const double med = __longlong_as_double((long long)prefix);
       double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
       sg = 4.6851*sg;
       s2 = sg*sg;
     }
+    PRR_STAMP(2);
     // weighted normal equations: 21 + 6 partial sums per thread
     double a[27];
 #pragma unroll
@@ -1192,15 +1228,19 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
         }
       }
     }
+    {
+      // the 27 sums over the wavefront as a reduce-scatter: at every butterfly step a lane hands half of its entries to its partner
+      // and adds the partner's half of the entries it keeps -- 16 + 8 + 4 + 2 + 1 + 1 exchanges instead of 27 x 6, in a fixed tree
+      double w32[32];
 #pragma unroll
-    for (int q = 0; q < 27; ++q) { double v = a[q]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[q] = v; }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 27; ++q) red[wave][q] = a[q];
+      for (int q = 0; q < 32; ++q) w32[q] = q < 27 ? a[q] : 0.0;
+      int idx; const double total = wave_reduce_scatter32(w32, lane, idx);
+      if (!(lane & 1) && idx < 27) red[wave][idx] = total;
     }
     __syncthreads();
     if (t < 27) { double sum = 0.0; for (int wv = 0; wv < NW; ++wv) sum += red[wv][t]; tot[t] = sum; }
     __syncthreads();
+    PRR_STAMP(3);
     if (t == 0) {
       double C[36], v[6], mu[6], rd[6];
       int q = 0;
@@ -1232,7 +1272,9 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
       pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
       for (int k = 0; k < 6; ++k) v6[k] = mu[k];
     }
+    PRR_STAMP(4);
     __syncthreads();
+    PRR_STAMP(5);
   }
 #pragma unroll
   for (int k = 0; k < PRR_PPT; ++k) {
