@@ -231,4 +231,27 @@ __host__ __device__ inline void point_oplus(const double* x, const double* u, do
   out[0] = o0; out[1] = o1; out[2] = o2;
 }
 
+// Sum of v[0..31] over the 64 lanes of a wavefront, entry by entry, as a reduce-scatter butterfly: on return lanes 2i and 2i + 1 hold
+// the total of entry idx = i (= lane >> 1).  At offset 32, 16, 8, 4, 2 a lane keeps the half of its entries its lane bit selects and
+// receives the partner's contribution to them (16 + 8 + 4 + 2 + 1 exchanges), the last exchange (offset 1) completes the sum.
+template <int N>
+__device__ inline void wave_rs_step(const double* in, double* out, int lane, int off) {
+  const bool up = (lane & off) != 0;
+#pragma unroll
+  for (int j = 0; j < N/2; ++j) {
+    const double keep = up ? in[j + N/2] : in[j], send = up ? in[j] : in[j + N/2];
+    out[j] = keep + __shfl_xor(send, off, 64);
+  }
+}
+__device__ inline double wave_reduce_scatter32(const double (&v)[32], int lane, int& idx) {
+  double a16[16], a8[8], a4[4], a2[2], a1[1];
+  wave_rs_step<32>(v, a16, lane, 32);
+  wave_rs_step<16>(a16, a8, lane, 16);
+  wave_rs_step<8>(a8, a4, lane, 8);
+  wave_rs_step<4>(a4, a2, lane, 4);
+  wave_rs_step<2>(a2, a1, lane, 2);
+  idx = (lane >> 1) & 31;
+  return a1[0] + __shfl_xor(a1[0], 1, 64);
+}
+
 }  // namespace mcp

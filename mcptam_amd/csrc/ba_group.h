@@ -298,26 +298,22 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     const int leader = __ffsll((long long)todo) - 1;
     const int key = __shfl(ls, leader, 64);
     const bool mine = (ls == key);
-    double vals[27];
+    // reduce-scatter over the wavefront (ba_device.h): 32 lane exchanges instead of 27 x 6, and the 27 totals land in 27 different
+    // lanes, each of which adds its own entry to the tile
+    double w32[32];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) vals[i] = mine ? Uss[i] : 0.0;
+    for (int i = 0; i < 21; ++i) w32[i] = mine ? Uss[i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) vals[21 + i] = mine ? bs[i] : 0.0;
+    for (int i = 0; i < 6; ++i) w32[21 + i] = mine ? bs[i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 27; ++i) {
-      double v = vals[i];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      vals[i] = v;
-    }
-    if (lane == leader) {
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) { Sc[36*(int)pslot[17*key] + 6*r + c] += vals[q]; ++q; }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) bl[6*key + r] += vals[21 + r];
+    for (int i = 27; i < 32; ++i) w32[i] = 0.0;
+    int idx; const double total = wave_reduce_scatter32(w32, lane, idx);
+    if (!(lane & 1) && idx < 27) {
+      if (idx < 21) {
+        int r = 0; while ((r + 1)*(r + 2)/2 <= idx) ++r;
+        const int c = idx - r*(r + 1)/2;
+        Sc[36*(int)pslot[17*key] + 6*r + c] += total;
+      } else bl[6*key + idx - 21] += total;
     }
     todo &= ~__ballot(mine);
     __syncthreads();

@@ -1033,29 +1033,6 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 }
 
 
-// Sum of v[0..31] over the 64 lanes of a wavefront, entry by entry, as a reduce-scatter butterfly: on return lanes 2i and 2i + 1 hold
-// the total of entry idx = i (= lane >> 1).  At offset 32, 16, 8, 4, 2 a lane keeps the half of its entries its lane bit selects and
-// receives the partner's contribution to them (16 + 8 + 4 + 2 + 1 exchanges), the last exchange (offset 1) completes the sum.
-template <int N>
-__device__ inline void wave_rs_step(const double* in, double* out, int lane, int off) {
-  const bool up = (lane & off) != 0;
-#pragma unroll
-  for (int j = 0; j < N/2; ++j) {
-    const double keep = up ? in[j + N/2] : in[j], send = up ? in[j] : in[j + N/2];
-    out[j] = keep + __shfl_xor(send, off, 64);
-  }
-}
-__device__ inline double wave_reduce_scatter32(const double (&v)[32], int lane, int& idx) {
-  double a16[16], a8[8], a4[4], a2[2], a1[1];
-  wave_rs_step<32>(v, a16, lane, 32);
-  wave_rs_step<16>(a16, a8, lane, 16);
-  wave_rs_step<8>(a8, a4, lane, 8);
-  wave_rs_step<4>(a4, a2, lane, 4);
-  wave_rs_step<2>(a2, a1, lane, 2);
-  idx = (lane >> 1) & 31;
-  return a1[0] + __shfl_xor(a1[0], 1, 64);
-}
-
 // ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
 // One workgroup of 256 threads = one wavefront per SIMD, so a thread may keep 512 registers: its four points' found position,
 // noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips
