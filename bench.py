@@ -242,9 +242,11 @@ def main():
 
     # warmup: W untimed LM iterations (code objects, allocations, clocks) on a second handle, run AFTER the timed handle has been
     # populated and prepared (60 ms of host work during which the device would idle and clock down) and right before the timed region
+    PREWARM = 40     # untimed iterations before the W warm-up ones: brings the device clocks up after an idle or profiled period
     bw = fresh() if args.warmup > 0 else None
     b = fresh()
     if bw is not None:
+        bw.Compute(PREWARM)
         bw.Compute(args.warmup)
         bw.close()
     barrier()
@@ -275,6 +277,7 @@ def main():
                 args.config, len(problem.cams), problem.n_mkf, problem.n_points, problem.n_meas),
                 "trials_per_iteration": trials / args.steps, "trial_solves_per_s": world * trials / dt, "parallelism": "points sharded x%d, poses replicated" % world, "allreduce_transport": transport,
                 "chi2_first": chi_first, "chi2_last": chi_last,
+                "device_prewarm_iterations": PREWARM if args.warmup > 0 else 0,      # untimed, on a separate handle, before the W warm-up iterations
                 "setup_outside_timed_region": dict(setup_ms, note="once per BundleAdjust call: C-ABI replay of the map (populate) and "
                                                    "host structure build + PCIe upload (prepare); not part of `value`")},
         }
