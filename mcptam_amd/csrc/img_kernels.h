@@ -985,11 +985,12 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
         }
       }
     }
+    {
+      double w32[32];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) { double v = a[k]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[k] = v; }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 27; ++k) red[wave][k] = a[k];
+      for (int k = 0; k < 32; ++k) w32[k] = k < 27 ? a[k] : 0.0;
+      int idx; const double total = wave_reduce_scatter32(w32, lane, idx);          // ba_device.h: 32 lane exchanges instead of 27 x 6
+      if (!(lane & 1) && idx < 27) red[wave][idx] = total;
     }
     __syncthreads();
     if (t < 27) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][t]; tot[t] = sum; }      // the wavefronts' partials in wavefront order
@@ -1366,11 +1367,12 @@ k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restri
       }
     }
   }
+  {
+    double w32[32];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) { double v = a[k]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); a[k] = v; }
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) red[wave][k] = a[k];
+    for (int k = 0; k < 32; ++k) w32[k] = k < 27 ? a[k] : 0.0;
+    int idx; const double total = wave_reduce_scatter32(w32, lane, idx);
+    if (!(lane & 1) && idx < 27) red[wave][idx] = total;
   }
   __syncthreads();
   if (t < 27) { double sum = 0.0; for (int wv = 0; wv < 16; ++wv) sum += red[wv][t]; out27[t] = sum; }
