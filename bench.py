@@ -257,6 +257,7 @@ def main():
     if rc != args.steps:
         raise SystemExit("bench: Compute ran %d of %d iterations (%s)" % (rc, args.steps, chain_bundle.last_error()))
     logs = b.IterLogs()
+    tm_run = b.Timing()
     trials = sum(l["trials"] for l in logs)
     chi_first, chi_last = logs[0]["chi2_start"], logs[-1]["chi2_end"]
     b.close()
@@ -281,6 +282,13 @@ def main():
                 "setup_outside_timed_region": dict(setup_ms, note="once per BundleAdjust call: C-ABI replay of the map (populate) and "
                                                    "host structure build + PCIe upload (prepare); not part of `value`")},
         }
+        if world > 1:
+            # what the LM loop put on the wire, per iteration (the first iteration's extras and the final statistics included):
+            # main lane = the collectives the trial path waits for, speculative lane = beside it on the second stream
+            result["config"]["collectives_per_iteration"] = {
+                "main_lane": tm_run["n_collectives_main"] / args.steps, "speculative_lane": tm_run["n_collectives_spec"] / args.steps,
+                "main_lane_bytes": tm_run["collective_bytes_main"] / args.steps, "speculative_lane_bytes": tm_run["collective_bytes_spec"] / args.steps,
+                "one_collective_medians": tm_run["n_median_fast"], "reduced_system_solves": tm_run["n_solves"]}
         if args.debug_single_device:
             result["config"]["debug"] = "all ranks share GPU 0, gloo transport: code-path check only, not a measurement"
     # per-stage HIP-event timing of the same run shape (separate pass so the events do not perturb `value`)

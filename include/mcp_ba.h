@@ -88,6 +88,11 @@ typedef struct mcp_ba_timing {
   int    n_linearize, n_trials;
   int    n_solves;        /* reduced systems built + factored (a solve may carry a second, speculative lambda) */
   int    n_spec_hits;     /* trials served by such a speculative solve */
+  /* several ranks: collectives enqueued by this compute() per lane (main stream / speculative stream) and their payload */
+  int    n_collectives_main, n_collectives_spec;
+  double collective_bytes_main, collective_bytes_spec;
+  int    n_median_fast;   /* medians that needed one collective (digit histograms rode on the accepted trial's all-reduce) */
+  int    pad_;
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);
@@ -167,8 +172,10 @@ int       mcp_comm_unique_id(void* id_out);
 mcp_comm* mcp_comm_init(const void* id, int rank, int world_size, int device);
 void      mcp_comm_destroy(mcp_comm*);
 int       mcp_ba_set_comm(mcp_ba*, mcp_comm*);
-/* SUM all-reduce of `count` doubles at a device pointer on the communicator (test hook) */
+/* SUM all-reduce of `count` doubles at a device pointer on the communicator (test hook); _lane: 0 = the main stream's
+ * RCCL communicator, 1 = the speculative stream's (split off the first at init) */
 int       mcp_comm_allreduce(mcp_comm*, void* device_buf, size_t count);
+int       mcp_comm_allreduce_lane(mcp_comm*, void* device_buf, size_t count, int lane);
 
 /* ---- introspection used by the parity tests (no reference counterpart) ---- */
 /* structure build + upload without solving; returns the number of unknowns 6P+3N */

@@ -39,7 +39,10 @@ class McpBaTiming(ctypes.Structure):
                 ("select_ms", ctypes.c_double), ("linearize_ms", ctypes.c_double), ("schur_ms", ctypes.c_double),
                 ("cholesky_ms", ctypes.c_double), ("solve_ms", ctypes.c_double), ("update_ms", ctypes.c_double),
                 ("n_linearize", ctypes.c_int), ("n_trials", ctypes.c_int), ("n_solves", ctypes.c_int),
-                ("n_spec_hits", ctypes.c_int)]
+                ("n_spec_hits", ctypes.c_int),
+                ("n_collectives_main", ctypes.c_int), ("n_collectives_spec", ctypes.c_int),
+                ("collective_bytes_main", ctypes.c_double), ("collective_bytes_spec", ctypes.c_double),
+                ("n_median_fast", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -53,7 +56,7 @@ BA_SYMBOLS = [
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
     "mcp_dense_spd_stress", "mcp_ba_debug_system",
-    "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce",
+    "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce", "mcp_comm_allreduce_lane",
 ]
 
 
@@ -101,6 +104,7 @@ def lib():
     L.mcp_comm_destroy.argtypes = [ctypes.c_void_p]
     L.mcp_ba_set_comm.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.mcp_comm_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.mcp_comm_allreduce_lane.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     _LIB = L
     return L
 
@@ -142,8 +146,9 @@ class Comm:
             raise RuntimeError("mcp_comm_init failed: " + last_error())
         self.rank, self.world_size = rank, world_size
 
-    def allreduce(self, device_ptr, count):
-        if self._L.mcp_comm_allreduce(self._h, ctypes.c_void_p(device_ptr), int(count)) != 0:
+    def allreduce(self, device_ptr, count, lane=0):
+        """lane 0: the RCCL communicator of the solver's main stream, 1: the speculative stream's (ncclCommSplit of lane 0)"""
+        if self._L.mcp_comm_allreduce_lane(self._h, ctypes.c_void_p(device_ptr), int(count), int(lane)) != 0:
             raise RuntimeError("mcp_comm_allreduce failed: " + last_error())
 
     def close(self):

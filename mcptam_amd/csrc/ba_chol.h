@@ -44,8 +44,34 @@ constexpr int CH_STEP_THREADS = 256;    // 4 wavefronts load and multiply; wavef
 // 32x32 tile (rows r0.., cols c0..) -> 4 registers per thread (zero outside [nrows) x [ncols)); issuing the
 // global loads of ALL tiles of a step before the first LDS write keeps them in flight together (one memory
 // round trip per step instead of one per tile)
+typedef double chol_d2 __attribute__((ext_vector_type(2)));
+// CH_LOAD16: a thread fetches two neighbouring columns with one 16-byte load (rows 16 i + (t >> 4), columns 2 (t & 15) ..):
+// half the memory requests per tile; needs an even leading dimension (n = 6 P always is; odd n -- test matrices -- takes the 8-byte form)
+#ifndef CH_LOAD16
+#define CH_LOAD16 0
+#endif
+#ifndef CH_STORE16       // trailing tiles written back as 16-byte column pairs
+#define CH_STORE16 0
+#endif
+#ifndef CH_PSTORE16      // panel rows leave through LDS as 16-byte column pairs
+#define CH_PSTORE16 0
+#endif
 __device__ inline void chol_load_tile_regs(const double* __restrict__ A, int ld, int nrows, int ncols, int r0, int c0, double* v) {
   const int t = threadIdx.x;
+  if (CH_LOAD16 && !(ld & 1)) {
+    const int c = (t & 15)*2, rb = t >> 4;      // rb 0..15
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 16*i + rb;
+      chol_d2 x = {0.0, 0.0};
+      if (r0 + r < nrows) {
+        if (c0 + c + 1 < ncols) x = *reinterpret_cast<const chol_d2*>(A + (size_t)(r0 + r)*ld + c0 + c);
+        else if (c0 + c < ncols) x[0] = A[(size_t)(r0 + r)*ld + c0 + c];
+      }
+      v[2*i] = x[0]; v[2*i + 1] = x[1];
+    }
+    return;
+  }
   const int c = t & 31, rb = t >> 5;          // rb 0..7
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -53,8 +79,14 @@ __device__ inline void chol_load_tile_regs(const double* __restrict__ A, int ld,
     v[i] = (r0 + r < nrows && c0 + c < ncols) ? A[(size_t)(r0 + r)*ld + c0 + c] : 0.0;
   }
 }
-__device__ inline void chol_regs_to_lds(const double* v, double (*T)[CH_NB + 1]) {
+__device__ inline void chol_regs_to_lds(const double* v, double (*T)[CH_NB + 1], int ld) {
   const int t = threadIdx.x;
+  if (CH_LOAD16 && !(ld & 1)) {
+    const int c = (t & 15)*2, rb = t >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { T[16*i + rb][c] = v[2*i]; T[16*i + rb][c + 1] = v[2*i + 1]; }
+    return;
+  }
   const int c = t & 31, rb = t >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) T[8*i + rb][c] = v[i];
@@ -198,9 +230,9 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
       chol_load_tile_regs(S, n, nrows, n, k0, k0, vd);
       if (k > 0) chol_load_tile_regs(S, n, nrows, n, k0, p0, ve);
     }
-    chol_regs_to_lds(vc, Tc);
-    if (k > 0) { chol_regs_to_lds(va, Ta); chol_regs_to_lds(vb, Tb); }
-    if (panel && offdiag) { chol_regs_to_lds(vd, Td); if (k > 0) chol_regs_to_lds(ve, Te); }
+    chol_regs_to_lds(vc, Tc, n);
+    if (k > 0) { chol_regs_to_lds(va, Ta, n); chol_regs_to_lds(vb, Tb, n); }
+    if (panel && offdiag) { chol_regs_to_lds(vd, Td, n); if (k > 0) chol_regs_to_lds(ve, Te, n); }
   }
   __syncthreads();
   CHOL_STAMP(1);
@@ -212,6 +244,15 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   __syncthreads();
   CHOL_STAMP(2);
   if (!panel) {      // plain trailing tile: write back and leave
+    if (CH_STORE16 && !(n & 1) && ti > tj) {      // off-diagonal tile, even n: whole 16-byte column pairs (c0 + c + 1 < n because n is even)
+      const int c = (lane & 15)*2, rb = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = 16*i + rb;
+        if (r0 + r < nrows && c0 + c < n) { chol_d2 x = {Tc[r][c], Tc[r][c + 1]}; *reinterpret_cast<chol_d2*>(S + (size_t)(r0 + r)*n + c0 + c) = x; }
+      }
+      return;
+    }
     const int c = lane & 31, rb = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -249,6 +290,27 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   chol_panel_pivots(d, inv, bad, &Ta[0][0], std::make_integer_sequence<int, CH_NB>());     // Ta is free now: column buffer
   CHOL_STAMP(3);
   if (bad && lane == 0) atomicOr(fail, 2);
+  if (CH_PSTORE16 && !(n & 1)) {
+    // even n: the 32 result rows leave through LDS (row per lane in, 16-byte column pairs out: a store instruction then covers
+    // four whole rows of the tile instead of one double in each of 64 rows).  Single wavefront: its LDS accesses execute in order.
+    if (low) {
+#pragma unroll
+      for (int c = 0; c < CH_NB; ++c) Tc[rr][c] = d[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = i*64 + lane, r = e >> 4, c = (e & 15)*2;
+      if (c >= nbe) continue;                                     // nbe is even
+      double* dst;
+      if (!offdiag && r < nbe) dst = Dg + (size_t)k*(CH_NB*CH_NB) + r*CH_NB + c;           // row r of L_kk^-T (entries left of the diagonal are never read)
+      else if (r0 + r < nrows && (offdiag || r >= nbe)) dst = S + (size_t)(r0 + r)*n + k0 + c;
+      else continue;
+      const chol_d2 x = {Tc[r][c], Tc[r][c + 1]};
+      *reinterpret_cast<chol_d2*>(dst) = x;
+    }
+    CHOL_STAMP(4);
+    return;
+  }
   if (!low) {
     // (L_kk itself is not stored: the forward substitution rides on the factorisation as the augmented row, the backward
     // one uses the inverse below; the other tiles of block column k already hold X = C L_kk^-T)

@@ -206,7 +206,8 @@ k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* _
 constexpr int MAIL_TICKET = 31;
 __global__ void __launch_bounds__(256)
 k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
-             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0) {
+             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0,
+             const double* ride_src = nullptr, int ride_dst = 0 /* out[ride_dst] = ride_src[0]: a value of an earlier kernel joins this block's all-reduce */) {
   __shared__ double lds[4];
   const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
   for (int a = 0; a < 3; ++a) {
@@ -217,6 +218,7 @@ k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const d
     if (threadIdx.x == 0) out[off + a] = t;
   }
   if (fail && threadIdx.x == 0) out[off + 3] = (fail[0] != 0) ? 1.0 : 0.0;
+  if (ride_src && threadIdx.x == 0) out[ride_dst] = ride_src[0];
   if (mail) {
     __syncthreads();                                 // thread 0's stores to `out` above; the other entries come from earlier kernels of the stream
     for (int i = threadIdx.x; i < mail_count; i += 256) mail[i] = out[i];

@@ -28,6 +28,7 @@
 #include "ba_chol.h"
 #include "ba_group.h"
 #include "ba_comm.h"
+#include "ba_trial.h"
 
 using namespace mcp;
 
@@ -182,6 +183,11 @@ struct mcp_ba {
   int sel_cap = 4096;           // candidates per rank slot (MCP_BA_SELECT_CAP)
   DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
+  // The sigma block is double-buffered by median: a trial evaluated ahead on the speculative stream that nobody consumes may
+  // still be reading its iteration's block when the next iteration's median writes the new one (the two streams only meet
+  // again in linearize()'s join_spec()); the block after that is written behind that join.
+  int sig_par = 0;
+  double* sig() { return d_sigma.p + 8*sig_par; }
   DevBuf<SelState> d_selstate;
   DevBuf<int> d_fail;
   double* h_res = nullptr;  // pinned, device-visible; [32..63] is the mailbox k_final_sums writes (ticket at 32 + MAIL_TICKET)
@@ -200,7 +206,23 @@ struct mcp_ba {
   // multi-rank
   mcp_allreduce_fn hook = nullptr; void* hook_user = nullptr; int rank = 0, world = 1;
   mcp_comm* comm = nullptr;        // native RCCL transport (takes precedence over the hook)
-  bool multi() const { return world > 1 && (hook || comm); }
+  // MCP_BA_FORCE_MULTI=1: a one-rank communicator / hook is driven through the whole multi-rank machine (packed tiles, per-lane
+  // collectives, riding histograms) -- sums over one rank are exact, so the result must equal the plain single-rank solve bit for
+  // bit; the GPU suite uses it to run the two-lane RCCL path on the one device a test box has
+  int force_multi = 0;
+  bool multi() const { return (world > 1 || force_multi) && (hook || comm); }
+  // every host-side wait of the solve is bounded (MCP_BA_TIMEOUT_MS, default 60 s): a rank that dies inside a collective leaves the
+  // others waiting on a kernel that never ends, which must surface as MCP_ERR_RUNTIME with the place, not as a hang
+  double timeout_ms = 60000.0;
+  unsigned long long coll_seq[2] = {0, 0}; const char* coll_what[2] = {"none", "none"};
+  int watchdog_fail(const char* where);
+  int wait_stream(hipStream_t s, const char* what);
+  // trial buffers of the multi-rank tail (ba_trial.h) and the selection state k_trial_post leaves in them
+  DevBuf<double> d_trial[MAX_SYS]; DevBuf<SelState> d_trstate[MAX_SYS];
+  int sel_ride = 1;                // MCP_BA_SELECT_RIDE=0: the median never uses the histograms that rode on the trial's all-reduce
+  int pred_bin = -1;               // first digit of the last median the host has seen (the prediction the trials histogram around)
+  int tr_pred_ok[MAX_SYS] = {0, 0, 0, 0}, tr_ovf[MAX_SYS] = {0, 0, 0, 0};
+  int sel_src = -1;                // trial buffer whose histograms belong to the current state's chi2 (the accepted trial), or -1
 
   // profiling
   struct Ev { int stage; hipEvent_t a, b; };
@@ -304,19 +326,23 @@ struct mcp_ba {
     return true;
   }
 
-  // SUM all-reduce of `count` doubles at `buf` over the ranks.  host_sync: the caller reads the result with a
-  // blocking copy next, so the stream-ordered RCCL path has to drain the stream first.
-  int allreduce(double* buf, size_t count, bool host_sync = false) {
-    if (world <= 1) return 0;
+  // SUM all-reduce of `count` doubles at `buf` over the ranks, on lane 0 (main stream) or 1 (speculative stream).
+  // host_sync: the caller reads the result with a blocking copy next, so the stream-ordered RCCL path has to drain the stream first.
+  int allreduce(double* buf, size_t count, int lane = 0, bool host_sync = false, const char* what = "all-reduce") {
+    if (!multi()) return 0;
+    hipStream_t s = lane ? st2 : st;
+    ++coll_seq[lane]; coll_what[lane] = what;
+    if (lane) { timing.n_collectives_spec++; timing.collective_bytes_spec += 8.0*(double)count; }
+    else { timing.n_collectives_main++; timing.collective_bytes_main += 8.0*(double)count; }
     if (comm) {
-      const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, comm->comm, st);
+      if (comm->dead) { set_err("communicator was aborted by an earlier time-out"); return -1; }
+      const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, comm->lane(lane), s);
       if (rc != 0) { set_err(std::string("ncclAllReduce failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?")); return -1; }
-      if (host_sync) HIPCK(hipStreamSynchronize(st));
+      if (host_sync) return wait_stream(s, what);
       return 0;
     }
-    if (!hook) return 0;
-    HIPCK(hipStreamSynchronize(st));
-    if (hook(hook_user, buf, count, (void*)st) != 0) { set_err("all-reduce hook failed"); return -1; }
+    if (wait_stream(s, what)) return -1;
+    if (hook(hook_user, buf, count, (void*)s) != 0) { set_err(std::string("all-reduce hook failed (") + what + ")"); return -1; }
     return 0;
   }
 
@@ -326,10 +352,13 @@ struct mcp_ba {
   void launch_chains(int which);
   void launch_eval(int which, bool sum, double* err_out);
   int select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma = false);
+  int select_gather_finish(const double* x, int n, const double* hist, SelState* state, double* out_dev, bool check_overflow);
   int median_sigma(int which);
   int read_results(int count);
   int wait_mail(int q, unsigned long long ticket, int count);
   int enqueue_spec_trial(hipStream_t s, int q);
+  int multi_trial_tail(hipStream_t s, int lane, int q, int slot, int nbe, const double* p0, int nbb, const double* p1, const double* p2,
+                       const double* pose_parts, int pose_off, bool main_block, double* mail, int mail_count, unsigned long long ticket);
   int cancel_spec_trials();
   int run_ahead(int q);
   unsigned long long mail_ticket0 = 0;
@@ -359,6 +388,34 @@ struct mcp_ba {
 };
 
 // ------------------------------------------------------------------------------------------
+// a wait ran into the time-out: say where, and take the communicator down so that the collective kernel this rank is stuck in
+// (its peers never arrived) leaves the device
+int mcp_ba::watchdog_fail(const char* where) {
+  char msg[384];
+  std::snprintf(msg, sizeof msg, "rank %d of %d: no progress within %.0f ms while waiting for %s (last collectives: main lane #%llu '%s', "
+                "speculative lane #%llu '%s')", rank, world, timeout_ms, where, coll_seq[0], coll_what[0], coll_seq[1], coll_what[1]);
+  set_err(msg);
+  if (comm && !comm->dead) {
+    comm->dead = true;
+    if (rccl().CommAbort) { if (comm->comm2 && comm->comm2 != comm->comm) (void)rccl().CommAbort(comm->comm2); (void)rccl().CommAbort(comm->comm); comm->comm = comm->comm2 = nullptr; }
+  }
+  return -1;
+}
+// hipStreamSynchronize with a deadline
+int mcp_ba::wait_stream(hipStream_t s, const char* what) {
+  if (!multi()) { HIPCK(hipStreamSynchronize(s)); return 0; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) { set_err(std::string("stream failed while waiting for ") + what + ": " + hipGetErrorString(e)); return -1; }
+    if (spins > 2000) {
+      std::this_thread::yield();
+      if ((spins & 0xff) == 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) return watchdog_fail(what);
+    }
+  }
+}
+
 int mcp_ba::prepare() {
   auto t0 = std::chrono::steady_clock::now();
   auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
@@ -383,7 +440,7 @@ int mcp_ba::prepare() {
     flags[npose + 1] = nfree;
     DevBuf<double> tmp;
     if (tmp.upload(flags, st)) return -1;
-    if (allreduce(tmp.p, flags.size(), true)) return -1;
+    if (allreduce(tmp.p, flags.size(), 0, true, "set-up: active poses and counts")) return -1;
     HIPCK(hipMemcpy(flags.data(), tmp.p, flags.size()*sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < npose; ++i) poses[i].active = flags[i] > 0;
     m_total = flags[npose]; nfl_total = flags[npose + 1];
@@ -597,7 +654,7 @@ int mcp_ba::prepare() {
       std::vector<double> pd(pat.begin(), pat.end());
       DevBuf<double> tmp;
       if (tmp.upload(pd, st)) return -1;
-      if (allreduce(tmp.p, pd.size(), true)) return -1;
+      if (allreduce(tmp.p, pd.size(), 0, true, "set-up: tile pattern")) return -1;
       HIPCK(hipMemcpy(pd.data(), tmp.p, pd.size()*sizeof(double), hipMemcpyDeviceToHost));
       for (size_t i = 0; i < pd.size(); ++i) pat[i] = pd[i] > 0;
       std::vector<int> rt;
@@ -703,14 +760,18 @@ int mcp_ba::prepare() {
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
-  if (world > 1 && d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
+  if (multi()) {
+    if (d_seltab.alloc((size_t)world*sel_cap + world + 2)) return -1;
+    for (int q = 0; q < MAX_SYS; ++q) if (d_trial[q].alloc(TRIAL_LEN) || d_trstate[q].alloc(SEL_PASSES + 1)) return -1;
+  }
+  sel_src = -1; pred_bin = -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
   for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) { (void)hipGraphExecDestroy(chain_exec[q][r]); chain_exec[q][r] = nullptr; }
   if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)nrhs_rows*6) || d_stS.alloc(MAX_SYS*nstage*36) ||
       d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
-      d_part2.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(8) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
+      d_part2.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(16) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
   // pinned, device-visible: [0..31] read-back block, [32 + 32 q ..] mailbox of trial q (ticket at + MAIL_TICKET)
   constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
@@ -723,7 +784,7 @@ int mcp_ba::prepare() {
   if (!h_fail) HIPCK(hipHostMalloc((void**)&h_fail, 4*sizeof(int)));
   HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
   HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
-  HIPCK(hipMemsetAsync(d_sigma.p, 0, 8*sizeof(double), st));
+  HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st)); sig_par = 0;
 
   P.cams = d_cams.p; P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
   P.npose = npose; P.pose_unk = d_pose_unk.p; P.npoint = npoint; P.pt_chain = d_pt_chain.p; P.pt_unk = d_pt_unk.p;
@@ -779,62 +840,79 @@ void mcp_ba::launch_chains(int w) {
 void mcp_ba::launch_eval(int w, bool sum, double* err_out) {
   const int nb = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nb == 0) return;
-  if (sum) hipLaunchKernelGGL((k_eval<true>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, d_sigma.p, d_part0.p);
-  else hipLaunchKernelGGL((k_eval<false>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, d_sigma.p, d_part0.p);
+  if (sum) hipLaunchKernelGGL((k_eval<true>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, sig(), d_part0.p);
+  else hipLaunchKernelGGL((k_eval<false>), dim3(nb), dim3(EVAL_BLOCK), 0, st, P, d_pt[w].p, d_last[w].p, d_chi2[w].p, err_out, sig(), d_part0.p);
 }
 
 // exact k-th smallest |x| (global over ranks when a hook is installed); result left at out_dev[0]
 int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma) {
   const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
-  if (world == 1) {
+  if (!multi()) {
     // single GPU: two full histogram passes, gather, one-workgroup finish (which also writes the Huber sigma block if asked)
     HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)(2*SEL_BINS + 1)*sizeof(double), st));        // two histograms + the gather counter behind them
     unsigned int* cnt = reinterpret_cast<unsigned int*>(d_hist.p + 2*SEL_BINS);
     for (int p = 0; p < 2; ++p) hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
     hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, (const double*)d_hist.p, d_selstate.p, cnt, d_selvals.p);
     hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_selvals.p, (const SelState*)d_selstate.p,
-                       m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma, out_dev, huber_sigma ? d_sigma.p : (double*)nullptr,
+                       m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma, out_dev, huber_sigma ? sig() : (double*)nullptr,
                        huber_sigma ? d_res.p + 25 : (double*)nullptr);
     return 0;
   }
   // several ranks: two all-reduced histogram passes, then the few candidates of every rank are gathered through a
   // zero-filled (ranks x sel_cap) table summed over the ranks, and each rank finishes locally: 3 collectives
   HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
-  const size_t tab = (size_t)world*sel_cap;              // [tab] overflow flag, [tab+1 .. tab+world] counts, [tab+world+1] gather counter
-  HIPCK(hipMemsetAsync(d_seltab.p, 0, (tab + world + 2)*sizeof(double), st));
   for (int p = 0; p < 2; ++p) {
     hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
-    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
+    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS, 0, false, "median: digit histogram")) return -1;
   }
-  unsigned int* cnt = reinterpret_cast<unsigned int*>(d_seltab.p + tab + world + 1);
-  hipLaunchKernelGGL(k_select_gather_slot, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, (const double*)d_hist.p, d_selstate.p, cnt,
-                     d_seltab.p + (size_t)rank*sel_cap, sel_cap, rank == 0 ? d_seltab.p + tab : (double*)nullptr);
-  hipLaunchKernelGGL(k_select_publish, dim3(1), dim3(64), 0, st, (const unsigned int*)cnt, sel_cap, d_seltab.p + tab + 1 + rank);
-  if (allreduce(d_seltab.p, tab + 1 + world)) return -1;
   // the flag is the same on every rank (it is derived from the all-reduced histogram), so all ranks take the same branch
-  HIPCK(hipMemcpyAsync(h_res + 30, d_seltab.p + tab, sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCK(hipStreamSynchronize(st));
-  if (h_res[30] == 0.0) {
-    hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_seltab.p, (const SelState*)d_selstate.p,
-                       m_total, 0.0, out_dev, (double*)nullptr, (double*)nullptr, (const double*)(d_seltab.p + tab + 1), world, sel_cap);
-    return 0;
-  }
+  if (select_gather_finish(x, n, d_hist.p, d_selstate.p, out_dev, true)) return -1;
+  if (h_res[30] == 0.0) return 0;
   // more candidates than the table holds (tens of thousands of values equal in their top 22 bits): the remaining digits by histogram
   for (int p = 2; p < SEL_PASSES; ++p) {
     hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
-    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS)) return -1;
+    if (allreduce(d_hist.p + (size_t)p*SEL_BINS, SEL_BINS, 0, false, "median: digit histogram (overflow path)")) return -1;
   }
   hipLaunchKernelGGL(k_select_final, dim3(1), dim3(SEL_BLOCK), 0, st, d_hist.p, d_selstate.p, out_dev);
+  return 0;
+}
+// multi-rank: with the first two digits fixed (hist pass 1 + state[1] given), gather every rank's candidates through the slot table
+// (one all-reduce) and resolve the remaining digits locally.  check_overflow: read the overflow flag back (h_res[30]; one host
+// wait) and skip the finish if it is up; without it the caller knows from the summed histogram that no slot can overflow.
+int mcp_ba::select_gather_finish(const double* x, int n, const double* hist, SelState* state, double* out_dev, bool check_overflow) {
+  const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
+  const size_t tab = (size_t)world*sel_cap;              // [tab] overflow flag, [tab+1 .. tab+world] counts, [tab+world+1] gather counter
+  HIPCK(hipMemsetAsync(d_seltab.p, 0, (tab + world + 2)*sizeof(double), st));
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(d_seltab.p + tab + world + 1);
+  hipLaunchKernelGGL(k_select_gather_slot, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, hist, state, cnt,
+                     d_seltab.p + (size_t)rank*sel_cap, sel_cap, rank == 0 ? d_seltab.p + tab : (double*)nullptr);
+  hipLaunchKernelGGL(k_select_publish, dim3(1), dim3(64), 0, st, (const unsigned int*)cnt, sel_cap, d_seltab.p + tab + 1 + rank);
+  if (allreduce(d_seltab.p, tab + 1 + world, 0, false, "median: candidate gather")) return -1;
+  if (check_overflow) {
+    HIPCK(hipMemcpyAsync(h_res + 30, d_seltab.p + tab, sizeof(double), hipMemcpyDeviceToHost, st));
+    if (wait_stream(st, "median: overflow flag")) return -1;
+    if (h_res[30] != 0.0) return 0;
+  }
+  hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_seltab.p, (const SelState*)state,
+                     m_total, 0.0, out_dev, (double*)nullptr, (double*)nullptr, (const double*)(d_seltab.p + tab + 1), world, sel_cap);
   return 0;
 }
 // RobustKernelData::RecomputeNow on the chi2 array of buffer `w`
 int mcp_ba::median_sigma(int w) {
   tic(ST_SELECT);
+  sig_par ^= 1;                                                      // a fresh block: stragglers of the last iteration keep reading theirs
   const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
-  if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8, true)) return -1;
-  if (world > 1)       // (the single-GPU path writes the sigma block in its last kernel)
+  // several ranks, and the state is the one an accepted trial left: that trial's all-reduce carried the first two digit histograms
+  // of this very chi2 array (ba_trial.h) -- if its prediction held and the selected bin fits the gather table, the median costs
+  // ONE collective and no host wait
+  if (multi() && sel_src >= 0 && tr_pred_ok[sel_src] && !tr_ovf[sel_src]) {
+    if (select_gather_finish(d_chi2[w].p, P.nmeas, d_trial[sel_src].p + TRIAL_HDR, d_trstate[sel_src].p, d_res.p + 8, false)) return -1;
+    timing.n_median_fast++;
+  } else if (select_kth(d_chi2[w].p, P.nmeas, k, d_res.p + 8, true)) return -1;
+  sel_src = -1;
+  if (multi())         // (the single-GPU path writes the sigma block in its last kernel)
     hipLaunchKernelGGL(k_sigma_from_median, dim3(1), dim3(64), 0, st, d_res.p + 8, m_total,
-                       prm.min_mestimator_sigma*prm.min_mestimator_sigma, d_sigma.p, d_res.p + 25 /* compute()'s read-back block */);
+                       prm.min_mestimator_sigma*prm.min_mestimator_sigma, sig(), d_res.p + 25 /* compute()'s read-back block */);
   toc();
   return 0;
 }
@@ -845,16 +923,52 @@ int mcp_ba::wait_mail(int q, unsigned long long ticket, int count) {
   const double* box = h_res + 32 + 32*q;
   volatile unsigned long long* tk = (volatile unsigned long long*)(box + MAIL_TICKET);
   hipStream_t watched = (q == 0) ? st : st2;
+  // The result is normally a few tens of microseconds away: poll hard for a while (a trial is ~70 us, a solve ~1 ms), then give
+  // the core to whoever else wants it between polls -- a tracker thread beside the mapper (BASELINE c5) should not lose a core
+  // to a solver that waits for a long factorisation or for another rank.  Every so often: has the stream died, drained without
+  // delivering, or made no progress for timeout_ms?
+  constexpr unsigned long long HARD_SPINS = 1ull << 16;
   for (unsigned long long spins = 0; __atomic_load_n(tk, __ATOMIC_ACQUIRE) != ticket; ++spins) {
-    if ((spins & 0xfffff) == 0xfffff) {             // every ~million polls: has the stream died or drained without delivering?
-      hipError_t e = hipStreamQuery(watched);
-      if (e == hipSuccess && q > 0 && st3) e = hipStreamQuery(st3);
-      if (e == hipSuccess) { if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == ticket) break; set_err("mailbox ticket never arrived"); return -1; }
-      if (e != hipErrorNotReady) { set_err(std::string("stream failed while waiting for a trial: ") + hipGetErrorString(e)); return -1; }
+    if (spins >= HARD_SPINS) {
+      std::this_thread::yield();
+      if ((spins & 0x3ff) == 0) {
+        hipError_t e = hipStreamQuery(watched);
+        if (e == hipSuccess && q > 0 && st3) e = hipStreamQuery(st3);
+        if (e == hipSuccess) { if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == ticket) break; set_err("mailbox ticket never arrived"); return -1; }
+        if (e != hipErrorNotReady) { set_err(std::string("stream failed while waiting for a trial: ") + hipGetErrorString(e)); return -1; }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count() > timeout_ms)
+          return watchdog_fail(q ? "the result of a trial evaluated ahead (speculative lane)" : "the result of a trial (main lane)");
+      }
+    } else {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#elif defined(__aarch64__)
+      __asm__ __volatile__("yield");
+#endif
     }
-    __builtin_ia32_pause();
   }
   std::memcpy(h_res, box, count*sizeof(double));
+  return 0;
+}
+// several ranks: what follows the evaluation of a trial (candidate state `slot`, system q of the batch) on stream s / lane --
+// digit histograms of its chi2, final sums into the trial buffer, ONE all-reduce, scan + result block (+ mailbox)   (ba_trial.h)
+int mcp_ba::multi_trial_tail(hipStream_t s, int lane, int q, int slot, int nbe, const double* p0, int nbb, const double* p1, const double* p2,
+                             const double* pose_parts, int pose_off, bool main_block, double* mail, int mail_count, unsigned long long ticket) {
+  double* T = d_trial[q].p;
+  HIPCK(hipMemsetAsync(T, 0, TRIAL_LEN*sizeof(double), s));
+  const bool ride = robust && sel_ride && P.nmeas > 0;
+  if (ride) {
+    const int grid = std::max(1, std::min(256, (P.nmeas + SEL_BLOCK*8 - 1)/(SEL_BLOCK*8)));
+    hipLaunchKernelGGL(k_select_hist2, dim3(grid), dim3(SEL_BLOCK), 0, s, P.nmeas, (const double*)d_chi2[slot].p, pred_bin, T + TRIAL_HDR);
+  }
+  const bool rides = main_block && start_rides;
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, s, nbe, p0, nbb, p1, nbb, p2, T, 0, (const int*)d_fail.p + q, (double*)nullptr, 0, 0ull,
+                     rides ? (const double*)(d_res.p + 24) : (const double*)nullptr, 4);
+  if (allreduce(T, ride ? TRIAL_LEN : TRIAL_HDR, lane, false, lane ? "trial evaluated ahead: result block + median histograms" : "trial: result block + median histograms")) return -1;
+  hipLaunchKernelGGL(k_trial_post, dim3(1), dim3(SEL_BLOCK), 0, s, T, d_trstate[q].p, (unsigned long long)(m_total/2), pred_bin, (double)sel_cap, ride ? 1 : 0,
+                     pose_parts, pose_off, main_block ? (const double*)(d_res.p + 24) : (const double*)nullptr, rides ? 1 : 0,
+                     main_block ? d_res.p : (double*)nullptr, mail, mail_count, ticket);
+  if (rides) start_rides = false;
   return 0;
 }
 // the step of speculative system q applied and evaluated on stream s (which has just solved it): candidate state cand(q), its own
@@ -871,8 +985,11 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   if (P.nchain) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
-                              (const double*)d_sigma.p, d_sp0[q].p);
+                              (const double*)sig(), d_sp0[q].p);
   pre_ticket[q] = ++mail_ticket;
+  if (multi()) {
+    if (multi_trial_tail(s, 1, q, slot, nbe, d_sp0[q].p, nbb, nfl ? d_sp1[q].p : nullptr, nfl ? d_sp2[q].p : nullptr, resq + 4, 4, false, h_mail_dev + 32*q, MAIL_TICKET, pre_ticket[q])) return -1;
+  } else
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, s, nbe, (const double*)d_sp0[q].p, nbb, (const double*)(nfl ? d_sp1[q].p : nullptr),
                      nbb, (const double*)(nfl ? d_sp2[q].p : nullptr), resq, 0, (const int*)d_fail.p + q, h_mail_dev + 32*q, 6, pre_ticket[q]);
   HIPCK(hipEventRecord(ev_tr[q], s));
@@ -888,7 +1005,8 @@ int mcp_ba::cancel_spec_trials() {
 // One trial ahead: when the host turns to trial q - 1, the step of system q (if it was solved speculatively on another stream) is
 // applied and evaluated there already, so that a rejection of q - 1 finds q's result waiting.
 int mcp_ba::run_ahead(int q) {
-  if (!spec_trials || !use_mailbox || world != 1 || prm.profile) return 0;
+  if (!spec_trials || !use_mailbox || prm.profile) return 0;
+  if (multi() && overlap_spec != 1) return 0;       // (the speculative lane belongs to the second stream)
   if (!spec_pending && !spec3_pending && q >= spec2_from) { /* its stream has been joined already: still valid to use it */ }
   if (q < spec2_from || q >= batch_n || pre_run[q]) return 0;
   return enqueue_spec_trial(q >= spec3_from ? st3 : st2, q);
@@ -896,8 +1014,7 @@ int mcp_ba::run_ahead(int q) {
 int mcp_ba::read_results(int count) {
   // the failure flag of a trial travels inside the block (k_final_sums, d_res[3]): one copy, one wait
   HIPCK(hipMemcpyAsync(h_res, d_res.p, count*sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCK(hipStreamSynchronize(st));
-  return 0;
+  return wait_stream(st, "a result block");
 }
 
 // buildSystem at the current state (sigma block must be current)
@@ -916,11 +1033,11 @@ int mcp_ba::linearize() {
     }
     if (ninc) HIPCK(hipMemsetAsync(d_W.p, 0, (size_t)ninc*18*sizeof(double), st));
     if (P.nmeas) hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
   }
   if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, d_sigma.p, d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
 #ifdef MCP_LIN_PROF
   {
     HIPCK(hipStreamSynchronize(st));
@@ -969,11 +1086,13 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
   }
 #endif
   if (np && multi()) {
-    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack (main stream only: one communicator)
+    // pack the structurally non-zero tiles of S with rhs and bp, sum over the ranks, unpack -- on the stream that built the systems,
+    // through that stream's lane: the trial's own system never queues behind the speculative ones
     const size_t npack = pack_stride*nsys;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)Sq, np, (const int*)d_red_tiles.p, n_red_tiles, d_pack.p, 1, red_stride, pack_stride);
-    if (allreduce(d_pack.p, npack)) return -1;
-    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, st, (const double*)d_pack.p, np, (const int*)d_red_tiles.p, n_red_tiles, Sq, 0, red_stride, pack_stride);
+    double* pk = d_pack.p + q0*pack_stride;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, s, (const double*)Sq, np, (const int*)d_red_tiles.p, n_red_tiles, pk, 1, red_stride, pack_stride);
+    if (allreduce(pk, npack, main_stream ? 0 : 1, false, main_stream ? "reduced system of the trial (packed tiles)" : "speculative reduced systems (packed tiles)")) return -1;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(n_red_tiles + 1, nsys), dim3(256), 0, s, (const double*)pk, np, (const int*)d_red_tiles.p, n_red_tiles, Sq, 0, red_stride, pack_stride);
   }
   return 0;
 }
@@ -1014,12 +1133,13 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       const int q = sys_cur;
       last_tr = cand(q); last_xp = &d_sxp[q]; last_xl = &d_sxl[q];
       if (run_ahead(q + 1)) return -1;
-      if (wait_mail(q, pre_ticket[q], 6)) return -1;
+      if (wait_mail(q, pre_ticket[q], multi() ? MAIL_TICKET : 6)) return -1;
+      if (multi()) { tr_pred_ok[q] = h_res[MAIL_PRED_OK] != 0.0; tr_ovf[q] = h_res[MAIL_OVERFLOW] != 0.0; }
       pre_run[q] = false;
       HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));         // whatever the main stream does next with the trial's state comes after the kernels that made it
       mark("pre_used", st);
       ++dbg_pre;
-      if (!nfl) h_res[1] = h_res[2] = 0.0;
+      if (!nfl_total) h_res[1] = h_res[2] = 0.0;
       h_res[1] += h_res[4]; h_res[2] += h_res[5];
       ok2 = (h_res[3] == 0.0);
       timing.n_trials++;
@@ -1036,7 +1156,8 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (cancel_spec_trials()) return -1;   // (a re-solve inside an iteration: nothing of the previous batch is wanted any more)
     if (join_spec()) return -1;            // (... and its stragglers first)
     HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-    const bool split = overlap_spec && nsys > 1 && np > 0 && !multi() && st2;
+    const int ov = multi() ? std::min(overlap_spec, 1) : overlap_spec;      // several ranks: one speculative stream, the one lane 1 belongs to
+    const bool split = ov && nsys > 1 && np > 0 && st2;
     if (split) {
       // system 0 -- the one this trial needs -- alone on the main stream; the speculative systems behind the fork on the second
       // stream.  Same kernels on the same data as the batched path: the numbers do not depend on which stream produced them.
@@ -1050,7 +1171,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       // host enqueue order: the other streams' Schur complements right away (they start at the fork on the device and run beside
       // the main stream's), their factorisation chains only after this trial's own chain and tail (below) -- the main stream never
       // runs dry behind the ~45 launches of another chain
-      defer_n2 = (overlap_spec >= 2 && nsys - n1 > 1 && st3) ? 1 : nsys - n1;       // systems on the second stream
+      defer_n2 = (ov >= 2 && nsys - n1 > 1 && st3) ? 1 : nsys - n1;       // systems on the second stream
       HIPCK(hipStreamWaitEvent(st2, ev_fork, 0));
       mark("spec_start", st2);
       if (build_system(defer_n2, sb, n1, st2)) return -1;
@@ -1102,12 +1223,19 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   launch_chains(tr);
   launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  const bool mailbox = use_mailbox && world == 1 && !prm.profile;
-  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
-                     nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
-                     mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0 = ++mail_ticket);
+  const bool mailbox = use_mailbox && !prm.profile;
+  mail_ticket0 = ++mail_ticket;
+  if (multi()) {
+    // (several ranks: the sums are rank-local until the trial's all-reduce; k_trial_post writes the block and the mailbox)
+    if (multi_trial_tail(st, 0, sys_cur, tr, nbe, d_part0.p, nbb, nfl ? d_part1.p : nullptr, nfl ? d_part2.p : nullptr, d_res.p + 6, 6, true,
+                         mailbox ? h_mail_dev : (double*)nullptr, MAIL_TICKET, mail_ticket0)) return -1;
+  } else {
+    hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
+                       nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
+                       mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0);
+    if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
+  }
   toc();
-  if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
   mark("trial_end", st);
   if (defer_nsys) {
     const int n2 = defer_n2;
@@ -1124,23 +1252,11 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   }
   if (defer_nsys && run_ahead(1)) return -1;
   if (mailbox) {
-    // one rank: nothing to reduce; the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
-    if (wait_mail(0, mail_ticket0, 29)) return -1;
-    if (!nfl) h_res[1] = h_res[2] = 0.0;
-    h_res[1] += h_res[6]; h_res[2] += h_res[7];
-    ok2 = (h_res[3] == 0.0);
-    timing.n_trials++;
-    return 0;
-  }
-  // robust chi2, point parts of the step statistics, failure flag (any rank); on the first trial of an iteration also the
-  // iteration-start robust chi2 (moved next to them for the occasion, and back)
-  if (start_rides) {
-    HIPCK(hipMemcpyAsync(d_res.p + 4, d_res.p + 24, sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (allreduce(d_res.p, 5)) return -1;
-    HIPCK(hipMemcpyAsync(d_res.p + 24, d_res.p + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
-    start_rides = false;
-  } else if (allreduce(d_res.p, 4)) return -1;
-  if (read_results(29)) return -1;          // trial results [0..7] and, for compute(), the iteration-start block [24..28]
+    // the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
+    if (wait_mail(0, mail_ticket0, multi() ? MAIL_TICKET : 29)) return -1;
+  } else if (read_results(MAIL_TICKET)) return -1;          // trial results [0..7] and, for compute(), the iteration-start block [24..28]
+  if (multi()) { tr_pred_ok[sys_cur] = h_res[MAIL_PRED_OK] != 0.0; tr_ovf[sys_cur] = h_res[MAIL_OVERFLOW] != 0.0; }
+  if (!nfl_total) h_res[1] = h_res[2] = 0.0;
   h_res[1] += h_res[6]; h_res[2] += h_res[7];
   ok2 = (h_res[3] == 0.0);
   timing.n_trials++;
@@ -1173,7 +1289,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
       const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-      if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+      if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
       // iteration-start robust chi2 and the sigma block go to d_res[24..28]; they are read back together with the first
       // trial's results (one host synchronisation less per iteration) -- except in the first iteration, whose lambda comes
       // from the diagonal of the freshly built system
@@ -1182,14 +1298,14 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       toc();
       // several ranks: the sum over the ranks rides on the first trial's all-reduce (d_res[0..3] + d_res[4], see solve_trial);
       // the first iteration needs it before its first trial
-      if (it == 0) { if (allreduce(d_res.p + RS, 1)) return MCP_ERR_RUNTIME; }
-      start_rides = (it > 0 && world > 1);
+      if (it == 0) { if (allreduce(d_res.p + RS, 1, 0, false, "iteration-start chi2")) return MCP_ERR_RUNTIME; }
+      start_rides = (it > 0 && multi());
       if (linearize()) return MCP_ERR_RUNTIME;
       if (it == 0 && !(user_lambda > 0)) {
         // computeLambdaInit [g2o]: 1e-5 * max |H_jj| over the pose and point diagonals; the pose diagonal is summed from
         // the staged blocks (and over the ranks), the point diagonals are rank-local (maximum over ranks taken below)
         if (np) hipLaunchKernelGGL(k_udiag, dim3((np + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
-        if (world > 1 && np) { if (allreduce(d_udiag.p, np)) return MCP_ERR_RUNTIME; }
+        if (multi() && np) { if (allreduce(d_udiag.p, np, 0, false, "pose diagonal for the initial lambda")) return MCP_ERR_RUNTIME; }
         hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_udiag.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }
       static_assert(RS + 1 == 25, "median_sigma() writes the sigma block to d_res + 25");
@@ -1197,7 +1313,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       bool start_pending = true;
       auto take_start = [&]() {
         currentChi = tempChi = h_res[RS];
-        if (robust) { sigma_sq = h_res[RS + 1]; sigma_sq_lim = h_res[RS + 2]; }
+        if (robust) { sigma_sq = h_res[RS + 1]; sigma_sq_lim = h_res[RS + 2]; pred_bin = sel_coarse_bin(h_res[RS + 4]); }
         lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
         start_pending = false;
       };
@@ -1206,10 +1322,11 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         if (user_lambda > 0) lambda = user_lambda;
         else {
           double md = h_res[5];
-          if (world > 1) {   // max over ranks of the V diagonals (U is already global)
+          if (multi()) {   // max over ranks of the V diagonals (U is already global)
+            if (world > 8) { set_err("more than 8 ranks"); return MCP_ERR_RUNTIME; }
             std::vector<double> slots(world, 0.0); slots[rank] = md;
             HIPCK(hipMemcpyAsync(d_res.p + 16, slots.data(), world*sizeof(double), hipMemcpyHostToDevice, st));
-            if (allreduce(d_res.p + 16, world, true)) return MCP_ERR_RUNTIME;
+            if (allreduce(d_res.p + 16, world, 0, true, "initial lambda")) return MCP_ERR_RUNTIME;
             HIPCK(hipMemcpy(slots.data(), d_res.p + 16, world*sizeof(double), hipMemcpyDeviceToHost));
             for (double v : slots) md = std::max(md, v);
           }
@@ -1240,10 +1357,10 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           for (int j = 0; j < np; ++j) { scale += xp[j]*(lambda*xp[j] + bpv[j]); ss += xp[j]*xp[j]; }
           double sl = 0, sq = 0;
           for (size_t j = 0; j < xl.size(); ++j) { sl += xl[j]*(lambda*xl[j] + gv[j]); sq += xl[j]*xl[j]; }
-          if (world > 1) {   // point parts are rank-local
+          if (multi()) {   // point parts are rank-local
             double v2[2] = { sl, sq };
             HIPCK(hipMemcpy(d_res.p + 16, v2, 16, hipMemcpyHostToDevice));
-            if (allreduce(d_res.p + 16, 2, true)) return MCP_ERR_RUNTIME;
+            if (allreduce(d_res.p + 16, 2, 0, true, "step statistics after a failed factorisation")) return MCP_ERR_RUNTIME;
             HIPCK(hipMemcpy(v2, d_res.p + 16, 16, hipMemcpyDeviceToHost)); sl = v2[0]; sq = v2[1];
           }
           scale += sl; ss += sq;
@@ -1258,6 +1375,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           const double sf = std::max(1./3., alpha);
           lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
           cur = last_tr;                             // discardTop: the trial state becomes current
+          sel_src = multi() ? sys_cur : -1;          // ... and the digit histograms that rode on its all-reduce describe the new chi2 array
         } else {
           lambda *= ni; ni *= 2; accepted = 0;       // pop: the current buffers were never touched
         }
@@ -1315,10 +1433,10 @@ int mcp_ba::final_stats(int nCounter) {
   if (m_total == 0 || dirty) { max_cov = 0; return 0; }
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)d_sigma.p, d_part0.p);
+  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
-  if (allreduce(d_res.p, 1)) return -2;
-  HIPCK(hipMemcpyAsync(d_res.p + 9, d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (allreduce(d_res.p, 1, 0, false, "final robust chi2")) return -2;
+  HIPCK(hipMemcpyAsync(d_res.p + 9, sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, st));
   if (read_results(13)) return -2;
   if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
   mean_chi2 = h_res[0]/m_total;
@@ -1355,7 +1473,7 @@ int mcp_ba::final_stats(int nCounter) {
     if (build_system(1, sb)) return -2;
     const size_t n2 = (size_t)np*np;
     hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, 0, (const double*)nullptr, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)d_fail.p);
-    if (allreduce(d_res.p + 3, 1)) return -2;
+    if (allreduce(d_res.p + 3, 1, 0, false, "covariance: failure flag")) return -2;
     std::vector<double> Sh(n2 + 1), Sinv(n2 + 1, 0.0);
     if (np) HIPCK(hipMemcpyAsync(Sh.data(), S(), n2*8, hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(h_res + 3, d_res.p + 3, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1423,6 +1541,9 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
   { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
+  { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
+  { const char* e = getenv("MCP_BA_SELECT_RIDE"); if (e) h->sel_ride = atoi(e); }
+  { const char* e = getenv("MCP_BA_TIMEOUT_MS"); if (e && atof(e) > 0) h->timeout_ms = atof(e); }
   for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
   if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
@@ -1538,18 +1659,28 @@ mcp_comm* mcp_comm_init(const void* id, int rank, int world_size, int device) {
   mcp_comm* c = new mcp_comm(); c->rank = rank; c->world = world_size; c->device = device;
   const int rc = rccl().CommInitRank(&c->comm, world_size, uid, rank);
   if (rc != 0) { set_err(std::string("ncclCommInitRank failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?")); delete c; return nullptr; }
+  // lane 1 (speculative stream): the same ranks in the same order, split off lane 0 -- collective over all ranks like the init itself
+  if (!rccl().CommSplit) { set_err("mcp_comm_init: this librccl has no ncclCommSplit (needed for the second lane)"); (void)rccl().CommDestroy(c->comm); delete c; return nullptr; }
+  const int rc2 = rccl().CommSplit(c->comm, 0, rank, &c->comm2, nullptr);
+  if (rc2 != 0 || !c->comm2) { set_err(std::string("ncclCommSplit failed: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc2) : "?")); (void)rccl().CommDestroy(c->comm); delete c; return nullptr; }
   return c;
 }
-void mcp_comm_destroy(mcp_comm* c) { if (c) { if (c->comm) (void)rccl().CommDestroy(c->comm); delete c; } }
+void mcp_comm_destroy(mcp_comm* c) {
+  if (!c) return;
+  if (c->comm2 && c->comm2 != c->comm) (void)rccl().CommDestroy(c->comm2);
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  delete c;
+}
 int mcp_ba_set_comm(mcp_ba* h, mcp_comm* c) {
   if (c && c->device != h->device) { set_err("mcp_ba_set_comm: communicator lives on another device"); return -1; }
   h->comm = c; h->rank = c ? c->rank : 0; h->world = c ? c->world : 1; h->dirty = true;
   return 0;
 }
-int mcp_comm_allreduce(mcp_comm* c, void* buf, size_t count) {
-  if (!c || !c->comm) { set_err("mcp_comm_allreduce: no communicator"); return -1; }
+int mcp_comm_allreduce(mcp_comm* c, void* buf, size_t count) { return mcp_comm_allreduce_lane(c, buf, count, 0); }
+int mcp_comm_allreduce_lane(mcp_comm* c, void* buf, size_t count, int lane) {
+  if (!c || !c->comm || c->dead) { set_err("mcp_comm_allreduce: no communicator"); return -1; }
   HIPCK(hipSetDevice(c->device));
-  const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, c->comm, nullptr);
+  const int rc = rccl().AllReduce(buf, buf, count, RCCL_FLOAT64, RCCL_SUM, c->lane(lane), nullptr);
   if (rc != 0) { set_err("ncclAllReduce failed"); return -1; }
   HIPCK(hipStreamSynchronize(nullptr));
   return 0;
@@ -1585,10 +1716,10 @@ int mcp_ba_robust_chi2(mcp_ba* h, double* sigma_sq_raw, double* chi2_sum) {
   h->launch_eval(h->cur, false, nullptr);
   if (h->robust && h->median_sigma(h->cur)) return -1;
   const int nbe = (n + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, h->st, n, h->robust, (const double*)h->d_chi2[h->cur].p, (const double*)h->d_sigma.p, h->d_part0.p);
+  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, h->st, n, h->robust, (const double*)h->d_chi2[h->cur].p, (const double*)h->sig(), h->d_part0.p);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, h->st, nbe, (const double*)h->d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, h->d_res.p, 0, (const int*)nullptr);
-  if (h->allreduce(h->d_res.p, 1)) return -1;
-  HIPCK(hipMemcpyAsync(h->d_res.p + 9, h->d_sigma.p, 4*sizeof(double), hipMemcpyDeviceToDevice, h->st));
+  if (h->allreduce(h->d_res.p, 1, 0, false, "robust chi2")) return -1;
+  HIPCK(hipMemcpyAsync(h->d_res.p + 9, h->sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, h->st));
   if (h->read_results(13)) return -1;
   if (sigma_sq_raw) *sigma_sq_raw = h->h_res[9];
   if (chi2_sum) *chi2_sum = h->h_res[0];

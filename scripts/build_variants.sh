@@ -12,6 +12,10 @@ for v in "$@"; do
   case $v in
     panel2) build panel2 -DMCP_CHOL_PANEL2=1 & ;;          # panel split over two wavefronts by column halves
     rsq2) build rsq2 -DCH_RSQ2=1 & ;;
+    ld16) build ld16 -DCH_LOAD16=1 & ;;                  # k_chol_step: 16-byte tile loads
+    st16) build st16 -DCH_STORE16=1 & ;;                 # k_chol_step: 16-byte stores of the trailing tiles
+    pst16) build pst16 -DCH_PSTORE16=1 & ;;              # k_chol_step: panel rows through LDS, 16-byte stores
+    ldst16) build ldst16 -DCH_LOAD16=1 -DCH_STORE16=1 & ;;
     lin2) build lin2 -DLIN_WAVES=2 & ;;
     sch4) build sch4 -DSCH_WAVES=4 & ;;                    # k_schur_group held to 128 registers: four workgroups per CU (1024 slots >= 785 groups)
     sch2) build sch2 -DSCH_WAVES=2 & ;;

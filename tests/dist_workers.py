@@ -45,8 +45,11 @@ def sharded_solve_on_one_gpu(rank, world, port, outdir, cfg, iters):
     rc = b.Compute(iters)
     R, t, X = collect(b, ids)
     logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in b.IterLogs()])
+    tm = b.Timing()
     np.savez(os.path.join(outdir, "shard_%d.npz" % rank), rc=rc, R=R, t=t, X=X, logs=logs, sigma_sq=b.GetSigmaSquared(),
-             mean_chi2=b.GetMeanChiSquared(), calls=hook.calls, n_out=len(b.GetOutlierMeasurements()))
+             mean_chi2=b.GetMeanChiSquared(), calls=hook.calls, n_out=len(b.GetOutlierMeasurements()),
+             coll_main=tm["n_collectives_main"], coll_spec=tm["n_collectives_spec"], median_fast=tm["n_median_fast"],
+             trials=tm["n_trials"], solves=tm["n_solves"], bytes_main=tm["collective_bytes_main"], bytes_spec=tm["collective_bytes_spec"])
     b.close()
     dist.destroy_process_group()
 
@@ -112,6 +115,61 @@ def rccl_hook_single_rank(rank, world, port, outdir):
     torch.cuda.synchronize()
     np.savez(os.path.join(outdir, "rccl.npz"), t=t.cpu().numpy(), calls=h.calls)
     dist.destroy_process_group()
+
+
+def forced_multi_native_rccl(rank, world, port, outdir, cfg, iters):
+    """MCP_BA_FORCE_MULTI=1 with a one-rank RCCL communicator: the two-lane multi-rank machine (packed-tile all-reduces on both
+    streams, trial blocks with riding histograms, one-collective medians) on the real transport.  Sums over one rank are exact."""
+    os.environ["MCP_BA_FORCE_MULTI"] = "1"
+    import torch
+    torch.cuda.set_device(0)
+    from mcptam_amd import chain_bundle, synth
+    from helpers import collect
+    comm = chain_bundle.Comm(chain_bundle.comm_unique_id(), 0, 1, 0)
+    t = torch.arange(4096, dtype=torch.float64, device="cuda") * 0.25
+    comm.allreduce(t.data_ptr(), t.numel(), lane=1)
+    p = synth.make_config(**cfg)
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, disable_convergence=True, device=0)
+    ids = p.populate(b)
+    b.SetComm(comm)
+    rc = b.Compute(iters)
+    R, tt, X = collect(b, ids)
+    tm = b.Timing()
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in b.IterLogs()])
+    np.savez(os.path.join(outdir, "forced.npz"), t=t.cpu().numpy(), rc=rc, R=R, tt=tt, X=X, logs=logs, sigma_sq=b.GetSigmaSquared(),
+             coll_main=tm["n_collectives_main"], coll_spec=tm["n_collectives_spec"], median_fast=tm["n_median_fast"], trials=tm["n_trials"], solves=tm["n_solves"])
+    b.close(); comm.close()
+
+
+def watchdog_stall(rank, world, port, outdir):
+    """The all-reduce hook parks a long sleep kernel on the solver's stream once: the next bounded wait must give up."""
+    os.environ["MCP_BA_FORCE_MULTI"] = "1"
+    os.environ["MCP_BA_TIMEOUT_MS"] = "150"
+    import time
+    import torch
+    torch.cuda.set_device(0)
+    from mcptam_amd import chain_bundle, synth
+    p = synth.make_config("c1")
+    g = chain_bundle.ChainBundle(p.cams, True, True, False, disable_convergence=True, device=0)
+    p.populate(g)
+    n = [0]
+
+    def stalling(ptr, count, stream):
+        n[0] += 1
+        if n[0] == 12 and stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=torch.device("cuda", 0))):
+                torch.cuda._sleep(int(6e9))
+    g.SetAllReduce(stalling, 0, 1)
+    t0 = time.time()
+    msg = "no error"
+    try:
+        g.Compute(10)
+    except RuntimeError as exc:
+        msg = str(exc)
+    dt = time.time() - t0
+    torch.cuda.synchronize()
+    g.close()
+    np.savez(os.path.join(outdir, "watchdog.npz"), msg=msg, seconds=dt, calls=n[0])
 
 
 def native_rccl_single_rank(rank, world, port, outdir):

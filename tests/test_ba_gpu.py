@@ -295,6 +295,100 @@ def test_two_rank_sharded_solve_equals_merged_single_rank(gpu_required):
     assert np.allclose(r0["logs"], logs, rtol=1e-9)
     assert abs(float(r0["sigma_sq"]) - ref["sigma_sq"]) <= 1e-12 * ref["sigma_sq"]        # global median is exact
     assert int(r0["n_out"]) + int(r1["n_out"]) == len(ref["outliers"])
+    # the multi-rank solve is the single-rank machine: speculative systems + trials ahead on the second lane, and the collective
+    # budget of DESIGN.md 6 -- per iteration one packed-tile all-reduce per solve and lane, one block per trial, one gather per median
+    for r in (r0, r1):
+        assert int(r["coll_spec"]) > 0, "no collective on the speculative lane: the second stream is off"
+        assert int(r["median_fast"]) >= iters - 2, "the medians should ride on the accepted trials' all-reduces"
+        # main lane: prepare 2, first iteration 6 (three-collective median, start chi2, pose diagonal, lambda), final statistics <= 4;
+        # then per iteration ONE for the median (three if its prediction missed) and per solve TWO (packed tiles, the trial's block)
+        slow = max(0, iters - 1 - int(r["median_fast"]))
+        assert int(r["coll_main"]) <= 12 + (iters - 1) + 2 * slow + 2 * int(r["solves"]), (int(r["coll_main"]), int(r["solves"]), int(r["median_fast"]))
+        assert int(r["solves"]) <= iters + 1
+    assert int(r0["coll_main"]) == int(r1["coll_main"]) and int(r0["coll_spec"]) == int(r1["coll_spec"])
+
+
+def _logs_array(logs):
+    return np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in logs])
+
+
+def test_forced_multi_rank_machine_with_identity_hook_is_bit_identical(gpu_required, monkeypatch):
+    """MCP_BA_FORCE_MULTI=1 drives a ONE-rank solve through everything a multi-rank solve does (packed tiles, both lanes, trial
+    blocks + riding median histograms + k_trial_post, slot-table gather); the hook sums over one rank, i.e. changes nothing, so
+    logs, poses and points must equal the plain single-rank solve bit for bit -- on the noisy metric map, whose iterations reject."""
+    from mcptam_amd import synth
+    p = synth.make_config("metric")
+    base = run_bundle(_gpu(p.cams, disable_convergence=True), p, 7)
+    monkeypatch.setenv("MCP_BA_FORCE_MULTI", "1")
+    calls = []
+    g = _gpu(p.cams, disable_convergence=True)
+    g.SetAllReduce(lambda ptr, count, stream: calls.append(count), 0, 1)
+    alt = run_bundle(g, p, 7)
+    tm = g.Timing()
+    assert base["rc"] == alt["rc"] == 7 and sum(l["trials"] for l in base["logs"]) > 10
+    assert base["logs"] == alt["logs"]
+    assert np.array_equal(base["R"], alt["R"]) and np.array_equal(base["t"], alt["t"]) and np.array_equal(base["X"], alt["X"])
+    assert base["outliers"] == alt["outliers"] and base["sigma_sq"] == alt["sigma_sq"] and base["lam"] == alt["lam"]
+    assert tm["n_collectives_spec"] > 0 and tm["n_median_fast"] >= 5 and len(calls) == tm["n_collectives_main"] + tm["n_collectives_spec"]
+    # the riding histograms can be switched off (three-collective medians): same numbers
+    monkeypatch.setenv("MCP_BA_SELECT_RIDE", "0")
+    g2 = _gpu(p.cams, disable_convergence=True)
+    g2.SetAllReduce(lambda ptr, count, stream: None, 0, 1)
+    alt2 = run_bundle(g2, p, 7)
+    assert g2.Timing()["n_median_fast"] == 0
+    assert base["logs"] == alt2["logs"] and np.array_equal(base["X"], alt2["X"])
+    # ... and a gather table too small for the selected bin sends every median down the remaining-digits path
+    monkeypatch.setenv("MCP_BA_SELECT_RIDE", "1")
+    monkeypatch.setenv("MCP_BA_SELECT_CAP", "1")
+    g3 = _gpu(p.cams, disable_convergence=True)
+    g3.SetAllReduce(lambda ptr, count, stream: None, 0, 1)
+    alt3 = run_bundle(g3, p, 7)
+    assert g3.Timing()["n_median_fast"] == 0
+    assert base["logs"] == alt3["logs"] and np.array_equal(base["X"], alt3["X"])
+
+
+@pytest.mark.timeout(300)
+def test_forced_multi_rank_machine_on_native_rccl_lanes(gpu_required):
+    """The same on the real transport: a one-rank RCCL communicator with its two lanes (ncclCommSplit), all-reduces enqueued on
+    the solver's two streams, no host synchronisation inside the LM loop."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    from mcptam_amd import synth
+    cfg = dict(name="c2")
+    iters = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.forced_multi_native_rccl, args=(1, port, d, cfg, iters), nprocs=1, join=True)
+        r = np.load(os.path.join(d, "forced.npz"))
+    assert np.array_equal(r["t"], np.arange(4096) * 0.25)
+    p = synth.make_config(**cfg)
+    ref = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    assert int(r["rc"]) == ref["rc"] == iters
+    assert np.array_equal(r["logs"], _logs_array(ref["logs"]))
+    assert np.array_equal(r["R"], ref["R"]) and np.array_equal(r["tt"], ref["t"]) and np.array_equal(r["X"], ref["X"])
+    assert int(r["coll_spec"]) > 0 and int(r["median_fast"]) >= iters - 2
+
+
+@pytest.mark.timeout(300)
+def test_watchdog_bounds_a_stalled_collective(gpu_required):
+    """A rank that never arrives leaves the others' streams stuck behind a collective.  Simulated with a hook that parks a
+    long sleep kernel on the solver's stream: the solve must come back with MCP_BA_ERR_RUNTIME and say where it waited
+    (worker process: torch has to own the HIP runtime it launches the sleep kernel with)."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.watchdog_stall, args=(1, port, d), nprocs=1, join=True)
+        r = np.load(os.path.join(d, "watchdog.npz"))
+    msg = str(r["msg"])
+    assert "no progress within" in msg and "rank 0 of 1" in msg and "lane" in msg, msg
+    assert float(r["seconds"]) < 30.0
 
 
 def test_rccl_hook_on_device_buffer(gpu_required):
