@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = "r02"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
+ROUND = "r03"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
@@ -231,7 +231,8 @@ def main():
         # what a BundleAdjust() call pays once before its first LM iteration (the reference builds a fresh ChainBundle per
         # call, BundleAdjusterMulti.cc:75): populate = the AddPose/AddPoint/AddMeas replay through the C ABI (batched
         # entries, from Python here), prepare = symbolic structure on the host + upload over PCIe
-        setup_ms["populate_ms"] = (t1 - t0) * 1e3
+        setup_ms["populate_ms"] = (t1 - t0) * 1e3                  # from Python: numpy marshalling + the library's entries
+        setup_ms["populate_in_library_ms"] = b.abi_seconds * 1e3     # what a native caller (shim/ChainBundle.cc) pays: the bulk Add* entries alone
         setup_ms["prepare_ms"] = (t2 - t1) * 1e3
         return b
 
@@ -282,6 +283,10 @@ def main():
                 "setup_outside_timed_region": dict(setup_ms, note="once per BundleAdjust call: C-ABI replay of the map (populate) and "
                                                    "host structure build + PCIe upload (prepare); not part of `value`")},
         }
+        # the same K iterations as one BundleAdjust() call pays for them: bulk replay through the C ABI + Prepare() + the iterations
+        call_s = (setup_ms["populate_in_library_ms"] + setup_ms["prepare_ms"]) * 1e-3 + dt
+        result["value_including_setup"] = {"value": world * args.steps / call_s, "unit": "LM iterations/s over a whole call of %d iterations" % args.steps,
+                                           "setup_ms": setup_ms["populate_in_library_ms"] + setup_ms["prepare_ms"], "iterations_ms": dt * 1e3}
         if world > 1:
             # what the LM loop put on the wire, per iteration (the first iteration's extras and the final statistics included):
             # main lane = the collectives the trial path waits for, speculative lane = beside it on the second stream
@@ -359,6 +364,38 @@ def main():
         result["cpu_baseline"] = base_a                 # the denominator SURVEY.md 8(d) names for the >= 10x target
         result["cpu_baseline_variants"] = variants
         result["speedup_vs_cpu"] = {k: result["value"] / v["value"] for k, v in variants.items()}
+    # secondary line: the call MCPTAM makes most -- BundleAdjustRecent (src/BundleAdjusterBase.cc:188-265): the newest MKF + its 3
+    # neighbours free, every other MKF that sees their points fixed, 10 iterations; timed as WHOLE calls (fresh handle, bulk replay,
+    # Prepare, Compute(10), read-back of poses and points), the way BundleAdjusterMulti::BundleAdjust runs it
+    if rank == 0 and world == 1 and args.config == "metric":
+        try:
+            import numpy as np
+            w = synth.recent_window(problem)
+            calls = []
+            parts = {"populate_in_library_ms": [], "prepare_ms": [], "compute_ms": [], "readback_ms": []}
+            for rep_ in range(12):
+                t0 = time.perf_counter()
+                bw_ = chain_bundle.ChainBundle(w.cams, True, True, False, device=local_rank)
+                ids = w.populate(bw_)
+                t1 = time.perf_counter()
+                bw_.Prepare()
+                t2 = time.perf_counter()
+                rcw = bw_.Compute(10)
+                t3 = time.perf_counter()
+                bw_.GetPoses(ids["mkf"]); bw_.GetPoints(ids["point"]); bw_.GetOutlierMeasurements()
+                t4 = time.perf_counter()
+                if rep_ >= 2:
+                    calls.append(t4 - t0 - (t1 - t0) + bw_.abi_seconds)       # the Python marshalling of populate() is the harness, not the call
+                    parts["populate_in_library_ms"].append(bw_.abi_seconds * 1e3); parts["prepare_ms"].append((t2 - t1) * 1e3)
+                    parts["compute_ms"].append((t3 - t2) * 1e3); parts["readback_ms"].append((t4 - t3) * 1e3)
+                bw_.close()
+            med = float(np.median(calls))
+            result["recent_window"] = {"workload": "BundleAdjustRecent window of the metric map: %d MKF (%d free), %d points, %d measurements, 10 LM iterations per call"
+                                       % (w.n_mkf, int((~w.base_fixed).sum()), w.n_points, w.n_meas),
+                                       "calls_per_s": 1.0 / med, "ms_per_call": med * 1e3, "iterations_run": rcw,
+                                       "ms_median": {k: float(np.median(v)) for k, v in parts.items()}, "calls_timed": len(calls)}
+        except Exception as exc:
+            result["recent_window"] = {"error": repr(exc)}
     # secondary line: the per-frame Tracker path (BASELINE config c3), GPU through the C ABI next to the scalar CPU port
     if rank == 0 and world == 1 and not args.no_tracker and args.cpu_iters > 0:
         try:

@@ -7,6 +7,7 @@ library or a gfx950 device is missing this module raises -- there is no CPU path
 """
 import ctypes
 import os
+import time
 
 import numpy as np
 
@@ -201,6 +202,7 @@ class ChainBundle:
             raise RuntimeError("mcp_ba_create failed: " + last_error())
         self.abort = ctypes.c_ubyte(0)      # the caller's mbBundleAbortRequested
         self._hook = None
+        self.abi_seconds = 0.0               # time spent inside the library's Add* entries (what a native caller pays; the rest is Python)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -236,8 +238,11 @@ class ChainBundle:
         chain_len = np.ascontiguousarray(chain_len, dtype=np.int32)
         fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
         ids = np.zeros(x.shape[0], dtype=np.int32)
-        self._check(self._L.mcp_ba_add_points(self._h, x.shape[0], _dp(x), _ip(chains), chains.shape[1], _ip(chain_len),
-                                              fixed.ctypes.data_as(c_ubyte_p), _ip(ids)), "AddPointBatch")
+        t0 = time.perf_counter()
+        rc = self._L.mcp_ba_add_points(self._h, x.shape[0], _dp(x), _ip(chains), chains.shape[1], _ip(chain_len),
+                                       fixed.ctypes.data_as(c_ubyte_p), _ip(ids))
+        self.abi_seconds += time.perf_counter() - t0
+        self._check(rc, "AddPointBatch")
         return ids
 
     def AddMeasBatch(self, chains, chain_len, point_ids, uv, sigma_sq, cam_index):
@@ -247,8 +252,11 @@ class ChainBundle:
         uv = np.ascontiguousarray(uv, dtype=np.float64)
         sigma_sq = np.ascontiguousarray(sigma_sq, dtype=np.float64)
         cam_index = np.ascontiguousarray(cam_index, dtype=np.int32)
-        self._check(self._L.mcp_ba_add_measurements(self._h, uv.shape[0], _ip(chains), chains.shape[1], _ip(chain_len),
-                                                    _ip(point_ids), _dp(uv), _dp(sigma_sq), _ip(cam_index)), "AddMeasBatch")
+        t0 = time.perf_counter()
+        rc = self._L.mcp_ba_add_measurements(self._h, uv.shape[0], _ip(chains), chains.shape[1], _ip(chain_len),
+                                             _ip(point_ids), _dp(uv), _dp(sigma_sq), _ip(cam_index))
+        self.abi_seconds += time.perf_counter() - t0
+        self._check(rc, "AddMeasBatch")
 
     def DebugSystem(self, lam):
         """(S, rhs, J^T r) of the reduced pose system at the current state (test hook, mcp_ba_debug_system)."""

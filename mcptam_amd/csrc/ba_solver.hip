@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -72,7 +74,7 @@ template <class T> struct DevBuf {
     if (e != hipSuccess) { set_err(std::string("hipMalloc: ") + hipGetErrorString(e)); p = nullptr; return -1; }
     n = count; return 0;
   }
-  int upload(const std::vector<T>& v, hipStream_t st) {
+  template <class A> int upload(const std::vector<T, A>& v, hipStream_t st) {
     if (alloc(v.size())) return -1;
     if (!v.empty()) HIPCK(hipMemcpyAsync(p, v.data(), v.size()*sizeof(T), hipMemcpyHostToDevice, st));
     return 0;
@@ -101,6 +103,102 @@ static int usable_cores() {
   return std::max(n, 1);
 }
 
+// Persistent worker threads for the host side of Prepare() (structure build): run(fn) executes fn(tid) for tid in [0, size()),
+// the caller taking tid 0, and returns when all are done.  Workers sleep on a condition variable between jobs.
+class HostPool {
+ public:
+  explicit HostPool(int n) : n_(std::max(1, n)) { for (int i = 1; i < n_; ++i) th_.emplace_back([this, i] { worker(i); }); }
+  ~HostPool() { { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+  int size() const { return n_; }
+  void run(const std::function<void(int)>& fn) {
+    std::lock_guard<std::mutex> one_job(run_m_);
+    { std::lock_guard<std::mutex> lk(m_); job_ = &fn; pending_ = n_ - 1; ++gen_; gen_a_.store(gen_, std::memory_order_release); }
+    cv_.notify_all();
+    fn(0);
+    // the phases of one Prepare() follow each other within microseconds: poll before sleeping (workers do the same for the next job)
+    for (int spin = 0; spin < 20000 && done_a_.load(std::memory_order_acquire) != gen_; ++spin) cpu_relax();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+ private:
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+  }
+  void worker(int tid) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* f;
+      for (int spin = 0; spin < 40000 && gen_a_.load(std::memory_order_acquire) == seen; ++spin) cpu_relax();     // ~100 us, then sleep
+      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; f = job_; }
+      (*f)(tid);
+      { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) { done_a_.store(seen, std::memory_order_release); done_.notify_one(); } }
+    }
+  }
+  int n_; std::vector<std::thread> th_; std::mutex m_, run_m_; std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr; unsigned long long gen_ = 0; int pending_ = 0; bool stop_ = false;
+  std::atomic<unsigned long long> gen_a_{0}, done_a_{0};
+};
+
+// Process-wide pinned staging arena for the structure arrays of Prepare(): the builders write them straight into page-locked
+// memory (no page faults on fresh allocations, no zero fill, no pageable-to-pinned bounce inside hipMemcpyAsync), one bump
+// allocation per array, everything released when the upload has completed.  One Prepare() at a time holds it.
+class PinnedArena {
+ public:
+  std::mutex& mutex() { return m_; }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (blocks_.empty() || used_ + bytes > blocks_.back().size) {
+      size_t want = std::max<size_t>(bytes, blocks_.empty() ? ((size_t)64 << 20) : 2*blocks_.back().size);
+      Block b; b.size = want; b.pinned = true;
+      if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = std::malloc(want); b.pinned = false; if (!b.p) throw std::bad_alloc(); }
+      blocks_.push_back(b); used_ = 0;
+    }
+    void* r = (char*)blocks_.back().p + used_; used_ += bytes; total_ += bytes;
+    return r;
+  }
+  void reset() {      // nothing of the arena is in use any more
+    if (blocks_.size() > 1) {      // settle on one block that holds a whole build
+      size_t sum = 0; for (auto& b : blocks_) { sum += b.size; if (b.pinned) (void)hipHostFree(b.p); else std::free(b.p); }
+      blocks_.clear();
+      Block b; b.size = sum; b.pinned = true;
+      if (hipHostMalloc(&b.p, sum, hipHostMallocDefault) == hipSuccess) blocks_.push_back(b); else (void)hipGetLastError();
+    }
+    used_ = 0; total_ = 0;
+  }
+ private:
+  struct Block { void* p = nullptr; size_t size = 0; bool pinned = false; };
+  std::vector<Block> blocks_; size_t used_ = 0, total_ = 0; std::mutex m_;
+};
+static PinnedArena& pinned_arena() { static PinnedArena* a = new PinnedArena(); return *a; }      // (never destroyed: the HIP runtime may be gone at exit)
+template <class T> struct ArenaAlloc {
+  using value_type = T;
+  ArenaAlloc() = default;
+  template <class U> ArenaAlloc(const ArenaAlloc<U>&) {}
+  T* allocate(size_t n) { return (T*)pinned_arena().alloc(n*sizeof(T)); }
+  void deallocate(T*, size_t) {}
+  // resize(n) default-initialises (no fill) -- the builders write every entry they need; assign(n, v) still fills
+  template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new((void*)p) U; else ::new((void*)p) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const ArenaAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const ArenaAlloc<U>&) const { return false; }
+};
+template <class T> using avec = std::vector<T, ArenaAlloc<T>>;
+// end of a build (any exit path): the copies out of the arena have to be done before it is handed to the next build
+struct ArenaGuard { hipStream_t st; ~ArenaGuard() { if (st) (void)hipStreamSynchronize(st); pinned_arena().reset(); } };
+static HostPool& host_pool() { static HostPool p(std::min(16, usable_cores())); return p; }
+
+// std::allocator whose resize(n) leaves new elements uninitialised (bulk entries size the arrays once and fill every record)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... A> void construct(U* p, A&&... a) { if constexpr (sizeof...(A) == 0) ::new((void*)p) U; else ::new((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct HPose { int id; int fixed; double T[12]; int unk; int active; };
 struct HPoint { int id; int fixed; double x[3]; int chain; int unk; int active; };
 struct HMeas { int chain, point, cam; double u, v, omega; };
@@ -125,8 +223,9 @@ struct mcp_ba {
 
   std::vector<HPose> poses;
   std::vector<HPoint> points;
-  std::vector<HMeas> meas;
-  std::vector<int> meas_point;      // meas[i].point, compact: the bucketing by point at Prepare() reads 4 bytes per measurement instead of 40
+  std::vector<HMeas, NoInitAlloc<HMeas>> meas;
+  std::vector<int, NoInitAlloc<int>> meas_point;      // meas[i].point, compact: the bucketing by point at Prepare() reads 4 bytes per measurement instead of 40
+  std::vector<int, NoInitAlloc<int>> meas_chain;      // meas[i].chain, likewise
   std::vector<HChain> chains;
   std::map<std::array<int, 1 + MCP_MAX_CHAIN>, int> chain_map;
   std::vector<int> id_kind, id_index;   // by id; kind 1 pose, 2 point
@@ -292,9 +391,35 @@ struct mcp_ba {
   // last chain looked up: the adapters add measurements KeyFrame by KeyFrame (BundleAdjusterMulti.cc:168-200), so consecutive
   // calls repeat the same pose chain and the ordered-map search is skipped for them
   int last_chain_n = 0, last_chain_idx = -1; int last_chain_ids[MCP_MAX_CHAIN];
+  // ... and a direct-mapped cache in front of the ordered map for adapters that add point by point (every row another chain)
+  struct ChainSlot { int n = 0, idx = -1; int ids[MCP_MAX_CHAIN]; };
+  static constexpr int CHAIN_CACHE = 4096;
+  std::vector<ChainSlot> chain_cache;
+  static unsigned chain_hash(const int* ids, int n) { unsigned h = 2166136261u ^ (unsigned)n; for (int i = 0; i < n; ++i) { h ^= (unsigned)ids[i]; h *= 16777619u; } return (h ^ (h >> 13)) & (CHAIN_CACHE - 1); }
+  // read-only look-up (safe from several threads while nobody adds a chain): index, -1 = not known yet, -2 = malformed
+  int lookup_chain(const int* ids, int n) const {
+    if (n < 1 || n > MCP_MAX_CHAIN) return -2;
+    if (!chain_cache.empty()) {
+      const ChainSlot& cs = chain_cache[chain_hash(ids, n)];
+      if (cs.idx >= 0 && cs.n == n && std::memcmp(ids, cs.ids, sizeof(int)*n) == 0) return cs.idx;
+    }
+    std::array<int, 1 + MCP_MAX_CHAIN> key; key.fill(-1); key[0] = n;
+    for (int i = 0; i < n; ++i) {
+      if (ids[i] <= 0 || ids[i] >= next_id || id_kind[ids[i]] != 1) return -2;
+      key[1 + i] = id_index[ids[i]];
+    }
+    auto it = chain_map.find(key);
+    return it == chain_map.end() ? -1 : it->second;
+  }
   int find_chain(const int* ids, int n) {
     if (n < 1 || n > MCP_MAX_CHAIN) return -1;
     if (n == last_chain_n && last_chain_idx >= 0 && std::memcmp(ids, last_chain_ids, sizeof(int)*n) == 0) return last_chain_idx;
+    if (chain_cache.empty()) chain_cache.resize(CHAIN_CACHE);
+    ChainSlot& cs = chain_cache[chain_hash(ids, n)];
+    if (cs.idx >= 0 && cs.n == n && std::memcmp(ids, cs.ids, sizeof(int)*n) == 0) {
+      last_chain_n = n; last_chain_idx = cs.idx; std::memcpy(last_chain_ids, ids, sizeof(int)*n);
+      return cs.idx;
+    }
     std::array<int, 1 + MCP_MAX_CHAIN> key; key.fill(-1); key[0] = n;
     for (int i = 0; i < n; ++i) {
       if (ids[i] <= 0 || ids[i] >= next_id || id_kind[ids[i]] != 1) return -1;
@@ -309,6 +434,7 @@ struct mcp_ba {
       idx = (int)chains.size() - 1; chain_map[key] = idx;
     }
     last_chain_n = n; last_chain_idx = idx; std::memcpy(last_chain_ids, ids, sizeof(int)*n);
+    cs.n = n; cs.idx = idx; std::memcpy(cs.ids, ids, sizeof(int)*n);
     return idx;
   }
   // PoseChainHelper::MoveTogether, ChainBundle.cc:157-199 (structural: evaluated once per chain pair)
@@ -346,7 +472,16 @@ struct mcp_ba {
     return 0;
   }
 
+  struct HostStruct {      // (in the pinned staging arena)
+    avec<int> m_pt, m_chain, m_sp, slot_start, slot_unk, slot_inc, l_i0, l_i1, l_sp, inc_unk, sp_pt, sp_m, sp_i, g_sp0, g_pose, g_blk0,
+              pair_id, pr_start, blk_dst, po_start, rhs_dst;
+    avec<unsigned char> m_cam, slot_first, sp_big, slot_lp, inc_lp, inc_mixed, blk_pair;
+    avec<unsigned short> m_mask;
+    avec<double> m_u, m_v, m_om;
+  };
   int prepare();
+  int prepare_legacy();
+  int finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace);
   int upload_state();
   int download_state();
   void launch_chains(int which);
@@ -416,7 +551,367 @@ int mcp_ba::wait_stream(hipStream_t s, const char* what) {
   }
 }
 
+// Structure build of one Compute() -- the analogue of g2o's initializeOptimization + buildStructure -- on the host's cores:
+// which poses / points take part, points ordered by source pose, measurements bucketed by point, per-measurement Jacobian
+// slots and per-point incidences, groups of points for the LDS-tiled kernels, the fixed-order staging plan of their pose
+// blocks, the tile pattern of the reduced system.  Every phase that touches the measurements runs on the worker pool over
+// disjoint ranges and writes to positions that are known beforehand, so the arrays are those of the serial reference
+// implementation (prepare_legacy, MCP_BA_PREPARE_LEGACY=1; tests/test_ba_gpu.py compares the two) whatever the thread count.
 int mcp_ba::prepare() {
+  if (getenv("MCP_BA_PREPARE_LEGACY")) return prepare_legacy();
+  auto t0 = std::chrono::steady_clock::now();
+  auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
+  auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
+  HIPCK(hipSetDevice(device));
+  const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
+  const size_t nch = chains.size();
+  HostPool& pool = host_pool();
+  const int T = (nmeas >= 32768) ? pool.size() : 1;
+  auto par = [&](const std::function<void(int)>& fn) { if (T == 1) fn(0); else pool.run(fn); };
+  auto lo_of = [&](int tid, long n) { return (long)(n*tid/T); };
+  lap("  entry");
+  // ---- one pass over the measurements in add order, a range per thread: which chains are used, and how many measurements of
+  // every point the range holds (private counters: no shared writes)
+  std::vector<unsigned char> chain_used(nch, 0);
+  std::unique_ptr<int[]> cnt_t(new int[(size_t)T*std::max(npoint, 1)]);
+  {
+    std::vector<unsigned char> cu_all((size_t)T*nch, 0);
+    par([&](int tid) {
+      unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t.get() + (size_t)tid*npoint;
+      std::memset(ct, 0, sizeof(int)*(size_t)npoint);
+      const int* mc = meas_chain.data(); const int* mp = meas_point.data();
+      for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; }
+    });
+    for (int t = 0; t < T; ++t) for (size_t c = 0; c < nch; ++c) chain_used[c] |= cu_all[(size_t)t*nch + c];
+  }
+  // per point: total, and the rank at which every thread's measurements of it start (add order = thread order, then index order)
+  std::vector<int> cnt(npoint + 1, 0);
+  par([&](int tid) {
+    for (long p = lo_of(tid, npoint), e = lo_of(tid + 1, npoint); p < e; ++p) {
+      int tot = 0;
+      for (int t = 0; t < T; ++t) { int& c = cnt_t[(size_t)t*npoint + p]; const int v = c; c = tot; tot += v; }
+      cnt[p + 1] = tot;
+    }
+  });
+  lap("  counts (threads)");
+  for (auto& p : poses) { p.active = 0; p.unk = -1; }
+  for (int i = 0; i < npoint; ++i) { points[i].active = cnt[i + 1] > 0; points[i].unk = -1; if (points[i].active) chain_used[points[i].chain] = 1; }
+  for (size_t c = 0; c < nch; ++c) if (chain_used[c]) for (int k = 0; k < chains[c].len; ++k) poses[chains[c].v[k]].active = 1;
+  m_total = (double)nmeas;
+  if (multi()) {
+    // ranks hold different measurement shards: agree on the active poses and the global count
+    std::vector<double> flags(npose + 2);
+    for (int i = 0; i < npose; ++i) flags[i] = poses[i].active;
+    flags[npose] = (double)nmeas;
+    double nfree = 0; for (const auto& p : points) if (p.active && !p.fixed) nfree += 1;
+    flags[npose + 1] = nfree;
+    DevBuf<double> tmp;
+    if (tmp.upload(flags, st)) return -1;
+    if (allreduce(tmp.p, flags.size(), 0, true, "set-up: active poses and counts")) return -1;
+    HIPCK(hipMemcpy(flags.data(), tmp.p, flags.size()*sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < npose; ++i) poses[i].active = flags[i] > 0;
+    m_total = flags[npose]; nfl_total = flags[npose + 1];
+  }
+  fp_pose.clear(); fl_point.clear();
+  for (int i = 0; i < npose; ++i) if (poses[i].active && !poses[i].fixed) { poses[i].unk = (int)fp_pose.size(); fp_pose.push_back(i); }
+  for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
+  nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
+  if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
+  if (!multi()) nfl_total = nfl;
+  lap("activity");
+  for (int i = 0; i < npoint; ++i) cnt[i + 1] += cnt[i];        // measurements by point (add order kept inside a point): ranges
+  // ---- point order: by the first free pose of the chain the point is expressed in (counting sort: stable)
+  std::vector<int> order;
+  {
+    std::vector<int> pkey(npoint, -1), kc(nfp + 2, 0);
+    for (int i = 0; i < npoint; ++i) {
+      if (!points[i].active) continue;
+      const HChain& c = chains[points[i].chain];
+      int key = nfp;
+      for (int k = 0; k < c.len; ++k) if (poses[c.v[k]].unk >= 0) { key = poses[c.v[k]].unk; break; }
+      pkey[i] = key; kc[key + 1]++;
+    }
+    for (int k = 0; k <= nfp; ++k) kc[k + 1] += kc[k];
+    order.resize(kc[nfp + 1]);
+    for (int i = 0; i < npoint; ++i) if (pkey[i] >= 0) order[kc[pkey[i]]++] = i;
+  }
+  nsp = (int)order.size();
+  // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
+  const bool dense_table = nch <= 4096;
+  // (entries are written concurrently by the structure threads below: every writer stores the same value, relaxed atomics)
+  std::unique_ptr<std::atomic<unsigned short>[]> mask_table(dense_table ? new std::atomic<unsigned short>[nch*nch] : nullptr);
+  if (dense_table) for (size_t i = 0; i < nch*nch; ++i) mask_table[i].store(0xffff, std::memory_order_relaxed);
+  std::map<std::pair<int, int>, unsigned short> mask_cache;
+  std::mutex mask_mutex;
+  auto compute_mask = [&](int oc, int sc) -> unsigned short {
+    unsigned short mk = 0;
+    const HChain& o = chains[oc]; const HChain& s2 = chains[sc];
+    for (int i = 0; i < o.len; ++i) if (!poses[o.v[i]].fixed && !move_together(o, s2, i)) mk |= (1 << i);
+    for (int i = 0; i < s2.len; ++i) if (!poses[s2.v[i]].fixed && !move_together(s2, o, i)) mk |= (1 << (MAXC + i));
+    return mk;
+  };
+  auto pair_mask = [&](int oc, int sc) -> unsigned short {
+    if (dense_table) {
+      std::atomic<unsigned short>& e = mask_table[(size_t)oc*nch + sc];
+      unsigned short v = e.load(std::memory_order_relaxed);
+      if (v == 0xffff) { v = compute_mask(oc, sc); e.store(v, std::memory_order_relaxed); }
+      return v;
+    }
+    std::lock_guard<std::mutex> lk(mask_mutex);
+    auto key = std::make_pair(oc, sc);
+    auto it = mask_cache.find(key);
+    if (it != mask_cache.end()) return it->second;
+    const unsigned short mk = compute_mask(oc, sc);
+    mask_cache[key] = mk; return mk;
+  };
+  std::unique_lock<std::mutex> arena_lock(pinned_arena().mutex());
+  ArenaGuard arena_guard{st};
+  HostStruct H;
+  H.m_pt.resize(nmeas); H.m_chain.resize(nmeas); H.m_sp.resize(nmeas); H.slot_start.resize(nmeas + 1);
+  H.m_cam.resize(nmeas); H.m_mask.resize(nmeas); H.m_u.resize(nmeas); H.m_v.resize(nmeas); H.m_om.resize(nmeas);
+  H.l_i0.assign(nfl + 1, 0); H.l_i1.assign(nfl + 1, 0); H.l_sp.assign(nfl + 1, 0);
+  H.sp_pt.resize(nsp); H.sp_m.assign(nsp + 1, 0); H.sp_i.assign(nsp + 1, 0); H.sp_big.assign(nsp, 0);
+  perm.assign(nmeas, 0);
+  std::vector<int> sp_of(std::max(npoint, 1), -1);
+  for (int sp = 0; sp < nsp; ++sp) { H.sp_m[sp + 1] = H.sp_m[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]); sp_of[order[sp]] = sp; }
+  // ---- every measurement to its final position, a range of the add order per thread (sequential reads, one scattered 40-byte
+  // write each; the reference's adapters add measurements KeyFrame by KeyFrame, so a point's measurements lie far apart).
+  // Measurements of a point are stored rotated by the point's position: neighbouring points (= neighbouring lanes of
+  // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
+  // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
+  struct SMeas { int chain, cam, mi, pad_; double u, v, omega; };
+  std::unique_ptr<SMeas[]> sorted(new SMeas[std::max(nmeas, 1)]);
+  par([&](int tid) {
+    int* ct = cnt_t.get() + (size_t)tid*npoint; const int* mp = meas_point.data(); const int* smp = H.sp_m.data();
+    for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
+      const int p = mp[i], r = ct[p]++, sp = sp_of[p], nm = cnt[p + 1] - cnt[p];
+      int kk = (r - sp) % nm; if (kk < 0) kk += nm;                    // rank r sits at slot kk with (kk + sp) % nm == r
+      const HMeas& m = meas[i];
+      SMeas& o = sorted[smp[sp] + kk];
+      o.chain = m.chain; o.cam = m.cam; o.mi = (int)i; o.u = m.u; o.v = m.v; o.omega = m.omega;
+    }
+  });
+  lap("  by point, order");
+  // ---- slots, incidences and the poses of every point: contiguous ranges of sorted points per thread (balanced by measurement
+  // count), each into its own arrays with range-relative indices; concatenated below with the offsets fixed up
+  std::vector<unsigned char> cov((size_t)std::max(nfp, 1)*std::max(nfp, 1), 0);        // pose-pair co-visibility, a >= b
+  struct Chunk { int sp0 = 0, sp1 = 0; std::vector<int> slot_unk, slot_inc, inc_unk, slot_cnt, sp_ninc, q_n, q_data; std::vector<unsigned char> slot_first, inc_state; };
+  std::vector<Chunk> chunks(T);
+  const avec<int>& sp_m = H.sp_m;
+  for (int t = 0; t < T; ++t) {
+    const long m0 = (long)nmeas*t/T, m1 = (long)nmeas*(t + 1)/T;
+    chunks[t].sp0 = (t == 0) ? 0 : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m0) - sp_m.begin());
+    chunks[t].sp1 = (t == T - 1) ? nsp : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m1) - sp_m.begin());
+  }
+  std::vector<double> thr_ms(T, 0.0);
+  par([&](int tid) {
+    const auto tt0 = std::chrono::steady_clock::now();
+    struct Stamp { double* d; std::chrono::steady_clock::time_point t; ~Stamp() { *d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } stamp_{&thr_ms[tid], tt0};
+    Chunk& C = chunks[tid];
+    const size_t nm_chunk = (size_t)(sp_m[C.sp1] - sp_m[C.sp0]);
+    C.slot_unk.reserve(nm_chunk*2 + 16); C.slot_inc.reserve(nm_chunk*2 + 16); C.slot_first.reserve(nm_chunk*2 + 16);
+    C.inc_unk.reserve(nm_chunk + 16); C.inc_state.reserve(nm_chunk + 16); C.q_data.reserve(nm_chunk + 16);
+    C.sp_ninc.assign(C.sp1 - C.sp0, 0); C.q_n.assign(C.sp1 - C.sp0, 0); C.slot_cnt.assign(nm_chunk, 0);
+    std::vector<int> q; q.reserve(64);
+    unsigned char* covp = cov.data();
+    for (int sp = C.sp0; sp < C.sp1; ++sp) {
+      const int pt = order[sp];
+      const int lpt = points[pt].unk, pch = points[pt].chain;
+      const HChain& sc = chains[pch];
+      const int ibase = (int)C.inc_unk.size();
+      H.sp_pt[sp] = pt;
+      q.clear();
+      const int nm_pt = cnt[pt + 1] - cnt[pt];
+      int j = sp_m[sp];
+      for (int kk = 0; kk < nm_pt; ++kk, ++j) {
+        const SMeas& m = sorted[j];
+        perm[j] = m.mi;
+        H.m_pt[j] = pt; H.m_chain[j] = m.chain; H.m_cam[j] = (unsigned char)m.cam; H.m_u[j] = m.u; H.m_v[j] = m.v; H.m_om[j] = m.omega; H.m_sp[j] = sp;
+        const unsigned short mk = pair_mask(m.chain, pch);
+        H.m_mask[j] = mk;
+        int nsl = 0;
+        const HChain& oc = chains[m.chain];
+        for (unsigned bits = mk; bits; bits &= bits - 1) {
+          const int b = __builtin_ctz(bits);
+          const HChain& c = (b < MAXC) ? oc : sc;
+          const int u = poses[c.v[b & (MAXC - 1)]].unk;
+          C.slot_unk.push_back(u); ++nsl;
+          if (std::find(q.begin(), q.end(), u) == q.end()) q.push_back(u);
+          // slot_first: first contribution to its W block among the slots that write it through memory (every slot but
+          // the first source link, whose block is kept in registers by k_linearize_group); inc_mixed: both kinds occur
+          int inc = -1; unsigned char first = 0;
+          if (lpt >= 0) {
+            for (int t2 = ibase; t2 < (int)C.inc_unk.size(); ++t2) if (C.inc_unk[t2] == u) { inc = t2; break; }
+            if (inc < 0) { inc = (int)C.inc_unk.size(); C.inc_unk.push_back(u); C.inc_state.push_back(0); }
+            if (b == MAXC) C.inc_state[inc] |= 1;
+            else { if (!(C.inc_state[inc] & 2)) first = 1; C.inc_state[inc] |= 2; }
+          }
+          C.slot_inc.push_back(inc); C.slot_first.push_back(first);
+        }
+        C.slot_cnt[j - sp_m[C.sp0]] = nsl;
+      }
+      C.sp_ninc[sp - C.sp0] = (int)C.inc_unk.size() - ibase;
+      C.q_n[sp - C.sp0] = (int)q.size();
+      C.q_data.insert(C.q_data.end(), q.begin(), q.end());
+      if ((int)q.size() > GRP_LMAX) H.sp_big[sp] = 1;
+      for (int a : q) for (int b2 : q) if (a >= b2 && !__atomic_load_n(covp + (size_t)a*nfp + b2, __ATOMIC_RELAXED)) __atomic_store_n(covp + (size_t)a*nfp + b2, (unsigned char)1, __ATOMIC_RELAXED);
+    }
+  });
+  lap("  slot threads");
+  if (trace) { fprintf(stderr, "[mcp_ba prepare]   per-thread ms:"); for (double v : thr_ms) fprintf(stderr, " %.2f", v); fprintf(stderr, "\n"); }
+  std::vector<int> sp_q0(nsp + 1, 0), sp_q;           // distinct pose unknowns touched by every sorted point
+  std::vector<unsigned char> inc_state;
+  {
+    std::vector<size_t> soff(T + 1, 0), ioff(T + 1, 0), qoff(T + 1, 0);
+    for (int t = 0; t < T; ++t) { soff[t + 1] = soff[t] + chunks[t].slot_unk.size(); ioff[t + 1] = ioff[t] + chunks[t].inc_unk.size(); qoff[t + 1] = qoff[t] + chunks[t].q_data.size(); }
+    H.slot_unk.resize(soff[T]); H.slot_inc.resize(soff[T]); H.slot_first.resize(soff[T]); H.inc_unk.resize(ioff[T]); inc_state.resize(ioff[T]); sp_q.resize(qoff[T]);
+    par([&](int tid) {
+      const Chunk& C = chunks[tid];
+      const int io = (int)ioff[tid];
+      int so = (int)soff[tid];
+      for (int j = sp_m[C.sp0]; j < sp_m[C.sp1]; ++j) { H.slot_start[j] = so; so += C.slot_cnt[j - sp_m[C.sp0]]; }
+      if (!C.slot_unk.empty()) {
+        std::memcpy(&H.slot_unk[soff[tid]], C.slot_unk.data(), C.slot_unk.size()*sizeof(int));
+        std::memcpy(&H.slot_first[soff[tid]], C.slot_first.data(), C.slot_first.size());
+        int* d = &H.slot_inc[soff[tid]];
+        for (size_t k = 0; k < C.slot_inc.size(); ++k) d[k] = C.slot_inc[k] < 0 ? -1 : C.slot_inc[k] + io;
+      }
+      if (!C.inc_unk.empty()) { std::memcpy(&H.inc_unk[ioff[tid]], C.inc_unk.data(), C.inc_unk.size()*sizeof(int)); std::memcpy(&inc_state[ioff[tid]], C.inc_state.data(), C.inc_state.size()); }
+      if (!C.q_data.empty()) std::memcpy(&sp_q[qoff[tid]], C.q_data.data(), C.q_data.size()*sizeof(int));
+      int ib = io, qb = (int)qoff[tid];
+      for (int sp = C.sp0; sp < C.sp1; ++sp) {
+        H.sp_i[sp] = ib; sp_q0[sp] = qb;
+        const int lpt = points[order[sp]].unk;
+        if (lpt >= 0) { H.l_i0[lpt] = ib; H.l_i1[lpt] = ib + C.sp_ninc[sp - C.sp0]; H.l_sp[lpt] = sp; }
+        ib += C.sp_ninc[sp - C.sp0]; qb += C.q_n[sp - C.sp0];
+      }
+    });
+    sp_q0[nsp] = (int)qoff[T];
+    H.sp_i[nsp] = (int)ioff[T];
+    H.slot_start[nmeas] = (int)soff[T];
+  }
+  ninc = (int)H.inc_unk.size(); nslot = (int)H.slot_unk.size();
+  lap("sort+slots");
+  // ---- groups: consecutive points, <= GRP_PTS points and <= GRP_LMAX distinct poses (greedy, in order)
+  nbig = 0;
+  {
+    std::vector<int> stamp(std::max(nfp, 1), -1), curset; curset.reserve(GRP_LMAX);
+    int start = 0, gid = 0;
+    auto close = [&](int end) {
+      if (end <= start) return;
+      std::sort(curset.begin(), curset.end());
+      H.g_sp0.push_back(start);
+      for (int k = 0; k < GRP_LMAX; ++k) H.g_pose.push_back(k < (int)curset.size() ? curset[k] : -1);
+      curset.clear(); start = end; ++gid;
+    };
+    for (int sp = 0; sp < nsp; ++sp) {
+      const bool big = H.sp_big[sp] != 0;                          // big points ride along with no poses
+      if (big) ++nbig;
+      const int* q = sp_q.data() + sp_q0[sp]; const int nq = big ? 0 : sp_q0[sp + 1] - sp_q0[sp];
+      int fresh = 0;
+      for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) ++fresh;
+      if ((int)curset.size() + fresh > GRP_LMAX || sp - start >= GRP_PTS) close(sp);
+      for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) { stamp[q[k]] = gid; curset.push_back(q[k]); }
+    }
+    close(nsp);
+    H.g_sp0.push_back(nsp);
+  }
+  ngroup = (int)H.g_sp0.size() - 1;
+  lap("groups");
+  // ---- tile occupancy of the reduced pose system: poses a, b interact iff some point touches both
+  if (np > 0) {
+    const int ntc = (np + CH_NB - 1)/CH_NB;
+    std::vector<unsigned char> pat((size_t)ntc*ntc, 0);
+    for (int a = 0; a < nfp; ++a) for (int b = 0; b <= a; ++b) {
+      if (!cov[(size_t)a*nfp + b]) continue;
+      const int ra0 = (6*a)/CH_NB, ra1 = (6*a + 5)/CH_NB, rb0 = (6*b)/CH_NB, rb1 = (6*b + 5)/CH_NB;
+      for (int ra = ra0; ra <= ra1; ++ra) for (int rb = rb0; rb <= rb1; ++rb) if (ra >= rb) pat[(size_t)ra*ntc + rb] = 1;
+    }
+    for (int i = 0; i < ntc; ++i) pat[(size_t)i*ntc + i] = 1;
+    if (multi()) {
+      // the union of every rank's co-visibility pattern: agreed once, used for the factorisation plan and for the
+      // packed all-reduce of the reduced system (only structurally non-zero tiles travel over xGMI)
+      std::vector<double> pd(pat.begin(), pat.end());
+      DevBuf<double> tmp;
+      if (tmp.upload(pd, st)) return -1;
+      if (allreduce(tmp.p, pd.size(), 0, true, "set-up: tile pattern")) return -1;
+      HIPCK(hipMemcpy(pd.data(), tmp.p, pd.size()*sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < pd.size(); ++i) pat[i] = pd[i] > 0;
+      std::vector<int> rt;
+      for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (pat[(size_t)i*ntc + j]) rt.push_back((i << 16) | j);
+      n_red_tiles = (int)rt.size();
+      if (d_red_tiles.upload(rt, st) || d_pack.alloc(MAX_SYS*((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np))) return -1;
+      pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
+    }
+    lap("  covisibility");
+    if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
+    lap("  symbolic plan");
+  } else plan.all_tiles.clear();
+  // ---- per group (threads over ranges of groups): local pose indices of slots and incidences, and which local pose pairs the
+  // group's points co-observe (one bit per pair of the 16 x 17 / 2)
+  H.slot_lp.assign(nslot + 1, 0); H.inc_lp.assign(ninc + 1, 0); H.inc_mixed.assign(ninc + 1, 0);
+  constexpr int NPAIR = GRP_LMAX*(GRP_LMAX + 1)/2;
+  std::vector<unsigned char> gcov((size_t)std::max(ngroup, 1)*NPAIR, 0);
+  H.g_blk0.assign(ngroup + 1, 0);
+  auto ltri = [](int r, int c) { return r*(r + 1)/2 + c; };
+  par([&](int tid) {
+    for (long i = lo_of(tid, ninc), e = lo_of(tid + 1, ninc); i < e; ++i) H.inc_mixed[i] = (inc_state[i] == 3);
+    std::vector<unsigned char> lpmap(std::max(nfp, 1), 0);
+    for (int gi = (int)lo_of(tid, ngroup), ge = (int)lo_of(tid + 1, ngroup); gi < ge; ++gi) {
+      const int* gp = &H.g_pose[(size_t)gi*GRP_LMAX];
+      for (int k = 0; k < GRP_LMAX; ++k) if (gp[k] >= 0) lpmap[gp[k]] = (unsigned char)k;
+      unsigned char* gc = &gcov[(size_t)gi*NPAIR];
+      for (int sp = H.g_sp0[gi]; sp < H.g_sp0[gi + 1]; ++sp) {
+        if (H.sp_big[sp]) continue;
+        for (int s2 = H.slot_start[sp_m[sp]]; s2 < H.slot_start[sp_m[sp + 1]]; ++s2) H.slot_lp[s2] = lpmap[H.slot_unk[s2]];
+        for (int i2 = H.sp_i[sp]; i2 < H.sp_i[sp + 1]; ++i2) H.inc_lp[i2] = lpmap[H.inc_unk[i2]];
+        const int* q = sp_q.data() + sp_q0[sp]; const int nq = sp_q0[sp + 1] - sp_q0[sp];
+        for (int x = 0; x < nq; ++x) for (int y = 0; y < nq; ++y) { const int lx = lpmap[q[x]], ly = lpmap[q[y]]; if (lx >= ly) gc[ltri(lx, ly)] = 1; }
+      }
+      int nb = 0; for (int k = 0; k < NPAIR; ++k) nb += gc[k];
+      H.g_blk0[gi + 1] = nb;
+    }
+  });
+  lap("  local indices");
+  // ---- fixed-order assembly plan (ba_group.h): which local pose pairs every group stages, and for every global pose
+  // pair / pose the list of staged slots in ascending group order
+  grp_blk_max = 0;
+  for (int gi = 0; gi < ngroup; ++gi) { grp_blk_max = std::max(grp_blk_max, H.g_blk0[gi + 1]); H.g_blk0[gi + 1] += H.g_blk0[gi]; }
+  nstage = (size_t)H.g_blk0[ngroup];
+  H.blk_pair.resize(nstage); H.blk_dst.assign(nstage, 0);
+  H.pair_id.assign((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1); H.po_start.assign(nfp + 1, 0); H.rhs_dst.assign((size_t)std::max(ngroup, 1)*GRP_LMAX, -1);
+  {
+    std::vector<int> blk_pid(nstage);            // global pose pair (id) of every staged block
+    std::vector<int> cnt_pair; int npairs = 0;
+    for (int gi = 0; gi < ngroup; ++gi) {
+      const int* gp = &H.g_pose[(size_t)gi*GRP_LMAX];
+      const unsigned char* gc = &gcov[(size_t)gi*NPAIR];
+      size_t k = (size_t)H.g_blk0[gi];
+      for (int la = 0; la < GRP_LMAX; ++la) for (int lb = 0; lb <= la; ++lb) if (gc[ltri(la, lb)]) {
+        H.blk_pair[k] = (unsigned char)((la << 4) | lb);
+        int& id = H.pair_id[(size_t)gp[la]*nfp + gp[lb]];               // g_pose is ascending: gp[la] >= gp[lb]
+        if (id < 0) { id = npairs++; cnt_pair.push_back(0); }
+        cnt_pair[id]++; blk_pid[k] = id; ++k;
+      }
+      for (int q2 = 0; q2 < GRP_LMAX; ++q2) if (gp[q2] >= 0) H.po_start[gp[q2] + 1]++;
+    }
+    H.pr_start.assign(npairs + 1, 0);
+    for (int i = 0; i < npairs; ++i) H.pr_start[i + 1] = H.pr_start[i] + cnt_pair[i];
+    // destination-ordered staging: the blocks of one pose pair are consecutive, in ascending group order (blocks are
+    // numbered group by group, so walking them in order fills every pair's run in that order)
+    { std::vector<int> pos(H.pr_start.begin(), H.pr_start.end() - 1);
+      for (size_t k = 0; k < nstage; ++k) H.blk_dst[k] = pos[blk_pid[k]]++; }
+    for (int a = 0; a < nfp; ++a) H.po_start[a + 1] += H.po_start[a];
+    nrhs_rows = H.po_start[nfp];
+    { std::vector<int> pos(H.po_start.begin(), H.po_start.end() - 1);
+      for (int gi = 0; gi < ngroup; ++gi) for (int k = 0; k < GRP_LMAX; ++k) { const int u = H.g_pose[(size_t)gi*GRP_LMAX + k]; if (u >= 0) H.rhs_dst[(size_t)gi*GRP_LMAX + k] = pos[u]++; } }
+  }
+  lap("pattern+plan");
+  if (trace) fprintf(stderr, "[mcp_ba prepare] %d groups, %zu staged blocks (%.1f per group, at most %d), %d host threads\n", ngroup, nstage, ngroup ? (double)nstage/ngroup : 0.0, grp_blk_max, T);
+  return finish_prepare(H, t0, tlast, trace);
+}
+
+int mcp_ba::prepare_legacy() {
   auto t0 = std::chrono::steady_clock::now();
   auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
   auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
@@ -732,7 +1227,21 @@ int mcp_ba::prepare() {
 
   lap("pattern+plan");
   if (trace) fprintf(stderr, "[mcp_ba prepare] %d groups, %zu staged blocks (%.1f per group, at most %d)\n", ngroup, nstage, ngroup ? (double)nstage/ngroup : 0.0, grp_blk_max);
-  // upload
+  std::unique_lock<std::mutex> arena_lock(pinned_arena().mutex());
+  ArenaGuard arena_guard{st};
+  HostStruct H;
+#define CP(x) H.x.assign(x.begin(), x.end())
+  CP(m_pt); CP(m_chain); CP(m_sp); CP(slot_start); CP(slot_unk); CP(slot_inc); CP(l_i0); CP(l_i1); CP(l_sp); CP(inc_unk); CP(sp_pt); CP(sp_m); CP(sp_i);
+  CP(g_sp0); CP(g_pose); CP(g_blk0); CP(pair_id); CP(pr_start); CP(blk_dst); CP(po_start); CP(rhs_dst); CP(m_cam); CP(slot_first); CP(sp_big); CP(slot_lp);
+  CP(inc_lp); CP(inc_mixed); CP(blk_pair); CP(m_mask); CP(m_u); CP(m_v); CP(m_om);
+#undef CP
+  return finish_prepare(H, t0, tlast, trace);
+}
+
+// allocation + upload of a finished host structure (common to both builders)
+int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace) {
+  auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
+  const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
   std::vector<unsigned char> pt_fixed(npoint);
   for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
@@ -740,16 +1249,16 @@ int mcp_ba::prepare() {
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
   if (d_cams.upload(cams, st) || d_chain_len.upload(chain_len, st) || d_chain_pose.upload(chain_pose, st) ||
       d_pose_unk.upload(pose_unk, st) || d_pt_chain.upload(pt_chain, st) || d_pt_unk.upload(pt_unk, st) ||
-      d_pt_fixed.upload(pt_fixed, st) || d_m_pt.upload(m_pt, st) || d_m_chain.upload(m_chain, st) ||
-      d_m_cam.upload(m_cam, st) || d_m_mask.upload(m_mask, st) || d_m_u.upload(m_u, st) || d_m_v.upload(m_v, st) ||
-      d_m_omega.upload(m_om, st) || d_slot_start.upload(slot_start, st) || d_slot_unk.upload(slot_unk, st) ||
-      d_slot_inc.upload(slot_inc, st) || d_l_i0.upload(l_i0, st) || d_l_i1.upload(l_i1, st) || d_inc_unk.upload(inc_unk, st) ||
-      d_fl_point.upload(fl_point, st) || d_sp_pt.upload(sp_pt, st) || d_sp_m.upload(sp_m, st) || d_sp_i.upload(sp_i, st) ||
-      d_sp_big.upload(sp_big, st) || d_m_sp.upload(m_sp, st) || d_l_sp.upload(l_sp, st) || d_g_sp0.upload(g_sp0, st) ||
-      d_g_pose.upload(g_pose, st) || d_slot_lp.upload(slot_lp, st) || d_slot_first.upload(slot_first, st) ||
-      d_inc_lp.upload(inc_lp, st) || d_inc_mixed.upload(inc_mixed, st) ||
-      d_g_blk0.upload(g_blk0, st) || d_blk_pair.upload(blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(pair_id, st) ||
-      d_pr_start.upload(pr_start, st) || d_blk_dst.upload(blk_dst, st) || d_po_start.upload(po_start, st) || d_rhs_dst.upload(rhs_dst, st)) return -1;
+      d_pt_fixed.upload(pt_fixed, st) || d_m_pt.upload(H.m_pt, st) || d_m_chain.upload(H.m_chain, st) ||
+      d_m_cam.upload(H.m_cam, st) || d_m_mask.upload(H.m_mask, st) || d_m_u.upload(H.m_u, st) || d_m_v.upload(H.m_v, st) ||
+      d_m_omega.upload(H.m_om, st) || d_slot_start.upload(H.slot_start, st) || d_slot_unk.upload(H.slot_unk, st) ||
+      d_slot_inc.upload(H.slot_inc, st) || d_l_i0.upload(H.l_i0, st) || d_l_i1.upload(H.l_i1, st) || d_inc_unk.upload(H.inc_unk, st) ||
+      d_fl_point.upload(fl_point, st) || d_sp_pt.upload(H.sp_pt, st) || d_sp_m.upload(H.sp_m, st) || d_sp_i.upload(H.sp_i, st) ||
+      d_sp_big.upload(H.sp_big, st) || d_m_sp.upload(H.m_sp, st) || d_l_sp.upload(H.l_sp, st) || d_g_sp0.upload(H.g_sp0, st) ||
+      d_g_pose.upload(H.g_pose, st) || d_slot_lp.upload(H.slot_lp, st) || d_slot_first.upload(H.slot_first, st) ||
+      d_inc_lp.upload(H.inc_lp, st) || d_inc_mixed.upload(H.inc_mixed, st) ||
+      d_g_blk0.upload(H.g_blk0, st) || d_blk_pair.upload(H.blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(H.pair_id, st) ||
+      d_pr_start.upload(H.pr_start, st) || d_blk_dst.upload(H.blk_dst, st) || d_po_start.upload(H.po_start, st) || d_rhs_dst.upload(H.rhs_dst, st)) return -1;
   const size_t nc = chains.size();
   for (int b = 0; b < NSTATE; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*MAXC*12) ||
@@ -956,7 +1465,7 @@ int mcp_ba::multi_trial_tail(hipStream_t s, int lane, int q, int slot, int nbe, 
                              const double* pose_parts, int pose_off, bool main_block, double* mail, int mail_count, unsigned long long ticket) {
   double* T = d_trial[q].p;
   HIPCK(hipMemsetAsync(T, 0, TRIAL_LEN*sizeof(double), s));
-  const bool ride = robust && sel_ride && P.nmeas > 0;
+  const bool ride = robust && sel_ride && m_total > 0;       // (decided on GLOBAL quantities: the payload size must agree on every rank)
   if (ride) {
     const int grid = std::max(1, std::min(256, (P.nmeas + SEL_BLOCK*8 - 1)/(SEL_BLOCK*8)));
     hipLaunchKernelGGL(k_select_hist2, dim3(grid), dim3(SEL_BLOCK), 0, s, P.nmeas, (const double*)d_chi2[slot].p, pred_bin, T + TRIAL_HDR);
@@ -1576,7 +2085,7 @@ int mcp_ba_add_meas(mcp_ba* h, const int* chain, int n, int point_id, const doub
   if (c < 0) { set_err("mcp_ba_add_meas: bad chain"); return -1; }
   HMeas m; m.chain = c; m.point = h->id_index[point_id]; m.cam = cam_index; m.u = uv[0]; m.v = uv[1];
   m.omega = 1/std::sqrt(sigma_sq);                    // information = I / sqrt(sigma^2), ChainBundle.cc:1244-1245
-  h->meas.push_back(m); h->meas_point.push_back(m.point); h->dirty = true;
+  h->meas.push_back(m); h->meas_point.push_back(m.point); h->meas_chain.push_back(m.chain); h->dirty = true;
   return 0;
 }
 int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, int stride, const int* chain_len,
@@ -1590,9 +2099,51 @@ int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, 
 }
 int mcp_ba_add_measurements(mcp_ba* h, int count, const int* chains, int stride, const int* chain_len, const int* point_ids,
                             const double* uv, const double* sigma_sq, const int* cam_index) {
-  h->meas.reserve(h->meas.size() + count); h->meas_point.reserve(h->meas_point.size() + count);
-  for (int i = 0; i < count; ++i)
-    if (mcp_ba_add_meas(h, chains + (size_t)stride*i, chain_len[i], point_ids[i], uv + 2*(size_t)i, sigma_sq[i], cam_index[i])) return -1;
+  // one crossing for a whole map: the arrays are sized once and filled in place by the worker pool (same checks and the same
+  // records as `count` calls of mcp_ba_add_meas; on a bad row the rows before it stay added, as they would).  Pose chains that
+  // are known already -- all of them, normally: an observer chain (MKF, camera) was met as some point's source chain -- are
+  // resolved read-only by the threads; rows with a new chain are completed afterwards in row order, so chains are numbered as
+  // a serial replay numbers them.
+  if (count <= 0) return 0;
+  const size_t n0 = h->meas.size();
+  h->meas.resize(n0 + count); h->meas_point.resize(n0 + count); h->meas_chain.resize(n0 + count);
+  HMeas* mo = h->meas.data() + n0; int* po = h->meas_point.data() + n0; int* co = h->meas_chain.data() + n0;
+  const int ncam = (int)h->cams.size(), next_id = h->next_id;
+  const int* kind = h->id_kind.data(); const int* index = h->id_index.data();
+  HostPool& pool = host_pool();
+  const int T = (count >= 32768) ? pool.size() : 1;
+  std::vector<int> bad_row(T, count), bad_why(T, 0);
+  auto body = [&](int tid) {
+    const int lo = (int)((long)count*tid/T), hi = (int)((long)count*(tid + 1)/T);
+    int last_n = 0, last_idx = -3; const int* last_ids = nullptr;
+    for (int i = lo; i < hi; ++i) {
+      const int pid = point_ids[i], cam = cam_index[i];
+      if (pid <= 0 || pid >= next_id || kind[pid] != 2) { bad_row[tid] = i; bad_why[tid] = 1; return; }
+      if (cam < 0 || cam >= ncam) { bad_row[tid] = i; bad_why[tid] = 2; return; }
+      const int* ids = chains + (size_t)stride*i; const int n = chain_len[i];
+      int c;
+      if (last_idx >= -1 && n == last_n && std::memcmp(ids, last_ids, sizeof(int)*n) == 0) c = last_idx;
+      else { c = h->lookup_chain(ids, n); if (c == -2) { bad_row[tid] = i; bad_why[tid] = 3; return; } last_n = n; last_idx = c; last_ids = ids; }
+      HMeas& m = mo[i];
+      m.chain = c; m.point = index[pid]; m.cam = cam; m.u = uv[2*(size_t)i]; m.v = uv[2*(size_t)i + 1];
+      m.omega = 1/std::sqrt(sigma_sq[i]);                   // information = I / sqrt(sigma^2), ChainBundle.cc:1244-1245
+      po[i] = m.point; co[i] = c;
+    }
+  };
+  if (T == 1) body(0); else pool.run(body);
+  int ibad = count, why = 0;
+  for (int t = 0; t < T; ++t) if (bad_row[t] < ibad) { ibad = bad_row[t]; why = bad_why[t]; }
+  for (int i = 0; i < ibad; ++i) if (co[i] == -1) {          // chains met for the first time, in row order
+    const int c = h->find_chain(chains + (size_t)stride*i, chain_len[i]);
+    if (c < 0) { ibad = i; why = 3; break; }
+    co[i] = c; mo[i].chain = c;
+  }
+  h->dirty = true;
+  if (ibad < count) {
+    h->meas.resize(n0 + ibad); h->meas_point.resize(n0 + ibad); h->meas_chain.resize(n0 + ibad);
+    set_err(why == 1 ? "mcp_ba_add_measurements: unknown point id" : why == 2 ? "mcp_ba_add_measurements: bad camera index" : "mcp_ba_add_measurements: bad chain");
+    return -1;
+  }
   return 0;
 }
 

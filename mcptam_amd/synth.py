@@ -131,23 +131,25 @@ class Problem:
         N = self.n_points
         chains = np.zeros((N, 2), dtype=np.int32)
         chain_len = np.zeros(N, dtype=np.int32)
-        for i in range(N):
-            if self.pt_fixed[i]:
-                chains[i, 0] = world_id
-                chain_len[i] = 1
-            elif self.mode == "multi":
-                chains[i] = (mkf_id[self.pt_src[i, 0]], cam_id[self.pt_src[i, 1]])
-                chain_len[i] = 2
+        fx = np.asarray(self.pt_fixed, dtype=bool)
+        if N:
+            if self.mode == "multi":
+                chains[:, 0] = mkf_id[self.pt_src[:, 0]]
+                chains[:, 1] = cam_id[self.pt_src[:, 1]]
+                chain_len[:] = 2
             elif self.mode == "calib":
                 # BundleAdjusterCalib.cc:169-173: chain {MKF} for the first camera, {MKF, relative pose} otherwise
-                chains[i, 0] = mkf_id[self.pt_src[i, 0]]
-                chain_len[i] = 1
-                if self.pt_src[i, 1] > 0:
-                    chains[i, 1] = cam_id[self.pt_src[i, 1]]
-                    chain_len[i] = 2
+                chains[:, 0] = mkf_id[self.pt_src[:, 0]]
+                chain_len[:] = 1
+                rel = self.pt_src[:, 1] > 0
+                chains[rel, 1] = cam_id[self.pt_src[rel, 1]]
+                chain_len[rel] = 2
             else:
-                chains[i, 0] = mkf_id[self.pt_src[i, 0]]
-                chain_len[i] = 1
+                chains[:, 0] = mkf_id[self.pt_src[:, 0]]
+                chain_len[:] = 1
+            chains[fx, 0] = world_id
+            chains[fx, 1] = 0
+            chain_len[fx] = 1
         if batch and hasattr(bundle, "AddPointBatch"):
             pt_id = bundle.AddPointBatch(self.pt_x, chains, chain_len, self.pt_fixed)
         else:

@@ -839,3 +839,25 @@ def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypa
     assert base["logs"] == alt["logs"]
     assert np.array_equal(base["R"], alt["R"]) and np.array_equal(base["t"], alt["t"]) and np.array_equal(base["X"], alt["X"])
     assert base["outliers"] == alt["outliers"] and base["sigma_sq"] == alt["sigma_sq"] and base["lam"] == alt["lam"]
+
+
+@pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 8), ("calib", 6), ("c2", 6), ("metric", 5)])
+def test_threaded_prepare_builds_the_serial_structure(gpu_required, cfg, iters, monkeypatch):
+    """Prepare() builds the solver's structure on the host's worker pool (ranges of points per thread, positions known beforehand);
+    the serial reference implementation stays behind MCP_BA_PREPARE_LEGACY=1.  Same arrays => the same solve, bit for bit:
+    reduced system, iteration logs, poses, points, outlier list."""
+    from mcptam_amd import synth
+    p = synth.make_config(cfg)
+    g = _gpu(p.cams, disable_convergence=True)
+    p.populate(g)
+    S1 = g.DebugSystem(1e-3)
+    new = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    monkeypatch.setenv("MCP_BA_PREPARE_LEGACY", "1")
+    g = _gpu(p.cams, disable_convergence=True)
+    p.populate(g)
+    S0 = g.DebugSystem(1e-3)
+    old = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    for a, b in zip(S0, S1):
+        assert np.array_equal(a, b)
+    assert new["logs"] == old["logs"] and new["outliers"] == old["outliers"]
+    assert np.array_equal(new["R"], old["R"]) and np.array_equal(new["t"], old["t"]) and np.array_equal(new["X"], old["X"])
