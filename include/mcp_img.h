@@ -166,7 +166,8 @@ typedef struct mcp_td_out {
 } mcp_td_out;
 
 /* TrackerData::Project + GetDerivsUnsafe + CalcJacobian, PatchFinder::CalcSearchLevelAndWarpMatrix,
- * MakeTemplateCoarseCont (template cache neutralised: always refreshed), FindPatchCoarse,
+ * MakeTemplateCoarseCont (with a PatchFinder that has seen nothing: the template is always made; mcp_patch_sequences carries
+ * the finder's template cache from call to call), FindPatchCoarse,
  * MakeSubPixTemplate + IterateSubPixToConvergence, for n points against keyframe `target`.
  * base_from_world / cam_from_base: (R row-major 9, t 3).  range, subpix_its, exhaustive as
  * Tracker::SearchForPoints(vTD, cam, nRange, nSubPixIts, bExhaustive). */
@@ -178,6 +179,60 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double base_fr
 int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double base_from_world[12],
                            const double* cam_from_base /* ncam x 12 */, const int* n, const mcp_td_in* const* in,
                            int range, int subpix_its, int exhaustive, mcp_td_out* const* out);
+
+/* ---- PatchFinder with its members carried from call to call ------------------------------------------------------------
+ * The reference's PatchFinder is stateful (src/PatchFinder.cc:56-65): MakeTemplateCoarseCont keeps the template while it works on
+ * the same MapPoint and neither column of the warp matrix has moved by more than 0.07 (:144-181; mbTemplateBad and the sums stay
+ * too), MakeSubPixTemplate's Jacobians stay until it runs again (:362-390) and mdMeanDiff is only reset there.  What a search
+ * returns therefore depends on what the finder saw before.  mcp_pf_state holds those members; the caller owns one per PatchFinder
+ * object of the reference, zero-initialised (valid = 0) for a new one, and passes it in and out.
+ * A SEQUENCE is what one finder sees, in order (one wavefront walks it); sequences run in parallel.  Modes = the finder's callers:
+ *  MCP_PF_TRACK       Tracker::SearchForPoints (src/Tracker.cc:1299-1377).  One finder per TrackerData = per (point, camera), kept
+ *                     over the frames: one sequence of one item per tracked point.  range / subpix_its / exhaustive as there.
+ *                     (mcp_track_search* = this with finders that have seen nothing.)
+ *  MCP_PF_REFIND      MapMakerServerBase::ReFind_Common (src/MapMakerServerBase.cc:921-1002): ONE static finder over all calls --
+ *                     ReFindNewlyMade walks every keyframe with the same point, so templates are shared between keyframes with
+ *                     similar warps (one sequence per new point, one item per keyframe).  MakeTemplateCoarse ignores the verdict
+ *                     of CalcSearchLevelAndWarpMatrix; range 4 (pass it); sub-pixel iteration (8) only when the level is > 0, and
+ *                     its position is kept whether or not it converged (found stays 1, did_subpix = 1).
+ *  MCP_PF_EPI_COARSE  MapMakerServerBase::AddPointEpipolar, first loop (:745-795): one finder and ONE MapPoint object for all depth
+ *                     hypotheses of a candidate (same point_key): one sequence per candidate, one item per hypothesis.  Hypotheses
+ *                     that project outside the level-0 image / onto a zero of the target's level-0 mask are skipped; range 3.
+ *  MCP_PF_EPI_REFINE  the second loop (:827-853) on the SAME finder (pass the state the coarse sequence returned): Calc +
+ *                     MakeTemplateCoarseCont, SetSubPixPos(start_pos), IterateSubPixToConvergence(10); found = converged,
+ *                     found_pos = the sub-pixel position.
+ * mcp_td_out per item as in mcp_track_search (jacobian w.r.t. base_from_world; template_bad = the finder's flag after the item;
+ * searched = FindPatchCoarse ran).  Targets must live on one device. */
+#define MCP_PF_TRACK 0
+#define MCP_PF_REFIND 1
+#define MCP_PF_EPI_COARSE 2
+#define MCP_PF_EPI_REFINE 3
+typedef struct mcp_pf_state {
+  int     valid;          /* mpLastTemplateMapPoint != NULL                                                       */
+  int     point_key;      /* the map point the template was made for (caller's id; the reference compares &point) */
+  double  last_warp[4];   /* mm2LastWarpMatrix, row-major                                                         */
+  int     template_bad;   /* mbTemplateBad                                                                        */
+  int     jacs_valid;     /* MakeSubPixTemplate has run (mimJacs / mm3HInv hold something)                        */
+  double  mean_diff;      /* mdMeanDiff                                                                           */
+  uint8_t templ[64];      /* mimTemplate                                                                          */
+  uint8_t jac_templ[64];  /* the template mimJacs / mm3HInv were made from: differs from templ after a refresh that
+                             hit pixels outside the source image (:165-180 skips MakeSubPixTemplate then)         */
+} mcp_pf_state;
+typedef struct mcp_pf_target {
+  mcp_kf* kf;                   /* keyframe searched in (its level-0 mask, if it has one, serves MCP_PF_EPI_COARSE) */
+  const mcp_camera* cam;
+  double base_from_world[12];   /* (R row-major 9, t 3); map-maker callers pass the keyframe's CamFromWorld here ...   */
+  double cam_from_base[12];     /* ... and the identity here                                                        */
+} mcp_pf_target;
+typedef struct mcp_pf_item {
+  mcp_td_in point;
+  int point_key;                /* identity of the MapPoint object                                                  */
+  int target;                   /* index into targets[]                                                             */
+  double start_pos[2];          /* MCP_PF_EPI_REFINE: SetSubPixPos (level-0 coordinates)                            */
+} mcp_pf_item;
+int mcp_patch_sequences(int mode, int n_targets, const mcp_pf_target* targets, int n_seq, const int* seq_start /* n_seq + 1 */,
+                        const mcp_pf_item* items, mcp_pf_state* state /* n_seq, in/out */, int range, int subpix_its, int exhaustive,
+                        mcp_td_out* out /* one per item */);
 
 /* Tracker::CalcPoseUpdate (Tukey M-estimator, WLS<6> with prior 100)   Tracker.cc:1386-1512
  * found[i] != 0 rows contribute.  override_sigma <= 0: Tukey sigma^2 from the median.

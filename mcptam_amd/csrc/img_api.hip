@@ -69,6 +69,7 @@ struct mcp_kf {
   Buf<int> work;                    // threshold histogram + detected-corner count per level; k_row_compact leaves it zero again
   bool work_dirty = true;
   Buf<SearchCam> stab; Buf<DevTdIn> bt_in; Buf<mcp_td_out> bt_out;      // batched search: camera table + points of all cameras
+  Buf<PfTargetDev> pf_tab; Buf<PfItemDev> pf_items; Buf<int> pf_seq; Buf<mcp_pf_state> pf_state;      // mcp_patch_sequences
   hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
   Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
@@ -490,7 +491,7 @@ int mcp_sbi_iterate_last(mcp_kf* k, int iterations, double se2[6], double* score
 // SmallBlurryImage::SE3fromSE2 (:250-310): two points, three Gauss-Newton steps on SO3 -- control-plane arithmetic, run on the
 // host with the same camera functions the kernels use (ba_device.h is __host__ __device__)
 int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_camera* ct, double R[9]) {
-  if (!cs || !ct || cs->n_inv < 0) return img_fail("mcp_sbi_se3_from_se2: bad camera");
+  if (!cs || !ct || cs->n_inv < 0 || cs->n_inv > MCP_MAX_INV || ct->n_inv < 0 || ct->n_inv > MCP_MAX_INV) return img_fail("mcp_sbi_se3_from_se2: bad camera");
   const double c[2] = { SBI_W/2, SBI_H/2 };
   const double off[2][2] = { { 5, 0 }, { -5, 0 } };
   double turned[2][2], orig[2][3];
@@ -538,9 +539,12 @@ int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_ca
   return 0;
 }
 
+// a camera the device code may index: 0 (Newton mode) .. MCP_MAX_INV inverse-polynomial coefficients (as mcp_ba_create checks)
+static bool cam_ok(const mcp_camera* c) { return c && c->n_inv >= 0 && c->n_inv <= MCP_MAX_INV; }
+
 int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12], const double cfb[12], int n, const mcp_td_in* in,
                      int range, int subpix_its, int exhaustive, mcp_td_out* out) {
-  if (n < 0 || !cam || cam->n_inv < 0) return img_fail("mcp_track_search: bad arguments");
+  if (n < 0 || !target || !cam_ok(cam) || !bfw || !cfb || (n > 0 && (!in || !out))) return img_fail("mcp_track_search: bad arguments");
   if (n == 0) return 0;
   ICK(hipSetDevice(target->device));
   std::vector<DevTdIn> h(n);
@@ -567,7 +571,7 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
   if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
   int total = 0, maxn = 0;
   for (int c = 0; c < ncam; ++c) {
-    if (!targets[c] || n[c] < 0 || cams[c].n_inv < 0 || targets[c]->device != targets[0]->device) return img_fail("mcp_track_search_batch: bad arguments");
+    if (!targets[c] || n[c] < 0 || !cam_ok(&cams[c]) || targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || !out[c]))) return img_fail("mcp_track_search_batch: bad arguments");
     total += n[c]; maxn = std::max(maxn, n[c]);
   }
   if (total == 0) return 0;
@@ -603,6 +607,51 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
   } else
     for (int c = 0; c < ncam; ++c)
       if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + tab[c].first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
+  ICK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// PatchFinder with its members carried from call to call (include/mcp_img.h MCP_PF_*): sequences of items, one finder each
+int mcp_patch_sequences(int mode, int n_targets, const mcp_pf_target* targets, int n_seq, const int* seq_start, const mcp_pf_item* items,
+                        mcp_pf_state* state, int range, int subpix_its, int exhaustive, mcp_td_out* out) {
+  if (mode < MCP_PF_TRACK || mode > MCP_PF_EPI_REFINE || n_targets < 1 || !targets || n_seq < 0 || !seq_start || !state) return img_fail("mcp_patch_sequences: bad arguments");
+  if (n_seq == 0) return 0;
+  const int total = seq_start[n_seq];
+  if (seq_start[0] != 0 || total < 0 || (total > 0 && (!items || !out))) return img_fail("mcp_patch_sequences: bad sequence table");
+  for (int q = 0; q < n_seq; ++q) if (seq_start[q + 1] < seq_start[q]) return img_fail("mcp_patch_sequences: bad sequence table");
+  mcp_kf* k0 = targets[0].kf;
+  if (!k0) return img_fail("mcp_patch_sequences: target without a keyframe");
+  std::vector<PfTargetDev> tab(n_targets);
+  for (int t = 0; t < n_targets; ++t) {
+    const mcp_pf_target& G = targets[t];
+    if (!G.kf || !cam_ok(G.cam) || G.kf->device != k0->device) return img_fail("mcp_patch_sequences: bad target");
+    PfTargetDev& D = tab[t];
+    D.T = G.kf->view(); D.mask0 = G.kf->lev[0].has_mask ? G.kf->lev[0].mask.p : nullptr; D.cam = *G.cam;
+    std::memcpy(D.bfw.R, G.base_from_world, 72); std::memcpy(D.bfw.t, G.base_from_world + 9, 24);
+    std::memcpy(D.cfb.R, G.cam_from_base, 72); std::memcpy(D.cfb.t, G.cam_from_base + 9, 24);
+  }
+  std::vector<PfItemDev> h(std::max(total, 1));
+  for (int i = 0; i < total; ++i) {
+    const mcp_pf_item& I = items[i]; const mcp_td_in& p = I.point; PfItemDev& d = h[i];
+    if (I.target < 0 || I.target >= n_targets) return img_fail("mcp_patch_sequences: item with a bad target index");
+    if (!p.source_kf || p.source_level < 0 || p.source_level >= MCP_LEVELS) return img_fail("mcp_patch_sequences: point without a resident source keyframe");
+    std::memcpy(d.p.world_pos, p.world_pos, 24); std::memcpy(d.p.pixel_right_w, p.pixel_right_w, 24); std::memcpy(d.p.pixel_down_w, p.pixel_down_w, 24);
+    const Level& Sl = p.source_kf->lev[p.source_level];
+    d.p.src_img = Sl.img.p; d.p.src_w = Sl.w; d.p.src_h = Sl.h; d.p.center_x = p.center_x; d.p.center_y = p.center_y; d.p.fixed = p.fixed;
+    d.point_key = I.point_key; d.target = I.target; d.start_x = I.start_pos[0]; d.start_y = I.start_pos[1];
+  }
+  ICK(hipSetDevice(k0->device));
+  hipStream_t st = k0->st;
+  if (k0->pf_tab.alloc(n_targets) || k0->pf_items.alloc(std::max(total, 1)) || k0->pf_seq.alloc(n_seq + 1) || k0->pf_state.alloc(n_seq) || k0->bt_out.alloc(std::max(total, 1))) return -1;
+  ICK(hipMemcpyAsync(k0->pf_tab.p, tab.data(), sizeof(PfTargetDev)*(size_t)n_targets, hipMemcpyHostToDevice, st));
+  if (total) ICK(hipMemcpyAsync(k0->pf_items.p, h.data(), sizeof(PfItemDev)*(size_t)total, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->pf_seq.p, seq_start, sizeof(int)*(size_t)(n_seq + 1), hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->pf_state.p, state, sizeof(mcp_pf_state)*(size_t)n_seq, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_patch_sequences, dim3(n_seq), dim3(64), 0, st, mode, (const PfTargetDev*)k0->pf_tab.p, n_seq, (const int*)k0->pf_seq.p,
+                     (const PfItemDev*)k0->pf_items.p, k0->pf_state.p, range, subpix_its, exhaustive, k0->bt_out.p);
+  ICK(hipGetLastError());
+  if (total) ICK(hipMemcpyAsync(out, k0->bt_out.p, sizeof(mcp_td_out)*(size_t)total, hipMemcpyDeviceToHost, st));
+  ICK(hipMemcpyAsync(state, k0->pf_state.p, sizeof(mcp_pf_state)*(size_t)n_seq, hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
   return 0;
 }

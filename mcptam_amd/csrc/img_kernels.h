@@ -451,21 +451,86 @@ struct DevTdIn {
 };
 
 
-// one tracked point, one wavefront
-__device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp_camera& cam, const Se3& bfw, const Se3& cfb, const DevTdIn& P, mcp_td_out& O,
-                                                   int range, int subpix_its, int exhaustive, uint8_t* tmpl, double (*dprod)[36], int lane) {
+// ---- PatchFinder as a stateful object (src/PatchFinder.cc:56-65): what survives a call -- the template cache of
+// MakeTemplateCoarseCont (:144-181: mpLastTemplateMapPoint, mm2LastWarpMatrix, mimTemplate, mbTemplateBad), the template the
+// sub-pixel Jacobians were last made from (MakeSubPixTemplate :362-390) and mdMeanDiff.  Scalars are wave-uniform registers,
+// the two templates live in LDS (tmpl / jtmpl).  Callers and their differences: see mcp_img.h MCP_PF_*.
+struct PfRegs { int valid, key, bad, jvalid; double lw[4]; double mean; };
+constexpr int PF_TRACK = 0, PF_REFIND = 1, PF_EPI_COARSE = 2, PF_EPI_REFINE = 3;
+
+// IterateSubPixToConvergence (:392-410) / IterateSubPix (:415-472) from sp[]: Jacobians of jtmpl, differences against tmpl, mean
+// difference carried in `mean`; returns 1 converged, 0 iterations used up, -1 left the image.  Lanes 0..35 own the interior pixels.
+__device__ __forceinline__ int pf_iterate(const uint8_t* __restrict__ limg, int lw, int lh, int scale, const uint8_t* tmpl, const uint8_t* jtmpl,
+                                          double sp[2], double& mean, int its, double (*dprod)[36], int lane) {
+  const int sy = lane/6 + 1, sx = lane%6 + 1;
+  double gx = 0, gy = 0;
+  if (lane < 36) { gx = 0.5*((int)jtmpl[8*sy + sx + 1] - (int)jtmpl[8*sy + sx - 1]); gy = 0.5*((int)jtmpl[8*(sy + 1) + sx] - (int)jtmpl[8*(sy - 1) + sx]); }
+  // J^T J: sums of multiples of 1/4 -- exact in any order
+  double H[9];
+  { const double g[3] = { gx, gy, lane < 36 ? 1.0 : 0.0 };
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { double v = g[a]*g[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        H[3*a + b] = v; } }
+  double Hi[9];
+  { const double c00 = H[4]*H[8] - H[5]*H[7], c01 = H[5]*H[6] - H[3]*H[8], c02 = H[3]*H[7] - H[4]*H[6];
+    const double det = H[0]*c00 + H[1]*c01 + H[2]*c02, id = 1.0/det;
+    Hi[0] = c00*id; Hi[1] = (H[2]*H[7] - H[1]*H[8])*id; Hi[2] = (H[1]*H[5] - H[2]*H[4])*id;
+    Hi[3] = c01*id; Hi[4] = (H[0]*H[8] - H[2]*H[6])*id; Hi[5] = (H[2]*H[3] - H[0]*H[5])*id;
+    Hi[6] = c02*id; Hi[7] = (H[1]*H[6] - H[0]*H[7])*id; Hi[8] = (H[0]*H[4] - H[1]*H[3])*id; }
+  int conv = 0;
+  for (int it = 0; it < its && conv == 0; ++it) {
+    const double cx = (sp[0] + 0.5)/scale - 0.5, cy = (sp[1] + 0.5)/scale - 0.5;
+    const int rx = (int)round(cx), ry = (int)round(cy);
+    if (!(rx >= 5 && ry >= 5 && rx < lw - 5 && ry < lh - 5)) { conv = -1; break; }
+    const double bxs = cx - 4, bys = cy - 4;
+    const double dX = bxs - floor(bxs), dY = bys - floor(bys);
+    const float fTL = (float)((1.0 - dX)*(1.0 - dY)), fTR = (float)(dX*(1.0 - dY)), fBL = (float)((1.0 - dX)*dY), fBR = (float)(dX*dY);
+    if (lane < 36) {
+      const uint8_t* q = limg + (size_t)((int)bys + sy)*lw + (int)bxs + sx;
+      float fPixel = fTL*(float)q[0] + fTR*(float)q[1];
+      fPixel = fPixel + fBL*(float)q[lw];
+      fPixel = fPixel + fBR*(float)q[lw + 1];
+      const double d = (double)fPixel - (double)tmpl[8*sy + sx] + mean;
+      dprod[0][lane] = d*gx; dprod[1][lane] = d*gy; dprod[2][lane] = d;
+    }
+    __syncthreads();
+    double acc[3] = {0, 0, 0};          // summed in the reference's pixel order for bit-equal rounding
+    for (int q = 0; q < 36; ++q) { acc[0] += dprod[0][q]; acc[1] += dprod[1][q]; acc[2] += dprod[2][q]; }
+    __syncthreads();
+    double up[3]; mat3_vec(Hi, acc, up);
+    sp[0] -= up[0]*scale; sp[1] -= up[1]*scale; mean -= up[2];
+    const double u2 = up[0]*up[0] + up[1]*up[1];
+    if (u2 < 0.03*0.03) conv = 1;
+  }
+  return conv;
+}
+
+// one item of one finder, one wavefront (control flow is wave-uniform: every lane computes the geometry redundantly)
+__device__ __forceinline__ void patch_item(int mode, const DevKfView& T, const uint8_t* __restrict__ mask0, const mcp_camera& cam, const Se3& bfw, const Se3& cfb,
+                                           const DevTdIn& P, int point_key, double start_x, double start_y, PfRegs& S, uint8_t* tmpl, uint8_t* jtmpl,
+                                           mcp_td_out& O, int range, int subpix_its, int exhaustive, double (*dprod)[36], int lane) {
   const int MAXSSD = 8*8*250;
-  // all lanes compute the (uniform) geometry redundantly
   Se3 cfw; se3_compose(cfb, bfw, cfw);
   double xc[3]; se3_apply(cfw, P.world_pos, xc);
   Projection pr; cam_project<true>(cam, xc, pr);
-  bool in_image = !pr.invalid;
-  if (in_image && (pr.u < 0 || pr.v < 0 || pr.u > cam.image_size[0] || pr.v > cam.image_size[1])) in_image = false;
+  bool go = true;
+  if (mode == PF_TRACK || mode == PF_REFIND) {          // TrackerData.h:102-119; MapMakerServerBase.cc:941-953
+    go = !pr.invalid && !(pr.u < 0 || pr.v < 0 || pr.u > cam.image_size[0] || pr.v > cam.image_size[1]);
+  } else if (mode == PF_EPI_COARSE) {                   // :757-765: Invalid(), in_image(CVD::ir(v2Image)), mask == 0
+    go = !pr.invalid;
+    if (go) { const int ix = (int)pr.u, iy = (int)pr.v; go = ix >= 0 && iy >= 0 && ix < T.w[0] && iy < T.h[0] && !(mask0 && mask0[(size_t)iy*T.w[0] + ix] == 0); }
+  }
+  const bool in_image = go ? !pr.invalid : false;
   int level = -1, template_bad = 0, searched = 0, found = 0, did_subpix = 0, bx = 0, by = 0, best = MAXSSD + 1;
   double WI[4] = {0, 0, 0, 0}, J[12], fpos[2] = {0, 0}, sinv = 0;
 #pragma unroll
   for (int k = 0; k < 12; ++k) J[k] = 0;
-  if (in_image) {
+  bool have_templ = false;
+  if (go) {
     double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
     double xb[3]; se3_apply(bfw, P.world_pos, xb);
 #pragma unroll
@@ -482,141 +547,128 @@ __device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp
     double dDet = WI[0]*WI[3] - WI[1]*WI[2];
     int lv = 0;
     while (dDet > 3 && lv < MCP_LEVELS - 1) { lv++; dDet *= 0.25; }
-    if (dDet > 3 || dDet < 0.5 || !isfinite(dDet)) template_bad = 1; else level = lv;
+    const bool rejected = (dDet > 3 || dDet < 0.5 || !isfinite(dDet));
+    if (rejected) {
+      S.bad = 1;                                        // PatchFinder.cc:116-117: the member is set before -1 is returned
+      if (mode == PF_TRACK || mode == PF_EPI_COARSE) { template_bad = 1; go = false; }     // FindPVS drops the point; MapMakerServerBase.cc:769-770
+    }
+    if (go) level = lv;
   }
-  if (level >= 0) {
+  if (go) {
     const int scale = 1 << level;
     double m2[4];
     { const double det = WI[0]*WI[3] - WI[1]*WI[2], id = 1.0/det;
       m2[0] = WI[3]*id*scale; m2[3] = WI[0]*id*scale; m2[2] = -WI[2]*id*scale; m2[1] = -WI[1]*id*scale; }
-    // CVD::transform: incremental source position, replayed up to this lane's pixel so that it rounds identically
-    const int iw = P.src_w, ih = P.src_h;
-    const double across[2] = { m2[0], m2[2] }, down[2] = { m2[1], m2[3] };
-    double p0[2] = { (double)P.center_x - (m2[0]*4.0 + m2[1]*4.0), (double)P.center_y - (m2[2]*4.0 + m2[3]*4.0) };
-    double min_x = p0[0], min_y = p0[1], max_x = min_x, max_y = min_y;
-    if (across[0] < 0) min_x += 8*across[0]; else max_x += 8*across[0];
-    if (down[0] < 0) min_x += 8*down[0]; else max_x += 8*down[0];
-    if (across[1] < 0) min_y += 8*across[1]; else max_y += 8*across[1];
-    if (down[1] < 0) min_y += 8*down[1]; else max_y += 8*down[1];
-    const double cr[2] = { down[0] - 8*across[0], down[1] - 8*across[1] };
-    const bool inside = (min_x >= 0 && min_y >= 0 && max_x < iw - 1 && max_y < ih - 1);
-    double p[2] = { p0[0], p0[1] };
-    for (int q = 0; q < lane; ++q) { p[0] += across[0]; p[1] += across[1]; if ((q & 7) == 7) { p[0] += cr[0]; p[1] += cr[1]; } }
-    bool outside = false; int tv = 0;
-    if (inside || (0 <= p[0] && 0 <= p[1] && p[0] < (double)(iw - 1) && p[1] < (double)(ih - 1))) {
-      const int lx = (int)p[0], ly = (int)p[1];
-      const double x = p[0] - lx, y = p[1] - ly;
-      const uint8_t* q = P.src_img + (size_t)ly*iw + lx;
-      const double v = (1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]);
-      tv = (int)(uint8_t)v;
-    } else outside = true;
-    tmpl[lane] = (uint8_t)tv;
-    O.templ[lane] = (uint8_t)tv;
-    __syncthreads();
-    if (__ballot(outside) != 0ull) template_bad = 1;
-    else {
-      const int tsum = wave_sum_i(tv), tsumsq = wave_sum_i(tv*tv);
-      const bool bex = P.fixed || exhaustive;
-      const int its = bex ? 10 : subpix_its;
+    // MakeTemplateCoarseCont :135-182: keep the template while the finder works on the same map point and neither column of the
+    // warp matrix has moved by more than 0.07
+    bool refresh = !S.valid || S.key != point_key;
+    for (int c = 0; !refresh && c < 2; ++c) { const double d0 = m2[c] - S.lw[c], d1 = m2[2 + c] - S.lw[2 + c]; if (d0*d0 + d1*d1 > 0.07*0.07) refresh = true; }
+    if (refresh) {
+      // CVD::transform: incremental source position, replayed up to this lane's pixel so that it rounds identically
+      const int iw = P.src_w, ih = P.src_h;
+      const double across[2] = { m2[0], m2[2] }, down[2] = { m2[1], m2[3] };
+      double p0[2] = { (double)P.center_x - (m2[0]*4.0 + m2[1]*4.0), (double)P.center_y - (m2[2]*4.0 + m2[3]*4.0) };
+      double min_x = p0[0], min_y = p0[1], max_x = min_x, max_y = min_y;
+      if (across[0] < 0) min_x += 8*across[0]; else max_x += 8*across[0];
+      if (down[0] < 0) min_x += 8*down[0]; else max_x += 8*down[0];
+      if (across[1] < 0) min_y += 8*across[1]; else max_y += 8*across[1];
+      if (down[1] < 0) min_y += 8*down[1]; else max_y += 8*down[1];
+      const double cr[2] = { down[0] - 8*across[0], down[1] - 8*across[1] };
+      const bool inside = (min_x >= 0 && min_y >= 0 && max_x < iw - 1 && max_y < ih - 1);
+      double p[2] = { p0[0], p0[1] };
+      for (int q = 0; q < lane; ++q) { p[0] += across[0]; p[1] += across[1]; if ((q & 7) == 7) { p[0] += cr[0]; p[1] += cr[1]; } }
+      bool outside = false; int tv = 0;
+      if (inside || (0 <= p[0] && 0 <= p[1] && p[0] < (double)(iw - 1) && p[1] < (double)(ih - 1))) {
+        const int lx = (int)p[0], ly = (int)p[1];
+        const double x = p[0] - lx, y = p[1] - ly;
+        const uint8_t* q = P.src_img + (size_t)ly*iw + lx;
+        const double v = (1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]);
+        tv = (int)(uint8_t)v;
+      } else outside = true;
+      __syncthreads();
+      tmpl[lane] = (uint8_t)tv;
+      S.bad = (__ballot(outside) != 0ull) ? 1 : 0;
+      S.valid = 1; S.key = point_key; S.lw[0] = m2[0]; S.lw[1] = m2[1]; S.lw[2] = m2[2]; S.lw[3] = m2[3];
+      if (!S.bad) { jtmpl[lane] = (uint8_t)tv; S.jvalid = 1; S.mean = 0.0; }               // MakeSubPixTemplate :176-177
+      __syncthreads();
+    }
+    have_templ = true;
+    template_bad = S.bad;
+    const int tv = tmpl[lane];
+    if (!(S.bad && mode != PF_EPI_REFINE)) {            // Tracker.cc:1316; MapMakerServerBase.cc:774, 958 (the refinement loop does not look)
       const int lw = T.w[level], lh = T.h[level];
       const uint8_t* limg = T.img[level];
-      int px = (int)pr.u, py = (int)pr.v;
-      px = px/scale; py = py/scale;
-      const unsigned nr = ((unsigned)range + scale - 1)/scale;
-      int top = py - (int)nr, bot1 = py + (int)nr + 1, left = px - (int)nr, right = px + (int)nr;
-      searched = 1;
-      bool early = false;
-      if (top < 0) top = 0;
-      if (top >= lh) early = true;
-      if (bot1 <= 0) early = true;
-      if (left < 0) left = 0;
-      if (left >= lw) early = true;
-      if (!early) {
-        // candidates in reference order; one candidate per lane, first-best arg-min
-        int nc, c0 = 0, bw = 0;
-        if (bex) { const int yb = min(bot1, lh), xr = min(right, lw - 1); bw = xr - left + 1; nc = (bw > 0 && yb > top) ? bw*(yb - top) : 0; }
-        else { c0 = T.lut[level][top]; const int c1 = (bot1 >= lh) ? T.info[level]->n_corners : T.lut[level][bot1]; nc = c1 - c0; }
-        int mybest = MAXSSD + 1, myidx = 0x7fffffff, mx = 0, my = 0;
-        for (int c = lane; c < nc; c += 64) {
-          int x, y;
-          if (bex) { x = left + c % bw; y = top + c / bw; }
-          else { x = T.corners[level][c0 + c].x; y = T.corners[level][c0 + c].y; if (x < left || x > right) continue; }
-          if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
-          int s;
-          if (!(x >= 4 && y >= 4 && x < lw - 4 && y < lh - 4)) s = MAXSSD + 1;
-          else {
-            int isum = 0, isumsq = 0, cross = 0;
-            for (int r = 0; r < 8; ++r) { const uint8_t* ip = limg + (size_t)(y - 4 + r)*lw + x - 4;
+      if (mode == PF_EPI_REFINE) {                       // :845-851: SetSubPixPos, IterateSubPixToConvergence(kfTarget, 10)
+        sinv = 1.0/scale; did_subpix = 1;
+        double sp[2] = { start_x, start_y };
+        const int conv = S.jvalid ? pf_iterate(limg, lw, lh, scale, tmpl, jtmpl, sp, S.mean, 10, dprod, lane) : 0;
+        found = (conv == 1); fpos[0] = sp[0]; fpos[1] = sp[1];
+      } else {
+        const int tsum = wave_sum_i(tv), tsumsq = wave_sum_i(tv*tv);
+        const bool bex = (mode == PF_TRACK) && (P.fixed || exhaustive);
+        const int its = bex ? 10 : subpix_its;
+        int px = (int)pr.u, py = (int)pr.v;
+        px = px/scale; py = py/scale;
+        const unsigned nr = ((unsigned)range + scale - 1)/scale;
+        int top = py - (int)nr, bot1 = py + (int)nr + 1, left = px - (int)nr, right = px + (int)nr;
+        searched = 1;
+        bool early = false;
+        if (top < 0) top = 0;
+        if (top >= lh) early = true;
+        if (bot1 <= 0) early = true;
+        if (left < 0) left = 0;
+        if (left >= lw) early = true;
+        if (!early) {
+          // candidates in reference order; one candidate per lane, first-best arg-min
+          int nc, c0 = 0, bw = 0;
+          if (bex) { const int yb = min(bot1, lh), xr = min(right, lw - 1); bw = xr - left + 1; nc = (bw > 0 && yb > top) ? bw*(yb - top) : 0; }
+          else { c0 = T.lut[level][top]; const int c1 = (bot1 >= lh) ? T.info[level]->n_corners : T.lut[level][bot1]; nc = c1 - c0; }
+          int mybest = MAXSSD + 1, myidx = 0x7fffffff, mx = 0, my = 0;
+          for (int c = lane; c < nc; c += 64) {
+            int x, y;
+            if (bex) { x = left + c % bw; y = top + c / bw; }
+            else { x = T.corners[level][c0 + c].x; y = T.corners[level][c0 + c].y; if (x < left || x > right) continue; }
+            if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+            int s2;
+            if (!(x >= 4 && y >= 4 && x < lw - 4 && y < lh - 4)) s2 = MAXSSD + 1;
+            else {
+              int isum = 0, isumsq = 0, cross = 0;
+              for (int r = 0; r < 8; ++r) { const uint8_t* ip = limg + (size_t)(y - 4 + r)*lw + x - 4;
 #pragma unroll
-              for (int k = 0; k < 8; ++k) { const int v = ip[k]; isum += v; isumsq += v*v; cross += v*(int)tmpl[8*r + k]; } }
-            s = ((2*tsum*isum - tsum*tsum - isum*isum)/64 + isumsq + tsumsq - 2*cross);
-          }
-          if (s < mybest) { mybest = s; myidx = c; mx = x; my = y; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const int ob = __shfl_xor(mybest, o, 64), oi = __shfl_xor(myidx, o, 64), ox = __shfl_xor(mx, o, 64), oy = __shfl_xor(my, o, 64);
-          if (ob < mybest || (ob == mybest && oi < myidx)) { mybest = ob; myidx = oi; mx = ox; my = oy; }
-        }
-        best = mybest;
-        if (best < MAXSSD) {
-          found = 1; bx = mx; by = my;
-          const double coarse[2] = { (bx + 0.5)*scale - 0.5, (by + 0.5)*scale - 0.5 };
-          sinv = 1.0/scale; fpos[0] = coarse[0]; fpos[1] = coarse[1];
-          if (its > 0) {
-            did_subpix = 1;
-            // MakeSubPixTemplate: lanes 0..35 own the interior pixels (y outer, x inner)
-            const int sy = lane/6 + 1, sx = lane%6 + 1;
-            double gx = 0, gy = 0;
-            if (lane < 36) { gx = 0.5*((int)tmpl[8*sy + sx + 1] - (int)tmpl[8*sy + sx - 1]); gy = 0.5*((int)tmpl[8*(sy + 1) + sx] - (int)tmpl[8*(sy - 1) + sx]); }
-            // J^T J: sums of multiples of 1/4 -- exact in any order
-            double H[9];
-            { const double g[3] = { gx, gy, lane < 36 ? 1.0 : 0.0 };
-#pragma unroll
-              for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) { double v = g[a]*g[b];
-#pragma unroll
-                  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                  H[3*a + b] = v; } }
-            double Hi[9];
-            { const double c00 = H[4]*H[8] - H[5]*H[7], c01 = H[5]*H[6] - H[3]*H[8], c02 = H[3]*H[7] - H[4]*H[6];
-              const double det = H[0]*c00 + H[1]*c01 + H[2]*c02, id = 1.0/det;
-              Hi[0] = c00*id; Hi[1] = (H[2]*H[7] - H[1]*H[8])*id; Hi[2] = (H[1]*H[5] - H[2]*H[4])*id;
-              Hi[3] = c01*id; Hi[4] = (H[0]*H[8] - H[2]*H[6])*id; Hi[5] = (H[2]*H[3] - H[0]*H[5])*id;
-              Hi[6] = c02*id; Hi[7] = (H[1]*H[6] - H[0]*H[7])*id; Hi[8] = (H[0]*H[4] - H[1]*H[3])*id; }
-            double sp[2] = { coarse[0], coarse[1] }, mean = 0.0;
-            int conv = 0;
-            for (int it = 0; it < its && conv == 0; ++it) {
-              const double cx = (sp[0] + 0.5)/scale - 0.5, cy = (sp[1] + 0.5)/scale - 0.5;
-              const int rx = (int)round(cx), ry = (int)round(cy);
-              if (!(rx >= 5 && ry >= 5 && rx < lw - 5 && ry < lh - 5)) { conv = -1; break; }
-              const double bxs = cx - 4, bys = cy - 4;
-              const double dX = bxs - floor(bxs), dY = bys - floor(bys);
-              const float fTL = (float)((1.0 - dX)*(1.0 - dY)), fTR = (float)(dX*(1.0 - dY)), fBL = (float)((1.0 - dX)*dY), fBR = (float)(dX*dY);
-              if (lane < 36) {
-                const uint8_t* q = limg + (size_t)((int)bys + sy)*lw + (int)bxs + sx;
-                float fPixel = fTL*(float)q[0] + fTR*(float)q[1];
-                fPixel = fPixel + fBL*(float)q[lw];
-                fPixel = fPixel + fBR*(float)q[lw + 1];
-                const double d = (double)fPixel - (double)tmpl[8*sy + sx] + mean;
-                dprod[0][lane] = d*gx; dprod[1][lane] = d*gy; dprod[2][lane] = d;
-              }
-              __syncthreads();
-              double acc[3] = {0, 0, 0};          // summed in the reference's pixel order for bit-equal rounding
-              for (int q = 0; q < 36; ++q) { acc[0] += dprod[0][q]; acc[1] += dprod[1][q]; acc[2] += dprod[2][q]; }
-              __syncthreads();
-              double up[3]; mat3_vec(Hi, acc, up);
-              sp[0] -= up[0]*scale; sp[1] -= up[1]*scale; mean -= up[2];
-              const double u2 = up[0]*up[0] + up[1]*up[1];
-              if (u2 < 0.03*0.03) conv = 1;
+                for (int k = 0; k < 8; ++k) { const int v = ip[k]; isum += v; isumsq += v*v; cross += v*(int)tmpl[8*r + k]; } }
+              s2 = ((2*tsum*isum - tsum*tsum - isum*isum)/64 + isumsq + tsumsq - 2*cross);
             }
-            if (conv != 1) found = 0; else { fpos[0] = sp[0]; fpos[1] = sp[1]; }
+            if (s2 < mybest) { mybest = s2; myidx = c; mx = x; my = y; }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const int ob = __shfl_xor(mybest, o, 64), oi = __shfl_xor(myidx, o, 64), ox = __shfl_xor(mx, o, 64), oy = __shfl_xor(my, o, 64);
+            if (ob < mybest || (ob == mybest && oi < myidx)) { mybest = ob; myidx = oi; mx = ox; my = oy; }
+          }
+          best = mybest;
+          if (best < MAXSSD) {
+            found = 1; bx = mx; by = my;
+            const double coarse[2] = { (bx + 0.5)*scale - 0.5, (by + 0.5)*scale - 0.5 };
+            sinv = 1.0/scale; fpos[0] = coarse[0]; fpos[1] = coarse[1];
+            if (mode == PF_TRACK && its > 0) {                                              // Tracker.cc:1350-1366
+              did_subpix = 1;
+              __syncthreads(); jtmpl[lane] = tmpl[lane]; S.jvalid = 1; S.mean = 0.0; __syncthreads();      // MakeSubPixTemplate
+              double sp[2] = { coarse[0], coarse[1] };
+              const int conv = pf_iterate(limg, lw, lh, scale, tmpl, jtmpl, sp, S.mean, its, dprod, lane);
+              if (conv != 1) found = 0; else { fpos[0] = sp[0]; fpos[1] = sp[1]; }
+            } else if (mode == PF_REFIND && level > 0) {                                    // MapMakerServerBase.cc:981-987: eight iterations, result kept either way
+              did_subpix = 1;
+              __syncthreads(); jtmpl[lane] = tmpl[lane]; S.jvalid = 1; S.mean = 0.0; __syncthreads();
+              double sp[2] = { coarse[0], coarse[1] };
+              (void)pf_iterate(limg, lw, lh, scale, tmpl, jtmpl, sp, S.mean, 8, dprod, lane);
+              fpos[0] = sp[0]; fpos[1] = sp[1];
+            }
           }
         }
       }
     }
   }
+  O.templ[lane] = have_templ ? tmpl[lane] : (uint8_t)0;
   if (lane == 0) {
     O.image[0] = pr.u; O.image[1] = pr.v;
 #pragma unroll
@@ -627,28 +679,63 @@ __device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp
     O.in_image = in_image; O.search_level = level; O.template_bad = template_bad; O.searched = searched;
     O.found = found; O.did_subpix = did_subpix; O.coarse_x = bx; O.coarse_y = by; O.score = best;
   }
-  if (level < 0 || !in_image) O.templ[lane] = 0;
+}
+
+// one tracked point, one wavefront: Tracker::SearchForPoints with a PatchFinder that has seen nothing yet (the per-frame batch
+// entries; a caller that keeps the finders across frames uses k_patch_sequences)
+__device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp_camera& cam, const Se3& bfw, const Se3& cfb, const DevTdIn& P, mcp_td_out& O,
+                                                   int range, int subpix_its, int exhaustive, uint8_t* tmpl, uint8_t* jtmpl, double (*dprod)[36], int lane) {
+  PfRegs S; S.valid = 0; S.key = -1; S.bad = 0; S.jvalid = 0; S.lw[0] = S.lw[1] = S.lw[2] = S.lw[3] = 0.0; S.mean = 0.0;
+  patch_item(PF_TRACK, T, nullptr, cam, bfw, cfb, P, 0, 0.0, 0.0, S, tmpl, jtmpl, O, range, subpix_its, exhaustive, dprod, lane);
 }
 __global__ void __launch_bounds__(64)
 k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTdIn* __restrict__ in, int range,
                int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
-  __shared__ uint8_t tmpl[64];
+  __shared__ uint8_t tmpl[64], jtmpl[64];
   __shared__ double dprod[3][36];
   const int pi = blockIdx.x;
   if (pi >= n) return;
-  track_search_point(T, cam, bfw, cfb, in[pi], out[pi], range, subpix_its, exhaustive, tmpl, dprod, threadIdx.x);
+  track_search_point(T, cam, bfw, cfb, in[pi], out[pi], range, subpix_its, exhaustive, tmpl, jtmpl, dprod, threadIdx.x);
 }
 // the cameras of a frame in one launch (blockIdx.y = camera); the per-camera views, models and poses sit in a device table
 struct SearchCam { DevKfView T; mcp_camera cam; Se3 cfb; int n, first; };
 __global__ void __launch_bounds__(64)
 k_track_search_batch(const SearchCam* __restrict__ tab, Se3 bfw, const DevTdIn* __restrict__ in, int range, int subpix_its, int exhaustive,
                      mcp_td_out* __restrict__ out) {
-  __shared__ uint8_t tmpl[64];
+  __shared__ uint8_t tmpl[64], jtmpl[64];
   __shared__ double dprod[3][36];
   const SearchCam& S = tab[blockIdx.y];
   const int pi = blockIdx.x;
   if (pi >= S.n) return;
-  track_search_point(S.T, S.cam, bfw, S.cfb, in[S.first + pi], out[S.first + pi], range, subpix_its, exhaustive, tmpl, dprod, threadIdx.x);
+  track_search_point(S.T, S.cam, bfw, S.cfb, in[S.first + pi], out[S.first + pi], range, subpix_its, exhaustive, tmpl, jtmpl, dprod, threadIdx.x);
+}
+// Sequences of items through stateful finders: one wavefront per sequence, items in order, the finder's members in registers /
+// LDS between them and in `state` before and after.  tab: the targets (keyframe view, camera, poses; SearchCam::n / first unused).
+struct PfItemDev { DevTdIn p; int point_key, target; double start_x, start_y; };
+struct PfTargetDev { DevKfView T; const uint8_t* mask0; mcp_camera cam; Se3 bfw, cfb; };
+__global__ void __launch_bounds__(64)
+k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, const int* __restrict__ seq_start, const PfItemDev* __restrict__ items,
+                  mcp_pf_state* __restrict__ state, int range, int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
+  __shared__ uint8_t tmpl[64], jtmpl[64];
+  __shared__ double dprod[3][36];
+  const int sq = blockIdx.x, lane = threadIdx.x;
+  if (sq >= n_seq) return;
+  mcp_pf_state& G = state[sq];
+  PfRegs S; S.valid = G.valid; S.key = G.point_key; S.bad = G.template_bad; S.jvalid = G.jacs_valid; S.mean = G.mean_diff;
+  S.lw[0] = G.last_warp[0]; S.lw[1] = G.last_warp[1]; S.lw[2] = G.last_warp[2]; S.lw[3] = G.last_warp[3];
+  tmpl[lane] = G.templ[lane]; jtmpl[lane] = G.jac_templ[lane];
+  __syncthreads();
+  for (int i = seq_start[sq]; i < seq_start[sq + 1]; ++i) {
+    const PfItemDev& I = items[i];
+    const PfTargetDev& Tg = tab[I.target];
+    patch_item(mode, Tg.T, Tg.mask0, Tg.cam, Tg.bfw, Tg.cfb, I.p, I.point_key, I.start_x, I.start_y, S, tmpl, jtmpl, out[i], range, subpix_its, exhaustive, dprod, lane);
+    __syncthreads();
+  }
+  G.templ[lane] = tmpl[lane]; G.jac_templ[lane] = jtmpl[lane];
+  if (lane == 0) {
+    G.valid = S.valid; G.point_key = S.key; G.template_bad = S.bad; G.jacs_valid = S.jvalid; G.mean_diff = S.mean;
+    G.last_warp[0] = S.lw[0]; G.last_warp[1] = S.lw[1]; G.last_warp[2] = S.lw[2]; G.last_warp[3] = S.lw[3];
+  }
 }
 
 // ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------

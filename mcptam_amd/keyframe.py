@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_make_lite_batch", "mcp_track_search_batch", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_patch_sequences", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -83,6 +83,8 @@ def lib():
         L.mcp_kf_get_candidates.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, c_double_p, ctypes.c_int]
         L.mcp_minipatch_find.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mcp_patch_sequences.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.mcp_track_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.mcp_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
@@ -285,6 +287,62 @@ def track_search(target, cam, base_from_world, cam_from_base, points, rng, subpi
     _chk(lib().mcp_track_search(target._h, ctypes.byref(cs), _dp(b), _dp(c), len(points), ctypes.cast(arr, ctypes.c_void_p),
                                 int(rng), int(subpix_its), int(exhaustive), out.ctypes.data), "track_search")
     return out
+
+
+PF_TRACK, PF_REFIND, PF_EPI_COARSE, PF_EPI_REFINE = 0, 1, 2, 3
+PF_STATE_DTYPE = np.dtype([("valid", "i4"), ("point_key", "i4"), ("last_warp", "f8", 4), ("template_bad", "i4"), ("jacs_valid", "i4"),
+                           ("mean_diff", "f8"), ("templ", "u1", 64), ("jac_templ", "u1", 64)], align=True)
+assert PF_STATE_DTYPE.itemsize == 184
+
+
+class PfTarget(ctypes.Structure):
+    _fields_ = [("kf", ctypes.c_void_p), ("cam", ctypes.c_void_p), ("base_from_world", ctypes.c_double * 12), ("cam_from_base", ctypes.c_double * 12)]
+
+
+class PfItem(ctypes.Structure):
+    _fields_ = [("point", TdIn), ("point_key", ctypes.c_int), ("target", ctypes.c_int), ("start_pos", ctypes.c_double * 2)]
+
+
+def new_pf_states(n):
+    """n PatchFinder objects that have seen nothing (include/mcp_img.h mcp_pf_state)."""
+    return np.zeros(n, dtype=PF_STATE_DTYPE)
+
+
+def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaustive=False, fn=None, handle_of=None):
+    """mcp_patch_sequences: `targets` = list of (keyframe, camera, base_from_world (R, t), cam_from_base (R, t)); `sequences` = list of
+    lists of items dict(point=<point dict>, point_key, target, start_pos=(x, y)); `states` (new_pf_states) is updated in place.
+    Returns one TD_OUT_DTYPE array over all items in order.  fn / handle_of: the oracle's entry point and handle accessor (tests)."""
+    handle_of = handle_of or (lambda kf: kf._h)
+    cams = [t[1].to_struct() for t in targets]
+    tab = (PfTarget * len(targets))()
+    for i, (kf, _cam, bfw, cfb) in enumerate(targets):
+        tab[i].kf = handle_of(kf)
+        tab[i].cam = ctypes.addressof(cams[i])
+        b, c = _pose12(*bfw), _pose12(*cfb)
+        for k in range(12):
+            tab[i].base_from_world[k] = b[k]
+            tab[i].cam_from_base[k] = c[k]
+    flat = [it for seq in sequences for it in seq]
+    seq_start = np.zeros(len(sequences) + 1, dtype=np.int32)
+    seq_start[1:] = np.cumsum([len(s_) for s_ in sequences])
+    pts = pack_points([it["point"] for it in flat], handle_of if fn is None else (lambda kf: kf))
+    items = (PfItem * max(len(flat), 1))()
+    for i, it in enumerate(flat):
+        ctypes.memmove(ctypes.addressof(items[i].point), ctypes.addressof(pts[i]), ctypes.sizeof(TdIn))
+        items[i].point_key = int(it.get("point_key", 0))
+        items[i].target = int(it.get("target", 0))
+        sp = it.get("start_pos", (0.0, 0.0))
+        items[i].start_pos[0], items[i].start_pos[1] = float(sp[0]), float(sp[1])
+    out = np.zeros(max(len(flat), 1), dtype=TD_OUT_DTYPE)
+    assert states.dtype == PF_STATE_DTYPE and len(states) == len(sequences)
+    f = fn or lib().mcp_patch_sequences
+    rc = f(int(mode), len(targets), ctypes.cast(tab, ctypes.c_void_p), len(sequences), seq_start.ctypes.data, ctypes.cast(items, ctypes.c_void_p),
+           states.ctypes.data, int(rng), int(subpix_its), int(exhaustive), out.ctypes.data)
+    if fn is None:
+        _chk(rc, "patch_sequences")
+    else:
+        assert rc == 0
+    return out[:len(flat)]
 
 
 def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):

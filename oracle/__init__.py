@@ -425,6 +425,17 @@ def oracle_track_search(target, cam, base_from_world, cam_from_base, points, rng
     return out
 
 
+def oracle_patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaustive=False):
+    """CPU restatement of the stateful PatchFinder flows (same signature as mcptam_amd.keyframe.patch_sequences); the point dicts
+    carry the oracle's keyframe under 'source_kf_oracle', targets hold OracleKeyFrame objects."""
+    from mcptam_amd import keyframe as kf
+    L = img_lib()
+    L.orc_patch_sequences.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    seqs = [[dict(it, point=dict(it["point"], source_kf=it["point"]["source_kf_oracle"]._h)) for it in seq] for seq in sequences]
+    return kf.patch_sequences(mode, targets, seqs, states, rng, subpix_its, exhaustive, fn=L.orc_patch_sequences, handle_of=lambda k: k._h)
+
+
 def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):
     found = np.ascontiguousarray(found, dtype=np.uint8)
     n = found.shape[0]

@@ -539,6 +539,200 @@ int orc_track_search(orc_kf* target, const orc_camera* cam, const double bfw[12]
   return 0;
 }
 
+/* ------------------------------------------------------------------ PatchFinder as a stateful object
+ * The reference's PatchFinder keeps members across calls (src/PatchFinder.cc:56-65): the template cache of MakeTemplateCoarseCont
+ * (mpLastTemplateMapPoint, mm2LastWarpMatrix, mimTemplate, mbTemplateBad; :144-181), the sub-pixel Jacobians made by the last
+ * MakeSubPixTemplate (mimJacs, mm3HInv; :362-390) and mdMeanDiff.  Its callers use that differently:
+ *   ORC_PF_TRACK       Tracker::SearchForPoints (src/Tracker.cc:1299-1377): one finder per TrackerData, i.e. per (point, camera),
+ *                      living over the frames; a point whose warp CalcSearchLevelAndWarpMatrix rejects never gets here (FindPVS)
+ *   ORC_PF_REFIND      MapMakerServerBase::ReFind_Common (src/MapMakerServerBase.cc:921-1002): one static finder over all calls;
+ *                      MakeTemplateCoarse = Calc + MakeTemplateCoarseCont WITHOUT looking at Calc's verdict (a refreshed template
+ *                      overwrites mbTemplateBad); range 4; sub-pixel only above level 0, eight iterations, position kept whether
+ *                      it converged or not (:981-987)
+ *   ORC_PF_EPI_COARSE  MapMakerServerBase::AddPointEpipolar, first loop (:745-795): ONE finder and ONE MapPoint object over all depth
+ *                      hypotheses -- the cache compares &point, so a template is kept while the warp moves less than 0.07, and a
+ *                      rejected warp leaves mbTemplateBad = true for the next hypothesis that keeps its template
+ *   ORC_PF_EPI_REFINE  the same function's second loop (:827-853): Calc + MakeTemplateCoarseCont (verdicts ignored), SetSubPixPos,
+ *                      IterateSubPixToConvergence(10) with whatever mimJacs / mdMeanDiff the finder holds (MakeSubPixTemplate only
+ *                      ran if the template was refreshed and good)
+ * A sequence = the items one finder sees, in order; state[seq] is that finder's members, in and out. */
+static void pf_make_subpix_template(orc_pf_state* S) {          /* MakeSubPixTemplate :362-390 (mv2SubPixPos is set by every caller afterwards) */
+  memcpy(S->jac_templ, S->templ, 64); S->jacs_valid = 1; S->mean_diff = 0.0;
+}
+/* IterateSubPixToConvergence :392-410 + IterateSubPix :415-472 from sp[] with the finder's Jacobian template and mean difference;
+ * returns 1 converged, 0 iterations used up, -1 left the image; sp / S->mean_diff hold the last state either way */
+static int pf_iterate(const olevel* L, int scale, orc_pf_state* S, double sp[2], int max_its) {
+  double jx[36], jy[36], H[9] = {0,0,0,0,0,0,0,0,0};
+  const uint8_t* JT = S->jac_templ;
+  for (int x = 1; x < 7; x++) for (int y = 1; y < 7; y++) {
+    const double gx = 0.5*(JT[8*y + x + 1] - JT[8*y + x - 1]);
+    const double gy = 0.5*(JT[8*(y + 1) + x] - JT[8*(y - 1) + x]);
+    jx[(y - 1)*6 + x - 1] = gx; jy[(y - 1)*6 + x - 1] = gy;
+    const double g[3] = { gx, gy, 1.0 };
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) H[3*a + b] += g[a]*g[b];
+  }
+  double Hinv[9]; inv3(H, Hinv);
+  double mean = S->mean_diff;
+  int converged = 0;
+  for (int it = 0; it < max_its && !converged; it++) {
+    const double cx = (sp[0] + 0.5)/scale - 0.5, cy = (sp[1] + 0.5)/scale - 0.5;           /* LevelNPos */
+    const int rx = (int)round(cx), ry = (int)round(cy);
+    if (!in_border(L, rx, ry, 5)) { converged = -1; break; }
+    const double bxs = cx - 4, bys = cy - 4;
+    const double dX = bxs - floor(bxs), dY = bys - floor(bys);
+    const float fTL = (float)((1.0 - dX)*(1.0 - dY)), fTR = (float)(dX*(1.0 - dY)), fBL = (float)((1.0 - dX)*dY), fBR = (float)(dX*dY);
+    double acc[3] = {0, 0, 0};
+    for (int y = 1; y < 7; y++) {
+      const uint8_t* q = L->img + (size_t)((int)bys + y)*L->w + (int)bxs + 1;
+      for (int x = 1; x < 7; x++) {
+        float fPixel = fTL*q[0] + fTR*q[1] + fBL*q[L->w] + fBR*q[L->w + 1];
+        q++;
+        const double d = fPixel - S->templ[8*y + x] + mean;
+        acc[0] += d*jx[(y - 1)*6 + x - 1]; acc[1] += d*jy[(y - 1)*6 + x - 1]; acc[2] += d;
+      }
+    }
+    double up[3]; m3v(Hinv, acc, up);
+    sp[0] -= up[0]*scale; sp[1] -= up[1]*scale; mean -= up[2];
+    const double u2 = up[0]*up[0] + up[1]*up[1];
+    if (u2 < 0.03*0.03) converged = 1;
+  }
+  S->mean_diff = mean;
+  return converged;
+}
+int orc_patch_sequences(int mode, int n_targets, const orc_pf_target* targets, int n_seq, const int* seq_start, const orc_pf_item* items,
+                        orc_pf_state* state, int range, int subpix_its, int exhaustive, orc_td_out* out) {
+  const int MAXSSD = 8*8*250;
+  for (int sq = 0; sq < n_seq; sq++) {
+    orc_pf_state* S = &state[sq];
+    for (int ii = seq_start[sq]; ii < seq_start[sq + 1]; ii++) {
+      const orc_pf_item* I = &items[ii]; const orc_td_in* p = &I->point; orc_td_out* o = &out[ii];
+      if (I->target < 0 || I->target >= n_targets) return -1;
+      const orc_pf_target* G = &targets[I->target];
+      const orc_camera* cam = G->cam; const double* bfw = G->base_from_world; const double* cfb = G->cam_from_base;
+      double Rcw[9], tcw[3];
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rcw[3*i+j] = cfb[3*i]*bfw[j] + cfb[3*i+1]*bfw[3+j] + cfb[3*i+2]*bfw[6+j];
+      m3v(cfb, bfw + 9, tcw); tcw[0] += cfb[9]; tcw[1] += cfb[10]; tcw[2] += cfb[11];
+      memset(o, 0, sizeof *o); o->search_level = -1; o->score = MAXSSD + 1;
+      double xc[3]; m3v(Rcw, p->world_pos, xc); xc[0] += tcw[0]; xc[1] += tcw[1]; xc[2] += tcw[2];
+      const int invalid = orc_cam_project(cam, xc, o->image, o->cam_derivs);
+      const olevel* L0 = &G->kf->lev[0];
+      if (mode == ORC_PF_TRACK || mode == ORC_PF_REFIND) {                                    /* TrackerData.h:102-119; MapMakerServerBase.cc:941-953 */
+        if (invalid) continue;
+        if (o->image[0] < 0 || o->image[1] < 0 || o->image[0] > cam->image_size[0] || o->image[1] > cam->image_size[1]) continue;
+      } else if (mode == ORC_PF_EPI_COARSE) {                                                 /* :757-765: Invalid, in_image(CVD::ir(v2Image)), mask == 0 */
+        if (invalid) continue;
+        const int ix = (int)o->image[0], iy = (int)o->image[1];
+        if (!(ix >= 0 && iy >= 0 && ix < L0->w && iy < L0->h)) continue;
+        if (L0->mask[(size_t)iy*L0->w + ix] == 0) continue;
+      }
+      o->in_image = !invalid;
+      double dT[3], dP[3]; orc_cam_sphere_deriv(xc, dT, dP);
+      { double xb[3]; m3v(bfw, p->world_pos, xb); xb[0] += bfw[9]; xb[1] += bfw[10]; xb[2] += bfw[11];
+        for (int m = 0; m < 6; m++) {
+          double mb[3], mc[3]; gen_field(m, xb, mb); m3v(cfb, mb, mc);
+          const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+          o->jacobian[m] = o->cam_derivs[0]*s0 + o->cam_derivs[1]*s1; o->jacobian[6 + m] = o->cam_derivs[2]*s0 + o->cam_derivs[3]*s1;
+        } }
+      /* CalcSearchLevelAndWarpMatrix :69-122 */
+      double mr[3], md[3]; m3v(Rcw, p->pixel_right_w, mr); m3v(Rcw, p->pixel_down_w, md);
+      const double sr0 = dT[0]*mr[0] + dT[1]*mr[1] + dT[2]*mr[2], sr1 = dP[0]*mr[0] + dP[1]*mr[1] + dP[2]*mr[2];
+      const double sd0 = dT[0]*md[0] + dT[1]*md[1] + dT[2]*md[2], sd1 = dP[0]*md[0] + dP[1]*md[1] + dP[2]*md[2];
+      double* WI = o->warp_inverse;
+      WI[0] = o->cam_derivs[0]*sr0 + o->cam_derivs[1]*sr1; WI[2] = o->cam_derivs[2]*sr0 + o->cam_derivs[3]*sr1;
+      WI[1] = o->cam_derivs[0]*sd0 + o->cam_derivs[1]*sd1; WI[3] = o->cam_derivs[2]*sd0 + o->cam_derivs[3]*sd1;
+      double dDet = WI[0]*WI[3] - WI[1]*WI[2];
+      int level = 0;
+      while (dDet > 3 && level < ORC_LEVELS - 1) { level++; dDet *= 0.25; }
+      const int rejected = (dDet > 3 || dDet < 0.5 || !isfinite(dDet));
+      if (rejected) {
+        S->template_bad = 1;                                                                    /* :116-117: the member is set before returning -1 */
+        if (mode == ORC_PF_TRACK || mode == ORC_PF_EPI_COARSE) { o->template_bad = 1; continue; }     /* FindPVS drops the point; :769-770 `continue` */
+      }
+      o->search_level = level;
+      /* MakeTemplateCoarseCont :135-182 */
+      const int scale = 1 << level;
+      double m2[4];
+      { const double det = WI[0]*WI[3] - WI[1]*WI[2], id = 1.0/det;                         /* opts::M2Inverse, SmallMatrixOpts.h:67-79 */
+        m2[0] = WI[3]*id*scale; m2[3] = WI[0]*id*scale; m2[2] = -WI[2]*id*scale; m2[1] = -WI[1]*id*scale; }
+      int refresh = !S->valid || S->point_key != I->point_key;
+      for (int c = 0; !refresh && c < 2; c++) {                                               /* columns: m2.T()[c] = (m2[0][c], m2[1][c]) */
+        const double d0 = m2[c] - S->last_warp[c], d1 = m2[2 + c] - S->last_warp[2 + c];
+        if (d0*d0 + d1*d1 > 0.07*0.07) refresh = 1;
+      }
+      if (refresh) {
+        const olevel* SL = &p->source_kf->lev[p->source_level];
+        const int outside = cvd_transform8(SL, S->templ, m2, p->center_x, p->center_y, 4, 4);
+        S->template_bad = outside ? 1 : 0;
+        S->valid = 1; S->point_key = I->point_key; memcpy(S->last_warp, m2, sizeof m2);
+        if (!S->template_bad) pf_make_subpix_template(S);
+      }
+      memcpy(o->templ, S->templ, 64); o->template_bad = S->template_bad;
+      if (S->template_bad && mode != ORC_PF_EPI_REFINE) continue;                            /* Tracker.cc:1316; MapMakerServerBase.cc:774, 958 */
+      int tsum = 0, tsumsq = 0;                                                                 /* MakeTemplateSums :209-224 */
+      for (int q = 0; q < 64; q++) { tsum += S->templ[q]; tsumsq += S->templ[q]*S->templ[q]; }
+      const olevel* L = &G->kf->lev[level];
+      if (mode == ORC_PF_EPI_REFINE) {                                                        /* :845-851 */
+        o->sqrt_inv_noise = 1.0/scale; o->did_subpix = 1;
+        double sp[2] = { I->start_pos[0], I->start_pos[1] };
+        const int conv = S->jacs_valid ? pf_iterate(L, scale, S, sp, 10) : 0;
+        o->found = (conv == 1); o->found_pos[0] = sp[0]; o->found_pos[1] = sp[1];
+        continue;
+      }
+      /* FindPatchCoarse :229-355 */
+      const int bex = (mode == ORC_PF_TRACK) && (p->fixed || exhaustive);
+      int its = subpix_its; if (bex) its = 10;                                                  /* Tracker.cc:1326-1331 */
+      int px = (int)o->image[0], py = (int)o->image[1];                                         /* CVD::ir truncation */
+      px = px/scale; py = py/scale;
+      const unsigned nr = ((unsigned)range + scale - 1)/scale;
+      int top = py - (int)nr, bot1 = py + (int)nr + 1, left = px - (int)nr, right = px + (int)nr;
+      o->searched = 1;
+      int best = MAXSSD + 1, bx = 0, by = 0, early = 0;
+      if (top < 0) top = 0;
+      if (top >= L->h) early = 1;
+      if (bot1 <= 0) early = 1;
+      if (left < 0) left = 0;
+      if (left >= L->w) early = 1;
+      if (early) { o->found = 0; continue; }
+      if (bex) {
+        for (int y = top; y < bot1 && y < L->h; y++) for (int x = left; x <= right && x < L->w; x++) {
+          if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+          const int s = zmssd(L, S->templ, tsum, tsumsq, x, y);
+          if (s < best) { bx = x; by = y; best = s; }
+        }
+      } else {
+        const int c0 = L->lut[top], c1 = (bot1 >= L->h) ? L->ncorners : L->lut[bot1];
+        for (int c = c0; c < c1; c++) {
+          const int x = L->corners[c].x, y = L->corners[c].y;
+          if (x < left || x > right) continue;
+          if ((unsigned)((px - x)*(px - x) + (py - y)*(py - y)) > nr*nr) continue;
+          const int s = zmssd(L, S->templ, tsum, tsumsq, x, y);
+          if (s < best) { bx = x; by = y; best = s; }
+        }
+      }
+      o->score = best;
+      if (!(best < MAXSSD)) { o->found = 0; continue; }
+      o->found = 1; o->coarse_x = bx; o->coarse_y = by;
+      double coarse[2] = { (bx + 0.5)*scale - 0.5, (by + 0.5)*scale - 0.5 };                   /* LevelZeroPos */
+      o->sqrt_inv_noise = 1.0/scale;
+      o->found_pos[0] = coarse[0]; o->found_pos[1] = coarse[1];
+      if (mode == ORC_PF_TRACK && its > 0) {                                                    /* Tracker.cc:1350-1366 */
+        o->did_subpix = 1;
+        pf_make_subpix_template(S);
+        double sp[2] = { coarse[0], coarse[1] };
+        if (pf_iterate(L, scale, S, sp, its) != 1) { o->found = 0; continue; }
+        o->found_pos[0] = sp[0]; o->found_pos[1] = sp[1];
+      } else if (mode == ORC_PF_REFIND && level > 0) {                                          /* MapMakerServerBase.cc:981-987 */
+        o->did_subpix = 1;
+        pf_make_subpix_template(S);
+        double sp[2] = { coarse[0], coarse[1] };
+        (void)pf_iterate(L, scale, S, sp, 8);
+        o->found_pos[0] = sp[0]; o->found_pos[1] = sp[1];
+      }
+    }
+  }
+  return 0;
+}
+
 static int cmp_d(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
 /* Tracker::CalcPoseUpdate with the Tukey estimator and TooN WLS<6> [3P-memory], Tracker.cc:1386-1512 */
 int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sin,

@@ -66,6 +66,15 @@ typedef struct orc_td_out {
 int orc_track_search(orc_kf* target, const orc_camera* cam, const double base_from_world[12],
                      const double cam_from_base[12], int n, const orc_td_in* in, int range,
                      int subpix_its, int exhaustive, orc_td_out* out);
+/* PatchFinder with its members carried from call to call: the template cache and the sub-pixel state (see img_oracle.c) */
+typedef struct orc_pf_state {
+  int valid, point_key; double last_warp[4]; int template_bad, jacs_valid; double mean_diff; uint8_t templ[64], jac_templ[64];
+} orc_pf_state;
+typedef struct orc_pf_target { orc_kf* kf; const struct orc_camera* cam; double base_from_world[12], cam_from_base[12]; } orc_pf_target;
+typedef struct orc_pf_item { orc_td_in point; int point_key, target; double start_pos[2]; } orc_pf_item;
+enum { ORC_PF_TRACK = 0, ORC_PF_REFIND = 1, ORC_PF_EPI_COARSE = 2, ORC_PF_EPI_REFINE = 3 };
+int orc_patch_sequences(int mode, int n_targets, const orc_pf_target* targets, int n_seq, const int* seq_start, const orc_pf_item* items,
+                        orc_pf_state* state, int range, int subpix_its, int exhaustive, orc_td_out* out);
 int orc_track_pose_update(int n, const uint8_t* found, const double* found_pos, const double* image_pos,
                           const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
                           double mu[6], double* weights_out, double* sigma_sq_out);

@@ -667,3 +667,119 @@ def test_c5_eight_camera_frame_in_one_submission_beside_window_ba(gpu_required):
     for r in result["ba"]:
         assert r["rc"] == ref_ba["rc"] and r["logs"] == ref_ba["logs"]
         assert np.array_equal(r["R"], ref_ba["R"]) and np.array_equal(r["t"], ref_ba["t"]) and np.array_equal(r["X"], ref_ba["X"])
+
+
+def _assert_states_equal(sg, so):
+    for f in ("valid", "point_key", "template_bad", "jacs_valid", "templ", "last_warp"):
+        assert np.array_equal(sg[f], so[f]), f
+    jv = so["jacs_valid"] == 1
+    assert np.array_equal(sg["jac_templ"][jv], so["jac_templ"][jv])
+    assert np.allclose(sg["mean_diff"], so["mean_diff"], rtol=0, atol=1e-9)
+
+
+def _moved(pose, drot, dt):
+    from mcptam_amd.synth import so3_exp
+    R, t = pose
+    return so3_exp(np.asarray(drot, dtype=np.float64)) @ R, np.asarray(t) + np.asarray(dt)
+
+
+def test_template_cache_over_a_frame_sequence_matches_oracle(gpu_required, scene):
+    """PatchFinder::MakeTemplateCoarseCont's cache (src/PatchFinder.cc:144-181) through mcp_patch_sequences, one finder per tracked
+    point carried over three frames (creep, creep, jump): outputs AND the finders' members equal the oracle's after every frame;
+    in the creep frames the template bytes are frame 1's although a fresh warp would give others."""
+    from mcptam_amd import keyframe as kf
+    from oracle import oracle_patch_sequences
+    gA, oA = _pair(640, 480); gB, oB = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    gB.MakeKeyFrame_Lite(scene["imgB"]); oB.MakeKeyFrame_Lite(scene["imgB"])
+    pts = _points(scene, gA, oA)
+    pts[5]["fixed"] = 1
+    I = (np.eye(3), np.zeros(3))
+    cam = scene["cam"]
+    poses = [scene["poseB"], _moved(scene["poseB"], (0.0004, -0.0003, 0.0015), (0.004, -0.002, 0.003)),
+             _moved(scene["poseB"], (0.0006, -0.0002, 0.0025), (0.006, -0.001, 0.005)), _moved(scene["poseB"], (0.01, 0.02, 0.25), (0.05, 0.02, 0.4))]
+    seqs = [[dict(point=p, point_key=i, target=0)] for i, p in enumerate(pts)]
+    sg, so = kf.new_pf_states(len(pts)), kf.new_pf_states(len(pts))
+    first = None
+    for fi, pose in enumerate(poses):
+        og = kf.patch_sequences(kf.PF_TRACK, [(gB, cam, pose, I)], seqs, sg, 10, 8)
+        oo = oracle_patch_sequences(kf.PF_TRACK, [(oB, cam, pose, I)], seqs, so, 10, 8)
+        assert_track_equal(og, oo)
+        assert np.allclose(og["found_pos"], oo["found_pos"], rtol=0, atol=1e-9)
+        _assert_states_equal(sg, so)
+        if fi == 0:
+            first = og.copy()
+        elif fi < 3:
+            fresh = kf.track_search(gB, cam, pose, I, pts, 10, 8)
+            same = (og["templ"] == first["templ"]).all(axis=1) & (og["search_level"] >= 0) & (first["search_level"] >= 0)
+            assert same.sum() > 0.7 * len(pts)
+            assert ((fresh["templ"] != og["templ"]).any(axis=1) & same).sum() >= 5, "the cache must be observable"
+    fresh = kf.track_search(gB, cam, poses[3], I, pts, 10, 8)
+    assert_track_equal(og, fresh)                                      # after the jump every template was remade
+
+
+def test_map_maker_patchfinder_flows_match_oracle(gpu_required, scene):
+    """SURVEY.md 8(f)-1, both map-side callers with the reference's stateful PatchFinder: MapMakerServerBase::ReFind_Common
+    (src/MapMakerServerBase.cc:921-1002; one new point walked over several keyframes by ONE finder, sub-pixel only above level 0 and
+    kept unconverged) and AddPointEpipolar's two loops (:745-853; one finder and one MapPoint over all depth hypotheses, then
+    IterateSubPixToConvergence(10) from the caller's start position on the same finder) -- device against oracle, items and states."""
+    from mcptam_amd import keyframe as kf, synth_img
+    from oracle import oracle_patch_sequences
+    gA, oA = _pair(640, 480); gB, oB = _pair(640, 480); gC, oC = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    mask0 = np.full((480, 640), 255, dtype=np.uint8); mask0[:, 400:] = 0               # a static mask on the right part of the target
+    gB.MakeKeyFrame_Lite(scene["imgB"], [mask0, None, None, None]); oB.MakeKeyFrame_Lite(scene["imgB"], [mask0, None, None, None])
+    gC.MakeKeyFrame_Lite(scene["imgB"]); oC.MakeKeyFrame_Lite(scene["imgB"])
+    pts = _points(scene, gA, oA)
+    I = (np.eye(3), np.zeros(3))
+    cam = scene["cam"]
+    poseB = scene["poseB"]
+    poseC = _moved(poseB, (0.0003, -0.0002, 0.001), (0.003, -0.001, 0.002))            # a keyframe whose warps differ by < 0.07 from B's
+    # ---- ReFindNewlyMade: every point over the keyframes C (pose B), C again seen from a slightly different pose: 2 items per sequence
+    tg_g = [(gC, cam, poseB, I), (gC, cam, poseC, I)]
+    tg_o = [(oC, cam, poseB, I), (oC, cam, poseC, I)]
+    sub = pts[::3]
+    seqs = [[dict(point=p, point_key=i, target=0), dict(point=p, point_key=i, target=1)] for i, p in enumerate(sub)]
+    sg, so = kf.new_pf_states(len(sub)), kf.new_pf_states(len(sub))
+    rg = kf.patch_sequences(kf.PF_REFIND, tg_g, seqs, sg, 4)
+    ro = oracle_patch_sequences(kf.PF_REFIND, tg_o, seqs, so, 4)
+    assert_track_equal(rg, ro)
+    assert np.allclose(rg["found_pos"], ro["found_pos"], rtol=0, atol=1e-9)
+    _assert_states_equal(sg, so)
+    second = rg[1::2]
+    assert ((second["templ"] == rg[0::2]["templ"]).all(axis=1) & (second["search_level"] >= 0)).sum() > 0.7 * len(sub)      # second keyframe: cached template
+    up = (rg["found"] == 1) & (rg["search_level"] > 0)
+    assert up.any() and (rg["did_subpix"][up] == 1).all() and (rg["did_subpix"][(rg["found"] == 1) & (rg["search_level"] == 0)] == 0).all()
+    # ---- AddPointEpipolar: 20 candidates x 45 hypotheses, one finder per candidate; the mask removes the hypotheses projecting right of x = 400
+    cand, _ = gA.Candidates(1)
+    cand = cand[::max(1, len(cand) // 20)][:20]
+    scales = np.concatenate([np.linspace(5.0, 7.0, 41), [7.0], np.linspace(7.0, 7.05, 3)])
+    seqs, allh = [], []
+    for ci, c in enumerate(cand):
+        hyp = [synth_img.hypothesis_point(cam, gA, oA, scene["poseA"], c, 1, s_) for s_ in scales]
+        for k in ("pixel_right_w", "pixel_down_w"):
+            hyp[41][k] = np.asarray(hyp[41][k]) * 0.3                                  # a hypothesis CalcSearchLevelAndWarpMatrix rejects
+        allh.append(hyp)
+        seqs.append([dict(point=h, point_key=100 + ci, target=0) for h in hyp])
+    sg, so = kf.new_pf_states(len(cand)), kf.new_pf_states(len(cand))
+    eg = kf.patch_sequences(kf.PF_EPI_COARSE, [(gB, cam, poseB, I)], seqs, sg, 3)
+    eo = oracle_patch_sequences(kf.PF_EPI_COARSE, [(oB, cam, poseB, I)], seqs, so, 3)
+    assert_track_equal(eg, eo)
+    _assert_states_equal(sg, so)
+    eg2 = eg.reshape(len(cand), len(scales))
+    assert (eg2["in_image"][eg2["image"][:, :, 0] >= 401] == 0).all() and (eg2["in_image"] == 1).any()       # masked hypotheses are skipped
+    live = eg2["in_image"][:, 40] == 1
+    assert live.any() and (eg2["template_bad"][live, 42] == 1).all() and (eg2["searched"][live, 42] == 0).all()      # poisoned by the rejected warp before it
+    # second loop: the best one to three hypotheses per candidate, in score order, on the same finders
+    ref_seqs = []
+    for ci in range(len(cand)):
+        f = np.nonzero(eg2["found"][ci] == 1)[0]
+        order = f[np.argsort(eg2["score"][ci][f], kind="stable")][:3]
+        ref_seqs.append([dict(point=allh[ci][j], point_key=100 + ci, target=0, start_pos=eg2["found_pos"][ci][j]) for j in order])
+    assert sum(len(s_) for s_ in ref_seqs) >= 10
+    fg = kf.patch_sequences(kf.PF_EPI_REFINE, [(gB, cam, poseB, I)], ref_seqs, sg, 3)
+    fo = oracle_patch_sequences(kf.PF_EPI_REFINE, [(oB, cam, poseB, I)], ref_seqs, so, 3)
+    assert_track_equal(fg, fo)
+    assert np.allclose(fg["found_pos"], fo["found_pos"], rtol=0, atol=1e-9)
+    _assert_states_equal(sg, so)
+    assert (fg["found"] == 1).sum() >= 0.5 * len(fg) and (fg["did_subpix"] == 1).all()

@@ -1272,3 +1272,143 @@ def test_recent_window_selection():
     o = _orc(q.cams)
     q.populate(o)
     assert o.Compute(5) == 5
+
+
+def _pf_scene():
+    from mcptam_amd import synth_img
+    from oracle import OracleKeyFrame
+    sc = synth_img.make_tracking_scene(size=(320, 240))
+    A, B = OracleKeyFrame(320, 240), OracleKeyFrame(320, 240)
+    A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"]); A.MakeKeyFrame_Rest()
+    pts = synth_img.make_map_points(sc["cam"], A, A, sc["poseA"], sc["depth"], per_level=(80, 50, 30, 10))
+    return sc, A, B, pts
+
+
+def _moved(pose, drot, dt):
+    from mcptam_amd.synth import so3_exp
+    R, t = pose
+    return so3_exp(np.asarray(drot, dtype=np.float64)) @ R, np.asarray(t) + np.asarray(dt)
+
+
+def test_stateful_patchfinder_reduces_to_the_stateless_search():
+    """orc_patch_sequences in tracker mode with PatchFinders that have seen nothing = orc_track_search, field by field."""
+    from mcptam_amd import keyframe as kf
+    from oracle import oracle_track_search, oracle_patch_sequences
+    sc, A, B, pts = _pf_scene()
+    I = (np.eye(3), np.zeros(3))
+    pts[3]["fixed"] = 1
+    for rng, its in ((10, 8), (30, 0)):
+        ref = oracle_track_search(B, sc["cam"], sc["poseB"], I, pts, rng, its)
+        st = kf.new_pf_states(len(pts))
+        seqs = [[dict(point=p, point_key=i, target=0)] for i, p in enumerate(pts)]
+        got = oracle_patch_sequences(kf.PF_TRACK, [(B, sc["cam"], sc["poseB"], I)], seqs, st, rng, its)
+        for f in ref.dtype.names:
+            assert np.array_equal(ref[f], got[f]), f
+        ok = ref["search_level"] >= 0
+        assert np.array_equal(st["valid"][ok], np.ones(ok.sum(), dtype=np.int32)) and (st["valid"][~ok & (ref["in_image"] == 1)] == 0).all()
+
+
+def test_template_cache_keeps_the_template_while_the_warp_barely_moves():
+    """PatchFinder::MakeTemplateCoarseCont (src/PatchFinder.cc:144-181): a TrackerData's finder keeps its template from frame to
+    frame while neither column of the warp matrix has moved by more than 0.07, and makes a new one when it has.  Three frames:
+    the camera creeps (templates of frame 1 must be reused even where a fresh warp would give other bytes), then jumps."""
+    from mcptam_amd import keyframe as kf
+    from oracle import oracle_patch_sequences, oracle_track_search
+    sc, A, B, pts = _pf_scene()
+    I = (np.eye(3), np.zeros(3))
+    cam = sc["cam"]
+    pose1 = sc["poseB"]
+    pose2 = _moved(pose1, (0.0004, -0.0003, 0.0015), (0.004, -0.002, 0.003))          # a creep: warps move by ~1e-3
+    pose3 = _moved(pose1, (0.01, 0.02, 0.25), (0.05, 0.02, 0.4))                      # a jump: in-plane rotation + approach
+    seqs = [[dict(point=p, point_key=i, target=0)] for i, p in enumerate(pts)]
+    st = kf.new_pf_states(len(pts))
+    f1 = oracle_patch_sequences(kf.PF_TRACK, [(B, cam, pose1, I)], seqs, st, 10, 8)
+    s1 = st.copy()
+    f2 = oracle_patch_sequences(kf.PF_TRACK, [(B, cam, pose2, I)], seqs, st, 10, 8)
+    s2 = st.copy()
+    f3 = oracle_patch_sequences(kf.PF_TRACK, [(B, cam, pose3, I)], seqs, st, 10, 8)
+    fresh2 = oracle_track_search(B, cam, pose2, I, pts, 10, 8)
+    fresh3 = oracle_track_search(B, cam, pose3, I, pts, 10, 8)
+
+    def m2(out):       # the matrix MakeTemplateCoarseCont compares: inverse(warp_inverse) * 2^level
+        W = out["warp_inverse"].reshape(-1, 2, 2)
+        return np.linalg.inv(W) * (2.0 ** out["search_level"])[:, None, None]
+    both = (f1["search_level"] >= 0) & (f2["search_level"] >= 0)
+    col = np.linalg.norm(m2(f2)[both] - s1["last_warp"].reshape(-1, 2, 2)[both], axis=1)      # column norms of the difference
+    kept = np.zeros(len(pts), dtype=bool); kept[np.nonzero(both)[0]] = (col <= 0.07).all(axis=1)
+    assert kept.sum() > 0.8 * both.sum(), "the creep should stay inside the refresh limit for most points"
+    assert np.array_equal(f2["templ"][kept], f1["templ"][kept])                      # kept: frame 1's bytes ...
+    differs = (fresh2["templ"][kept] != f1["templ"][kept]).any(axis=1)
+    assert differs.sum() >= 3, "the scenario must contain templates a fresh warp would change, or it shows nothing"
+    assert np.array_equal(s2["last_warp"][kept], s1["last_warp"][kept])              # ... and the stored matrix is NOT advanced
+    refreshed = both & ~kept
+    assert np.array_equal(f2["templ"][refreshed], fresh2["templ"][refreshed])
+    # a search with the kept template scores differently from a fresh one exactly where the bytes differ
+    idx = np.nonzero(kept)[0][differs]
+    assert (f2["score"][idx] != fresh2["score"][idx]).any()
+    # frame 3: every warp moved by more than the limit -> all refreshed -> the stateless result
+    both3 = f3["search_level"] >= 0
+    assert np.array_equal(f3["templ"][both3], fresh3["templ"][both3]) and np.array_equal(f3["score"], fresh3["score"])
+    assert np.array_equal(f3["found"], fresh3["found"])
+
+
+def test_refind_and_epipolar_flows_of_the_stateful_patchfinder():
+    """MapMakerServerBase::ReFind_Common (src/MapMakerServerBase.cc:921-1002) and AddPointEpipolar's two PatchFinder loops (:745-853)
+    on the oracle: ReFind keeps a sub-pixel position that did not converge and refines only above level 0; the epipolar loops share
+    ONE finder and ONE MapPoint, so consecutive hypotheses reuse a template while the warp moves < 0.07 and a rejected warp poisons
+    mbTemplateBad for the next hypothesis that keeps its template; the refinement stage starts from the caller's position."""
+    from mcptam_amd import keyframe as kf, synth_img
+    from oracle import oracle_patch_sequences, oracle_track_search
+    sc, A, B, pts = _pf_scene()
+    I = (np.eye(3), np.zeros(3))
+    cam = sc["cam"]
+    tg = [(B, cam, sc["poseB"], I)]
+    # ---- ReFind: one sequence per point (ReFindNewlyMade walks the keyframes with one point; here one keyframe)
+    seqs = [[dict(point=p, point_key=i, target=0)] for i, p in enumerate(pts)]
+    st = kf.new_pf_states(len(pts))
+    rf = oracle_patch_sequences(kf.PF_REFIND, tg, seqs, st, 4)
+    tr8 = oracle_track_search(B, cam, sc["poseB"], I, pts, 4, 8)         # tracker semantics, same range, 8 iterations
+    tr0 = oracle_track_search(B, cam, sc["poseB"], I, pts, 4, 0)
+    ok = tr0["search_level"] >= 0
+    assert np.array_equal(rf["score"][ok], tr0["score"][ok]) and np.array_equal(rf["coarse_x"][ok], tr0["coarse_x"][ok])
+    found = ok & (tr0["found"] == 1)
+    lvl0 = found & (rf["search_level"] == 0)
+    assert lvl0.any() and (rf["did_subpix"][lvl0] == 0).all() and np.array_equal(rf["found_pos"][lvl0], tr0["found_pos"][lvl0])
+    up = found & (rf["search_level"] > 0)
+    assert up.any() and (rf["did_subpix"][up] == 1).all() and (rf["found"][up] == 1).all()
+    conv = up & (tr8["found"] == 1)
+    assert np.array_equal(rf["found_pos"][conv], tr8["found_pos"][conv])          # converged: the tracker's refined position
+    # a warp CalcSearchLevelAndWarpMatrix rejects is searched all the same (MakeTemplateCoarse ignores the verdict)
+    far = dict(pts[0]); far["pixel_right_w"] = np.asarray(far["pixel_right_w"]) * 0.5; far["pixel_down_w"] = np.asarray(far["pixel_down_w"]) * 0.5
+    stf = kf.new_pf_states(1)
+    rj = oracle_patch_sequences(kf.PF_REFIND, tg, [[dict(point=far, point_key=7, target=0)]], stf, 4)
+    tj = oracle_track_search(B, cam, sc["poseB"], I, [far], 4, 0)
+    assert tj["search_level"][0] == -1 and tj["template_bad"][0] == 1 and tj["searched"][0] == 0
+    assert rj["search_level"][0] == 0 and rj["searched"][0] == 1 and rj["template_bad"][0] == 0
+    # ---- epipolar: hypotheses along the view ray of one candidate, ONE finder, ONE point key
+    cand, _ = A.Candidates(1)
+    c = cand[len(cand) // 3]
+    scales = np.concatenate([np.linspace(5.0, 7.0, 41), [7.0], np.linspace(7.0, 7.05, 3)])      # dense steps; entry 41 is made degenerate below
+    hyp = [synth_img.hypothesis_point(cam, A, A, sc["poseA"], c, 1, s_) for s_ in scales]
+    for k in ("pixel_right_w", "pixel_down_w"):               # a patch seen at a third of its size: warp determinant < 0.5 (:107-121)
+        hyp[41][k] = np.asarray(hyp[41][k]) * 0.3
+    one = [[dict(point=h, point_key=1, target=0) for h in hyp]]
+    ste = kf.new_pf_states(1)
+    ec = oracle_patch_sequences(kf.PF_EPI_COARSE, tg, one, ste, 3)
+    fresh = oracle_track_search(B, cam, sc["poseB"], I, hyp, 3, 0)
+    good = fresh["search_level"] >= 0
+    assert good[:41].all() and not good[41], "the deep hypothesis must be the one CalcSearchLevelAndWarpMatrix rejects"
+    reuse = [i for i in range(1, 41) if np.array_equal(ec["templ"][i], ec["templ"][i - 1]) and not np.array_equal(fresh["templ"][i], fresh["templ"][i - 1])]
+    assert len(reuse) >= 2, "dense depth steps must show a template that was kept although a fresh warp differs"
+    assert np.array_equal(ec["templ"][0], fresh["templ"][0])
+    # the hypothesis after the rejected one keeps its template (warp back near the last refresh) and inherits mbTemplateBad = true
+    assert ec["template_bad"][41] == 1 and ec["searched"][41] == 0
+    assert ec["template_bad"][42] == 1 and ec["searched"][42] == 0 and fresh["template_bad"][42] == 0
+    # ---- refinement on the same finder: start at the best coarse match
+    f = np.nonzero(ec["found"] == 1)[0]
+    assert len(f) > 0
+    b = f[np.argmin(ec["score"][f])]
+    ref = oracle_patch_sequences(kf.PF_EPI_REFINE, tg, [[dict(point=hyp[b], point_key=1, target=0, start_pos=ec["found_pos"][b])]], ste, 3)
+    assert ref["did_subpix"][0] == 1 and ref["searched"][0] == 0
+    if ref["found"][0]:
+        assert np.linalg.norm(ref["found_pos"][0] - ec["found_pos"][b]) < 2.0 * (1 << int(ref["search_level"][0]))
