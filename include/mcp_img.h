@@ -241,6 +241,19 @@ int mcp_track_pose_update(int n, const uint8_t* found, const double* found_pos /
                           const double* image_pos /*n*2*/, const double* sqrt_inv_noise /*n*/,
                           const double* jacobian /*n*12*/, double override_sigma, double mu[6],
                           double* weights_out, double* sigma_sq_out);
+/* The same three entries with the M-estimator Tracker::CalcPoseUpdate dispatches on (Tracker::sMEstimatorName, src/Tracker.cc:1388-1401):
+ * Tukey (the default; what the entries without _m use), Cauchy, Huber -- weights and sigma^2 of include/mcptam/MEstimator.h:84-204.
+ * weights == 0 (the reference's outlier test, :1470) only ever happens with Tukey, as in the reference. */
+#define MCP_MEST_TUKEY 0
+#define MCP_MEST_CAUCHY 1
+#define MCP_MEST_HUBER 2
+int mcp_track_pose_update_m(int n, const uint8_t* found, const double* found_pos, const double* image_pos, const double* sqrt_inv_noise,
+                            const double* jacobian, double override_sigma, double mu[6], double* weights_out, double* sigma_sq_out, int estimator);
+int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cam_from_base, double base_from_world[12],
+                            int n_iter, const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last, int estimator);
+int mcp_track_pose_refine_sharded_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cam_from_base, double base_from_world[12],
+                                    int n_iter, const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last,
+                                    mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap, int estimator);
 
 #ifdef __cplusplus
 }

@@ -308,10 +308,21 @@ int mcp_minipatch_find(mcp_kf* src, mcp_kf* dst, int level, int n, const mcp_int
   return 0;
 }
 
+// a camera the device code may index: 0 (Newton mode) .. MCP_MAX_INV inverse-polynomial coefficients (as mcp_ba_create checks)
+static bool cam_ok(const mcp_camera* c) { return c && c->n_inv >= 0 && c->n_inv <= MCP_MAX_INV; }
+
+static bool est_ok(int e) { return e >= MCP_MEST_TUKEY && e <= MCP_MEST_HUBER; }
 int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
                           const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last) {
+  return mcp_track_pose_refine_m(n, pts, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, mu_last, weights_last, MCP_MEST_TUKEY);
+}
+int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
+                            const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last, int est) {
+  if (!mu_last) return img_fail("mcp_track_pose_refine: bad arguments");
   for (int k = 0; k < 6; ++k) mu_last[k] = 0;
-  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb) return img_fail("mcp_track_pose_refine: bad arguments");
+  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || !bfw || !est_ok(est) || (n > 0 && !pts) || (n_iter > 0 && (!nonlinear || !override_sigma)))
+    return img_fail("mcp_track_pose_refine: bad arguments");
+  for (int c = 0; c < ncam; ++c) if (!cam_ok(&cams[c])) return img_fail("mcp_track_pose_refine: bad camera");
   if (n == 0 || n_iter == 0) return 0;
   for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine: camera index out of range");
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine: no HIP device");
@@ -323,10 +334,19 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
   const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam;
   const size_t o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam, blk = ((o_nl + (size_t)n_iter + 15)/16)*16;
   static const int use_regs = [] { const char* e = getenv("MCP_TRACK_REFINE_REGS"); return e ? atoi(e) : 1; }();
-  static const bool regs_ok = hipFuncSetAttribute((const void*)k_pose_refine_regs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12*PRR_THREADS*PRR_PPT*sizeof(double))) == hipSuccess;
-  const bool regs = use_regs && regs_ok && n <= PRR_THREADS*PRR_PPT;          // the points fit the register-resident kernel
+  // (function attributes are per device: set on the device this call runs on, once per device and thread)
+  static thread_local unsigned long long regs_set_mask = 0, regs_ok_mask = 0;
+  int cur_dev = 0; (void)hipGetDevice(&cur_dev);
+  const unsigned long long dbit = 1ull << (cur_dev & 63);
+  if (!(regs_set_mask & dbit)) {
+    regs_set_mask |= dbit;
+    if (hipFuncSetAttribute((const void*)k_pose_refine_regs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12*PRR_THREADS*PRR_PPT*sizeof(double))) == hipSuccess) regs_ok_mask |= dbit;
+    else (void)hipGetLastError();
+  }
+  bool regs = use_regs && (regs_ok_mask & dbit) && n <= PRR_THREADS*PRR_PPT;          // the points fit the register-resident kernel
   if (rs.dp.alloc(n) || rs.dblk.alloc(blk) || rs.dw.alloc(n)) return -1;
-  if (!regs && (rs.dJ.alloc(12*(size_t)n) || rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n))) return -1;
+  auto alloc_plain = [&]() { return rs.dJ.alloc(12*(size_t)n) || rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n); };
+  if (!regs && alloc_plain()) return -1;
   rs.hblk.assign(blk, 0);
   std::memcpy(rs.hblk.data(), bfw, 96);
   std::memcpy(rs.hblk.data() + o_ov, override_sigma, 8*(size_t)n_iter);
@@ -340,10 +360,15 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
   double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
   const double* d_ov = reinterpret_cast<const double*>(rs.dblk.p + o_ov); const double* d_cfb = reinterpret_cast<const double*>(rs.dblk.p + o_cfb);
   const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
-  if (regs)
-    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), (size_t)12*PRR_THREADS*PRR_PPT*sizeof(double), st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p);
-  else
-    hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p);
+  if (regs) {
+    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), (size_t)12*PRR_THREADS*PRR_PPT*sizeof(double), st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p, est);
+    if (hipGetLastError() != hipSuccess) {       // the launch was refused (96 KB of dynamic LDS): the plain kernel does the same work from global memory
+      regs = false; regs_ok_mask &= ~dbit;
+      if (alloc_plain()) return -1;
+    }
+  }
+  if (!regs)
+    hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est);
 #ifdef MCP_PRR_PROF
   if (regs) {
     ICK(hipStreamSynchronize(st));
@@ -365,9 +390,17 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
 int mcp_track_pose_refine_sharded(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
                                   const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last,
                                   mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap) {
+  return mcp_track_pose_refine_sharded_m(n, pts, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, mu_last, weights_last, allreduce, user, rank, world, cap, MCP_MEST_TUKEY);
+}
+int mcp_track_pose_refine_sharded_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
+                                    const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last,
+                                    mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap, int est) {
+  if (!mu_last) return img_fail("mcp_track_pose_refine_sharded: bad arguments");
   for (int k = 0; k < 6; ++k) mu_last[k] = 0;
-  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || world < 1 || rank < 0 || rank >= world || cap < n || cap < 1 || (world > 1 && !allreduce))
+  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || !bfw || world < 1 || rank < 0 || rank >= world || cap < n || cap < 1 || (world > 1 && !allreduce) ||
+      !est_ok(est) || (n > 0 && !pts) || (n_iter > 0 && (!nonlinear || !override_sigma)))
     return img_fail("mcp_track_pose_refine_sharded: bad arguments");
+  for (int c = 0; c < ncam; ++c) if (!cam_ok(&cams[c])) return img_fail("mcp_track_pose_refine_sharded: bad camera");
   for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine_sharded: camera index out of range");
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine_sharded: no HIP device");
   if (n_iter == 0) return 0;      // (a rank without points still joins every collective below)
@@ -391,7 +424,7 @@ int mcp_track_pose_refine_sharded(int n, mcp_pose_point* pts, int ncam, const mc
                               rs.dtab.p + (size_t)rank*cap, rs.dtab.p + tab + rank, rs.dcnt.p);
     if (world > 1) { ICK(hipStreamSynchronize(st)); if (allreduce(user, rs.dtab.p, tab + world, (void*)st) != 0) return img_fail("mcp_track_pose_refine_sharded: all-reduce hook failed"); }
     hipLaunchKernelGGL(k_pr_accum, dim3(1), dim3(1024), 0, st, n, (const mcp_pose_point*)rs.dp.p, (const double*)rs.dJ.p, (const double*)rs.dex.p, (const double*)rs.de2.p,
-                       (const double*)rs.dtab.p, (const double*)(rs.dtab.p + tab), world, cap, override_sigma[it], (int)(it == n_iter - 1), rs.dacc.p, rs.dw.p);
+                       (const double*)rs.dtab.p, (const double*)(rs.dtab.p + tab), world, cap, override_sigma[it], (int)(it == n_iter - 1), rs.dacc.p, rs.dw.p, est);
     if (world > 1) { ICK(hipStreamSynchronize(st)); if (allreduce(user, rs.dacc.p, 27, (void*)st) != 0) return img_fail("mcp_track_pose_refine_sharded: all-reduce hook failed"); }
     hipLaunchKernelGGL(k_pr_solve, dim3(1), dim3(64), 0, st, (const double*)rs.dacc.p, (const double*)(rs.dtab.p + tab), world, rs.dpose.p, rs.dv6.p);
   }
@@ -539,9 +572,6 @@ int mcp_sbi_se3_from_se2(const double se2[6], const mcp_camera* cs, const mcp_ca
   return 0;
 }
 
-// a camera the device code may index: 0 (Newton mode) .. MCP_MAX_INV inverse-polynomial coefficients (as mcp_ba_create checks)
-static bool cam_ok(const mcp_camera* c) { return c && c->n_inv >= 0 && c->n_inv <= MCP_MAX_INV; }
-
 int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12], const double cfb[12], int n, const mcp_td_in* in,
                      int range, int subpix_its, int exhaustive, mcp_td_out* out) {
   if (n < 0 || !target || !cam_ok(cam) || !bfw || !cfb || (n > 0 && (!in || !out))) return img_fail("mcp_track_search: bad arguments");
@@ -658,6 +688,11 @@ int mcp_patch_sequences(int mode, int n_targets, const mcp_pf_target* targets, i
 
 int mcp_track_pose_update(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sinv, const double* J,
                           double override_sigma, double mu[6], double* wout, double* sigma_out) {
+  return mcp_track_pose_update_m(n, found, fpos, ipos, sinv, J, override_sigma, mu, wout, sigma_out, MCP_MEST_TUKEY);
+}
+int mcp_track_pose_update_m(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sinv, const double* J,
+                          double override_sigma, double mu[6], double* wout, double* sigma_out, int est) {
+  if (!est_ok(est)) return img_fail("mcp_track_pose_update: unknown M-estimator");
   for (int k = 0; k < 6; ++k) mu[k] = 0;
   if (sigma_out) *sigma_out = 0;
   if (n <= 0) return 0;
@@ -686,8 +721,8 @@ int mcp_track_pose_update(int n, const uint8_t* found, const double* fpos, const
     for (int p = 0; p < SEL_PASSES; ++p) hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, ne, (const double*)de2.p, dhist.p, dst.p, (unsigned long long)(ne/2));
     hipLaunchKernelGGL(k_select_final, dim3(1), dim3(SEL_BLOCK), 0, st, (const double*)dhist.p, (const SelState*)dst.p, dsig.p + 1);
   }
-  hipLaunchKernelGGL(k_tukey_sigma, dim3(1), dim3(64), 0, st, (const double*)(dsig.p + 1), (double)ne, override_sigma, dsig.p);
-  hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(256), 0, st, n, (const uint8_t*)dfound.p, (const double*)dex.p, (const double*)dsi.p, (const double*)dJ.p, (const double*)dsig.p, dmu.p, dw.p);
+  hipLaunchKernelGGL(k_tukey_sigma, dim3(1), dim3(64), 0, st, (const double*)(dsig.p + 1), (double)ne, override_sigma, dsig.p, est);
+  hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(256), 0, st, n, (const uint8_t*)dfound.p, (const double*)dex.p, (const double*)dsi.p, (const double*)dJ.p, (const double*)dsig.p, dmu.p, dw.p, est);
   ICK(hipDeviceSynchronize());
   ICK(hipMemcpy(mu, dmu.p, 48, hipMemcpyDeviceToHost));
   if (wout) ICK(hipMemcpy(wout, dw.p, 8*(size_t)n, hipMemcpyDeviceToHost));

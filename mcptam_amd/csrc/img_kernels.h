@@ -739,6 +739,19 @@ k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, cons
 }
 
 // ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------
+// The M-estimator Tracker::CalcPoseUpdate dispatches on (Tracker::sMEstimatorName, src/Tracker.cc:1388-1401, 1429-1468) with the
+// formulas of include/mcptam/MEstimator.h: Tukey :84-124, Cauchy :131-157, Huber :164-204.  est: MCP_MEST_TUKEY 0 / CAUCHY 1 / HUBER 2.
+__device__ inline double mest_sigma_sq(int est, double n, double med) {
+  double s = 1.4826*(1 + 5.0/mest_denom(n))*sqrt(med);
+  s = ((est == 2) ? 1.345 : 4.6851)*s;
+  return s*s;
+}
+__device__ inline double mest_weight(int est, double e, double s2) {
+  if (est == 1) return 1.0/(1.0 + e/s2);
+  if (est == 2) return (e < s2) ? 1.0 : sqrt(s2/e);
+  const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
+  return sq*sq;
+}
 __global__ void k_pose_errors(int n, const uint8_t* __restrict__ found, const double* __restrict__ fpos, const double* __restrict__ ipos,
                               const double* __restrict__ sinv, double* __restrict__ ex, double* __restrict__ e2_compact,
                               const int* __restrict__ slot) {
@@ -751,7 +764,7 @@ __global__ void k_pose_errors(int n, const uint8_t* __restrict__ found, const do
 // one block: Tukey weights, WLS<6> accumulation (prior 100), 6x6 Cholesky solve.  sig[0] = sigma^2
 __global__ void __launch_bounds__(256)
 k_pose_solve(int n, const uint8_t* __restrict__ found, const double* __restrict__ ex, const double* __restrict__ sinv,
-             const double* __restrict__ J, const double* __restrict__ sig, double* __restrict__ mu, double* __restrict__ wout) {
+             const double* __restrict__ J, const double* __restrict__ sig, double* __restrict__ mu, double* __restrict__ wout, int est) {
   __shared__ double red[27][4];
   double acc[27];
 #pragma unroll
@@ -761,8 +774,7 @@ k_pose_solve(int n, const uint8_t* __restrict__ found, const double* __restrict_
     double w = 0.0;
     if (found[i]) {
       const double e = ex[2*i]*ex[2*i] + ex[2*i + 1]*ex[2*i + 1];
-      const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
-      w = sq*sq;
+      w = mest_weight(est, e, s2);
       if (w != 0.0) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -800,10 +812,10 @@ k_pose_solve(int n, const uint8_t* __restrict__ found, const double* __restrict_
     for (int i = 0; i < 6; ++i) mu[i] = x[i];
   }
 }
-__global__ void k_tukey_sigma(const double* __restrict__ med, double n, double override_sigma, double* __restrict__ sig) {
+__global__ void k_tukey_sigma(const double* __restrict__ med, double n, double override_sigma, double* __restrict__ sig, int est) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     if (override_sigma > 0) sig[0] = override_sigma;
-    else { double s = 1.4826*(1 + 5.0/mest_denom((double)n))*sqrt(med[0]); s = 4.6851*s; sig[0] = s*s; }
+    else sig[0] = mest_sigma_sq(est, (double)n, med[0]);
   }
 }
 
@@ -982,7 +994,7 @@ constexpr int PR_THREADS = 1024;
 __global__ void __launch_bounds__(PR_THREADS)
 k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
               double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
-              double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out) {
+              double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out, int est) {
   __shared__ unsigned int hist[2048];
   __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
   __shared__ double red[PR_THREADS/64][28];
@@ -1039,9 +1051,7 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
         key = (unsigned long long)__double_as_longlong(fabs(e2s[i]));
         return true; }, hist, sel_sc, sel_st);
       const double med = __longlong_as_double((long long)sel_prefix);
-      double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
-      sg = 4.6851*sg;
-      s2 = sg*sg;
+      s2 = mest_sigma_sq(est, (double)nf, med);
     }
     // weighted normal equations: 21 + 6 partial sums per thread
     double a[27];
@@ -1052,8 +1062,7 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
       const mcp_pose_point& p = pts[i];
       if (!p.found) { if (last && w_out) w_out[i] = 0.0; continue; }
       const double err2 = e2s[i];
-      double sq = (err2 > s2) ? 0.0 : 1.0 - (err2/s2);
-      const double w = sq*sq;
+      const double w = mest_weight(est, err2, s2);
       if (last && w_out) w_out[i] = w;
       if (w == 0.0) continue;
       const double* Ji = J + 12*(size_t)i;
@@ -1137,7 +1146,7 @@ __device__ unsigned long long g_prr_prof[16*8];
 __global__ void __launch_bounds__(PRR_THREADS)
 k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
                    double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
-                   double* __restrict__ mu_out, double* __restrict__ w_out) {
+                   double* __restrict__ mu_out, double* __restrict__ w_out, int est) {
   constexpr int NT = PRR_THREADS, NW = NT/64, BPT = SEL_BINS/NT;
   __shared__ unsigned int hist[SEL_BINS];
   __shared__ unsigned int wtot[NW], sres[3];
@@ -1260,9 +1269,7 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
         }
       }
       const double med = __longlong_as_double((long long)prefix);
-      double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
-      sg = 4.6851*sg;
-      s2 = sg*sg;
+      s2 = mest_sigma_sq(est, (double)nf, med);
     }
     PRR_STAMP(2);
     // weighted normal equations: 21 + 6 partial sums per thread
@@ -1274,8 +1281,7 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
     for (int k = 0; k < PRR_PPT; ++k) {
       const int i = t + k*NT;
       if (!fnd[k]) { if (last && w_out && i < n) w_out[i] = 0.0; continue; }
-      const double sq = (e2[k] > s2) ? 0.0 : 1.0 - (e2[k]/s2);
-      const double w = sq*sq;
+      const double w = mest_weight(est, e2[k], s2);
       if (last && w_out) w_out[i] = w;
       if (w == 0.0) continue;
 #pragma unroll
@@ -1406,7 +1412,7 @@ k_pr_project(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restri
 __global__ void __launch_bounds__(1024)
 k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restrict__ J, const double* __restrict__ ex, const double* __restrict__ e2s,
            const double* __restrict__ table /* world x cap */, const double* __restrict__ counts /* world */, int world, int cap,
-           double override_sigma, int last, double* __restrict__ out27 /* [27] + [27] = total found */, double* __restrict__ w_out) {
+           double override_sigma, int last, double* __restrict__ out27 /* [27] + [27] = total found */, double* __restrict__ w_out, int est) {
   __shared__ unsigned int hist[2048];
   __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
   __shared__ double red[16][28];
@@ -1423,9 +1429,7 @@ k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restri
       key = (unsigned long long)__double_as_longlong(fabs(table[i]));
       return true; }, hist, sel_sc, sel_st);
     const double med = __longlong_as_double((long long)sel_prefix);
-    double sg = 1.4826*(1 + 5.0/mest_denom((double)nf))*sqrt(med);
-    sg = 4.6851*sg;
-    s2 = sg*sg;
+    s2 = mest_sigma_sq(est, (double)nf, med);
   }
   double a[27];
 #pragma unroll
@@ -1434,8 +1438,7 @@ k_pr_accum(int n, const mcp_pose_point* __restrict__ pts, const double* __restri
     const mcp_pose_point& p = pts[i];
     if (!p.found) { if (last && w_out) w_out[i] = 0.0; continue; }
     const double err2 = e2s[i];
-    const double sq = (err2 > s2) ? 0.0 : 1.0 - (err2/s2);
-    const double w = sq*sq;
+    const double w = mest_weight(est, err2, s2);
     if (last && w_out) w_out[i] = w;
     if (w == 0.0) continue;
     const double* Ji = J + 12*(size_t)i;

@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_make_lite_batch", "mcp_track_search_batch", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_patch_sequences", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_patch_sequences", "mcp_track_pose_update_m", "mcp_track_pose_refine_m", "mcp_track_pose_refine_sharded_m", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -345,7 +345,7 @@ def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaust
     return out[:len(flat)]
 
 
-def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):
+def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0, estimator="Tukey"):
     found = np.ascontiguousarray(found, dtype=np.uint8)
     n = found.shape[0]
     fp = np.ascontiguousarray(found_pos, dtype=np.float64)
@@ -355,7 +355,9 @@ def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, ove
     mu = np.zeros(6)
     w = np.zeros(max(n, 1))
     s = ctypes.c_double(0)
-    _chk(lib().mcp_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s)), "track_pose_update")
+    L = lib()
+    L.mcp_track_pose_update_m.argtypes = list(L.mcp_track_pose_update.argtypes) + [ctypes.c_int]
+    _chk(L.mcp_track_pose_update_m(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s), MEST[estimator]), "track_pose_update")
     return mu, w[:n], s.value
 
 
@@ -421,7 +423,10 @@ def pose_points_frame(world_pos_per_cam, td_outs):
     return p
 
 
-def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, structs):
+MEST = {"Tukey": 0, "Cauchy": 1, "Huber": 2}      # Tracker::sMEstimatorName (src/Tracker.cc:1388-1401)
+
+
+def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, structs, extra=()):
     pts = np.ascontiguousarray(pts, dtype=POSE_POINT_DTYPE).copy()
     n, ncam, nit = len(pts), len(cams), len(nonlinear)
     carr = cams if isinstance(cams, ctypes.Array) else (structs * ncam)(*[c.to_struct() for c in cams])      # (a caller with fixed cameras marshals them once: taylor_camera.camera_array)
@@ -432,7 +437,7 @@ def _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_s
     mu = np.zeros(6)
     w = np.zeros(max(n, 1))
     rc = fn(n, pts.ctypes.data, ncam, ctypes.cast(carr, ctypes.c_void_p), cfb.ctypes.data, bfw.ctypes.data, nit, nl.ctypes.data, ov.ctypes.data,
-            mu.ctypes.data, w.ctypes.data)
+            mu.ctypes.data, w.ctypes.data, *extra)
     return rc, (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), mu, w[:n], pts
 
 
@@ -458,9 +463,11 @@ def track_pose_refine_sharded(pts, cams, cam_from_base, base_from_world, allredu
     return pose, mu, w, out
 
 
-def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE):
+def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey"):
     """All Gauss-Newton pose iterations of one frame in one device launch.  Returns (BaseFromWorld (R, t), last update,
-    last Tukey weights, points with their final image positions)."""
-    rc, pose, mu, w, out = _refine(lib().mcp_track_pose_refine, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
+    last M-estimator weights, points with their final image positions)."""
+    L = lib()
+    L.mcp_track_pose_refine_m.argtypes = list(L.mcp_track_pose_refine.argtypes) + [ctypes.c_int]
+    rc, pose, mu, w, out = _refine(L.mcp_track_pose_refine_m, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera, extra=(MEST[estimator],))
     _chk(rc, "track_pose_refine")
     return pose, mu, w, out

@@ -282,6 +282,7 @@ def img_lib():
         L.orc_kf_make_sbi.argtypes = [ctypes.c_void_p, ctypes.c_double]
         L.orc_track_pose_refine.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_track_pose_refine_m.argtypes = list(L.orc_track_pose_refine.argtypes) + [ctypes.c_int]
         for f in ("orc_kf_sbi_small", "orc_kf_sbi_template", "orc_kf_sbi_jacs"):
             getattr(L, f).restype = ctypes.c_void_p
             getattr(L, f).argtypes = [ctypes.c_void_p]
@@ -436,7 +437,7 @@ def oracle_patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, 
     return kf.patch_sequences(mode, targets, seqs, states, rng, subpix_its, exhaustive, fn=L.orc_patch_sequences, handle_of=lambda k: k._h)
 
 
-def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0):
+def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0, estimator="Tukey"):
     found = np.ascontiguousarray(found, dtype=np.uint8)
     n = found.shape[0]
     fp = np.ascontiguousarray(found_pos, dtype=np.float64)
@@ -446,15 +447,18 @@ def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobi
     mu = np.zeros(6)
     w = np.zeros(max(n, 1))
     s = ctypes.c_double(0)
-    img_lib().orc_track_pose_update(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s))
+    from mcptam_amd.keyframe import MEST
+    L = img_lib()
+    L.orc_track_pose_update_m.argtypes = list(L.orc_track_pose_update.argtypes) + [ctypes.c_int]
+    L.orc_track_pose_update_m(n, found.ctypes.data, _dp(fp), _dp(ip), _dp(si), _dp(J), float(override_sigma), _dp(mu), _dp(w), ctypes.byref(s), MEST[estimator])
     return mu, w[:n], s.value
 
 
-def oracle_track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=None, override_sigma=None):
+def oracle_track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=None, override_sigma=None, estimator="Tukey"):
     """CPU restatement of Tracker::TrackMap's pose iterations (same signature as mcptam_amd.keyframe.track_pose_refine)."""
     from mcptam_amd import keyframe as kf
     from mcptam_amd.taylor_camera import McpCamera
     nonlinear = kf.FINE_NONLINEAR if nonlinear is None else nonlinear
     override_sigma = kf.FINE_OVERRIDE if override_sigma is None else override_sigma
-    rc, pose, mu, w, out = kf._refine(img_lib().orc_track_pose_refine, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
+    rc, pose, mu, w, out = kf._refine(img_lib().orc_track_pose_refine_m, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera, extra=(kf.MEST[estimator],))
     return pose, mu, w, out

@@ -734,9 +734,21 @@ int orc_patch_sequences(int mode, int n_targets, const orc_pf_target* targets, i
 }
 
 static int cmp_d(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
-/* Tracker::CalcPoseUpdate with the Tukey estimator and TooN WLS<6> [3P-memory], Tracker.cc:1386-1512 */
+/* The estimators Tracker::CalcPoseUpdate dispatches on (src/Tracker.cc:1388-1401, 1429-1468): include/mcptam/MEstimator.h
+ * Tukey :84-124, Cauchy :131-157 (same sigma as Tukey, weight 1/(1 + e/s)), Huber :164-204 (1.345; weight 1 or sqrt(s/e)). */
+static double mest_sigma_squared(int est, double* e2, int n) { return est == 2 ? orc_huber_sigma_squared(e2, n) : orc_tukey_sigma_squared(e2, n); }
+static double mest_weight(int est, double e, double s2) {
+  if (est == 1) return 1.0/(1.0 + e/s2);
+  if (est == 2) return (e < s2) ? 1.0 : sqrt(s2/e);
+  return orc_tukey_weight(e, s2);
+}
+/* Tracker::CalcPoseUpdate with TooN WLS<6> [3P-memory], Tracker.cc:1386-1512; est 0 Tukey (the default), 1 Cauchy, 2 Huber */
 int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sin,
                           const double* J, double override_sigma, double mu[6], double* wout, double* sigma_out) {
+  return orc_track_pose_update_m(n, found, fpos, ipos, sin, J, override_sigma, mu, wout, sigma_out, 0);
+}
+int orc_track_pose_update_m(int n, const uint8_t* found, const double* fpos, const double* ipos, const double* sin,
+                            const double* J, double override_sigma, double mu[6], double* wout, double* sigma_out, int est) {
   double* e2 = (double*)malloc(sizeof(double)*(n + 1)); int ne = 0;
   double* ex = (double*)malloc(sizeof(double)*(2*(size_t)n + 2));
   for (int i = 0; i < n; i++) {
@@ -748,7 +760,7 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const
   for (int k = 0; k < 6; k++) mu[k] = 0;
   if (ne == 0) { free(e2); free(ex); if (sigma_out) *sigma_out = 0; return 0; }
   double s2;
-  if (override_sigma > 0) s2 = override_sigma; else s2 = orc_tukey_sigma_squared(e2, ne);
+  if (override_sigma > 0) s2 = override_sigma; else s2 = mest_sigma_squared(est, e2, ne);
   if (sigma_out) *sigma_out = s2;
   double C[36], v[6];
   for (int a = 0; a < 36; a++) C[a] = 0;
@@ -756,7 +768,7 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* fpos, const
   for (int i = 0; i < n; i++) {
     if (!found[i]) continue;
     const double err2 = ex[2*i]*ex[2*i] + ex[2*i+1]*ex[2*i+1];
-    const double w = orc_tukey_weight(err2, s2);
+    const double w = mest_weight(est, err2, s2);
     if (wout) wout[i] = w;
     if (w == 0.0) continue;
     for (int r = 0; r < 2; r++) {
@@ -1006,6 +1018,11 @@ void orc_sbi_se3_from_se2(const double se2[6], const orc_camera* cs, const orc_c
 int orc_track_pose_refine(int n, orc_pose_point* pts, int ncam, const orc_camera* cams, const double* cfb_all,
                           double bfw[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
                           double mu_last[6], double* weights_last) {
+  return orc_track_pose_refine_m(n, pts, ncam, cams, cfb_all, bfw, n_iter, nonlinear, override_sigma, mu_last, weights_last, 0);
+}
+int orc_track_pose_refine_m(int n, orc_pose_point* pts, int ncam, const orc_camera* cams, const double* cfb_all,
+                            double bfw[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                            double mu_last[6], double* weights_last, int est) {
   uint8_t* found = (uint8_t*)malloc(n + 1);
   double* fpos = (double*)malloc(sizeof(double)*(2*(size_t)n + 2)); double* ipos = (double*)malloc(sizeof(double)*(2*(size_t)n + 2));
   double* sinv = (double*)malloc(sizeof(double)*(n + 1)); double* J = (double*)calloc(12*(size_t)n + 12, sizeof(double));
@@ -1036,7 +1053,7 @@ int orc_track_pose_refine(int n, orc_pose_point* pts, int ncam, const orc_camera
     }
     for (int i = 0; i < n; i++) { ipos[2*i] = pts[i].image[0]; ipos[2*i+1] = pts[i].image[1]; }
     double s2;
-    orc_track_pose_update(n, found, fpos, ipos, sinv, J, override_sigma[it], v6, (it == n_iter - 1) ? weights_last : NULL, &s2);
+    orc_track_pose_update_m(n, found, fpos, ipos, sinv, J, override_sigma[it], v6, (it == n_iter - 1) ? weights_last : NULL, &s2, est);
     double E[9], et[3]; orc_se3_exp(v6, E, et);            /* mse3BaseFromWorld = exp(v6) * mse3BaseFromWorld */
     double nb[12];
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) nb[3*a + b] = E[3*a]*bfw[b] + E[3*a+1]*bfw[3+b] + E[3*a+2]*bfw[6+b];

@@ -79,6 +79,10 @@ int orc_track_pose_update(int n, const uint8_t* found, const double* found_pos, 
                           const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
                           double mu[6], double* weights_out, double* sigma_sq_out);
 
+int orc_track_pose_update_m(int n, const uint8_t* found, const double* found_pos, const double* image_pos,
+                            const double* sqrt_inv_noise, const double* jacobian, double override_sigma,
+                            double mu[6], double* weights_out, double* sigma_sq_out, int estimator /* 0 Tukey, 1 Cauchy, 2 Huber */);
+
 /* The ten Gauss-Newton pose iterations of Tracker::TrackMap (src/Tracker.cc:775-838, 1038-1075): per iteration either
  * PoseUpdateStep (re-project the found points unless it is iteration 0, CalcJacobian, CalcPoseUpdate, BaseFromWorld <-
  * exp(mu) BaseFromWorld) or PoseUpdateStepLinear (LinearUpdate with the previous mu instead of re-projection). */
@@ -94,6 +98,10 @@ typedef struct orc_pose_point {
 int orc_track_pose_refine(int n, orc_pose_point* pts, int ncam, const struct orc_camera* cams, const double* cam_from_base /* ncam x 12 */,
                           double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
                           double mu_last[6], double* weights_last);
+
+int orc_track_pose_refine_m(int n, orc_pose_point* pts, int ncam, const struct orc_camera* cams, const double* cam_from_base,
+                            double base_from_world[12], int n_iter, const uint8_t* nonlinear, const double* override_sigma,
+                            double mu_last[6], double* weights_last, int estimator);
 
 /* ---- SmallBlurryImage / Relocaliser (src/SmallBlurryImage.cc:67-330, src/Relocaliser.cc:61-121) ----------------
  * 40x30 thumbnail of level 0 (cv::resize INTER_LINEAR [3P-memory]), zero-mean float template blurred with

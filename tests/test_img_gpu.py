@@ -783,3 +783,26 @@ def test_map_maker_patchfinder_flows_match_oracle(gpu_required, scene):
     assert np.allclose(fg["found_pos"], fo["found_pos"], rtol=0, atol=1e-9)
     _assert_states_equal(sg, so)
     assert (fg["found"] == 1).sum() >= 0.5 * len(fg) and (fg["did_subpix"] == 1).all()
+
+
+@pytest.mark.parametrize("est", ["Cauchy", "Huber"])
+def test_pose_update_and_refine_with_the_other_m_estimators(gpu_required, est):
+    """Tracker::CalcPoseUpdate dispatches on Tracker::sMEstimatorName (src/Tracker.cc:1388-1401): Cauchy and Huber next to the default
+    Tukey (include/mcptam/MEstimator.h:126-204) -- single update and the ten-iteration loop, both pose-refine kernels, against the oracle."""
+    import os
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_update, track_pose_refine
+    from oracle import oracle_track_pose_update, oracle_track_pose_refine
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    rng = np.random.default_rng(3)
+    n = len(recs)
+    J = rng.normal(size=(n, 12)) * 30
+    mg, wg, sg = track_pose_update(recs["found"].astype(np.uint8), recs["found_pos"], recs["image"], recs["sqrt_inv_noise"], J, -1.0, est)
+    mo, wo, so = oracle_track_pose_update(recs["found"].astype(np.uint8), recs["found_pos"], recs["image"], recs["sqrt_inv_noise"], J, -1.0, est)
+    assert abs(sg - so) <= 1e-13 * so and np.allclose(wg, wo, rtol=1e-12, atol=0) and np.allclose(mg, mo, rtol=1e-9, atol=1e-13)
+    pg, mug, wgl, outg = track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
+    po, muo, wol, outo = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
+    assert np.allclose(pg[0], po[0], rtol=0, atol=1e-11) and np.allclose(pg[1], po[1], rtol=0, atol=1e-11)
+    assert np.allclose(mug, muo, rtol=1e-7, atol=1e-12) and np.allclose(wgl, wol, rtol=1e-9, atol=1e-12)
+    pt, _, wt, _ = track_pose_refine(recs, [cam, cam], cfbs, bfw)
+    assert np.abs(pt[1] - pg[1]).max() > 1e-9          # another estimator, another pose

@@ -1412,3 +1412,39 @@ def test_refind_and_epipolar_flows_of_the_stateful_patchfinder():
     assert ref["did_subpix"][0] == 1 and ref["searched"][0] == 0
     if ref["found"][0]:
         assert np.linalg.norm(ref["found_pos"][0] - ec["found_pos"][b]) < 2.0 * (1 << int(ref["search_level"][0]))
+
+
+@pytest.mark.parametrize("est", ["Tukey", "Cauchy", "Huber"])
+def test_pose_update_estimators_against_numpy(est):
+    """Tracker::CalcPoseUpdate's M-estimator dispatch (src/Tracker.cc:1388-1401, 1429-1468) with the formulas of
+    include/mcptam/MEstimator.h:84-204, against numpy weighted least squares."""
+    from oracle import oracle_track_pose_update
+    rng = np.random.default_rng(11)
+    n = 300
+    found = (rng.uniform(size=n) < 0.85).astype(np.uint8)
+    J = rng.normal(size=(n, 12)) * 40
+    ipos = rng.uniform(50, 400, size=(n, 2))
+    fpos = ipos + rng.normal(size=(n, 2)) * 1.5
+    fpos[::17] += 40
+    sinv = 1.0 / 2.0 ** rng.integers(0, 4, size=n)
+    mu, w, s2 = oracle_track_pose_update(found, fpos, ipos, sinv, J, -1.0, est)
+    f = found.astype(bool)
+    e = sinv[f, None] * (fpos[f] - ipos[f])
+    e2 = np.sort((e ** 2).sum(axis=1))
+    sig = 1.4826 * (1 + 5.0 / (2 * len(e2) - 6)) * np.sqrt(e2[len(e2) // 2]) * (1.345 if est == "Huber" else 4.6851)
+    assert abs(s2 - sig ** 2) <= 1e-12 * sig ** 2
+    err2 = (e ** 2).sum(axis=1)
+    if est == "Tukey":
+        wr = np.where(err2 > s2, 0.0, (1 - err2 / s2) ** 2)
+    elif est == "Cauchy":
+        wr = 1.0 / (1.0 + err2 / s2)
+    else:
+        wr = np.where(err2 < s2, 1.0, np.sqrt(s2 / err2))
+    assert np.allclose(w[f], wr, rtol=1e-13) and (w[~f] == 0).all()
+    C = 100.0 * np.eye(6); v = np.zeros(6)
+    Jf = J[f].reshape(-1, 2, 6) * sinv[f, None, None]
+    for r in range(2):
+        C += np.einsum("i,ia,ib->ab", wr, Jf[:, r], Jf[:, r]); v += np.einsum("i,i,ia->a", wr, e[:, r], Jf[:, r])
+    assert np.allclose(mu, np.linalg.solve(C, v), rtol=1e-9, atol=1e-13)
+    if est != "Tukey":
+        assert (w[f] > 0).all()          # only the cut-off estimator produces outliers (dWeight == 0, :1470)
