@@ -33,7 +33,12 @@ void ToArray12(const SE3<>& se3, double a[12])
 }
 }  // namespace
 
-// Find points in the image: one device call for the whole vector (include/mcp_img.h, mcp_track_search)
+// Find points in the image: one device call for the whole vector (include/mcp_img.h, mcp_patch_sequences in MCP_PF_TRACK mode).
+// PatchFinder's members that live from frame to frame -- the template cache of MakeTemplateCoarseCont (src/PatchFinder.cc:144-181)
+// and the sub-pixel state -- move from TrackerData::mFinder into an mcp_pf_state per TrackerData: add
+//     mcp_pf_state mFinderState;      // zero-initialised in the constructor (a PatchFinder that has seen nothing)
+// to class TrackerData (include/mcptam/TrackerData.h:75, next to mFinder, which keeps CalcSearchLevelAndWarpMatrix for FindPVS).
+// One sequence of one item per tracked point; the map point's address is its key, as the reference compares &point.
 int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, int nRange, int nSubPixIts, bool bExhaustive)
 {
   if(vTD.empty())
@@ -42,12 +47,19 @@ int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, 
   KeyFrame& kf = *mpCurrentMKF->mmpKeyFrames[cameraName];
   ROS_ASSERT(kf.mpDev);
 
-  std::vector<mcp_td_in> vIn(vTD.size());
+  std::vector<mcp_pf_item> vIn(vTD.size());
   std::vector<mcp_td_out> vOut(vTD.size());
+  std::vector<mcp_pf_state> vState(vTD.size());
+  std::vector<int> vSeqStart(vTD.size() + 1);
   for(unsigned i = 0; i < vTD.size(); ++i)
   {
     MapPoint& point = vTD[i]->mPoint;
-    mcp_td_in& in = vIn[i];
+    vSeqStart[i] = (int)i;
+    vState[i] = vTD[i]->mFinderState;
+    vIn[i].point_key = (int)(reinterpret_cast<uintptr_t>(&point) >> 4);   // identity of the MapPoint object (the finder of a TrackerData only ever sees this one)
+    vIn[i].target = 0;
+    vIn[i].start_pos[0] = vIn[i].start_pos[1] = 0.0;
+    mcp_td_in& in = vIn[i].point;
     for(int k = 0; k < 3; ++k)
     {
       in.world_pos[k] = point.mv3WorldPos[k];
@@ -62,12 +74,15 @@ int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, 
     in.fixed = point.mbFixed ? 1 : 0;
   }
 
+  vSeqStart[vTD.size()] = (int)vTD.size();
   mcp_camera cam = mcptam_hip::CameraExport::Make(mmCameraModels[cameraName]);
-  double adBaseFromWorld[12], adCamFromBase[12];
-  ToArray12(mpCurrentMKF->mse3BaseFromWorld, adBaseFromWorld);
-  ToArray12(kf.mse3CamFromBase, adCamFromBase);
+  mcp_pf_target target;
+  target.kf = kf.mpDev;
+  target.cam = &cam;
+  ToArray12(mpCurrentMKF->mse3BaseFromWorld, target.base_from_world);
+  ToArray12(kf.mse3CamFromBase, target.cam_from_base);
 
-  if(mcp_track_search(kf.mpDev, &cam, adBaseFromWorld, adCamFromBase, (int)vTD.size(), &vIn[0], nRange, nSubPixIts, bExhaustive ? 1 : 0, &vOut[0]) != 0)
+  if(mcp_patch_sequences(MCP_PF_TRACK, 1, &target, (int)vTD.size(), &vSeqStart[0], &vIn[0], &vState[0], nRange, nSubPixIts, bExhaustive ? 1 : 0, &vOut[0]) != 0)
   {
     ROS_FATAL_STREAM("Tracker::SearchForPoints: "<<mcp_last_error());
     ros::shutdown();
@@ -79,6 +94,7 @@ int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, 
   {
     TrackerData& td = *vTD[i];
     const mcp_td_out& out = vOut[i];
+    td.mFinderState = vState[i];      // the finder's members after this frame
 
     // the device re-derives the projection it searches around: identical to what FindPVS left in the TrackerData
     td.mv2Image = makeVector(out.image[0], out.image[1]);
@@ -110,14 +126,20 @@ int Tracker::SearchForPoints(TrackerDataPtrVector& vTD, std::string cameraName, 
   return nFound;
 }
 
-// Pose update from the found measurements: Tukey M-estimator + WLS<6> with prior 100 on the device (mcp_track_pose_update).
-// The device path implements the Tukey estimator, the tracker's default (Tracker::sMEstimatorName); the two others the reference
-// offers (Cauchy, Huber) are refused loudly rather than silently replaced.
+// Pose update from the found measurements: M-estimator weights + WLS<6> with prior 100 on the device (mcp_track_pose_update_m),
+// with the estimator Tracker::sMEstimatorName selects (src/Tracker.cc:1388-1401): Tukey, Cauchy or Huber.
 Vector<6> Tracker::CalcPoseUpdate(std::vector<TrackerDataPtrVector>& vIterationSets, double dOverrideSigma, bool bMarkOutliers)
 {
-  if(Tracker::sMEstimatorName != "Tukey")
+  int nEstimator = MCP_MEST_TUKEY;
+  if(Tracker::sMEstimatorName == "Tukey")
+    nEstimator = MCP_MEST_TUKEY;
+  else if(Tracker::sMEstimatorName == "Cauchy")
+    nEstimator = MCP_MEST_CAUCHY;
+  else if(Tracker::sMEstimatorName == "Huber")
+    nEstimator = MCP_MEST_HUBER;
+  else
   {
-    ROS_FATAL_STREAM("Tracker: the MI355X pose update implements the Tukey M-estimator only (requested: "<<Tracker::sMEstimatorName<<")");
+    ROS_FATAL_STREAM("Tracker: Invalid Tracker MEstimator selected: "<<Tracker::sMEstimatorName<<", choices are [Tukey, Cauchy, Huber]");
     ros::shutdown();
     return makeVector(0, 0, 0, 0, 0, 0);
   }
@@ -150,7 +172,7 @@ Vector<6> Tracker::CalcPoseUpdate(std::vector<TrackerDataPtrVector>& vIterationS
     return makeVector(0, 0, 0, 0, 0, 0);
 
   double adMu[6], dSigmaSquared = 0;
-  if(mcp_track_pose_update(n, &vFound[0], &vFoundPos[0], &vImagePos[0], &vSqrtInvNoise[0], &vJac[0], dOverrideSigma, adMu, &vWeights[0], &dSigmaSquared) != 0)
+  if(mcp_track_pose_update_m(n, &vFound[0], &vFoundPos[0], &vImagePos[0], &vSqrtInvNoise[0], &vJac[0], dOverrideSigma, adMu, &vWeights[0], &dSigmaSquared, nEstimator) != 0)
   {
     ROS_FATAL_STREAM("Tracker::CalcPoseUpdate: "<<mcp_last_error());
     ros::shutdown();
