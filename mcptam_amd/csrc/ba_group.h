@@ -89,12 +89,14 @@ __device__ inline void tile_add_cross(double* Sc, const unsigned char* pslot, in
 #pragma unroll
       for (int c = 0; c < 6; ++c) lds_add(B + 6*r + c, w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
   } else {
+    // one pose vertex at two positions of the edge (slot a before slot b in the edge's vertex order): g2o's one-sided block, of which
+    // its solver reads the upper triangle -- (Ja^T Omega Jb)(c, r), c <= r, mirrored into the lower entry (r, c)  (ba_kernels.h k_linearize)
     double* B = Sc + 36*(int)pslot[17*la];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c)
-        lds_add(B + 6*r + c, w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+        lds_add(B + 6*r + c, w*(Ja[c]*Jb[r] + Ja[6+c]*Jb[6+r]));
   }
 }
 

@@ -383,10 +383,12 @@ k_linearize(DevProblem P, int only_big, const double* __restrict__ pt_x, const d
       } else if (ub > ua) {
         for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
           unsafeAtomicAdd(U + (size_t)(6*ub + r)*np + 6*ua + c, w*(Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
-      } else {   // the same vertex in both chains: symmetric sum, lower triangle
+      } else {
+        // The same pose vertex at two positions of the edge (BundleAdjusterCalib: the relative camera pose in both chains).  g2o adds
+        // Ja^T Omega Jb ONCE to the vertex's diagonal block and its linear solver reads that block's upper triangle
+        // (BaseMultiEdge::constructQuadraticForm / BlockSolver::buildStructure / fillCCS [3P-memory]): the symmetric matrix that is solved has (Ja^T Omega Jb)(c, r), c <= r, at the lower entry (r, c).
         for (int r = 0; r < 6; ++r) for (int c = 0; c <= r; ++c)
-          unsafeAtomicAdd(U + (size_t)(6*ua + r)*np + 6*ua + c,
-                          w*(Ja[r]*Jb[c] + Ja[6+r]*Jb[6+c] + Jb[r]*Ja[c] + Jb[6+r]*Ja[6+c]));
+          unsafeAtomicAdd(U + (size_t)(6*ua + r)*np + 6*ua + c, w*(Ja[c]*Jb[r] + Ja[6+c]*Jb[6+r]));
       }
       ++ib;
     }

@@ -122,6 +122,11 @@ class OracleBundle:
         self._L.orc_ba_set_solver(self._h, int(solver), int(threads))
         return self._L.orc_ba_threads(self._h)
 
+    def SetDupSymmetric(self, on=True):
+        """oracle-only switch: symmetric cross terms for a pose vertex that occurs twice in an edge (ba_oracle.c build_system)"""
+        self._L.orc_ba_set_dup_symmetric.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._L.orc_ba_set_dup_symmetric(self._h, int(on))
+
     def DisableConvergence(self, disable=True):
         self._L.orc_ba_disable_convergence(self._h, int(disable))
 

@@ -69,6 +69,7 @@ struct orc_ba {
   /* CPU-baseline variants (ba_baseline.inc): 0 = the oracle proper (Schur, dense Cholesky, 1 thread), 1 = A (sparse
    * L D L^T of the un-marginalised system, 1 thread), 2 = B (Schur, OpenMP) */
   int solver, threads; void* sparse; void* par;
+  int dup_symmetric;          /* 1: a vertex that occurs twice in an edge gets both cross terms (see build_system) */
 };
 
 static void baseline_free(orc_ba* h);
@@ -303,6 +304,7 @@ void orc_ba_set_limits(orc_ba* h, int max_trials, double pct, double rms, double
   h->max_trials = max_trials; h->pct_limit = pct; h->rms_limit = rms; h->min_sigma = min_sigma;
 }
 void orc_ba_disable_convergence(orc_ba* h, int d) { h->no_converge = d; }
+void orc_ba_set_dup_symmetric(orc_ba* h, int on) { h->dup_symmetric = on; }
 
 static int new_id(orc_ba* h, int kind, int index) {
   int id = h->next_id++;
@@ -667,7 +669,16 @@ static int find_inc(const orc_ba* h, const opoint* p, int unk) {
   return -1;
 }
 /* g2o BlockSolver::buildSystem + BaseMultiEdge::constructQuadraticForm [3P-memory]:
- * H += Ji^T (rho' Omega) Jj, b += -Ji^T (rho' Omega) e over the free vertices of each edge. */
+ * H += Ji^T (rho' Omega) Jj, b += -Ji^T (rho' Omega) e over the free vertices of each edge, i < j in the edge's vertex order
+ * (observer chain, then source chain, then the point: ChainBundle.cc:1258-1267).
+ * A pose vertex may sit at TWO positions i < j of one edge (BundleAdjusterCalib: the relative camera pose is link 2 of the
+ * observer chain and of the source chain, BundleAdjusterCalib.cc:166-199).  g2o maps the (i, j) block of such an edge onto the
+ * vertex's own diagonal block (BlockSolver::buildStructure: _Hpp->block(ind1, ind2) with ind1 == ind2, not transposed) and adds
+ * Ji^T Omega Jj to it ONCE -- the transposed term is never added, so the block is not symmetric -- and LinearSolverCholmod reads
+ * the upper triangle of diagonal blocks (fillCCS(..., upperTriangle = true)).  The system solved is therefore the symmetric matrix
+ * whose entries (r, c), r <= c, of that block are Ji^T Omega Ji + Jj^T Omega Jj + Ji^T Omega Jj.  Reproduced here
+ * (dup_symmetric = 0, the default); dup_symmetric = 1 adds the transposed term as well (the mathematically complete Gauss-Newton
+ * block; round 1-2 behaviour, kept as a switch for the sensitivity report). */
 static void build_system(orc_ba* h) {
   if (h->solver == 2) { build_system_par(h); return; }
   const int np = h->np;
@@ -691,6 +702,10 @@ static void build_system(orc_ba* h) {
       for (int c2 = a; c2 < ns; c2++) {
         for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
           const double v = w*(J[a][r]*J[c2][c] + J[a][6+r]*J[c2][6+c]);
+          if (c2 != a && U[a] == U[c2] && !h->dup_symmetric) {      /* one vertex at two positions: upper triangle of Ja^T Omega Jb, mirrored */
+            if (r <= c) { h->Hpp[(size_t)(6*U[a]+r)*np + 6*U[a]+c] += v; if (r < c) h->Hpp[(size_t)(6*U[a]+c)*np + 6*U[a]+r] += v; }
+            continue;
+          }
           h->Hpp[(size_t)(6*U[a]+r)*np + 6*U[c2]+c] += v;
           if (c2 != a || U[a] != U[c2]) { if (c2 != a) h->Hpp[(size_t)(6*U[c2]+c)*np + 6*U[a]+r] += v; }
         }

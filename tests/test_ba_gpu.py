@@ -261,7 +261,9 @@ def test_calibration_chain_shapes(gpu_required):
         assert rel_err(Rg, Rr) < 1e-6 and rel_err(tg, tr) < 1e-6
         Rt = p.cam_R[c] @ p.cam_R[0].T
         tt = p.cam_t[c] - Rt @ p.cam_t[0]
-        assert np.abs(tg - tt).max() < 0.25 * np.abs(p.rel_t[c] - tt).max()
+        # (ten iterations with g2o's one-sided block for the doubly-present relative pose, DESIGN.md 2: slower than the complete
+        # Gauss-Newton block, which covered three quarters of the way in the same ten iterations)
+        assert np.abs(tg - tt).max() < 0.5 * np.abs(p.rel_t[c] - tt).max()
 
 
 def _pose(run, p, c):

@@ -1448,3 +1448,27 @@ def test_pose_update_estimators_against_numpy(est):
     assert np.allclose(mu, np.linalg.solve(C, v), rtol=1e-9, atol=1e-13)
     if est != "Tukey":
         assert (w[f] > 0).all()          # only the cut-off estimator produces outliers (dWeight == 0, :1470)
+
+
+def test_duplicated_vertex_one_sided_block_and_its_symmetric_variant_meet_at_the_optimum():
+    """BundleAdjusterCalib with non-fixed points puts the relative camera pose at two positions of one edge (link 2 of the observer
+    chain and of the source chain, src/BundleAdjusterCalib.cc:166-199).  g2o adds that pair's cross term to the vertex's diagonal block
+    once and solves with the block's upper triangle (ba_oracle.c build_system, [3P-memory]); the default follows it.  The switch
+    dup_symmetric adds the transposed term too (the complete Gauss-Newton block).  Both are approximations of the same Hessian with
+    the exact gradient: different iterates, same fixed point."""
+    from mcptam_amd import synth
+    from helpers import run_bundle, rel_err
+    p = synth.make_config("calib")
+    assert (~p.pt_fixed).sum() > 100 and ((p.pt_src[~p.pt_fixed, 1] > 0).sum() > 50), "needs non-fixed points whose source camera is a relative one"
+    runs = {}
+    for sym in (False, True):
+        o = _orc(p.cams)
+        o.SetDupSymmetric(sym)
+        runs[sym] = run_bundle(o, p)            # to convergence
+        assert runs[sym]["converged"]
+    a, b = runs[False], runs[True]
+    assert a["logs"][2]["chi2_end"] != b["logs"][2]["chi2_end"], "the switch must change the iterates"
+    assert rel_err(a["R"], b["R"]) < 1e-6 and rel_err(a["t"], b["t"]) < 1e-6 and rel_err(a["X"], b["X"]) < 1e-6
+    assert abs(a["logs"][-1]["chi2_end"] - b["logs"][-1]["chi2_end"]) <= 1e-7 * b["logs"][-1]["chi2_end"]
+    cr = [rel_err(a["cam_R"][c], b["cam_R"][c]) for c in range(1, len(p.cams))]
+    assert max(cr) < 1e-6
