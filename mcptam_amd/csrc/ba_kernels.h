@@ -570,6 +570,17 @@ k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const doub
   if (threadIdx.x == 0) { part_scale[blockIdx.x] = a; part_ss[blockIdx.x] = b; }
 }
 
+// VertexRelPoint::oplusImpl (ChainBundle.cc:237-281) with a GIVEN update per free point: what g2o's update(_solver->x()) does with the
+// x its solver still holds after a failed factorisation
+__global__ void k_apply_point_step(DevProblem P, const double* __restrict__ xl, const double* __restrict__ pt_cur, double* __restrict__ pt_trial) {
+  const int l = blockIdx.x*blockDim.x + threadIdx.x;
+  if (l >= P.nfl) return;
+  const int pt = P.fl_point[l];
+  double o[3];
+  point_oplus(pt_cur + 3*(size_t)pt, xl + 3*(size_t)l, o);
+  pt_trial[3*(size_t)pt] = o[0]; pt_trial[3*(size_t)pt+1] = o[1]; pt_trial[3*(size_t)pt+2] = o[2];
+}
+
 // Tukey outlier flags in sorted order (ChainBundle.cc:1385-1398 with MEstimator.h:84-96)
 __global__ void k_tukey_flags(int n, const double* __restrict__ chi2, double s2, unsigned char* __restrict__ flag) {
   const int m = blockIdx.x*blockDim.x + threadIdx.x;

@@ -318,6 +318,7 @@ struct mcp_ba {
   int wait_stream(hipStream_t s, const char* what);
   // trial buffers of the multi-rank tail (ba_trial.h) and the selection state k_trial_post leaves in them
   DevBuf<double> d_trial[MAX_SYS]; DevBuf<SelState> d_trstate[MAX_SYS];
+  int test_fail_trial = 0, test_trial_no = 0;      // MCP_BA_TEST_FAIL_TRIAL=k: the k-th trial of the handle's life is treated as a failed factorisation
   int sel_ride = 1;                // MCP_BA_SELECT_RIDE=0: the median never uses the histograms that rode on the trial's all-reduce
   int pred_bin = -1;               // first digit of the last median the host has seen (the prediction the trials histogram around)
   int tr_pred_ok[MAX_SYS] = {0, 0, 0, 0}, tr_ovf[MAX_SYS] = {0, 0, 0, 0};
@@ -1848,6 +1849,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         bool ok2 = true;
         if (solve_trial(lambda, ok2, ni)) return MCP_ERR_RUNTIME;
         if (start_pending) take_start();
+        if (test_fail_trial > 0 && ++test_trial_no == test_fail_trial) ok2 = false;      // (test hook: this trial's factorisation "failed")
         double scale, ss;
         trial_chi_raw = h_res[0];
         if (ok2) {
@@ -1873,6 +1875,22 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
             HIPCK(hipMemcpy(v2, d_res.p + 16, 16, hipMemcpyDeviceToHost)); sl = v2[0]; sq = v2[1];
           }
           scale += sl; ss += sq;
+          // g2o goes on with update(_solver->x()) -- the solver's x is what the last successful solve left -- and computeActiveErrors:
+          // the edges then hold the errors of (current state (+) stale x), which is what the residual action reads if this was the
+          // iteration's last trial (OptimizationAlgorithmLevenberg::solve [3P-memory]; ChainBundle.cc:1096-1116).  Same here.
+          {
+            const int tr = last_tr;
+            hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lambda, (const double*)d_xp_good.p, (const double*)bp(), (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
+            if (nfl) hipLaunchKernelGGL(k_apply_point_step, dim3((nfl + 255)/256), dim3(256), 0, st, P, (const double*)d_xl_good.p, (const double*)d_pt[cur].p, d_pt[tr].p);
+            launch_chains(tr);
+            launch_eval(tr, true, nullptr);
+            const int nbe2 = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+            hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe2, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
+            if (allreduce(d_res.p, 1, 0, false, "chi2 of the stale step after a failed factorisation")) return MCP_ERR_RUNTIME;
+            if (read_results(1)) return MCP_ERR_RUNTIME;
+            trial_chi_raw = h_res[0];
+            sel_src = -1;
+          }
         }
         ss_last = ss;
         rho = currentChi - tempChi;
@@ -1899,7 +1917,9 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       {
         // activeRobustChi2 of whatever errors the edges hold: the last trial's (or, when verbose, the
         // recomputed errors of the current state)
-        double curchi = accepted ? currentChi : (verbose ? currentChi : trial_chi_raw);
+        // (an accepted trial's errors ARE the edges' errors; only after a failed factorisation whose stale step was accepted --
+        // negative scale -- does that differ from the schedule's currentChi, which is DBL_MAX then)
+        double curchi = accepted ? trial_chi_raw : (verbose ? currentChi : trial_chi_raw);
         const double pct = (last_chi2_action - curchi)/last_chi2_action;
         if (!prm.disable_convergence) {
           if (pct >= 0 && pct <= prm.update_percent_limit) { conv_res = 1; if (abort_flag) *abort_flag = 1; }
@@ -2051,6 +2071,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
   { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
+  { const char* e = getenv("MCP_BA_TEST_FAIL_TRIAL"); if (e) h->test_fail_trial = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_RIDE"); if (e) h->sel_ride = atoi(e); }
   { const char* e = getenv("MCP_BA_TIMEOUT_MS"); if (e && atof(e) > 0) h->timeout_ms = atof(e); }
   for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }

@@ -127,6 +127,11 @@ class OracleBundle:
         self._L.orc_ba_set_dup_symmetric.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self._L.orc_ba_set_dup_symmetric(self._h, int(on))
 
+    def SetFailTrial(self, k):
+        """test switch: the k-th LM trial behaves as a failed factorisation"""
+        self._L.orc_ba_set_fail_trial.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._L.orc_ba_set_fail_trial(self._h, int(k))
+
     def DisableConvergence(self, disable=True):
         self._L.orc_ba_disable_convergence(self._h, int(disable))
 

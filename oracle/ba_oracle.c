@@ -69,6 +69,7 @@ struct orc_ba {
   /* CPU-baseline variants (ba_baseline.inc): 0 = the oracle proper (Schur, dense Cholesky, 1 thread), 1 = A (sparse
    * L D L^T of the un-marginalised system, 1 thread), 2 = B (Schur, OpenMP) */
   int solver, threads; void* sparse; void* par;
+  int fail_trial, trial_no;   /* test switch: the fail_trial-th trial is treated as a failed factorisation (CHOLMOD not positive definite) */
   int dup_symmetric;          /* 1: a vertex that occurs twice in an edge gets both cross terms (see build_system) */
 };
 
@@ -305,6 +306,7 @@ void orc_ba_set_limits(orc_ba* h, int max_trials, double pct, double rms, double
 }
 void orc_ba_disable_convergence(orc_ba* h, int d) { h->no_converge = d; }
 void orc_ba_set_dup_symmetric(orc_ba* h, int on) { h->dup_symmetric = on; }
+void orc_ba_set_fail_trial(orc_ba* h, int k) { h->fail_trial = k; h->trial_no = 0; }
 
 static int new_id(orc_ba* h, int kind, int index) {
   int id = h->next_id++;
@@ -929,7 +931,8 @@ int orc_ba_compute(orc_ba* h, volatile unsigned char* abort_flag, int n_iter, do
       gather_b(h);
       do {
         push_state(h);
-        int ok2 = (solve_system(h, h->lambda, h->x) == 0);     /* x untouched on failure */
+        int ok2 = (h->fail_trial > 0 && ++h->trial_no == h->fail_trial) ? 0       /* test switch: this trial's factorisation "fails" */
+                  : (solve_system(h, h->lambda, h->x) == 0);     /* x untouched on failure */
         apply_update(h, h->x);
         compute_active_errors(h);
         tempChi = active_robust_chi2(h);

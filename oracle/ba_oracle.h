@@ -66,6 +66,9 @@ void orc_ba_disable_convergence(orc_ba*, int disable);
 /* oracle-only switch (sensitivity report): 1 = a pose vertex that occurs at two positions of one edge receives both cross terms
  * (symmetric Gauss-Newton block) instead of g2o's one-sided block (ba_oracle.c build_system) */
 void orc_ba_set_dup_symmetric(orc_ba*, int on);
+/* test switch: the k-th LM trial of the handle behaves as if the linear solver had failed (g2o: x keeps its previous content, is
+ * applied, the trial is rejected) */
+void orc_ba_set_fail_trial(orc_ba*, int k);
 /* CPU-baseline variants for bench.py (ba_baseline.inc): solver 0 = the oracle proper, 1 = A "reference-shaped" (sparse
  * L D L^T of the un-marginalised system, one thread), 2 = B "best CPU" (Schur, OpenMP over `threads`) */
 void orc_ba_set_solver(orc_ba*, int solver, int threads);

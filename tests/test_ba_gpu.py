@@ -863,3 +863,33 @@ def test_threaded_prepare_builds_the_serial_structure(gpu_required, cfg, iters, 
         assert np.array_equal(a, b)
     assert new["logs"] == old["logs"] and new["outliers"] == old["outliers"]
     assert np.array_equal(new["R"], old["R"]) and np.array_equal(new["t"], old["t"]) and np.array_equal(new["X"], old["X"])
+
+
+@pytest.mark.parametrize("k,max_trials", [(4, 100), (2, 2)])
+def test_failed_factorisation_applies_the_stale_step_like_g2o(gpu_required, k, max_trials, monkeypatch):
+    """When the linear solver fails, g2o's x keeps the last successful solve's content, update(x) applies it, the trial is rejected
+    and popped -- but the edges keep that trial's errors, which the residual action reads if it was the iteration's last trial
+    (OptimizationAlgorithmLevenberg::solve [3P-memory], src/ChainBundle.cc:1096-1116).  Forced on the k-th trial on both sides; with
+    max_trials = 2 the failed trial IS the last one of its iteration, so chi2_end is the stale step's chi2."""
+    from mcptam_amd import synth
+    from mcptam_amd.chain_bundle import ChainBundle
+    p = synth.make_config("c2small") if "c2small" in synth.CONFIGS else synth.make_config("c2", n_mkf=16, n_points=1200)
+    monkeypatch.setattr(ChainBundle, "snMaxTrialsAfterFailure", max_trials)
+    monkeypatch.setenv("MCP_BA_TEST_FAIL_TRIAL", str(k))
+    g = _gpu(p.cams, disable_convergence=True)
+    o = _orc(p.cams); o.DisableConvergence(True); o.SetFailTrial(k); o.SetLimits(max_trials)
+    gpu = run_bundle(g, p, 5)
+    ref = run_bundle(o, p, 5)
+    assert gpu["rc"] == ref["rc"]
+    assert [l["trials"] for l in gpu["logs"]] == [l["trials"] for l in ref["logs"]] and [l["accepted"] for l in gpu["logs"]] == [l["accepted"] for l in ref["logs"]]
+    for a, b in zip(gpu["logs"], ref["logs"]):
+        assert abs(a["chi2_end"] - b["chi2_end"]) <= 1e-9 * abs(b["chi2_end"]) and abs(a["lambda_end"] - b["lambda_end"]) <= 1e-9 * b["lambda_end"]
+        assert abs(a["rms_update"] - b["rms_update"]) <= 1e-7 * max(b["rms_update"], 1e-30)
+    assert rel_err(gpu["R"], ref["R"]) < 1e-8 and rel_err(gpu["X"], ref["X"]) < 1e-8
+    plain = run_bundle(_orc_nc(p.cams), p, 5)
+    assert plain["logs"] != ref["logs"], "the forced failure must be visible in the iteration log"
+
+
+def _orc_nc(cams):
+    o = _orc(cams); o.DisableConvergence(True)
+    return o
