@@ -127,6 +127,11 @@ class OracleBundle:
         self._L.orc_ba_set_dup_symmetric.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self._L.orc_ba_set_dup_symmetric(self._h, int(on))
 
+    def SetVariant(self, key, value):
+        """oracle-only [3P-memory] switches of the LM schedule (ba_oracle.h orc_ba_set_variant)"""
+        self._L.orc_ba_set_variant.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        self._L.orc_ba_set_variant(self._h, int(key), float(value))
+
     def SetFailTrial(self, k):
         """test switch: the k-th LM trial behaves as a failed factorisation"""
         self._L.orc_ba_set_fail_trial.argtypes = [ctypes.c_void_p, ctypes.c_int]

@@ -69,6 +69,11 @@ struct orc_ba {
   /* CPU-baseline variants (ba_baseline.inc): 0 = the oracle proper (Schur, dense Cholesky, 1 thread), 1 = A (sparse
    * L D L^T of the un-marginalised system, 1 thread), 2 = B (Schur, OpenMP) */
   int solver, threads; void* sparse; void* par;
+  /* [3P-memory] pieces of g2o's OptimizationAlgorithmLevenberg as switches (sensitivity report, scripts/oracle_sensitivity.py):
+   * var_tau: initial lambda = tau * max diag (1e-5); var_rho_eps: the constant added to the rho denominator (1e-3);
+   * var_reject: 0 = lambda *= ni, ni *= 2; 1 = lambda *= 2 every time; var_accept: 0 = max(1/3, min(1 - (2 rho - 1)^3, 2/3)),
+   * 1 = 1/3 always, 2 = no 2/3 cap */
+  double var_tau, var_rho_eps; int var_reject, var_accept;
   int fail_trial, trial_no;   /* test switch: the fail_trial-th trial is treated as a failed factorisation (CHOLMOD not positive definite) */
   int dup_symmetric;          /* 1: a vertex that occurs twice in an edge gets both cross terms (see build_system) */
 };
@@ -285,6 +290,7 @@ orc_ba* orc_ba_create(const orc_camera* cams, int ncam, int use_robust, int use_
   h->next_id = 1;                                   /* mnCurrId = 1, :1145 */
   h->max_cov = DBL_MAX;                             /* :1179 */
   h->last_chi2_action = DBL_MAX;                    /* _dLastChi2, :1068 */
+  h->var_tau = 1e-5; h->var_rho_eps = 1e-3;          /* g2o defaults [3P-memory] */
   return h;
 }
 static void free_structure(orc_ba* h) {
@@ -306,6 +312,9 @@ void orc_ba_set_limits(orc_ba* h, int max_trials, double pct, double rms, double
 }
 void orc_ba_disable_convergence(orc_ba* h, int d) { h->no_converge = d; }
 void orc_ba_set_dup_symmetric(orc_ba* h, int on) { h->dup_symmetric = on; }
+void orc_ba_set_variant(orc_ba* h, int key, double value) {
+  switch (key) { case 0: h->var_tau = value; break; case 1: h->var_rho_eps = value; break; case 2: h->var_reject = (int)value; break; case 3: h->var_accept = (int)value; break; default: break; }
+}
 void orc_ba_set_fail_trial(orc_ba* h, int k) { h->fail_trial = k; h->trial_no = 0; }
 
 static int new_id(orc_ba* h, int kind, int index) {
@@ -923,7 +932,7 @@ int orc_ba_compute(orc_ba* h, volatile unsigned char* abort_flag, int n_iter, do
           double maxd = 0;
           for (int i = 0; i < h->np; i++) { double d = fabs(h->Hpp[(size_t)i*h->np + i]); if (d > maxd) maxd = d; }
           for (int l = 0; l < h->nfl; l++) for (int k = 0; k < 3; k++) { double d = fabs(h->V[9*(size_t)l + 4*k]); if (d > maxd) maxd = d; }
-          h->lambda = 1e-5*maxd;
+          h->lambda = h->var_tau*maxd;
         }
         ni = 2;
       }
@@ -940,15 +949,17 @@ int orc_ba_compute(orc_ba* h, volatile unsigned char* abort_flag, int n_iter, do
         rho = currentChi - tempChi;
         double scale = 0;
         for (int j = 0; j < h->nx; j++) scale += h->x[j]*(h->lambda*h->x[j] + h->ball[j]);
-        scale += 1e-3;
+        scale += h->var_rho_eps;
         rho /= scale;
         if (rho > 0 && isfinite(tempChi)) {
           double alpha = 1. - pow((2*rho - 1), 3);
-          alpha = fmin(alpha, 2./3.);
+          if (h->var_accept != 2) alpha = fmin(alpha, 2./3.);
           double sf = fmax(1./3., alpha);
+          if (h->var_accept == 1) sf = 1./3.;
           h->lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
         } else {
-          h->lambda *= ni; ni *= 2; pop_state(h); accepted = 0;
+          if (h->var_reject == 1) h->lambda *= 2; else { h->lambda *= ni; ni *= 2; }
+          pop_state(h); accepted = 0;
         }
         qmax++;
       } while (rho < 0 && qmax < h->max_trials && !terminate_flag(abort_flag));

@@ -66,6 +66,10 @@ void orc_ba_disable_convergence(orc_ba*, int disable);
 /* oracle-only switch (sensitivity report): 1 = a pose vertex that occurs at two positions of one edge receives both cross terms
  * (symmetric Gauss-Newton block) instead of g2o's one-sided block (ba_oracle.c build_system) */
 void orc_ba_set_dup_symmetric(orc_ba*, int on);
+/* [3P-memory] constants / rules of g2o's Levenberg schedule as oracle-only switches (scripts/oracle_sensitivity.py):
+ * key 0 initial-lambda factor tau (1e-5), 1 constant in the rho denominator (1e-3), 2 rejection rule (0: lambda *= ni, ni *= 2;
+ * 1: lambda *= 2), 3 acceptance rule (0: max(1/3, min(1 - (2 rho - 1)^3, 2/3)); 1: 1/3; 2: no 2/3 cap) */
+void orc_ba_set_variant(orc_ba*, int key, double value);
 /* test switch: the k-th LM trial of the handle behaves as if the linear solver had failed (g2o: x keeps its previous content, is
  * applied, the trial is rejected) */
 void orc_ba_set_fail_trial(orc_ba*, int k);

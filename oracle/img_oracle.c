@@ -366,6 +366,8 @@ static void gen_field(int i, const double* p, double* o) {
 }
 /* CVD::transform + sample [3P-memory]: incremental source position, bilinear sample in double,
  * truncating conversion to byte; returns the number of destination pixels that fell outside */
+static int g_transform_round = 0;      /* oracle-only switch (sensitivity report): 1 = the byte conversion rounds half up instead of truncating */
+void orc_img_set_variant(int key, int value) { if (key == 0) g_transform_round = value; }
 static int cvd_transform8(const olevel* in, uint8_t* out /*8x8*/, const double M[4], double inx, double iny, double outx, double outy) {
   const int w = 8, h = 8, iw = in->w, ih = in->h;
   const double across[2] = { M[0], M[2] }, down[2] = { M[1], M[3] };
@@ -387,7 +389,7 @@ static int cvd_transform8(const olevel* in, uint8_t* out /*8x8*/, const double M
         const double x = p[0] - lx, y = p[1] - ly;
         const uint8_t* q = in->img + (size_t)ly*iw + lx;
         const double v = (1 - y)*((1 - x)*q[0] + x*q[1]) + y*((1 - x)*q[iw] + x*q[iw + 1]);
-        out[i*8 + j] = (uint8_t)v;
+        out[i*8 + j] = g_transform_round ? (uint8_t)(v + 0.5) : (uint8_t)v;
       } else { out[i*8 + j] = 0; ++count; }
     }
   return count;

@@ -43,6 +43,10 @@ int     orc_kf_make_rest(orc_kf*, int use_shi, int use_percent, double top_fract
 int     orc_kf_num_candidates(orc_kf*, int level);
 int     orc_kf_get_candidates(orc_kf*, int level, orc_int2* pos, double* score, int cap);
 
+/* oracle-only [3P-memory] switch (scripts/oracle_sensitivity.py): key 0 = CVD::transform's float -> byte conversion, 0 truncating
+ * (default), 1 rounding half up */
+void orc_img_set_variant(int key, int value);
+
 /* primitives exposed for unit checks */
 int    orc_fast10_is_corner(const uint8_t* p, int stride, int b);
 int    orc_fast10_score(const uint8_t* p, int stride, int bstart);
