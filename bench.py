@@ -425,6 +425,10 @@ def main():
             result["tracker_c3"] = bench_tracker.main(frames=20, cpu_frames=2)
         except Exception as exc:       # the headline line must not depend on the secondary one
             result["tracker_c3"] = {"error": repr(exc)}
+        try:
+            result["tracker_c5"] = bench_tracker.main_c5(frames=10, cpu_frames=1)       # eight 1280x960 cameras, 8k points, on this one device
+        except Exception as exc:
+            result["tracker_c5"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

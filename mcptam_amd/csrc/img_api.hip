@@ -329,7 +329,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   // device scratch, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d | pad 6 d |
   // override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back in
   // one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
-  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; std::vector<uint8_t> hblk; };
+  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; std::vector<uint8_t> hblk; };
   static thread_local RefineScratch rs;
   const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam;
   const size_t o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam, blk = ((o_nl + (size_t)n_iter + 15)/16)*16;
@@ -344,6 +344,11 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
     else (void)hipGetLastError();
   }
   bool regs = use_regs && (regs_ok_mask & dbit) && n <= PRR_THREADS*PRR_PPT;          // the points fit the register-resident kernel
+  // many points: the iterations over several workgroups (k_pose_refine_multi); MCP_TRACK_REFINE_MULTI = 0 never, 1 whenever the
+  // points do not fit the register-resident kernel (default), 2 always
+  const int use_multi = [] { const char* e = getenv("MCP_TRACK_REFINE_MULTI"); return e ? atoi(e) : 1; }();
+  const bool multi = n_iter <= PRM_MAX_ITER && ((use_multi == 2 && n >= 64) || (use_multi == 1 && !regs && n > PRR_THREADS*PRR_PPT));
+  if (multi) regs = false;
   if (rs.dp.alloc(n) || rs.dblk.alloc(blk) || rs.dw.alloc(n)) return -1;
   auto alloc_plain = [&]() { return rs.dJ.alloc(12*(size_t)n) || rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n); };
   if (!regs && alloc_plain()) return -1;
@@ -367,7 +372,16 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
       if (alloc_plain()) return -1;
     }
   }
-  if (!regs)
+  unsigned int prm_err = 0;
+  if (multi) {
+    if (rs.dprm.alloc(1)) return -1;
+    ICK(hipMemsetAsync(rs.dprm.p, 0, sizeof(PrmScratch), st));
+    const int ppw = [] { const char* e = getenv("MCP_TRACK_REFINE_PPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();      // points per workgroup (measured at 8000 points: 128: 407 us, 256: 337, 512: 311, 1024: 322)
+    const int nwg = std::max(1, std::min(PRM_MAX_WG, (n + ppw - 1)/ppw));
+    hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p);
+    ICK(hipGetLastError());
+    ICK(hipMemcpyAsync(&prm_err, &rs.dprm.p->err, sizeof prm_err, hipMemcpyDeviceToHost, st));
+  } else if (!regs)
     hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est);
 #ifdef MCP_PRR_PROF
   if (regs) {
@@ -383,6 +397,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
   if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
+  if (prm_err) return img_fail("mcp_track_pose_refine: a workgroup of the multi-workgroup iterations gave up waiting for the others");
   std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48);
   return 0;
 }

@@ -1130,6 +1130,235 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 }
 
 
+// ---- the same ten iterations over MANY workgroups (frames with thousands of tracked points: BASELINE c5, eight cameras) -------
+// k_pose_refine is one workgroup: at 8000 points its ten iterations take 0.76 ms -- 70 % of the device time of a c5 frame.  Here
+// every workgroup owns a slice of the points; what the iterations need from ALL points crosses the workgroups through small
+// device-scope buffers and a counter barrier:
+//   * Tukey / Cauchy / Huber sigma^2: the exact [nf/2] order statistic by most-significant-digit radix select -- per digit every
+//     workgroup adds its LDS histogram to a global one (integer atomics at device scope), barrier, every workgroup scans the same
+//     global histogram; after two digits the few candidates are gathered (atomic slot counter), barrier, and every workgroup
+//     resolves the remaining digits from that list on its own (lds_radix_select_1024) -- three barriers, all workgroups end with
+//     the same median, bit for bit;
+//   * the 21 + 6 WLS sums: a partial per workgroup, barrier, every workgroup adds the partials in workgroup order and solves the
+//     6 x 6 itself (identical inputs, identical arithmetic: identical poses everywhere, nothing to broadcast).
+// Cross-workgroup data is written and read with 8-byte device-scope atomics (the per-XCD L2s are not coherent with each other,
+// MI355X_MICROARCH.md "Workgroup dispatch ..."); the barrier is one monotonic counter: drain own stores, add, poll.  Every buffer
+// is per (iteration, digit), zeroed by the host once per call: no reuse, no reset races.  A spin that exceeds its bound raises
+// an error word that ends every later wait (the call then fails; nothing hangs).
+constexpr int PRM_THREADS = 1024, PRM_MAX_WG = 64, PRM_CAND_CAP = 4096, PRM_MAX_ITER = 16;
+struct PrmScratch {           // device memory, zeroed before the launch
+  unsigned int sync;          // barrier counter
+  unsigned int err;           // a wait gave up
+  unsigned int nf;            // found points over all workgroups
+  unsigned int pad_;
+  unsigned int cand_n[PRM_MAX_ITER];
+  unsigned int hist[PRM_MAX_ITER][SEL_PASSES][SEL_BINS];
+  double cand[PRM_MAX_ITER][PRM_CAND_CAP];
+  double acc[PRM_MAX_ITER][PRM_MAX_WG][28];
+};
+__device__ inline unsigned int prm_ld(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double prm_ldd(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void prm_std(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all threads of all workgroups; `epoch` counts the barriers passed (uniform)
+__device__ inline void prm_barrier(PrmScratch* G, unsigned int& epoch, unsigned int nwg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY thread: its own device-scope stores / atomics have completed ...
+  __syncthreads();                                            // ... before thread 0 tells the other workgroups that this one has arrived
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&G->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int want = (epoch + 1)*nwg;
+    unsigned long long spins = 0;
+    while (prm_ld(&G->sync) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1ull << 24) || prm_ld(&G->err)) { __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  ++epoch;
+  __syncthreads();
+}
+__global__ void __launch_bounds__(PRM_THREADS)
+k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
+                    double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
+                    double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out,
+                    int est, PrmScratch* __restrict__ G) {
+  __shared__ unsigned int hist[SEL_BINS];
+  __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
+  __shared__ double red[PRM_THREADS/64][28];
+  __shared__ double pose[12], v6[6], tot[27];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned int nwg = gridDim.x, wg = blockIdx.x;
+  const int i0 = (int)((long long)n*wg/nwg), i1 = (int)((long long)n*(wg + 1)/nwg);
+  unsigned int epoch = 0;
+  if (t < 12) pose[t] = bfw_io[t];
+  if (t < 6) v6[t] = 0.0;
+  // found points over all slices (constant over the iterations)
+  {
+    int nf_loc = 0;
+    for (int i = i0 + t; i < i1; i += PRM_THREADS) nf_loc += pts[i].found ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) nf_loc += __shfl_xor(nf_loc, o, 64);
+    if (lane == 0 && nf_loc) __hip_atomic_fetch_add(&G->nf, (unsigned int)nf_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  prm_barrier(G, epoch, nwg);
+  const int nf = (int)prm_ld(&G->nf);
+  for (int it = 0; it < n_iter; ++it) {
+    const bool nl = nonlinear[it] != 0;
+    for (int i = i0 + t; i < i1; i += PRM_THREADS) {
+      mcp_pose_point& p = pts[i];
+      if (!p.found) continue;
+      double* Ji = J + 12*(size_t)i;
+      if (nl) {
+        const double* cfb = cfb_all + 12*(size_t)p.cam;
+        double xb[3], xc[3];
+        mat3_vec(pose, p.world_pos, xb); xb[0] += pose[9]; xb[1] += pose[10]; xb[2] += pose[11];
+        mat3_vec(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+        if (it != 0) {
+          Projection pr; cam_project<true>(cams[p.cam], xc, pr);
+          p.image[0] = pr.u; p.image[1] = pr.v; p.cam_derivs[0] = pr.D[0]; p.cam_derivs[1] = pr.D[1]; p.cam_derivs[2] = pr.D[2]; p.cam_derivs[3] = pr.D[3];
+        }
+        double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+          double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb, mb, mc);
+          const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
+          Ji[m] = p.cam_derivs[0]*s0 + p.cam_derivs[1]*s1; Ji[6 + m] = p.cam_derivs[2]*s0 + p.cam_derivs[3]*s1;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { double a = 0.0; for (int k = 0; k < 6; ++k) a += Ji[6*r + k]*v6[k]; p.image[r] += a; }
+      }
+      const double e0 = p.sqrt_inv_noise*(p.found_pos[0] - p.image[0]), e1 = p.sqrt_inv_noise*(p.found_pos[1] - p.image[1]);
+      ex[2*(size_t)i] = e0; ex[2*(size_t)i + 1] = e1; e2s[i] = e0*e0 + e1*e1;
+    }
+    __syncthreads();
+    if (nf == 0) { if (t < 6) v6[t] = 0.0; __syncthreads(); continue; }           // no valid measurements: null update (the same decision everywhere)
+    double s2 = override_sigma[it];
+    if (!(s2 > 0)) {
+      // exact [nf/2] order statistic of the squared errors of ALL workgroups
+      unsigned long long prefix = 0, kk = (unsigned long long)(nf/2);
+      bool done = false;
+      for (int pass = 0; pass < SEL_PASSES && !done; ++pass) {
+        const int sh = sel_shift(pass);
+        const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
+        const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
+        for (int b = t; b < SEL_BINS; b += PRM_THREADS) hist[b] = 0u;
+        __syncthreads();
+        for (int i = i0 + t; i < i1; i += PRM_THREADS) {
+          if (!pts[i].found) continue;
+          const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(e2s[i]));
+          if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        unsigned int* gh = G->hist[it][pass];
+        for (int b = t; b < SEL_BINS; b += PRM_THREADS) if (hist[b]) __hip_atomic_fetch_add(gh + b, hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prm_barrier(G, epoch, nwg);
+        for (int b = t; b < SEL_BINS; b += PRM_THREADS) hist[b] = prm_ld(gh + b);
+        __syncthreads();
+        int bin; unsigned long long kin; unsigned int in_bin;
+        lds_find_bin_1024(hist, kk, bin, kin, in_bin, sel_sc);
+        prefix |= (unsigned long long)bin << sh; kk = kin;
+        if (sh == 0) { done = true; break; }
+        if (in_bin <= (unsigned int)PRM_CAND_CAP) {
+          // few enough keys share the prefix: gather them, every workgroup finishes on its own
+          const unsigned long long hm2 = ~0ull << sh;
+          for (int i = i0 + t; i < i1; i += PRM_THREADS) {
+            if (!pts[i].found) continue;
+            const double a = fabs(e2s[i]);
+            if (((unsigned long long)__double_as_longlong(a) & hm2) == prefix) {
+              const unsigned int slot = __hip_atomic_fetch_add(&G->cand_n[it], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (slot < (unsigned int)PRM_CAND_CAP) prm_std(&G->cand[it][slot], a);
+            }
+          }
+          prm_barrier(G, epoch, nwg);
+          const int m = (int)min(prm_ld(&G->cand_n[it]), (unsigned int)PRM_CAND_CAP);
+          const double* cd = G->cand[it];
+          prefix = lds_radix_select_1024(m, kk, pass + 1, prefix, [&](int i, unsigned long long& key) {
+            key = (unsigned long long)__double_as_longlong(prm_ldd(cd + i));
+            return true; }, hist, sel_sc, sel_st);
+          done = true;
+        }
+      }
+      const double med = __longlong_as_double((long long)prefix);
+      s2 = mest_sigma_sq(est, (double)nf, med);
+    }
+    // this workgroup's part of the weighted normal equations
+    double a[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a[k] = 0.0;
+    const bool last = (it == n_iter - 1);
+    for (int i = i0 + t; i < i1; i += PRM_THREADS) {
+      const mcp_pose_point& p = pts[i];
+      if (!p.found) { if (last && w_out) w_out[i] = 0.0; continue; }
+      const double err2 = e2s[i];
+      const double w = mest_weight(est, err2, s2);
+      if (last && w_out) w_out[i] = w;
+      if (w == 0.0) continue;
+      const double* Ji = J + 12*(size_t)i;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double Jr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jr[k] = p.sqrt_inv_noise*Ji[6*r + k];
+        const double m = ex[2*(size_t)i + r];
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          a[21 + x] += w*m*Jr[x];
+#pragma unroll
+          for (int y = 0; y <= x; ++y) { a[q] += w*Jr[x]*Jr[y]; ++q; }
+        }
+      }
+    }
+    {
+      double w32[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w32[k] = k < 27 ? a[k] : 0.0;
+      int idx; const double total = wave_reduce_scatter32(w32, lane, idx);
+      if (!(lane & 1) && idx < 27) red[wave][idx] = total;
+    }
+    __syncthreads();
+    if (t < 27) { double sum = 0.0; for (int wv = 0; wv < PRM_THREADS/64; ++wv) sum += red[wv][t]; prm_std(&G->acc[it][wg][t], sum); }
+    prm_barrier(G, epoch, nwg);
+    if (t < 27) { double sum = 0.0; for (unsigned int g = 0; g < nwg; ++g) sum += prm_ldd(&G->acc[it][g][t]); tot[t] = sum; }      // workgroup order: the same sum everywhere
+    __syncthreads();
+    if (t == 0) {
+      double C[36], v[6], mu[6], rd[6];
+      int q = 0;
+#pragma unroll
+      for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
+#pragma unroll
+      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double d = C[7*j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
+        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
+      Se3 E, T, R;
+      se3_exp(mu, E);
+      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
+      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
+      se3_compose(E, T, R);
+      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
+      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
+      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+    }
+    __syncthreads();
+  }
+  if (wg == 0) {
+    if (t < 12) bfw_io[t] = pose[t];
+    if (t < 6) mu_out[t] = v6[t];
+  }
+}
+
+
 // ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
 // One workgroup of 256 threads = one wavefront per SIMD, so a thread may keep 512 registers: its four points' found position,
 // noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
+def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 50, 20), label="c3"):
     from mcptam_amd import synth_img
     from mcptam_amd.keyframe import KeyFrame, pack_points, pose_points, track_pose_refine, track_pose_update, track_search
     sc = synth_img.make_tracking_scene(size=size)
@@ -18,7 +18,7 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
     for c in range(cams):
         src[c].MakeKeyFrame_Lite(sc["imgA"]); src[c].MakeKeyFrame_Rest()
         osrc[c].MakeKeyFrame_Lite(sc["imgA"]); osrc[c].MakeKeyFrame_Rest()
-        pts.append(synth_img.make_map_points(sc["cam"], src[c], osrc[c], sc["poseA"], sc["depth"], per_level=(100, 80, 50, 20)))
+        pts.append(synth_img.make_map_points(sc["cam"], src[c], osrc[c], sc["poseA"], sc["depth"], per_level=per_level))
     npts = sum(len(p) for p in pts)
     cur = [KeyFrame(*size) for _ in range(cams)]
     wpos = [np.array([p["world_pos"] for p in pts[c]]) for c in range(cams)]
@@ -68,7 +68,7 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
             oracle_track_pose_update(o["found"], o["found_pos"], o["image"], o["sqrt_inv_noise"], o["jacobian"], 16.0 if it > 5 else -1.0)
     cdt = (time.perf_counter() - t0)/cpu_frames
     px = cams*size[0]*size[1]
-    res = {"metric": "Tracker frames/s (c3: %d x %dx%d, %d tracked points/frame, 10 pose iterations)" % (cams, size[0], size[1], npts),
+    res = {"metric": "Tracker frames/s (%s: %d x %dx%d, %d tracked points/frame, 10 pose iterations)" % (label, cams, size[0], size[1], npts),
            "gpu_frames_per_s": 1/gdt, "gpu_ms_per_frame": gdt*1e3, "gpu_ms_per_frame_with_pcie_upload": gdt_pcie*1e3, "found_per_frame": found,
            "cpu_oracle_frames_per_s": 1/cdt, "cpu_cores": 1,
            "algorithmic_bytes_per_frame": int(px*(1.64 + 1.33) + npts*1500),
@@ -79,5 +79,10 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4):
     return res
 
 
+def main_c5(frames=10, cpu_frames=1):
+    """BASELINE config c5 on ONE device: eight 1280x960 cameras, 1000 tracked points per camera"""
+    return main(frames=frames, cpu_frames=cpu_frames, size=(1280, 960), cams=8, per_level=(400, 320, 200, 80), label="c5 on one GPU")
+
+
 if __name__ == "__main__":
-    print(json.dumps(main()))
+    print(json.dumps(main_c5() if len(sys.argv) > 1 and sys.argv[1] == "c5" else main()))

@@ -806,3 +806,40 @@ def test_pose_update_and_refine_with_the_other_m_estimators(gpu_required, est):
     assert np.allclose(mug, muo, rtol=1e-7, atol=1e-12) and np.allclose(wgl, wol, rtol=1e-9, atol=1e-12)
     pt, _, wt, _ = track_pose_refine(recs, [cam, cam], cfbs, bfw)
     assert np.abs(pt[1] - pg[1]).max() > 1e-9          # another estimator, another pose
+
+
+@pytest.mark.parametrize("est", ["Tukey", "Huber"])
+def test_pose_refine_over_many_workgroups_matches_oracle(gpu_required, est, monkeypatch):
+    """k_pose_refine_multi: the pose iterations with the points sliced over workgroups (frames with thousands of tracked points,
+    BASELINE c5) -- global exact median through device-scope histograms + candidate gather, partial WLS sums added in workgroup
+    order, every workgroup solving the same 6 x 6.  Against the oracle on 6000 points in 4 cameras (the default route at that size),
+    forced on the small scene (two workgroups), with schedules that exercise every median / override combination, and repeatable
+    bit for bit."""
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_refine
+    from oracle import oracle_track_pose_refine
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    rng = np.random.default_rng(17)
+    big = np.concatenate([recs]*12)[:6000].copy()
+    big["found_pos"] += rng.normal(size=(len(big), 2))*0.3                     # no two points alike
+    big["cam"] = rng.integers(0, 2, size=len(big))
+    big["found"][rng.uniform(size=len(big)) < 0.1] = 0
+    schedules = [(None, None), (np.ones(10, dtype=np.uint8), np.full(10, -1.0)), (np.array([1, 0, 0, 1], dtype=np.uint8), np.array([-1.0, 4.0, -1.0, -1.0]))]
+    for nl, ov in schedules:
+        kw = dict(estimator=est) if nl is None else dict(nonlinear=nl, override_sigma=ov, estimator=est)
+        pg, mg, wg, og = track_pose_refine(big, [cam, cam], cfbs, bfw, **kw)
+        po, mo, wo, oo = oracle_track_pose_refine(big, [cam, cam], cfbs, bfw, **kw)
+        assert np.allclose(pg[0], po[0], rtol=0, atol=1e-10) and np.allclose(pg[1], po[1], rtol=0, atol=1e-10)
+        assert np.allclose(mg, mo, rtol=0, atol=1e-10)
+        assert np.allclose(wg, wo, rtol=0, atol=1e-8) and np.array_equal(wg == 0, wo == 0)          # same outlier set: the median is exact
+        f = big["found"] != 0
+        assert np.allclose(og["image"][f], oo["image"][f], rtol=0, atol=1e-8)
+        p2, m2, w2, _ = track_pose_refine(big, [cam, cam], cfbs, bfw, **kw)
+        assert np.array_equal(pg[0], p2[0]) and np.array_equal(pg[1], p2[1]) and np.array_equal(mg, m2) and np.array_equal(wg, w2)
+    monkeypatch.setenv("MCP_TRACK_REFINE_MULTI", "2")
+    pg, mg, wg, og = track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
+    po, mo, wo, oo = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
+    assert np.allclose(pg[1], po[1], rtol=0, atol=1e-9) and np.allclose(mg, mo, rtol=0, atol=1e-9) and np.array_equal(wg == 0, wo == 0)
+    none = big.copy(); none["found"] = 0
+    pg, mg, wg, og = track_pose_refine(none, [cam, cam], cfbs, bfw)
+    assert np.all(mg == 0) and np.array_equal(pg[0], bfw[0]) and np.all(wg == 0)
