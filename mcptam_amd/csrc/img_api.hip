@@ -329,7 +329,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   // device scratch, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d | pad 6 d |
   // override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back in
   // one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
-  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; std::vector<uint8_t> hblk; };
+  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; };
   static thread_local RefineScratch rs;
   const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam;
   const size_t o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam, blk = ((o_nl + (size_t)n_iter + 15)/16)*16;
@@ -378,7 +378,19 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
     ICK(hipMemsetAsync(rs.dprm.p, 0, sizeof(PrmScratch), st));
     const int ppw = [] { const char* e = getenv("MCP_TRACK_REFINE_PPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();      // points per workgroup (measured at 8000 points: 128: 407 us, 256: 337, 512: 311, 1024: 322)
     const int nwg = std::max(1, std::min(PRM_MAX_WG, (n + ppw - 1)/ppw));
-    hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p);
+    // the median: per-digit global histograms (default), or -- MCP_TRACK_REFINE_GATHER=1, up to 16k points -- all squared errors through
+    // every workgroup's LDS with one barrier.  Measured at 8000 points in 16 workgroups: 311 us vs 322 us per ten iterations; the
+    // redundant 8000-key selection in every workgroup costs what the two extra barriers of the histogram form cost.
+    const bool gather = n <= PRM_GATHER_MAX && [] { const char* e = getenv("MCP_TRACK_REFINE_GATHER"); return e ? atoi(e) != 0 : false; }();
+    size_t dyn = 0;
+    if (gather) {
+      if (rs.de2all.alloc(2*(size_t)n)) return -1;
+      dyn = (size_t)n*sizeof(double);
+      static thread_local unsigned long long prm_attr_mask = 0;
+      if (!(prm_attr_mask & dbit)) { ICK(hipFuncSetAttribute((const void*)k_pose_refine_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRM_GATHER_MAX*sizeof(double)))); prm_attr_mask |= dbit; }
+    }
+    hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), dyn, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p,
+                       gather ? rs.de2all.p : (double*)nullptr);
     ICK(hipGetLastError());
     ICK(hipMemcpyAsync(&prm_err, &rs.dprm.p->err, sizeof prm_err, hipMemcpyDeviceToHost, st));
   } else if (!regs)

@@ -1156,6 +1156,7 @@ struct PrmScratch {           // device memory, zeroed before the launch
   double cand[PRM_MAX_ITER][PRM_CAND_CAP];
   double acc[PRM_MAX_ITER][PRM_MAX_WG][28];
 };
+constexpr int PRM_GATHER_MAX = 16384;      // squared errors of all points fit one workgroup's LDS (128 KB) up to here
 __device__ inline unsigned int prm_ld(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double prm_ldd(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void prm_std(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1179,7 +1180,8 @@ __global__ void __launch_bounds__(PRM_THREADS)
 k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
                     double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
                     double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out,
-                    int est, PrmScratch* __restrict__ G) {
+                    int est, PrmScratch* __restrict__ G, double* __restrict__ e2_all /* 2 x n, or null: per-digit global histograms */) {
+  extern __shared__ double sh_e2[];            // gather mode: everybody's squared errors
   __shared__ unsigned int hist[SEL_BINS];
   __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
   __shared__ double red[PRM_THREADS/64][28];
@@ -1231,7 +1233,22 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
     __syncthreads();
     if (nf == 0) { if (t < 6) v6[t] = 0.0; __syncthreads(); continue; }           // no valid measurements: null update (the same decision everywhere)
     double s2 = override_sigma[it];
-    if (!(s2 > 0)) {
+    if (!(s2 > 0) && e2_all) {
+      // Few enough points for one LDS: every workgroup publishes its slice's squared errors (-1 = not found), ONE barrier, every
+      // workgroup copies all of them and selects the [nf/2] order statistic on its own -- the same key set everywhere, the same
+      // median.  The buffer alternates by iteration: its next writer is two barriers behind its last reader.
+      double* eb = e2_all + (size_t)(it & 1)*n;
+      for (int i = i0 + t; i < i1; i += PRM_THREADS) prm_std(eb + i, pts[i].found ? e2s[i] : -1.0);
+      prm_barrier(G, epoch, nwg);
+      for (int i = t; i < n; i += PRM_THREADS) sh_e2[i] = prm_ldd(eb + i);
+      __syncthreads();
+      const unsigned long long sel = lds_radix_select_1024(n, (unsigned long long)(nf/2), 0, 0ull, [&](int i, unsigned long long& key) {
+        const double v = sh_e2[i];
+        if (v < 0.0) return false;
+        key = (unsigned long long)__double_as_longlong(v);
+        return true; }, hist, sel_sc, sel_st);
+      s2 = mest_sigma_sq(est, (double)nf, __longlong_as_double((long long)sel));
+    } else if (!(s2 > 0)) {
       // exact [nf/2] order statistic of the squared errors of ALL workgroups
       unsigned long long prefix = 0, kk = (unsigned long long)(nf/2);
       bool done = false;

@@ -836,6 +836,12 @@ def test_pose_refine_over_many_workgroups_matches_oracle(gpu_required, est, monk
         assert np.allclose(og["image"][f], oo["image"][f], rtol=0, atol=1e-8)
         p2, m2, w2, _ = track_pose_refine(big, [cam, cam], cfbs, bfw, **kw)
         assert np.array_equal(pg[0], p2[0]) and np.array_equal(pg[1], p2[1]) and np.array_equal(mg, m2) and np.array_equal(wg, w2)
+    # the same with the median taken from all squared errors gathered into every workgroup's LDS (one barrier instead of three)
+    monkeypatch.setenv("MCP_TRACK_REFINE_GATHER", "1")
+    ph, mh, wh, _ = track_pose_refine(big, [cam, cam], cfbs, bfw, estimator=est)
+    monkeypatch.delenv("MCP_TRACK_REFINE_GATHER")
+    pq, mq, wq, _ = track_pose_refine(big, [cam, cam], cfbs, bfw, estimator=est)
+    assert np.array_equal(ph[1], pq[1]) and np.array_equal(mh, mq) and np.array_equal(wh, wq)          # an exact median either way: identical runs
     monkeypatch.setenv("MCP_TRACK_REFINE_MULTI", "2")
     pg, mg, wg, og = track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
     po, mo, wo, oo = oracle_track_pose_refine(recs, [cam, cam], cfbs, bfw, estimator=est)
