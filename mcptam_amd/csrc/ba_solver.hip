@@ -208,9 +208,67 @@ enum Stage { ST_EVAL = 0, ST_SELECT, ST_LIN, ST_SCHUR, ST_CHOL, ST_SOLVE, ST_UPD
 
 }  // namespace
 
+// ---- the solver's streams come from a per-device pool that is set up ONCE per process ----------------------------------------
+// The HIP runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that land on the
+// same queue execute strictly one after the other.  The solver lives on its main chain and its speculative chain running SIDE BY
+// SIDE: measured on one box, the very same build ran 810 or 535 LM iterations/s depending only on how many streams
+// the process had created before the handle's (which decides the queue each one gets).  A handle created per BundleAdjust call
+// must not roll those dice every time: the first handle on a device creates candidate streams, MEASURES which ones really overlap
+// with the main stream (two 150 us spin kernels: ~160 us together, ~310 us in sequence), keeps those, and every later
+// handle borrows the same streams.  Handles that are alive at the same time share them -- stream order keeps each of them correct.
+__global__ void k_spin_us(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
+struct SolverStreams { hipStream_t main = nullptr, spec = nullptr, spec3 = nullptr, tr[mcp::MAX_SYS] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false; int overlapping = 0; };
+static SolverStreams& solver_streams(int device) {
+  static std::mutex mu;
+  static SolverStreams pools[16];
+  std::lock_guard<std::mutex> lk(mu);
+  SolverStreams& P = pools[device & 15];
+  if (P.ok) return P;
+  if (hipStreamCreateWithFlags(&P.main, hipStreamNonBlocking) != hipSuccess) return P;
+  const bool calibrate = [] { const char* e = getenv("MCP_BA_STREAM_CALIBRATE"); return e ? atoi(e) != 0 : true; }();
+  hipEvent_t e0 = nullptr, e1 = nullptr, ej = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+  int rate_khz = 100000; (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device);      // wall_clock64 ticks per ms
+  const long long ticks = (long long)rate_khz*150/1000;                                                    // ~150 us
+  auto overlaps = [&](hipStream_t other) -> bool {
+    if (!calibrate || !e0 || !e1 || !ej) return true;
+    float best = 1e9f;
+    for (int rep = 0; rep < 2; ++rep) {      // (the first repetition also pays the kernel's first launch; the minimum counts)
+      (void)hipEventRecord(e0, P.main);
+      (void)hipStreamWaitEvent(other, e0, 0);
+      hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, P.main, ticks);
+      hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, other, ticks);
+      (void)hipEventRecord(ej, other);
+      (void)hipStreamWaitEvent(P.main, ej, 0);
+      (void)hipEventRecord(e1, P.main);
+      if (hipEventSynchronize(e1) != hipSuccess) return true;
+      float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) best = std::min(best, ms);
+    }
+    if (getenv("MCP_BA_TRACE")) fprintf(stderr, "[mcp_ba streams]   candidate: two 150 us kernels took %.0f us\n", best*1e3);
+    return best < 0.230f;                  // together ~0.16 ms, in sequence ~0.31 ms
+  };
+  // up to 12 candidates for the 4 side streams (speculative chain, a second one for MCP_BA_OVERLAP=2, two trial streams); the ones that
+  // share the main stream's queue are kept alive unused, so that no later stream inherits their place
+  hipStream_t* want[4] = { &P.spec, &P.tr[2], &P.tr[3], &P.spec3 };
+  int got = 0;
+  for (int c = 0; c < 12 && got < 4; ++c) {
+    hipStream_t s2 = nullptr;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) break;
+    if (overlaps(s2)) { *want[got++] = s2; }
+  }
+  P.overlapping = got;
+  for (int k = got; k < 4; ++k) (void)hipStreamCreateWithFlags(want[k], hipStreamNonBlocking);        // not enough queues: plain streams (still correct)
+  if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (ej) (void)hipEventDestroy(ej);
+  (void)hipGetLastError();
+  P.ok = P.main && P.spec;
+  if (getenv("MCP_BA_TRACE")) fprintf(stderr, "[mcp_ba streams] device %d: %d side streams overlap with the main stream%s\n", device, got, calibrate ? "" : " (not measured)");
+  return P;
+}
+
 struct mcp_ba {
   int device = 0;
   hipStream_t st = nullptr;
+  bool pooled = false;             // the streams belong to the device's pool (solver_streams): never destroyed by a handle
   // second stream: the speculative systems of a solve are built and factored here while the main stream already factors the
   // system the trial needs (both chains are latency-bound and overlap); ev_fork / ev_spec order the two
   // (MCP_BA_OVERLAP: 0 = one stream, 1 = the speculative systems together on a second stream, 2 = system 1 on the second and
@@ -264,7 +322,13 @@ struct mcp_ba {
   DevBuf<double> d_sxp[MAX_SYS], d_sxl[MAX_SYS], d_sp0[MAX_SYS], d_sp1[MAX_SYS], d_sp2[MAX_SYS];
   bool pre_run[MAX_SYS] = {false, false, false, false}, ahead_enq[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
   hipEvent_t ev_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
-  int spec_trials = 1;             // MCP_BA_SPEC_TRIALS=0: trials strictly in sequence
+  // MCP_BA_SPEC_TRIALS: 0 = trials strictly in sequence; 1 (default) = one trial ahead on the stream that solved it; 2 = the steps
+  // of ALL speculatively solved systems are applied and evaluated as soon as their solutions exist, each on its own stream
+  // (st_tr[q], behind the speculative chain's event).  Measured, same box and run: 819 / 835 it/s (1) vs 733 / 743 (2) -- three
+  // trial evaluations at once take the compute units from the trial the host is waiting for.
+  int spec_trials = 1;
+  hipStream_t st_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t tr_stream[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};      // where the trial ahead of system q was enqueued
   // system
   DevBuf<double> d_ubig;    // [U (np*np) | bp (np)] contributions of the points outside the groups (> GRP_LMAX poses); only if nbig
   DevBuf<double> d_red;     // [S (np*np) | rhs (np) | bp = J^T r (np)]   (the all-reduced block)
@@ -318,6 +382,7 @@ struct mcp_ba {
   int wait_stream(hipStream_t s, const char* what);
   // trial buffers of the multi-rank tail (ba_trial.h) and the selection state k_trial_post leaves in them
   DevBuf<double> d_trial[MAX_SYS]; DevBuf<SelState> d_trstate[MAX_SYS];
+  int spec_delay = 0;
   int test_fail_trial = 0, test_trial_no = 0;      // MCP_BA_TEST_FAIL_TRIAL=k: the k-th trial of the handle's life is treated as a failed factorisation
   int sel_ride = 1;                // MCP_BA_SELECT_RIDE=0: the median never uses the histograms that rode on the trial's all-reduce
   int pred_bin = -1;               // first digit of the last median the host has seen (the prediction the trials histogram around)
@@ -336,18 +401,19 @@ struct mcp_ba {
     if (st) (void)hipStreamSynchronize(st);
     if (st2) (void)hipStreamSynchronize(st2);
     if (st3) (void)hipStreamSynchronize(st3);
+    for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q]) { (void)hipStreamSynchronize(st_tr[q]); if (!pooled) (void)hipStreamDestroy(st_tr[q]); }
     if (h_res) (void)hipHostFree(h_res);
     if (h_fail) (void)hipHostFree(h_fail);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
     for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) (void)hipGraphExecDestroy(chain_exec[q][r]);
-    if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
-    if (st3) { (void)hipStreamSynchronize(st3); (void)hipStreamDestroy(st3); }
+    if (st2) { (void)hipStreamSynchronize(st2); if (!pooled) (void)hipStreamDestroy(st2); }
+    if (st3) { (void)hipStreamSynchronize(st3); if (!pooled) (void)hipStreamDestroy(st3); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_spec) (void)hipEventDestroy(ev_spec);
     if (ev_spec3) (void)hipEventDestroy(ev_spec3);
     for (int q = 0; q < MAX_SYS; ++q) if (ev_tr[q]) (void)hipEventDestroy(ev_tr[q]);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && !pooled) (void)hipStreamDestroy(st);
   }
   // everything the second stream still has in flight reads the current linearisation (W, V, g, staged blocks): the main stream
   // must not overwrite any of it, nor consume a speculative solution, before that work is done
@@ -1432,7 +1498,7 @@ int mcp_ba::wait_mail(int q, unsigned long long ticket, int count) {
   struct Acc { mcp_ba* h; int q; std::chrono::steady_clock::time_point t; ~Acc() { h->dbg_wait_us[q ? 1 : 0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } acc_{this, q, w0};
   const double* box = h_res + 32 + 32*q;
   volatile unsigned long long* tk = (volatile unsigned long long*)(box + MAIL_TICKET);
-  hipStream_t watched = (q == 0) ? st : st2;
+  hipStream_t watched = (q == 0) ? st : (tr_stream[q] ? tr_stream[q] : st2);
   // The result is normally a few tens of microseconds away: poll hard for a while (a trial is ~70 us, a solve ~1 ms), then give
   // the core to whoever else wants it between polls -- a tracker thread beside the mapper (BASELINE c5) should not lose a core
   // to a solver that waits for a long factorisation or for another rank.  Every so often: has the stream died, drained without
@@ -1484,6 +1550,7 @@ int mcp_ba::multi_trial_tail(hipStream_t s, int lane, int q, int slot, int nbe, 
 // the step of speculative system q applied and evaluated on stream s (which has just solved it): candidate state cand(q), its own
 // scratch, result block d_res[32 + 8 q ..] -> mailbox q.
 int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
+  tr_stream[q] = s;
   const int slot = cand(q);
   const double lam = batch_lambda[q];
   double* Sq = d_red.p + q*red_stride; double* rhsq = Sq + (size_t)np*np;
@@ -1519,6 +1586,12 @@ int mcp_ba::run_ahead(int q) {
   if (multi() && overlap_spec != 1) return 0;       // (the speculative lane belongs to the second stream)
   if (!spec_pending && !spec3_pending && q >= spec2_from) { /* its stream has been joined already: still valid to use it */ }
   if (q < spec2_from || q >= batch_n || pre_run[q]) return 0;
+  if (spec_trials >= 2 && !multi() && st_tr[q] && q > spec2_from) {      // (the first one stays on the chain's own stream: hardware queues are few)
+    // its own stream, ordered behind the chain that produced system q: the trials ahead run side by side
+    hipEvent_t done = (q >= spec3_from) ? ev_spec3 : ev_spec;
+    HIPCK(hipStreamWaitEvent(st_tr[q], done, 0));
+    return enqueue_spec_trial(st_tr[q], q);
+  }
   return enqueue_spec_trial(q >= spec3_from ? st3 : st2, q);
 }
 int mcp_ba::read_results(int count) {
@@ -1678,6 +1751,9 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       mark("fork", st);
       if (build_system(n1, sb, 0, st)) return -1;
       mark("main_built", st);
+      // MCP_BA_SPEC_DELAY=1: the speculative systems' Schur complements start only when the trial's own is through (they share the
+      // compute units otherwise: 85 us alone, 170 us side by side) -- the first trial sooner, a rejected trial's successor later
+      if (spec_delay) HIPCK(hipEventRecord(ev_fork, st));
       // host enqueue order: the other streams' Schur complements right away (they start at the fork on the device and run beside
       // the main stream's), their factorisation chains only after this trial's own chain and tail (below) -- the main stream never
       // runs dry behind the ~45 launches of another chain
@@ -1760,7 +1836,10 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       spec3_pending = true;
     }
   }
-  if (defer_nsys && run_ahead(1)) return -1;
+  if (defer_nsys) {
+    if (run_ahead(1)) return -1;
+    if (spec_trials >= 2 && !multi()) for (int q = 2; q < defer_nsys; ++q) if (run_ahead(q)) return -1;
+  }
   if (mailbox) {
     // the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
     if (wait_mail(0, mail_ticket0, multi() ? MAIL_TICKET : 29)) return -1;
@@ -2064,7 +2143,10 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   h->cams.assign(cams, cams + ncam);
   std::memset(&h->timing, 0, sizeof h->timing);
   std::memset(&h->P, 0, sizeof h->P);
-  if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
+  const bool use_pool = [] { const char* e = getenv("MCP_BA_STREAM_POOL"); return e ? atoi(e) != 0 : true; }();
+  SolverStreams* pool = use_pool ? &solver_streams(dev) : nullptr;
+  if (pool && pool->ok) { h->pooled = true; h->st = pool->main; }
+  else if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
   { const char* e = getenv("MCP_BA_OVERLAP"); if (e) h->overlap_spec = atoi(e); }
   { const char* e = getenv("MCP_BA_MAILBOX"); if (e) h->use_mailbox = atoi(e); }
   { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
@@ -2072,10 +2154,20 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
   { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
   { const char* e = getenv("MCP_BA_TEST_FAIL_TRIAL"); if (e) h->test_fail_trial = atoi(e); }
+  { const char* e = getenv("MCP_BA_SPEC_DELAY"); if (e) h->spec_delay = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_RIDE"); if (e) h->sel_ride = atoi(e); }
   { const char* e = getenv("MCP_BA_TIMEOUT_MS"); if (e && atof(e) > 0) h->timeout_ms = atof(e); }
   for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
-  if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess ||
+  // (the runtime multiplexes streams onto a handful of hardware queues -- GPU_MAX_HW_QUEUES, 4 by default: main, speculative and two
+  // trial streams use them up; a third stream for MCP_BA_OVERLAP=2 is only created when asked for)
+  if (h->pooled) {
+    if (h->spec_trials >= 2) for (int q = 2; q < mcp::MAX_SYS; ++q) h->st_tr[q] = pool->tr[q];
+    if (h->overlap_spec) { h->st2 = pool->spec; if (h->overlap_spec >= 2) h->st3 = pool->spec3; }
+  } else {
+    if (h->spec_trials >= 2) for (int q = 2; q < mcp::MAX_SYS; ++q) if (hipStreamCreateWithFlags(&h->st_tr[q], hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
+    if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || (h->overlap_spec >= 2 && hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess))) { set_err("second stream could not be created"); delete h; return nullptr; }
+  }
+  if (h->overlap_spec && (
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess)) { set_err("second stream / events could not be created"); delete h; return nullptr; }
