@@ -251,9 +251,16 @@ static SolverStreams& solver_streams(int device) {
   // share the main stream's queue are kept alive unused, so that no later stream inherits their place
   hipStream_t* want[4] = { &P.spec, &P.tr[2], &P.tr[3], &P.spec3 };
   int got = 0;
+  // MCP_BA_SPEC_CUS=n (experiment): the side streams may only use the first n compute units (hipExtStreamCreateWithCUMask)
+  const int spec_cus = [] { const char* e = getenv("MCP_BA_SPEC_CUS"); return e ? atoi(e) : 0; }();
   for (int c = 0; c < 12 && got < 4; ++c) {
     hipStream_t s2 = nullptr;
-    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) break;
+    if (spec_cus > 0) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < spec_cus && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+      if (hipExtStreamCreateWithCUMask(&s2, 8, mask) != hipSuccess) { (void)hipGetLastError(); s2 = nullptr; }
+    }
+    if (!s2 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) break;
     if (overlaps(s2)) { *want[got++] = s2; }
   }
   P.overlapping = got;

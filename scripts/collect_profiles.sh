@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the judged summaries from gpurun_out/ (scratch) into profiles/$ROUND/ (tracked)
 set -e
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 cd "$(dirname "$0")/.."
 mkdir -p profiles/$ROUND
 cp gpurun_out/traffic.json profiles/$ROUND/pmc_traffic_per_launch.json
@@ -10,3 +10,5 @@ f=$(ls -t gpurun_out/prof_final/*/*kernel_stats.csv | head -1); cp "$f" profiles
 cp gpurun_out/final_tests.log profiles/$ROUND/final_gpu_tests.log
 ls -la profiles/$ROUND
 [ -f gpurun_out/trk_kernel_stats.csv ] && cp gpurun_out/trk_kernel_stats.csv profiles/$ROUND/tracker_c3_kernel_stats.csv
+[ -f gpurun_out/trk5_kernel_stats.csv ] && cp gpurun_out/trk5_kernel_stats.csv profiles/$ROUND/tracker_c5_kernel_stats.csv
+true

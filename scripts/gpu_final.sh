@@ -2,7 +2,7 @@
 # Round-end measurement pass on the MI355X box: full GPU test suite, PMC traffic (two separate rocprofv3 --pmc passes, as
 # MI355X_MICROARCH.md prescribes), rocprofv3 kernel stats of the bench, the bench line (incl. CPU baselines and the tracker line).
 # Everything lands in gpurun_out/ (scratch, merged back); scripts/collect_profiles.sh copies the summaries into profiles/$ROUND/.
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd $R
@@ -21,3 +21,8 @@ echo "stats rc=$?"; tail -1 $R/gpurun_out/prof_final.log | cut -c1-300
 cd $R
 timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/final_bench.json; tail -2 gpurun_out/final_bench.err
 bash $R/scripts/gpu_trk_prof.sh > gpurun_out/trk_prof_stdout.log 2>&1; tail -3 gpurun_out/trk_prof_stdout.log
+# kernel stats of the c5 tracker frame (eight 1280x960 cameras, 8000 points, one device)
+cd /tmp; rm -rf $R/gpurun_out/trk5_prof
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trk5_prof -- python $R/scripts/bench_tracker.py c5 > $R/gpurun_out/trk5_prof.json 2> $R/gpurun_out/trk5_prof.err
+f=$(find $R/gpurun_out/trk5_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/trk5_kernel_stats.csv
+find $R/gpurun_out/trk5_prof -name '*kernel_trace.csv' -delete; cd $R
