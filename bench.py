@@ -388,7 +388,7 @@ def main():
     # secondary line: the call MCPTAM makes most -- BundleAdjustRecent (src/BundleAdjusterBase.cc:188-265): the newest MKF + its 3
     # neighbours free, every other MKF that sees their points fixed, 10 iterations; timed as WHOLE calls (fresh handle, bulk replay,
     # Prepare, Compute(10), read-back of poses and points), the way BundleAdjusterMulti::BundleAdjust runs it
-    if rank == 0 and world == 1 and args.config == "metric":
+    if rank == 0 and world == 1 and args.config == "metric" and args.cpu_iters > 0:      # (--cpu-iters 0 = the profiling passes: headline workload only)
         try:
             import numpy as np
             w = synth.recent_window(problem)
