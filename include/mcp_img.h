@@ -255,6 +255,25 @@ int mcp_track_pose_refine_sharded_m(int n, mcp_pose_point* pts, int ncam, const 
                                     int n_iter, const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last,
                                     mcp_allreduce_fn allreduce, void* user, int rank, int world, int cap, int estimator);
 
+/* ---- One stage of Tracker::TrackMap for a whole frame in ONE submission ------------------------------------------------------
+ * What Tracker::TrackFrame / TrackMap do per frame and stage (src/Tracker.cc:303-318 MakeKeyFrame_Lite of every camera, :985-1030 +
+ * :1299-1384 SearchForPoints per camera, :1040-1075 the ten CalcPoseUpdate iterations) as one call with one wait:
+ *   imgs != NULL : mcp_kf_make_lite_batch(ncam, targets, imgs, strides, imgs_on_device, masks) first (NULL: the pyramids are current,
+ *                  e.g. the fine stage after the coarse one);
+ *   the search   : state == NULL: mcp_track_search_batch (finders that have seen nothing);  state != NULL: the reference's persistent
+ *                  finders -- state[c][i] / point_key[c][i] belong to point i of camera c, as one single-item MCP_PF_TRACK sequence
+ *                  each of mcp_patch_sequences (states updated in place);
+ *   the records of the pose iterations are built from the search results on the device (world position from in[c][i], camera = c);
+ *   mcp_track_pose_refine_m(total, ..., n_iter, nonlinear, override_sigma, ..., estimator) over the points of all cameras.
+ * Same kernels on the same data as the separate calls: out[c] (n[c] results), pts_out (total records as the iterations left them,
+ * may be NULL), base_from_world (in: the prior, out: refined), mu_last, weights_last (total, camera-major; may be NULL) are bit-identical
+ * to theirs.  n_iter = 0: search only.  The two host round trips between the three calls are what it saves. */
+int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                    const uint8_t* const* const* masks, const mcp_camera* cams, double base_from_world[12], const double* cam_from_base /* ncam x 12 */,
+                    const int* n, const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state,
+                    int range, int subpix_its, int exhaustive, int n_iter, const uint8_t* nonlinear, const double* override_sigma, int estimator,
+                    mcp_td_out* const* out, mcp_pose_point* pts_out, double mu_last[6], double* weights_last);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,13 @@ template <class T> struct Buf {
   int alloc(size_t c) { if (c == 0) c = 1; if (c <= n) return 0; if (p) (void)hipFree(p); p = nullptr; n = 0;
     if (hipMalloc((void**)&p, c*sizeof(T)) != hipSuccess) { mcp_set_error("hipMalloc failed"); return -1; } n = c; return 0; }
 };
+// pinned host staging that outlives the call that fills it (the uploads of an enqueue-only helper are still in flight when it returns)
+template <class T> struct PinBuf {
+  T* p = nullptr; size_t n = 0;
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+  int alloc(size_t c) { if (c == 0) c = 1; if (c <= n) return 0; if (p) (void)hipHostFree(p); p = nullptr; n = 0;
+    if (hipHostMalloc((void**)&p, c*sizeof(T)) != hipSuccess) { mcp_set_error("hipHostMalloc failed"); return -1; } n = c; return 0; }
+};
 struct Level {
   int w = 0, h = 0, cap = 0;
   Buf<uint8_t> img, mask, tmp_a, tmp_b;
@@ -70,6 +77,8 @@ struct mcp_kf {
   bool work_dirty = true;
   Buf<SearchCam> stab; Buf<DevTdIn> bt_in; Buf<mcp_td_out> bt_out;      // batched search: camera table + points of all cameras
   Buf<PfTargetDev> pf_tab; Buf<PfItemDev> pf_items; Buf<int> pf_seq; Buf<mcp_pf_state> pf_state;      // mcp_patch_sequences
+  PinBuf<SearchCam> h_stab; PinBuf<DevTdIn> h_bt_in;                                                   // host staging of the batched search ...
+  PinBuf<PfTargetDev> h_pf_tab; PinBuf<PfItemDev> h_pf_items; PinBuf<int> h_pf_seq; PinBuf<mcp_pf_state> h_pf_state;      // ... and of mcp_track_frame's finder sequences
   hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
   Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
@@ -114,8 +123,9 @@ void mcp_kf_destroy(mcp_kf* k) { if (k) { (void)hipSetDevice(k->device); delete 
 
 // MakeKeyFrame_Lite of every camera of a frame in one submission (the loop of Tracker::TrackFrame, src/Tracker.cc:303-318): the
 // uploads, three launches for all levels of all cameras (k_pyr_fast, k_row_count, k_row_compact) and one wait.
-int mcp_kf_make_lite_batch(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
-                           const uint8_t* const* const* masks) {
+// (enqueue on kfs[0]->st without waiting; lite_batch_finish after the stream has been waited for)
+static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                              const uint8_t* const* const* masks) {
   if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !kfs || !imgs || !strides) return img_fail("mcp_kf_make_lite_batch: bad arguments");
   for (int c = 0; c < ncam; ++c) {
     if (!kfs[c] || !imgs[c] || kfs[c]->device != kfs[0]->device) return img_fail("mcp_kf_make_lite_batch: keyframes must live on one device");
@@ -172,12 +182,20 @@ int mcp_kf_make_lite_batch(int ncam, mcp_kf* const* kfs, const uint8_t* const* i
   hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
   hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
   ICK(hipGetLastError());
-  ICK(hipStreamSynchronize(st));
+  return 0;
+}
+static int lite_batch_finish(int ncam, mcp_kf* const* kfs) {
   for (int c = 0; c < ncam; ++c) {
     kfs[c]->work_dirty = false;
     for (int l = 0; l < MCP_LEVELS; ++l) if (kfs[c]->h_info[l].overflow) return img_fail("mcp_kf_make_lite: corner capacity exceeded");
   }
   return 0;
+}
+int mcp_kf_make_lite_batch(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                           const uint8_t* const* const* masks) {
+  if (lite_batch_enqueue(ncam, kfs, imgs, strides, imgs_on_device, masks)) return -1;
+  ICK(hipStreamSynchronize(kfs[0]->st));
+  return lite_batch_finish(ncam, kfs);
 }
 int mcp_kf_make_lite(mcp_kf* k, const uint8_t* img, int stride, const uint8_t* const* masks) {
   mcp_kf* kfs[1] = { k }; const uint8_t* imgs[1] = { img }; const int strides[1] = { stride }; const uint8_t* const* ms[1] = { masks };
@@ -316,21 +334,17 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
                           const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last) {
   return mcp_track_pose_refine_m(n, pts, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, mu_last, weights_last, MCP_MEST_TUKEY);
 }
-int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
-                            const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last, int est) {
-  if (!mu_last) return img_fail("mcp_track_pose_refine: bad arguments");
-  for (int k = 0; k < 6; ++k) mu_last[k] = 0;
-  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || !bfw || !est_ok(est) || (n > 0 && !pts) || (n_iter > 0 && (!nonlinear || !override_sigma)))
-    return img_fail("mcp_track_pose_refine: bad arguments");
-  for (int c = 0; c < ncam; ++c) if (!cam_ok(&cams[c])) return img_fail("mcp_track_pose_refine: bad camera");
-  if (n == 0 || n_iter == 0) return 0;
-  for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine: camera index out of range");
-  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine: no HIP device");
-  // device scratch, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d | pad 6 d |
-  // override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back in
-  // one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
-  struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; };
-  static thread_local RefineScratch rs;
+// device scratch of the pose iterations, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d |
+// pad 6 d | override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back
+// in one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
+struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; };
+static RefineScratch& refine_scratch() { static thread_local RefineScratch rs; return rs; }
+// The iterations enqueued on `st`: the points come from host_pts (uploaded first) or are in the scratch's dp already (host_pts == nullptr:
+// mcp_track_frame packs them on the device).  BaseFromWorld | mu are left at the head of the scratch's dblk, the weights in dw; *prm_err
+// receives the multi-workgroup kernel's give-up flag once the stream has been waited for.
+static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const mcp_camera* cams, const double* cfb, const double bfw[12], int n_iter,
+                          const uint8_t* nonlinear, const double* override_sigma, int est, hipStream_t st, unsigned int* prm_err) {
+  RefineScratch& rs = refine_scratch();
   const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam;
   const size_t o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam, blk = ((o_nl + (size_t)n_iter + 15)/16)*16;
   static const int use_regs = [] { const char* e = getenv("MCP_TRACK_REFINE_REGS"); return e ? atoi(e) : 1; }();
@@ -358,8 +372,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   std::memcpy(rs.hblk.data() + o_cfb, cfb, 96*(size_t)ncam);
   std::memcpy(rs.hblk.data() + o_cam, cams, sizeof(mcp_camera)*(size_t)ncam);
   std::memcpy(rs.hblk.data() + o_nl, nonlinear, (size_t)n_iter);
-  hipStream_t st = nullptr;
-  ICK(hipMemcpyAsync(rs.dp.p, pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
+  if (host_pts) ICK(hipMemcpyAsync(rs.dp.p, host_pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
   ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), blk, hipMemcpyHostToDevice, st));
   ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
   double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
@@ -372,7 +385,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
       if (alloc_plain()) return -1;
     }
   }
-  unsigned int prm_err = 0;
+  *prm_err = 0;
   if (multi) {
     if (rs.dprm.alloc(1)) return -1;
     ICK(hipMemsetAsync(rs.dprm.p, 0, sizeof(PrmScratch), st));
@@ -392,7 +405,7 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
     hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), dyn, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p,
                        gather ? rs.de2all.p : (double*)nullptr);
     ICK(hipGetLastError());
-    ICK(hipMemcpyAsync(&prm_err, &rs.dprm.p->err, sizeof prm_err, hipMemcpyDeviceToHost, st));
+    ICK(hipMemcpyAsync(prm_err, &rs.dprm.p->err, sizeof *prm_err, hipMemcpyDeviceToHost, st));
   } else if (!regs)
     hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est);
 #ifdef MCP_PRR_PROF
@@ -404,6 +417,23 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
               q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4]); }
   }
 #endif
+  ICK(hipGetLastError());
+  return 0;
+}
+int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_camera* cams, const double* cfb, double bfw[12], int n_iter,
+                            const uint8_t* nonlinear, const double* override_sigma, double mu_last[6], double* weights_last, int est) {
+  if (!mu_last) return img_fail("mcp_track_pose_refine: bad arguments");
+  for (int k = 0; k < 6; ++k) mu_last[k] = 0;
+  if (n < 0 || ncam <= 0 || n_iter < 0 || !cams || !cfb || !bfw || !est_ok(est) || (n > 0 && !pts) || (n_iter > 0 && (!nonlinear || !override_sigma)))
+    return img_fail("mcp_track_pose_refine: bad arguments");
+  for (int c = 0; c < ncam; ++c) if (!cam_ok(&cams[c])) return img_fail("mcp_track_pose_refine: bad camera");
+  if (n == 0 || n_iter == 0) return 0;
+  for (int i = 0; i < n; ++i) if (pts[i].cam < 0 || pts[i].cam >= ncam) return img_fail("mcp_track_pose_refine: camera index out of range");
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return img_fail("mcp_track_pose_refine: no HIP device");
+  hipStream_t st = nullptr;
+  unsigned int prm_err = 0;
+  if (refine_enqueue(n, pts, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, est, st, &prm_err)) return -1;
+  RefineScratch& rs = refine_scratch();
   double back[18];
   ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
   ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
@@ -623,8 +653,10 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12]
 }
 
 // SearchForPoints of every camera of a frame in one launch (the per-camera loops of Tracker::TrackMap, src/Tracker.cc:985-1030, 1299-1384)
-int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
-                           const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out) {
+// (the launch on targets[0]->st, results left in targets[0]->bt_out in camera-major order; *total_out = points of all cameras)
+static int search_batch_enqueue(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                                const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out, int* total_out) {
+  *total_out = 0;
   if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
   int total = 0, maxn = 0;
   for (int c = 0; c < ncam; ++c) {
@@ -634,7 +666,8 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
   if (total == 0) return 0;
   mcp_kf* k0 = targets[0];
   ICK(hipSetDevice(k0->device));
-  std::vector<SearchCam> tab(ncam); std::vector<DevTdIn> h(total);
+  if (k0->h_stab.alloc(MCP_MAX_FRAME_CAMS) || k0->h_bt_in.alloc(total)) return -1;
+  SearchCam* tab = k0->h_stab.p; DevTdIn* h = k0->h_bt_in.p;
   int first = 0;
   for (int c = 0; c < ncam; ++c) {
     SearchCam& S = tab[c];
@@ -650,21 +683,132 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
   }
   if (k0->stab.alloc(MCP_MAX_FRAME_CAMS) || k0->bt_in.alloc(total) || k0->bt_out.alloc(total)) return -1;
   hipStream_t st = k0->st;
-  ICK(hipMemcpyAsync(k0->stab.p, tab.data(), sizeof(SearchCam)*(size_t)ncam, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(k0->bt_in.p, h.data(), sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->stab.p, tab, sizeof(SearchCam)*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->bt_in.p, h, sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
   Se3 Bw; std::memcpy(Bw.R, bfw, 72); std::memcpy(Bw.t, bfw + 9, 24);
   hipLaunchKernelGGL(k_track_search_batch, dim3(maxn, ncam), dim3(64), 0, st, (const SearchCam*)k0->stab.p, Bw, (const DevTdIn*)k0->bt_in.p, range, subpix_its, exhaustive, k0->bt_out.p);
+  ICK(hipGetLastError());
+  *total_out = total;
+  return 0;
+}
+static int search_batch_copy_out(int ncam, mcp_kf* k0, const int* n, mcp_td_out* const* out, int total) {
   // one copy when the caller's per-camera result arrays are the slices of one array (they are laid out like the device buffer)
+  hipStream_t st = k0->st;
   bool contiguous = true;
   { mcp_td_out* expect = nullptr;
     for (int c = 0; c < ncam; ++c) { if (!n[c]) continue; if (expect && out[c] != expect) contiguous = false; expect = out[c] + n[c]; } }
   if (contiguous) {
     int c0 = 0; while (c0 < ncam && !n[c0]) ++c0;
     ICK(hipMemcpyAsync(out[c0], k0->bt_out.p, sizeof(mcp_td_out)*(size_t)total, hipMemcpyDeviceToHost, st));
-  } else
-    for (int c = 0; c < ncam; ++c)
-      if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + tab[c].first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
+  } else {
+    int first = 0;
+    for (int c = 0; c < ncam; ++c) {
+      if (n[c]) ICK(hipMemcpyAsync(out[c], k0->bt_out.p + first, sizeof(mcp_td_out)*(size_t)n[c], hipMemcpyDeviceToHost, st));
+      first += n[c];
+    }
+  }
+  return 0;
+}
+int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                           const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out) {
+  int total = 0;
+  if (search_batch_enqueue(ncam, targets, cams, bfw, cfb, n, in, range, subpix_its, exhaustive, out, &total)) return -1;
+  if (total == 0) return 0;
+  if (search_batch_copy_out(ncam, targets[0], n, out, total)) return -1;
+  ICK(hipStreamSynchronize(targets[0]->st));
+  return 0;
+}
+
+// One stage of Tracker::TrackMap for a whole frame in ONE submission (include/mcp_img.h): the launches of mcp_kf_make_lite_batch, the search
+// (mcp_track_search_batch, or -- with finder states -- mcp_patch_sequences in MCP_PF_TRACK mode, one single-item sequence per point) and
+// mcp_track_pose_refine_m back to back on the frame's stream, the TrackerData -> pose-point packing in between done on the device, one wait at
+// the end.  Same kernels on the same data as the three calls: identical results.
+static int track_sequences_enqueue(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                                   const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state, int range, int subpix_its,
+                                   int exhaustive, int* total_out) {
+  *total_out = 0;
+  int total = 0;
+  for (int c = 0; c < ncam; ++c) {
+    if (!targets[c] || n[c] < 0 || targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || !state[c] || !point_key[c]))) return img_fail("mcp_track_frame: bad arguments");
+    total += n[c];
+  }
+  if (total == 0) return 0;
+  mcp_kf* k0 = targets[0];
+  if (k0->h_pf_tab.alloc(MCP_MAX_FRAME_CAMS) || k0->h_pf_items.alloc(total) || k0->h_pf_seq.alloc(total + 1) || k0->h_pf_state.alloc(total)) return -1;
+  PfTargetDev* tab = k0->h_pf_tab.p; PfItemDev* h = k0->h_pf_items.p; int* seq = k0->h_pf_seq.p; mcp_pf_state* hs = k0->h_pf_state.p;
+  for (int c = 0; c < ncam; ++c) {
+    PfTargetDev& D = tab[c];
+    D.T = targets[c]->view(); D.mask0 = targets[c]->lev[0].has_mask ? targets[c]->lev[0].mask.p : nullptr; D.cam = cams[c];
+    std::memcpy(D.bfw.R, bfw, 72); std::memcpy(D.bfw.t, bfw + 9, 24);
+    std::memcpy(D.cfb.R, cfb + 12*c, 72); std::memcpy(D.cfb.t, cfb + 12*c + 9, 24);
+  }
+  int first = 0;
+  for (int c = 0; c < ncam; ++c) {
+    for (int i = 0; i < n[c]; ++i) {
+      const mcp_td_in& p = in[c][i]; PfItemDev& d = h[first + i];
+      if (!p.source_kf || p.source_level < 0 || p.source_level >= MCP_LEVELS) return img_fail("mcp_track_frame: point without a resident source keyframe");
+      std::memcpy(d.p.world_pos, p.world_pos, 24); std::memcpy(d.p.pixel_right_w, p.pixel_right_w, 24); std::memcpy(d.p.pixel_down_w, p.pixel_down_w, 24);
+      const Level& Sl = p.source_kf->lev[p.source_level];
+      d.p.src_img = Sl.img.p; d.p.src_w = Sl.w; d.p.src_h = Sl.h; d.p.center_x = p.center_x; d.p.center_y = p.center_y; d.p.fixed = p.fixed;
+      d.point_key = point_key[c][i]; d.target = c; d.start_x = 0.0; d.start_y = 0.0;
+    }
+    if (n[c]) std::memcpy(&hs[first], state[c], sizeof(mcp_pf_state)*(size_t)n[c]);
+    first += n[c];
+  }
+  for (int i = 0; i <= total; ++i) seq[i] = i;
+  ICK(hipSetDevice(k0->device));
+  hipStream_t st = k0->st;
+  if (k0->pf_tab.alloc(ncam) || k0->pf_items.alloc(total) || k0->pf_seq.alloc(total + 1) || k0->pf_state.alloc(total) || k0->bt_out.alloc(total)) return -1;
+  ICK(hipMemcpyAsync(k0->pf_tab.p, tab, sizeof(PfTargetDev)*(size_t)ncam, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->pf_items.p, h, sizeof(PfItemDev)*(size_t)total, hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->pf_seq.p, seq, sizeof(int)*(size_t)(total + 1), hipMemcpyHostToDevice, st));
+  ICK(hipMemcpyAsync(k0->pf_state.p, hs, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_patch_sequences, dim3(total), dim3(64), 0, st, (int)MCP_PF_TRACK, (const PfTargetDev*)k0->pf_tab.p, total, (const int*)k0->pf_seq.p,
+                     (const PfItemDev*)k0->pf_items.p, k0->pf_state.p, range, subpix_its, exhaustive, k0->bt_out.p);
+  ICK(hipGetLastError());
+  *total_out = total;
+  return 0;
+}
+int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
+                    const uint8_t* const* const* masks, const mcp_camera* cams, double bfw[12], const double* cfb, const int* n,
+                    const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state, int range, int subpix_its, int exhaustive,
+                    int n_iter, const uint8_t* nonlinear, const double* override_sigma, int est, mcp_td_out* const* out, mcp_pose_point* pts_out,
+                    double mu_last[6], double* weights_last) {
+  if (!mu_last) return img_fail("mcp_track_frame: bad arguments");
+  for (int k = 0; k < 6; ++k) mu_last[k] = 0;
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out || n_iter < 0 || !est_ok(est) ||
+      (n_iter > 0 && (!nonlinear || !override_sigma)) || (imgs && !strides) || (state && !point_key)) return img_fail("mcp_track_frame: bad arguments");
+  for (int c = 0; c < ncam; ++c) if (!targets[c] || !cam_ok(&cams[c]) || n[c] < 0 || (n[c] > 0 && !out[c])) return img_fail("mcp_track_frame: bad arguments");
+  mcp_kf* k0 = targets[0];
+  hipStream_t st = k0->st;
+  if (imgs && lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks)) return -1;
+  int total = 0;
+  if (state) { if (track_sequences_enqueue(ncam, targets, cams, bfw, cfb, n, in, point_key, state, range, subpix_its, exhaustive, &total)) return -1; }
+  else if (search_batch_enqueue(ncam, targets, cams, bfw, cfb, n, in, range, subpix_its, exhaustive, out, &total)) return -1;
+  ICK(hipSetDevice(k0->device));
+  unsigned int prm_err = 0;
+  double back[18];
+  RefineScratch& rs = refine_scratch();
+  const bool iterate = total > 0 && n_iter > 0;
+  if (total > 0) {
+    if (rs.dp.alloc(total)) return -1;
+    if (state) hipLaunchKernelGGL(k_pack_pose_points_items, dim3((total + 255)/256), dim3(256), 0, st, total, (const PfItemDev*)k0->pf_items.p, (const mcp_td_out*)k0->bt_out.p, rs.dp.p);
+    else hipLaunchKernelGGL(k_pack_pose_points, dim3((total + 255)/256), dim3(256), 0, st, total, (const SearchCam*)k0->stab.p, ncam, (const DevTdIn*)k0->bt_in.p,
+                            (const mcp_td_out*)k0->bt_out.p, rs.dp.p);
+    if (iterate && refine_enqueue(total, nullptr, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, est, st, &prm_err)) return -1;
+    if (search_batch_copy_out(ncam, k0, n, out, total)) return -1;
+    if (state) ICK(hipMemcpyAsync(k0->h_pf_state.p, k0->pf_state.p, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyDeviceToHost, st));
+    if (pts_out) ICK(hipMemcpyAsync(pts_out, rs.dp.p, sizeof(mcp_pose_point)*(size_t)total, hipMemcpyDeviceToHost, st));
+    if (iterate) {
+      ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
+      if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)total, hipMemcpyDeviceToHost, st));
+    } else if (weights_last) std::memset(weights_last, 0, 8*(size_t)total);
+  }
   ICK(hipStreamSynchronize(st));
+  if (imgs && lite_batch_finish(ncam, targets)) return -1;
+  if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
+  if (prm_err) return img_fail("mcp_track_frame: a workgroup of the multi-workgroup iterations gave up waiting for the others");
+  if (iterate) { std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48); }
   return 0;
 }
 

@@ -738,6 +738,41 @@ k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, cons
   }
 }
 
+// TrackerData -> the records the pose iterations read (what the loops of Tracker::TrackMap take from vTD after SearchForPoints,
+// src/Tracker.cc:1040-1075): world position, found position, noise, projection + camera derivatives at the search pose, camera, found flag.
+// `tab` is the batched search's camera table (first point / count per camera), `in` / `o` its inputs and results in camera-major order.
+__global__ void __launch_bounds__(256)
+k_pack_pose_points(int total, const SearchCam* __restrict__ tab, int ncam, const DevTdIn* __restrict__ in, const mcp_td_out* __restrict__ o,
+                   mcp_pose_point* __restrict__ p) {
+  const int i = blockIdx.x*256 + threadIdx.x;
+  if (i >= total) return;
+  int c = 0;
+  while (c + 1 < ncam && i >= tab[c + 1].first) ++c;          // the last camera that starts at or before i (empty cameras share a start with their successor)
+  mcp_pose_point q;
+  q.world_pos[0] = in[i].world_pos[0]; q.world_pos[1] = in[i].world_pos[1]; q.world_pos[2] = in[i].world_pos[2];
+  q.found_pos[0] = o[i].found_pos[0]; q.found_pos[1] = o[i].found_pos[1];
+  q.sqrt_inv_noise = o[i].sqrt_inv_noise;
+  q.image[0] = o[i].image[0]; q.image[1] = o[i].image[1];
+  q.cam_derivs[0] = o[i].cam_derivs[0]; q.cam_derivs[1] = o[i].cam_derivs[1]; q.cam_derivs[2] = o[i].cam_derivs[2]; q.cam_derivs[3] = o[i].cam_derivs[3];
+  q.cam = c; q.found = o[i].found;
+  p[i] = q;
+}
+
+// the same from the items of k_patch_sequences run as one single-item sequence per tracked point (item i = point i; camera = its target)
+__global__ void __launch_bounds__(256)
+k_pack_pose_points_items(int total, const PfItemDev* __restrict__ items, const mcp_td_out* __restrict__ o, mcp_pose_point* __restrict__ p) {
+  const int i = blockIdx.x*256 + threadIdx.x;
+  if (i >= total) return;
+  mcp_pose_point q;
+  q.world_pos[0] = items[i].p.world_pos[0]; q.world_pos[1] = items[i].p.world_pos[1]; q.world_pos[2] = items[i].p.world_pos[2];
+  q.found_pos[0] = o[i].found_pos[0]; q.found_pos[1] = o[i].found_pos[1];
+  q.sqrt_inv_noise = o[i].sqrt_inv_noise;
+  q.image[0] = o[i].image[0]; q.image[1] = o[i].image[1];
+  q.cam_derivs[0] = o[i].cam_derivs[0]; q.cam_derivs[1] = o[i].cam_derivs[1]; q.cam_derivs[2] = o[i].cam_derivs[2]; q.cam_derivs[3] = o[i].cam_derivs[3];
+  q.cam = items[i].target; q.found = o[i].found;
+  p[i] = q;
+}
+
 // ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------
 // The M-estimator Tracker::CalcPoseUpdate dispatches on (Tracker::sMEstimatorName, src/Tracker.cc:1388-1401, 1429-1468) with the
 // formulas of include/mcptam/MEstimator.h: Tukey :84-124, Cauchy :131-157, Huber :164-204.  est: MCP_MEST_TUKEY 0 / CAUCHY 1 / HUBER 2.

@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_make_lite_batch", "mcp_track_search_batch", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_patch_sequences", "mcp_track_pose_update_m", "mcp_track_pose_refine_m", "mcp_track_pose_refine_sharded_m", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_patch_sequences", "mcp_track_frame", "mcp_track_pose_update_m", "mcp_track_pose_refine_m", "mcp_track_pose_refine_sharded_m", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -87,6 +87,9 @@ def lib():
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.mcp_track_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.mcp_track_frame.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mcp_track_pose_update.argtypes = [ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                             ctypes.c_double, c_double_p, c_double_p, c_double_p]
         _BOUND = True
@@ -461,6 +464,61 @@ def track_pose_refine_sharded(pts, cams, cam_from_base, base_from_world, allredu
     rc, pose, mu, w, out = _refine(fn, pts, cams, cam_from_base, base_from_world, nonlinear, override_sigma, McpCamera)
     _chk(rc, "track_pose_refine_sharded")
     return pose, mu, w, out
+
+
+class TrackFrame:
+    """mcp_track_frame with everything that does not change from frame to frame marshalled once (what a native caller keeps in its own
+    structs): the keyframes of the rig, the camera models, CamFromBase, the packed points of every camera, and -- `stateful=True` -- the
+    persistent PatchFinder members of every (point, camera) (mcp_pf_state, point keys = position in the packed list unless given).
+    `run(imgs, base_from_world, ...)` = one stage of Tracker::TrackMap: MakeKeyFrame_Lite of every camera (imgs=None: skip), the search,
+    the pose iterations.  Returns (td_outs per camera, pose points, (R, t), mu, weights)."""
+
+    def __init__(self, kfs, cams, cams_from_base, points, stateful=False, point_keys=None):
+        from .taylor_camera import camera_array
+        self.kfs = list(kfs)
+        n = self.n = len(self.kfs)
+        self.hs = (ctypes.c_void_p * n)(*[k._h for k in self.kfs])
+        self.cs = cams if isinstance(cams, ctypes.Array) else camera_array(cams)
+        self.cfb = np.ascontiguousarray(cams_from_base.reshape(-1)) if isinstance(cams_from_base, np.ndarray) else np.ascontiguousarray(np.concatenate([_pose12(*c) for c in cams_from_base]))
+        self.arrs = [p if isinstance(p, ctypes.Array) else pack_points(p, lambda kf: kf._h) for p in points]
+        self.lens = [len(a) for a in self.arrs]
+        self.total = sum(self.lens)
+        self.offs = np.concatenate([[0], np.cumsum(self.lens)]).astype(int)
+        self.ns = (ctypes.c_int * n)(*self.lens)
+        self.ins = (ctypes.c_void_p * n)(*[ctypes.cast(a, ctypes.c_void_p) for a in self.arrs])
+        self.whole = np.zeros(max(self.total, 1), dtype=TD_OUT_DTYPE)
+        self.ops = (ctypes.c_void_p * n)(*[self.whole.ctypes.data + int(self.offs[c])*TD_OUT_DTYPE.itemsize for c in range(n)])
+        self.pts = np.zeros(max(self.total, 1), dtype=POSE_POINT_DTYPE)
+        self.w = np.zeros(max(self.total, 1))
+        self.mu = np.zeros(6)
+        self.states = self.keys = self.sp = self.kp = None
+        if stateful:
+            self.states = [new_pf_states(m) for m in self.lens]
+            self.keys = [np.ascontiguousarray(point_keys[c] if point_keys is not None else np.arange(self.lens[c]), dtype=np.int32) for c in range(n)]
+            self.sp = (ctypes.c_void_p * n)(*[s_.ctypes.data for s_ in self.states])
+            self.kp = (ctypes.c_void_p * n)(*[k_.ctypes.data for k_ in self.keys])
+
+    def run(self, imgs, base_from_world, rng, subpix_its, exhaustive=False, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey",
+            on_device=False, strides=None):
+        n = self.n
+        ip = st = None
+        keep = None
+        if imgs is not None:
+            if on_device:
+                ip = (ctypes.c_void_p * n)(*[int(a) for a in imgs])
+                st = (ctypes.c_int * n)(*[int(s_) for s_ in (strides or [k.w for k in self.kfs])])
+            else:
+                keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in imgs]
+                ip = (ctypes.c_void_p * n)(*[a.ctypes.data for a in keep])
+                st = (ctypes.c_int * n)(*[a.strides[0] for a in keep])
+        bfw = _pose12(*base_from_world).copy()
+        nl = np.ascontiguousarray(nonlinear, dtype=np.uint8)
+        ov = np.ascontiguousarray(override_sigma, dtype=np.float64)
+        _chk(lib().mcp_track_frame(n, self.hs, ip, st, int(on_device), None, ctypes.cast(self.cs, ctypes.c_void_p), bfw.ctypes.data, self.cfb.ctypes.data, self.ns, self.ins,
+                                   self.kp, self.sp, int(rng), int(subpix_its), int(exhaustive), len(nl), nl.ctypes.data, ov.ctypes.data, MEST[estimator],
+                                   self.ops, self.pts.ctypes.data, self.mu.ctypes.data, self.w.ctypes.data), "track_frame")
+        outs = [self.whole[self.offs[c]:self.offs[c + 1]] for c in range(n)]
+        return outs, self.pts[:self.total], (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), self.mu.copy(), self.w[:self.total]
 
 
 def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey"):

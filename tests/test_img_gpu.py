@@ -849,3 +849,58 @@ def test_pose_refine_over_many_workgroups_matches_oracle(gpu_required, est, monk
     none = big.copy(); none["found"] = 0
     pg, mg, wg, og = track_pose_refine(none, [cam, cam], cfbs, bfw)
     assert np.all(mg == 0) and np.array_equal(pg[0], bfw[0]) and np.all(wg == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stateful", [False, True])
+def test_track_frame_in_one_submission_equals_the_three_calls(gpu_required, scene, stateful):
+    """mcp_track_frame = MakeKeyFrame_Lite of every camera + SearchForPoints + the ten pose iterations of one Tracker::TrackMap stage in one
+    submission (src/Tracker.cc:303-318, 985-1075, 1299-1384), the pose points packed on the device.  Same kernels, same data as
+    mcp_kf_make_lite_batch + mcp_track_search_batch (or, stateful, mcp_patch_sequences with persistent finders) + host packing +
+    mcp_track_pose_refine: every output bit for bit, over two frames (history rotation, template cache), one camera without points;
+    the refined pose also against the oracle's iterations."""
+    from mcptam_amd import keyframe as kf
+    from oracle import oracle_track_pose_update
+    cam = scene["cam"]
+    gA, oA = _pair(640, 480)
+    gA.MakeKeyFrame_Lite(scene["imgA"]); oA.MakeKeyFrame_Lite(scene["imgA"])
+    pts = _points(scene, gA, oA)
+    lists = [pts, pts[:41], [], pts[7:90]]
+    ncam = len(lists)
+    cfbs = [(np.eye(3), np.array([0.01*c, 0.0, 0.0])) for c in range(ncam)]
+    cfb_arr = np.ascontiguousarray(np.stack([kf._pose12(*c) for c in cfbs]))
+    wpos = [np.array([p["world_pos"] for p in l]).reshape(-1, 3) for l in lists]
+    fused_kfs = [kf.KeyFrame(640, 480) for _ in range(ncam)]
+    plain_kfs = [kf.KeyFrame(640, 480) for _ in range(ncam)]
+    tf = kf.TrackFrame(fused_kfs, [cam]*ncam, cfb_arr, lists, stateful=stateful)
+    states = [kf.new_pf_states(len(l)) for l in lists]
+    frames = [[scene["imgB"]]*ncam, [np.roll(scene["imgB"], 1, axis=1)]*ncam]
+    poses = [scene["poseB"], _moved(scene["poseB"], (0.0004, -0.0003, 0.0015), (0.004, -0.002, 0.003))]
+    for imgs, pose in zip(frames, poses):
+        outs, recs, pose_f, mu_f, w_f = tf.run(imgs, pose, 10, 8)
+        kf.make_lite_batch(plain_kfs, imgs)
+        if stateful:
+            ref = []
+            for c in range(ncam):
+                seqs = [[dict(point=p, point_key=i, target=0)] for i, p in enumerate(lists[c])]
+                ref.append(kf.patch_sequences(kf.PF_TRACK, [(plain_kfs[c], cam, pose, cfbs[c])], seqs, states[c], 10, 8) if lists[c] else np.zeros(0, dtype=kf.TD_OUT_DTYPE))
+        else:
+            ref = kf.track_search_batch(plain_kfs, [cam]*ncam, pose, cfb_arr, lists, 10, 8)
+        for c in range(ncam):
+            assert len(outs[c]) == len(lists[c])
+            for f in ref[c].dtype.names:
+                assert np.array_equal(ref[c][f], outs[c][f], equal_nan=ref[c][f].dtype.kind == "f"), (c, f)
+            _assert_lite_equal_gpu = [np.array_equal(fused_kfs[c].Image(l), plain_kfs[c].Image(l)) and np.array_equal(fused_kfs[c].Corners(l), plain_kfs[c].Corners(l)) for l in range(4)]
+            assert all(_assert_lite_equal_gpu)
+            if stateful and len(lists[c]):
+                for f in tf.states[c].dtype.names:
+                    assert np.array_equal(tf.states[c][f], states[c][f], equal_nan=tf.states[c][f].dtype.kind == "f"), (c, f)
+        host_recs = kf.pose_points_frame(wpos, ref)
+        pose_p, mu_p, w_p, recs_p = kf.track_pose_refine(host_recs, [cam]*ncam, cfb_arr, pose)
+        assert np.array_equal(pose_f[0], pose_p[0]) and np.array_equal(pose_f[1], pose_p[1]) and np.array_equal(mu_f, mu_p) and np.array_equal(w_f, w_p)
+        for f in recs_p.dtype.names:
+            assert np.array_equal(recs[f], recs_p[f]), f
+        assert sum(int(o_["found"].sum()) for o_ in outs) > 150 and np.abs(mu_f).max() > 0
+    # search only (n_iter = 0): the pose stays, the weights are zero
+    outs, recs, pose0, mu0, w0 = tf.run(None, poses[1], 10, 8, nonlinear=np.zeros(0, dtype=np.uint8), override_sigma=np.zeros(0))
+    assert np.array_equal(pose0[0], poses[1][0]) and not mu0.any() and not w0.any()
