@@ -215,3 +215,128 @@ Vector<6> Tracker::CalcPoseUpdate(std::vector<TrackerDataPtrVector>& vIterationS
 
   return makeVector(adMu[0], adMu[1], adMu[2], adMu[3], adMu[4], adMu[5]);
 }
+
+
+// ---- one TrackMap stage in one submission (optional) -----------------------------------------------------------------------------
+// Tracker::TrackMap spends a stage as: SearchForPoints per camera, then ten PoseUpdateStep / PoseUpdateStepLinear iterations over all
+// cameras (src/Tracker.cc:1013-1035 coarse, 1043-1075 fine).  mcp_track_frame runs that whole stage -- and, when the frame has just
+// arrived, the MakeKeyFrame_Lite of every camera before it (src/Tracker.cc:303-318) -- as one device submission with one wait: the
+// searches of all cameras in one launch with the persistent finders, the pose-iteration records built on the device, the ten iterations
+// in one kernel.  A maintainer who wants it declares
+//     Vector<6> TrackStageOnDevice(std::vector<TrackerDataPtrVector>& vIterationSets, int nRange, int nSubPixIts, bool bFineStage, bool bMakeLite);
+// in Tracker.h and calls it where the stage's SearchForPoints loop + iteration loop stood, after having collected every camera's
+// points to search into vIterationSets[i] (TestForCoarse / SetupFineTracking minus their SearchForPoints calls).  Results are those
+// of the per-camera calls above followed by mcp_track_pose_refine_m (tests/test_img_gpu.py::
+// test_track_frame_in_one_submission_equals_the_three_calls).  The outlier marking of the last fine iteration stays on the host:
+// weights_last is what CalcPoseUpdate's marking branch reads.
+Vector<6> Tracker::TrackStageOnDevice(std::vector<TrackerDataPtrVector>& vIterationSets, int nRange, int nSubPixIts, bool bFineStage, bool bMakeLite)
+{
+  const int nCams = (int)mvCurrCamNames.size();
+  std::vector<mcp_kf*> vKF(nCams);
+  std::vector<mcp_camera> vCams(nCams);
+  std::vector<double> vCfB(12 * nCams);
+  std::vector<int> vN(nCams);
+  std::vector<std::vector<mcp_td_in> > vvIn(nCams);
+  std::vector<std::vector<int> > vvKey(nCams);
+  std::vector<std::vector<mcp_pf_state> > vvState(nCams);
+  std::vector<std::vector<mcp_td_out> > vvOut(nCams);
+  std::vector<const mcp_td_in*> vpIn(nCams);
+  std::vector<const int*> vpKey(nCams);
+  std::vector<mcp_pf_state*> vpState(nCams);
+  std::vector<mcp_td_out*> vpOut(nCams);
+  std::vector<const uint8_t*> vpImg(nCams);
+  std::vector<int> vStride(nCams);
+  int nTotal = 0;
+  for(int c = 0; c < nCams; ++c)
+  {
+    KeyFrame& kf = *mpCurrentMKF->mmpKeyFrames[mvCurrCamNames[c]];
+    ROS_ASSERT(kf.mpDev);
+    vKF[c] = kf.mpDev;
+    vCams[c] = mcptam_hip::CameraExport::Make(mmCameraModels[mvCurrCamNames[c]]);
+    ToArray12(kf.mse3CamFromBase, &vCfB[12*c]);
+    TrackerDataPtrVector& vTD = vIterationSets[c];
+    vN[c] = (int)vTD.size();
+    vvIn[c].resize(vTD.size()); vvKey[c].resize(vTD.size()); vvState[c].resize(vTD.size()); vvOut[c].resize(vTD.size());
+    for(unsigned i = 0; i < vTD.size(); ++i)
+    {
+      MapPoint& point = vTD[i]->mPoint;
+      mcp_td_in& in = vvIn[c][i];
+      for(int k = 0; k < 3; ++k)
+      {
+        in.world_pos[k] = point.mv3WorldPos[k];
+        in.pixel_right_w[k] = point.mv3PixelRight_W[k];
+        in.pixel_down_w[k] = point.mv3PixelDown_W[k];
+      }
+      in.source_kf = point.mpPatchSourceKF->mpDev;
+      in.source_level = point.mnSourceLevel;
+      in.center_x = point.mirCenter.x;
+      in.center_y = point.mirCenter.y;
+      in.fixed = point.mbFixed ? 1 : 0;
+      vvKey[c][i] = (int)(reinterpret_cast<uintptr_t>(&point) >> 4);
+      vvState[c][i] = vTD[i]->mFinderState;
+    }
+    vpIn[c] = vvIn[c].empty() ? NULL : &vvIn[c][0];
+    vpKey[c] = vvKey[c].empty() ? NULL : &vvKey[c][0];
+    vpState[c] = vvState[c].empty() ? NULL : &vvState[c][0];
+    vpOut[c] = vvOut[c].empty() ? NULL : &vvOut[c][0];
+    vpImg[c] = kf.maLevels[0].image.data();                 // only read when bMakeLite (the frame the tracker was handed)
+    vStride[c] = kf.maLevels[0].image.row_stride();
+    nTotal += vN[c];
+  }
+
+  // coarse stage: ten full re-projections, sigma override 1.0; fine stage: re-projection at 0, 4, 9, override 16.0 (src/Tracker.cc:1027-1030,
+  // 1063-1072); PoseUpdateStep / PoseUpdateStepLinear drop the override up to the fifth iteration (:800-802)
+  uint8_t abNonlinear[10];
+  double adOverride[10];
+  for(int it = 0; it < 10; ++it)
+  {
+    abNonlinear[it] = (!bFineStage || it == 0 || it == 4 || it == 9) ? 1 : 0;
+    adOverride[it] = it <= 5 ? 0.0 : (bFineStage ? 16.0 : 1.0);
+  }
+  int nEstimator = MCP_MEST_TUKEY;
+  if(Tracker::sMEstimatorName == "Cauchy") nEstimator = MCP_MEST_CAUCHY;
+  else if(Tracker::sMEstimatorName == "Huber") nEstimator = MCP_MEST_HUBER;
+
+  double adBfW[12], adMu[6];
+  ToArray12(mpCurrentMKF->mse3BaseFromWorld, adBfW);
+  std::vector<double> vWeights(std::max(nTotal, 1));
+  if(mcp_track_frame(nCams, &vKF[0], bMakeLite ? &vpImg[0] : NULL, &vStride[0], 0, NULL, &vCams[0], adBfW, &vCfB[0], &vN[0], &vpIn[0], &vpKey[0], &vpState[0],
+                     nRange, nSubPixIts, 0, 10, abNonlinear, adOverride, nEstimator, &vpOut[0], NULL, adMu, &vWeights[0]) != 0)
+  {
+    ROS_FATAL_STREAM("Tracker::TrackStageOnDevice: "<<mcp_last_error());
+    ros::shutdown();
+    return Zeros;
+  }
+
+  // BaseFromWorld as the ten iterations left it, TrackerData as SearchForPoints leaves it
+  Matrix<3> m3R;
+  for(int i = 0; i < 3; ++i)
+    for(int j = 0; j < 3; ++j)
+      m3R(i, j) = adBfW[3*i + j];
+  mpCurrentMKF->mse3BaseFromWorld = SE3<>(SO3<>(m3R), makeVector(adBfW[9], adBfW[10], adBfW[11]));
+  int w = 0;
+  for(int c = 0; c < nCams; ++c)
+  {
+    TrackerDataPtrVector& vTD = vIterationSets[c];
+    for(unsigned i = 0; i < vTD.size(); ++i, ++w)
+    {
+      TrackerData& td = *vTD[i];
+      const mcp_td_out& out = vvOut[c][i];
+      td.mFinderState = vvState[c][i];
+      td.mnSearchLevel = out.search_level;
+      td.mbSearched = out.searched != 0;
+      td.mbFound = out.found != 0 && !out.template_bad;
+      td.mbDidSubPix = out.did_subpix != 0;
+      if(out.template_bad) { td.mbInImage = false; continue; }
+      if(!td.mbFound) continue;
+      td.mdSqrtInvNoise = out.sqrt_inv_noise;
+      td.mv2Found = makeVector(out.found_pos[0], out.found_pos[1]);
+      if(bFineStage && !IsLost())        // the marking iteration's bookkeeping (src/Tracker.cc:1448-1487)
+      {
+        if(vWeights[w] == 0.0) td.mPoint.mnMEstimatorOutlierCount++;
+        else td.mPoint.mnMEstimatorInlierCount++;
+      }
+    }
+  }
+  return makeVector(adMu[0], adMu[1], adMu[2], adMu[3], adMu[4], adMu[5]);
+}
