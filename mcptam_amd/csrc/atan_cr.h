@@ -109,6 +109,68 @@ MCP_ATAN_HD dd dd_div(dd a, dd b) { MCP_NOCONTRACT
   return dd_add_d(q, q3);
 }
 
+// Fast path (Ziv's strategy): the same range reduction with ONE division and the series carried as double + correction terms gives
+// atan|x| = hi + lo with an error below 2^-80 of the result; if rounding hi + lo - e and hi + lo + e (e = 2^-75 of the result) agree,
+// that double IS the correctly rounded value -- on any platform, whatever its division or fma do in the last place of the intermediate
+// terms -- and the full double-double evaluation below is only needed for the ~2^-21 of the arguments that come closer to a rounding
+// boundary.  Error budget (|r| <= 2^-7, V = result): the tail q (r^5/5 .. r^11/11 in double) 2^-50 |q| <= 2^-80 |r|; series truncation
+// r^13/13 <= 2^-87 |r|; r, r^2, r^3, r^3/3 are double-doubles (errors ~2^-103 |r|); the table entries and pi/2 are exact to 2^-107;
+// the final additions lose < 2^-104 V.  |r| <= V, and for |x| > 1 the result is >= pi/4 >= what it is subtracted from.
+#define MCP_C9 0x1.c71c71c71c71cp-4
+#define MCP_C11 0x1.745d1745d1746p-4
+MCP_ATAN_HD bool atan_fast(double ax, bool inv, double* out) { MCP_NOCONTRACT
+  // c = k/64 near u = ax (or 1/ax): any k within a hair of the nearest one keeps |r| <= 1/128 + 2^-22
+  double rh, rl; int k;
+  if (inv) {
+    if (ax > 3.0e38) return false;                             // (beyond float range: the slow path's double-double reciprocal)
+    const float uf = 1.0f/(float)ax;
+    const double kf = __builtin_rint((double)uf*64.0);
+    k = (int)kf;
+    if (k == 0) {                                              // ax > 128: r = 1/ax
+      rh = 1.0/ax;
+      rl = __builtin_fma(-rh, ax, 1.0)*rh;
+    } else {
+      // r = (1/ax - c)/(1 + c/ax) = (1 - c ax)/(ax + c)
+      const double c = kf*0.015625;
+      const double p = c*ax, pl = __builtin_fma(c, ax, -p);    // c ax = p + pl exactly
+      dd num = two_sum(1.0, -p); num.lo -= pl;                 // exact sum, then a tiny correction
+      const dd den = two_sum(ax, c);
+      const double id = 1.0/den.hi;
+      rh = num.hi*id;
+      rl = ((__builtin_fma(-rh, den.hi, num.hi) + num.lo) - rh*den.lo)*id;
+    }
+  } else {
+    const double kf = __builtin_rint(ax*64.0);
+    k = (int)kf;
+    if (k == 0) { rh = ax; rl = 0.0; }
+    else {
+      const double c = kf*0.015625;
+      const double n0 = ax - c;                                // exact (ax / c in [1/2, 2])
+      const double p = ax*c, pl = __builtin_fma(ax, c, -p);
+      dd den = two_sum(1.0, p); den.lo += pl;
+      const double id = 1.0/den.hi;
+      rh = n0*id;
+      rl = (__builtin_fma(-rh, den.hi, n0) - rh*den.lo)*id;
+    }
+  }
+  const double sh = rh*rh, sl = __builtin_fma(rh, rh, -sh) + 2.0*rh*rl;                      // r^2
+  const double wh = rh*sh, wl = __builtin_fma(rh, sh, -wh) + (rh*sl + rl*sh);               // r^3
+  const double th = wh*MCP_C3_HI, tl = __builtin_fma(wh, MCP_C3_HI, -th) + (wh*MCP_C3_LO + wl*MCP_C3_HI);      // r^3/3
+  const double q = (wh*sh)*(MCP_C5_HI + sh*(-MCP_C7_HI + sh*(MCP_C9 - sh*MCP_C11)));       // r^5/5 - r^7/7 + r^9/9 - r^11/11
+  const dd s1 = two_sum(kAtanHi[k], rh);
+  const dd s2 = two_sum(s1.hi, -th);
+  const double low = s2.lo + (s1.lo + ((kAtanLo[k] + rl) + (q - tl)));
+  dd res = fast_two_sum(s2.hi, low);
+  if (inv) {
+    const dd p1 = two_sum(MCP_PIO2_HI, -res.hi);
+    res = fast_two_sum(p1.hi, p1.lo + (MCP_PIO2_LO - res.lo));
+  }
+  const double e = res.hi*0x1p-75;
+  const double a = res.hi + (res.lo - e), b = res.hi + (res.lo + e);
+  *out = a;
+  return a == b;
+}
+
 MCP_ATAN_HD double atan_cr(double x) { MCP_NOCONTRACT
   if (x != x) return x;
   const double ax = x < 0 ? -x : x;
@@ -119,6 +181,9 @@ MCP_ATAN_HD double atan_cr(double x) { MCP_NOCONTRACT
     const double r = MCP_PIO2_HI;
     return x < 0 ? -r : r;
   }
+#if !defined(MCP_ATAN_NO_FAST)
+  { double fast; if (atan_fast(ax, inv, &fast)) return x < 0 ? -fast : fast; }
+#endif
   if (inv) { dd one; one.hi = 1.0; one.lo = 0.0; dd t; t.hi = ax; t.lo = 0.0; u = dd_div(one, t); }
   else { u.hi = ax; u.lo = 0.0; }
   const double kf = __builtin_rint(u.hi*64.0);

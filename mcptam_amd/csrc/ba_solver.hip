@@ -625,6 +625,17 @@ int mcp_ba::wait_stream(hipStream_t s, const char* what) {
   }
 }
 
+// Large host scratch of Prepare() (the measurements in sorted order, the per-thread counters): one grow-only block per process, kept
+// between calls -- a fresh 16 MB allocation per call comes back from the allocator as untouched pages, and sixteen threads faulting
+// them in cost the phase that fills them anything between 1 and 6 ms.  Held (mutex) for the duration of a Prepare().
+namespace {
+struct PrepScratch {
+  std::mutex m; std::unique_ptr<char[]> p; size_t cap = 0, used = 0;
+  void reset(size_t bytes) { if (bytes > cap) { cap = bytes + bytes/4 + 4096; p.reset(new char[cap]); } used = 0; }
+  template <class T> T* take(size_t count) { used = (used + 63) & ~(size_t)63; T* r = reinterpret_cast<T*>(p.get() + used); used += count*sizeof(T); return r; }
+};
+PrepScratch& prep_scratch() { static PrepScratch s; return s; }
+}
 // Structure build of one Compute() -- the analogue of g2o's initializeOptimization + buildStructure -- on the host's cores:
 // which poses / points take part, points ordered by source pose, measurements bucketed by point, per-measurement Jacobian
 // slots and per-point incidences, groups of points for the LDS-tiled kernels, the fixed-order staging plan of their pose
@@ -647,11 +658,16 @@ int mcp_ba::prepare() {
   // ---- one pass over the measurements in add order, a range per thread: which chains are used, and how many measurements of
   // every point the range holds (private counters: no shared writes)
   std::vector<unsigned char> chain_used(nch, 0);
-  std::unique_ptr<int[]> cnt_t(new int[(size_t)T*std::max(npoint, 1)]);
+  struct SMeas { int chain, cam, mi, pad_; double u, v, omega; };
+  PrepScratch& scratch = prep_scratch();
+  std::unique_lock<std::mutex> scratch_lock(scratch.m);
+  scratch.reset(sizeof(int)*(size_t)T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + 256);
+  int* const cnt_t = scratch.take<int>((size_t)T*std::max(npoint, 1));
+  SMeas* const sorted = scratch.take<SMeas>(std::max(nmeas, 1));
   {
     std::vector<unsigned char> cu_all((size_t)T*nch, 0);
     par([&](int tid) {
-      unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t.get() + (size_t)tid*npoint;
+      unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t + (size_t)tid*npoint;
       std::memset(ct, 0, sizeof(int)*(size_t)npoint);
       const int* mc = meas_chain.data(); const int* mp = meas_point.data();
       for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; }
@@ -714,7 +730,8 @@ int mcp_ba::prepare() {
   const bool dense_table = nch <= 4096;
   // (entries are written concurrently by the structure threads below: every writer stores the same value, relaxed atomics)
   std::unique_ptr<std::atomic<unsigned short>[]> mask_table(dense_table ? new std::atomic<unsigned short>[nch*nch] : nullptr);
-  if (dense_table) for (size_t i = 0; i < nch*nch; ++i) mask_table[i].store(0xffff, std::memory_order_relaxed);
+  static_assert(sizeof(std::atomic<unsigned short>) == 2, "mask table is filled bytewise");
+  if (dense_table) std::memset(static_cast<void*>(mask_table.get()), 0xff, nch*nch*sizeof(unsigned short));      // (no thread reads it before the pool starts)
   std::map<std::pair<int, int>, unsigned short> mask_cache;
   std::mutex mask_mutex;
   auto compute_mask = [&](int oc, int sc) -> unsigned short {
@@ -753,10 +770,8 @@ int mcp_ba::prepare() {
   // Measurements of a point are stored rotated by the point's position: neighbouring points (= neighbouring lanes of
   // k_linearize_group) share their observers, and walking the lists in the same order makes all lanes add to the same
   // LDS tile entries at the same time; a per-lane rotation spreads them over the observers.
-  struct SMeas { int chain, cam, mi, pad_; double u, v, omega; };
-  std::unique_ptr<SMeas[]> sorted(new SMeas[std::max(nmeas, 1)]);
   par([&](int tid) {
-    int* ct = cnt_t.get() + (size_t)tid*npoint; const int* mp = meas_point.data(); const int* smp = H.sp_m.data();
+    int* ct = cnt_t + (size_t)tid*npoint; const int* mp = meas_point.data(); const int* smp = H.sp_m.data();
     for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
       const int p = mp[i], r = ct[p]++, sp = sp_of[p], nm = cnt[p + 1] - cnt[p];
       int kk = (r - sp) % nm; if (kk < 0) kk += nm;                    // rank r sits at slot kk with (kk + sp) % nm == r

@@ -1,6 +1,8 @@
 // atan_cr (mcptam_amd/csrc/atan_cr.h, the device's correctly rounded arctangent) against round(atanq) from libquadmath,
 // the route the oracle takes: every argument must give the same double.  Usage: atan_cr_check [count] -> prints
-// "mismatches <n> of <count>" and, for information, how often glibc's atan differs from the correctly rounded value.
+// "mismatches <n> of <count>", how often the fast (Ziv) path had to hand over to the double-double evaluation for the arguments a
+// camera produces ("angle-uniform slow <n> of <m>"), and, for information, how often glibc's atan differs from the correctly rounded
+// value.  Built twice by the test: as is, and with -DMCP_ATAN_NO_FAST (the double-double evaluation alone must pass as well).
 #include <quadmath.h>
 #include <cstdio>
 #include <cstdlib>
@@ -15,10 +17,10 @@ static double uni() { return (double)(next() >> 11)*(1.0/9007199254740992.0); }
 
 int main(int argc, char** argv) {
   const long N = argc > 1 ? atol(argv[1]) : 4000000;
-  long bad = 0, glibc_bad = 0;
+  long bad = 0, glibc_bad = 0, cam_n = 0, cam_slow = 0;
   for (long i = 0; i < N; ++i) {
     double x;
-    switch (i % 8) {
+    switch (i % 10) {
       case 0: x = uni()*2.0 - 1.0; break;                          // [-1, 1]
       case 1: x = (uni()*2.0 - 1.0)*64.0; break;                   // wide
       case 2: x = ldexp(uni() + 0.5, (int)(next() % 120) - 60); break;      // many binades
@@ -26,8 +28,13 @@ int main(int argc, char** argv) {
       case 4: x = 1.0 + (uni() - 0.5)*ldexp(1.0, -(int)(next() % 52)); break;                          // around 1
       case 5: { uint64_t b = next(); memcpy(&x, &b, 8); if (!(x == x) || std::isinf(x)) x = 0.5; break; }  // any bit pattern
       case 6: x = tan((uni() - 0.5)*3.0); break;                   // uniform in the angle (what a camera sees)
-      default: x = -ldexp(uni(), -(int)(next() % 1000)); break;    // tiny / subnormal-ish
+      case 7: x = -ldexp(uni(), -(int)(next() % 1000)); break;     // tiny / subnormal-ish
+      case 8: x = 1.0/((double)(next() % 64 + 1)/64.0 + (uni() - 0.5)*ldexp(1.0, -(int)(next() % 50))); break;   // reciprocals of the table nodes
+      default: x = ldexp(uni() + 0.5, (int)(next() % 300)); break; // large, past the float range of the fast path's node choice
     }
+#if !defined(MCP_ATAN_NO_FAST)
+    if (i % 10 == 6) { double f; ++cam_n; if (!mcp_atan::atan_fast(fabs(x), fabs(x) > 1.0, &f)) ++cam_slow; }
+#endif
     const double want = (double)atanq((__float128)x);
     const double got = mcp_atan::atan_cr(x);
     if (memcmp(&want, &got, 8) != 0) { if (bad < 10) printf("x=%a want=%a got=%a\n", x, want, got); ++bad; }
@@ -35,6 +42,7 @@ int main(int argc, char** argv) {
     if (memcmp(&want, &gl, 8) != 0) ++glibc_bad;
   }
   printf("mismatches %ld of %ld (glibc atan differs from the correctly rounded value for %ld)\n", bad, N, glibc_bad);
+  printf("angle-uniform slow %ld of %ld\n", cam_slow, cam_n);
   const double sp[] = {0.0, -0.0, 1.0, -1.0, INFINITY, -INFINITY, 1e300, 5e-324, 0x1p-1022};
   for (double v : sp) { const double w = (double)atanq((__float128)v), g = mcp_atan::atan_cr(v); if (memcmp(&w, &g, 8)) { printf("special %a: want %a got %a\n", v, w, g); ++bad; } }
   return bad ? 1 : 0;

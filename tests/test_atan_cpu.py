@@ -14,11 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_device_atan_algorithm_equals_rounded_binary128(tmp_path):
-    exe = str(tmp_path / "atan_cr_check")
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "cpp", "atan_cr_check.cpp"), "-lquadmath"])
-    out = subprocess.run([exe, "3000000"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout[-2000:]
-    assert "mismatches 0 of 3000000" in out.stdout
+    """Both forms: with the fast path (one division, error < 2^-80, accepted only when rounding is unambiguous at 2^-75 -- Ziv's
+    strategy) and the double-double evaluation alone.  The fast path must also be what camera arguments actually take."""
+    import re
+    for flags in ([], ["-DMCP_ATAN_NO_FAST"]):
+        exe = str(tmp_path / ("atan_cr_check" + ("_slow" if flags else "")))
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off"] + flags + ["-o", exe, os.path.join(ROOT, "tests", "cpp", "atan_cr_check.cpp"), "-lquadmath"])
+        out = subprocess.run([exe, "3000000"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout[-2000:]
+        assert "mismatches 0 of 3000000" in out.stdout
+        if not flags:
+            slow, n = map(int, re.search(r"angle-uniform slow (\d+) of (\d+)", out.stdout).groups())
+            assert n == 300000 and slow <= 3, (slow, n)
 
 
 def test_oracle_atan_is_within_one_ulp_of_libm():
