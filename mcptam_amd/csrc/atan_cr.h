@@ -8,6 +8,12 @@
 // here (error < 2^-100 before the final rounding), the oracle computes it independently through libquadmath's atanq and
 // rounds -- two routes to the same bits.
 //
+// What "correctly rounded" rests on: the fast path below carries a rounding test (Ziv), so whatever it returns is the correctly rounded
+// value; an argument it cannot decide goes to the double-double evaluation (error < 2^-100), whose result is rounded without a further test --
+// it would be wrong only for an argument within 2^-100 of a rounding boundary as well, i.e. with probability ~2^-46 per argument that reaches
+// it (the known worst cases of atan in binary64 sit near 2^-110; none has been found by the 300 M-argument comparison with atanq, and
+// the oracle's single cast of a 113-bit atanq has the same order of exposure).
+//
 // Method: |x| > 1 is inverted (atan x = pi/2 - atan 1/x, the reciprocal carried as a double-double); the argument u in
 // [0, 1] is split at c = k/64 nearest to it, atan u = atan c + atan r with r = (u - c)/(1 + u c) in double-double
 // (|r| <= 1/128); atan r = r - r^3/3 + r^5/5 - r^7/7 in double-double plus the r^9.. tail in double (it is below

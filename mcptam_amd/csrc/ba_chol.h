@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -569,8 +570,14 @@ inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys 
   const int n = plan.n;
   S += q0*sys_stride;
   const double* dg = plan.d_diag + q0*plan.diag_stride;
-  static bool attr_set = false;      // x (up to CH_SOLVE_MAX doubles) + the staged tiles can exceed the default 64 KB of LDS
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SOLVE_MAX*(int)sizeof(double)); attr_set = true; }
+  // x (up to CH_SOLVE_MAX doubles) + the staged tiles can exceed the default 64 KB of LDS; function attributes are per device
+  static std::atomic<unsigned long long> attr_mask{0};
+  int dev = 0; (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
+    (void)hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, CH_SOLVE_MAX*(int)sizeof(double));
+    attr_mask.fetch_or(bit, std::memory_order_relaxed);
+  }
   hipLaunchKernelGGL(k_chol_back, dim3(nsys), dim3(CH_BACK_THREADS), (size_t)n*sizeof(double), st, (const double*)S, n,
                      (const int*)plan.d_row_start, (const int*)plan.d_row_tiles, S + (size_t)n*n, sys_stride, dg, plan.diag_stride);
 }
