@@ -21,7 +21,38 @@ def _lib():
         _rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
         _rt.hipFree.argtypes = [ctypes.c_void_p]
         _rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _rt.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        _rt.hipHostFree.argtypes = [ctypes.c_void_p]
     return _rt
+
+
+class _Pinned:
+    """owner of one hipHostMalloc block (freed with the last array that views it)"""
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        rc = _lib().hipHostMalloc(ctypes.byref(p), max(int(nbytes), 1), 0)
+        if rc != 0:
+            raise RuntimeError("hipHostMalloc failed (%d)" % rc)
+        self.ptr, self.nbytes = p.value, max(int(nbytes), 1)
+        self.buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            _lib().hipHostFree(ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_zeros(count, dtype):
+    """numpy array of `count` zero elements in pinned (page-locked) host memory: a result buffer the library's device-to-host copies
+    reach by DMA instead of through the runtime's staging of pageable memory (what a native caller gets from hipHostMalloc /
+    hipHostRegister on its own arrays)."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    own = _Pinned(int(count)*dt.itemsize)
+    a = np.frombuffer(own.buf, dtype=dt, count=int(count))
+    ctypes.memset(own.ptr, 0, own.nbytes)
+    return a, own
 
 
 def dev_alloc(nbytes):

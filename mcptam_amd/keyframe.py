@@ -473,7 +473,7 @@ class TrackFrame:
     `run(imgs, base_from_world, ...)` = one stage of Tracker::TrackMap: MakeKeyFrame_Lite of every camera (imgs=None: skip), the search,
     the pose iterations.  Returns (td_outs per camera, pose points, (R, t), mu, weights)."""
 
-    def __init__(self, kfs, cams, cams_from_base, points, stateful=False, point_keys=None):
+    def __init__(self, kfs, cams, cams_from_base, points, stateful=False, point_keys=None, pinned=True):
         from .taylor_camera import camera_array
         self.kfs = list(kfs)
         n = self.n = len(self.kfs)
@@ -486,10 +486,12 @@ class TrackFrame:
         self.offs = np.concatenate([[0], np.cumsum(self.lens)]).astype(int)
         self.ns = (ctypes.c_int * n)(*self.lens)
         self.ins = (ctypes.c_void_p * n)(*[ctypes.cast(a, ctypes.c_void_p) for a in self.arrs])
-        self.whole = np.zeros(max(self.total, 1), dtype=TD_OUT_DTYPE)
+        # result buffers in pinned host memory (a native tracker registers its TrackerData arrays the same way): the copies back are DMA
+        from . import hip_rt
+        self.whole, self._own0 = hip_rt.pinned_zeros(max(self.total, 1), TD_OUT_DTYPE) if pinned else (np.zeros(max(self.total, 1), dtype=TD_OUT_DTYPE), None)
         self.ops = (ctypes.c_void_p * n)(*[self.whole.ctypes.data + int(self.offs[c])*TD_OUT_DTYPE.itemsize for c in range(n)])
-        self.pts = np.zeros(max(self.total, 1), dtype=POSE_POINT_DTYPE)
-        self.w = np.zeros(max(self.total, 1))
+        self.pts, self._own1 = hip_rt.pinned_zeros(max(self.total, 1), POSE_POINT_DTYPE) if pinned else (np.zeros(max(self.total, 1), dtype=POSE_POINT_DTYPE), None)
+        self.w, self._own2 = hip_rt.pinned_zeros(max(self.total, 1), np.float64) if pinned else (np.zeros(max(self.total, 1)), None)
         self.mu = np.zeros(6)
         self.states = self.keys = self.sp = self.kp = None
         if stateful:
@@ -499,7 +501,7 @@ class TrackFrame:
             self.kp = (ctypes.c_void_p * n)(*[k_.ctypes.data for k_ in self.keys])
 
     def run(self, imgs, base_from_world, rng, subpix_its, exhaustive=False, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey",
-            on_device=False, strides=None):
+            on_device=False, strides=None, want_points=True):
         n = self.n
         ip = st = None
         keep = None
@@ -516,9 +518,9 @@ class TrackFrame:
         ov = np.ascontiguousarray(override_sigma, dtype=np.float64)
         _chk(lib().mcp_track_frame(n, self.hs, ip, st, int(on_device), None, ctypes.cast(self.cs, ctypes.c_void_p), bfw.ctypes.data, self.cfb.ctypes.data, self.ns, self.ins,
                                    self.kp, self.sp, int(rng), int(subpix_its), int(exhaustive), len(nl), nl.ctypes.data, ov.ctypes.data, MEST[estimator],
-                                   self.ops, self.pts.ctypes.data, self.mu.ctypes.data, self.w.ctypes.data), "track_frame")
+                                   self.ops, self.pts.ctypes.data if want_points else None, self.mu.ctypes.data, self.w.ctypes.data), "track_frame")
         outs = [self.whole[self.offs[c]:self.offs[c + 1]] for c in range(n)]
-        return outs, self.pts[:self.total], (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), self.mu.copy(), self.w[:self.total]
+        return outs, (self.pts[:self.total] if want_points else None), (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), self.mu.copy(), self.w[:self.total]
 
 
 def track_pose_refine(pts, cams, cam_from_base, base_from_world, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey"):

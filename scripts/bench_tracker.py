@@ -57,7 +57,8 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
     tf = TrackFrame(cur, carr, cfb_arr, packed)
 
     def fused_frame(upload=False):
-        outs, _recs, _pose, _mu, _w = tf.run([sc["imgB"]]*cams if upload else ring, sc["poseB"], 10, 8, on_device=not upload)
+        # (the pose-iteration records are not read back: the tracker needs the TrackerData, the pose and the last weights)
+        outs, _recs, _pose, _mu, _w = tf.run([sc["imgB"]]*cams if upload else ring, sc["poseB"], 10, 8, on_device=not upload, want_points=False)
         return sum(int(o_["found"].sum()) for o_ in outs)
 
     assert fused_frame() == found
