@@ -212,7 +212,8 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
     tt = np.array([-tR[k] @ centres[k] for k in range(n_mkf)])
     # points in a 2..15 m shell around the trajectory; over-generate then keep well-observed ones
     need = n_points
-    world, obs_list = [], []
+    world = []
+    obs_mk, obs_cam, obs_uv = [], [], []                   # per accepted point: per_point observations (MKF, camera, pixel), in candidate order
     kk = min(k_near, n_mkf)
     rounds = 0
     while need > 0:
@@ -226,8 +227,18 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
         u /= np.linalg.norm(u, axis=1, keepdims=True)
         d = rng.uniform(2.0, 15.0, n_try)
         X = centres[anchor] + u * d[:, None]
-        d2 = ((X[:, None, :] - centres[None, :, :]) ** 2).sum(axis=2)   # (n_try, P)
-        near = np.argsort(d2, axis=1, kind="stable")[:, :kk]
+        # the kk nearest MKF centres of every candidate, nearest first (ties by index, as a stable argsort of the whole row gives them);
+        # in row chunks: the (n_try, P, 3) difference array of a 100k-point round would be 1.8 GB
+        near = np.empty((n_try, kk), dtype=np.int64)
+        for r0 in range(0, n_try, 8192):
+            d2 = ((X[r0:r0 + 8192, None, :] - centres[None, :, :]) ** 2).sum(axis=2)   # (chunk, P)
+            if kk < n_mkf:
+                part = np.argpartition(d2, kk - 1, axis=1)[:, :kk]
+                pd = np.take_along_axis(d2, part, axis=1)
+                o2 = np.lexsort((part, pd), axis=1)                  # by distance, then by index
+                near[r0:r0 + 8192] = np.take_along_axis(part, o2, axis=1)
+            else:
+                near[r0:r0 + 8192] = np.argsort(d2, axis=1, kind="stable")[:, :kk]
         # candidate observations ordered by (distance rank, cam)
         cand_valid = np.zeros((n_try, kk, n_cams), dtype=bool)
         cand_uv = np.zeros((n_try, kk, n_cams, 2))
@@ -242,31 +253,34 @@ def make_problem(n_cams=4, n_mkf=50, n_points=10000, per_point=8, mode="multi", 
         flat_valid = cand_valid.reshape(n_try, -1)
         count = flat_valid.sum(axis=1)
         good = np.nonzero(count >= per_point)[0][:need]
-        for i in good:
-            sel = np.nonzero(flat_valid[i])[0][:per_point]
-            obs = [(int(near[i, s // n_cams]), int(s % n_cams), cand_uv[i, s // n_cams, s % n_cams]) for s in sel]
-            world.append(X[i])
-            obs_list.append(obs)
+        if len(good):
+            # the first per_point valid candidates of every accepted point, in candidate order (distance rank, then camera)
+            fv = flat_valid[good]
+            pick = fv & (np.cumsum(fv, axis=1) <= per_point)
+            gi, si = np.nonzero(pick)                          # row-major: per point, ascending candidate index
+            rank, camc = si // n_cams, si % n_cams
+            obs_mk.append(near[good[gi], rank].reshape(len(good), per_point))
+            obs_cam.append(camc.reshape(len(good), per_point))
+            obs_uv.append(cand_uv[good[gi], rank, camc].reshape(len(good), per_point, 2))
+            world.append(X[good])
         need -= len(good)
-    world = np.array(world)
+    world = np.concatenate(world) if world else np.zeros((0, 3))
+    obs_mk = np.concatenate(obs_mk).astype(np.int64); obs_cam = np.concatenate(obs_cam).astype(np.int64); obs_uv = np.concatenate(obs_uv)
     N = n_points
     # fixed (calibration) points: stored in world coordinates with chain {world}
     pt_fixed = np.zeros(N, dtype=bool)
     if n_fixed_points:
         pt_fixed[rng.choice(N, n_fixed_points, replace=False)] = True
     # measurements, populated MKF-major then camera then point (BundleAdjusterMulti.cc:168-200)
-    rows = []
     pt_src = np.zeros((N, 2), dtype=np.int32)
-    for i, obs in enumerate(obs_list):
-        src = min(obs, key=lambda o: (o[0], o[1]))                       # "first KF that sees it"
-        pt_src[i] = (src[0], src[1])
-        for (mk, c, uv) in obs:
-            rows.append((mk, c, i, uv[0], uv[1]))
-    rows.sort(key=lambda r: (r[0], r[1], r[2]))
-    ms_mkf = np.array([r[0] for r in rows], dtype=np.int32)
-    ms_cam = np.array([r[1] for r in rows], dtype=np.int32)
-    ms_pt = np.array([r[2] for r in rows], dtype=np.int32)
-    ms_uv = np.array([[r[3], r[4]] for r in rows], dtype=np.float64)
+    first = np.argmin(obs_mk*n_cams + obs_cam, axis=1)                    # "first KF that sees it": smallest (MKF, camera)
+    pt_src[:, 0] = obs_mk[np.arange(N), first]; pt_src[:, 1] = obs_cam[np.arange(N), first]
+    pt_of = np.repeat(np.arange(N), per_point)
+    order = np.lexsort((pt_of, obs_cam.reshape(-1), obs_mk.reshape(-1)))   # by (MKF, camera, point)
+    ms_mkf = obs_mk.reshape(-1)[order].astype(np.int32)
+    ms_cam = obs_cam.reshape(-1)[order].astype(np.int32)
+    ms_pt = pt_of[order].astype(np.int32)
+    ms_uv = np.ascontiguousarray(obs_uv.reshape(-1, 2)[order], dtype=np.float64)
     M = ms_uv.shape[0]
     ms_level = rng.choice(4, size=M, p=[0.55, 0.25, 0.15, 0.05]).astype(np.int32)
     if noise:

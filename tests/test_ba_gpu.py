@@ -421,6 +421,26 @@ def test_c4_size_single_rank_properties(gpu_required):
     assert np.abs(R - p.true_base_R).max() < 1e-8 and np.abs(t - p.true_base_t).max() < 1e-7
 
 
+def test_c4_size_with_noise_matches_the_oracle_and_repeats_bit_for_bit(gpu_required):
+    """The c4 map WITH measurement noise and outliers (800 k measurements, 2994-unknown reduced system, 94 block steps): the first LM
+    iterations against the oracle (Schur path of oracle/ba_baseline.inc, one thread: the same numbers as the oracle proper to 1e-12) --
+    same accept / reject sequence, chi2, lambda, state -- and a second GPU run identical to the first bit for bit."""
+    from mcptam_amd import synth
+    p = synth.make_config("c4")
+    iters = 2
+    a = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    b = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    assert a["logs"] == b["logs"] and np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["X"], b["X"])
+    o = _orc(p.cams); o.DisableConvergence(True); o.SetSolver(2, 1)
+    ref = run_bundle(o, p, iters)
+    assert [l["trials"] for l in a["logs"]] == [l["trials"] for l in ref["logs"]] and [l["accepted"] for l in a["logs"]] == [l["accepted"] for l in ref["logs"]]
+    for x, y in zip(a["logs"], ref["logs"]):
+        assert abs(x["chi2_end"] - y["chi2_end"]) <= 1e-9*abs(y["chi2_end"]) and abs(x["lambda_end"] - y["lambda_end"]) <= 1e-9*y["lambda_end"]
+        assert abs(x["sigma_sq"] - y["sigma_sq"]) <= 1e-9*y["sigma_sq"]
+    assert rel_err(a["R"], ref["R"]) < 1e-6 and rel_err(a["t"], ref["t"]) < 1e-6 and rel_err(a["X"], ref["X"]) < 1e-6
+    assert a["outliers"] == ref["outliers"]
+
+
 def test_native_rccl_communicator_single_rank(gpu_required):
     import os
     import socket
