@@ -516,9 +516,14 @@ class TrackFrame:
         bfw = _pose12(*base_from_world).copy()
         nl = np.ascontiguousarray(nonlinear, dtype=np.uint8)
         ov = np.ascontiguousarray(override_sigma, dtype=np.float64)
-        _chk(lib().mcp_track_frame(n, self.hs, ip, st, int(on_device), None, ctypes.cast(self.cs, ctypes.c_void_p), bfw.ctypes.data, self.cfb.ctypes.data, self.ns, self.ins,
-                                   self.kp, self.sp, int(rng), int(subpix_its), int(exhaustive), len(nl), nl.ctypes.data, ov.ctypes.data, MEST[estimator],
-                                   self.ops, self.pts.ctypes.data if want_points else None, self.mu.ctypes.data, self.w.ctypes.data), "track_frame")
+        import time as _time
+        fn = lib().mcp_track_frame
+        t0 = _time.perf_counter()
+        rc = fn(n, self.hs, ip, st, int(on_device), None, ctypes.cast(self.cs, ctypes.c_void_p), bfw.ctypes.data, self.cfb.ctypes.data, self.ns, self.ins,
+                self.kp, self.sp, int(rng), int(subpix_its), int(exhaustive), len(nl), nl.ctypes.data, ov.ctypes.data, MEST[estimator],
+                self.ops, self.pts.ctypes.data if want_points else None, self.mu.ctypes.data, self.w.ctypes.data)
+        self.abi_seconds = _time.perf_counter() - t0          # the C call alone: what a native caller pays for the frame
+        _chk(rc, "track_frame")
         outs = [self.whole[self.offs[c]:self.offs[c + 1]] for c in range(n)]
         return outs, (self.pts[:self.total] if want_points else None), (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), self.mu.copy(), self.w[:self.total]
 
