@@ -165,7 +165,7 @@ static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const
     glare = glare || k->prm.glare_masking;
     maxtiles = std::max(maxtiles, ((C.w + PYR_T - 1)/PYR_T)*((C.h + PYR_T - 1)/PYR_T)); maxh = std::max(maxh, C.h);
   }
-  hipLaunchKernelGGL(k_pyr_fast, dim3(maxtiles, ncam), dim3(256), 0, st, B);
+  hipLaunchKernelGGL(k_pyr_fast, dim3(maxtiles, ncam), dim3(PYR_NT), 0, st, B);
   if (glare) for (int c = 0; c < ncam; ++c) {        // cv::dilate x5 of every level image, KeyFrame.cc:214-238 (needs the level images: after k_pyr_fast)
     mcp_kf* k = kfs[c];
     if (!k->prm.glare_masking) continue;

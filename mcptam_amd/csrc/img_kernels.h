@@ -157,6 +157,11 @@ __device__ inline int knee_threshold(const int* hist, int w, int h) {
 // k_row_count    threshold from the histogram knee (or the fixed one), kept corners per image row (one wavefront per row).
 // k_row_compact  exclusive prefix over the rows = vCornerRowLUT; the row's corners are written in x order at that offset, so
 //                vCorners comes out in raster order exactly as fast_corner_detect_10 + the filter loop produce it.
+#ifndef PYR_NT
+#define PYR_NT 512                        // threads per tile workgroup: a tile's phases are latency chains of one workgroup (load 15 k, half-samples 7 k, level-0
+                                          // detection 23 k cycles with 256 threads), and the c3 frame has 1.25 tiles per compute unit -- 256: 34.0 / 78.2 us
+                                          // per launch at c3 / c5, 512: 26.7 / 72.5, 1024: 24.7 / 79.0
+#endif
 constexpr int PYR_T = 64;                 // level-0 tile edge
 constexpr int PYR_A = 24;                 // level-0 apron = 3 << (MCP_LEVELS - 1)
 constexpr int PYR_R = PYR_T + 2*PYR_A;    // 112: staged region edge at level 0 (56, 28, 14 above)
@@ -171,7 +176,7 @@ struct FrameCam {             // one camera of a frame: everything the three ker
 };
 struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; int detect_t[MCP_LEVELS]; };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PYR_NT)
 k_pyr_fast(const FrameBatch B) {
   const FrameCam& C = B.c[blockIdx.y];
   const int ntx = (C.w + PYR_T - 1)/PYR_T, nty = (C.h + PYR_T - 1)/PYR_T;
@@ -191,7 +196,7 @@ k_pyr_fast(const FrameBatch B) {
   {
     const int ox = tx*PYR_T - PYR_A, oy = ty*PYR_T - PYR_A;
     const bool al = ((((uintptr_t)C.src) | (uintptr_t)C.src_stride) & 3) == 0;
-    for (int i = tid; i < PYR_R*(PYR_R/4); i += 256) {
+    for (int i = tid; i < PYR_R*(PYR_R/4); i += PYR_NT) {
       const int ry = i/(PYR_R/4), rx = (i % (PYR_R/4))*4, gy = oy + ry, gx = ox + rx;
       uint32_t v = 0;
       if (gy >= 0 && gy < C.h && gx + 3 >= 0 && gx < C.w) {
@@ -211,7 +216,7 @@ k_pyr_fast(const FrameBatch B) {
   for (int l = 1; l < MCP_LEVELS; ++l) {
     const int n = PYR_R >> l, wl = C.w >> l, hl = C.h >> l, ox = (tx*PYR_T - PYR_A) >> l, oy = (ty*PYR_T - PYR_A) >> l;     // arithmetic shift: the origin is a multiple of 8
     const uint8_t* in = reg[l - 1]; uint8_t* out = reg[l]; const int ni = n*2;
-    for (int i = tid; i < n*n; i += 256) {
+    for (int i = tid; i < n*n; i += PYR_NT) {
       const int y = i / n, x = i % n, gx = ox + x, gy = oy + y;
       int v = 0;
       if (gx >= 0 && gx < wl && gy >= 0 && gy < hl) {
@@ -233,7 +238,7 @@ k_pyr_fast(const FrameBatch B) {
     // scoring inside this loop would make a whole wavefront pay for fast10_score whenever one of its 64 pixels is a corner
     if (tid == 0) qn = 0;
     __syncthreads();
-    for (int i = tid; i < t*t; i += 256) {
+    for (int i = tid; i < t*t; i += PYR_NT) {
       const int ly = i / t, lx = i % t, gx = gx0 + lx, gy = gy0 + ly;
       if (gx >= wl || gy >= hl) continue;
       const uint8_t* p = R + (a + ly)*n + a + lx;
@@ -250,7 +255,7 @@ k_pyr_fast(const FrameBatch B) {
     }
     __syncthreads();
     const int nq = qn;
-    for (int j = tid; j < nq; j += 256) {
+    for (int j = tid; j < nq; j += PYR_NT) {
       const int i = queue[j], ly = i / t, lx = i % t;
       const uint8_t* p = R + (a + ly)*n + a + lx;
       int r[16]; fast_ring(p, n, r);
