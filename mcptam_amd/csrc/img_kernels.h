@@ -1417,12 +1417,15 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
 
 
 // ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
-// One workgroup of 256 threads = one wavefront per SIMD, so a thread may keep 512 registers: its four points' found position,
+// One workgroup of 512 threads = two wavefronts per SIMD at up to 256 registers each: a thread's two points' found position,
 // noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips
-// inside an iteration (world position and camera model are re-read only by the re-projecting iterations), four-wavefront barriers,
+// inside an iteration (world position and camera model are re-read only by the re-projecting iterations), eight-wavefront barriers,
 // the Tukey median selected from the register-held squared errors.  Same arithmetic per point as k_pose_refine; the order of the
-// 27 sums differs (4 points per thread, 4 wavefronts), i.e. results agree to rounding, the median exactly.
-constexpr int PRR_THREADS = 256, PRR_PPT = 4;
+// 27 sums differs (PRR_PPT points per thread, PRR_THREADS/64 wavefronts), i.e. results agree to rounding, the median exactly.
+#ifndef PRR_NT
+#define PRR_NT 512      // threads; 1024/PRR_NT points each.  256 x 4: 125.8 us per ten iterations at c3 (one wavefront per SIMD, 512 registers), 512 x 2: 102.4
+#endif                  // (two wavefronts per SIMD at 255 registers overlap each other's latencies), 1024 x 1: 176.7 (eight-wavefront barriers, spills)
+constexpr int PRR_THREADS = PRR_NT, PRR_PPT = 1024/PRR_NT;
 #ifdef MCP_PRR_PROF
 __device__ unsigned long long g_prr_prof[16*8];
 #define PRR_STAMP(i) do { if (threadIdx.x == 0 && it < 16) g_prr_prof[it*8 + (i)] = clock64(); } while (0)
