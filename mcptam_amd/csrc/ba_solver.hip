@@ -329,6 +329,7 @@ struct mcp_ba {
   DevBuf<double> d_sxp[MAX_SYS], d_sxl[MAX_SYS], d_sp0[MAX_SYS], d_sp1[MAX_SYS], d_sp2[MAX_SYS];
   bool pre_run[MAX_SYS] = {false, false, false, false}, ahead_enq[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
   hipEvent_t ev_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_wf[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};      // trial q evaluated ahead: its last reader of the linearisation (k_backsub) is through
   // MCP_BA_SPEC_TRIALS: 0 = trials strictly in sequence; 1 (default) = one trial ahead on the stream that solved it; 2 = the steps
   // of ALL speculatively solved systems are applied and evaluated as soon as their solutions exist, each on its own stream
   // (st_tr[q], behind the speculative chain's event).  Measured, same box and run: 819 / 835 it/s (1) vs 733 / 743 (2) -- three
@@ -420,6 +421,7 @@ struct mcp_ba {
     if (ev_spec) (void)hipEventDestroy(ev_spec);
     if (ev_spec3) (void)hipEventDestroy(ev_spec3);
     for (int q = 0; q < MAX_SYS; ++q) if (ev_tr[q]) (void)hipEventDestroy(ev_tr[q]);
+    for (int q = 0; q < MAX_SYS; ++q) if (ev_wf[q]) (void)hipEventDestroy(ev_wf[q]);
     if (st && !pooled) (void)hipStreamDestroy(st);
   }
   // everything the second stream still has in flight reads the current linearisation (W, V, g, staged blocks): the main stream
@@ -435,6 +437,18 @@ struct mcp_ba {
     return 0;
   }
 
+  // What linearize() needs of that join: nobody may still READ the linearisation it is about to overwrite (W, V, g, staged blocks).  The
+  // speculative chains are done reading it once their systems are built (ev_spec covers their whole chain); of a trial evaluated ahead
+  // only the pose update and the point back-substitution read it -- its chain transforms, residuals and final sums (45 of its 70 us)
+  // may run beside the linearisation.  The trial's remaining kernels stay registered (ahead_enq): the fresh solve of the iteration
+  // joins them before anything reuses the candidate states (solve_trial).
+  int join_spec_lin() {
+    if (spec_pending) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
+    if (spec3_pending) { HIPCK(hipStreamWaitEvent(st, ev_spec3, 0)); spec3_pending = false; }
+    for (int k = 0; k < MAX_SYS; ++k) if (ahead_enq[k]) HIPCK(hipStreamWaitEvent(st, ev_wf[k], 0));
+    return 0;
+  }
+
   double* Ubig() { return nbig ? d_ubig.p : nullptr; }
   double* bp() { return rhs() + np; }            // J^T r of the current linearisation (written by k_assemble behind every system's rhs)
   // multi-lambda batch (ba_kernels.h SysBatch): systems 1.. are speculative solves for the next lambdas of the LM
@@ -443,6 +457,7 @@ struct mcp_ba {
   bool start_rides = false;        // the iteration-start chi2 still has to be summed over the ranks
   int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
   int speculate = 3;                 // speculative systems per solve at most; MCP_BA_SPECULATE=0 turns them off
+  int lin_join_full = 0;             // MCP_BA_LIN_JOIN=1: linearize() waits for everything the speculative stream has in flight (round 2's behaviour)
   int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
   hipGraphExec_t chol_exec[MAX_SYS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t chain_exec[MAX_SYS + 1][MAX_SYS] = {};      // [systems][first system]: factorisation + back-substitution of a sub-batch, captured once
@@ -1356,6 +1371,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
   red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
+  { const char* e = getenv("MCP_BA_LIN_JOIN"); if (e) lin_join_full = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (multi()) {
@@ -1581,6 +1597,7 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, s, P, lam, (const double*)rhsq, (const double*)d_g.p, (const double*)d_W.p,
                               (const double*)(d_Vinv.p + q*vinv_stride), (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
+  HIPCK(hipEventRecord(ev_wf[q], s));                     // the linearisation's outputs are not read below this line (join_spec_lin)
   if (P.nchain) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
@@ -1625,7 +1642,7 @@ int mcp_ba::read_results(int count) {
 // buildSystem at the current state (sigma block must be current)
 int mcp_ba::linearize() {
   mark("lin_wait", st);
-  if (join_spec()) return -1;        // the second stream may still be reading the previous linearisation
+  if ((lin_join_full ? join_spec() : join_spec_lin())) return -1;        // the second stream may still be reading the previous linearisation
   mark("lin_go", st);
   spec_ok = false;                   // a speculative solve belongs to the linearisation it was built from
   tic(ST_LIN);
@@ -2179,7 +2196,8 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_SPEC_DELAY"); if (e) h->spec_delay = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_RIDE"); if (e) h->sel_ride = atoi(e); }
   { const char* e = getenv("MCP_BA_TIMEOUT_MS"); if (e && atof(e) > 0) h->timeout_ms = atof(e); }
-  for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
+  for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess ||
+                                              hipEventCreateWithFlags(&h->ev_wf[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
   // (the runtime multiplexes streams onto a handful of hardware queues -- GPU_MAX_HW_QUEUES, 4 by default: main, speculative and two
   // trial streams use them up; a third stream for MCP_BA_OVERLAP=2 is only created when asked for)
   if (h->pooled) {
