@@ -845,7 +845,8 @@ def test_bench_two_rank_path_end_to_end(gpu_required):
 
 
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
-                                 dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2")])
+                                 dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
+                                 dict(MCP_BA_STREAM_POOL="0")])
 def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
     """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox and graph replay are
     scheduling: the same kernels see the same inputs whichever of them is on, so iteration logs, poses and points are identical
