@@ -108,6 +108,14 @@ def init_rccl_comm(rank, world_size, device_index):
     (already initialised) torch.distributed default group; every rank then joins on its device."""
     import torch.distributed as dist
     from .chain_bundle import Comm, comm_unique_id
-    box = [comm_unique_id() if rank == 0 else None]
+    uid, err = None, None
+    if rank == 0:
+        try:
+            uid = comm_unique_id()
+        except Exception as exc:          # (the other ranks are waiting in the broadcast: tell them instead of leaving them there)
+            err = repr(exc)
+    box = [uid, err]
     dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        raise RuntimeError("rank 0 could not create the RCCL unique id: %s" % (box[1],))
     return Comm(box[0], rank, world_size, device_index)
