@@ -74,30 +74,41 @@ __device__ inline void sel_find_bin(const double* __restrict__ hist, int nbins, 
   __syncthreads();
 }
 
-// 1024 threads, one digit histogram of SEL_BINS counters in LDS: the bin holding rank k, the rank inside it and the bin's count
-// (uniform on return).  sc: 1024/64 + 3 words.
-__device__ inline void lds_find_bin_1024(const unsigned int* hist, unsigned long long k, int& bin, unsigned long long& k_in, unsigned int& in_bin,
-                                         unsigned long long* sc) {
+// NT threads (a divisor of SEL_BINS), one digit histogram of SEL_BINS counters in LDS: the bin holding rank k, the rank inside it and the
+// bin's count (uniform on return).  sc: NT/64 + 3 words.
+template <int NT>
+__device__ inline void lds_find_bin(const unsigned int* hist, unsigned long long k, int& bin, unsigned long long& k_in, unsigned int& in_bin,
+                                    unsigned long long* sc) {
+  constexpr int BPT = SEL_BINS/NT;
+  static_assert(BPT*NT == SEL_BINS && BPT >= 1, "threads must divide the bins");
   const int t = threadIdx.x;
-  const unsigned int h0 = hist[2*t], h1 = hist[2*t + 1];
+  unsigned int h[BPT]; unsigned long long loc = 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) { h[q] = hist[BPT*t + q]; loc += h[q]; }
   int tt; unsigned long long acc;
-  block_find_rank<1024>((unsigned long long)h0 + h1, k, tt, acc, sc);
+  block_find_rank<NT>(loc, k, tt, acc, sc);
   if (t == tt) {
-    int b = 2*t;
-    if (!(acc + h0 > k)) { acc += h0; b = 2*t + 1; }
-    sc[0] = (unsigned long long)b; sc[1] = k - acc; sc[2] = (b & 1) ? h1 : h0;
+    int b = 0;
+#pragma unroll
+    for (int q = 0; q < BPT - 1; ++q) if (b == q && !(acc + h[q] > k)) { acc += h[q]; b = q + 1; }
+    unsigned int inb = h[0];
+#pragma unroll
+    for (int q = 1; q < BPT; ++q) if (b == q) inb = h[q];
+    sc[0] = (unsigned long long)(BPT*t + b); sc[1] = k - acc; sc[2] = inb;
   }
   __syncthreads();
   bin = (int)sc[0]; k_in = sc[1]; in_bin = (unsigned int)sc[2];
   __syncthreads();
 }
+__device__ inline void lds_find_bin_1024(const unsigned int* hist, unsigned long long k, int& bin, unsigned long long& k_in, unsigned int& in_bin,
+                                         unsigned long long* sc) { lds_find_bin<1024>(hist, k, bin, k_in, in_bin, sc); }
 
-// One workgroup of 1024 threads: the rank-k element (bit pattern) among the keys keyfn(i, key) yields for i in [0, m), continuing
+// One workgroup of NT threads: the rank-k element (bit pattern) among the keys keyfn(i, key) yields for i in [0, m), continuing
 // a most-significant-digit radix select at digit `pass0` with the bits above it fixed to `prefix0`.  Digit histograms live in
 // LDS; the bin search is a parallel scan; as soon as the selected bin holds a single key, that key is the answer and its
-// remaining bits are read off directly.  hist: SEL_BINS counters, sc: 1024/64 + 3 words, st: 2 words (all LDS).  Uniform result.
-template <class KeyFn>
-__device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long long k, int pass0, unsigned long long prefix0, KeyFn keyfn,
+// remaining bits are read off directly.  hist: SEL_BINS counters, sc: NT/64 + 3 words, st: 2 words (all LDS).  Uniform result.
+template <int NT, class KeyFn>
+__device__ inline unsigned long long lds_radix_select(int m, unsigned long long k, int pass0, unsigned long long prefix0, KeyFn keyfn,
                                                            unsigned int* hist, unsigned long long* sc, unsigned long long* st) {
   const int t = threadIdx.x;
   if (t == 0) { st[0] = prefix0; st[1] = k; }
@@ -106,21 +117,21 @@ __device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long 
     const int sh = sel_shift(pass);
     const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
     const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
-    for (int b = t; b < SEL_BINS; b += 1024) hist[b] = 0u;
+    for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;
     __syncthreads();
     const unsigned long long prefix = st[0];
-    for (int i = t; i < m; i += 1024) {
+    for (int i = t; i < m; i += NT) {
       unsigned long long key;
       if (!keyfn(i, key)) continue;
       if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> sh) & dmask], 1u);
     }
     __syncthreads();
     int bin; unsigned long long kin; unsigned int in_bin;
-    lds_find_bin_1024(hist, st[1], bin, kin, in_bin, sc);
+    lds_find_bin<NT>(hist, st[1], bin, kin, in_bin, sc);
     const unsigned long long np_ = prefix | ((unsigned long long)bin << sh);
     if (in_bin == 1u && sh > 0) {
       const unsigned long long hm2 = ~0ull << sh;
-      for (int i = t; i < m; i += 1024) {
+      for (int i = t; i < m; i += NT) {
         unsigned long long key;
         if (!keyfn(i, key)) continue;
         if ((key & hm2) == np_) st[0] = key;
@@ -134,6 +145,11 @@ __device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long 
   const unsigned long long r = st[0];
   __syncthreads();
   return r;
+}
+template <class KeyFn>
+__device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long long k, int pass0, unsigned long long prefix0, KeyFn keyfn,
+                                                           unsigned int* hist, unsigned long long* sc, unsigned long long* st) {
+  return lds_radix_select<1024>(m, k, pass0, prefix0, keyfn, hist, sc, st);
 }
 
 // pass kernel: derive state[pass] from state[pass-1] and hist[pass-1], then histogram digit `pass`

@@ -1185,7 +1185,10 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
 // MI355X_MICROARCH.md "Workgroup dispatch ..."); the barrier is one monotonic counter: drain own stores, add, poll.  Every buffer
 // is per (iteration, digit), zeroed by the host once per call: no reuse, no reset races.  A spin that exceeds its bound raises
 // an error word that ends every later wait (the call then fails; nothing hangs).
-constexpr int PRM_THREADS = 1024, PRM_MAX_WG = 64, PRM_CAND_CAP = 4096, PRM_MAX_ITER = 16;
+#ifndef PRM_NT
+#define PRM_NT 512       // threads per workgroup: 1024 (four wavefronts per SIMD, 128 registers, 216 B of scratch) 0.744 ms per c5 frame, 512 (two per
+#endif                   // SIMD, no spills) 0.671, 256 0.706 -- each with 512 points per workgroup
+constexpr int PRM_THREADS = PRM_NT, PRM_MAX_WG = 64, PRM_CAND_CAP = 4096, PRM_MAX_ITER = 16;
 struct PrmScratch {           // device memory, zeroed before the launch
   unsigned int sync;          // barrier counter
   unsigned int err;           // a wait gave up
@@ -1282,7 +1285,7 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
       prm_barrier(G, epoch, nwg);
       for (int i = t; i < n; i += PRM_THREADS) sh_e2[i] = prm_ldd(eb + i);
       __syncthreads();
-      const unsigned long long sel = lds_radix_select_1024(n, (unsigned long long)(nf/2), 0, 0ull, [&](int i, unsigned long long& key) {
+      const unsigned long long sel = lds_radix_select<PRM_THREADS>(n, (unsigned long long)(nf/2), 0, 0ull, [&](int i, unsigned long long& key) {
         const double v = sh_e2[i];
         if (v < 0.0) return false;
         key = (unsigned long long)__double_as_longlong(v);
@@ -1310,7 +1313,7 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
         for (int b = t; b < SEL_BINS; b += PRM_THREADS) hist[b] = prm_ld(gh + b);
         __syncthreads();
         int bin; unsigned long long kin; unsigned int in_bin;
-        lds_find_bin_1024(hist, kk, bin, kin, in_bin, sel_sc);
+        lds_find_bin<PRM_THREADS>(hist, kk, bin, kin, in_bin, sel_sc);
         prefix |= (unsigned long long)bin << sh; kk = kin;
         if (sh == 0) { done = true; break; }
         if (in_bin <= (unsigned int)PRM_CAND_CAP) {
@@ -1327,7 +1330,7 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
           prm_barrier(G, epoch, nwg);
           const int m = (int)min(prm_ld(&G->cand_n[it]), (unsigned int)PRM_CAND_CAP);
           const double* cd = G->cand[it];
-          prefix = lds_radix_select_1024(m, kk, pass + 1, prefix, [&](int i, unsigned long long& key) {
+          prefix = lds_radix_select<PRM_THREADS>(m, kk, pass + 1, prefix, [&](int i, unsigned long long& key) {
             key = (unsigned long long)__double_as_longlong(prm_ldd(cd + i));
             return true; }, hist, sel_sc, sel_st);
           done = true;
