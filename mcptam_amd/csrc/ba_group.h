@@ -568,7 +568,10 @@ struct AsmPlan {
   const int* po_start;            // [nfp+1] staged rhs rows of the pose, ascending group
 };
 
-__global__ void __launch_bounds__(256)
+#ifndef ASM_NT
+#define ASM_NT 1024      // one entry of the 32 x 32 tile per thread: every entry's walk over its staged contributions is a chain of memory round trips,
+#endif                   // and four times the threads have four times the walks in flight (256: 810-813, 512: 804-821, 1024: 822-825 it/s)
+__global__ void __launch_bounds__(ASM_NT)
 k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ stb,
            const double* __restrict__ stS, const double* __restrict__ str,
            const double* __restrict__ Ubig /* dense np x np + np contributions of the points outside the groups, or null */,
@@ -579,7 +582,7 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
   const int packed = A.tiles[blockIdx.x];
   const int ti = packed >> 16, tj = packed & 0xffff;
   const size_t n2 = (size_t)np*np;
-  for (int e = threadIdx.x; e < 1024; e += 256) {
+  for (int e = threadIdx.x; e < 1024; e += ASM_NT) {
     const int row = 32*ti + (e >> 5), col = 32*tj + (e & 31);
     if (col >= np || row > np) continue;
     if (row == np) {                       // right-hand side (row n of the augmented matrix) and, behind it, the plain J^T r

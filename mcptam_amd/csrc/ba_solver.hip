@@ -1693,7 +1693,7 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
     HIPCK(hipMemsetAsync(stSq, 0, (size_t)nsys*nstage*36*sizeof(double), s));
     HIPCK(hipMemsetAsync(strq, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), s));
   }
-  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(256), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
+  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(ASM_NT), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
                              (const double*)stSq, (const double*)strq, (const double*)Ubig(), Sq, sb);
   if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, s, P, 1, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, Sq, Sq + (size_t)np*np, failq, sb);
   if (main_stream) toc();
