@@ -196,6 +196,12 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x);
  * batched launch chain, `reps` times from the same device-resident input; x (nsys*n) receives the first repetition's
  * solutions and *n_mismatch the number of later repetitions whose solutions differ from it in any bit. */
 int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int reps, double* x, int* n_mismatch);
+/* the one-launch factorisation (ba_chol2.h) seen from outside: L (n*n row-major, lower; its diagonal 32x32 BLOCKS hold
+ * L_kk^-1, which is what the kernels keep), y = L^-1 b (n), info[0] = hand-off error word, info[1] = failure flag */
+int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out, double* y_out, int* info);
+/* device time (HIP events, ms per solve, first repetition left out) of the factorisation and the back-substitution launches
+ * for (A + q I) x_q = b, q < nsys; band > 0: banded + bordered tile plan (i - j <= band, last `band` block rows dense) */
+int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, int band, double* ms_factor, double* ms_back, double* x);
 /* the reduced pose system the solver would factor at the current state for `lambda`: S (np*np, row-major, lower
  * triangle meaningful inside the tiles of the factorisation plan, other entries 0), rhs (np) and J^T r (np) behind it;
  * np = 6 * free poses.  Returns np (buffers may be NULL to query it), < 0 on error. */

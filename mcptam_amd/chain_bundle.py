@@ -56,7 +56,7 @@ BA_SYMBOLS = [
     "mcp_ba_num_outliers", "mcp_ba_get_outliers", "mcp_ba_sigma_squared", "mcp_ba_mean_chi_squared", "mcp_ba_max_cov",
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
-    "mcp_dense_spd_stress", "mcp_ba_debug_system",
+    "mcp_dense_spd_stress", "mcp_ba_debug_system", "mcp_chol_debug_factor", "mcp_chol_time",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce", "mcp_comm_allreduce_lane",
 ]
 
@@ -97,6 +97,8 @@ def lib():
     L.mcp_ba_robust_chi2.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.mcp_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_dense_spd_solve.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p]
+    L.mcp_chol_debug_factor.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int)]
+    L.mcp_chol_time.argtypes = [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p]
     L.mcp_dense_spd_stress.argtypes = [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_int)]
     L.mcp_ba_debug_system.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_comm_unique_id.argtypes = [ctypes.c_void_p]
@@ -166,6 +168,30 @@ def dense_spd_solve(A, b):
     if lib().mcp_dense_spd_solve(_dp(A), A.shape[0], _dp(b), _dp(x)) != 0:
         raise RuntimeError("mcp_dense_spd_solve failed: " + last_error())
     return x
+
+
+def chol_debug_factor(A, b):
+    """The one-launch factorisation seen from outside (test hook): (L with L_kk^-1 in its diagonal 32x32 blocks, y = L^-1 b,
+    hand-off error word, failure flag)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = A.shape[0]
+    L = np.zeros((n, n)); y = np.zeros(n)
+    info = (ctypes.c_int * 2)(0, 0)
+    if lib().mcp_chol_debug_factor(_dp(A), n, _dp(b), _dp(L), _dp(y), info) != 0:
+        raise RuntimeError("mcp_chol_debug_factor failed: " + last_error())
+    return L, y, info[0], info[1]
+
+
+def chol_time(A, b, nsys=1, reps=20, band=0):
+    """Device milliseconds per solve of the factorisation and the back-substitution launches (tuning hook) and the solutions."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros((nsys, A.shape[0]))
+    tf = ctypes.c_double(0); tb = ctypes.c_double(0)
+    if lib().mcp_chol_time(_dp(A), A.shape[0], _dp(b), int(nsys), int(reps), int(band), ctypes.byref(tf), ctypes.byref(tb), _dp(x)) != 0:
+        raise RuntimeError("mcp_chol_time failed: " + last_error())
+    return tf.value, tb.value, x
 
 
 def dense_spd_stress(A, b, nsys=1, reps=10):

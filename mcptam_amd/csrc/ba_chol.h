@@ -491,6 +491,10 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
   for (int i = t; i < n; i += CH_BACK_THREADS) xout[i] = xs[i];
 }
 
+}  // namespace mcp
+#include "ba_chol2.h"
+namespace mcp {
+
 // Block-sparse execution plan (the job CHOLMOD's symbolic analysis does for the reference): which 32x32 tiles
 // of the lower triangle are structurally non-zero after fill-in, in the given (natural) pose order.
 struct CholPlan {
@@ -501,6 +505,8 @@ struct CholPlan {
   int* d_all_tiles = nullptr;
   int* d_step_tiles = nullptr; int* d_row_start = nullptr; int* d_row_tiles = nullptr;
   double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
+  // the one-launch factorisation + chain back-substitution of ba_chol2.h (MCP_BA_CHOL_PERSIST=0: the per-step kernels below)
+  mutable CholPersist persist; bool use_persist = false;
   ~CholPlan() { release(); }
   void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
                    if (d_diag) (void)hipFree(d_diag);
@@ -548,6 +554,8 @@ struct CholPlan {
     if (!row_tiles.empty() && hipMemcpy(d_row_tiles, row_tiles.data(), sizeof(int)*row_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (hipMalloc((void**)&d_all_tiles, sizeof(int)*std::max<size_t>(all_tiles.size(), 1)) != hipSuccess) return -1;
     if (!all_tiles.empty() && hipMemcpy(d_all_tiles, all_tiles.data(), sizeof(int)*all_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    { const char* e = getenv("MCP_BA_CHOL_PERSIST"); use_persist = !(e && atoi(e) == 0); }
+    if (use_persist && persist.build(n, pattern, pattern.empty() ? std::vector<int>() : all_tiles)) return -1;
     return 0;
   }
   size_t tile_updates() const { return step_tiles.size(); }
@@ -557,6 +565,7 @@ struct CholPlan {
 // nsys > 1 factors further systems stored q*sys_stride doubles behind the first in the same launches (fail[q] is their flag)
 // q0: index of the first of the nsys systems inside the batch buffers (S, fail and the diagonal side array are offset by it)
 inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
+  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_factor(st, plan.persist, S, fail, nsys, sys_stride, q0); return; }
   const int n = plan.n, nrows = n + 1;
   S += q0*sys_stride; fail += q0;
   double* dg = plan.d_diag + q0*plan.diag_stride;
@@ -567,6 +576,7 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
 }
 // row n: y -> x = L^-T y
 inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
+  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0); return; }
   const int n = plan.n;
   S += q0*sys_stride;
   const double* dg = plan.d_diag + q0*plan.diag_stride;

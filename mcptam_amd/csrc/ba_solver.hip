@@ -2500,10 +2500,103 @@ int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int 
     HIPCK(hipMemcpyAsync(fl, f.p, 16, hipMemcpyDeviceToHost, nullptr));
     HIPCK(hipStreamSynchronize(nullptr));
     for (int q = 0; q < nsys; ++q) if (fl[q]) { set_err("mcp_dense_spd_stress: matrix not positive definite"); return -1; }
+    if (plan.use_persist && plan.persist.ok) {
+      int ew[4] = {0, 0, 0, 0}; HIPCK(hipMemcpy(ew, plan.persist.d_err, 16, hipMemcpyDeviceToHost));
+      for (int q = 0; q < nsys; ++q) if (ew[q]) { char m[112]; std::snprintf(m, sizeof m, "mcp_dense_spd_stress: a hand-off of the one-launch factorisation timed out (system %d, code 0x%x, repetition %d)", q, ew[q], rep); set_err(m); return -3; }
+    }
     if (rep && std::memcmp(first.data(), cur.data(), first.size()*8) != 0) ++bad;
   }
   std::memcpy(x, first.data(), first.size()*8);
   if (n_mismatch) *n_mismatch = bad;
+  return 0;
+}
+
+// the one-launch factorisation of ba_chol2.h looked at from outside (test hook): L (n x n, row-major, lower triangle; the
+// diagonal BLOCKS hold L_kk^-1, which is what the kernels keep) and y = L^-1 b; info[0] = error word, info[1] = failure flag
+int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out, double* y_out, int* info) {
+  if (n <= 0 || n > CH_SOLVE_MAX) { set_err("mcp_chol_debug_factor: bad n"); return -1; }
+  DevBuf<double> d; DevBuf<int> f;
+  if (d.alloc((size_t)n*n + n) || f.alloc(4)) return -1;
+  HIPCK(hipMemcpy(d.p, A, (size_t)n*n*8, hipMemcpyHostToDevice));
+  HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
+  HIPCK(hipMemset(f.p, 0, 16));
+  CholPlan plan;
+  if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_chol_debug_factor: plan allocation failed"); return -1; }
+  CholPersist& P = plan.persist;
+  if (!plan.use_persist || !P.ok) { set_err("mcp_chol_debug_factor: the persistent factorisation is switched off"); return -1; }
+  if (chol_persist_factor(nullptr, P, d.p, f.p, 1, 0, 0)) { set_err("mcp_chol_debug_factor: launch failed"); return -1; }
+  HIPCK(hipDeviceSynchronize());
+  std::vector<double> lt(P.lt_stride);
+  HIPCK(hipMemcpy(lt.data(), P.d_Lt, P.lt_stride*8, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(info, P.d_err, 4, hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(info + 1, f.p, 4, hipMemcpyDeviceToHost));
+  HIPCK(hipMemset(P.d_err, 0, 4));
+  const int ntc = P.ntc;
+  auto at = [&](int slot, int r, int c) {
+    const int qd = (r >> 4)*2 + (c >> 4), ri = r & 15;
+    return lt[(size_t)slot*CP_TQ + (qd*64 + ((ri & 3) << 4 | (c & 15)))*4 + (ri >> 2)];
+  };
+  std::memset(L_out, 0, (size_t)n*n*8);
+  for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) {
+    const int sl = P.slot_of[(size_t)i*ntc + j];
+    if (sl < 0) continue;
+    for (int r = 0; r < 32 && 32*i + r < n; ++r) for (int c = 0; c < 32 && 32*j + c < n; ++c) L_out[(size_t)(32*i + r)*n + 32*j + c] = at(sl, r, c);
+  }
+  for (int j = 0; j < ntc; ++j) { const int sl = P.slot_of[(size_t)ntc*ntc + j]; for (int c = 0; c < 32 && 32*j + c < n; ++c) y_out[32*j + c] = at(sl, 0, c); }
+  return 0;
+}
+
+// device time of the factorisation and of the back-substitution launches (test / tuning hook): `reps` solves of (A + q I) x = b,
+// q < nsys, from a device-resident copy; band > 0 restricts the plan to a banded + bordered tile pattern like a loop trajectory's
+// (tiles with i - j <= band, and the last `band` block rows dense; the matrix should have that structure then)
+int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, int band, double* ms_factor, double* ms_back, double* x) {
+  if (n <= 0 || n > CH_SOLVE_MAX || nsys < 1 || nsys > MAX_SYS || reps < 1) { set_err("mcp_chol_time: bad arguments"); return -1; }
+  const size_t stride = (size_t)n*n + n;
+  DevBuf<double> pristine, work; DevBuf<int> f;
+  if (pristine.alloc(stride*nsys) || work.alloc(stride*nsys) || f.alloc(4)) return -1;
+  {
+    std::vector<double> host(stride);
+    for (int q = 0; q < nsys; ++q) {
+      std::memcpy(host.data(), A, (size_t)n*n*8);
+      for (int i = 0; i < n; ++i) host[(size_t)i*n + i] += (double)q;
+      std::memcpy(host.data() + (size_t)n*n, b, (size_t)n*8);
+      HIPCK(hipMemcpy(pristine.p + q*stride, host.data(), stride*8, hipMemcpyHostToDevice));
+    }
+  }
+  CholPlan plan;
+  std::vector<unsigned char> pattern;
+  if (band > 0) {
+    const int ntc = (n + CH_NB - 1)/CH_NB;
+    pattern.assign((size_t)ntc*ntc, 0);
+    for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (i - j <= band || i >= ntc - band) pattern[(size_t)i*ntc + j] = 1;
+  }
+  if (plan.build(n, pattern)) { set_err("mcp_chol_time: plan allocation failed"); return -1; }
+  std::vector<hipEvent_t> ev((size_t)3*reps);
+  for (auto& e : ev) HIPCK(hipEventCreate(&e));
+  for (int rep = 0; rep < reps; ++rep) {
+    HIPCK(hipMemcpyAsync(work.p, pristine.p, stride*nsys*8, hipMemcpyDeviceToDevice, nullptr));
+    HIPCK(hipMemsetAsync(f.p, 0, 16, nullptr));
+    HIPCK(hipEventRecord(ev[3*rep], nullptr));
+    chol_factor(nullptr, plan, work.p, f.p, nsys, stride);
+    HIPCK(hipEventRecord(ev[3*rep + 1], nullptr));
+    chol_back(nullptr, plan, work.p, nsys, stride);
+    HIPCK(hipEventRecord(ev[3*rep + 2], nullptr));
+  }
+  HIPCK(hipStreamSynchronize(nullptr));
+  double tf = 0, tb = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    float a = 0, c = 0;
+    HIPCK(hipEventElapsedTime(&a, ev[3*rep], ev[3*rep + 1])); HIPCK(hipEventElapsedTime(&c, ev[3*rep + 1], ev[3*rep + 2]));
+    if (rep > 0 || reps == 1) { tf += a; tb += c; }
+  }
+  const int cnt = std::max(1, reps - 1);
+  *ms_factor = tf/cnt; *ms_back = tb/cnt;
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (int q = 0; q < nsys; ++q) HIPCK(hipMemcpy(x + (size_t)q*n, work.p + q*stride + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
+  if (plan.use_persist && plan.persist.ok) {
+    int ew[4] = {0, 0, 0, 0}; HIPCK(hipMemcpy(ew, plan.persist.d_err, 16, hipMemcpyDeviceToHost));
+    for (int q = 0; q < nsys; ++q) if (ew[q]) { char m[112]; std::snprintf(m, sizeof m, "mcp_chol_time: a hand-off of the one-launch factorisation timed out (system %d, code 0x%x)", q, ew[q]); set_err(m); return -3; }
+  }
   return 0;
 }
 
@@ -2571,6 +2664,10 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x) {
 #endif
   int fl = 0;
   HIPCK(hipMemcpy(&fl, f.p, 4, hipMemcpyDeviceToHost));
+  if (plan.use_persist && plan.persist.ok) {
+    int ew = 0; HIPCK(hipMemcpy(&ew, plan.persist.d_err, 4, hipMemcpyDeviceToHost));
+    if (ew) { char m[96]; std::snprintf(m, sizeof m, "mcp_dense_spd_solve: a hand-off of the one-launch factorisation timed out (code 0x%x)", ew); set_err(m); return -3; }
+  }
   HIPCK(hipMemcpy(x, d.p + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
   if (fl) { set_err("mcp_dense_spd_solve: matrix not positive definite"); return -1; }
   return 0;
