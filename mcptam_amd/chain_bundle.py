@@ -14,7 +14,7 @@ import numpy as np
 from .taylor_camera import camera_array
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcptam_hip.so")
+LIB_PATH = os.environ.get("MCP_HIP_LIB") or os.path.join(_HERE, "libmcptam_hip.so")      # MCP_HIP_LIB: a build variant (scripts/build_variants.sh)
 _LIB = None
 
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -38,21 +38,41 @@ constexpr unsigned CP_SPIN_MAX = 1u << 22;
 constexpr int CP_BACK_NEAR = 3;               // rows k+1 .. k+CP_BACK_NEAR of column k stay with the chain workgroup
 constexpr unsigned long long CP_SENT = 0xFFFDEADBEEF5A5A5ull;      // "not written yet" (a NaN payload arithmetic never yields)
 
-struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s; };      // kind: 0 far tile, 1 band tile
+struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
+// kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
+// index pre_flag), so that the band tiles of row i, whose last update needs L(i, i - CP_W), need not wait for this tile's own
+// publication: they redo the solve from that sum the moment L_jj^-1 appears (band tile: pre = that band slot, pre_diag = slot of
+// L_jj^-1, and the LAST entry of its update list is the one to be taken that way)
+// what the critical workgroup looks up per step, laid out for it by the host (copied to LDS once: a table look-up in global
+// memory is a round trip, and a waited-for load also waits for every load issued before it -- the band row fetched ahead)
+constexpr int CP_STEP_INTS = 12;
+enum { CPS_SD = 0, CPS_S1, CPS_S2, CPS_DL, CPS_F0, CPS_F1, CPS_F2, CPS_B0, CPS_B1, CPS_B2 };
 struct CpArgs {
   const double* S; size_t sys_stride; int n, ntc, nsys, nhelpers;
-  const int* slot_of; const int* bslot_of; const CpHelper* helpers; const int2* upd;
+  const int* slot_of; const int* bslot_of; const int* delta_of; const int* steps; const CpHelper* helpers; const int2* upd;
   double* Lt; size_t lt_stride;               // published L tiles / L_kk^-1, per system
   double* Bt; size_t bt_stride;               // band tiles handed to the critical workgroup, per system
-  int* flags; int nslots; int* err; int* fail; int epoch4;
+  int* flags; int nslots; int nflags; int* err; int* fail; const int* epoch;      // epoch[q]: bumped by the back-substitution launch (graph replay safe)
   double* xbuf; double* fbuf; int vec_stride;
 };
 struct CpBackArgs {
   const double* Lt; size_t lt_stride; const int* slot_of; int n, ntc, nsys, ncols;
   const int* far_start; const int* far_slot; const int* far_row;      // per block column: its far tiles, rows descending
-  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err;
+  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch;
 };
 
+#ifdef MCP_CP_PROF
+// phase stamps (100 MHz wall clock, the same on every compute unit) of system 0: critical workgroup [step + 1][16], helpers [index][4]
+__device__ unsigned long long g_cp_prof[256*16];
+__device__ unsigned long long g_cp_hprof[8192*4];
+// MCP_CP_PROF = 1: everything; 2: critical workgroup only; 3: step start / end only (0x101 mask); 4: wavefront 0's stamps only
+#define CP_STAMP_ON(i) (MCP_CP_PROF == 1 || MCP_CP_PROF == 2 || (MCP_CP_PROF == 3 && ((i) == 0 || (i) == 8)) || (MCP_CP_PROF == 4 && ((i) <= 2 || (i) >= 8 && (i) <= 10)))
+#define CP_STAMP(step, i) do { if (CP_STAMP_ON(i) && q == 0 && (step) + 1 < 256) g_cp_prof[((step) + 1)*16 + (i)] = wall_clock64(); } while (0)
+#define CP_HSTAMP(i) do { if (MCP_CP_PROF == 1 && q == 0 && hidx < 8192) g_cp_hprof[hidx*4 + (i)] = wall_clock64(); } while (0)
+#else
+#define CP_STAMP(step, i) do {} while (0)
+#define CP_HSTAMP(i) do {} while (0)
+#endif
 typedef unsigned int cp_u4 __attribute__((ext_vector_type(4)));
 typedef double (*cp_tile)[CP_LD];
 
@@ -75,12 +95,32 @@ __device__ inline void cp_st4(__amdgpu_buffer_rsrc_t r, unsigned off, const chol
 #define CP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 __device__ inline int cp_flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void cp_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a flag load that is ISSUED here (the compiler may not sink it to its use) and waited for by cp_flag_wait: the round trip to the
+// memory side hides behind whatever is done in between
+__device__ inline int cp_flag_load_early(const int* f) {
+  int v;
+  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(f) : "memory");
+  return v;
+}
+__device__ inline void cp_flag_wait(int& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 // one lane: spin until *f == want; false = gave up (this spin timed out, or another workgroup of the system raised the error word)
 __device__ inline bool cp_poll(const int* f, int want, int* err, int code, bool patient) {
   for (unsigned it = 0; it < CP_SPIN_MAX; ++it) {
     if (cp_flag_load(f) == want) return true;
     if ((it & 31) == 31 && cp_flag_load(err) != 0) return false;
     if (patient) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
+  }
+  cp_flag_store(err, code);
+  return false;
+}
+
+// one lane: up to three flags polled together (their loads in flight at once: a poll is a round trip to the memory side)
+__device__ inline bool cp_poll3(const int* f0, const int* f1, const int* f2, int want, int* err, int code) {
+  for (unsigned it = 0; it < CP_SPIN_MAX; ++it) {
+    const int a = cp_flag_load(f0), b = cp_flag_load(f1), c = cp_flag_load(f2);
+    if (a == want && b == want && c == want) return true;
+    if ((it & 31) == 31 && cp_flag_load(err) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
   cp_flag_store(err, code);
   return false;
@@ -101,29 +141,40 @@ __device__ inline chol_d4 cp_lds_to_regs(cp_tile T, int qd, int l) {
   return v;
 }
 // acc (+/-)= Pi[rows of the quadrant] Pj[columns of the quadrant]^T over K = 32
-template <bool NEG>
+template <bool NEG, int KMAX = CH_NB>
 __device__ inline void cp_mma(chol_d4& acc, cp_tile Pi, cp_tile Pj, int qd, int l) {
   const int ri = 16*(qd >> 1) + (l & 15), rj = 16*(qd & 1) + (l & 15), rq = l >> 4;
 #pragma unroll
-  for (int kk = 0; kk < CH_NB; kk += 4) {
+  for (int kk = 0; kk < KMAX; kk += 4) {
     const double x = Pi[ri][kk + rq];
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -x : x, Pj[rj][kk + rq], acc, 0, 0, 0);
   }
 }
 __device__ inline unsigned cp_chunk_off(int slot, int qd, int l) { return (unsigned)(((size_t)slot*CP_TQ + (size_t)(qd*64 + l)*4)*sizeof(double)); }
 
-// A(ti, tj) out of S (row-major n x n, right-hand side = row n); block row R = ntc is the right-hand side (one row)
+// A(ti, tj) out of S (row-major n x n, right-hand side = row n); block row R = ntc is the right-hand side (one row).
+// Beyond the matrix a diagonal tile continues as the identity (the panel then needs no notion of the matrix edge), others as zero.
 __device__ inline chol_d4 cp_load_A(const double* __restrict__ S, int n, int ntc, int ti, int tj, int qd, int l) {
   chol_d4 v = {0.0, 0.0, 0.0, 0.0};
   const int rl = 16*(qd >> 1) + (l >> 4), c = tj*CH_NB + 16*(qd & 1) + (l & 15);
-  if (c >= n) return v;
-  if (ti == ntc) { if (rl == 0) v[0] = S[(size_t)n*n + c]; return v; }
+  if (ti == ntc) { if (rl == 0 && c < n) v[0] = S[(size_t)n*n + c]; return v; }
 #pragma unroll
-  for (int g = 0; g < 4; ++g) { const int r = ti*CH_NB + rl + 4*g; if (r < n) v[g] = S[(size_t)r*n + c]; }
+  for (int g = 0; g < 4; ++g) {
+    const int r = ti*CH_NB + rl + 4*g;
+    if (r < n && c < n) v[g] = S[(size_t)r*n + c];
+    else if (r == c) v[g] = 1.0;
+  }
   return v;
 }
 
 // ---- the critical workgroup ------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS only: __syncthreads() also drains the vector memory counter, i.e. would wait for the band row
+// the team has just asked for (fetched ahead precisely so that nobody waits for it)
+__device__ inline void cp_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 // LDS-only rendezvous of the three team wavefronts (the hardware barrier would include wavefront 0, which is inside the panel)
 __device__ inline void cp_team_sync(int* ctr, int& target, int lane) {
   target += 3;
@@ -132,17 +183,50 @@ __device__ inline void cp_team_sync(int* ctr, int& target, int lane) {
   while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
-// wavefront 0: L L^T = D (identity beyond nbe), L^-1 -> Dinv (row-major); the pivot loop is ba_chol.h's panel
-__device__ __forceinline__ void cp_potrf(cp_tile D, int nbe, cp_tile Dinv, double* colbuf, int* fail) {
-  const int lane = threadIdx.x, rr = lane & 31;
+// X = T Dinv^T for one quadrant; Dinv = L^-1 is lower triangular, so the left column quadrants only see k < 16
+__device__ inline chol_d4 cp_trsm_quadrant(cp_tile T, cp_tile Dinv, int qd, int l) {
+  chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  if (qd & 1) cp_mma<false>(acc, T, Dinv, qd, l); else cp_mma<false, 16>(acc, T, Dinv, qd, l);
+  return acc;
+}
+__device__ inline void cp_pair_sync(int* ctr, int& target, int lane) {      // the same for two wavefronts
+  target += 2;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+// wavefront 0: L L^T = D (a diagonal tile arrives with the identity beyond the matrix), L^-1 -> Dinv (row-major); the pivot loop
+// is ba_chol.h's panel: lanes 0..31 carry the tile's rows, lanes 32..63 the identity through the same column operations
+__device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf, int* fail, int q, int s) {
+  const int lane = threadIdx.x;
+  int rr = lane & 31;
+  asm volatile("" : "+v"(rr));       // opaque per call: the identity rows' 32 compares stay here (hoisted out of the step loop they were spilled)
   const bool low = lane >= 32;
   double d[CH_NB];
+  const double* src = &D[rr][0];
+  // every lane reads its row (32 loads in flight, one wait), THEN the upper lanes swap in the identity: written as one select per
+  // entry the compiler made 32 branches of it, each with its own LDS round trip (1.4 us per step)
 #pragma unroll
-  for (int c = 0; c < CH_NB; ++c) d[c] = (!low && c <= rr && rr < nbe && c < nbe) ? D[rr][c] : ((c == rr) ? 1.0 : 0.0);
+  for (int c = 0; c < CH_NB; ++c) d[c] = src[c];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (low) {
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) d[c] = (c == rr) ? 1.0 : 0.0;
+  }
   const double piv0 = readlane_f64(d[0], 0);
   bool bad = !(piv0 > 0.0);
   double inv = rsqrt(piv0);
+  if (lane == 0) CP_STAMP(s, 9);
+#if defined(CP_EXP) && CP_EXP == 5
+  asm volatile(".p2align 6");
+#elif defined(CP_EXP) && CP_EXP == 6
+  asm volatile("s_nop 0");
+#elif defined(CP_EXP) && CP_EXP == 7
+  asm volatile(".p2align 6\n\ts_nop 0");
+#endif
   chol_panel_pivots(d, inv, bad, colbuf, std::make_integer_sequence<int, CH_NB>());
+  if (lane == 0) CP_STAMP(s, 10);
   if (bad && lane == 0) atomicOr(fail, 2);
   // lane 32 + r ends with row r of L^-T = column r of L^-1
   if (low) {
@@ -153,7 +237,7 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, int nbe, cp_tile Dinv, doubl
 
 __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int n = a.n, ntc = a.ntc, R = a.ntc;
+  const int ntc = a.ntc, R = a.ntc;
   // LDS tiles (pointers computed, never kept in an indexed array: that would live in scratch)
   auto Dv = [&](int i) { return (cp_tile)(lds + (i & 1)*CP_TILE); };             // L_kk^-1 of block k in Dv(k)
   const cp_tile Xb0 = (cp_tile)(lds + 2*CP_TILE), Xb1 = (cp_tile)(lds + 3*CP_TILE);
@@ -161,22 +245,22 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   auto Dt = [&](int i) { return (cp_tile)(lds + (6 + (i & 1))*CP_TILE); };
   double* colbuf = lds + 8*CP_TILE;
   int* ctl = (int*)(colbuf + 64);            // [0] team counter, [1] ok / abort word
-  int* flags = a.flags + (size_t)q*a.nslots;
+  int* flags = a.flags + (size_t)q*a.nflags;
   int* err = a.err + q; int* fail = a.fail + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
   const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
-  const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of;
-  const int want_band = a.epoch4 | 1, done_l = a.epoch4 | 2;
+  const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of; const int* delta_of = a.delta_of;
+  const int epoch4 = a.epoch[q] << 2, want_band = epoch4 | 1, done_l = epoch4 | 2;
   const int code = 0x100;
-  if (t == 0) { ctl[0] = 0; ctl[1] = 1; }
+  int* stp = ctl + 16;                       // the step table
+  for (int i = t; i < (ntc + 1)*CP_STEP_INTS; i += CP_THREADS) stp[i] = a.steps[i];
+  if (t == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; }
   __syncthreads();
   // ---- prologue: rows 0 and 1 of the band (their helpers pass A through), diagonal tile 0 factored
   const bool row1_diag = 1 < ntc;
   if (t == 0) {
-    bool ok = cp_poll(flags + slot_of[0], want_band, err, code | 1, false);
-    ok = ok && cp_poll(flags + slot_of[1*ntc + 0], want_band, err, code | 2, false);
-    if (row1_diag) ok = ok && cp_poll(flags + slot_of[1*ntc + 1], want_band, err, code | 3, false);
-    if (!ok) ctl[1] = 0;
+    const int* fb = flags + slot_of[1*ntc + 0];
+    if (!cp_poll3(flags + slot_of[0], fb, row1_diag ? flags + slot_of[1*ntc + 1] : fb, want_band, err, code | 1)) ctl[1] = 0;
   }
   __syncthreads();
   if (!ctl[1]) return;
@@ -188,95 +272,173 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
     cp_regs_to_lds(which == 0 ? Dt(0) : (which == 1 ? Tc : Dt(1)), qd, lane, v);
   }
   __syncthreads();
-  int dcur = 0;                 // Dt(dcur): diagonal tile (s+1, s+1), updated through column s - 1
-  int team_target = 0;
-  // s = -1 is the lead-in: only the factorisation of diagonal tile 0 (the one call site of the panel code)
-  for (int s = -1; s < ntc; ++s) {
-    const int i1 = s + 1, i2 = s + 2;
-    const cp_tile Ds = Dv(s);
-    if (s >= 0) {
-      // ---- P1: X1 = A'(s+1, s) L_ss^-T
-      {
-        chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        cp_mma<false>(acc, Tc, Ds, wave, lane);
-        cp_regs_to_lds(Xb0, wave, lane, acc);
+  // Two loops, one per role, with the same barriers: what the team carries from step to step (the band row fetched ahead) and what
+  // the panel keeps in registers never share a live range that way (one loop with a branch per role spilled 63 registers).
+  if (wave == 0) {
+    int dcur = 0;               // Dt(dcur): diagonal tile (s+1, s+1), updated through column s - 1
+    // s = -1 is the lead-in: only the factorisation of diagonal tile 0 (the one call site of the panel code)
+    for (int s = -1; s < ntc; ++s) {
+      const int i1 = s + 1;
+      const cp_tile Ds = Dv(s);
+      if (t == 0) CP_STAMP(s, 0);
+      if (s >= 0) {
+        cp_regs_to_lds(Xb0, 0, lane, cp_trsm_quadrant(Tc, Ds, 0, lane));      // P1, quadrant 0
+        cp_barrier();
+        if (i1 < ntc) {                                                          // P2, quadrant 0
+          chol_d4 acc = cp_lds_to_regs(Dt(dcur), 0, lane);
+          cp_mma<true>(acc, Xb0, Xb0, 0, lane);
+          cp_regs_to_lds(Dt(dcur), 0, lane, acc);
+        }
+        cp_barrier();
       }
-      __syncthreads();
+      if (t == 0) CP_STAMP(s, 1);
+      if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, fail, q, s);
+      if (t == 0) CP_STAMP(s, 2);
+#if defined(CP_EXP) && CP_EXP == 2
+      __builtin_amdgcn_s_sleep(2);
+#endif
+      cp_barrier();
+#if defined(CP_EXP) && CP_EXP == 1
+      __builtin_amdgcn_s_sleep(2);
+#elif defined(CP_EXP) && CP_EXP == 3
+      { unsigned long long tt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); }
+#elif defined(CP_EXP) && CP_EXP == 4
+      if (t == 0) a.err[8 + q] = s;
+#endif
+      if (t == 0) CP_STAMP(s, 8);
+      if (!ctl[1]) return;
+      dcur ^= 1;
+    }
+    return;
+  }
+  int dcur = 0;
+  int team_target = 0, pair_target = 0;
+  // The loop body starts where the team asks for the band row it needs a step later and ends where it has used it: the request and
+  // its use sit in ONE iteration (carried around the loop the compiler waited for the loads at the loop head, i.e. hid nothing).
+  // `s` is the step that is ending (-1: the lead-in, wavefront 0 factors diagonal tile 0).
+  for (int s = -1; s < ntc; ++s) {
+    chol_d4 v0 = {0.0, 0.0, 0.0, 0.0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0;       // wavefronts 2, 3: band row s+3
+    {
+      // the row after next into registers (wavefronts 2, 3; also in the lead-in step): its helpers finished it a step ago
+      if (wave >= 2 && s + 3 <= R && ctl[1]) {
+        const int* se = stp + (s + 1)*CP_STEP_INTS;
+        if (t == 128) {
+          if (!cp_poll3(flags + se[CPS_F0], flags + se[CPS_F1], flags + se[CPS_F2], want_band, err, code | 4)) ctl[1] = 0;
+          CP_STAMP(s, 4);
+        }
+        cp_pair_sync(ctl + 2, pair_target, lane);
+        if (ctl[1]) {
+          const int b0 = se[CPS_B0], b1 = se[CPS_B1], b2 = se[CPS_B2];
+          const int h = wave - 2;                    // 0: quadrants 0, 1   1: quadrants 2, 3
+          v0 = cp_ld4(rB, cp_chunk_off(b0, 2*h, lane)); v1 = cp_ld4(rB, cp_chunk_off(b0, 2*h + 1, lane));
+          v2 = cp_ld4(rB, cp_chunk_off(b1, 2*h, lane)); v3 = cp_ld4(rB, cp_chunk_off(b1, 2*h + 1, lane));
+          v4 = cp_ld4(rB, cp_chunk_off(b2, 2*h, lane)); v5 = cp_ld4(rB, cp_chunk_off(b2, 2*h + 1, lane));
+        }
+      }
+    }
+    cp_barrier();                      // end of step s
+    if (!ctl[1]) return;
+    dcur ^= 1;
+    if (s + 1 >= ntc) break;
+    // ---------------- step s + 1 ----------------
+    const int sn = s + 1;
+    {
+      const int s = sn;               // (the body below was written in terms of the step it works on)
+      const int i1 = s + 1, i2 = s + 2;
+      const cp_tile Ds = Dv(s);
+      // ---- P1: X1 = A'(s+1, s) L_ss^-T (all four wavefronts, a quadrant each)
+      cp_regs_to_lds(Xb0, wave, lane, cp_trsm_quadrant(Tc, Ds, wave, lane));
+      cp_barrier();
       // ---- P2: A'(s+1, s+1) -= X1 X1^T
       if (i1 < ntc) {
         chol_d4 acc = cp_lds_to_regs(Dt(dcur), wave, lane);
         cp_mma<true>(acc, Xb0, Xb0, wave, lane);
         cp_regs_to_lds(Dt(dcur), wave, lane, acc);
       }
-      __syncthreads();
-    }
-    // ---- P3: wavefront 0 factors the next diagonal tile; the team finishes column s
-    if (wave == 0) {
-      if (i1 < ntc) cp_potrf(Dt(dcur), min(CH_NB, n - i1*CH_NB), Dv(i1), colbuf, fail);
-    } else if (s >= 0) {
+      cp_barrier();
+      // ---- P3: wavefront 0 factors the next diagonal tile; the team finishes column s
       const int tw = wave - 1;
-      // (a) publish L_ss^-1 and L(s+1, s)
-      {
-        const int sd = slot_of[s*ntc + s], s1 = slot_of[i1*ntc + s];
-        for (int j = tw; j < 8; j += 3) {
-          const int qd = j & 3;
-          if (j < 4) cp_st4(rL, cp_chunk_off(sd, qd, lane), cp_lds_to_regs(Ds, qd, lane));
-          else cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
-        }
+      const bool row2 = i2 <= R, diag2 = i2 < ntc;
+      const int* se = stp + (s + 1)*CP_STEP_INTS;
+      const int sd = se[CPS_SD], s1 = se[CPS_S1];
+      const int dl = (row2 && ctl[1]) ? se[CPS_DL] : -1;        // band slot of row s+2's late product, -1 = none
+      chol_d4 dq0 = {0.0, 0.0, 0.0, 0.0}, dq1 = dq0;
+      // the late product's flag: asked for first (it was raised a step ago), looked at after the work below
+      int dflag = want_band;
+      if (dl >= 0) dflag = cp_flag_load_early(flags + a.nslots + i2);
+      if (tw == 0) {
+        // (a) wavefront 1 publishes L_ss^-1 and L(s+1, s) first thing: the helpers of row s+3 hang on these two flags
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(sd, qd, lane), cp_lds_to_regs(Ds, qd, lane));
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
         CP_DRAIN();
-        cp_team_sync(ctl, team_target, lane);
-        if (t == 64) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); }
+        if (lane == 0) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
+      } else if (row2 && ctl[1]) {
+        // (b) wavefronts 2, 3: row s+2 of the band was fetched into registers while the previous step ended; now that X1 is out of
+        //     Tc it goes to LDS
+        const int h = tw - 1;
+        cp_regs_to_lds(T2, 2*h, lane, v0); cp_regs_to_lds(T2, 2*h + 1, lane, v1);
+        cp_regs_to_lds(Tc, 2*h, lane, v2); cp_regs_to_lds(Tc, 2*h + 1, lane, v3);
+        if (diag2) { cp_regs_to_lds(Dt(dcur ^ 1), 2*h, lane, v4); cp_regs_to_lds(Dt(dcur ^ 1), 2*h + 1, lane, v5); }
       }
-      if (i2 <= R && ctl[1]) {
-        const bool diag2 = i2 < ntc;
-        // (b) row s+2 of the band, updated through column s - 1 by its helpers
-        if (t == 64) {
-          bool ok = cp_poll(flags + slot_of[i2*ntc + s], want_band, err, code | 4, false);
-          ok = ok && cp_poll(flags + slot_of[i2*ntc + i1], want_band, err, code | 5, false);
-          if (diag2) ok = ok && cp_poll(flags + slot_of[i2*ntc + i2], want_band, err, code | 6, false);
-          if (!ok) ctl[1] = 0;
+      // the late product of tile (s+2, s+1): every wavefront fetches the quadrants it will update (U1 below: 0 | 1 | 2, 3); the
+      // loads are in flight through the solve and the first product
+      if (dl >= 0) {
+        cp_flag_wait(dflag);
+        unsigned it = 0;
+        while (dflag != want_band) {
+          if (++it >= CP_SPIN_MAX) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
+          if ((it & 31) == 31 && cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+          dflag = cp_flag_load(flags + a.nslots + i2);
         }
+        dq0 = cp_ld4(rB, cp_chunk_off(dl, tw, lane));
+        if (tw == 2) dq1 = cp_ld4(rB, cp_chunk_off(dl, 3, lane));
+      }
+      cp_team_sync(ctl, team_target, lane);
+      if (t == 64) CP_STAMP(s, 5);
+      if (row2 && ctl[1]) {
+        // (c) X2 = A'(s+2, s) L_ss^-T: the two right quadrants take 8 matrix instructions each, the two left ones 4 each
+        if (tw == 0) cp_regs_to_lds(Xb1, 1, lane, cp_trsm_quadrant(T2, Ds, 1, lane));
+        else if (tw == 1) cp_regs_to_lds(Xb1, 3, lane, cp_trsm_quadrant(T2, Ds, 3, lane));
+        else { cp_regs_to_lds(Xb1, 0, lane, cp_trsm_quadrant(T2, Ds, 0, lane)); cp_regs_to_lds(Xb1, 2, lane, cp_trsm_quadrant(T2, Ds, 2, lane)); }
         cp_team_sync(ctl, team_target, lane);
-        if (ctl[1]) {
-          for (int j = tw; j < 12; j += 3) {
-            const int which = j >> 2, qd = j & 3;
-            if (which == 2 && !diag2) continue;
-            const int bs = bslot_of[i2*ntc + (which == 0 ? s : (which == 1 ? i1 : i2))];
-            const chol_d4 v = cp_ld4(rB, cp_chunk_off(bs, qd, lane));
-            cp_regs_to_lds(which == 0 ? T2 : (which == 1 ? Tc : Dt(dcur ^ 1)), qd, lane, v);
-          }
-          cp_team_sync(ctl, team_target, lane);
-          // (c) X2 = A'(s+2, s) L_ss^-T
-          for (int j = tw; j < 4; j += 3) {
-            chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
-            cp_mma<false>(acc, T2, Ds, j, lane);
-            cp_regs_to_lds(Xb1, j, lane, acc);
-          }
-          cp_team_sync(ctl, team_target, lane);
-          // (d) A'(s+2, s+1) -= X2 X1^T, A'(s+2, s+2) -= X2 X2^T; publish L(s+2, s)
-          const int s2 = slot_of[i2*ntc + s];
-          for (int j = tw; j < 12; j += 3) {
-            const int which = j >> 2, qd = j & 3;
-            if (which == 0) {
-              chol_d4 acc = cp_lds_to_regs(Tc, qd, lane);
-              cp_mma<true>(acc, Xb1, Xb0, qd, lane);
-              cp_regs_to_lds(Tc, qd, lane, acc);
-            } else if (which == 1) {
-              if (!diag2) continue;
-              chol_d4 acc = cp_lds_to_regs(Dt(dcur ^ 1), qd, lane);
-              cp_mma<true>(acc, Xb1, Xb1, qd, lane);
-              cp_regs_to_lds(Dt(dcur ^ 1), qd, lane, acc);
-            } else cp_st4(rL, cp_chunk_off(s2, qd, lane), cp_lds_to_regs(Xb1, qd, lane));
-          }
-          CP_DRAIN();
-          cp_team_sync(ctl, team_target, lane);
-          if (t == 64) cp_flag_store(flags + s2, done_l);
+        if (t == 64) CP_STAMP(s, 6);
+        // (d) L(s+2, s) leaves first (its stores fly during the products), then A'(s+2, s+1) -= X2 X1^T + late product,
+        //     A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1))
+        const int s2 = se[CPS_S2];
+        for (int qd = tw; qd < 4; qd += 3) cp_st4(rL, cp_chunk_off(s2, qd, lane), cp_lds_to_regs(Xb1, qd, lane));
+        if (t == 64) CP_STAMP(s, 11);
+        {
+          chol_d4 acc = cp_lds_to_regs(Tc, tw, lane);                    // U1 quadrant tw
+          cp_mma<true>(acc, Xb1, Xb0, tw, lane);
+          if (dl >= 0) acc += dq0;                                       // (the helper summed -L(s+2,s-1) L(s+1,s-1)^T)
+          cp_regs_to_lds(Tc, tw, lane, acc);
         }
+        if (tw == 2) {
+          chol_d4 acc = cp_lds_to_regs(Tc, 3, lane);                     // U1 quadrant 3
+          cp_mma<true>(acc, Xb1, Xb0, 3, lane);
+          if (dl >= 0) acc += dq1;
+          cp_regs_to_lds(Tc, 3, lane, acc);
+        } else if (diag2) {
+          const int qd = tw == 0 ? 0 : 2;                                // U2 quadrants 0 | 2, then 3 with wavefront 2
+          chol_d4 acc = cp_lds_to_regs(Dt(dcur ^ 1), qd, lane);
+          cp_mma<true>(acc, Xb1, Xb1, qd, lane);
+          cp_regs_to_lds(Dt(dcur ^ 1), qd, lane, acc);
+          if (tw == 1) {
+            chol_d4 acc3 = cp_lds_to_regs(Dt(dcur ^ 1), 3, lane);
+            cp_mma<true>(acc3, Xb1, Xb1, 3, lane);
+            cp_regs_to_lds(Dt(dcur ^ 1), 3, lane, acc3);
+          }
+        }
+        if (t == 64) CP_STAMP(s, 12);
+        CP_DRAIN();
+        if (t == 64) CP_STAMP(s, 13);
+        cp_team_sync(ctl, team_target, lane);
+        if (t == 64) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
       }
     }
-    __syncthreads();
-    if (!ctl[1]) return;
-    dcur ^= 1;
   }
 }
 
@@ -286,12 +448,12 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   const CpHelper h = a.helpers[hidx];
   cp_tile Pa = (cp_tile)(lds), Pb = (cp_tile)(lds + CP_TILE);
   int* ctl = (int*)(lds + 2*CP_TILE);
-  int* flags = a.flags + (size_t)q*a.nslots;
+  int* flags = a.flags + (size_t)q*a.nflags;
   int* err = a.err + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
   const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
   const double* S = a.S + q*a.sys_stride;
-  const int done_l = a.epoch4 | 2;
+  const int epoch4 = a.epoch[q] << 2, done_l = epoch4 | 2;
   const int code = 0x200 | (hidx << 12);
   // the right-hand-side row's helpers also arm the back-substitution's data-tagged vectors
   if (h.ti == a.ntc && t < 64) {
@@ -299,14 +461,17 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
     *reinterpret_cast<unsigned long long*>(dst) = CP_SENT;
   }
   chol_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  if (t == 0) CP_HSTAMP(0);
   if (h.in_s) acc = cp_load_A(S, a.n, a.ntc, h.ti, h.tj, wave, lane);
-  for (int u = 0; u < h.nupd; ++u) {
+  const int nplain = (h.kind == 1 && h.pre >= 0) ? h.nupd - 1 : h.nupd;
+  for (int u = 0; u < nplain; ++u) {
     const int2 sl = a.upd[h.upd0 + u];
     if (t == 0) {
       const bool patient = u + 3 < h.nupd;           // far behind the frontier of this tile: poll gently
-      bool ok = cp_poll(flags + sl.x, done_l, err, code | 1, patient);
-      ok = ok && (sl.y == sl.x || cp_poll(flags + sl.y, done_l, err, code | 2, patient));
+      const bool ok = patient ? (cp_poll(flags + sl.x, done_l, err, code | 1, true) && (sl.y == sl.x || cp_poll(flags + sl.y, done_l, err, code | 2, true)))
+                              : cp_poll3(flags + sl.x, flags + sl.y, flags + sl.y, done_l, err, code | 1);
       ctl[0] = ok ? 1 : 0;
+      if (u + 1 == h.nupd) CP_HSTAMP(1);
     }
     __syncthreads();
     if (!ctl[0]) return;
@@ -320,29 +485,58 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
     cp_mma<true>(acc, Pa, sl.y == sl.x ? Pa : Pb, wave, lane);
     __syncthreads();
   }
+  if (h.kind == 1 && h.pre >= 0) {
+    // last update of a band tile of row i, column m = i - CP_W: L(i, m) = (the far tile's sum, handed over early) L_mm^-T, redone here
+    const int2 sl = a.upd[h.upd0 + h.nupd - 1];        // (x: the far tile itself -- not waited for; y: L(j, m), x if j = i)
+    if (t == 0) {
+      const bool ok = cp_poll(flags + h.pre_flag, epoch4 | 1, err, code | 4, false) &&
+                      cp_poll3(flags + h.pre_diag, flags + (sl.y == sl.x ? h.pre_diag : sl.y), flags + h.pre_diag, done_l, err, code | 5);
+      ctl[0] = ok ? 1 : 0;
+      CP_HSTAMP(1);
+    }
+    __syncthreads();
+    if (!ctl[0]) return;
+    const chol_d4 vp = cp_ld4(rB, cp_chunk_off(h.pre, wave, lane)), vd = cp_ld4(rL, cp_chunk_off(h.pre_diag, wave, lane));
+    chol_d4 vy = vp;
+    if (sl.y != sl.x) vy = cp_ld4(rL, cp_chunk_off(sl.y, wave, lane));
+    cp_regs_to_lds(Pa, wave, lane, vp); cp_regs_to_lds(Pb, wave, lane, vd);
+    __syncthreads();
+    const chol_d4 x = cp_trsm_quadrant(Pa, Pb, wave, lane);
+    __syncthreads();
+    cp_regs_to_lds(Pa, wave, lane, x);
+    if (sl.y != sl.x) cp_regs_to_lds(Pb, wave, lane, vy);
+    __syncthreads();
+    cp_mma<true>(acc, Pa, sl.y == sl.x ? Pa : Pb, wave, lane);
+  }
+  if (h.kind == 0 && h.pre >= 0) {
+    // far tile (i, i - CP_W): the sum before the solve goes out first (see CpHelper)
+    cp_st4(rB, cp_chunk_off(h.pre, wave, lane), acc);
+    CP_DRAIN();
+    __syncthreads();
+    if (t == 0) cp_flag_store(flags + h.pre_flag, epoch4 | 1);
+  }
   if (h.kind == 1) {          // band tile: the partial sum goes to the critical workgroup
     cp_st4(rB, cp_chunk_off(h.dslot, wave, lane), acc);        // (dslot of a band tile = its band slot)
     CP_DRAIN();
     __syncthreads();
-    if (t == 0) cp_flag_store(flags + h.slot, a.epoch4 | 1);
+    if (t == 0) { cp_flag_store(flags + h.slot, epoch4 | 1); CP_HSTAMP(3); }
     return;
   }
   // far tile: X = acc L_jj^-T
-  if (t == 0) ctl[0] = cp_poll(flags + h.dslot, done_l, err, code | 3, false) ? 1 : 0;
+  if (t == 0) { ctl[0] = cp_poll(flags + h.dslot, done_l, err, code | 3, false) ? 1 : 0; CP_HSTAMP(2); }
   __syncthreads();
   if (!ctl[0]) return;
   cp_regs_to_lds(Pb, wave, lane, cp_ld4(rL, cp_chunk_off(h.dslot, wave, lane)));
   cp_regs_to_lds(Pa, wave, lane, acc);
   __syncthreads();
-  chol_d4 x = {0.0, 0.0, 0.0, 0.0};
-  cp_mma<false>(x, Pa, Pb, wave, lane);
+  const chol_d4 x = cp_trsm_quadrant(Pa, Pb, wave, lane);
   cp_st4(rL, cp_chunk_off(h.slot, wave, lane), x);
   CP_DRAIN();
   __syncthreads();
-  if (t == 0) cp_flag_store(flags + h.slot, done_l);
+  if (t == 0) { cp_flag_store(flags + h.slot, done_l); CP_HSTAMP(3); }
 }
 
-constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 8;
+constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 8;          // + the step table of the critical workgroup behind it
 __global__ void __launch_bounds__(CP_THREADS, 2)
 k_chol_persist(CpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
@@ -484,7 +678,7 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
   if (ntc > 0) { if (wave >= 1) prepare(ntc - 1, wave); }
   __syncthreads();
   for (int k = ntc - 1; k >= 0; --k) {
-    if (!ctl[0]) return;
+    if (!ctl[0]) break;
     const int par = k & 1;
     if (wave == 0) {
       const double* P = pre + par*3*64;
@@ -511,9 +705,13 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
     } else if (k > 0) prepare(k - 1, wave);
     __syncthreads();
   }
+  if (t == 0) a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
   if (!ctl[0]) return;
   for (int i = t; i < n; i += CP_THREADS) a.xout[q*a.sys_stride + i] = xs[i];
 }
+
+// a factorisation that is not followed by k_chol_back2 (debug hook) closes its epoch itself
+__global__ void k_cp_bump(int* epoch, int nsys) { if (threadIdx.x < (unsigned)nsys) epoch[threadIdx.x] += 1; }
 
 __global__ void __launch_bounds__(CP_THREADS)
 k_chol_back2(CpBackArgs a) {
@@ -526,21 +724,21 @@ k_chol_back2(CpBackArgs a) {
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 struct CholPersist {
   static constexpr int max_sys = 4;
-  int n = 0, ntc = 0, nslots = 0, nbslots = 0, nhelpers = 0, nfarcols = 0;
+  int n = 0, ntc = 0, nslots = 0, nbslots = 0, nflags = 0, nhelpers = 0, nfarcols = 0;
   bool ok = false;
-  std::vector<int> slot_of, bslot_of;
+  std::vector<int> steps;            // [ntc + 1][CP_STEP_INTS], index = step + 1
+  std::vector<int> slot_of, bslot_of, delta_of;       // delta_of[i]: band slot of row i's late product (below), -1 = none
   std::vector<CpHelper> helpers; std::vector<int2> upd;
   std::vector<int> far_start, far_slot, far_row;
-  int *d_slot_of = nullptr, *d_bslot_of = nullptr, *d_flags = nullptr, *d_err = nullptr, *d_far_start = nullptr, *d_far_slot = nullptr, *d_far_row = nullptr;
+  int *d_steps = nullptr, *d_slot_of = nullptr, *d_bslot_of = nullptr, *d_delta_of = nullptr, *d_flags = nullptr, *d_err = nullptr, *d_epoch = nullptr, *d_far_start = nullptr, *d_far_slot = nullptr, *d_far_row = nullptr;
   CpHelper* d_helpers = nullptr; int2* d_upd = nullptr;
   double *d_Lt = nullptr, *d_Bt = nullptr, *d_x = nullptr, *d_f = nullptr;
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
-  unsigned epoch = 0;
   ~CholPersist() { release(); }
   void release() {
-    void* ps[] = {d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
+    void* ps[] = {d_steps, d_delta_of, d_epoch, d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
     for (void* p : ps) if (p) (void)hipFree(p);
-    d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = nullptr; d_helpers = nullptr; d_upd = nullptr;
+    d_steps = d_delta_of = d_epoch = d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = nullptr; d_helpers = nullptr; d_upd = nullptr;
     d_Lt = d_Bt = d_x = d_f = nullptr; ok = false;
   }
   template <class T> static int up(T*& d, const std::vector<T>& v) {
@@ -572,29 +770,61 @@ struct CholPersist {
       slot_of[(size_t)i*ntc + j] = nslots++;
       if (i - j < CP_W) bslot_of[(size_t)i*ntc + j] = nbslots++;
     }
-    // helpers, in the order of the column that completes them: far tile (i, j) -> j; band tile (i, j) -> i - CP_W
+    // The last update of band tile (i, i-1), column m = i - 3, needs L(i-1, i-3): the critical workgroup's own tile of the step before
+    // the row is taken in -- a round trip through a helper on the critical cycle.  That one product travels apart ("delta"): its own
+    // helper, its own band slot and flag (index nslots + i); the critical workgroup subtracts it a step later, when it has long arrived.
+    delta_of.assign(nr, -1);
+    for (int i = CP_W; i < nr; ++i) if (i - 1 < ntc && slot_of[(size_t)i*ntc + i - CP_W] >= 0 && slot_of[(size_t)(i - 1)*ntc + i - CP_W] >= 0) delta_of[i] = nbslots++;
+    // ... and the far tile (i, i - CP_W) hands its sum to the band tiles of its row before its own solve (CpHelper): flag index nslots + nr + i
+    std::vector<int> pre_of(nr, -1);
+    for (int i = CP_W; i < nr; ++i) if (slot_of[(size_t)i*ntc + i - CP_W] >= 0) pre_of[i] = nbslots++;
+    nflags = nslots + 2*nr;
+    // helpers, in the order of the column that completes them: far tile (i, j) -> j; band tile (i, j) -> i - CP_W; delta of row i -> i - CP_W
     struct Key { int key, kind, i, j; };
     std::vector<Key> ks;
     for (int i = 0; i < nr; ++i) for (int j = 0; j < ntc && j <= i; ++j) if (P[(size_t)i*ntc + j]) {
       const bool band = i - j < CP_W;
       ks.push_back({band ? i - CP_W : j, band ? 1 : 0, i, j});
     }
+    for (int i = 0; i < nr; ++i) if (delta_of[i] >= 0) ks.push_back({i - CP_W, 2, i, i - 1});
     std::stable_sort(ks.begin(), ks.end(), [](const Key& x, const Key& y) { if (x.key != y.key) return x.key < y.key; if (x.kind != y.kind) return x.kind < y.kind; return x.i < y.i; });
     helpers.clear(); upd.clear();
     for (const Key& k : ks) {
-      CpHelper h; h.ti = k.i; h.tj = k.j; h.kind = k.kind; h.slot = slot_of[(size_t)k.i*ntc + k.j];
-      h.dslot = k.kind ? bslot_of[(size_t)k.i*ntc + k.j] : slot_of[(size_t)k.j*ntc + k.j];
-      h.in_s = inS[(size_t)k.i*ntc + k.j];
-      h.upd0 = (int)upd.size();
-      const int mlast = k.kind ? std::min(k.j - 1, k.i - CP_W) : k.j - 1;
-      for (int m = 0; m <= mlast; ++m) {
-        const int sa = slot_of[(size_t)k.i*ntc + m], sb = slot_of[(size_t)k.j*ntc + m];
-        if (sa >= 0 && sb >= 0) upd.push_back(make_int2(sa, sb));
+      CpHelper h; h.ti = k.i; h.tj = k.j; h.upd0 = (int)upd.size(); h.pre = -1; h.pre_flag = h.pre_diag = h.pad = 0;
+      if (k.kind == 2) {       // runs the band tile's code: zero start, one product, handed over through its band slot
+        h.kind = 1; h.in_s = 0; h.slot = nslots + k.i; h.dslot = delta_of[k.i];
+        upd.push_back(make_int2(slot_of[(size_t)k.i*ntc + k.i - CP_W], slot_of[(size_t)(k.i - 1)*ntc + k.i - CP_W]));
+        h.ti = -1 - k.i;        // (not a tile of its own: never touches S, never arms the back-substitution's vectors)
+      } else {
+        h.kind = k.kind; h.slot = slot_of[(size_t)k.i*ntc + k.j];
+        h.dslot = k.kind ? bslot_of[(size_t)k.i*ntc + k.j] : slot_of[(size_t)k.j*ntc + k.j];
+        h.in_s = inS[(size_t)k.i*ntc + k.j];
+        int mlast = k.kind ? std::min(k.j - 1, k.i - CP_W) : k.j - 1;
+        if (k.kind == 1 && k.j == k.i - 1 && delta_of[k.i] >= 0) mlast = std::min(mlast, k.i - CP_W - 1);
+        for (int m = 0; m <= mlast; ++m) {
+          const int sa = slot_of[(size_t)k.i*ntc + m], sb = slot_of[(size_t)k.j*ntc + m];
+          if (sa >= 0 && sb >= 0) upd.push_back(make_int2(sa, sb));
+        }
+        const int mw = k.i - CP_W;          // the column whose far tile of this row feeds the row's band tiles
+        if (k.kind == 0 && k.j == mw && pre_of[k.i] >= 0) { h.pre = pre_of[k.i]; h.pre_flag = nslots + nr + k.i; }
+        if (k.kind == 1 && mlast == mw && mw >= 0 && pre_of[k.i] >= 0 && slot_of[(size_t)k.j*ntc + mw] >= 0) {
+          h.pre = pre_of[k.i]; h.pre_flag = nslots + nr + k.i; h.pre_diag = slot_of[(size_t)mw*ntc + mw];      // (its last list entry is column mw's)
+        }
       }
       h.nupd = (int)upd.size() - h.upd0;
       helpers.push_back(h);
     }
     nhelpers = (int)helpers.size();
+    steps.assign((size_t)(ntc + 1)*CP_STEP_INTS, -1);
+    for (int st = -1; st < ntc; ++st) {
+      int* e = &steps[(size_t)(st + 1)*CP_STEP_INTS];
+      const int i1 = st + 1, i2 = st + 2, i3 = st + 3;
+      if (st >= 0) { e[CPS_SD] = slot_of[(size_t)st*ntc + st]; e[CPS_S1] = slot_of[(size_t)i1*ntc + st]; if (i2 <= R) { e[CPS_S2] = slot_of[(size_t)i2*ntc + st]; e[CPS_DL] = delta_of[i2]; } }
+      if (i3 <= R) {
+        e[CPS_F0] = slot_of[(size_t)i3*ntc + i1]; e[CPS_F1] = slot_of[(size_t)i3*ntc + i2]; e[CPS_F2] = i3 < ntc ? slot_of[(size_t)i3*ntc + i3] : e[CPS_F1];
+        e[CPS_B0] = bslot_of[(size_t)i3*ntc + i1]; e[CPS_B1] = bslot_of[(size_t)i3*ntc + i2]; e[CPS_B2] = i3 < ntc ? bslot_of[(size_t)i3*ntc + i3] : e[CPS_B1];
+      }
+    }
     // back-substitution: far tiles per block column, columns right to left (role 1 + idx <-> column ntc - 1 - idx)
     far_start.assign(1, 0); far_slot.clear(); far_row.clear();
     for (int idx = 0; idx < ntc; ++idx) {
@@ -603,11 +833,12 @@ struct CholPersist {
       far_start.push_back((int)far_slot.size());
     }
     lt_stride = (size_t)nslots*CP_TQ; bt_stride = (size_t)std::max(nbslots, 1)*CP_TQ; vec_stride = ntc*CH_NB;
-    if (up(d_slot_of, slot_of) || up(d_bslot_of, bslot_of) || up(d_helpers, helpers) || up(d_upd, upd) || up(d_far_start, far_start) || up(d_far_slot, far_slot) || up(d_far_row, far_row)) return -1;
+    if (up(d_slot_of, slot_of) || up(d_bslot_of, bslot_of) || up(d_delta_of, delta_of) || up(d_steps, steps) || up(d_helpers, helpers) || up(d_upd, upd) || up(d_far_start, far_start) || up(d_far_slot, far_slot) || up(d_far_row, far_row)) return -1;
     if (hipMalloc((void**)&d_Lt, sizeof(double)*lt_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_Bt, sizeof(double)*bt_stride*max_sys) != hipSuccess ||
-        hipMalloc((void**)&d_flags, sizeof(int)*(size_t)nslots*max_sys) != hipSuccess || hipMalloc((void**)&d_err, sizeof(int)*max_sys*2) != hipSuccess ||
+        hipMalloc((void**)&d_flags, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMalloc((void**)&d_err, sizeof(int)*max_sys*4) != hipSuccess ||
         hipMalloc((void**)&d_x, sizeof(double)*vec_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_f, sizeof(double)*vec_stride*max_sys) != hipSuccess) return -1;
-    if (hipMemset(d_flags, 0, sizeof(int)*(size_t)nslots*max_sys) != hipSuccess || hipMemset(d_err, 0, sizeof(int)*max_sys*2) != hipSuccess) return -1;
+    if (hipMemset(d_flags, 0, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMemset(d_err, 0, sizeof(int)*max_sys*4) != hipSuccess) return -1;
+    { const int one[max_sys] = {1, 1, 1, 1}; if (hipMalloc((void**)&d_epoch, sizeof one) != hipSuccess || hipMemcpy(d_epoch, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return -1; }
     ok = true;
     return 0;
   }
@@ -620,18 +851,18 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   int dev = 0; (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
-    if (hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_DOUBLES*(int)sizeof(double)) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 2)*CP_STEP_INTS*(int)sizeof(int)) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (4*CP_TILE + 512 + CH_SOLVE_MAX + 64)*(int)sizeof(double)) != hipSuccess) return -1;
     attr_mask.fetch_or(bit, std::memory_order_relaxed);
   }
   CpArgs a;
   a.S = S + q0*sys_stride; a.sys_stride = sys_stride; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.nhelpers = P.nhelpers;
-  a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.helpers = P.d_helpers; a.upd = P.d_upd;
+  a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.delta_of = P.d_delta_of; a.steps = P.d_steps; a.helpers = P.d_helpers; a.upd = P.d_upd;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.Bt = P.d_Bt + q0*P.bt_stride; a.bt_stride = P.bt_stride;
-  a.flags = P.d_flags + (size_t)q0*P.nslots; a.nslots = P.nslots; a.err = P.d_err + q0; a.fail = fail + q0;
-  a.epoch4 = (int)((++P.epoch) << 2);
+  a.flags = P.d_flags + (size_t)q0*P.nflags; a.nslots = P.nslots; a.nflags = P.nflags; a.err = P.d_err + q0; a.fail = fail + q0;
+  a.epoch = P.d_epoch + q0;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
-  hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nhelpers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double), st, a);
+  hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nhelpers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
   return 0;
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)
@@ -640,7 +871,7 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.slot_of = P.d_slot_of; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.ncols = P.ntc;
   a.far_start = P.d_far_start; a.far_slot = P.d_far_slot; a.far_row = P.d_far_row;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
-  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0;
+  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0;
   const size_t lds = (size_t)(4*CP_TILE + 2*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double);
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
   return 0;

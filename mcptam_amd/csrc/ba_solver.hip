@@ -2525,6 +2525,7 @@ int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out
   CholPersist& P = plan.persist;
   if (!plan.use_persist || !P.ok) { set_err("mcp_chol_debug_factor: the persistent factorisation is switched off"); return -1; }
   if (chol_persist_factor(nullptr, P, d.p, f.p, 1, 0, 0)) { set_err("mcp_chol_debug_factor: launch failed"); return -1; }
+  hipLaunchKernelGGL(k_cp_bump, dim3(1), dim3(64), 0, nullptr, P.d_epoch, 1);
   HIPCK(hipDeviceSynchronize());
   std::vector<double> lt(P.lt_stride);
   HIPCK(hipMemcpy(lt.data(), P.d_Lt, P.lt_stride*8, hipMemcpyDeviceToHost));
@@ -2591,6 +2592,35 @@ int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, i
   }
   const int cnt = std::max(1, reps - 1);
   *ms_factor = tf/cnt; *ms_back = tb/cnt;
+#ifdef MCP_CP_PROF
+  if (plan.use_persist && plan.persist.ok) {
+    // stamps of the LAST repetition, system 0: 10 ns ticks
+    std::vector<unsigned long long> pr(256*16), hp(8192*4);
+    (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_cp_prof), pr.size()*8); (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_cp_hprof), hp.size()*8);
+    const CholPersist& P = plan.persist;
+    auto us = [&](unsigned long long a, unsigned long long b0) { return a && b0 ? ((double)a - (double)b0)*0.01 : -1.0; };
+    fprintf(stderr, "[cp prof] n=%d ntc=%d helpers=%d   (us from the start of P3: wave 0 reads D | pivots | writes L^-1;  team: flags of L^-1, L(s+1,s) | [next row polled, measured from P3 as well] | staged row in LDS | trsm | last flag;  step)\n", n, P.ntc, P.nhelpers);
+    double sum[10] = {0}; int c2 = 0;
+    for (int s = 2; s + 3 < P.ntc; ++s, ++c2) {
+      const unsigned long long* q0 = &pr[(s + 1)*16];
+      const double v[10] = {us(q0[1], q0[0]), us(q0[9], q0[1]), us(q0[10], q0[9]), us(q0[2], q0[10]), us(q0[3], q0[1]), us(q0[4], q0[1]), us(q0[5], q0[1]), us(q0[6], q0[1]), us(q0[7], q0[1]), us(q0[8], q0[0])};
+      for (int i = 0; i < 10; ++i) sum[i] += v[i];
+      if (s == 10) fprintf(stderr, "  step 10, wave 1 after the trsm: X2 stores issued %+.2f  products done %+.2f  drained %+.2f  flag %+.2f\n", us(q0[11], q0[6]), us(q0[12], q0[6]), us(q0[13], q0[6]), us(q0[7], q0[6]));
+      if (s >= 10 && s < 13) {
+        fprintf(stderr, "  step %2d: P1+P2 %5.2f | D in %5.2f pivots %5.2f L^-1 out %5.2f | published %5.2f polled %5.2f in LDS %5.2f trsm %5.2f flag %5.2f | step %5.2f\n", s, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+        const unsigned long long pub = pr[(s - 1 + 1)*16 + 3], pub2 = pr[(s - 1 + 1)*16 + 7];
+        for (int hi = 0; hi < P.nhelpers && hi < 8192; ++hi) {
+          const CpHelper& h = P.helpers[hi];
+          if (h.ti != s + 2 || !((h.kind == 0 && h.tj == s - 1) || h.kind == 1)) continue;
+          fprintf(stderr, "      helper (%d,%d) %s: last poll ok %+6.2f  diag poll ok %+6.2f  published %+6.2f   (vs publish of L^-1(%d) / L(%d,%d); L(%d,%d) came %+5.2f)\n", h.ti, h.tj, h.kind ? "band" : "far ",
+                  us(hp[hi*4 + 1], pub), us(hp[hi*4 + 2], pub), us(hp[hi*4 + 3], pub), s - 1, s, s - 1, s + 1, s - 1, us(pub2, pub));
+        }
+      }
+    }
+    if (c2) fprintf(stderr, "  mean over %d steps: P1+P2 %.2f | D in %.2f pivots %.2f L^-1 out %.2f | published %.2f polled %.2f in LDS %.2f trsm %.2f flag %.2f | step %.2f\n", c2,
+                    sum[0]/c2, sum[1]/c2, sum[2]/c2, sum[3]/c2, sum[4]/c2, sum[5]/c2, sum[6]/c2, sum[7]/c2, sum[8]/c2, sum[9]/c2);
+  }
+#endif
   for (auto& e : ev) (void)hipEventDestroy(e);
   for (int q = 0; q < nsys; ++q) HIPCK(hipMemcpy(x + (size_t)q*n, work.p + q*stride + (size_t)n*n, (size_t)n*8, hipMemcpyDeviceToHost));
   if (plan.use_persist && plan.persist.ok) {

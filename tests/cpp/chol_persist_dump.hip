@@ -18,8 +18,10 @@ int main() {
   printf("%d %d %d %d %d %d %d\n", P.n, P.ntc, P.nslots, P.nbslots, P.nhelpers, mcp::CP_W, mcp::CP_BACK_NEAR);
   for (int i = 0; i <= P.ntc; ++i) { for (int j = 0; j < P.ntc; ++j) printf("%d ", P.slot_of[(size_t)i*P.ntc + j]); printf("\n"); }
   for (int i = 0; i <= P.ntc; ++i) { for (int j = 0; j < P.ntc; ++j) printf("%d ", P.bslot_of[(size_t)i*P.ntc + j]); printf("\n"); }
+  for (int i = 0; i <= P.ntc; ++i) printf("%d ", P.delta_of[i]);
+  printf("\n");
   for (const mcp::CpHelper& h : P.helpers) {
-    printf("%d %d %d %d %d %d %d:", h.ti, h.tj, h.slot, h.dslot, h.kind, h.in_s, h.nupd);
+    printf("%d %d %d %d %d %d %d %d %d %d:", h.ti, h.tj, h.slot, h.dslot, h.kind, h.in_s, h.nupd, h.pre, h.pre_flag, h.pre_diag);
     for (int u = 0; u < h.nupd; ++u) printf(" %d,%d", P.upd[h.upd0 + u].x, P.upd[h.upd0 + u].y);
     printf("\n");
   }

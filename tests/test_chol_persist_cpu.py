@@ -30,18 +30,19 @@ def _plan(exe, n, pattern, dense=False):
     assert (n_, ntc_) == (n, ntc)
     slot_of = np.array([[int(v) for v in lines[1 + i].split()] for i in range(ntc + 1)])
     bslot_of = np.array([[int(v) for v in lines[2 + ntc + i].split()] for i in range(ntc + 1)])
+    delta_of = [int(v) for v in lines[3 + 2 * ntc].split()]
     helpers = []
-    for ln in lines[3 + 2 * ntc:3 + 2 * ntc + nh]:
+    for ln in lines[4 + 2 * ntc:4 + 2 * ntc + nh]:
         head, _, rest = ln.partition(":")
-        ti, tj, slot, dslot, kind, in_s, nupd = (int(v) for v in head.split())
+        ti, tj, slot, dslot, kind, in_s, nupd, pre, pre_flag, pre_diag = (int(v) for v in head.split())
         upd = [tuple(int(v) for v in it.split(",")) for it in rest.split()]
         assert len(upd) == nupd
-        helpers.append(dict(ti=ti, tj=tj, slot=slot, dslot=dslot, kind=kind, in_s=in_s, upd=upd))
+        helpers.append(dict(ti=ti, tj=tj, slot=slot, dslot=dslot, kind=kind, in_s=in_s, upd=upd, pre=pre, pre_flag=pre_flag, pre_diag=pre_diag))
     far = []
-    for ln in lines[3 + 2 * ntc + nh:]:
+    for ln in lines[4 + 2 * ntc + nh:]:
         _, _, rest = ln.partition(":")
         far.append([tuple(int(v) for v in it.split(",")) for it in rest.split()])
-    return dict(n=n, ntc=ntc, nslots=nslots, nbslots=nbslots, W=W, near=near, slot_of=slot_of, bslot_of=bslot_of, helpers=helpers, far=far)
+    return dict(n=n, ntc=ntc, nslots=nslots, nbslots=nbslots, W=W, near=near, slot_of=slot_of, bslot_of=bslot_of, delta_of=delta_of, helpers=helpers, far=far)
 
 
 class Wait(Exception):
@@ -49,7 +50,8 @@ class Wait(Exception):
 
 
 def _tile_of(S, rhs, n, ntc, ti, tj):
-    """A(ti, tj) as cp_load_A reads it: zero beyond the matrix; block row ntc = the right-hand side in its first row."""
+    """A(ti, tj) as cp_load_A reads it: beyond the matrix a diagonal tile continues as the identity, every other tile as zero; block
+    row ntc = the right-hand side in its first row."""
     T = np.zeros((NB, NB))
     c0 = tj * NB
     c1 = min(n, c0 + NB)
@@ -59,13 +61,16 @@ def _tile_of(S, rhs, n, ntc, ti, tj):
     r0 = ti * NB
     r1 = min(n, r0 + NB)
     T[:r1 - r0, :c1 - c0] = S[r0:r1, c0:c1]
+    if ti == tj:
+        for r in range(r1 - r0, NB):
+            T[r, r] = 1.0
     return T
 
 
-def _potrf(D, nbe):
-    """cp_potrf: identity beyond nbe, returns L^-1 (what the kernels keep of a diagonal tile)."""
-    Dp = np.eye(NB)
-    Dp[:nbe, :nbe] = np.tril(D[:nbe, :nbe]) + np.tril(D[:nbe, :nbe], -1).T
+def _potrf(D):
+    """cp_potrf: reads the lower triangle of the whole tile (it arrives with the identity beyond the matrix), returns L^-1 (what the
+    kernels keep of a diagonal tile)."""
+    Dp = np.tril(D) + np.tril(D, -1).T
     return np.linalg.inv(np.linalg.cholesky(Dp))
 
 
@@ -82,7 +87,8 @@ def _replay_factor(P, S, rhs, rng):
 
     def helper(h):
         acc = _tile_of(S, rhs, n, ntc, h["ti"], h["tj"]) if h["in_s"] else np.zeros((NB, NB))
-        for (sa, sb) in h["upd"]:
+        via_pre = h["kind"] == 1 and h["pre"] >= 0
+        for (sa, sb) in (h["upd"][:-1] if via_pre else h["upd"]):
             while True:
                 try:
                     A, B = need(Lt, sa), need(Lt, sb)
@@ -90,6 +96,20 @@ def _replay_factor(P, S, rhs, rng):
                 except Wait:
                     yield
             acc = acc - A @ B.T
+        if via_pre:
+            # last update of a band tile: the far tile of its row is NOT waited for -- its sum before the solve is, and L^-1 of the column
+            sa, sb = h["upd"][-1]
+            while True:
+                try:
+                    X = need(Bt, ("pre", h["pre"])) @ need(Lt, h["pre_diag"]).T
+                    B = X if sb == sa else need(Lt, sb)
+                    break
+                except Wait:
+                    yield
+            acc = acc - X @ B.T
+        if h["kind"] == 0 and h["pre"] >= 0:
+            Bt[("pre", h["pre"])] = acc.copy()
+            yield
         if h["kind"] == 1:
             assert h["dslot"] not in Bt
             Bt[h["dslot"]] = acc
@@ -118,7 +138,7 @@ def _replay_factor(P, S, rhs, rng):
                 if i1 < ntc:
                     Dt[i1] = Dt[i1] - X1 @ X1.T
             if i1 < ntc:
-                Dv[i1] = _potrf(Dt[i1], min(NB, n - i1 * NB))
+                Dv[i1] = _potrf(Dt[i1])
             if s < 0:
                 continue
             Lt[slot_of[s, s]] = Dv[s]
@@ -132,6 +152,10 @@ def _replay_factor(P, S, rhs, rng):
                 Tc = Bt[bslot_of[i2, i1]].copy()
                 X2 = T2 @ Dv[s].T
                 Tc = Tc - X2 @ X1.T
+                if P["delta_of"][i2] >= 0:              # the late product of tile (s+2, s+1), summed with a minus sign by its helper
+                    while P["delta_of"][i2] not in Bt:
+                        yield
+                    Tc = Tc + Bt[P["delta_of"][i2]]
                 if i2 < ntc:
                     Dt[i2] = Bt[bslot_of[i2, i2]] - X2 @ X2.T
                 Lt[slot_of[i2, s]] = X2
@@ -231,15 +255,26 @@ def test_persistent_plan_replays_to_the_dense_solution(dump_exe, n, kind):
     # structure: every tile has exactly one helper, in dependency order; band tiles end their own sums at column i - W
     seen = set()
     key_prev = None
+    n_delta = 0
     for h in P["helpers"]:
         ti, tj = h["ti"], h["tj"]
-        assert P["slot_of"][ti, tj] == h["slot"] and (ti, tj) not in seen
-        seen.add((ti, tj))
-        band = ti - tj < W
-        assert h["kind"] == int(band)
-        key = (ti - W if band else tj, h["kind"], ti)
+        if ti < 0:                       # the late product of band tile (i, i-1): L(i, i-W) L(i-1, i-W)^T on its own
+            i = -1 - ti
+            n_delta += 1
+            assert tj == i - 1 and h["kind"] == 1 and not h["in_s"] and h["slot"] == P["nslots"] + i and h["dslot"] == P["delta_of"][i]
+            assert h["upd"] == [(P["slot_of"][i, i - W], P["slot_of"][i - 1, i - W])]
+            key = (i - W, 2, i)
+        else:
+            assert P["slot_of"][ti, tj] == h["slot"] and (ti, tj) not in seen
+            seen.add((ti, tj))
+            band = ti - tj < W
+            assert h["kind"] == int(band)
+            key = (ti - W if band else tj, h["kind"], ti)
+            if band and tj == ti - 1 and P["delta_of"][ti] >= 0:
+                assert all(sa != P["slot_of"][ti, ti - W] for (sa, _) in h["upd"])      # ... which the tile's own helper leaves out
         assert key_prev is None or key_prev <= key
         key_prev = key
+    assert n_delta == sum(1 for d in P["delta_of"] if d >= 0)
     assert len(seen) == P["nslots"] == int((P["slot_of"] >= 0).sum())
     for i in range(ntc):
         for j in range(max(0, i - W + 1), i + 1):
@@ -250,7 +285,7 @@ def test_persistent_plan_replays_to_the_dense_solution(dump_exe, n, kind):
     rhs = rng.normal(size=n)
     S_seen = S.copy()
     for h in P["helpers"]:
-        if not h["in_s"] and h["ti"] < ntc:
+        if not h["in_s"] and 0 <= h["ti"] < ntc:
             r0, c0 = h["ti"] * NB, h["tj"] * NB
             assert np.abs(S[r0:r0 + NB, c0:c0 + NB]).max() == 0.0
             S_seen[r0:r0 + NB, c0:c0 + NB] = np.nan                              # poison: reading it would show
