@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = "r03"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
+ROUND = "r04"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
@@ -45,8 +45,8 @@ STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ;
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
     "select": [("mcp::k_select_pass", 2), ("mcp::k_select_gather", 1), ("mcp::k_select_small", 1)],
-    "cholesky": [("mcp::k_chol_step", -1)],
-    "tri_solve": [("mcp::k_chol_back", 1)],
+    "cholesky": [("mcp::k_chol_persist", 1)],        # one persistent launch per solve (ba_chol2.h); MCP_BA_CHOL_PERSIST=0: k_chol_step x steps
+    "tri_solve": [("mcp::k_chol_back2", 1)],
 }
 
 

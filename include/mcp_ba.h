@@ -92,7 +92,7 @@ typedef struct mcp_ba_timing {
   int    n_collectives_main, n_collectives_spec;
   double collective_bytes_main, collective_bytes_spec;
   int    n_median_fast;   /* medians that needed one collective (digit histograms rode on the accepted trial's all-reduce) */
-  int    pad_;
+  int    n_persist_fallbacks;   /* solves redone with the per-step kernels after a hand-off of the one-launch factorisation timed out (0 in a healthy run) */
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);

@@ -52,13 +52,14 @@ struct CpArgs {
   const int* slot_of; const int* bslot_of; const int* delta_of; const int* steps; const CpHelper* helpers; const int2* upd;
   double* Lt; size_t lt_stride;               // published L tiles / L_kk^-1, per system
   double* Bt; size_t bt_stride;               // band tiles handed to the critical workgroup, per system
+  int test_fail_step;             // >= 0: the critical workgroup raises the error word at that step (test of the fall-back)
   int* flags; int nslots; int nflags; int* err; int* fail; const int* epoch;      // epoch[q]: bumped by the back-substitution launch (graph replay safe)
   double* xbuf; double* fbuf; int vec_stride;
 };
 struct CpBackArgs {
   const double* Lt; size_t lt_stride; const int* slot_of; int n, ntc, nsys, ncols;
   const int* far_start; const int* far_slot; const int* far_row;      // per block column: its far tiles, rows descending
-  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch;
+  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail;
 };
 
 #ifdef MCP_CP_PROF
@@ -363,6 +364,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       const int sd = se[CPS_SD], s1 = se[CPS_S1];
       const int dl = (row2 && ctl[1]) ? se[CPS_DL] : -1;        // band slot of row s+2's late product, -1 = none
       chol_d4 dq0 = {0.0, 0.0, 0.0, 0.0}, dq1 = dq0;
+      if (a.test_fail_step == s && t == 64) { cp_flag_store(err, code | 0xf); ctl[1] = 0; }
       // the late product's flag: asked for first (it was raised a step ago), looked at after the work below
       int dflag = want_band;
       if (dl >= 0) dflag = cp_flag_load_early(flags + a.nslots + i2);
@@ -705,7 +707,10 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
     } else if (k > 0) prepare(k - 1, wave);
     __syncthreads();
   }
-  if (t == 0) a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
+  if (t == 0) {
+    a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
+    if (cp_flag_load(err) != 0 && a.fail) atomicOr(a.fail + q, 4);      // a hand-off timed out somewhere: the host falls back to the per-step kernels
+  }
   if (!ctl[0]) return;
   for (int i = t; i < n; i += CP_THREADS) a.xout[q*a.sys_stride + i] = xs[i];
 }
@@ -734,6 +739,7 @@ struct CholPersist {
   CpHelper* d_helpers = nullptr; int2* d_upd = nullptr;
   double *d_Lt = nullptr, *d_Bt = nullptr, *d_x = nullptr, *d_f = nullptr;
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
+  int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
   ~CholPersist() { release(); }
   void release() {
     void* ps[] = {d_steps, d_delta_of, d_epoch, d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
@@ -839,6 +845,7 @@ struct CholPersist {
         hipMalloc((void**)&d_x, sizeof(double)*vec_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_f, sizeof(double)*vec_stride*max_sys) != hipSuccess) return -1;
     if (hipMemset(d_flags, 0, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMemset(d_err, 0, sizeof(int)*max_sys*4) != hipSuccess) return -1;
     { const int one[max_sys] = {1, 1, 1, 1}; if (hipMalloc((void**)&d_epoch, sizeof one) != hipSuccess || hipMemcpy(d_epoch, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return -1; }
+    { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
     ok = true;
     return 0;
   }
@@ -860,7 +867,8 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.delta_of = P.d_delta_of; a.steps = P.d_steps; a.helpers = P.d_helpers; a.upd = P.d_upd;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.Bt = P.d_Bt + q0*P.bt_stride; a.bt_stride = P.bt_stride;
   a.flags = P.d_flags + (size_t)q0*P.nflags; a.nslots = P.nslots; a.nflags = P.nflags; a.err = P.d_err + q0; a.fail = fail + q0;
-  a.epoch = P.d_epoch + q0;
+  a.epoch = P.d_epoch + q0; P.fail_ptr = fail;
+  a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
   hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nhelpers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
   return 0;
@@ -871,7 +879,7 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.slot_of = P.d_slot_of; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.ncols = P.ntc;
   a.far_start = P.d_far_start; a.far_slot = P.d_far_slot; a.far_row = P.d_far_row;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
-  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0;
+  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0; a.fail = P.fail_ptr ? P.fail_ptr + q0 : nullptr;
   const size_t lds = (size_t)(4*CP_TILE + 2*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double);
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
   return 0;

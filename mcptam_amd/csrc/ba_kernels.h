@@ -217,7 +217,9 @@ k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const d
     const double t = block_sum<256>(v, lds);
     if (threadIdx.x == 0) out[off + a] = t;
   }
-  if (fail && threadIdx.x == 0) out[off + 3] = (fail[0] != 0) ? 1.0 : 0.0;
+  // (bit 2: a hand-off of the one-launch factorisation timed out, ba_chol2.h -- the host redoes the solve with the per-step kernels;
+  //  1e9 survives the sum over ranks as "some rank had it")
+  if (fail && threadIdx.x == 0) out[off + 3] = (fail[0] & 4) ? 1e9 : ((fail[0] != 0) ? 1.0 : 0.0);
   if (ride_src && threadIdx.x == 0) out[ride_dst] = ride_src[0];
   if (mail) {
     __syncthreads();                                 // thread 0's stores to `out` above; the other entries come from earlier kernels of the stream

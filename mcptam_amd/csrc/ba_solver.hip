@@ -281,7 +281,7 @@ struct mcp_ba {
   // (MCP_BA_OVERLAP: 0 = one stream, 1 = the speculative systems together on a second stream, 2 = system 1 on the second and
   // systems 2.. on a third stream, so that the system the SECOND trial needs is ready as early as the first one's)
   hipStream_t st2 = nullptr, st3 = nullptr; hipEvent_t ev_fork = nullptr, ev_spec = nullptr, ev_spec3 = nullptr;
-  bool spec_pending = false, spec3_pending = false; int spec2_from = 1, spec3_from = MAX_SYS; int overlap_spec = 1, main_sys = 1;
+  bool spec_pending = false, spec3_pending = false; int spec2_from = 1, spec3_from = MAX_SYS; int overlap_spec = 1, main_sys = 1; bool overlap_auto = true;
   std::vector<mcp_camera> cams;
   int robust = 1, tukey = 1, verbose = 0;
   mcp_ba_params prm;
@@ -596,7 +596,10 @@ struct mcp_ba {
     (void)hipDeviceSynchronize();
     size_t base = 0;
     for (size_t i = 0; i < evt_log.size(); ++i) {
-      if (!std::strcmp(evt_log[i].first, "iter")) { base = i; fprintf(stderr, "\n[evt]"); }
+      if (!std::strcmp(evt_log[i].first, "iter")) {
+        float gap = 0; if (i) (void)hipEventElapsedTime(&gap, evt_log[i - 1].second, evt_log[i].second);       // last mark of the previous iteration -> this one's start
+        base = i; fprintf(stderr, "\n[evt] (+%.0f)", gap*1e3);
+      }
       float ms = 0; (void)hipEventElapsedTime(&ms, evt_log[base].second, evt_log[i].second); fprintf(stderr, " %s %.0f", evt_log[i].first, ms*1e3);
     }
     fprintf(stderr, "\n");
@@ -607,6 +610,7 @@ struct mcp_ba {
   int linearize();
   int build_system(int nsys, SysBatch& sb, int q0 = 0, hipStream_t on = nullptr);
   int solve_trial(double lam, bool& ok2, double ni = 0);
+  int persist_fallback(double lam, bool& ok2, double ni);
   int compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda);
   int final_stats(int nCounter);
 };
@@ -1746,6 +1750,7 @@ int mcp_ba::solve_chain(hipStream_t s, int n, int q0) {
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   int defer_n1 = 0, defer_n2 = 0, defer_nsys = 0;
+  bool ahead_single = false;      // whole batch solved on the main stream: the speculative systems' trials can still be evaluated ahead on the second
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
     // an earlier trial of this iteration already built and solved this system speculatively (possibly on the second stream)
     ++sys_cur;
@@ -1763,6 +1768,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       ++dbg_pre;
       if (!nfl_total) h_res[1] = h_res[2] = 0.0;
       h_res[1] += h_res[4]; h_res[2] += h_res[5];
+      if (h_res[3] >= 1e9) return persist_fallback(lam, ok2, ni);
       ok2 = (h_res[3] == 0.0);
       timing.n_trials++;
       return 0;
@@ -1778,7 +1784,11 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (cancel_spec_trials()) return -1;   // (a re-solve inside an iteration: nothing of the previous batch is wanted any more)
     if (join_spec()) return -1;            // (... and its stragglers first)
     HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
-    const int ov = multi() ? std::min(overlap_spec, 1) : overlap_spec;      // several ranks: one speculative stream, the one lane 1 belongs to
+    // One rank, one-launch factorisation: every system of the batch has its own critical workgroup, four systems take the time of
+    // one, so the batch stays on the main stream (measured: 990 vs 940 LM it/s; MCP_BA_OVERLAP=1 splits it as the per-step kernels
+    // want it).  Several ranks: one speculative stream, the one lane 1 belongs to.
+    const int ov_single = (overlap_auto && plan.use_persist && plan.persist.ok) ? 0 : overlap_spec;
+    const int ov = multi() ? std::min(overlap_spec, 1) : ov_single;
     const bool split = ov && nsys > 1 && np > 0 && st2;
     if (split) {
       // system 0 -- the one this trial needs -- alone on the main stream; the speculative systems behind the fork on the second
@@ -1830,6 +1840,12 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
         tic(ST_CHOL); chol_factor(st, plan, S(), d_fail.p, nsys, red_stride); toc();
         tic(ST_SOLVE); chol_back(st, plan, S(), nsys, red_stride); toc();
       }
+      if (st2 && nsys > 1 && !multi() && spec_trials && use_mailbox && !prm.profile) {
+        // every system of the batch is solved: while this trial runs on the main stream, the next one's step is applied and evaluated
+        // on the second stream (enqueue_spec_trial), so that a rejection finds its result waiting
+        HIPCK(hipEventRecord(ev_fork, st)); HIPCK(hipStreamWaitEvent(st2, ev_fork, 0));
+        spec2_from = 1; spec3_from = MAX_SYS; ahead_single = true;
+      }
     }
     }
     spec_ok = (nsys > 1);
@@ -1878,7 +1894,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   if (defer_nsys) {
     if (run_ahead(1)) return -1;
     if (spec_trials >= 2 && !multi()) for (int q = 2; q < defer_nsys; ++q) if (run_ahead(q)) return -1;
-  }
+  } else if (ahead_single) { if (run_ahead(1)) return -1; }
   if (mailbox) {
     // the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
     if (wait_mail(0, mail_ticket0, multi() ? MAIL_TICKET : 29)) return -1;
@@ -1886,9 +1902,27 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   if (multi()) { tr_pred_ok[sys_cur] = h_res[MAIL_PRED_OK] != 0.0; tr_ovf[sys_cur] = h_res[MAIL_OVERFLOW] != 0.0; }
   if (!nfl_total) h_res[1] = h_res[2] = 0.0;
   h_res[1] += h_res[6]; h_res[2] += h_res[7];
+  if (h_res[3] >= 1e9) return persist_fallback(lam, ok2, ni);
   ok2 = (h_res[3] == 0.0);
   timing.n_trials++;
   return 0;
+}
+// A hand-off of the one-launch factorisation (ba_chol2.h) timed out somewhere in the batch this trial belongs to: its numbers
+// are void.  The reduced systems themselves are intact (that factorisation never writes S), but simplest and safest is to redo
+// the whole solve of this lambda with the per-step kernels, which this handle then keeps for the rest of its life.
+int mcp_ba::persist_fallback(double lam, bool& ok2, double ni) {
+  if (!plan.use_persist) { set_err("the factorisation reported a hand-off time-out although the one-launch path is off"); return -1; }
+  static std::atomic<int> warned{0};
+  if (!warned.exchange(1)) fprintf(stderr, "mcptam_hip: a hand-off of the one-launch Cholesky factorisation timed out; falling back to the per-step kernels\n");
+  plan.use_persist = false;
+  spec_ok = false;
+  if (cancel_spec_trials()) return -1;
+  if (join_spec()) return -1;
+  HIPCK(hipStreamSynchronize(st));
+  if (st2) HIPCK(hipStreamSynchronize(st2));
+  HIPCK(hipMemsetAsync(plan.persist.d_err, 0, sizeof(int)*CholPersist::max_sys, st));
+  timing.n_persist_fallbacks++;
+  return solve_trial(lam, ok2, ni);
 }
 
 int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda) {
@@ -2186,7 +2220,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   SolverStreams* pool = use_pool ? &solver_streams(dev) : nullptr;
   if (pool && pool->ok) { h->pooled = true; h->st = pool->main; }
   else if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
-  { const char* e = getenv("MCP_BA_OVERLAP"); if (e) h->overlap_spec = atoi(e); }
+  { const char* e = getenv("MCP_BA_OVERLAP"); if (e) { h->overlap_spec = atoi(e); h->overlap_auto = false; } }
   { const char* e = getenv("MCP_BA_MAILBOX"); if (e) h->use_mailbox = atoi(e); }
   { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
   { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }

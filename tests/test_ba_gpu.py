@@ -914,3 +914,81 @@ def test_failed_factorisation_applies_the_stale_step_like_g2o(gpu_required, k, m
 def _orc_nc(cams):
     o = _orc(cams); o.DisableConvergence(True)
     return o
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the reduced system factored in ONE persistent launch (ba_chol2.h)
+
+@pytest.mark.parametrize("n", [1, 32, 33, 97, 200, 1194])
+def test_one_launch_factorisation_matches_numpy(gpu_required, n):
+    """k_chol_persist seen from outside: every off-diagonal tile of L, L_kk^-1 in place of the diagonal tiles (what the kernels keep)
+    and y = L^-1 b against numpy, no hand-off time-out, no failure flag."""
+    from mcptam_amd.chain_bundle import chol_debug_factor
+    rng = np.random.default_rng(4000 + n)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    L, y, err, fail = chol_debug_factor(np.tril(A), b)
+    assert err == 0 and fail == 0
+    Lr = np.linalg.cholesky(A)
+    ntc = (n + 31) // 32
+    for i in range(ntc):
+        for j in range(i + 1):
+            g, r = L[32 * i:32 * i + 32, 32 * j:32 * j + 32], Lr[32 * i:32 * i + 32, 32 * j:32 * j + 32]
+            if i == j:
+                r = np.linalg.inv(r)
+            assert np.abs(g - r).max() <= 1e-11 * np.abs(r).max(), (i, j)
+    yr = np.linalg.solve(Lr, b)
+    assert np.abs(y - yr).max() <= 1e-11 * np.abs(yr).max()
+
+
+@pytest.mark.parametrize("n,nsys,band", [(1194, 1, 6), (1194, 4, 6), (1194, 3, 2), (700, 2, 0), (2994, 2, 6)])
+def test_one_launch_factorisation_on_banded_plans(gpu_required, n, nsys, band):
+    """Banded + bordered tile plans (a loop trajectory's co-visibility; band 2 < the critical workgroup's own band: tiles it owns
+    that the assembly never writes start from zero), several systems in one launch; the solutions against numpy."""
+    from mcptam_amd.chain_bundle import chol_time
+    rng = np.random.default_rng(77 + n + band)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T + n * np.eye(n)
+    if band:
+        ntc = (n + 31) // 32
+        for i in range(ntc):
+            for j in range(ntc):
+                lo, hi = max(i, j), min(i, j)
+                if not (lo - hi <= band or lo >= ntc - band):
+                    A[32 * i:32 * i + 32, 32 * j:32 * j + 32] = 0.0
+        A += 4 * n * np.eye(n)
+    b = rng.normal(size=n)
+    tf, tb, x = chol_time(np.tril(A), b, nsys=nsys, reps=5, band=band)
+    for q in range(nsys):
+        ref = np.linalg.solve(A + q * np.eye(n), b)
+        assert rel_err(x[q], ref) < 1e-11, (q, rel_err(x[q], ref))
+
+
+def test_one_launch_and_step_kernels_agree_on_the_metric_map(gpu_required, monkeypatch):
+    """Same LM run with the one-launch factorisation and with the per-step kernels: another summation order inside the factorisation,
+    so not the same bits -- but the same branches and the same state to 1e-9."""
+    from mcptam_amd import synth
+    p = synth.make_config("metric")
+    a = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
+    monkeypatch.setenv("MCP_BA_CHOL_PERSIST", "0")
+    b = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
+    assert [(l["trials"], l["accepted"]) for l in a["logs"]] == [(l["trials"], l["accepted"]) for l in b["logs"]]
+    assert rel_err(a["R"], b["R"]) < 1e-9 and rel_err(a["t"], b["t"]) < 1e-9 and rel_err(a["X"], b["X"]) < 1e-9
+    assert a["outliers"] == b["outliers"]
+
+
+def test_handoff_timeout_falls_back_to_the_step_kernels(gpu_required, monkeypatch):
+    """A hand-off of the one-launch factorisation that never arrives (forced: the critical workgroup of the third factorisation raises
+    the error word) must not hang and must not be taken for a result: every spinner leaves, the failure flag says so, the host
+    redoes that solve with the per-step kernels and keeps them."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2")
+    ref = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
+    monkeypatch.setenv("MCP_BA_TEST_PERSIST_FAIL", "3")
+    bundle = _gpu(p.cams, disable_convergence=True)
+    alt = run_bundle(bundle, p, 6)
+    assert bundle.Timing()["n_persist_fallbacks"] == 1
+    assert alt["rc"] == ref["rc"] == 6
+    assert [(l["trials"], l["accepted"]) for l in alt["logs"]] == [(l["trials"], l["accepted"]) for l in ref["logs"]]
+    assert rel_err(alt["R"], ref["R"]) < 1e-9 and rel_err(alt["t"], ref["t"]) < 1e-9 and rel_err(alt["X"], ref["X"]) < 1e-9
