@@ -2054,7 +2054,9 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           const double sf = std::max(1./3., alpha);
           lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
           cur = last_tr;                             // discardTop: the trial state becomes current
-          sel_src = multi() ? sys_cur : -1;          // ... and the digit histograms that rode on its all-reduce describe the new chi2 array
+          // ... and the digit histograms that rode on its all-reduce describe the new chi2 array -- unless the factorisation had failed:
+          // then the accepted state is the STALE step's (negative scale), whose chi2 never rode on anything
+          sel_src = (multi() && ok2) ? sys_cur : -1;
         } else {
           lambda *= ni; ni *= 2; accepted = 0;       // pop: the current buffers were never touched
         }

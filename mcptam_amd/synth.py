@@ -341,6 +341,42 @@ def merge_shards(shards):
                    true_base_R=a.true_base_R, true_base_t=a.true_base_t, true_world=np.concatenate(tw))
 
 
+def partition(p, world, rank=None):
+    """Split ONE map over `world` ranks the way SURVEY.md 8(e) prescribes: points sorted by the MKF they are expressed in, cut into
+    contiguous blocks that balance the MEASUREMENT counts; every measurement lives with its point's owner; poses, cameras and the
+    fixed flags are replicated.  What BundleAdjusterMulti hands over is one population (src/BundleAdjusterMulti.cc:90-200) -- this is
+    the step that turns it into the per-rank shards the sharded solve takes (BASELINE c4: one 800k-measurement map over 8 GPUs).
+    Returns the list of shard Problems (or shard `rank` alone); shard.part = dict(points=map point indices in shard order,
+    meas=map measurement indices in shard order).  merge_shards() of the result is the map again up to the point order."""
+    assert world >= 1
+    N, M = p.n_points, p.n_meas
+    per_pt = np.bincount(p.ms_pt, minlength=N).astype(np.int64)
+    order = np.argsort(p.pt_src[:, 0], kind="stable")              # by source MKF, ties in map order
+    cum = np.cumsum(per_pt[order])
+    # block b ends where the running measurement count first reaches (b + 1) M / world
+    cuts = [0] + [int(np.searchsorted(cum, (b + 1) * M / world, side="left")) + 1 for b in range(world - 1)] + [N]
+    cuts = [min(max(c, 0), N) for c in cuts]
+    for b in range(1, len(cuts)):
+        cuts[b] = max(cuts[b], cuts[b - 1])
+    owner = np.empty(N, dtype=np.int64)
+    for b in range(world):
+        owner[order[cuts[b]:cuts[b + 1]]] = b
+    shards = []
+    for b in (range(world) if rank is None else [rank]):
+        pts = order[cuts[b]:cuts[b + 1]]
+        pmap = -np.ones(N, dtype=np.int64)
+        pmap[pts] = np.arange(len(pts))
+        ms = np.flatnonzero(owner[p.ms_pt] == b)                      # map order is kept: MKF, camera, point
+        q = Problem(cams=p.cams, mode=p.mode, n_mkf=p.n_mkf, base_R=p.base_R.copy(), base_t=p.base_t.copy(), base_fixed=p.base_fixed.copy(),
+                    cam_R=p.cam_R, cam_t=p.cam_t, pt_x=p.pt_x[pts].copy(), pt_src=p.pt_src[pts].copy(), pt_fixed=p.pt_fixed[pts].copy(),
+                    ms_mkf=p.ms_mkf[ms].copy(), ms_cam=p.ms_cam[ms].copy(), ms_pt=pmap[p.ms_pt[ms]].astype(p.ms_pt.dtype),
+                    ms_uv=p.ms_uv[ms].copy(), ms_level=p.ms_level[ms].copy(), true_base_R=p.true_base_R, true_base_t=p.true_base_t,
+                    true_world=None if p.true_world is None else p.true_world[pts], rel_R=p.rel_R, rel_t=p.rel_t)
+        q.part = dict(points=pts, meas=ms, rank=b, world=world)
+        shards.append(q)
+    return shards if rank is None else shards[0]
+
+
 # the BASELINE.json configurations (SURVEY.md 8 notation)
 CONFIGS = {
     "c1": dict(n_cams=1, n_mkf=10, n_points=500, per_point=6, mode="single", arc_step=0.3, n_fixed_mkf=2),  # 2 fixed KFs pin the monocular scale gauge

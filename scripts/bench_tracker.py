@@ -103,5 +103,94 @@ def main_c5(frames=10, cpu_frames=1):
     return main(frames=frames, cpu_frames=cpu_frames, size=(1280, 960), cams=8, per_level=(400, 320, 200, 80), label="c5 on one GPU")
 
 
+def per_rank_loop(rank, world, allreduce, frames=10, size=(1280, 960), cams=8, per_level=(400, 320, 200, 80), device=0, barrier=None):
+    """BASELINE config c5 as stated: one camera (or cams / world of them) per GPU.  Per frame this rank runs MakeKeyFrame_Lite and the
+    PatchFinder search for ITS cameras (src/Tracker.cc:303-318, 985-1030) -- no exchange -- and then the ten pose iterations with the
+    other ranks (mcp_track_pose_refine_sharded: the squared errors for the global Tukey median and the 6x6 + 6 accumulator cross the
+    ranks once per iteration, src/Tracker.cc:1040-1075, 1386-1512).  Returns (seconds per frame, pose, found on this rank)."""
+    from mcptam_amd import hip_rt, synth_img
+    from mcptam_amd.keyframe import KeyFrame, make_lite_batch, pack_points, pose_points, track_pose_refine_sharded, track_search_batch, _pose12
+    from mcptam_amd.taylor_camera import camera_array
+    from oracle import OracleKeyFrame
+    assert cams % world == 0
+    mine = list(range(rank*(cams//world), (rank + 1)*(cams//world)))
+    sc = synth_img.make_tracking_scene(size=size)
+    I = (np.eye(3), np.zeros(3))
+    src = [KeyFrame(*size, device=device) for _ in mine]
+    osrc = [OracleKeyFrame(*size) for _ in mine]         # (the synthetic map-point generator wants both; set-up only)
+    pts = []
+    for k in range(len(mine)):
+        src[k].MakeKeyFrame_Lite(sc["imgA"]); src[k].MakeKeyFrame_Rest()
+        osrc[k].MakeKeyFrame_Lite(sc["imgA"]); osrc[k].MakeKeyFrame_Rest()
+        pts.append(synth_img.make_map_points(sc["cam"], src[k], osrc[k], sc["poseA"], sc["depth"], per_level=per_level))
+    cur = [KeyFrame(*size, device=device) for _ in mine]
+    wpos = [np.array([p["world_pos"] for p in pts[k]]) for k in range(len(mine))]
+    packed = [pack_points(pts[k], lambda kf: kf._h) for k in range(len(mine))]
+    carr_mine = camera_array([sc["cam"]]*len(mine))
+    cfb_mine = np.ascontiguousarray(np.stack([_pose12(*I) for _ in mine]))
+    all_cams = [sc["cam"]]*cams
+    cfb_all = [I]*cams
+    frame_img = np.ascontiguousarray(sc["imgB"])
+    ring = [hip_rt.dev_alloc(frame_img.nbytes) for _ in mine]
+    for r in ring:
+        hip_rt.dev_upload(r, frame_img)
+    cap = sum(per_level)*len(mine)            # the same bound on every rank: no rank tracks more points than the generator makes
+
+    def frame():
+        make_lite_batch(cur, ring, on_device=True)
+        outs = track_search_batch(cur, carr_mine, sc["poseB"], cfb_mine, packed, 10, 8)
+        recs = np.concatenate([pose_points(wpos[k], outs[k], mine[k]) for k in range(len(mine))])
+        pose, mu, w, _ = track_pose_refine_sharded(recs, all_cams, cfb_all, sc["poseB"], allreduce=allreduce, rank=rank, world=world, cap=cap)
+        return pose, sum(int(o_["found"].sum()) for o_ in outs)
+
+    frame()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pose, found = frame()
+    if barrier:
+        barrier()
+    return (time.perf_counter() - t0)/frames, pose, found
+
+
+def main_per_rank(argv):
+    """`python -m torch.distributed.run --nproc-per-node N scripts/bench_tracker.py c5 --gpus N [--debug-single-device] [--small]`"""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which"); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--debug-single-device", action="store_true"); ap.add_argument("--small", action="store_true", help="2 x 640x480 cameras instead of 8 x 1280x960 (tests)")
+    a = ap.parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    from mcptam_amd.dist import GlooAllReduce, RcclAllReduce
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    dev = 0 if a.debug_single_device else local
+    torch.cuda.set_device(dev)
+    hook = None
+    if world > 1:
+        dist.init_process_group(backend="gloo" if a.debug_single_device else "nccl", **({} if a.debug_single_device else {"device_id": torch.device("cuda", dev)}))
+        hook = GlooAllReduce(host=False) if a.debug_single_device else RcclAllReduce(torch.device("cuda", dev))
+
+    kw = dict(size=(640, 480), cams=world if world > 1 else 2, per_level=(100, 80, 50, 20)) if a.small else {}
+    bar = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else (lambda: torch.cuda.synchronize())
+    dt, pose, found = per_rank_loop(rank, world, hook, frames=a.frames, device=dev, barrier=bar, **kw)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.debug_single_device else torch.device("cuda", dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        cams_ = kw.get("cams", 8); size_ = kw.get("size", (1280, 960))
+        print(json.dumps({"metric": "Tracker frames/s, camera per GPU (c5: %d x %dx%d over %d ranks)" % (cams_, size_[0], size_[1], world), "value": 1.0/dt,
+                          "unit": "frames/s", "n_gpus": world, "ms_per_frame": dt*1e3, "found_on_rank_0": found, "pose_t": pose[1].tolist(),
+                          "exchange": "per pose iteration: squared errors (global Tukey median) + 6x6+6 accumulator; images and searches stay on their rank",
+                          "debug": "all ranks on one GPU, gloo" if a.debug_single_device else None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    print(json.dumps(main_c5() if len(sys.argv) > 1 and sys.argv[1] == "c5" else main()))
+    if "--gpus" in sys.argv:
+        main_per_rank(sys.argv[1:])
+    else:
+        print(json.dumps(main_c5() if len(sys.argv) > 1 and sys.argv[1] == "c5" else main()))

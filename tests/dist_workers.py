@@ -54,6 +54,25 @@ def sharded_solve_on_one_gpu(rank, world, port, outdir, cfg, iters):
     dist.destroy_process_group()
 
 
+def partitioned_solve_on_one_gpu(rank, world, port, outdir, cfg, iters):
+    """ONE map split by synth.partition (points by source MKF, measurement counts balanced): this rank adjusts its block."""
+    dist = _init(rank, world, port)
+    from mcptam_amd import chain_bundle, synth
+    from mcptam_amd.dist import GlooAllReduce
+    from helpers import collect
+    p = synth.partition(synth.make_config(**cfg), world, rank)
+    b = chain_bundle.ChainBundle(p.cams, True, True, False, device=0)
+    ids = p.populate(b)
+    b.SetAllReduce(GlooAllReduce(host=False), rank, world)
+    rc = b.Compute(iters)
+    R, t, X = collect(b, ids)
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in b.IterLogs()])
+    np.savez(os.path.join(outdir, "part_%d.npz" % rank), rc=rc, R=R, t=t, X=X, logs=logs, points=p.part["points"], sigma_sq=b.GetSigmaSquared(),
+             n_out=len(b.GetOutlierMeasurements()), n_meas=p.n_meas)
+    b.close()
+    dist.destroy_process_group()
+
+
 def _empty_copy(p):
     """The same trajectory and cameras with no point and no measurement (a rank whose shard of the map is empty)."""
     import copy

@@ -909,6 +909,16 @@ def test_failed_factorisation_applies_the_stale_step_like_g2o(gpu_required, k, m
     assert rel_err(gpu["R"], ref["R"]) < 1e-8 and rel_err(gpu["X"], ref["X"]) < 1e-8
     plain = run_bundle(_orc_nc(p.cams), p, 5)
     assert plain["logs"] != ref["logs"], "the forced failure must be visible in the iteration log"
+    # the same through the multi-rank machine (one-rank communicator semantics: identity all-reduce): an ACCEPTED stale step must not
+    # leave the riding median pointed at the failed trial's histograms (the next sigma^2 would be silently wrong)
+    monkeypatch.setenv("MCP_BA_FORCE_MULTI", "1")
+    gm = _gpu(p.cams, disable_convergence=True)
+    gm.SetAllReduce(lambda ptr, count, stream: None, 0, 1)
+    multi = run_bundle(gm, p, 5)
+    assert [l["trials"] for l in multi["logs"]] == [l["trials"] for l in gpu["logs"]] and [l["accepted"] for l in multi["logs"]] == [l["accepted"] for l in gpu["logs"]]
+    for a, b in zip(multi["logs"], gpu["logs"]):
+        assert a["sigma_sq"] == b["sigma_sq"] and a["chi2_end"] == b["chi2_end"]
+    assert np.array_equal(multi["R"], gpu["R"]) and np.array_equal(multi["X"], gpu["X"])
 
 
 def _orc_nc(cams):
@@ -992,3 +1002,53 @@ def test_handoff_timeout_falls_back_to_the_step_kernels(gpu_required, monkeypatc
     assert alt["rc"] == ref["rc"] == 6
     assert [(l["trials"], l["accepted"]) for l in alt["logs"]] == [(l["trials"], l["accepted"]) for l in ref["logs"]]
     assert rel_err(alt["R"], ref["R"]) < 1e-9 and rel_err(alt["t"], ref["t"]) < 1e-9 and rel_err(alt["X"], ref["X"]) < 1e-9
+
+
+@pytest.mark.timeout(900)
+def test_partitioned_map_on_two_ranks_equals_the_oracle_on_the_whole_map(gpu_required):
+    """SURVEY.md 8(e) as BundleAdjusterMulti needs it: ONE population (src/BundleAdjusterMulti.cc:90-200) split by synth.partition --
+    points sorted by source MKF, contiguous blocks balancing the measurement counts -- at the per-rank size of BASELINE c4 over 8 GPUs
+    (12.5k points, 100k measurements per rank), two ranks sharing this GPU through gloo; against the ORACLE's run of the whole map."""
+    import os
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    import dist_workers
+    from mcptam_amd import synth
+    cfg = dict(name="c4", n_mkf=60, n_points=25000)
+    iters = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dist_workers.partitioned_solve_on_one_gpu, args=(2, port, d, cfg, iters), nprocs=2, join=True)
+        r = [dict(np.load(os.path.join(d, "part_%d.npz" % k))) for k in range(2)]
+    p = synth.make_config(**cfg)
+    assert r[0]["X"].shape[0] >= 12000 and r[1]["X"].shape[0] >= 12000
+    assert abs(int(r[0]["n_meas"]) - int(r[1]["n_meas"])) <= 16 and int(r[0]["n_meas"]) + int(r[1]["n_meas"]) == p.n_meas
+    ref = run_bundle(_orc(p.cams), p, iters)
+    assert int(r[0]["rc"]) == int(r[1]["rc"]) == ref["rc"]
+    assert np.array_equal(r[0]["R"], r[1]["R"]) and np.array_equal(r[0]["t"], r[1]["t"])
+    from helpers import rel_err_elem
+    assert rel_err_elem(r[0]["R"], ref["R"]) < 1e-6 and rel_err_elem(r[0]["t"], ref["t"]) < 1e-6
+    for k in range(2):
+        assert rel_err_elem(r[k]["X"], ref["X"][r[k]["points"]]) < 1e-6
+    logs = np.array([[l["chi2_start"], l["chi2_end"], l["lambda_end"], l["sigma_sq"], l["trials"], l["accepted"]] for l in ref["logs"]])
+    assert np.array_equal(r[0]["logs"][:, 4:], logs[:, 4:]) and np.allclose(r[0]["logs"][:, :4], logs[:, :4], rtol=1e-7)
+    assert int(r[0]["n_out"]) + int(r[1]["n_out"]) == len(ref["outliers"])
+
+
+@pytest.mark.timeout(600)
+def test_bench_spawns_its_own_ranks(gpu_required):
+    """`python bench.py --gpus 2` WITHOUT the launcher (how a driver may call it) re-executes itself under torch.distributed.run;
+    here with both ranks on this box's single GPU (--debug-single-device) and the strong-scaling partition of ONE map."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2", "--cpu-iters", "0",
+                          "--scaling", "strong", "--debug-single-device"], capture_output=True, text=True, timeout=500, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "5000 points, 40000 measurements per rank" in d["config"]["workload"]

@@ -904,3 +904,29 @@ def test_track_frame_in_one_submission_equals_the_three_calls(gpu_required, scen
     # search only (n_iter = 0): the pose stays, the weights are zero
     outs, recs, pose0, mu0, w0 = tf.run(None, poses[1], 10, 8, nonlinear=np.zeros(0, dtype=np.uint8), override_sigma=np.zeros(0))
     assert np.array_equal(pose0[0], poses[1][0]) and not mu0.any() and not w0.any()
+
+
+@pytest.mark.timeout(600)
+def test_camera_per_rank_frame_loop_runs_on_two_ranks(gpu_required):
+    """scripts/bench_tracker.py per_rank_loop: BASELINE c5's shape (a camera per GPU: pyramids + FAST + search on the camera's own rank,
+    the pose iterations across the ranks) as a runnable loop -- two ranks on this box's single GPU through gloo; both ranks end every
+    frame on the same pose, and it is the single-device pose of the same two cameras."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "scripts", "bench_tracker.py"), "c5", "--gpus", "2", "--frames", "3", "--small", "--debug-single-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["found_on_rank_0"] > 100
+    out1 = subprocess.run([sys.executable, os.path.join(root, "scripts", "bench_tracker.py"), "c5", "--gpus", "1", "--frames", "2", "--small"],
+                          capture_output=True, text=True, timeout=500, cwd=root, env=env)
+    assert out1.returncode == 0, out1.stdout[-2000:] + out1.stderr[-2000:]
+    one = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
+    assert np.abs(np.array(two["pose_t"]) - np.array(one["pose_t"])).max() < 1e-9
