@@ -311,11 +311,10 @@ def new_pf_states(n):
     return np.zeros(n, dtype=PF_STATE_DTYPE)
 
 
-def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaustive=False, fn=None, handle_of=None):
-    """mcp_patch_sequences: `targets` = list of (keyframe, camera, base_from_world (R, t), cam_from_base (R, t)); `sequences` = list of
-    lists of items dict(point=<point dict>, point_key, target, start_pos=(x, y)); `states` (new_pf_states) is updated in place.
-    Returns one TD_OUT_DTYPE array over all items in order.  fn / handle_of: the oracle's entry point and handle accessor (tests)."""
-    handle_of = handle_of or (lambda kf: kf._h)
+def marshal_patch_sequences(targets, sequences, handle_of, point_handle_of):
+    """The argument block of mcp_patch_sequences (include/mcp_img.h) as ctypes objects: target table, sequence offsets, items.
+    `handle_of(keyframe)` gives the keyframe handle of a target, `point_handle_of(keyframe)` the source-keyframe handle stored in a
+    point record.  Returns (keep-alive tuple, n_targets, table pointer, seq_start array, items pointer, number of items)."""
     cams = [t[1].to_struct() for t in targets]
     tab = (PfTarget * len(targets))()
     for i, (kf, _cam, bfw, cfb) in enumerate(targets):
@@ -328,7 +327,7 @@ def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaust
     flat = [it for seq in sequences for it in seq]
     seq_start = np.zeros(len(sequences) + 1, dtype=np.int32)
     seq_start[1:] = np.cumsum([len(s_) for s_ in sequences])
-    pts = pack_points([it["point"] for it in flat], handle_of if fn is None else (lambda kf: kf))
+    pts = pack_points([it["point"] for it in flat], point_handle_of)
     items = (PfItem * max(len(flat), 1))()
     for i, it in enumerate(flat):
         ctypes.memmove(ctypes.addressof(items[i].point), ctypes.addressof(pts[i]), ctypes.sizeof(TdIn))
@@ -336,16 +335,21 @@ def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaust
         items[i].target = int(it.get("target", 0))
         sp = it.get("start_pos", (0.0, 0.0))
         items[i].start_pos[0], items[i].start_pos[1] = float(sp[0]), float(sp[1])
-    out = np.zeros(max(len(flat), 1), dtype=TD_OUT_DTYPE)
+    return (cams, tab, pts, items, seq_start), len(targets), ctypes.cast(tab, ctypes.c_void_p), seq_start, ctypes.cast(items, ctypes.c_void_p), len(flat)
+
+
+def patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, exhaustive=False):
+    """mcp_patch_sequences: `targets` = list of (keyframe, camera, base_from_world (R, t), cam_from_base (R, t)); `sequences` = list of
+    lists of items dict(point=<point dict>, point_key, target, start_pos=(x, y)); `states` (new_pf_states) is updated in place.
+    Returns one TD_OUT_DTYPE array over all items in order."""
+    keep, ntar, tab, seq_start, items, nflat = marshal_patch_sequences(targets, sequences, lambda kf: kf._h, lambda kf: kf._h)
+    out = np.zeros(max(nflat, 1), dtype=TD_OUT_DTYPE)
     assert states.dtype == PF_STATE_DTYPE and len(states) == len(sequences)
-    f = fn or lib().mcp_patch_sequences
-    rc = f(int(mode), len(targets), ctypes.cast(tab, ctypes.c_void_p), len(sequences), seq_start.ctypes.data, ctypes.cast(items, ctypes.c_void_p),
-           states.ctypes.data, int(rng), int(subpix_its), int(exhaustive), out.ctypes.data)
-    if fn is None:
-        _chk(rc, "patch_sequences")
-    else:
-        assert rc == 0
-    return out[:len(flat)]
+    rc = lib().mcp_patch_sequences(int(mode), ntar, tab, len(sequences), seq_start.ctypes.data, items, states.ctypes.data, int(rng), int(subpix_its),
+                                   int(exhaustive), out.ctypes.data)
+    _chk(rc, "patch_sequences")
+    del keep
+    return out[:nflat]
 
 
 def track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0, estimator="Tukey"):

@@ -449,7 +449,15 @@ def oracle_patch_sequences(mode, targets, sequences, states, rng, subpix_its=0, 
     L.orc_patch_sequences.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     seqs = [[dict(it, point=dict(it["point"], source_kf=it["point"]["source_kf_oracle"]._h)) for it in seq] for seq in sequences]
-    return kf.patch_sequences(mode, targets, seqs, states, rng, subpix_its, exhaustive, fn=L.orc_patch_sequences, handle_of=lambda k: k._h)
+    # the C structs are the C ABI's (include/mcp_img.h), so the product binding's marshaller lays them out; the call is the oracle's own
+    keep, ntar, tab, seq_start, items, nflat = kf.marshal_patch_sequences(targets, seqs, lambda k: k._h, lambda h: h)
+    out = np.zeros(max(nflat, 1), dtype=kf.TD_OUT_DTYPE)
+    assert states.dtype == kf.PF_STATE_DTYPE and len(states) == len(sequences)
+    rc = L.orc_patch_sequences(int(mode), ntar, tab, len(sequences), seq_start.ctypes.data, items, states.ctypes.data, int(rng), int(subpix_its),
+                               int(exhaustive), out.ctypes.data)
+    assert rc == 0
+    del keep
+    return out[:nflat]
 
 
 def oracle_track_pose_update(found, found_pos, image_pos, sqrt_inv_noise, jacobian, override_sigma=-1.0, estimator="Tukey"):
