@@ -220,9 +220,9 @@ __global__ void k_spin_us(long long ticks) { const long long t0 = wall_clock64()
 struct SolverStreams { hipStream_t main = nullptr, spec = nullptr, spec3 = nullptr, tr[mcp::MAX_SYS] = {nullptr, nullptr, nullptr, nullptr}; bool ok = false; int overlapping = 0; };
 static SolverStreams& solver_streams(int device) {
   static std::mutex mu;
-  static SolverStreams pools[16];
+  static std::map<int, SolverStreams> pools;          // by device ordinal (a fixed array indexed by `device & 15` aliased devices 16+ onto 0-15)
   std::lock_guard<std::mutex> lk(mu);
-  SolverStreams& P = pools[device & 15];
+  SolverStreams& P = pools[device];
   if (P.ok) return P;
   if (hipStreamCreateWithFlags(&P.main, hipStreamNonBlocking) != hipSuccess) return P;
   const bool calibrate = [] { const char* e = getenv("MCP_BA_STREAM_CALIBRATE"); return e ? atoi(e) != 0 : true; }();

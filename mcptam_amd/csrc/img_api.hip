@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 #include <limits>
+#include <map>
+#include <memory>
 #include <cmath>
 
 #include "../../include/mcp_img.h"
@@ -337,8 +339,16 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
 // device scratch of the pose iterations, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d |
 // pad 6 d | override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back
 // in one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
-struct RefineScratch { Buf<mcp_pose_point> dp; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; };
-static RefineScratch& refine_scratch() { static thread_local RefineScratch rs; return rs; }
+struct RefineScratch { Buf<mcp_pose_point> dp, dp_keep; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; bool last_multi = false; };
+// one scratch per (thread, device): the buffers live on the device that was current when they were allocated, and a thread that serves
+// keyframes on two devices must not hand one device's kernels the other's pointers
+static RefineScratch& refine_scratch() {
+  static thread_local std::map<int, std::unique_ptr<RefineScratch>> per_dev;
+  int dev = 0; (void)hipGetDevice(&dev);
+  std::unique_ptr<RefineScratch>& p = per_dev[dev];
+  if (!p) p.reset(new RefineScratch());
+  return *p;
+}
 // The iterations enqueued on `st`: the points come from host_pts (uploaded first) or are in the scratch's dp already (host_pts == nullptr:
 // mcp_track_frame packs them on the device).  BaseFromWorld | mu are left at the head of the scratch's dblk, the weights in dw; *prm_err
 // receives the multi-workgroup kernel's give-up flag once the stream has been waited for.
@@ -363,6 +373,7 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   const int use_multi = [] { const char* e = getenv("MCP_TRACK_REFINE_MULTI"); return e ? atoi(e) : 1; }();
   const bool multi = n_iter <= PRM_MAX_ITER && ((use_multi == 2 && n >= 64) || (use_multi == 1 && !regs && n > PRR_THREADS*PRR_PPT));
   if (multi) regs = false;
+  rs.last_multi = multi;
   if (rs.dp.alloc(n) || rs.dblk.alloc(blk) || rs.dw.alloc(n)) return -1;
   auto alloc_plain = [&]() { return rs.dJ.alloc(12*(size_t)n) || rs.dex.alloc(2*(size_t)n) || rs.de2.alloc(n); };
   if (!regs && alloc_plain()) return -1;
@@ -402,6 +413,10 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
       static thread_local unsigned long long prm_attr_mask = 0;
       if (!(prm_attr_mask & dbit)) { ICK(hipFuncSetAttribute((const void*)k_pose_refine_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(PRM_GATHER_MAX*sizeof(double)))); prm_attr_mask |= dbit; }
     }
+    // the workgroups of this launch wait for each other; should one give up (not all of them resident next to the mapper's kernels), the
+    // caller redoes the iterations with the single-workgroup kernel from this copy of the points (refine_redo_single)
+    if (rs.dp_keep.alloc(n)) return -1;
+    ICK(hipMemcpyAsync(rs.dp_keep.p, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), dyn, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p,
                        gather ? rs.de2all.p : (double*)nullptr);
     ICK(hipGetLastError());
@@ -417,6 +432,21 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
               q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4]); }
   }
 #endif
+  ICK(hipGetLastError());
+  return 0;
+}
+// the multi-workgroup iterations gave up (prm_err): the same iterations again in ONE workgroup, from the kept copy of the points and the
+// parameter block still in the scratch's host image; results where refine_enqueue leaves them.  The stream has been waited for.
+static int refine_redo_single(int n, int n_iter, int ncam, int est, hipStream_t st) {
+  RefineScratch& rs = refine_scratch();
+  if (!rs.dp_keep.p || rs.hblk.empty()) return img_fail("pose iterations: nothing kept to redo them from");
+  const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam, o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam;
+  ICK(hipMemcpyAsync(rs.dp.p, rs.dp_keep.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToDevice, st));
+  ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), rs.hblk.size(), hipMemcpyHostToDevice, st));
+  ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));
+  double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
+  hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam), reinterpret_cast<const double*>(rs.dblk.p + o_cfb),
+                     d_bfw, n_iter, (const uint8_t*)(rs.dblk.p + o_nl), reinterpret_cast<const double*>(rs.dblk.p + o_ov), rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est);
   ICK(hipGetLastError());
   return 0;
 }
@@ -439,7 +469,13 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
   if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
   ICK(hipStreamSynchronize(st));
-  if (prm_err) return img_fail("mcp_track_pose_refine: a workgroup of the multi-workgroup iterations gave up waiting for the others");
+  if (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP"))) {
+    if (refine_redo_single(n, n_iter, ncam, est, st)) return -1;
+    ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
+    ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
+    if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+    ICK(hipStreamSynchronize(st));
+  }
   std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48);
   return 0;
 }
@@ -779,8 +815,16 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out || n_iter < 0 || !est_ok(est) ||
       (n_iter > 0 && (!nonlinear || !override_sigma)) || (imgs && !strides) || (state && !point_key)) return img_fail("mcp_track_frame: bad arguments");
   for (int c = 0; c < ncam; ++c) if (!targets[c] || !cam_ok(&cams[c]) || n[c] < 0 || (n[c] > 0 && !out[c])) return img_fail("mcp_track_frame: bad arguments");
+  // every per-point argument is checked BEFORE the first enqueue: an input rejected later would leave launches and copies in flight
+  for (int c = 0; c < ncam; ++c) {
+    if (targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || (state && (!state[c] || !point_key[c]))))) return img_fail("mcp_track_frame: bad arguments");
+    for (int i = 0; i < n[c]; ++i) if (!in[c][i].source_kf || in[c][i].source_level < 0 || in[c][i].source_level >= MCP_LEVELS) return img_fail("mcp_track_frame: point without a resident source keyframe");
+  }
   mcp_kf* k0 = targets[0];
   hipStream_t st = k0->st;
+  // ... and whatever fails after it waits for the stream before the stack variables the copies write to (back, prm_err) go away
+  struct DrainOnError { hipStream_t st; bool armed; int ncam; mcp_kf* const* targets; bool lite; ~DrainOnError() { if (armed) { (void)hipStreamSynchronize(st); if (lite) (void)lite_batch_finish(ncam, targets); (void)hipGetLastError(); } } };
+  DrainOnError drain{st, true, ncam, targets, imgs != nullptr};
   if (imgs && lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks)) return -1;
   int total = 0;
   if (state) { if (track_sequences_enqueue(ncam, targets, cams, bfw, cfb, n, in, point_key, state, range, subpix_its, exhaustive, &total)) return -1; }
@@ -805,9 +849,17 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
     } else if (weights_last) std::memset(weights_last, 0, 8*(size_t)total);
   }
   ICK(hipStreamSynchronize(st));
+  drain.armed = false;
   if (imgs && lite_batch_finish(ncam, targets)) return -1;
   if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
-  if (prm_err) return img_fail("mcp_track_frame: a workgroup of the multi-workgroup iterations gave up waiting for the others");
+  if (iterate && (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP")))) {
+    // a workgroup of the multi-workgroup iterations gave up waiting for the others: the frame is not lost, one workgroup redoes them
+    if (refine_redo_single(total, n_iter, ncam, est, st)) return -1;
+    if (pts_out) ICK(hipMemcpyAsync(pts_out, rs.dp.p, sizeof(mcp_pose_point)*(size_t)total, hipMemcpyDeviceToHost, st));
+    ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
+    if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)total, hipMemcpyDeviceToHost, st));
+    ICK(hipStreamSynchronize(st));
+  }
   if (iterate) { std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48); }
   return 0;
 }

@@ -930,3 +930,22 @@ def test_camera_per_rank_frame_loop_runs_on_two_ranks(gpu_required):
     assert out1.returncode == 0, out1.stdout[-2000:] + out1.stderr[-2000:]
     one = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][-1])
     assert np.abs(np.array(two["pose_t"]) - np.array(one["pose_t"])).max() < 1e-9
+
+
+def test_pose_iterations_survive_a_workgroup_that_gives_up(gpu_required, monkeypatch):
+    """The multi-workgroup pose iterations wait for each other; next to the mapper's kernels not every workgroup need be resident and one
+    may give up.  The frame is not lost: the single-workgroup kernel redoes the iterations from a kept copy of the points (forced here
+    on every call).  Same poses as the undisturbed run to the rounding of another summation order."""
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_refine
+    cam, cfbs, bfw, recs = toc._refine_scene()
+    rng = np.random.default_rng(5)
+    big = np.concatenate([recs]*12)[:6000].copy()
+    big["found_pos"] += rng.normal(size=(len(big), 2))*0.3
+    big["cam"] = rng.integers(0, 2, size=len(big))
+    pg, mg, wg, og = track_pose_refine(big, [cam, cam], cfbs, bfw)
+    monkeypatch.setenv("MCP_TRACK_TEST_PRM_GIVEUP", "1")
+    pr, mr, wr, orr = track_pose_refine(big, [cam, cam], cfbs, bfw)
+    assert np.allclose(pr[0], pg[0], rtol=0, atol=1e-11) and np.allclose(pr[1], pg[1], rtol=0, atol=1e-11) and np.allclose(mr, mg, rtol=0, atol=1e-11)
+    assert np.array_equal(wr == 0, wg == 0) and np.allclose(wr, wg, rtol=0, atol=1e-9)
+    assert np.allclose(orr["image"], og["image"], rtol=0, atol=1e-9)
