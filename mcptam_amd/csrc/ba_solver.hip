@@ -2114,6 +2114,9 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
 // ChainBundle.cc:1339-1345 (final sigma^2), :1368-1399 (Tukey outliers), :1401-1448 (depth covariance)
 int mcp_ba::final_stats(int nCounter) {
   if (m_total == 0 || dirty) { max_cov = 0; return 0; }
+  // a trial evaluated ahead that nobody consumed may still be running on the second stream and reads the sigma block of the parity
+  // median_sigma() is about to rewrite: order everything behind it first (it had only ever been joined by the next solve)
+  if (join_spec()) return -2;
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
