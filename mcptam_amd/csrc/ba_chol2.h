@@ -48,7 +48,7 @@ struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag
 constexpr int CP_STEP_INTS = 12;
 enum { CPS_SD = 0, CPS_S1, CPS_S2, CPS_DL, CPS_F0, CPS_F1, CPS_F2, CPS_B0, CPS_B1, CPS_B2 };
 struct CpArgs {
-  const double* S; size_t sys_stride; int n, ntc, nsys, nhelpers;
+  const double* S; size_t sys_stride; int n, ntc, nsys, nhelpers, nworkers;
   const int* slot_of; const int* bslot_of; const int* delta_of; const int* steps; const CpHelper* helpers; const int2* upd;
   double* Lt; size_t lt_stride;               // published L tiles / L_kk^-1, per system
   double* Bt; size_t bt_stride;               // band tiles handed to the critical workgroup, per system
@@ -59,6 +59,7 @@ struct CpArgs {
 struct CpBackArgs {
   const double* Lt; size_t lt_stride; const int* slot_of; int n, ntc, nsys, ncols;
   const int* far_start; const int* far_slot; const int* far_row;      // per block column: its far tiles, rows descending
+  const int* back_tab;            // [ntc][CPB_INTS] (below)
   double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail;
 };
 
@@ -445,7 +446,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
 }
 
 // ---- a helper workgroup: one tile of the plan, left-looking -------------------------------------------------------------------
-__device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) {
+__device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const CpHelper h = a.helpers[hidx];
   cp_tile Pa = (cp_tile)(lds), Pb = (cp_tile)(lds + CP_TILE);
@@ -476,7 +477,7 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
       if (u + 1 == h.nupd) CP_HSTAMP(1);
     }
     __syncthreads();
-    if (!ctl[0]) return;
+    if (!ctl[0]) return false;
     const chol_d4 va = cp_ld4(rL, cp_chunk_off(sl.x, wave, lane));
     if (sl.y != sl.x) {
       const chol_d4 vb = cp_ld4(rL, cp_chunk_off(sl.y, wave, lane));
@@ -497,7 +498,7 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
       CP_HSTAMP(1);
     }
     __syncthreads();
-    if (!ctl[0]) return;
+    if (!ctl[0]) return false;
     const chol_d4 vp = cp_ld4(rB, cp_chunk_off(h.pre, wave, lane)), vd = cp_ld4(rL, cp_chunk_off(h.pre_diag, wave, lane));
     chol_d4 vy = vp;
     if (sl.y != sl.x) vy = cp_ld4(rL, cp_chunk_off(sl.y, wave, lane));
@@ -522,12 +523,12 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
     CP_DRAIN();
     __syncthreads();
     if (t == 0) { cp_flag_store(flags + h.slot, epoch4 | 1); CP_HSTAMP(3); }
-    return;
+    return true;
   }
   // far tile: X = acc L_jj^-T
   if (t == 0) { ctl[0] = cp_poll(flags + h.dslot, done_l, err, code | 3, false) ? 1 : 0; CP_HSTAMP(2); }
   __syncthreads();
-  if (!ctl[0]) return;
+  if (!ctl[0]) return false;
   cp_regs_to_lds(Pb, wave, lane, cp_ld4(rL, cp_chunk_off(h.dslot, wave, lane)));
   cp_regs_to_lds(Pa, wave, lane, acc);
   __syncthreads();
@@ -536,6 +537,7 @@ __device__ inline void cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   CP_DRAIN();
   __syncthreads();
   if (t == 0) { cp_flag_store(flags + h.slot, done_l); CP_HSTAMP(3); }
+  return true;
 }
 
 constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 8;          // + the step table of the critical workgroup behind it
@@ -543,8 +545,15 @@ __global__ void __launch_bounds__(CP_THREADS, 2)
 k_chol_persist(CpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
   const int q = blockIdx.x % a.nsys, role = blockIdx.x / a.nsys;
-  if (role == 0) cp_critical(a, q, cp_lds);
-  else cp_helper(a, q, role - 1, cp_lds);
+  if (role == 0) { cp_critical(a, q, cp_lds); return; }
+  // worker `role - 1` of the system takes the helpers role - 1, role - 1 + nworkers, ... of the dependency-ordered list, one after the
+  // other: a bounded number of resident workgroups whatever the number of tiles (no reliance on dispatch order: everything a
+  // worker waits for is held by the critical workgroup or by a worker further ahead in the same order), and a footprint that leaves
+  // the rest of the chip to whatever runs beside the factorisation
+  for (int h = role - 1; h < a.nhelpers; h += a.nworkers) {
+    if (!cp_helper(a, q, h, cp_lds)) return;
+    __syncthreads();
+  }
 }
 
 // ---- back-substitution ----------------------------------------------------------------------------------------------------------
@@ -612,6 +621,9 @@ __device__ inline void cp_back_far(const CpBackArgs& a, int q, int cidx, double*
 // the chain: x_k = L_kk^-T (y_k - f_k - sum_{d=1..NEAR} L(k+d, k)^T x_{k+d}), k = ntc-1 .. 0
 // wavefront 0 does the two dependent 32 x 32 products of a step out of LDS; wavefronts 1-3 prepare step k-1 meanwhile:
 // tile (k, k-1) and L^-1 of block k-1 into LDS, y - f and the products of the rows beyond k (their x blocks are known)
+// per block column k, for the chain workgroup (copied to LDS once): slots of L_kk^-1, of the near tiles (k+1..k+3, k), of y_k; far tiles?
+constexpr int CPB_INTS = 8;
+enum { CPB_D = 0, CPB_N1, CPB_N2, CPB_N3, CPB_Y, CPB_FAR };
 __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int n = a.n, ntc = a.ntc;
@@ -619,84 +631,95 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
   const double* fb = a.fbuf + (size_t)q*a.vec_stride;
   double* xb = a.xbuf + (size_t)q*a.vec_stride;
   int* err = a.err + q;
-  auto N1 = [&](int par) { return (cp_tile)(lds + (par & 1)*CP_TILE); };
-  auto Dn = [&](int par) { return (cp_tile)(lds + (2 + (par & 1))*CP_TILE); };
-  double* pre = lds + 4*CP_TILE;                // [2][3][64]: per step parity: y - f, and the far-of-near partial sums of two wavefronts (two halves each)
-  double* zb = pre + 2*3*64;                    // [32]
+  // a ring of three: column k is read (wavefront 0) while column k-1 gets its partial sums (wavefronts 1, 2) and column k-2's tiles,
+  // asked for at the top of the step, are written at its bottom (wavefront 3): every global round trip has a whole step to land
+  auto N1 = [&](int k) { return (cp_tile)(lds + (k % 3)*CP_TILE); };
+  auto Dn = [&](int k) { return (cp_tile)(lds + (3 + k % 3)*CP_TILE); };
+  double* pre = lds + 6*CP_TILE;                // [3][3][64]: y - f | partial sums of rows k+2 | k+3 (two 16-row halves each)
+  double* zb = pre + 3*3*64;                    // [32]
   int* ctl = (int*)(zb + 32);
-  double* xs = zb + 32 + 8;                     // [ntc*32]
-  const int* slot_of = a.slot_of;
+  int* tab = ctl + 8;                           // [ntc][CPB_INTS]
+  double* xs = (double*)(tab + ((ntc*CPB_INTS + 1) & ~1));     // [ntc*32]
+  for (int i = t; i < ntc*CPB_INTS; i += CP_THREADS) tab[i] = a.back_tab[i];
   if (t == 0) ctl[0] = 1;
-  // prepare step k (tiles and sums of block column k) -- called by wavefronts 1..3 during step k+1 (and by everybody before the loop)
-  auto prepare = [&](int k, int w) {
-    const int par = k & 1;
-    double* P = pre + par*3*64;
-    if (w == 3) {
-      // L^-1 of block k and tile (k+1, k) -> LDS (row-major), y_k - f_k
-      const double* Dg = Lt + (size_t)slot_of[k*ntc + k]*CP_TQ;
-      const int s1 = (k + 1 < ntc) ? slot_of[(k + 1)*ntc + k] : -1;
-      for (int qd = 0; qd < 4; ++qd) {
-        const chol_d4 v = *reinterpret_cast<const chol_d4*>(Dg + (qd*64 + lane)*4);
-        cp_regs_to_lds(Dn(par), qd, lane, v);
-        chol_d4 u = {0.0, 0.0, 0.0, 0.0};
-        if (s1 >= 0) u = *reinterpret_cast<const chol_d4*>(Lt + (size_t)s1*CP_TQ + (qd*64 + lane)*4);
-        cp_regs_to_lds(N1(par), qd, lane, u);
-      }
-      if (lane < 32) {
-        const int sy = slot_of[ntc*ntc + k];
-        double y = Lt[(size_t)sy*CP_TQ + cp_tq_index(0, lane)];
-        // far sum of the column (a column without far tiles has none)
-        if (a.far_start[ntc - 1 - k + 1] > a.far_start[ntc - 1 - k]) {
-          double f; unsigned it = 0;
-          for (;;) {
-            f = cp_tagged_load(fb + k*CH_NB + lane);
-            if (!cp_is_sent(f)) break;
-            if (++it >= CP_SPIN_MAX) { cp_flag_store(err, 0x500 | (k << 12)); ctl[0] = 0; break; }
-            if ((it & 31) == 31 && cp_flag_load(err) != 0) { ctl[0] = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          y -= f;
-        }
-        P[lane] = y;
-      }
-    } else {
-      // w = 1, 2: the tile d = w + 1 rows above: partial[c] over the two 16-row halves
-      const int d = w + 1, i = k + d;
-      const int c = lane & 31, hh = lane >> 5;
-      double s = 0.0;
-      const int sl = (i < ntc) ? slot_of[i*ntc + k] : -1;
-      if (sl >= 0) {
-        const double* T = Lt + (size_t)sl*CP_TQ;
-        double v[16];
+  __syncthreads();
+  // wavefront 3, two steps ahead of the chain: tiles of column k into registers (top of a step) ...
+  struct Staged { chol_d4 d[4], u[4]; double y, f; };
+  auto stage_load = [&](int k, Staged& g) {
+    const int* e = tab + k*CPB_INTS;
+    const double* Dg = Lt + (size_t)e[CPB_D]*CP_TQ;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = T[cp_tq_index(16*hh + r, c)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s = __builtin_fma(v[r], xs[i*CH_NB + 16*hh + r], s);
-      }
-      P[w*64 + lane] = s;
+    for (int qd = 0; qd < 4; ++qd) {
+      g.d[qd] = *reinterpret_cast<const chol_d4*>(Dg + (qd*64 + lane)*4);
+      g.u[qd] = (chol_d4){0.0, 0.0, 0.0, 0.0};
+      if (e[CPB_N1] >= 0) g.u[qd] = *reinterpret_cast<const chol_d4*>(Lt + (size_t)e[CPB_N1]*CP_TQ + (qd*64 + lane)*4);
+    }
+    g.y = 0.0; g.f = 0.0;
+    if (lane < 32) {
+      g.y = Lt[(size_t)e[CPB_Y]*CP_TQ + cp_tq_index(0, lane)];
+      if (e[CPB_FAR]) g.f = cp_tagged_load(fb + k*CH_NB + lane);       // (looked at in stage_store: usually there by then)
     }
   };
-  __syncthreads();
-  if (ntc > 0) { if (wave >= 1) prepare(ntc - 1, wave); }
+  // ... and into LDS (bottom of the step); the far sum of the column must have arrived by now
+  auto stage_store = [&](int k, Staged& g) {
+    const int* e = tab + k*CPB_INTS;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) { cp_regs_to_lds(Dn(k), qd, lane, g.d[qd]); cp_regs_to_lds(N1(k), qd, lane, g.u[qd]); }
+    if (lane < 32) {
+      double f = g.f;
+      if (e[CPB_FAR]) {
+        unsigned it = 0;
+        while (cp_is_sent(f)) {
+          if (++it >= CP_SPIN_MAX) { cp_flag_store(err, 0x500 | (k << 12)); ctl[0] = 0; break; }
+          if ((it & 31) == 31 && cp_flag_load(err) != 0) { ctl[0] = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+          f = cp_tagged_load(fb + k*CH_NB + lane);
+        }
+      }
+      pre[(k % 3)*192 + lane] = g.y - f;
+    }
+  };
+  // wavefronts 1, 2, one step ahead: rows k+2 | k+3 of column k against their (known) x blocks, two 16-row halves per column
+  auto partial = [&](int k, int w) {
+    const int i = k + w + 1;
+    const int c = lane & 31, hh = lane >> 5;
+    double sacc = 0.0;
+    const int sl = tab[k*CPB_INTS + (w == 1 ? CPB_N2 : CPB_N3)];
+    if (sl >= 0) {
+      const double* T = Lt + (size_t)sl*CP_TQ;
+      double v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = T[cp_tq_index(16*hh + r, c)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc = __builtin_fma(v[r], xs[i*CH_NB + 16*hh + r], sacc);
+    }
+    pre[(k % 3)*192 + w*64 + lane] = sacc;
+  };
+  // lead-in: columns ntc-1 and ntc-2 staged, the partial sums of column ntc-1 (no rows below it: zeros)
+  if (wave == 3) {
+    Staged g;
+    stage_load(ntc - 1, g); stage_store(ntc - 1, g);
+    if (ntc >= 2) { stage_load(ntc - 2, g); stage_store(ntc - 2, g); }
+  } else if (wave >= 1) pre[((ntc - 1) % 3)*192 + wave*64 + lane] = 0.0;
   __syncthreads();
   for (int k = ntc - 1; k >= 0; --k) {
     if (!ctl[0]) break;
-    const int par = k & 1;
+    Staged g;
     if (wave == 0) {
-      const double* P = pre + par*3*64;
+      const double* P = pre + (k % 3)*192;
       const int c = lane & 31, hh = lane >> 5;
-      double s = 0.0;
+      double sacc = 0.0;
       if (k + 1 < ntc) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s = __builtin_fma(N1(par)[16*hh + r][c], xs[(k + 1)*CH_NB + 16*hh + r], s);
+        for (int r = 0; r < 16; ++r) sacc = __builtin_fma(N1(k)[16*hh + r][c], xs[(k + 1)*CH_NB + 16*hh + r], sacc);
       }
-      s += __shfl_xor(s, 32, 64);
-      const double z = P[c] - ((P[64 + c] + P[64 + 32 + c]) + (P[128 + c] + P[128 + 32 + c])) - s;
+      sacc += __shfl_xor(sacc, 32, 64);
+      const double z = P[c] - ((P[64 + c] + P[64 + 32 + c]) + (P[128 + c] + P[128 + 32 + c])) - sacc;
       if (lane < 32) zb[lane] = z;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       double x = 0.0;
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) x = __builtin_fma(Dn(par)[16*hh + cc][c], zb[16*hh + cc], x);
+      for (int cc = 0; cc < 16; ++cc) x = __builtin_fma(Dn(k)[16*hh + cc][c], zb[16*hh + cc], x);
       x += __shfl_xor(x, 32, 64);
       const int nbe = min(CH_NB, n - k*CH_NB);
       if (lane < 32) {
@@ -704,9 +727,12 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
         xs[k*CH_NB + lane] = x;
         cp_tagged_store(xb + k*CH_NB + lane, x);
       }
-    } else if (k > 0) prepare(k - 1, wave);
-    __syncthreads();
+    } else if (wave == 3) { if (k >= 2) stage_load(k - 2, g); }
+    else if (k >= 1) partial(k - 1, wave);
+    cp_barrier();
+    if (wave == 3 && k >= 2) stage_store(k - 2, g);
   }
+  __syncthreads();
   if (t == 0) {
     a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
     if (cp_flag_load(err) != 0 && a.fail) atomicOr(a.fail + q, 4);      // a hand-off timed out somewhere: the host falls back to the per-step kernels
@@ -734,17 +760,18 @@ struct CholPersist {
   std::vector<int> steps;            // [ntc + 1][CP_STEP_INTS], index = step + 1
   std::vector<int> slot_of, bslot_of, delta_of;       // delta_of[i]: band slot of row i's late product (below), -1 = none
   std::vector<CpHelper> helpers; std::vector<int2> upd;
-  std::vector<int> far_start, far_slot, far_row;
-  int *d_steps = nullptr, *d_slot_of = nullptr, *d_bslot_of = nullptr, *d_delta_of = nullptr, *d_flags = nullptr, *d_err = nullptr, *d_epoch = nullptr, *d_far_start = nullptr, *d_far_slot = nullptr, *d_far_row = nullptr;
+  std::vector<int> far_start, far_slot, far_row, back_tab;
+  int *d_steps = nullptr, *d_slot_of = nullptr, *d_bslot_of = nullptr, *d_delta_of = nullptr, *d_flags = nullptr, *d_err = nullptr, *d_epoch = nullptr, *d_far_start = nullptr, *d_far_slot = nullptr, *d_far_row = nullptr, *d_back_tab = nullptr;
   CpHelper* d_helpers = nullptr; int2* d_upd = nullptr;
   double *d_Lt = nullptr, *d_Bt = nullptr, *d_x = nullptr, *d_f = nullptr;
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
+  int nworkers = 0;                      // helper workgroups per system (MCP_BA_CHOL_WORKERS)
   int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
   ~CholPersist() { release(); }
   void release() {
-    void* ps[] = {d_steps, d_delta_of, d_epoch, d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
+    void* ps[] = {d_steps, d_delta_of, d_epoch, d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_back_tab, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
     for (void* p : ps) if (p) (void)hipFree(p);
-    d_steps = d_delta_of = d_epoch = d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = nullptr; d_helpers = nullptr; d_upd = nullptr;
+    d_steps = d_delta_of = d_epoch = d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = d_back_tab = nullptr; d_helpers = nullptr; d_upd = nullptr;
     d_Lt = d_Bt = d_x = d_f = nullptr; ok = false;
   }
   template <class T> static int up(T*& d, const std::vector<T>& v) {
@@ -838,13 +865,29 @@ struct CholPersist {
       for (int i = ntc - 1; i > j + CP_BACK_NEAR; --i) if (P[(size_t)i*ntc + j]) { far_slot.push_back(slot_of[(size_t)i*ntc + j]); far_row.push_back(i); }
       far_start.push_back((int)far_slot.size());
     }
+    back_tab.assign((size_t)ntc*8, -1);
+    for (int k = 0; k < ntc; ++k) {
+      int* e = &back_tab[(size_t)k*8];
+      e[0] = slot_of[(size_t)k*ntc + k];
+      for (int d = 1; d <= 3; ++d) e[d] = (k + d < ntc) ? slot_of[(size_t)(k + d)*ntc + k] : -1;
+      e[4] = slot_of[(size_t)ntc*ntc + k];
+      e[5] = far_start[ntc - 1 - k + 1] > far_start[ntc - 1 - k] ? 1 : 0;
+    }
     lt_stride = (size_t)nslots*CP_TQ; bt_stride = (size_t)std::max(nbslots, 1)*CP_TQ; vec_stride = ntc*CH_NB;
-    if (up(d_slot_of, slot_of) || up(d_bslot_of, bslot_of) || up(d_delta_of, delta_of) || up(d_steps, steps) || up(d_helpers, helpers) || up(d_upd, upd) || up(d_far_start, far_start) || up(d_far_slot, far_slot) || up(d_far_row, far_row)) return -1;
+    if (up(d_slot_of, slot_of) || up(d_bslot_of, bslot_of) || up(d_delta_of, delta_of) || up(d_steps, steps) || up(d_helpers, helpers) || up(d_upd, upd) || up(d_far_start, far_start) || up(d_far_slot, far_slot) || up(d_far_row, far_row) || up(d_back_tab, back_tab)) return -1;
     if (hipMalloc((void**)&d_Lt, sizeof(double)*lt_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_Bt, sizeof(double)*bt_stride*max_sys) != hipSuccess ||
         hipMalloc((void**)&d_flags, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMalloc((void**)&d_err, sizeof(int)*max_sys*4) != hipSuccess ||
         hipMalloc((void**)&d_x, sizeof(double)*vec_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_f, sizeof(double)*vec_stride*max_sys) != hipSuccess) return -1;
     if (hipMemset(d_flags, 0, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMemset(d_err, 0, sizeof(int)*max_sys*4) != hipSuccess) return -1;
     { const int one[max_sys] = {1, 1, 1, 1}; if (hipMalloc((void**)&d_epoch, sizeof one) != hipSuccess || hipMemcpy(d_epoch, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return -1; }
+    {
+      // enough workers to hold a few block columns' worth of tiles at once (a column's far tile, its row's band tiles and the late product
+      // work side by side; the columns ahead are being summed while they wait), at most 126 so that four systems are resident together
+      const char* e = getenv("MCP_BA_CHOL_WORKERS");
+      const int per_col = (nhelpers + ntc - 1)/std::max(ntc, 1);
+      nworkers = e && atoi(e) > 0 ? atoi(e) : std::max(16, std::min(126, 10*per_col));
+      nworkers = std::min(nworkers, std::max(nhelpers, 1));
+    }
     { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
     ok = true;
     return 0;
@@ -859,28 +902,29 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
     if (hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 2)*CP_STEP_INTS*(int)sizeof(int)) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (4*CP_TILE + 512 + CH_SOLVE_MAX + 64)*(int)sizeof(double)) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (6*CP_TILE + 700 + CH_SOLVE_MAX + 64)*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 4)*8*(int)sizeof(int)) != hipSuccess) return -1;
     attr_mask.fetch_or(bit, std::memory_order_relaxed);
   }
   CpArgs a;
-  a.S = S + q0*sys_stride; a.sys_stride = sys_stride; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.nhelpers = P.nhelpers;
+  a.S = S + q0*sys_stride; a.sys_stride = sys_stride; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.nhelpers = P.nhelpers; a.nworkers = P.nworkers;
   a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.delta_of = P.d_delta_of; a.steps = P.d_steps; a.helpers = P.d_helpers; a.upd = P.d_upd;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.Bt = P.d_Bt + q0*P.bt_stride; a.bt_stride = P.bt_stride;
   a.flags = P.d_flags + (size_t)q0*P.nflags; a.nslots = P.nslots; a.nflags = P.nflags; a.err = P.d_err + q0; a.fail = fail + q0;
   a.epoch = P.d_epoch + q0; P.fail_ptr = fail;
   a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
-  hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nhelpers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
+  hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
   return 0;
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)
 inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys, size_t sys_stride, int q0) {
   CpBackArgs a;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.slot_of = P.d_slot_of; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.ncols = P.ntc;
-  a.far_start = P.d_far_start; a.far_slot = P.d_far_slot; a.far_row = P.d_far_row;
+  a.far_start = P.d_far_start; a.far_slot = P.d_far_slot; a.far_row = P.d_far_row; a.back_tab = P.d_back_tab;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
   a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0; a.fail = P.fail_ptr ? P.fail_ptr + q0 : nullptr;
-  const size_t lds = (size_t)(4*CP_TILE + 2*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double);
+  static_assert(CP_BACK_NEAR == 3 && CPB_INTS == 8, "the chain workgroup's column table holds three near tiles");
+  const size_t lds = (size_t)(6*CP_TILE + 3*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double) + (size_t)(P.ntc*CPB_INTS + 18)*sizeof(int);
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
   return 0;
 }
