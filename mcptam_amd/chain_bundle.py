@@ -222,13 +222,16 @@ class ChainBundle:
         prm = McpBaParams(self.snMaxIterations, self.snMaxTrialsAfterFailure, self.sdUpdatePercentConvergenceLimit,
                           self.sdUpdateRMSConvergenceLimit, self.sdMinMEstimatorSigma, int(disable_convergence),
                           int(device), int(profile))
+        t0 = time.perf_counter()
         self._h = self._L.mcp_ba_create(ctypes.cast(self._cams, ctypes.c_void_p), len(cams), int(use_robust),
                                         int(use_tukey), int(verbose), ctypes.byref(prm))
+        self.abi_create_seconds = time.perf_counter() - t0
         if not self._h:
             raise RuntimeError("mcp_ba_create failed: " + last_error())
         self.abort = ctypes.c_ubyte(0)      # the caller's mbBundleAbortRequested
         self._hook = None
         self.abi_seconds = 0.0               # time spent inside the library's Add* entries (what a native caller pays; the rest is Python)
+        self.abi_read_seconds = 0.0          # ... and inside its Get* entries
 
     def close(self):
         if getattr(self, "_h", None):
@@ -322,20 +325,28 @@ class ChainBundle:
     def GetPoints(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         x = np.zeros((len(ids), 3))
-        self._check(self._L.mcp_ba_get_points(self._h, len(ids), _ip(ids), _dp(x)), "GetPoints")
+        t0 = time.perf_counter()
+        rc = self._L.mcp_ba_get_points(self._h, len(ids), _ip(ids), _dp(x))
+        self.abi_read_seconds += time.perf_counter() - t0
+        self._check(rc, "GetPoints")
         return x
 
     def GetPoses(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         R = np.zeros((len(ids), 3, 3))
         t = np.zeros((len(ids), 3))
-        self._check(self._L.mcp_ba_get_poses(self._h, len(ids), _ip(ids), _dp(R), _dp(t)), "GetPoses")
+        t0 = time.perf_counter()
+        rc = self._L.mcp_ba_get_poses(self._h, len(ids), _ip(ids), _dp(R), _dp(t))
+        self.abi_read_seconds += time.perf_counter() - t0
+        self._check(rc, "GetPoses")
         return R, t
 
     def GetOutlierMeasurements(self):
+        t0 = time.perf_counter()
         n = self._L.mcp_ba_num_outliers(self._h)
-        out = np.zeros((max(n, 1), 3), dtype=np.int32)
+        out = np.empty((max(n, 1), 3), dtype=np.int32)
         n = self._L.mcp_ba_get_outliers(self._h, _ip(out), n)
+        self.abi_read_seconds += time.perf_counter() - t0
         return [tuple(int(v) for v in out[i]) for i in range(n)]
 
     def GetSigmaSquared(self):

@@ -14,8 +14,11 @@
 // A non-positive pivot (CHOLMOD failure in the reference == rejected LM trial) raises *fail.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ba_pool.h"
 #include <algorithm>
 #include <atomic>
+#include <cstring>
+#include <mutex>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -208,8 +211,12 @@ __global__ void __launch_bounds__(CH_STEP_THREADS)
 k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride CH_DIAG_PARAMS()) {
   if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; CH_DIAG_OFFSET(blockIdx.y); }     // further systems of a multi-lambda batch
   // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
-  const int packed = tiles[blockIdx.x];
-  const int ti = packed >> 16, tj = packed & 0xffff;
+  // bit 31: both tiles of panel k-1 the update of this tile multiplies -- (ti, k-1) and (tj, k-1) -- are tiles of the plan; bit 30:
+  // so is (k, k-1), which updates the diagonal tile.  A tile outside the plan is structurally zero and S holds NOTHING for it (the
+  // assembly writes the plan's tiles only): it must not be read -- whatever the buffer held before would be taken for numbers.
+  const unsigned int packed = (unsigned int)tiles[blockIdx.x];
+  const int ti = (int)((packed >> 16) & 0x3fffu), tj = (int)(packed & 0xffffu);
+  const bool upd = k > 0 && (packed >> 31) != 0u, upd_d = k > 0 && ((packed >> 30) & 1u) != 0u;
   __shared__ double Ta[CH_NB][CH_NB + 1];
   __shared__ double Tb[CH_NB][CH_NB + 1];
   __shared__ double Tc[CH_NB][CH_NB + 1];
@@ -223,23 +230,23 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
   {
     double vc[4], va[4], vb[4], vd[4], ve[4];
     chol_load_tile_regs(S, n, nrows, n, r0, c0, vc);
-    if (k > 0) {
+    if (upd) {
       chol_load_tile_regs(S, n, nrows, n, r0, p0, va);
       chol_load_tile_regs(S, n, nrows, n, c0, p0, vb);
     }
     if (panel && offdiag) {
       chol_load_tile_regs(S, n, nrows, n, k0, k0, vd);
-      if (k > 0) chol_load_tile_regs(S, n, nrows, n, k0, p0, ve);
+      if (upd_d) chol_load_tile_regs(S, n, nrows, n, k0, p0, ve);
     }
     chol_regs_to_lds(vc, Tc, n);
-    if (k > 0) { chol_regs_to_lds(va, Ta, n); chol_regs_to_lds(vb, Tb, n); }
-    if (panel && offdiag) { chol_regs_to_lds(vd, Td, n); if (k > 0) chol_regs_to_lds(ve, Te, n); }
+    if (upd) { chol_regs_to_lds(va, Ta, n); chol_regs_to_lds(vb, Tb, n); }
+    if (panel && offdiag) { chol_regs_to_lds(vd, Td, n); if (upd_d) chol_regs_to_lds(ve, Te, n); }
   }
   __syncthreads();
   CHOL_STAMP(1);
   chol_d4 acc, dacc;
-  chol_quadrant_update(Tc, Ta, Tb, k > 0, acc);
-  if (panel && offdiag) chol_quadrant_update(Td, Te, Te, k > 0, dacc);
+  chol_quadrant_update(Tc, Ta, Tb, upd, acc);
+  if (panel && offdiag) chol_quadrant_update(Td, Te, Te, upd_d, dacc);
   chol_quadrant_store(Tc, acc);                 // each wavefront reads and writes only its own quadrant of Tc / Td
   if (panel && offdiag) chol_quadrant_store(Td, dacc);
   __syncthreads();
@@ -339,7 +346,7 @@ constexpr int CH_SOLVE_MAX = 6144;       // x is staged in LDS
 // Tt = the tile below it, L[k0+32 .. ][k0 ..] (zero outside); coalesced row segments; load and LDS store are split so the
 // loads stay in flight during the update
 constexpr int CH_STAGE_PER = 5;                            // ceil(2*1024 / (CH_BACK_THREADS - 64))
-__device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG_PARAMS(const), int n, int nblk, int kb, int u, int nth, double* v) {
+__device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG_PARAMS(const), int n, int nblk, int kb, int u, int nth, double* v, bool below /* tile (kb+1, kb) is a tile of the plan: S holds it */) {
   const int k0 = kb*CH_NB, nbe = min(CH_NB, n - k0);
   const int kb0 = k0 + CH_NB, nbb = (kb + 1 < nblk) ? min(CH_NB, n - kb0) : 0;
 #pragma unroll
@@ -349,7 +356,7 @@ __device__ inline void chol_back_stage_load(const double* __restrict__ S CH_DIAG
     v[i] = 0.0;
     if (e < 2048) {
       if (which == 0) v[i] = (c >= r && r < nbe && c < nbe) ? Dg[(size_t)kb*(CH_NB*CH_NB) + r*CH_NB + c] : ((r == c) ? 1.0 : 0.0);   // L_kk^-T, upper
-      else v[i] = (r < nbb && c < nbe) ? S[(size_t)(kb0 + r)*n + k0 + c] : 0.0;
+      else v[i] = (below && r < nbb && c < nbe) ? S[(size_t)(kb0 + r)*n + k0 + c] : 0.0;
     }
   }
 }
@@ -395,10 +402,17 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
   // the solver's two tiles travel global -> registers -> LDS two steps ahead of their use: loaded during step j+2, stored to
   // LDS at the start of step j+1 (into the buffer of the other parity), read by the solver in step j
   double sv[CH_STAGE_PER];
+  // is the tile below the diagonal tile of step kb -- (kb+1, kb) -- one of the plan's?  (block row kb+1 lists its tile columns in
+  // ascending order.)  If not it is structurally zero and S holds nothing for it.
+  auto below_in_plan = [&](int kb) -> bool {
+    if (kb + 1 >= nblk) return false;
+    const int b = row_start[kb + 1], e = row_start[kb + 2];
+    return e > b && row_tiles[e - 1] == kb;
+  };
   if (t >= 64) {
-    chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv);
+    chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 1, t - 64, CH_BACK_THREADS - 64, sv, false);
     chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(nblk - 1) & 1], Tt[(nblk - 1) & 1]);
-    if (nblk > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 2, t - 64, CH_BACK_THREADS - 64, sv);
+    if (nblk > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, nblk - 2, t - 64, CH_BACK_THREADS - 64, sv, below_in_plan(nblk - 2));
   }
   __syncthreads();
   // updaters: (tile, column pair, row slice) items of block row ub against x of block ub; item q of a thread's first round is
@@ -468,7 +482,7 @@ k_chol_back(const double* __restrict__ S, int n, const int* __restrict__ row_sta
       BACK_STAMP(0, 1);
     } else {
       if (kb > 0) chol_back_stage_store(t - 64, CH_BACK_THREADS - 64, sv, Lt[(kb - 1) & 1], Tt[(kb - 1) & 1]);      // tiles of step kb-1 (loaded a step ago)
-      if (kb > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, kb - 2, t - 64, CH_BACK_THREADS - 64, sv);           // tiles of step kb-2: a full step to land
+      if (kb > 1) chol_back_stage_load(S CH_BACK_DG, n, nblk, kb - 2, t - 64, CH_BACK_THREADS - 64, sv, rs_l[kb] > rs_l[kb - 1] && rt[rs_l[kb] - 1] == kb - 2);           // tiles of step kb-2: a full step to land
       if (kb + 1 < nblk) {
         // x of block kb+1 (solved in the previous step) against the structurally non-zero tiles of block row kb+1 left of tile kb
         const int ub = kb + 1;
@@ -507,12 +521,12 @@ struct CholPlan {
   double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
   // the one-launch factorisation + chain back-substitution of ba_chol2.h (MCP_BA_CHOL_PERSIST=0: the per-step kernels below)
   mutable CholPersist persist; bool use_persist = false;
+  int persist_min_ntc = 3;      // smallest system (in tiles) the one-launch plan is built for (the test hooks set 1)
   ~CholPlan() { release(); }
-  void release() { if (d_step_tiles) (void)hipFree(d_step_tiles); if (d_row_start) (void)hipFree(d_row_start); if (d_row_tiles) (void)hipFree(d_row_tiles);
-                   if (d_diag) (void)hipFree(d_diag);
-                   if (d_all_tiles) (void)hipFree(d_all_tiles);
+  char* arena = nullptr; size_t arena_cap = 0;      // one cached block (ba_pool.h): [step tiles | row starts | row tiles | all tiles | factored diagonal tiles]
+  void release() { if (arena) DevCache::get().put(arena, arena_cap); arena = nullptr; arena_cap = 0;
                    d_diag = nullptr; d_all_tiles = nullptr;
-                   d_step_tiles = d_row_start = d_row_tiles = nullptr; }
+                   d_step_tiles = d_row_start = d_row_tiles = nullptr; persist.release(); }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
   int build(int n_, const std::vector<unsigned char>& pattern) {
     release();
@@ -544,18 +558,37 @@ struct CholPlan {
     row_start.assign(ntc + 1, 0); row_tiles.clear();
     for (int i = 0; i < ntc; ++i) { row_start[i] = (int)row_tiles.size(); for (int j = 0; j < i; ++j) if (P[(size_t)i*ntc + j]) row_tiles.push_back(j); }
     row_start[ntc] = (int)row_tiles.size();
-    if (hipMalloc((void**)&d_step_tiles, sizeof(int)*std::max<size_t>(step_tiles.size(), 1)) != hipSuccess ||
-        hipMalloc((void**)&d_row_start, sizeof(int)*row_start.size()) != hipSuccess ||
-        hipMalloc((void**)&d_row_tiles, sizeof(int)*std::max<size_t>(row_tiles.size(), 1)) != hipSuccess) return -1;
-    if (!step_tiles.empty() && hipMemcpy(d_step_tiles, step_tiles.data(), sizeof(int)*step_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (hipMemcpy(d_row_start, row_start.data(), sizeof(int)*row_start.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     diag_stride = (size_t)std::max(ntc, 1)*CH_NB*CH_NB;
-    if (hipMalloc((void**)&d_diag, sizeof(double)*diag_stride*max_sys) != hipSuccess) return -1;
-    if (!row_tiles.empty() && hipMemcpy(d_row_tiles, row_tiles.data(), sizeof(int)*row_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (hipMalloc((void**)&d_all_tiles, sizeof(int)*std::max<size_t>(all_tiles.size(), 1)) != hipSuccess) return -1;
-    if (!all_tiles.empty() && hipMemcpy(d_all_tiles, all_tiles.data(), sizeof(int)*all_tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    {
+      auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+      const size_t o_step = 0, o_rs = o_step + al(4*std::max<size_t>(step_tiles.size(), 1)), o_rt = o_rs + al(4*row_start.size()),
+                   o_all = o_rt + al(4*std::max<size_t>(row_tiles.size(), 1)), o_diag = o_all + al(4*std::max<size_t>(all_tiles.size(), 1));
+      arena = (char*)DevCache::get().take(o_diag + sizeof(double)*diag_stride*max_sys, &arena_cap);
+      if (!arena) return -1;
+      std::vector<char> stage(o_diag, 0);
+      {
+        // the device's copy carries the update flags of k_chol_step (which tiles of panel k-1 exist)
+        unsigned int* dst = reinterpret_cast<unsigned int*>(stage.data() + o_step);
+        for (int k = 0; k < ntc; ++k) for (int i = step_start[k]; i < step_start[k + 1]; ++i) {
+          const int ti = step_tiles[i] >> 16, tj = step_tiles[i] & 0xffff;
+          unsigned int v = (unsigned int)step_tiles[i];
+          if (k > 0) {
+            if (P[(size_t)ti*ntc + k - 1] && P[(size_t)tj*ntc + k - 1]) v |= 1u << 31;
+            if (P[(size_t)k*ntc + k - 1]) v |= 1u << 30;
+          }
+          dst[i] = v;
+        }
+      }
+      std::memcpy(stage.data() + o_rs, row_start.data(), 4*row_start.size());
+      if (!row_tiles.empty()) std::memcpy(stage.data() + o_rt, row_tiles.data(), 4*row_tiles.size());
+      if (!all_tiles.empty()) std::memcpy(stage.data() + o_all, all_tiles.data(), 4*all_tiles.size());
+      if (hipMemcpy(arena, stage.data(), o_diag, hipMemcpyHostToDevice) != hipSuccess) return -1;
+      d_step_tiles = (int*)(arena + o_step); d_row_start = (int*)(arena + o_rs); d_row_tiles = (int*)(arena + o_rt); d_all_tiles = (int*)(arena + o_all);
+      d_diag = (double*)(arena + o_diag);
+    }
     { const char* e = getenv("MCP_BA_CHOL_PERSIST"); use_persist = !(e && atoi(e) == 0); }
-    if (use_persist && persist.build(n, pattern, pattern.empty() ? std::vector<int>() : all_tiles)) return -1;
+    // (a reduced system of one or two tiles -- the BundleAdjustRecent window, <= 5 free poses -- is two launches either way: no plan for it)
+    if (use_persist && ntc >= persist_min_ntc && persist.build(n, pattern, pattern.empty() ? std::vector<int>() : all_tiles)) return -1;
     return 0;
   }
   size_t tile_updates() const { return step_tiles.size(); }

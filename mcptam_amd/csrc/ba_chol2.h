@@ -768,17 +768,16 @@ struct CholPersist {
   int nworkers = 0;                      // helper workgroups per system (MCP_BA_CHOL_WORKERS)
   int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
   ~CholPersist() { release(); }
+  // One device arena per plan: [tables (one upload) | flags, error words, epochs | L tiles | band tiles | x | f], a block of the
+  // process-wide cache (ba_pool.h): a ChainBundle lives for one BundleAdjust call, plans are built and dropped all the time.
+  char* arena = nullptr; size_t arena_bytes = 0;
   void release() {
-    void* ps[] = {d_steps, d_delta_of, d_epoch, d_slot_of, d_bslot_of, d_flags, d_err, d_far_start, d_far_slot, d_far_row, d_back_tab, d_helpers, d_upd, d_Lt, d_Bt, d_x, d_f};
-    for (void* p : ps) if (p) (void)hipFree(p);
+    if (arena) DevCache::get().put(arena, arena_bytes);
+    arena = nullptr; arena_bytes = 0;
     d_steps = d_delta_of = d_epoch = d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = d_back_tab = nullptr; d_helpers = nullptr; d_upd = nullptr;
     d_Lt = d_Bt = d_x = d_f = nullptr; ok = false;
   }
-  template <class T> static int up(T*& d, const std::vector<T>& v) {
-    if (hipMalloc((void**)&d, sizeof(T)*std::max<size_t>(v.size(), 1)) != hipSuccess) return -1;
-    if (!v.empty() && hipMemcpy(d, v.data(), sizeof(T)*v.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    return 0;
-  }
+  int arena_get(size_t bytes) { arena = (char*)DevCache::get().take(bytes, &arena_bytes); return arena ? 0 : -1; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (empty = dense); in_old: the tiles the assembly writes (ti << 16 | tj),
   // with the right-hand side inside block row n / 32 as ba_chol.h's plan has it
   int build(int n_, const std::vector<unsigned char>& pattern, const std::vector<int>& old_tiles) {
@@ -874,12 +873,30 @@ struct CholPersist {
       e[5] = far_start[ntc - 1 - k + 1] > far_start[ntc - 1 - k] ? 1 : 0;
     }
     lt_stride = (size_t)nslots*CP_TQ; bt_stride = (size_t)std::max(nbslots, 1)*CP_TQ; vec_stride = ntc*CH_NB;
-    if (up(d_slot_of, slot_of) || up(d_bslot_of, bslot_of) || up(d_delta_of, delta_of) || up(d_steps, steps) || up(d_helpers, helpers) || up(d_upd, upd) || up(d_far_start, far_start) || up(d_far_slot, far_slot) || up(d_far_row, far_row) || up(d_back_tab, back_tab)) return -1;
-    if (hipMalloc((void**)&d_Lt, sizeof(double)*lt_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_Bt, sizeof(double)*bt_stride*max_sys) != hipSuccess ||
-        hipMalloc((void**)&d_flags, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMalloc((void**)&d_err, sizeof(int)*max_sys*4) != hipSuccess ||
-        hipMalloc((void**)&d_x, sizeof(double)*vec_stride*max_sys) != hipSuccess || hipMalloc((void**)&d_f, sizeof(double)*vec_stride*max_sys) != hipSuccess) return -1;
-    if (hipMemset(d_flags, 0, sizeof(int)*(size_t)nflags*max_sys) != hipSuccess || hipMemset(d_err, 0, sizeof(int)*max_sys*4) != hipSuccess) return -1;
-    { const int one[max_sys] = {1, 1, 1, 1}; if (hipMalloc((void**)&d_epoch, sizeof one) != hipSuccess || hipMemcpy(d_epoch, one, sizeof one, hipMemcpyHostToDevice) != hipSuccess) return -1; }
+    // lay the arena out (every part 256-byte aligned), stage the tables in one host block, one upload
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    struct Part { const void* src; size_t bytes; void** dst; };
+    Part parts[] = {
+      {slot_of.data(), slot_of.size()*4, (void**)&d_slot_of}, {bslot_of.data(), bslot_of.size()*4, (void**)&d_bslot_of}, {delta_of.data(), delta_of.size()*4, (void**)&d_delta_of},
+      {steps.data(), steps.size()*4, (void**)&d_steps}, {helpers.data(), helpers.size()*sizeof(CpHelper), (void**)&d_helpers}, {upd.data(), upd.size()*sizeof(int2), (void**)&d_upd},
+      {far_start.data(), far_start.size()*4, (void**)&d_far_start}, {far_slot.data(), far_slot.size()*4, (void**)&d_far_slot}, {far_row.data(), far_row.size()*4, (void**)&d_far_row},
+      {back_tab.data(), back_tab.size()*4, (void**)&d_back_tab}};
+    size_t tab_bytes = 0;
+    for (const Part& pt : parts) tab_bytes += al(std::max<size_t>(pt.bytes, 4));
+    const size_t flag_bytes = al(sizeof(int)*(size_t)nflags*max_sys), err_bytes = al(sizeof(int)*max_sys*4), ep_bytes = al(sizeof(int)*max_sys);
+    const size_t lt_bytes = al(sizeof(double)*lt_stride*max_sys), bt_bytes = al(sizeof(double)*bt_stride*max_sys), vec_bytes = al(sizeof(double)*(size_t)vec_stride*max_sys);
+    if (arena_get(tab_bytes + flag_bytes + err_bytes + ep_bytes + lt_bytes + bt_bytes + 2*vec_bytes)) return -1;
+    std::vector<char> stage(tab_bytes + flag_bytes + err_bytes + ep_bytes, 0);
+    size_t off = 0;
+    for (const Part& pt : parts) { if (pt.bytes) std::memcpy(stage.data() + off, pt.src, pt.bytes); *pt.dst = arena + off; off += al(std::max<size_t>(pt.bytes, 4)); }
+    d_flags = (int*)(arena + off); off += flag_bytes;
+    d_err = (int*)(arena + off); off += err_bytes;
+    d_epoch = (int*)(arena + off); { int* e = (int*)(stage.data() + off); for (int q = 0; q < max_sys; ++q) e[q] = 1; } off += ep_bytes;
+    if (hipMemcpy(arena, stage.data(), off, hipMemcpyHostToDevice) != hipSuccess) return -1;      // (tables, zeroed flags and error words, epochs = 1)
+    d_Lt = (double*)(arena + off); off += lt_bytes;
+    d_Bt = (double*)(arena + off); off += bt_bytes;
+    d_x = (double*)(arena + off); off += vec_bytes;
+    d_f = (double*)(arena + off); off += vec_bytes;
     {
       // enough workers to hold a few block columns' worth of tiles at once (a column's far tile, its row's band tiles and the late product
       // work side by side; the columns ahead are being summed while they wait), at most 126 so that four systems are resident together

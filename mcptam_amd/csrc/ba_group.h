@@ -109,15 +109,17 @@ __device__ unsigned long long g_lin_prof[8*8];
 #ifndef LIN_WAVES
 #define LIN_WAVES 0   // > 0: wavefronts per SIMD the register allocation is held to
 #endif
-#if LIN_WAVES > 0      // (the bound is a promise of at most 128 threads -- the launch has 64; with a one-wavefront bound the compiler ignores the occupancy request)
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(LIN_WAVES, LIN_WAVES)))
-#else
-__global__ void __launch_bounds__(64)
-#endif
-k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
-                  const double* __restrict__ second, const double* __restrict__ sigma,
-                  double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
-                  double* __restrict__ V, double* __restrict__ g, double* __restrict__ W) {
+// LPP = lanes per point.  1: one lane per point, groups of <= 64 points (the layout for maps large enough to fill the chip: a lane
+// walks all measurements of its point).  4: groups of <= 16 points, a point's measurements dealt to its 4 lanes -- the per-group
+// latency of a small problem (BundleAdjustRecent's window: 40 groups on 256 compute units, all of the stage is one group's latency)
+// falls from 8 dependent measurements to 2.  What a lane kept in registers per point (V, g, the source pose's blocks) is summed over
+// the point's lanes at the end (butterfly inside the quad: same value on every lane, fixed order); W blocks that several
+// measurements of a point contribute to are accumulated in LDS (wl_off = offset of that area in doubles) and go out once.
+template <int LPP>
+__device__ __forceinline__ void linearize_group_body(const DevProblem& P, const double* __restrict__ pt_x, const double* __restrict__ first,
+                    const double* __restrict__ second, const double* __restrict__ sigma,
+                    double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
+                    double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off) {
   extern __shared__ double Sc[];                 // the group's blocks, 36 doubles each (launch: 288 B x the largest block count of any group)
   __shared__ double bl[GRP_DOF];
   __shared__ unsigned char pslot[GRP_LMAX*16];
@@ -129,9 +131,13 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
     for (int i = lane; i < nb; i += 64) pslot[P.blk_pair[b0 + i]] = (unsigned char)i;      // (pairs outside the list are never looked up)
   }
+  double* const Wl = Sc + wl_off;                // LPP > 1: the group's W blocks, 18 doubles per incidence
+  const int inc0 = (LPP > 1) ? P.sp_i[P.g_sp0[grp]] : 0;
+  if constexpr (LPP > 1) { const int ni = P.sp_i[P.g_sp0[grp + 1]] - inc0; for (int i = lane; i < ni*18; i += 64) Wl[i] = 0.0; }
   __syncthreads();
   LIN_STAMP(1);
-  const int sp = P.g_sp0[grp] + lane;
+  const int sub = lane % LPP;
+  const int sp = P.g_sp0[grp] + lane/LPP;
   const bool valid = sp < P.g_sp0[grp + 1] && !P.sp_big[sp];
   // register accumulators of the first source-chain slot (the pose the point is expressed in)
   double Uss[21], bs[6], Wss[18];
@@ -165,7 +171,7 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
     double Vp[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
     const bool fixed_neg = P.pt_fixed[pt] && P.robust;
     LIN_STAMP(2);
-    for (int m = P.sp_m[sp]; m < P.sp_m[sp + 1]; ++m) {
+    for (int m = P.sp_m[sp] + sub; m < P.sp_m[sp + 1]; m += LPP) {
       const int oc = P.m_chain[m], olen = P.chain_len[oc];
       const int mask = P.m_mask[m];
       if (mask == 0 && lpt < 0) continue;
@@ -248,6 +254,12 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
             for (int r = 0; r < 6; ++r)
 #pragma unroll
               for (int c = 0; c < 3; ++c) Wss[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+          } else if constexpr (LPP > 1) {
+            double* Wb = Wl + 18*(P.slot_inc[s0 + ia] - inc0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) lds_add(Wb + 3*r + c, w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]));
           } else {
             double* Wb = W + 18*(size_t)P.slot_inc[s0 + ia];
             if (P.slot_first[s0 + ia]) {
@@ -276,6 +288,41 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
       }
     }
     LIN_STAMP(3);
+    if constexpr (LPP > 1) {
+      // the point's lanes (all of them are here: `valid` is a property of the point) sum what each kept in registers
+#pragma unroll
+      for (int d = 1; d < LPP; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Vp[k] += __shfl_xor(Vp[k], d, 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gp[k] += __shfl_xor(gp[k], d, 64);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Uss[k] += __shfl_xor(Uss[k], d, 64);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bs[k] += __shfl_xor(bs[k], d, 64);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wss[k] += __shfl_xor(Wss[k], d, 64);
+        wss_inc = max(wss_inc, __shfl_xor(wss_inc, d, 64));
+        ls = max(ls, __shfl_xor(ls, d, 64));
+      }
+      if (lpt >= 0) {
+        // (LDS operations of one wavefront execute in order: the loop's atomics on these blocks are done)
+        if (wss_inc >= 0 && sub == 0) {
+          double* Wb = Wl + 18*(wss_inc - inc0);
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wb[k] += Wss[k];
+        }
+        const int i0 = P.sp_i[sp], npi = P.sp_i[sp + 1] - i0;
+        for (int e = sub; e < npi*18; e += LPP) W[18*(size_t)i0 + e] = Wl[18*(i0 - inc0) + e];
+        if (sub == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) V[6*(size_t)lpt + k] = Vp[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) g[3*(size_t)lpt + k] = gp[k];
+        }
+      }
+      if (sub != 0) ls = -1;                  // one lane per point enters the reduction over the points below
+    } else
     if (lpt >= 0) {
       if (wss_inc >= 0) {
         double* Wb = W + 18*(size_t)wss_inc;
@@ -325,6 +372,23 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
   // flush the local tile to the group's staging slots (k_assemble sums them in group order)
   flush_compact_blocks<64>(Sc, bl, grp, P, stU, stb);
   LIN_STAMP(6);
+}
+#if LIN_WAVES > 0      // (the bound is a promise of at most 128 threads -- the launch has 64; with a one-wavefront bound the compiler ignores the occupancy request)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(LIN_WAVES, LIN_WAVES)))
+#else
+__global__ void __launch_bounds__(64)
+#endif
+k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+                  const double* __restrict__ second, const double* __restrict__ sigma,
+                  double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W) {
+  linearize_group_body<1>(P, pt_x, first, second, sigma, stU, stb, V, g, W, 0);
+}
+constexpr int LIN_QUAD_PTS = 16;           // points per group when the quad form runs (64 lanes / 4)
+__global__ void __launch_bounds__(64)
+k_linearize_quad(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+                 const double* __restrict__ second, const double* __restrict__ sigma,
+                 double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off) {
+  linearize_group_body<4>(P, pt_x, first, second, sigma, stU, stb, V, g, W, wl_off);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -588,7 +652,15 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
     if (row == np) {                       // right-hand side (row n of the augmented matrix) and, behind it, the plain J^T r
       const int a = col/6, r = col - 6*a;
       double b = 0.0, sr = 0.0;
-      for (int k = A.po_start[a]; k < A.po_start[a + 1]; ++k) { const size_t o = (size_t)k*6 + r; b += stb[o]; sr += str[o]; }
+      int k = A.po_start[a]; const int k1 = A.po_start[a + 1];
+      for (; k + 8 <= k1; k += 8) {            // independent loads in flight, summed in list order (a window's few free poses are staged by every group)
+        double bb[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const size_t o = (size_t)(k + j)*6 + r; bb[j] = stb[o]; ss[j] = str[o]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b += bb[j]; sr += ss[j]; }
+      }
+      for (; k < k1; ++k) { const size_t o = (size_t)k*6 + r; b += stb[o]; sr += str[o]; }
       if (Ubig) b += Ubig[n2 + col];
       S[n2 + col] = b - sr;
       S[n2 + np + col] = b;
@@ -604,7 +676,14 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
         const double* pu = stU + (size_t)k0*36 + r*6 + c;
         const double* pw = stS + (size_t)k0*36 + r*6 + c;
         int k = k0;
-        for (; k + 4 <= k1; k += 4, pu += 144, pw += 144) {       // independent loads in flight, summed in list order
+        for (; k + 8 <= k1; k += 8, pu += 288, pw += 288) {       // independent loads in flight, summed in list order
+          double uu[8], ww[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { uu[j] = pu[36*j]; ww[j] = pw[36*j]; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { u += uu[j]; w += ww[j]; }
+        }
+        for (; k + 4 <= k1; k += 4, pu += 144, pw += 144) {
           const double u0 = pu[0], u1 = pu[36], u2 = pu[72], u3 = pu[108];
           const double w0 = pw[0], w1 = pw[36], w2 = pw[72], w3 = pw[108];
           u += u0; u += u1; u += u2; u += u3;

@@ -25,12 +25,14 @@
 #include <vector>
 
 #include "../../include/mcp_ba.h"
+#include "ba_pool.h"
 #include "ba_kernels.h"
 #include "ba_select.h"
 #include "ba_chol.h"
 #include "ba_group.h"
 #include "ba_comm.h"
 #include "ba_trial.h"
+#include "ba_small.h"
 
 using namespace mcp;
 
@@ -63,15 +65,16 @@ extern "C" int mcp_device_count(void) {
 namespace {
 
 template <class T> struct DevBuf {
-  T* p = nullptr; size_t n = 0;
+  T* p = nullptr; size_t n = 0; size_t cap_bytes = 0; bool alias = false;      // alias: p points into another buffer (packed structure upload)
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  // (blocks come from and go back to the process-wide cache, ba_pool.h: a handle lives for one BundleAdjust call)
+  void release() { if (p && !alias) mcp::DevCache::get().put(p, cap_bytes); p = nullptr; n = 0; cap_bytes = 0; alias = false; }
   int alloc(size_t count) {
     if (count == 0) count = 1;
     if (count <= n) return 0;
     release();
-    hipError_t e = hipMalloc((void**)&p, count*sizeof(T));
-    if (e != hipSuccess) { set_err(std::string("hipMalloc: ") + hipGetErrorString(e)); p = nullptr; return -1; }
+    p = (T*)mcp::DevCache::get().take(count*sizeof(T), &cap_bytes);
+    if (!p) { set_err("hipMalloc: out of device memory"); cap_bytes = 0; return -1; }
     n = count; return 0;
   }
   template <class A> int upload(const std::vector<T, A>& v, hipStream_t st) {
@@ -306,6 +309,7 @@ struct mcp_ba {
   int nx_total() const { return np + 3*(int)nfl_total; }
 
   // device problem
+  DevBuf<char> d_struct;          // the structure arrays of Prepare(), packed (finish_prepare): the d_* of this block alias into it
   DevBuf<mcp_camera> d_cams;
   DevBuf<int> d_chain_len, d_chain_pose, d_pose_unk, d_pt_chain, d_pt_unk, d_m_pt, d_m_chain;
   DevBuf<unsigned char> d_pt_fixed, d_m_cam, d_flags;
@@ -345,6 +349,17 @@ struct mcp_ba {
   DevBuf<int> d_g_blk0, d_asm_tiles, d_pair_id, d_pr_start, d_blk_dst, d_po_start, d_rhs_dst;
   DevBuf<unsigned char> d_blk_pair;
   int grp_blk_max = 0;            // most staged blocks of any group (sizes the LDS tile of k_linearize_group)
+  int head_ahead_for = -1;        // state buffer whose iteration head is already on the main stream (small bundles), or -1
+  bool head_ahead_want = false; int dbg_head_ahead = 0;
+  int head_ahead(int w);
+  int small_on = 1;               // MCP_BA_SMALL=0: a small bundle runs the same launches as a large one (ba_small.h)
+  bool small_mode() const { return small_on && !multi() && P.nmeas > 0 && P.nmeas <= SMALL_MEAS && P.nchain <= SMALL_CHAINS; }
+  int grp_pts = GRP_PTS;          // points per group: GRP_PTS, or LIN_QUAD_PTS for a map of few points (k_linearize_quad: four lanes per point)
+  static int group_points(int nsp) {
+    const char* e = getenv("MCP_BA_SMALL_POINTS"); const int small_pts = e ? atoi(e) : 16384;      // (0: the large-map layout for every map)
+    return (nsp <= small_pts) ? LIN_QUAD_PTS : GRP_PTS;
+  }
+  int grp_inc_max = 0;            // most point-pose incidences of any group (the W area of k_linearize_quad)
   size_t nstage = 0;        // staged 6x6 blocks over all groups
   int nrhs_rows = 0;        // staged rhs rows (6 doubles each) over all groups
   AsmPlan A;
@@ -361,6 +376,7 @@ struct mcp_ba {
   double* sig() { return d_sigma.p + 8*sig_par; }
   DevBuf<SelState> d_selstate;
   DevBuf<int> d_fail;
+  static constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
   double* h_res = nullptr;  // pinned, device-visible; [32..63] is the mailbox k_final_sums writes (ticket at 32 + MAIL_TICKET)
   unsigned long long mail_ticket = 0; int use_mailbox = 1; double* h_mail_dev = nullptr;
   int* h_fail = nullptr;    // pinned
@@ -404,14 +420,19 @@ struct mcp_ba {
   DevProblem P;
   CholPlan plan;                   // block-sparse structure of the reduced system
 
-  ~mcp_ba() {
-    // nothing of this handle may still be running when its mailbox goes back to the host allocator (a trial evaluated ahead writes there)
+  void drain() {
     if (st) (void)hipStreamSynchronize(st);
     if (st2) (void)hipStreamSynchronize(st2);
     if (st3) (void)hipStreamSynchronize(st3);
-    for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q]) { (void)hipStreamSynchronize(st_tr[q]); if (!pooled) (void)hipStreamDestroy(st_tr[q]); }
-    if (h_res) (void)hipHostFree(h_res);
-    if (h_fail) (void)hipHostFree(h_fail);
+    for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q]) (void)hipStreamSynchronize(st_tr[q]);
+    (void)hipStreamSynchronize(nullptr);          // (synchronous copies and the debug hooks use the null stream)
+  }
+  ~mcp_ba() {
+    // nothing of this handle may still be running when its mailbox goes back to the host allocator (a trial evaluated ahead writes there)
+    drain();
+    for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q] && !pooled) (void)hipStreamDestroy(st_tr[q]);
+    if (h_res) mcp::PinnedCache::get().put(h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    if (h_fail) mcp::PinnedCache::get().put(h_fail, 4*sizeof(int), hipHostMallocDefault);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
     for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) (void)hipGraphExecDestroy(chain_exec[q][r]);
@@ -900,7 +921,10 @@ int mcp_ba::prepare() {
   }
   ninc = (int)H.inc_unk.size(); nslot = (int)H.slot_unk.size();
   lap("sort+slots");
-  // ---- groups: consecutive points, <= GRP_PTS points and <= GRP_LMAX distinct poses (greedy, in order)
+  // ---- groups: consecutive points, <= grp_pts points and <= GRP_LMAX distinct poses (greedy, in order).  A map of few points
+  // (every BundleAdjustRecent window) gets quarter-size groups: four times the workgroups on a chip they do not fill anyway, a
+  // quarter of the per-group latency in the linearisation (four lanes per point) and in the Schur complement (one chunk per group)
+  grp_pts = group_points(nsp);
   nbig = 0;
   {
     std::vector<int> stamp(std::max(nfp, 1), -1), curset; curset.reserve(GRP_LMAX);
@@ -918,7 +942,7 @@ int mcp_ba::prepare() {
       const int* q = sp_q.data() + sp_q0[sp]; const int nq = big ? 0 : sp_q0[sp + 1] - sp_q0[sp];
       int fresh = 0;
       for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) ++fresh;
-      if ((int)curset.size() + fresh > GRP_LMAX || sp - start >= GRP_PTS) close(sp);
+      if ((int)curset.size() + fresh > GRP_LMAX || sp - start >= grp_pts) close(sp);
       for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) { stamp[q[k]] = gid; curset.push_back(q[k]); }
     }
     close(nsp);
@@ -983,8 +1007,11 @@ int mcp_ba::prepare() {
   lap("  local indices");
   // ---- fixed-order assembly plan (ba_group.h): which local pose pairs every group stages, and for every global pose
   // pair / pose the list of staged slots in ascending group order
-  grp_blk_max = 0;
-  for (int gi = 0; gi < ngroup; ++gi) { grp_blk_max = std::max(grp_blk_max, H.g_blk0[gi + 1]); H.g_blk0[gi + 1] += H.g_blk0[gi]; }
+  grp_blk_max = 0; grp_inc_max = 0;
+  for (int gi = 0; gi < ngroup; ++gi) {
+    grp_blk_max = std::max(grp_blk_max, H.g_blk0[gi + 1]); H.g_blk0[gi + 1] += H.g_blk0[gi];
+    grp_inc_max = std::max(grp_inc_max, H.sp_i[H.g_sp0[gi + 1]] - H.sp_i[H.g_sp0[gi]]);
+  }
   nstage = (size_t)H.g_blk0[ngroup];
   H.blk_pair.resize(nstage); H.blk_dst.assign(nstage, 0);
   H.pair_id.assign((size_t)std::max(nfp, 1)*std::max(nfp, 1), -1); H.po_start.assign(nfp + 1, 0); H.rhs_dst.assign((size_t)std::max(ngroup, 1)*GRP_LMAX, -1);
@@ -1208,8 +1235,9 @@ int mcp_ba::prepare_legacy() {
   slot_start[nmeas] = (int)slot_unk.size();
   ninc = (int)inc_unk.size(); nslot = (int)slot_unk.size();
   lap("sort+slots");
-  // ---- groups: consecutive points, <= GRP_PTS points and <= GRP_LMAX distinct poses
+  // ---- groups: consecutive points, <= grp_pts points and <= GRP_LMAX distinct poses
   std::vector<int> g_sp0, g_pose;
+  grp_pts = group_points(nsp);
   nbig = 0;
   {
     std::vector<int> curset;
@@ -1226,7 +1254,7 @@ int mcp_ba::prepare_legacy() {
       if (sp_big[sp]) ++nbig;
       std::vector<int> merged = curset;
       for (int u : q) if (std::find(merged.begin(), merged.end(), u) == merged.end()) merged.push_back(u);
-      if ((int)merged.size() > GRP_LMAX || sp - start >= GRP_PTS) { close(sp); merged = q; }
+      if ((int)merged.size() > GRP_LMAX || sp - start >= grp_pts) { close(sp); merged = q; }
       curset = merged;
     }
     close(nsp);
@@ -1311,8 +1339,8 @@ int mcp_ba::prepare_legacy() {
     }
     g_blk0[ngroup] = (int)blk_pair.size();
     nstage = blk_pair.size();
-    grp_blk_max = 0;
-    for (int gi = 0; gi < ngroup; ++gi) grp_blk_max = std::max(grp_blk_max, g_blk0[gi + 1] - g_blk0[gi]);
+    grp_blk_max = 0; grp_inc_max = 0;
+    for (int gi = 0; gi < ngroup; ++gi) { grp_blk_max = std::max(grp_blk_max, g_blk0[gi + 1] - g_blk0[gi]); grp_inc_max = std::max(grp_inc_max, sp_i[g_sp0[gi + 1]] - sp_i[g_sp0[gi]]); }
     int npairs = 0;
     std::vector<int> cnt_pair;
     for (const auto& ab : blk_ab) {
@@ -1355,18 +1383,58 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
   for (int i = 0; i < npose; ++i) pose_unk[i] = poses[i].unk;
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
-  if (d_cams.upload(cams, st) || d_chain_len.upload(chain_len, st) || d_chain_pose.upload(chain_pose, st) ||
-      d_pose_unk.upload(pose_unk, st) || d_pt_chain.upload(pt_chain, st) || d_pt_unk.upload(pt_unk, st) ||
-      d_pt_fixed.upload(pt_fixed, st) || d_m_pt.upload(H.m_pt, st) || d_m_chain.upload(H.m_chain, st) ||
-      d_m_cam.upload(H.m_cam, st) || d_m_mask.upload(H.m_mask, st) || d_m_u.upload(H.m_u, st) || d_m_v.upload(H.m_v, st) ||
-      d_m_omega.upload(H.m_om, st) || d_slot_start.upload(H.slot_start, st) || d_slot_unk.upload(H.slot_unk, st) ||
-      d_slot_inc.upload(H.slot_inc, st) || d_l_i0.upload(H.l_i0, st) || d_l_i1.upload(H.l_i1, st) || d_inc_unk.upload(H.inc_unk, st) ||
-      d_fl_point.upload(fl_point, st) || d_sp_pt.upload(H.sp_pt, st) || d_sp_m.upload(H.sp_m, st) || d_sp_i.upload(H.sp_i, st) ||
-      d_sp_big.upload(H.sp_big, st) || d_m_sp.upload(H.m_sp, st) || d_l_sp.upload(H.l_sp, st) || d_g_sp0.upload(H.g_sp0, st) ||
-      d_g_pose.upload(H.g_pose, st) || d_slot_lp.upload(H.slot_lp, st) || d_slot_first.upload(H.slot_first, st) ||
-      d_inc_lp.upload(H.inc_lp, st) || d_inc_mixed.upload(H.inc_mixed, st) ||
-      d_g_blk0.upload(H.g_blk0, st) || d_blk_pair.upload(H.blk_pair, st) || d_asm_tiles.upload(plan.all_tiles, st) || d_pair_id.upload(H.pair_id, st) ||
-      d_pr_start.upload(H.pr_start, st) || d_blk_dst.upload(H.blk_dst, st) || d_po_start.upload(H.po_start, st) || d_rhs_dst.upload(H.rhs_dst, st)) return -1;
+  // The ~40 structure arrays go into ONE device block (d_struct; every d_* below is an alias into it): one allocation, and one
+  // host-to-device copy for all the small arrays together (staged through the pinned arena) -- the large per-measurement arrays,
+  // which the builders wrote into the pinned arena already, are copied from where they lie.
+  {
+    struct Item { const void* src; size_t bytes, off; bool direct; };
+    std::vector<Item> items; items.reserve(48);
+    size_t total = 0, staged = 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    auto add = [&](auto& dbuf, const auto& vec, bool pinned) {
+      using E = typename std::remove_reference<decltype(vec)>::type::value_type;
+      const size_t bytes = vec.size()*sizeof(E);
+      dbuf.release();
+      dbuf.alias = true; dbuf.n = std::max<size_t>(vec.size(), 1); dbuf.p = reinterpret_cast<decltype(dbuf.p)>(total);      // (offset for now)
+      const bool direct = pinned && bytes >= 16384;
+      items.push_back({vec.data(), bytes, total, direct});
+      if (!direct) staged += al(std::max<size_t>(bytes, 1));
+      total += al(std::max<size_t>(bytes, 1));
+    };
+    add(d_cams, cams, false); add(d_chain_len, chain_len, false); add(d_chain_pose, chain_pose, false); add(d_pose_unk, pose_unk, false);
+    add(d_pt_chain, pt_chain, false); add(d_pt_unk, pt_unk, false); add(d_pt_fixed, pt_fixed, false);
+    add(d_m_pt, H.m_pt, true); add(d_m_chain, H.m_chain, true); add(d_m_cam, H.m_cam, true); add(d_m_mask, H.m_mask, true);
+    add(d_m_u, H.m_u, true); add(d_m_v, H.m_v, true); add(d_m_omega, H.m_om, true); add(d_slot_start, H.slot_start, true);
+    add(d_slot_unk, H.slot_unk, true); add(d_slot_inc, H.slot_inc, true); add(d_l_i0, H.l_i0, true); add(d_l_i1, H.l_i1, true);
+    add(d_inc_unk, H.inc_unk, true); add(d_fl_point, fl_point, false); add(d_sp_pt, H.sp_pt, true); add(d_sp_m, H.sp_m, true);
+    add(d_sp_i, H.sp_i, true); add(d_sp_big, H.sp_big, true); add(d_m_sp, H.m_sp, true); add(d_l_sp, H.l_sp, true);
+    add(d_g_sp0, H.g_sp0, true); add(d_g_pose, H.g_pose, true); add(d_slot_lp, H.slot_lp, true); add(d_slot_first, H.slot_first, true);
+    add(d_inc_lp, H.inc_lp, true); add(d_inc_mixed, H.inc_mixed, true); add(d_g_blk0, H.g_blk0, true); add(d_blk_pair, H.blk_pair, true);
+    add(d_asm_tiles, plan.all_tiles, false); add(d_pair_id, H.pair_id, true); add(d_pr_start, H.pr_start, true); add(d_blk_dst, H.blk_dst, true);
+    add(d_po_start, H.po_start, true); add(d_rhs_dst, H.rhs_dst, true);
+    if (d_struct.alloc(total)) return -1;
+    char* const base = d_struct.p;
+    auto fix = [&](auto& dbuf) { dbuf.p = reinterpret_cast<decltype(dbuf.p)>(base + reinterpret_cast<size_t>(dbuf.p)); };
+    fix(d_cams); fix(d_chain_len); fix(d_chain_pose); fix(d_pose_unk); fix(d_pt_chain); fix(d_pt_unk); fix(d_pt_fixed);
+    fix(d_m_pt); fix(d_m_chain); fix(d_m_cam); fix(d_m_mask); fix(d_m_u); fix(d_m_v); fix(d_m_omega); fix(d_slot_start);
+    fix(d_slot_unk); fix(d_slot_inc); fix(d_l_i0); fix(d_l_i1); fix(d_inc_unk); fix(d_fl_point); fix(d_sp_pt); fix(d_sp_m);
+    fix(d_sp_i); fix(d_sp_big); fix(d_m_sp); fix(d_l_sp); fix(d_g_sp0); fix(d_g_pose); fix(d_slot_lp); fix(d_slot_first);
+    fix(d_inc_lp); fix(d_inc_mixed); fix(d_g_blk0); fix(d_blk_pair); fix(d_asm_tiles); fix(d_pair_id); fix(d_pr_start); fix(d_blk_dst);
+    fix(d_po_start); fix(d_rhs_dst);
+    // the small ones: contiguous runs of staged items are contiguous in the device block too -- one copy per run
+    char* stage = staged ? (char*)pinned_arena().alloc(staged) : nullptr;
+    size_t so = 0;
+    for (size_t i = 0; i < items.size(); ) {
+      if (items[i].direct) { if (items[i].bytes) HIPCK(hipMemcpyAsync(base + items[i].off, items[i].src, items[i].bytes, hipMemcpyHostToDevice, st)); ++i; continue; }
+      const size_t run_off = items[i].off, run_so = so;
+      size_t run_bytes = 0;
+      for (; i < items.size() && !items[i].direct; ++i) {
+        if (items[i].bytes) std::memcpy(stage + so, items[i].src, items[i].bytes);
+        const size_t a = al(std::max<size_t>(items[i].bytes, 1)); so += a; run_bytes += a;
+      }
+      HIPCK(hipMemcpyAsync(base + run_off, stage + run_so, run_bytes, hipMemcpyHostToDevice, st));
+    }
+  }
   const size_t nc = chains.size();
   for (int b = 0; b < NSTATE; ++b)
     if (d_pose[b].alloc((size_t)npose*12) || d_pt[b].alloc((size_t)npoint*3) || d_first[b].alloc(nc*MAXC*12) ||
@@ -1391,15 +1459,23 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(16) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
+  if (const char* e = getenv("MCP_BA_DEBUG_POISON_RED")) {      // test aid: "q,lo,hi" -- the reduced-system buffer zeroed, doubles [lo, hi) of system q set to NaN
+    int q = 0; long lo = 0, hi = 0;
+    if (std::sscanf(e, "%d,%ld,%ld", &q, &lo, &hi) == 3 && q >= 0 && q < MAX_SYS && lo >= 0 && hi <= (long)(n2 + 2*(size_t)np) && lo < hi) {
+      HIPCK(hipMemset(d_red.p, 0, MAX_SYS*(n2 + 2*(size_t)np)*sizeof(double)));
+      HIPCK(hipMemset(d_red.p + q*(n2 + 2*(size_t)np) + lo, 0xFF, (size_t)(hi - lo)*sizeof(double)));
+    }
+  }
   // pinned, device-visible: [0..31] read-back block, [32 + 32 q ..] mailbox of trial q (ticket at + MAIL_TICKET)
-  constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
   if (!h_res) {
-    HIPCK(hipHostMalloc((void**)&h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)); std::memset(h_res, 0, HRES*sizeof(double));
+    h_res = (double*)mcp::PinnedCache::get().take(HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+    if (!h_res) { set_err("hipHostMalloc failed"); return -1; }
+    std::memset(h_res, 0, HRES*sizeof(double));
     void* dp = nullptr; HIPCK(hipHostGetDevicePointer(&dp, h_res, 0)); h_mail_dev = (double*)dp + 32;
   }
   for (int q = 1; q < MAX_SYS; ++q)
     if (d_sxp[q].alloc(np) || d_sxl[q].alloc((size_t)nfl*3) || d_sp0[q].alloc(nblk) || d_sp1[q].alloc(nblk) || d_sp2[q].alloc(nblk)) return -1;
-  if (!h_fail) HIPCK(hipHostMalloc((void**)&h_fail, 4*sizeof(int)));
+  if (!h_fail) { h_fail = (int*)mcp::PinnedCache::get().take(4*sizeof(int), hipHostMallocDefault); if (!h_fail) { set_err("hipHostMalloc failed"); return -1; } }
   HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
   HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
   HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st)); sig_par = 0;
@@ -1428,16 +1504,31 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   return 0;
 }
 
+// poses and points of the host state into every state buffer (current + one per trial candidate): fixed poses and points are never
+// written by a trial, so every buffer has to hold them.  One staged copy through the pinned arena (the caller, prepare(), holds it
+// until its final stream synchronisation) and one kernel that fans it out -- ten pageable hipMemcpyAsync were 0.2 ms of a window's set-up.
+struct StateFan { double* pose[MAX_SYS]; double* pt[MAX_SYS]; };
+__global__ void k_fan_state(size_t npose_d, size_t npt_d, const double* __restrict__ pose0, const double* __restrict__ pt0, StateFan f) {
+  const size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x;
+  if (i < npose_d) { const double v = pose0[i];
+#pragma unroll
+    for (int b = 0; b < MAX_SYS; ++b) f.pose[b][i] = v; }
+  if (i < npt_d) { const double v = pt0[i];
+#pragma unroll
+    for (int b = 0; b < MAX_SYS; ++b) f.pt[b][i] = v; }
+}
 int mcp_ba::upload_state() {
-  std::vector<double> pt((size_t)points.size()*3), ps((size_t)poses.size()*12);
-  for (size_t i = 0; i < poses.size(); ++i) std::memcpy(&ps[i*12], poses[i].T, 96);
-  for (size_t i = 0; i < points.size(); ++i) std::memcpy(&pt[i*3], points[i].x, 24);
+  const size_t nps = poses.size()*12, npt = points.size()*3;
+  double* stage = (double*)pinned_arena().alloc((nps + npt + 1)*sizeof(double));
+  for (size_t i = 0; i < poses.size(); ++i) std::memcpy(stage + i*12, poses[i].T, 96);
+  for (size_t i = 0; i < points.size(); ++i) std::memcpy(stage + nps + i*3, points[i].x, 24);
   cur = 0;
-  for (int b = 0; b < NSTATE; ++b) {
-    if (!ps.empty()) HIPCK(hipMemcpyAsync(d_pose[b].p, ps.data(), ps.size()*8, hipMemcpyHostToDevice, st));
-    if (!pt.empty()) HIPCK(hipMemcpyAsync(d_pt[b].p, pt.data(), pt.size()*8, hipMemcpyHostToDevice, st));
-  }
-  HIPCK(hipStreamSynchronize(st));
+  if (nps) HIPCK(hipMemcpyAsync(d_pose[0].p, stage, nps*8, hipMemcpyHostToDevice, st));
+  if (npt) HIPCK(hipMemcpyAsync(d_pt[0].p, stage + nps, npt*8, hipMemcpyHostToDevice, st));
+  StateFan f;
+  for (int b = 0; b < MAX_SYS; ++b) { f.pose[b] = d_pose[b + 1].p; f.pt[b] = d_pt[b + 1].p; }
+  const size_t nmax = std::max(nps, npt);
+  if (nmax) hipLaunchKernelGGL(k_fan_state, dim3((unsigned)((nmax + 255)/256)), dim3(256), 0, st, nps, npt, (const double*)d_pose[0].p, (const double*)d_pt[0].p, f);
   return 0;
 }
 int mcp_ba::download_state() {
@@ -1597,12 +1688,15 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   const double lam = batch_lambda[q];
   double* Sq = d_red.p + q*red_stride; double* rhsq = Sq + (size_t)np*np;
   double* resq = d_res.p + 32 + 8*q;
-  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
+  const bool small = small_mode();
+  if (small) hipLaunchKernelGGL(k_update_chains, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p,
+                                d_first[slot].p, d_second[slot].p, d_last[slot].p);
+  else hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, s, P, lam, (const double*)rhsq, (const double*)d_g.p, (const double*)d_W.p,
                               (const double*)(d_Vinv.p + q*vinv_stride), (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
   HIPCK(hipEventRecord(ev_wf[q], s));                     // the linearisation's outputs are not read below this line (join_spec_lin)
-  if (P.nchain) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
+  if (P.nchain && !small) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
                               (const double*)sig(), d_sp0[q].p);
@@ -1661,7 +1755,10 @@ int mcp_ba::linearize() {
     if (P.nmeas) hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
   }
-  if (ngroup)
+  if (ngroup && grp_pts <= LIN_QUAD_PTS)
+    hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), ((size_t)std::max(grp_blk_max, 1)*36 + (size_t)std::max(grp_inc_max, 1)*18)*sizeof(double), st, P,
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36);
+  else if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
 #ifdef MCP_LIN_PROF
@@ -1723,6 +1820,23 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
   return 0;
 }
 
+// Small bundles: the head of the NEXT iteration (median of |chi2|, sigma block, robust chi2 of the state -> d_res[24..28]) for the
+// trial state `w`, enqueued right behind the trial's own kernels, before the host has seen its result.  A trial is accepted nine
+// times out of ten; then the device has spent the host's turn-around (mailbox -> accept/reject -> first launch of the next
+// iteration: ~30 us of an ~170 us iteration) on work the next iteration needs first.  If the trial is rejected the block is never
+// looked at: it went to the sigma block of the other parity (which nobody reads: the trials of the last iteration that may still
+// have been evaluating with it are waited for below) and to d_res[24..28], which the host has already taken for this iteration.
+int mcp_ba::head_ahead(int w) {
+  for (int q = 1; q < MAX_SYS; ++q) if (ev_tr[q]) HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));
+  if (robust && median_sigma(w)) return -1;          // (flips to the fresh sigma block)
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[w].p, (const double*)sig(), d_part0.p);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 24, (const int*)nullptr);
+  if (robust) sig_par ^= 1;                          // ... which becomes the current one only if the trial is accepted (compute())
+  head_ahead_for = w;
+  return 0;
+}
+
 // one LM trial up to and including the evaluation of the trial state.
 // factorisation + back-substitution of systems [q0, q0 + n) of the batch on stream s: ~40 dependent launches, or -- with
 // MCP_BA_GRAPH=1 -- one launch of a graph captured the first time this sub-batch shape occurs (same buffers, same plan every time).
@@ -1750,6 +1864,7 @@ int mcp_ba::solve_chain(hipStream_t s, int n, int q0) {
 // on return h_res: [0] robust chi2 of the trial, [1] sum x(lambda x + b), [2] sum x^2
 int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   int defer_n1 = 0, defer_n2 = 0, defer_nsys = 0;
+  head_ahead_for = -1;
   bool ahead_single = false;      // whole batch solved on the main stream: the speculative systems' trials can still be evaluated ahead on the second
   if (spec_ok && sys_cur + 1 < batch_n && batch_lambda[sys_cur + 1] == lam) {
     // an earlier trial of this iteration already built and solved this system speculatively (possibly on the second stream)
@@ -1855,13 +1970,16 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const int tr = cand(sys_cur); last_tr = tr; last_xp = &d_xp_cand; last_xl = &d_xl;
   const double* bp_glob = bp();
   tic(ST_UPDATE);
-  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
+  const bool small = small_mode();
+  if (small) hipLaunchKernelGGL(k_update_chains, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p,
+                                d_first[tr].p, d_second[tr].p, d_last[tr].p);
+  else hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
   toc();
   tic(ST_EVAL);
-  launch_chains(tr);
+  if (!small) launch_chains(tr);
   launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   const bool mailbox = use_mailbox && !prm.profile;
@@ -1878,6 +1996,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   }
   toc();
   mark("trial_end", st);
+  if (head_ahead_want && mailbox && !multi()) { if (head_ahead(tr)) return -1; mark("head_ahead", st); }
   if (defer_nsys) {
     const int n2 = defer_n2;
     if (solve_chain(st2, n2, defer_n1)) return -1;
@@ -1948,16 +2067,24 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       mcp_ba_iter_log lg; std::memset(&lg, 0, sizeof lg);
       mark("iter", st);
       // preIteration + first robustify: sigma^2 from |chi2| at the iteration-start state
+      constexpr int RS = 24;
+      const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+      // (small bundle: the head of this iteration was enqueued behind the trial that produced this state, before the host knew it
+      //  would be accepted -- head_ahead(); all that is left is to make its sigma block the current one)
+      const bool head_done = (it > 0 && head_ahead_for == cur);
+      head_ahead_for = -1;
+      head_ahead_want = small_mode() && use_mailbox && !prm.profile && it + 1 < n_iter;
+      if (head_done) { if (robust) sig_par ^= 1; ++dbg_head_ahead; }
+      else {
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
-      const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
       if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
       // iteration-start robust chi2 and the sigma block go to d_res[24..28]; they are read back together with the first
       // trial's results (one host synchronisation less per iteration) -- except in the first iteration, whose lambda comes
       // from the diagonal of the freshly built system
-      constexpr int RS = 24;
       hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, RS, (const int*)nullptr);
       toc();
+      }
       // several ranks: the sum over the ranks rides on the first trial's all-reduce (d_res[0..3] + d_res[4], see solve_trial);
       // the first iteration needs it before its first trial
       if (it == 0) { if (allreduce(d_res.p + RS, 1, 0, false, "iteration-start chi2")) return MCP_ERR_RUNTIME; }
@@ -2014,6 +2141,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           // scale terms from it with the current lambda and b
           tempChi = DBL_MAX;
           scale = 0; ss = 0;
+          head_ahead_for = -1;                       // (the state is about to be rewritten with the stale step)
           std::vector<double> xp(np), xl((size_t)nfl*3), bpv(np), gv((size_t)nfl*3);
           if (np) { HIPCK(hipMemcpy(xp.data(), d_xp_good.p, (size_t)np*8, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(bpv.data(), bp(), (size_t)np*8, hipMemcpyDeviceToHost)); }
           if (nfl) { HIPCK(hipMemcpy(xl.data(), d_xl_good.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(gv.data(), d_g.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); }
@@ -2089,6 +2217,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     nCounter = cj;
   }
   if (join_spec()) return MCP_ERR_RUNTIME;
+  if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d\n", dbg_head_ahead); dbg_head_ahead = 0; }
   if (evt_debug) { fprintf(stderr, "[evt] trials evaluated ahead and used: %d; host wait on mailbox: own trials %.0f us, ahead trials %.0f us\n", dbg_pre, dbg_wait_us[0], dbg_wait_us[1]); dbg_pre = 0; dbg_wait_us[0] = dbg_wait_us[1] = 0; }
   evt_flush();
   int rc = final_stats(nCounter);
@@ -2233,6 +2362,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
   { const char* e = getenv("MCP_BA_TEST_FAIL_TRIAL"); if (e) h->test_fail_trial = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_DELAY"); if (e) h->spec_delay = atoi(e); }
+  { const char* e = getenv("MCP_BA_SMALL"); if (e) h->small_on = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_RIDE"); if (e) h->sel_ride = atoi(e); }
   { const char* e = getenv("MCP_BA_TIMEOUT_MS"); if (e && atof(e) > 0) h->timeout_ms = atof(e); }
   for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->ev_tr[q], hipEventDisableTiming) != hipSuccess ||
@@ -2252,7 +2382,13 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
                           hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess)) { set_err("second stream / events could not be created"); delete h; return nullptr; }
   return h;
 }
-void mcp_ba_destroy(mcp_ba* h) { if (h) { (void)hipSetDevice(h->device); delete h; } }
+void mcp_ba_destroy(mcp_ba* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  h->drain();                          // nothing of this handle is in flight any more ...
+  mcp::DevCache::Quiesced q;           // ... so its blocks can go straight back to the cache (ba_pool.h)
+  delete h;
+}
 
 int mcp_ba_add_pose(mcp_ba* h, const double R[9], const double t[3], int fixed) {
   HPose p; std::memset(&p, 0, sizeof p);
@@ -2559,7 +2695,7 @@ int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out
   HIPCK(hipMemcpy(d.p, A, (size_t)n*n*8, hipMemcpyHostToDevice));
   HIPCK(hipMemcpy(d.p + (size_t)n*n, b, (size_t)n*8, hipMemcpyHostToDevice));
   HIPCK(hipMemset(f.p, 0, 16));
-  CholPlan plan;
+  CholPlan plan; plan.persist_min_ntc = 1;
   if (plan.build(n, std::vector<unsigned char>())) { set_err("mcp_chol_debug_factor: plan allocation failed"); return -1; }
   CholPersist& P = plan.persist;
   if (!plan.use_persist || !P.ok) { set_err("mcp_chol_debug_factor: the persistent factorisation is switched off"); return -1; }

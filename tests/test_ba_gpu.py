@@ -844,6 +844,39 @@ def test_bench_two_rank_path_end_to_end(gpu_required):
     assert "debug" in d["config"] and d["config"]["chi2_last"] < d["config"]["chi2_first"]
 
 
+@pytest.mark.parametrize("cfg,iters", [("c1", 12), ("c2small", 10), ("window", 10)])
+def test_small_bundle_scheduling_does_not_change_a_single_bit(gpu_required, cfg, iters, monkeypatch):
+    """A small bundle (BundleAdjustRecent's window) gets the trial's pose update and chain transforms in one launch and the next
+    iteration's head (median, sigma block, robust chi2) enqueued behind every trial before the host has seen its result
+    (ba_small.h, mcp_ba::head_ahead).  Scheduling only: with MCP_BA_SMALL=0 the same problem runs the general sequence of launches
+    and must give the same iteration logs, poses, points and outliers, bit for bit -- rejected trials (whose head is thrown
+    away) included."""
+    from mcptam_amd import synth
+    p = (synth.recent_window(synth.make_config("metric")) if cfg == "window" else
+         synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg))
+    small = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    monkeypatch.setenv("MCP_BA_SMALL", "0")
+    plain = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    assert small["rc"] == plain["rc"] == iters
+    assert small["logs"] == plain["logs"]
+    assert np.array_equal(small["R"], plain["R"]) and np.array_equal(small["t"], plain["t"]) and np.array_equal(small["X"], plain["X"])
+    assert small["outliers"] == plain["outliers"] and small["sigma_sq"] == plain["sigma_sq"] and small["lam"] == plain["lam"]
+
+
+@pytest.mark.parametrize("cfg,iters", [("c1", 10), ("c2small", 8)])
+def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeypatch):
+    """Maps of few points are cut into groups of 16 points with four lanes per point in the linearisation (k_linearize_quad) instead
+    of groups of 64 with one lane each: other summation orders, same mathematics.  MCP_BA_SMALL_POINTS=0 forces the large-map
+    layout; the two runs agree to rounding, and both are within the oracle's tolerance of each other's state."""
+    from mcptam_amd import synth
+    p = synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg)
+    quad = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")
+    full = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    rep = compare_runs(quad, full, tol_state=1e-7, tol_chi=1e-9)
+    assert rep["branch_flips"] == 0, rep
+
+
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
                                  dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
                                  dict(MCP_BA_STREAM_POOL="0")])
