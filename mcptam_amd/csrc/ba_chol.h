@@ -208,7 +208,7 @@ __device__ unsigned long long g_chol_prof[256*2*8];
 #define CHOL_STAMP(i) do {} while (0)
 #endif
 __global__ void __launch_bounds__(CH_STEP_THREADS)
-k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride CH_DIAG_PARAMS()) {
+k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restrict__ tiles, int* __restrict__ fail, size_t sys_stride CH_DIAG_PARAMS(), int fuse_back /* single-tile system: the back-substitution here too */) {
   if (blockIdx.y) { S += blockIdx.y*sys_stride; fail += blockIdx.y; CH_DIAG_OFFSET(blockIdx.y); }     // further systems of a multi-lambda batch
   // tiles: the structurally non-zero tiles this step touches, packed (ti << 16 | tj), block column k first
   // bit 31: both tiles of panel k-1 the update of this tile multiplies -- (ti, k-1) and (tj, k-1) -- are tiles of the plan; bit 30:
@@ -319,6 +319,21 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     CHOL_STAMP(4);
     return;
   }
+  if (fuse_back) {
+    // A system of one tile (n <= 32: the BundleAdjustRecent window, <= 5 free poses): x = L^-T y is a 32 x 32 matrix-vector product of
+    // what this wavefront holds -- lane 32 + r: row r of L^-T, lane 32 + nbe: y (the right-hand-side row after the column operations)
+    // -- taken here, in the order k_chol_back takes it (even and odd columns apart, then their sum), instead of in a launch of its own.
+    const int ly = 32 + nbe;
+    double xa = 0.0, xb = 0.0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; c += 2) {
+      const double y0 = readlane_f64(d[c], ly), y1 = readlane_f64(d[c + 1], ly);
+      const double l0 = (c >= rr && rr < nbe && c < nbe) ? d[c] : ((c == rr) ? 1.0 : 0.0);
+      const double l1 = (c + 1 >= rr && rr < nbe && c + 1 < nbe) ? d[c + 1] : ((c + 1 == rr) ? 1.0 : 0.0);
+      xa += l0*((c < nbe) ? y0 : 0.0); xb += l1*((c + 1 < nbe) ? y1 : 0.0);
+    }
+    if (low && rr < nbe) S[(size_t)n*n + rr] = xa + xb;
+  }
   if (!low) {
     // (L_kk itself is not stored: the forward substitution rides on the factorisation as the augmented row, the backward
     // one uses the inverse below; the other tiles of block column k already hold X = C L_kk^-T)
@@ -326,7 +341,7 @@ k_chol_step(double* __restrict__ S, int n, int nrows, int k, const int* __restri
     double* p = Dg + (size_t)k*(CH_NB*CH_NB) + rr*CH_NB;        // row rr of L_kk^-T (upper triangular)
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) if (c >= rr && c < nbe) p[c] = d[c];
-  } else if (r0 + rr < nrows && (offdiag || rr >= nbe)) {
+  } else if (!fuse_back && r0 + rr < nrows && (offdiag || rr >= nbe)) {      // (fused back-substitution: row n holds x already)
     double* p = S + (size_t)(r0 + rr)*n + k0;
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) if (c < nbe) p[c] = d[c];
@@ -592,6 +607,9 @@ struct CholPlan {
     return 0;
   }
   size_t tile_updates() const { return step_tiles.size(); }
+  // one tile, 16-byte panel stores off (the fused path lives in the plain store branch): factorisation and back-substitution in one launch
+  bool fuse_single() const { return ntc == 1 && n < CH_NB /* the right-hand-side row lies in the same tile */ && !(CH_PSTORE16 && !(n & 1)) && fuse_single_on; }
+  bool fuse_single_on = [] { const char* e = getenv("MCP_BA_CHOL_FUSE1"); return !(e && atoi(e) == 0); }();
 };
 
 // factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
@@ -604,12 +622,14 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
   double* dg = plan.d_diag + q0*plan.diag_stride;
   for (int k = 0; k < plan.ntc; ++k) {
     const int cnt = plan.step_start[k + 1] - plan.step_start[k];
-    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride, dg, plan.diag_stride);
+    if (cnt > 0) hipLaunchKernelGGL(k_chol_step, dim3(cnt, nsys), dim3(CH_STEP_THREADS), 0, st, S, n, nrows, k, (const int*)(plan.d_step_tiles + plan.step_start[k]), fail, sys_stride, dg, plan.diag_stride,
+                                    plan.fuse_single() ? 1 : 0);
   }
 }
 // row n: y -> x = L^-T y
 inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
   if (plan.use_persist && plan.persist.ok) { (void)chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0); return; }
+  if (plan.fuse_single()) return;      // (k_chol_step has left x in row n)
   const int n = plan.n;
   S += q0*sys_stride;
   const double* dg = plan.d_diag + q0*plan.diag_stride;

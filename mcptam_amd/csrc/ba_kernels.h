@@ -532,15 +532,15 @@ k_update_poses(DevProblem P, double lambda, const double* __restrict__ xp, const
 constexpr int BS_BLOCK = 256;
 constexpr int BS_TPP = 4;          // threads per point in k_backsub
 // back-substitution for the points + oplus; partial sums of x(lambda x + b) and x^2
-__global__ void __launch_bounds__(BS_BLOCK)
-k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ g,
+// (body: block `blk` of the launch -- k_backsub passes blockIdx.x, k_trial_apply of ba_small.h blockIdx.x - 1)
+__device__ __forceinline__ void backsub_body(const DevProblem& P, int blk, double lambda, const double* __restrict__ xp, const double* __restrict__ g,
           const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ pt_cur,
           double* __restrict__ pt_trial, double* __restrict__ xl, double* __restrict__ part_scale,
           double* __restrict__ part_ss) {
   __shared__ double lds[BS_BLOCK/64];
   // BS_TPP threads per point share its incidences (each walk is a chain of dependent index -> pose-update loads), partial
   // sums are combined with a fixed shuffle tree
-  const int l = (blockIdx.x*BS_BLOCK + threadIdx.x)/BS_TPP, q = threadIdx.x & (BS_TPP - 1);
+  const int l = (blk*BS_BLOCK + threadIdx.x)/BS_TPP, q = threadIdx.x & (BS_TPP - 1);
   double sc = 0.0, ss = 0.0;
   const bool valid = l < P.nfl;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -569,7 +569,14 @@ k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const doub
   }
   const double a = block_sum<BS_BLOCK>(sc, lds);
   const double b = block_sum<BS_BLOCK>(ss, lds);
-  if (threadIdx.x == 0) { part_scale[blockIdx.x] = a; part_ss[blockIdx.x] = b; }
+  if (threadIdx.x == 0) { part_scale[blk] = a; part_ss[blk] = b; }
+}
+__global__ void __launch_bounds__(BS_BLOCK)
+k_backsub(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ g,
+          const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ pt_cur,
+          double* __restrict__ pt_trial, double* __restrict__ xl, double* __restrict__ part_scale,
+          double* __restrict__ part_ss) {
+  backsub_body(P, blockIdx.x, lambda, xp, g, W, Vinv, pt_cur, pt_trial, xl, part_scale, part_ss);
 }
 
 // VertexRelPoint::oplusImpl (ChainBundle.cc:237-281) with a GIVEN update per free point: what g2o's update(_solver->x()) does with the

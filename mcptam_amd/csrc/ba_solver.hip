@@ -352,6 +352,11 @@ struct mcp_ba {
   int head_ahead_for = -1;        // state buffer whose iteration head is already on the main stream (small bundles), or -1
   bool head_ahead_want = false; int dbg_head_ahead = 0;
   int head_ahead(int w);
+  int head_small(int w, bool sum_aside = false);
+  int join_sum();
+  int sum_aside(); int sum_w = -1; const double* sum_sig = nullptr;
+  hipEvent_t ev_head = nullptr, ev_sum = nullptr; bool sum_pending = false;
+  DevBuf<double> d_parth;         // partial sums of the robust chi2 taken on the second stream (head_small)
   int small_on = 1;               // MCP_BA_SMALL=0: a small bundle runs the same launches as a large one (ba_small.h)
   bool small_mode() const { return small_on && !multi() && P.nmeas > 0 && P.nmeas <= SMALL_MEAS && P.nchain <= SMALL_CHAINS; }
   int grp_pts = GRP_PTS;          // points per group: GRP_PTS, or LIN_QUAD_PTS for a map of few points (k_linearize_quad: four lanes per point)
@@ -439,6 +444,8 @@ struct mcp_ba {
     if (st2) { (void)hipStreamSynchronize(st2); if (!pooled) (void)hipStreamDestroy(st2); }
     if (st3) { (void)hipStreamSynchronize(st3); if (!pooled) (void)hipStreamDestroy(st3); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_head) (void)hipEventDestroy(ev_head);
+    if (ev_sum) (void)hipEventDestroy(ev_sum);
     if (ev_spec) (void)hipEventDestroy(ev_spec);
     if (ev_spec3) (void)hipEventDestroy(ev_spec3);
     for (int q = 0; q < MAX_SYS; ++q) if (ev_tr[q]) (void)hipEventDestroy(ev_tr[q]);
@@ -1457,7 +1464,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
-      d_part2.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(16) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
+      d_part2.alloc(nblk) || d_parth.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(16) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
   if (const char* e = getenv("MCP_BA_DEBUG_POISON_RED")) {      // test aid: "q,lo,hi" -- the reduced-system buffer zeroed, doubles [lo, hi) of system q set to NaN
     int q = 0; long lo = 0, hi = 0;
@@ -1689,12 +1696,15 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   double* Sq = d_red.p + q*red_stride; double* rhsq = Sq + (size_t)np*np;
   double* resq = d_res.p + 32 + 8*q;
   const bool small = small_mode();
-  if (small) hipLaunchKernelGGL(k_update_chains, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p,
-                                d_first[slot].p, d_second[slot].p, d_last[slot].p);
-  else hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
+  if (small) hipLaunchKernelGGL(k_trial_apply, dim3(1 + (nfl ? nbb : 0)), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p,
+                                d_first[slot].p, d_second[slot].p, d_last[slot].p, (const double*)d_g.p, (const double*)d_W.p, (const double*)(d_Vinv.p + q*vinv_stride),
+                                (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
+  else {
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, s, P, lam, (const double*)rhsq, (const double*)d_g.p, (const double*)d_W.p,
                               (const double*)(d_Vinv.p + q*vinv_stride), (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
+  }
   HIPCK(hipEventRecord(ev_wf[q], s));                     // the linearisation's outputs are not read below this line (join_spec_lin)
   if (P.nchain && !small) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
@@ -1820,6 +1830,38 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
   return 0;
 }
 
+// small bundles: the whole head of an iteration for state `w` in one launch (ba_small.h) -- the sigma block of the other parity
+// becomes current (as median_sigma() does), d_res[24] = robust chi2 of the state, d_res[25..28] = copy of the sigma block
+int mcp_ba::head_small(int w, bool sum_aside) {
+  tic(ST_SELECT);
+  const double* prev = sig();
+  if (robust) { sig_par ^= 1; sel_src = -1; }
+  // sum_aside: linearize() needs the sigma block, nobody on the device needs the robust chi2 (the host reads it with the next
+  // trial's results): that sum -- a third of this kernel's time -- goes to the second stream, next to the linearisation
+  const bool aside = sum_aside && st2 && ev_head && ev_sum && d_parth.p;
+  hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), 0, st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, (unsigned long long)(m_total/2), m_total,
+                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, prev, d_res.p + 8, sig(), d_res.p + 25, d_res.p, 24, aside ? 0 : 1);
+  if (aside) { HIPCK(hipEventRecord(ev_head, st)); sum_w = w; sum_sig = sig(); }      // (the second stream's part: sum_aside(), once the caller has queued what else it has for that stream)
+  toc();
+  return 0;
+}
+// the robust chi2 of state sum_w on the second stream, behind the head kernel (ev_head) -- enqueued AFTER the speculative work of
+// the iteration, which must not wait for the main stream's trial
+int mcp_ba::sum_aside() {
+  if (sum_w < 0) return 0;
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  HIPCK(hipStreamWaitEvent(st2, ev_head, 0));
+  hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st2, P.nmeas, robust, (const double*)d_chi2[sum_w].p, (const double*)sum_sig, d_parth.p);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st2, nbe, (const double*)d_parth.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 24, (const int*)nullptr);
+  HIPCK(hipEventRecord(ev_sum, st2));
+  sum_pending = true; sum_w = -1;
+  return 0;
+}
+// the sum head_small() put on the second stream has to be in d_res[24] before anything on the main stream reads that block
+int mcp_ba::join_sum() {
+  if (sum_pending) { HIPCK(hipStreamWaitEvent(st, ev_sum, 0)); sum_pending = false; }
+  return 0;
+}
 // Small bundles: the head of the NEXT iteration (median of |chi2|, sigma block, robust chi2 of the state -> d_res[24..28]) for the
 // trial state `w`, enqueued right behind the trial's own kernels, before the host has seen its result.  A trial is accepted nine
 // times out of ten; then the device has spent the host's turn-around (mailbox -> accept/reject -> first launch of the next
@@ -1828,10 +1870,7 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
 // have been evaluating with it are waited for below) and to d_res[24..28], which the host has already taken for this iteration.
 int mcp_ba::head_ahead(int w) {
   for (int q = 1; q < MAX_SYS; ++q) if (ev_tr[q]) HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));
-  if (robust && median_sigma(w)) return -1;          // (flips to the fresh sigma block)
-  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[w].p, (const double*)sig(), d_part0.p);
-  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 24, (const int*)nullptr);
+  if (head_small(w, true)) return -1;                // (flips to the fresh sigma block)
   if (robust) sig_par ^= 1;                          // ... which becomes the current one only if the trial is accepted (compute())
   head_ahead_for = w;
   return 0;
@@ -1971,12 +2010,15 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const double* bp_glob = bp();
   tic(ST_UPDATE);
   const bool small = small_mode();
-  if (small) hipLaunchKernelGGL(k_update_chains, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p,
-                                d_first[tr].p, d_second[tr].p, d_last[tr].p);
-  else hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
+  if (small) hipLaunchKernelGGL(k_trial_apply, dim3(1 + (nfl ? nbb : 0)), dim3(256), 0, st, P, lam, (const double*)rhs(), bp_glob, (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p,
+                                d_first[tr].p, d_second[tr].p, d_last[tr].p, (const double*)d_g.p, (const double*)d_W.p, (const double*)Vinv(),
+                                (const double*)d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
+  else {
+  hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
                               d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
+  }
   toc();
   tic(ST_EVAL);
   if (!small) launch_chains(tr);
@@ -1989,6 +2031,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (multi_trial_tail(st, 0, sys_cur, tr, nbe, d_part0.p, nbb, nfl ? d_part1.p : nullptr, nfl ? d_part2.p : nullptr, d_res.p + 6, 6, true,
                          mailbox ? h_mail_dev : (double*)nullptr, MAIL_TICKET, mail_ticket0)) return -1;
   } else {
+    if (join_sum()) return -1;                       // (this launch forwards d_res[24..28], the head of the iteration, to the host)
     hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
                        nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
                        mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0);
@@ -2014,6 +2057,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (run_ahead(1)) return -1;
     if (spec_trials >= 2 && !multi()) for (int q = 2; q < defer_nsys; ++q) if (run_ahead(q)) return -1;
   } else if (ahead_single) { if (run_ahead(1)) return -1; }
+  if (sum_aside()) return -1;
   if (mailbox) {
     // the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
     if (wait_mail(0, mail_ticket0, multi() ? MAIL_TICKET : 29)) return -1;
@@ -2075,6 +2119,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       head_ahead_for = -1;
       head_ahead_want = small_mode() && use_mailbox && !prm.profile && it + 1 < n_iter;
       if (head_done) { if (robust) sig_par ^= 1; ++dbg_head_ahead; }
+      else if (small_mode()) { if (head_small(cur)) return MCP_ERR_RUNTIME; }
       else {
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
@@ -2217,7 +2262,16 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     nCounter = cj;
   }
   if (join_spec()) return MCP_ERR_RUNTIME;
+  if (join_sum()) return MCP_ERR_RUNTIME;
   if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d\n", dbg_head_ahead); dbg_head_ahead = 0; }
+#ifdef MCP_HS_PROF
+  if (evt_debug) {
+    (void)hipDeviceSynchronize();
+    unsigned long long pr[16]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_hs_prof), sizeof pr);
+    fprintf(stderr, "[hs prof] sweep1 %llu  find0 %llu  (sweep1b) %llu  find1 %llu  sweep2 %llu  lds-select %llu  sigma %llu  sum-sweep %llu  final %llu  (clock64 ticks; %llu candidates)\n",
+            pr[1] - pr[0], pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[10]);
+  }
+#endif
   if (evt_debug) { fprintf(stderr, "[evt] trials evaluated ahead and used: %d; host wait on mailbox: own trials %.0f us, ahead trials %.0f us\n", dbg_pre, dbg_wait_us[0], dbg_wait_us[1]); dbg_pre = 0; dbg_wait_us[0] = dbg_wait_us[1] = 0; }
   evt_flush();
   int rc = final_stats(nCounter);
@@ -2379,7 +2433,9 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   if (h->overlap_spec && (
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                          hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess)) { set_err("second stream / events could not be created"); delete h; return nullptr; }
+                          hipEventCreateWithFlags(&h->ev_spec, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_head, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->ev_sum, hipEventDisableTiming) != hipSuccess)) { set_err("second stream / events could not be created"); delete h; return nullptr; }
   return h;
 }
 void mcp_ba_destroy(mcp_ba* h) {

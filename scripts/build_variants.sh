@@ -22,6 +22,7 @@ for v in "$@"; do
     linabl3) build linabl3 -DLIN_ABL=3 & ;;                # timing ablation: no W block stores in k_linearize_group (results wrong)
     proflin) build proflin -DMCP_LIN_PROF & ;;             # phase stamps of k_linearize_group
     proflin2) build proflin2 -DMCP_LIN_PROF -DLIN_WAVES=2 & ;;                    # k_linearize_group held to 256 registers (two wavefronts per SIMD)                      # second-order rsqrt correction in the panel chain
+    hsprof) build hsprof -DMCP_HS_PROF=1 & ;;                # phase stamps of k_head_small (ba_small.h)
     cpprof) build cpprof -DMCP_CP_PROF=1 & ;;                # phase stamps of the one-launch factorisation (ba_chol2.h)
     cpprof2) build cpprof2 -DMCP_CP_PROF=2 & ;;
     cpprof3) build cpprof3 -DMCP_CP_PROF=3 & ;;

@@ -1,4 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-echo "== c2small, poison"; MCP_DEV_CACHE_POISON=1 timeout -k 5 200 python scripts/experiments/dbg_cache.py c2small 2>&1 | tail -8 | cut -c1-400
-echo "== tests, poison"; MCP_DEV_CACHE_POISON=1 timeout -k 5 500 python -m pytest tests/test_ba_gpu.py -q -m gpu 2>&1 | tail -8
+timeout -k 5 120 python scripts/bench_window.py --trace > gpurun_out/window.json 2>gpurun_out/window.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/window.json')); print(d['ms_median']); 
+PY
+grep "^\[evt\]" gpurun_out/window.err | tail -3
+timeout -k 5 500 python -m pytest tests/test_ba_gpu.py -q -m gpu 2>&1 | tail -5
