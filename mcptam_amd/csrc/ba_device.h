@@ -234,24 +234,60 @@ __host__ __device__ inline void point_oplus(const double* x, const double* u, do
 // Sum of v[0..31] over the 64 lanes of a wavefront, entry by entry, as a reduce-scatter butterfly: on return lanes 2i and 2i + 1 hold
 // the total of entry idx = i (= lane >> 1).  At offset 32, 16, 8, 4, 2 a lane keeps the half of its entries its lane bit selects and
 // receives the partner's contribution to them (16 + 8 + 4 + 2 + 1 exchanges), the last exchange (offset 1) completes the sum.
-template <int N>
-__device__ inline void wave_rs_step(const double* in, double* out, int lane, int off) {
-  const bool up = (lane & off) != 0;
+// The exchanges avoid the LDS crossbar (ds_bpermute, ~100 cycles each in a dependent chain) where the lane distance allows it:
+// distance 32 and 16 -- 24 of the 32 exchanges -- are one v_permlane32_swap / v_permlane16_swap per register half, which hands BOTH
+// partners what they are owed at once (the kept half of the lower lanes / even rows and the sent half of the upper lanes / odd rows
+// travel in one register, the other two in the other: after the swap every lane adds its two registers); distance 8, 2 and 1 are DPP
+// row rotations / quad permutations.  Same additions as with __shfl_xor (a + b vs b + a), so the same bits.
+__device__ inline double mk_f64(unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); }
+template <int OFF>
+__device__ inline double wave_swap_add(double a /* entries j */, double b /* entries j + N/2 */) {
+  static_assert(OFF == 32 || OFF == 16, "permlane swaps");
+  const unsigned int alo = (unsigned int)__double2loint(a), ahi = (unsigned int)__double2hiint(a);
+  const unsigned int blo = (unsigned int)__double2loint(b), bhi = (unsigned int)__double2hiint(b);
+  if constexpr (OFF == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), q = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return mk_f64(r[0], q[0]) + mk_f64(r[1], q[1]);
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), q = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return mk_f64(r[0], q[0]) + mk_f64(r[1], q[1]);
+  }
+}
+template <int CTRL>
+__device__ inline double wave_dpp(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false));
+}
+template <int OFF>
+__device__ inline double wave_xor(double v) {
+  if constexpr (OFF == 8) return wave_dpp<0x128>(v);            // row_ror:8
+  else if constexpr (OFF == 2) return wave_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+  else if constexpr (OFF == 1) return wave_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+  else return __shfl_xor(v, OFF, 64);
+}
+template <int N, int OFF>
+__device__ inline void wave_rs_step(const double* in, double* out, int lane) {
+  if constexpr (OFF == 32 || OFF == 16) {
 #pragma unroll
-  for (int j = 0; j < N/2; ++j) {
-    const double keep = up ? in[j + N/2] : in[j], send = up ? in[j] : in[j + N/2];
-    out[j] = keep + __shfl_xor(send, off, 64);
+    for (int j = 0; j < N/2; ++j) out[j] = wave_swap_add<OFF>(in[j], in[j + N/2]);
+  } else {
+    const bool up = (lane & OFF) != 0;
+#pragma unroll
+    for (int j = 0; j < N/2; ++j) {
+      const double keep = up ? in[j + N/2] : in[j], send = up ? in[j] : in[j + N/2];
+      out[j] = keep + wave_xor<OFF>(send);
+    }
   }
 }
 __device__ inline double wave_reduce_scatter32(const double (&v)[32], int lane, int& idx) {
   double a16[16], a8[8], a4[4], a2[2], a1[1];
-  wave_rs_step<32>(v, a16, lane, 32);
-  wave_rs_step<16>(a16, a8, lane, 16);
-  wave_rs_step<8>(a8, a4, lane, 8);
-  wave_rs_step<4>(a4, a2, lane, 4);
-  wave_rs_step<2>(a2, a1, lane, 2);
+  wave_rs_step<32, 32>(v, a16, lane);
+  wave_rs_step<16, 16>(a16, a8, lane);
+  wave_rs_step<8, 8>(a8, a4, lane);
+  wave_rs_step<4, 4>(a4, a2, lane);
+  wave_rs_step<2, 2>(a2, a1, lane);
   idx = (lane >> 1) & 31;
-  return a1[0] + __shfl_xor(a1[0], 1, 64);
+  return a1[0] + wave_xor<1>(a1[0]);
 }
 
 }  // namespace mcp

@@ -1441,12 +1441,13 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
                    double* __restrict__ mu_out, double* __restrict__ w_out, int est) {
   constexpr int NT = PRR_THREADS, NW = NT/64, BPT = SEL_BINS/NT;
   __shared__ unsigned int hist[SEL_BINS];
-  __shared__ unsigned int wtot[NW], sres[3];
+  __shared__ unsigned int wtot[NW], wtot2[NW], sres[3];
   __shared__ unsigned long long skey;
   __shared__ double red[NW][28];
   __shared__ double pose[12], v6[6], tot[27];
   __shared__ int nf_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned int pred_d0 = 0xffffffffu;            // digit 0 of the last median (none yet)
   for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;          // every digit pass leaves it zero again
   bool fnd[PRR_PPT]; int camk[PRR_PPT];
   double fpos[PRR_PPT][2], sinv[PRR_PPT], img[PRR_PPT][2], cd[PRR_PPT][4], ex[PRR_PPT][2], e2[PRR_PPT];
@@ -1521,7 +1522,28 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
 #pragma unroll
       for (int k = 0; k < PRR_PPT; ++k) key[k] = (unsigned long long)__double_as_longlong(fabs(e2[k]));
       unsigned long long prefix = 0ull; unsigned int kk = (unsigned int)(nf/2);
-      for (int pass = 0; pass < SEL_PASSES; ++pass) {
+      int pass0 = 0;
+      if (pred_d0 < (unsigned int)SEL_BINS) {
+        // Digit 0 (sign + exponent bits) without a histogram: the median of the last iteration's squared errors names the digit the
+        // new median most likely has; how many keys lie below that digit and how many share it are two votes per key and one
+        // barrier (a histogram pass is atomics on the same few counters, an owner scan and three barriers).  A wrong guess: pass 0 as before.
+        const int sh0 = sel_shift(0);
+        unsigned int cl = 0u, ce = 0u;
+#pragma unroll
+        for (int k = 0; k < PRR_PPT; ++k) {
+          const unsigned int b0 = (unsigned int)(key[k] >> sh0) & (SEL_BINS - 1);
+          cl += (unsigned int)__popcll(__ballot(fnd[k] && b0 < pred_d0));
+          ce += (unsigned int)__popcll(__ballot(fnd[k] && b0 == pred_d0));
+        }
+        if (lane == 0) { wtot[wave] = cl; wtot2[wave] = ce; }
+        __syncthreads();
+        unsigned int below = 0u, equal = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { below += wtot[w]; equal += wtot2[w]; }
+        __syncthreads();                               // (wtot is the scan's scratch below)
+        if (below <= kk && kk < below + equal && equal > 1u) { prefix = (unsigned long long)pred_d0 << sh0; kk -= below; pass0 = 1; }
+      }
+      for (int pass = pass0; pass < SEL_PASSES; ++pass) {
         const int sh = sel_shift(pass);
         const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
         const unsigned long long himask = (pass == 0) ? 0ull : (~0ull << sel_shift(pass - 1));
@@ -1561,6 +1583,7 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
         }
       }
       const double med = __longlong_as_double((long long)prefix);
+      pred_d0 = (unsigned int)(prefix >> sel_shift(0)) & (SEL_BINS - 1);
       s2 = mest_sigma_sq(est, (double)nf, med);
     }
     PRR_STAMP(2);
