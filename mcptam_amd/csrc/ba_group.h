@@ -699,6 +699,91 @@ k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __re
   }
 }
 
+// ---- the same assembly for systems whose entries are sums of MANY staged contributions -- a BundleAdjustRecent window: a handful of
+// free poses that every one of its 150 groups stages.  k_assemble gives an entry to one thread; 155 contributions are then 20 rounds
+// of 8 loads, 26 us of dependent round trips for a 19 x 18 system.  Here an entry has ASML_LPE lanes, each sums a contiguous eighth
+// of the list (in list order), and the eight partial sums are added in a fixed tree ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)); one
+// workgroup per tile ROW (32 entries x 8 lanes), so a one-tile system is spread over 19 compute units instead of one.
+// (Another -- fixed -- summation order than k_assemble's: which of the two runs is decided by the structure, at Prepare().)
+constexpr int ASML_LPE = 8;
+__device__ inline double asml_tree8(double v) {
+  v += wave_xor<1>(v); v += wave_xor<2>(v); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+// partial sum of p[0], p[stride], ... over this lane's share of n terms, in order, four loads in flight
+__device__ inline double asml_part(const double* __restrict__ p, int stride, int n, int l8) {
+  const int c0 = (n*l8)/ASML_LPE, c1 = (n*(l8 + 1))/ASML_LPE;
+  double a = 0.0;
+  int k = c0;
+  p += (size_t)c0*stride;
+  for (; k + 4 <= c1; k += 4, p += 4*(size_t)stride) {
+    const double x0 = p[0], x1 = p[stride], x2 = p[2*(size_t)stride], x3 = p[3*(size_t)stride];
+    a += x0; a += x1; a += x2; a += x3;
+  }
+  for (; k < c1; ++k, p += stride) a += p[0];
+  return a;
+}
+__global__ void __launch_bounds__(32*ASML_LPE)
+k_assemble_long(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ stb,
+                const double* __restrict__ stS, const double* __restrict__ str,
+                const double* __restrict__ Ubig, double* __restrict__ S, SysBatch sb) {
+  const int q = blockIdx.y;
+  S += q*sb.sstride; stS += q*sb.ststride; str += q*sb.strstride;
+  const double lam = sb.lambda_init[q];
+  const int packed = A.tiles[blockIdx.x >> 5];
+  const int ti = packed >> 16, tj = packed & 0xffff;
+  const int row = 32*ti + (blockIdx.x & 31);
+  if (row > np) return;                                  // (whole workgroup)
+  const int l8 = threadIdx.x & (ASML_LPE - 1), col = 32*tj + (threadIdx.x >> 3);
+  const size_t n2 = (size_t)np*np;
+  const bool active = col < np;
+  double u = 0.0, w = 0.0;
+  if (active) {
+    if (row == np) {                                     // right-hand side: b (from stb) and W V^-1 g (from str)
+      const int a = col/6, r = col - 6*a;
+      const int k0 = A.po_start[a], n = A.po_start[a + 1] - k0;
+      u = asml_part(stb + (size_t)k0*6 + r, 6, n, l8);
+      w = asml_part(str + (size_t)k0*6 + r, 6, n, l8);
+    } else if (col <= row) {
+      const int a = row/6, r = row - 6*a, b = col/6, c = col - 6*b;
+      const int pid = A.pair_id[(size_t)a*A.nfp + b];
+      if (pid >= 0) {
+        const int k0 = A.pr_start[pid], n = A.pr_start[pid + 1] - k0;
+        u = asml_part(stU + (size_t)k0*36 + r*6 + c, 36, n, l8);
+        w = asml_part(stS + (size_t)k0*36 + r*6 + c, 36, n, l8);
+      }
+    }
+  }
+  u = asml_tree8(u); w = asml_tree8(w);
+  if (!active || l8 != 0) return;
+  if (row == np) {
+    double b = u;
+    if (Ubig) b += Ubig[n2 + col];
+    S[n2 + col] = b - w;
+    S[n2 + np + col] = b;
+    return;
+  }
+  double v = 0.0;
+  if (col <= row) {
+    v = u - w;
+    if (Ubig) v += Ubig[(size_t)row*np + col];
+    if (row == col) v += lam;
+  }
+  S[(size_t)row*np + col] = v;
+}
+__global__ void __launch_bounds__(256)
+k_udiag_long(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ Ubig, double* __restrict__ d) {
+  const int i = (int)((blockIdx.x*blockDim.x + threadIdx.x) >> 3), l8 = threadIdx.x & (ASML_LPE - 1);
+  double u = 0.0;
+  if (i < np) {
+    const int a = i/6, r = i - 6*a;
+    const int pid = A.pair_id[(size_t)a*A.nfp + a];
+    if (pid >= 0) { const int k0 = A.pr_start[pid]; u = asml_part(stU + (size_t)k0*36 + 7*r, 36, A.pr_start[pid + 1] - k0, l8); }
+  }
+  u = asml_tree8(u);
+  if (i < np && l8 == 0) { if (Ubig) u += Ubig[(size_t)i*np + i]; d[i] = u; }
+}
+
 // diagonal of the pose part of J^T J (for computeLambdaInit [g2o]): d[6a+r] = sum_g U_g(6a+r, 6a+r)
 __global__ void k_udiag(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ Ubig, double* __restrict__ d) {
   const int i = blockIdx.x*blockDim.x + threadIdx.x;

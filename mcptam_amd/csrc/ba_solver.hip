@@ -364,6 +364,7 @@ struct mcp_ba {
     const char* e = getenv("MCP_BA_SMALL_POINTS"); const int small_pts = e ? atoi(e) : 16384;      // (0: the large-map layout for every map)
     return (nsp <= small_pts) ? LIN_QUAD_PTS : GRP_PTS;
   }
+  bool asm_long = false;          // the pose pairs' lists of staged blocks are long (a few free poses staged by every group): k_assemble_long
   int grp_inc_max = 0;            // most point-pose incidences of any group (the W area of k_linearize_quad)
   size_t nstage = 0;        // staged 6x6 blocks over all groups
   int nrhs_rows = 0;        // staged rhs rows (6 doubles each) over all groups
@@ -1390,6 +1391,12 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
   for (int i = 0; i < npose; ++i) pose_unk[i] = poses[i].unk;
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
+  {
+    // long lists of staged blocks per pose pair (mean >= 48: a handful of free poses that every group stages) go through k_assemble_long
+    const size_t npairs = H.pr_start.empty() ? 0 : H.pr_start.size() - 1;
+    asm_long = npairs > 0 && nstage >= 48*npairs;
+    if (const char* e = getenv("MCP_BA_ASM_LONG")) asm_long = atoi(e) != 0 && npairs > 0;
+  }
   // The ~40 structure arrays go into ONE device block (d_struct; every d_* below is an alias into it): one allocation, and one
   // host-to-device copy for all the small arrays together (staged through the pinned arena) -- the large per-measurement arrays,
   // which the builders wrote into the pinned arena already, are copied from where they lie.
@@ -1804,7 +1811,9 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
     HIPCK(hipMemsetAsync(stSq, 0, (size_t)nsys*nstage*36*sizeof(double), s));
     HIPCK(hipMemsetAsync(strq, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), s));
   }
-  if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(ASM_NT), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
+  if (np && asm_long) hipLaunchKernelGGL(k_assemble_long, dim3(A.ntiles*32, nsys), dim3(32*ASML_LPE), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
+                             (const double*)stSq, (const double*)strq, (const double*)Ubig(), Sq, sb);
+  else if (np) hipLaunchKernelGGL(k_assemble, dim3(A.ntiles, nsys), dim3(ASM_NT), 0, s, A, np, (const double*)d_stU.p, (const double*)d_stb.p,
                              (const double*)stSq, (const double*)strq, (const double*)Ubig(), Sq, sb);
   if (nfl && nbig) hipLaunchKernelGGL(k_schur, dim3((nfl + 3)/4, nsys), dim3(256), 0, s, P, 1, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, Sq, Sq + (size_t)np*np, failq, sb);
   if (main_stream) toc();
@@ -2138,7 +2147,8 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       if (it == 0 && !(user_lambda > 0)) {
         // computeLambdaInit [g2o]: 1e-5 * max |H_jj| over the pose and point diagonals; the pose diagonal is summed from
         // the staged blocks (and over the ranks), the point diagonals are rank-local (maximum over ranks taken below)
-        if (np) hipLaunchKernelGGL(k_udiag, dim3((np + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
+        if (np && asm_long) hipLaunchKernelGGL(k_udiag_long, dim3((np*ASML_LPE + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
+        else if (np) hipLaunchKernelGGL(k_udiag, dim3((np + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
         if (multi() && np) { if (allreduce(d_udiag.p, np, 0, false, "pose diagonal for the initial lambda")) return MCP_ERR_RUNTIME; }
         hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_udiag.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }

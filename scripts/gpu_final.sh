@@ -6,23 +6,23 @@ ROUND=${ROUND:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q --timeout 400 --timeout-method=thread 2>&1 | tail -6 > gpurun_out/final_tests.log; cat gpurun_out/final_tests.log
+timeout -k 10 700 python -m pytest tests -m gpu -q --timeout -k 10 400 --timeout-method=thread 2>&1 | tail -6 > gpurun_out/final_tests.log; cat gpurun_out/final_tests.log
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 6 --warmup 1 --cpu-iters 0 --no-roofline > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 6 --warmup 1 --cpu-iters 0 --no-roofline > $R/gpurun_out/pmc_$c.log 2>&1
   echo "$c rc=$?"
 done
 python $R/scripts/parse_traffic.py $R/gpurun_out > $R/gpurun_out/traffic.json
 mkdir -p $R/profiles/$ROUND && cp $R/gpurun_out/traffic.json $R/profiles/$ROUND/pmc_traffic_per_launch.json      # bench.py reads it from there (this box's copy)
 rm -rf $R/gpurun_out/prof_final
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python $R/bench.py --steps 20 --warmup 3 --cpu-iters 0 --no-roofline > $R/gpurun_out/prof_final.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python $R/bench.py --steps 20 --warmup 3 --cpu-iters 0 --no-roofline > $R/gpurun_out/prof_final.log 2>&1
 echo "stats rc=$?"; tail -1 $R/gpurun_out/prof_final.log | cut -c1-300
 cd $R
-timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/final_bench.json; tail -2 gpurun_out/final_bench.err
+timeout -k 10 500 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench rc=$?"; cut -c1-900 gpurun_out/final_bench.json; tail -2 gpurun_out/final_bench.err
 bash $R/scripts/gpu_trk_prof.sh > gpurun_out/trk_prof_stdout.log 2>&1; tail -3 gpurun_out/trk_prof_stdout.log
 # kernel stats of the c5 tracker frame (eight 1280x960 cameras, 8000 points, one device)
 cd /tmp; rm -rf $R/gpurun_out/trk5_prof
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trk5_prof -- python $R/scripts/bench_tracker.py c5 > $R/gpurun_out/trk5_prof.json 2> $R/gpurun_out/trk5_prof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trk5_prof -- python $R/scripts/bench_tracker.py c5 > $R/gpurun_out/trk5_prof.json 2> $R/gpurun_out/trk5_prof.err
 f=$(find $R/gpurun_out/trk5_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/trk5_kernel_stats.csv
 find $R/gpurun_out/trk5_prof -name '*kernel_trace.csv' -delete; cd $R

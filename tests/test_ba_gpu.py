@@ -865,6 +865,21 @@ def test_small_bundle_scheduling_does_not_change_a_single_bit(gpu_required, cfg,
     assert small["outliers"] == plain["outliers"] and small["sigma_sq"] == plain["sigma_sq"] and small["lam"] == plain["lam"]
 
 
+@pytest.mark.parametrize("cfg,iters,force", [("window", 10, "0"), ("c1", 10, "1"), ("c2small", 8, "1")])
+def test_split_assembly_agrees_with_one_thread_per_entry(gpu_required, cfg, iters, force, monkeypatch):
+    """k_assemble_long (eight lanes per entry of the reduced system, fixed tree over their partial sums; chosen when the lists of
+    staged blocks are long -- the window) against k_assemble (one thread per entry): other summation order, same system.  Forced
+    the other way round with MCP_BA_ASM_LONG on each problem."""
+    from mcptam_amd import synth
+    p = (synth.recent_window(synth.make_config("metric")) if cfg == "window" else
+         synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg))
+    a = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    monkeypatch.setenv("MCP_BA_ASM_LONG", force)
+    b = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    rep = compare_runs(a, b, tol_state=1e-7, tol_chi=1e-9)
+    assert rep["branch_flips"] == 0, rep
+
+
 @pytest.mark.parametrize("cfg,iters", [("c1", 10), ("c2small", 8)])
 def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeypatch):
     """Maps of few points are cut into groups of 16 points with four lanes per point in the linearisation (k_linearize_quad) instead
