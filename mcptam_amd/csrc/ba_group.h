@@ -119,7 +119,9 @@ template <int LPP>
 __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const double* __restrict__ pt_x, const double* __restrict__ first,
                     const double* __restrict__ second, const double* __restrict__ sigma,
                     double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
-                    double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off) {
+                    double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off, int* __restrict__ fail_zero) {
+  // (the failure flags of the reduced systems built from this linearisation: cleared here instead of by a fill launch of their own)
+  if (fail_zero && blockIdx.x == 0 && threadIdx.x < 4) fail_zero[threadIdx.x] = 0;
   extern __shared__ double Sc[];                 // the group's blocks, 36 doubles each (launch: 288 B x the largest block count of any group)
   __shared__ double bl[GRP_DOF];
   __shared__ unsigned char pslot[GRP_LMAX*16];
@@ -380,15 +382,15 @@ __global__ void __launch_bounds__(64)
 #endif
 k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
                   const double* __restrict__ second, const double* __restrict__ sigma,
-                  double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W) {
-  linearize_group_body<1>(P, pt_x, first, second, sigma, stU, stb, V, g, W, 0);
+                  double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int* __restrict__ fail_zero) {
+  linearize_group_body<1>(P, pt_x, first, second, sigma, stU, stb, V, g, W, 0, fail_zero);
 }
 constexpr int LIN_QUAD_PTS = 16;           // points per group when the quad form runs (64 lanes / 4)
 __global__ void __launch_bounds__(64)
 k_linearize_quad(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
                  const double* __restrict__ second, const double* __restrict__ sigma,
-                 double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off) {
-  linearize_group_body<4>(P, pt_x, first, second, sigma, stU, stb, V, g, W, wl_off);
+                 double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int wl_off, int* __restrict__ fail_zero) {
+  linearize_group_body<4>(P, pt_x, first, second, sigma, stU, stb, V, g, W, wl_off, fail_zero);
 }
 
 // ------------------------------------------------------------------------------------------

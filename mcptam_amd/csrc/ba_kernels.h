@@ -149,8 +149,7 @@ constexpr int EVAL_BLOCK = 256;
 // computeError + chi2 for every measurement; optional fused robust sum (sigma known: LM trials).
 // err_out (2 per measurement) only for introspection.
 template <bool SUM>
-__global__ void __launch_bounds__(EVAL_BLOCK)
-k_eval(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ last,
+__device__ __forceinline__ void eval_body(const DevProblem& P, const double* __restrict__ pt_x, const double* __restrict__ last,
        double* __restrict__ chi2, double* __restrict__ err_out, const double* __restrict__ sigma,
        double* __restrict__ partial) {
   __shared__ double lds[EVAL_BLOCK/64];
@@ -183,6 +182,14 @@ k_eval(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__
   }
 }
 
+template <bool SUM>
+__global__ void __launch_bounds__(EVAL_BLOCK)
+k_eval(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ last,
+       double* __restrict__ chi2, double* __restrict__ err_out, const double* __restrict__ sigma,
+       double* __restrict__ partial) {
+  eval_body<SUM>(P, pt_x, last, chi2, err_out, sigma, partial);
+}
+
 // robust sum over an existing chi2 array (first evaluation of an iteration, after the median)
 __global__ void __launch_bounds__(EVAL_BLOCK)
 k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* __restrict__ sigma,
@@ -204,10 +211,9 @@ k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* _
 // ticket mail[MAIL_TICKET] is released at system scope -- the host polls the ticket instead of enqueueing a copy and waiting on
 // the stream (the LM accept/reject decision is one PCIe write away instead of a blit kernel + a stream wait).
 constexpr int MAIL_TICKET = 31;
-__global__ void __launch_bounds__(256)
-k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
-             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0,
-             const double* ride_src = nullptr, int ride_dst = 0 /* out[ride_dst] = ride_src[0]: a value of an earlier kernel joins this block's all-reduce */) {
+__device__ __forceinline__ void final_sums_body(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
+             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail, int mail_count, unsigned long long ticket,
+             const double* ride_src, int ride_dst) {
   __shared__ double lds[4];
   const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
   for (int a = 0; a < 3; ++a) {
@@ -228,6 +234,12 @@ k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const d
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(mail + MAIL_TICKET), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+__global__ void __launch_bounds__(256)
+k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
+             double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0,
+             const double* ride_src = nullptr, int ride_dst = 0 /* out[ride_dst] = ride_src[0]: a value of an earlier kernel joins this block's all-reduce */) {
+  final_sums_body(n0, p0, n1, p1, n2, p2, out, off, fail, mail, mail_count, ticket, ride_src, ride_dst);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -364,6 +364,7 @@ struct mcp_ba {
     const char* e = getenv("MCP_BA_SMALL_POINTS"); const int small_pts = e ? atoi(e) : 16384;      // (0: the large-map layout for every map)
     return (nsp <= small_pts) ? LIN_QUAD_PTS : GRP_PTS;
   }
+  bool fail_clean = false;        // d_fail was cleared by the linearisation kernel and no system has been built since
   bool asm_long = false;          // the pose pairs' lists of staged blocks are long (a few free poses staged by every group): k_assemble_long
   int grp_inc_max = 0;            // most point-pose incidences of any group (the W area of k_linearize_quad)
   size_t nstage = 0;        // staged 6x6 blocks over all groups
@@ -699,7 +700,8 @@ int mcp_ba::prepare() {
   const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
   const size_t nch = chains.size();
   HostPool& pool = host_pool();
-  const int T = (nmeas >= 32768) ? pool.size() : 1;
+  static const int par_min = [] { const char* e = getenv("MCP_BA_PREP_PAR_MIN"); return e ? atoi(e) : 32768; }();      // measurements from which the structure is built on the worker pool
+  const int T = (nmeas >= par_min) ? pool.size() : 1;
   auto par = [&](const std::function<void(int)>& fn) { if (T == 1) fn(0); else pool.run(fn); };
   auto lo_of = [&](int tid, long n) { return (long)(n*tid/T); };
   lap("  entry");
@@ -1774,10 +1776,11 @@ int mcp_ba::linearize() {
   }
   if (ngroup && grp_pts <= LIN_QUAD_PTS)
     hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), ((size_t)std::max(grp_blk_max, 1)*36 + (size_t)std::max(grp_inc_max, 1)*18)*sizeof(double), st, P,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36);
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36, d_fail.p);
   else if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
-                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p);
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, d_fail.p);
+  fail_clean = ngroup > 0;            // (the group kernel has cleared the failure flags: the first solve of this linearisation needs no fill)
 #ifdef MCP_LIN_PROF
   {
     HIPCK(hipStreamSynchronize(st));
@@ -1946,7 +1949,8 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     batch_n = nsys;
     if (cancel_spec_trials()) return -1;   // (a re-solve inside an iteration: nothing of the previous batch is wanted any more)
     if (join_spec()) return -1;            // (... and its stragglers first)
-    HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    if (!fail_clean) HIPCK(hipMemsetAsync(d_fail.p, 0, 4*sizeof(int), st));
+    fail_clean = false;
     // One rank, one-launch factorisation: every system of the batch has its own critical workgroup, four systems take the time of
     // one, so the batch stays on the main stream (measured: 990 vs 940 LM it/s; MCP_BA_OVERLAP=1 splits it as the per-step kernels
     // want it).  Several ranks: one speculative stream, the one lane 1 belongs to.
@@ -2031,10 +2035,10 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   toc();
   tic(ST_EVAL);
   if (!small) launch_chains(tr);
-  launch_eval(tr, true, nullptr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   const bool mailbox = use_mailbox && !prm.profile;
   mail_ticket0 = ++mail_ticket;
+  launch_eval(tr, true, nullptr);
   if (multi()) {
     // (several ranks: the sums are rank-local until the trial's all-reduce; k_trial_post writes the block and the mailbox)
     if (multi_trial_tail(st, 0, sys_cur, tr, nbe, d_part0.p, nbb, nfl ? d_part1.p : nullptr, nfl ? d_part2.p : nullptr, d_res.p + 6, 6, true,
@@ -2693,7 +2697,7 @@ int mcp_ba_debug_system(mcp_ba* h, double lambda, double* out) {
   h->launch_eval(h->cur, false, nullptr);
   if (h->robust && h->median_sigma(h->cur)) return -1;
   if (h->linearize()) return -1;
-  h->sys_cur = 0; h->spec_ok = false;
+  h->sys_cur = 0; h->spec_ok = false; h->fail_clean = false;
   SysBatch sb; std::memset(&sb, 0, sizeof sb);
   sb.lambda[0] = lambda; sb.lambda_init[0] = (h->rank == 0) ? lambda : 0.0;
   HIPCK(hipMemsetAsync(h->d_fail.p, 0, 4*sizeof(int), h->st));
