@@ -1,9 +1,4 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-for rep in 1 2; do
-timeout -k 5 120 python scripts/bench_window.py > gpurun_out/window.json 2>gpurun_out/window.err; python - <<PY
-import json
-d=json.load(open('gpurun_out/window.json')); print(d['ms_median']); 
-PY
-done
-timeout -k 5 300 python -m pytest tests/test_ba_gpu.py -q -m gpu -k "small_bundle or oracle or failed_factor" 2>&1 | tail -3
+timeout -k 5 400 python -m pytest tests/test_img_gpu.py -q -m gpu 2>&1 | tail -4
+bash scripts/gpu_trk_prof.sh 2>&1 | cut -c1-110 | head -4
