@@ -1851,6 +1851,9 @@ int mcp_ba::head_small(int w, bool sum_aside) {
   // sum_aside: linearize() needs the sigma block, nobody on the device needs the robust chi2 (the host reads it with the next
   // trial's results): that sum -- a third of this kernel's time -- goes to the second stream, next to the linearisation
   const bool aside = sum_aside && st2 && ev_head && ev_sum && d_parth.p;
+  // a sum still on its way on the second stream (the head of a trial that was then rejected) writes the same d_res[24]: it must not
+  // land after the one this launch takes itself
+  if (!aside && join_sum()) return -1;
   hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), 0, st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, (unsigned long long)(m_total/2), m_total,
                      prm.min_mestimator_sigma*prm.min_mestimator_sigma, prev, d_res.p + 8, sig(), d_res.p + 25, d_res.p, 24, aside ? 0 : 1);
   if (aside) { HIPCK(hipEventRecord(ev_head, st)); sum_w = w; sum_sig = sig(); }      // (the second stream's part: sum_aside(), once the caller has queued what else it has for that stream)

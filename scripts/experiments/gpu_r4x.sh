@@ -1,4 +1,3 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-timeout -k 5 400 python -m pytest tests/test_img_gpu.py -q -m gpu 2>&1 | tail -4
-bash scripts/gpu_trk_prof.sh 2>&1 | cut -c1-110 | head -4
+timeout -k 10 700 python -m pytest tests -m gpu -q --timeout 400 --timeout-method=thread 2>&1 | tail -6 > gpurun_out/final_tests.log; cat gpurun_out/final_tests.log

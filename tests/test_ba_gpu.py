@@ -865,6 +865,23 @@ def test_small_bundle_scheduling_does_not_change_a_single_bit(gpu_required, cfg,
     assert small["outliers"] == plain["outliers"] and small["sigma_sq"] == plain["sigma_sq"] and small["lam"] == plain["lam"]
 
 
+def test_head_of_a_rejected_trial_never_reaches_the_next_iteration(gpu_required, monkeypatch):
+    """The head enqueued behind a trial that is then rejected leaves its robust-chi2 sum on the second stream; the head the next
+    iteration takes itself must be ordered behind it, or the stale sum lands last and becomes that iteration's chi2_start (seen once
+    in a round-end pass: a race).  Thirty runs of a bundle whose iterations reject trials, each against the general sequence of
+    launches, bit for bit."""
+    from mcptam_amd import synth
+    p = synth.make_config("tiny", n_points=120)
+    monkeypatch.setenv("MCP_BA_SMALL", "0")
+    plain = run_bundle(_gpu(p.cams, robust=False, tukey=True), p, 10)
+    monkeypatch.delenv("MCP_BA_SMALL")
+    assert sum(l["trials"] for l in plain["logs"]) > len(plain["logs"]), "the run must contain rejected trials for this to mean anything"
+    for rep in range(30):
+        small = run_bundle(_gpu(p.cams, robust=False, tukey=True), p, 10)
+        assert small["logs"] == plain["logs"], rep
+        assert np.array_equal(small["X"], plain["X"]) and np.array_equal(small["R"], plain["R"])
+
+
 @pytest.mark.parametrize("cfg,iters,force", [("window", 10, "0"), ("c1", 10, "1"), ("c2small", 8, "1")])
 def test_split_assembly_agrees_with_one_thread_per_entry(gpu_required, cfg, iters, force, monkeypatch):
     """k_assemble_long (eight lanes per entry of the reduced system, fixed tree over their partial sums; chosen when the lists of
