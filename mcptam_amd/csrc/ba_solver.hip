@@ -1510,7 +1510,14 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   A.pr_start = d_pr_start.p; A.po_start = d_po_start.p;
   // the staging arrays of a group that stages nothing for a slot are never read; slots are always fully written
   // before k_assemble runs, so they need no clearing either
-  HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
+  {   // (function attributes are per device: once, not once per Prepare())
+    static std::atomic<unsigned long long> sch_attr{0};
+    const unsigned long long bit = 1ull << (device & 63);
+    if (!(sch_attr.load(std::memory_order_relaxed) & bit)) {
+      HIPCK(hipFuncSetAttribute((const void*)k_schur_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
+      sch_attr.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
   lap("alloc+upload");
   if (upload_state()) return -1;
   HIPCK(hipStreamSynchronize(st));
@@ -2317,6 +2324,13 @@ int mcp_ba::final_stats(int nCounter) {
   // a trial evaluated ahead that nobody consumed may still be running on the second stream and reads the sigma block of the parity
   // median_sigma() is about to rewrite: order everything behind it first (it had only ever been joined by the next solve)
   if (join_spec()) return -2;
+  if (small_mode() && robust) {
+    // small bundle: median, sigma block and robust chi2 of the final state in one launch (ba_small.h), one read-back
+    if (head_small(cur)) return -2;
+    if (read_results(29)) return -2;
+    h_res[0] = h_res[24];
+    for (int i = 0; i < 4; ++i) h_res[9 + i] = h_res[25 + i];
+  } else {
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
@@ -2324,6 +2338,7 @@ int mcp_ba::final_stats(int nCounter) {
   if (allreduce(d_res.p, 1, 0, false, "final robust chi2")) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, st));
   if (read_results(13)) return -2;
+  }
   if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
   mean_chi2 = h_res[0]/m_total;
   const double median = h_res[12];
