@@ -102,7 +102,10 @@ int mcp_device_count(void);
 /* ChainBundle::ChainBundle(TaylorCameraMap&, bool, bool, bool)   ChainBundle.cc:1139-1181 */
 mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_tukey,
                       int verbose, const mcp_ba_params* params);
-/* ChainBundle::~ChainBundle                                       ChainBundle.cc:1183-1195 */
+/* ChainBundle::~ChainBundle                                       ChainBundle.cc:1183-1195
+ * (the reference builds one ChainBundle per BundleAdjust call, src/BundleAdjusterMulti.cc:75-76: the device blocks and pinned
+ *  blocks of a destroyed handle go to a process-wide cache and the next handle on that device takes them from there;
+ *  MCP_DEV_CACHE_MB bounds the cache per device, 0 switches it off -- INTEGRATION.md section 7) */
 void    mcp_ba_destroy(mcp_ba*);
 
 /* int ChainBundle::AddPose(SE3<> se3PoseFromRef, bool bFixed)     ChainBundle.cc:1198-1208 */

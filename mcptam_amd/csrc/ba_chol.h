@@ -538,8 +538,9 @@ struct CholPlan {
   mutable CholPersist persist; bool use_persist = false;
   int persist_min_ntc = 3;      // smallest system (in tiles) the one-launch plan is built for (the test hooks set 1)
   ~CholPlan() { release(); }
+  int arena_dev = -1;
   char* arena = nullptr; size_t arena_cap = 0;      // one cached block (ba_pool.h): [step tiles | row starts | row tiles | all tiles | factored diagonal tiles]
-  void release() { if (arena) DevCache::get().put(arena, arena_cap); arena = nullptr; arena_cap = 0;
+  void release() { if (arena) DevCache::get().put(arena, arena_cap, arena_dev); arena = nullptr; arena_cap = 0; arena_dev = -1;
                    d_diag = nullptr; d_all_tiles = nullptr;
                    d_step_tiles = d_row_start = d_row_tiles = nullptr; persist.release(); }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (true = may be non-zero); empty = dense
@@ -578,7 +579,7 @@ struct CholPlan {
       auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
       const size_t o_step = 0, o_rs = o_step + al(4*std::max<size_t>(step_tiles.size(), 1)), o_rt = o_rs + al(4*row_start.size()),
                    o_all = o_rt + al(4*std::max<size_t>(row_tiles.size(), 1)), o_diag = o_all + al(4*std::max<size_t>(all_tiles.size(), 1));
-      arena = (char*)DevCache::get().take(o_diag + sizeof(double)*diag_stride*max_sys, &arena_cap);
+      arena = (char*)DevCache::get().take(o_diag + sizeof(double)*diag_stride*max_sys, &arena_cap, &arena_dev);
       if (!arena) return -1;
       std::vector<char> stage(o_diag, 0);
       {

@@ -770,14 +770,14 @@ struct CholPersist {
   ~CholPersist() { release(); }
   // One device arena per plan: [tables (one upload) | flags, error words, epochs | L tiles | band tiles | x | f], a block of the
   // process-wide cache (ba_pool.h): a ChainBundle lives for one BundleAdjust call, plans are built and dropped all the time.
-  char* arena = nullptr; size_t arena_bytes = 0;
+  char* arena = nullptr; size_t arena_bytes = 0; int arena_dev = -1;
   void release() {
-    if (arena) DevCache::get().put(arena, arena_bytes);
-    arena = nullptr; arena_bytes = 0;
+    if (arena) DevCache::get().put(arena, arena_bytes, arena_dev);
+    arena = nullptr; arena_bytes = 0; arena_dev = -1;
     d_steps = d_delta_of = d_epoch = d_slot_of = d_bslot_of = d_flags = d_err = d_far_start = d_far_slot = d_far_row = d_back_tab = nullptr; d_helpers = nullptr; d_upd = nullptr;
     d_Lt = d_Bt = d_x = d_f = nullptr; ok = false;
   }
-  int arena_get(size_t bytes) { arena = (char*)DevCache::get().take(bytes, &arena_bytes); return arena ? 0 : -1; }
+  int arena_get(size_t bytes) { arena = (char*)DevCache::get().take(bytes, &arena_bytes, &arena_dev); return arena ? 0 : -1; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (empty = dense); in_old: the tiles the assembly writes (ti << 16 | tj),
   // with the right-hand side inside block row n / 32 as ba_chol.h's plan has it
   int build(int n_, const std::vector<unsigned char>& pattern, const std::vector<int>& old_tiles) {

@@ -32,10 +32,12 @@ class DevCache {
     if (cls) *cls = 4*m + k;
     return base + (size_t)k*step;
   }
-  // a block of at least `bytes`; *cap = what it really holds (hand that back to put())
-  void* take(size_t bytes, size_t* cap) {
+  // a block of at least `bytes` on the CURRENT device; *cap = what it really holds, *dev_out = that device (hand both back to put():
+  // the thread that drops a block need not have the block's device current)
+  void* take(size_t bytes, size_t* cap, int* dev_out = nullptr) {
     int cls; const size_t cb = class_bytes(bytes, &cls);
     int dev = 0; (void)hipGetDevice(&dev);
+    if (dev_out) *dev_out = dev;
     if (enabled_ && cls < NCLS) {
       std::lock_guard<std::mutex> lk(mu_);
       auto& v = free_[dev & (NDEV - 1)][cls];
@@ -51,11 +53,12 @@ class DevCache {
     poison(p, cb, cls);
     return p;
   }
-  void put(void* p, size_t cap) {
+  void put(void* p, size_t cap, int dev = -1) {
     if (!p) return;
-    if (!quiesced()) (void)hipDeviceSynchronize();
+    int cur = 0; (void)hipGetDevice(&cur);
+    if (dev < 0) dev = cur;
+    if (!quiesced()) { if (dev != cur) (void)hipSetDevice(dev); (void)hipDeviceSynchronize(); if (dev != cur) (void)hipSetDevice(cur); }
     int cls; const size_t cb = class_bytes(cap, &cls);
-    int dev = 0; (void)hipGetDevice(&dev);
     if (enabled_ && cb == cap && cls < NCLS) {
       std::lock_guard<std::mutex> lk(mu_);
       if (cached_[dev & (NDEV - 1)] + cb <= budget_) { free_[dev & (NDEV - 1)][cls].push_back(p); cached_[dev & (NDEV - 1)] += cb; return; }
@@ -104,22 +107,24 @@ class DevCache {
 class PinnedCache {
  public:
   static PinnedCache& get() { static PinnedCache* c = new PinnedCache(); return *c; }
+  // (keyed by the device that was current at allocation too: a mapped block is mapped into THAT device's address space)
   void* take(size_t bytes, unsigned flags) {
+    int dev = 0; (void)hipGetDevice(&dev);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      for (size_t i = 0; i < free_.size(); ++i) if (free_[i].bytes == bytes && free_[i].flags == flags) { void* p = free_[i].p; free_[i] = free_.back(); free_.pop_back(); return p; }
+      for (size_t i = 0; i < free_.size(); ++i) if (free_[i].bytes == bytes && free_[i].flags == flags && free_[i].dev == dev) { void* p = free_[i].p; free_[i] = free_.back(); free_.pop_back(); return p; }
     }
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
   }
-  void put(void* p, size_t bytes, unsigned flags) {
+  void put(void* p, size_t bytes, unsigned flags, int dev) {
     if (!p) return;
-    { std::lock_guard<std::mutex> lk(mu_); if (free_.size() < 64) { free_.push_back({p, bytes, flags}); return; } }
+    { std::lock_guard<std::mutex> lk(mu_); if (free_.size() < 64) { free_.push_back({p, bytes, flags, dev}); return; } }
     (void)hipHostFree(p);
   }
  private:
-  struct B { void* p; size_t bytes; unsigned flags; };
+  struct B { void* p; size_t bytes; unsigned flags; int dev; };
   std::mutex mu_; std::vector<B> free_;
 };
 

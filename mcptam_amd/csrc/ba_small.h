@@ -5,9 +5,11 @@
 // iteration is the sum of ~20 launch-to-launch latencies.  For such bundles (one rank, <= SMALL_MEAS measurements) what can be
 // merged is:
 //   k_head_small     the head of an iteration (median of |chi2|, sigma block, robust chi2 of the state): see below;
-//   k_update_chains  the trial's pose update (oplus) and the chain transforms that hang off it (PoseChainHelper::UpdateTransforms,
-//                    ChainBundle.cc:120-150) -- in place of k_update_poses + k_chains.
-// Same arithmetic per element as the kernels they replace; the sums are taken in a different (fixed) order.
+//   k_trial_apply    the step of a trial in one launch: workgroup 0 the pose update (oplus) and the chain transforms that hang off it
+//                    (PoseChainHelper::UpdateTransforms, ChainBundle.cc:120-150), the others the point back-substitution -- in place
+//                    of k_update_poses + k_chains + k_backsub.
+// Same arithmetic per element and the same order of every sum as the kernels they replace: a bundle gives the same bits on either
+// path (tests/test_ba_gpu.py::test_small_bundle_scheduling_does_not_change_a_single_bit).
 #pragma once
 #include "ba_kernels.h"
 #include "ba_select.h"

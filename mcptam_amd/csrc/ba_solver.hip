@@ -66,14 +66,15 @@ namespace {
 
 template <class T> struct DevBuf {
   T* p = nullptr; size_t n = 0; size_t cap_bytes = 0; bool alias = false;      // alias: p points into another buffer (packed structure upload)
+  int dev = -1;                                                                  // device the block lives on
   ~DevBuf() { release(); }
   // (blocks come from and go back to the process-wide cache, ba_pool.h: a handle lives for one BundleAdjust call)
-  void release() { if (p && !alias) mcp::DevCache::get().put(p, cap_bytes); p = nullptr; n = 0; cap_bytes = 0; alias = false; }
+  void release() { if (p && !alias) mcp::DevCache::get().put(p, cap_bytes, dev); p = nullptr; n = 0; cap_bytes = 0; alias = false; dev = -1; }
   int alloc(size_t count) {
     if (count == 0) count = 1;
     if (count <= n) return 0;
     release();
-    p = (T*)mcp::DevCache::get().take(count*sizeof(T), &cap_bytes);
+    p = (T*)mcp::DevCache::get().take(count*sizeof(T), &cap_bytes, &dev);
     if (!p) { set_err("hipMalloc: out of device memory"); cap_bytes = 0; return -1; }
     n = count; return 0;
   }
@@ -438,8 +439,8 @@ struct mcp_ba {
     // nothing of this handle may still be running when its mailbox goes back to the host allocator (a trial evaluated ahead writes there)
     drain();
     for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q] && !pooled) (void)hipStreamDestroy(st_tr[q]);
-    if (h_res) mcp::PinnedCache::get().put(h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-    if (h_fail) mcp::PinnedCache::get().put(h_fail, 4*sizeof(int), hipHostMallocDefault);
+    if (h_res) mcp::PinnedCache::get().put(h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, device);
+    if (h_fail) mcp::PinnedCache::get().put(h_fail, 4*sizeof(int), hipHostMallocDefault, device);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
     for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) (void)hipGraphExecDestroy(chain_exec[q][r]);
