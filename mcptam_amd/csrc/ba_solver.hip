@@ -1782,8 +1782,13 @@ int mcp_ba::linearize() {
     if (P.nmeas) hipLaunchKernelGGL(k_linearize, dim3((P.nmeas + LIN_BLOCK - 1)/LIN_BLOCK), dim3(LIN_BLOCK), 0, st, P, 1,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_ubig.p, d_ubig.p + n2, d_V.p, d_g.p, d_W.p);
   }
-  if (ngroup && grp_pts <= LIN_QUAD_PTS)
-    hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), ((size_t)std::max(grp_blk_max, 1)*36 + (size_t)std::max(grp_inc_max, 1)*18)*sizeof(double), st, P,
+  // (the quad form keeps the group's W blocks in LDS beside the pose blocks: groups whose points see many poses -- 16 points x 16
+  //  incidences is 36 KB on top of up to 39 KB of pose blocks -- do not fit the 64 KB a launch gets by default and take the
+  //  one-lane-per-point kernel, which handles groups of any size up to 64 points)
+  const size_t quad_lds = ((size_t)std::max(grp_blk_max, 1)*36 + (size_t)std::max(grp_inc_max, 1)*18)*sizeof(double);
+  static const bool quad_on = [] { const char* e = getenv("MCP_BA_LIN_QUAD"); return !(e && atoi(e) == 0); }();
+  if (ngroup && grp_pts <= LIN_QUAD_PTS && quad_on && quad_lds <= 60*1024)
+    hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), quad_lds, st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36, d_fail.p);
   else if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,

@@ -909,6 +909,21 @@ def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeyp
     full = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
     rep = compare_runs(quad, full, tol_state=1e-7, tol_chi=1e-9)
     assert rep["branch_flips"] == 0, rep
+    # groups of 16 points through the one-lane-per-point kernel (what a map whose groups need more LDS than a launch gets falls back to)
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import sys, json; sys.path[:0] = %r; import numpy as np; from mcptam_amd import synth, chain_bundle; from helpers import run_bundle; "
+                          "p = synth.make_config('c2', n_mkf=12, n_points=1500) if %r == 'c2small' else synth.make_config(%r); "
+                          "r = run_bundle(chain_bundle.ChainBundle(p.cams, True, True, False, disable_convergence=True), p, %d); "
+                          "print(json.dumps(dict(X=r['X'].tolist(), logs=r['logs'])))" % ([ROOT, os.path.join(ROOT, "tests")], cfg, cfg, iters)],
+                         capture_output=True, text=True, timeout=300, env=dict(os.environ, MCP_BA_SMALL_POINTS="16384", MCP_BA_LIN_QUAD="0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [(l["trials"], l["accepted"]) for l in r["logs"]] == [(l["trials"], l["accepted"]) for l in quad["logs"]]
+    assert rel_err(np.array(r["X"]), quad["X"]) < 1e-8
 
 
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
