@@ -2120,6 +2120,7 @@ int mcp_ba::persist_fallback(double lam, bool& ok2, double ni) {
 int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda) {
   auto t_begin = std::chrono::steady_clock::now();
   HIPCK(hipSetDevice(device));
+  (void)hipGetLastError();                 // (the check at the end is about THIS solve's launches)
   std::memset(&timing, 0, sizeof timing);
   evs.clear(); ev_used = 0;
   if (n_iter < 0) n_iter = prm.max_iterations;      // 0 runs nothing, as g2o optimize(0) (-> -1 unless externally aborted)
@@ -2312,6 +2313,12 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   else if (nCounter == 0 && terminate()) rc = 0;
   else rc = nCounter;
   if (download_state()) return MCP_ERR_RUNTIME;
+  // A launch the runtime refused (a configuration a kernel cannot run with) leaves no trace in the stream: the state simply stays
+  // what it was.  Kernel launches are not checked one by one; whatever one of them reported is still the thread's last error here.
+  {
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess && le != hipErrorNotReady) { set_err(std::string("a launch of this solve failed: ") + hipGetErrorString(le)); return MCP_ERR_RUNTIME; }
+  }
   // stage timings
   if (prm.profile) {
     (void)hipStreamSynchronize(st);
