@@ -2316,8 +2316,10 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   // A launch the runtime refused (a configuration a kernel cannot run with) leaves no trace in the stream: the state simply stays
   // what it was.  Kernel launches are not checked one by one; whatever one of them reported is still the thread's last error here.
   {
+    // (one rank only: a collective library probes the runtime on the caller's thread -- peer access that is already on, and the like --
+    //  and what it leaves behind is not ours to judge)
     const hipError_t le = hipGetLastError();
-    if (le != hipSuccess && le != hipErrorNotReady) { set_err(std::string("a launch of this solve failed: ") + hipGetErrorString(le)); return MCP_ERR_RUNTIME; }
+    if (!multi() && le != hipSuccess && le != hipErrorNotReady) { set_err(std::string("a launch of this solve failed: ") + hipGetErrorString(le)); return MCP_ERR_RUNTIME; }
   }
   // stage timings
   if (prm.profile) {
