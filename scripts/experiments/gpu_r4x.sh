@@ -1,4 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-timeout -k 10 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout -k 5 50 python -m pytest tests/test_ba_gpu.py -q -m gpu -k "small_bundle and window" 2>&1 | tail -1
+MCP_HIP_LIB=$R/variants/lib_prrprof.so timeout -k 5 40 python -c "
+import sys; sys.path.insert(0,'scripts')
+import bench_tracker
+bench_tracker.main(frames=2, cpu_frames=0)
+" 2>&1 | grep "prr prof" | tail -10
