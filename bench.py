@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = "r04"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
+ROUND = "r05"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
@@ -41,7 +41,7 @@ def load_traffic():
 
 STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ; count -1 = number of 32-column Cholesky steps
     "linearize": [("mcp::k_linearize_group", 1)],
-    "schur": [("mcp::k_schur_group", 1), ("mcp::k_assemble", 1)],
+    "schur": [("mcp::k_schur4", 1), ("mcp::k_assemble", 1)],      # round 5: every system of the batch in one workgroup per group (ba_schur4.h)
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
     "select": [("mcp::k_select_pass", 2), ("mcp::k_select_gather", 1), ("mcp::k_select_small", 1)],
@@ -68,6 +68,22 @@ def stage_rooflines(tm, M, N, np_, n_lin, n_trials, n_solves):
                              traffic=None, avg_ms=ms_total / launches, launches=launches, bytes_per_launch=nbytes)
     hbm("linearize", tm["linearize_ms"], n_lin, M * 36 + N * 24 + N * 72)
     hbm("schur", tm["schur_ms"], n_solves, useful * (M * 36 + N * 72))
+    if "schur" in out and tm.get("schur_mfma_per_system", 0) > 0:
+        # `bound: hbm` keeps SURVEY 8(d)'s algorithmic-byte basis for the fraction, but the stage is not bandwidth-bound: a workgroup is
+        # a chain of phases (index hops, W fetch, LDS staging, matrix-core products, flush) and the products themselves are zero-filled
+        # 16 x 16 x 4 tiles.  Said here in numbers: what the matrix pipe executes (every system of the batch), what of that is
+        # structurally non-zero work, and how busy that keeps the fp64 matrix cores over the stage's duration.
+        r = out["schur"]
+        dur = r["avg_ms"] * 1e-3
+        nsys_built = 4.0
+        exec_flops = tm["schur_mfma_per_system"] * 2048.0 * nsys_built
+        r["limited_by"] = "latency of one workgroup's phase chain + matrix-core issue (DESIGN.md 4), not HBM"
+        r["mfma_executed"] = {"instructions_per_launch": tm["schur_mfma_per_system"] * nsys_built, "tflops": exec_flops / dur / 1e12,
+                              "frac_of_fp64_mfma_peak": exec_flops / dur / 1e12 / FP64_PEAK_TFLOPS,
+                              "structural_tflops_consumed": useful * tm["schur_flops_structural"] / dur / 1e12,
+                              "zero_fill_factor": tm["schur_mfma_per_system"] * 2048.0 / max(tm["schur_flops_structural"], 1.0),
+                              "note": "instructions = non-empty 16-row tile pairs of every 16-point chunk x 12 x the 4 systems of a batch; structural = "
+                                      "sum over points of k(k+1)/2 x 324 flop (k poses see the point), only the systems a trial consumed"}
     hbm("backsub_update", tm["update_ms"], n_trials, M * 36 + N * 72 + N * 24)
     hbm("eval", tm["eval_ms"], n_trials + n_lin, M * 36 + N * 24 + M * 8)
     hbm("select", tm["select_ms"], n_lin + 1, M * 8)
@@ -339,7 +355,8 @@ def main():
                                                     "per launch, summed over the launches of the stage)") if r.get("traffic") is not None else "no PMC pass of this round's kernels in " + TRAFFIC_FILE
             result["config"]["reduced_system_solves"] = tm["n_solves"]
             result["config"]["trials_served_speculatively"] = tm["n_spec_hits"]
-            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic")} for k, v in roofs.items()}}
+            result["config"]["persist_fallbacks"] = tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"]      # 0 in a healthy run (one-launch factorisation never timed out)
+            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic", "limited_by", "mfma_executed") if kk in v} for k, v in roofs.items()}}
     # CPU baselines on this box's host cores, same map, same run; the oracle's iteration log doubles as the
     # parity check of the GPU run that was just timed
     if rank == 0 and world == 1 and args.cpu_iters > 0:

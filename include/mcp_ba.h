@@ -93,6 +93,11 @@ typedef struct mcp_ba_timing {
   double collective_bytes_main, collective_bytes_spec;
   int    n_median_fast;   /* medians that needed one collective (digit histograms rode on the accepted trial's all-reduce) */
   int    n_persist_fallbacks;   /* solves redone with the per-step kernels after a hand-off of the one-launch factorisation timed out (0 in a healthy run) */
+  /* profile != 0 only.  The Schur complement of ONE system as the kernel executes it: v_mfma_f64_16x16x4 instructions per launch
+   * (zero-filled 16 x 16 tile pairs of every 16-point chunk, 12 instructions each; 2048 flop per instruction), and the flops of the
+   * structurally non-zero 6x3 . 3x3 . 3x6 block products it stands for (sum over the free points of k (k + 1) / 2 x 324, k = poses
+   * that see the point: SURVEY 8(d)) */
+  double schur_mfma_per_system, schur_flops_structural;
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <cstdlib>
 #include <utility>
@@ -616,8 +617,13 @@ struct CholPlan {
 // factor S (n x n, lower) with the rhs in row n: afterwards row n holds y = L^-1 rhs
 // nsys > 1 factors further systems stored q*sys_stride doubles behind the first in the same launches (fail[q] is their flag)
 // q0: index of the first of the nsys systems inside the batch buffers (S, fail and the diagonal side array are offset by it)
-inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
-  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_factor(st, plan.persist, S, fail, nsys, sys_stride, q0); return; }
+// (a one-launch factorisation the runtime refuses -- hipFuncSetAttribute failed -- switches the plan to the per-step kernels and
+//  goes on with them in the same call: the back-substitution must never run on vectors no factorisation has armed)
+inline void chol_factor(hipStream_t st, CholPlan& plan, double* S, int* fail, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
+  if (plan.use_persist && plan.persist.ok) {
+    if (chol_persist_factor(st, plan.persist, S, fail, nsys, sys_stride, q0) == 0) return;
+    plan.use_persist = false; (void)hipGetLastError();
+  }
   const int n = plan.n, nrows = n + 1;
   S += q0*sys_stride; fail += q0;
   double* dg = plan.d_diag + q0*plan.diag_stride;
@@ -628,8 +634,8 @@ inline void chol_factor(hipStream_t st, const CholPlan& plan, double* S, int* fa
   }
 }
 // row n: y -> x = L^-T y
-inline void chol_back(hipStream_t st, const CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
-  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0); return; }
+inline void chol_back(hipStream_t st, CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
+  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0); return; }      // (always returns 0: a plain launch)
   if (plan.fuse_single()) return;      // (k_chol_step has left x in row n)
   const int n = plan.n;
   S += q0*sys_stride;

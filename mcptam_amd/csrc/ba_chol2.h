@@ -34,7 +34,11 @@ constexpr int CP_THREADS = 256;
 constexpr int CP_LD = CH_NB + 1;              // LDS row stride of a tile
 constexpr int CP_TILE = CH_NB*CP_LD;          // doubles per LDS tile
 constexpr int CP_TQ = CH_NB*CH_NB;            // doubles per tile in global memory (thread-major quadrant layout)
-constexpr unsigned CP_SPIN_MAX = 1u << 22;
+// Every spin is bounded in WALL-CLOCK time (s_memrealtime: 100 MHz on gfx950, the same on every compute unit): a poll that has
+// seen nothing for cp_deadline ticks (20 ms by default, MCP_BA_CHOL_DEADLINE_MS; a whole factorisation takes 0.23 ms) raises the
+// error word.  (Round 4 counted 2^22 polls instead: seconds inside a kernel.)
+__device__ long long cp_deadline = 2000000;
+__device__ inline bool cp_expired(long long t0) { return wall_clock64() - t0 > cp_deadline; }
 constexpr int CP_BACK_NEAR = 3;               // rows k+1 .. k+CP_BACK_NEAR of column k stay with the chain workgroup
 constexpr unsigned long long CP_SENT = 0xFFFDEADBEEF5A5A5ull;      // "not written yet" (a NaN payload arithmetic never yields)
 
@@ -55,12 +59,13 @@ struct CpArgs {
   int test_fail_step;             // >= 0: the critical workgroup raises the error word at that step (test of the fall-back)
   int* flags; int nslots; int nflags; int* err; int* fail; const int* epoch;      // epoch[q]: bumped by the back-substitution launch (graph replay safe)
   double* xbuf; double* fbuf; int vec_stride;
+  int* claim;                     // claim[q]: next entry of the helper list nobody has taken yet (zeroed by the launch that follows: k_chol_back2 / k_cp_bump)
 };
 struct CpBackArgs {
   const double* Lt; size_t lt_stride; const int* slot_of; int n, ntc, nsys, ncols;
   const int* far_start; const int* far_slot; const int* far_row;      // per block column: its far tiles, rows descending
   const int* back_tab;            // [ntc][CPB_INTS] (below)
-  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail;
+  double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail; int* claim;
 };
 
 #ifdef MCP_CP_PROF
@@ -107,9 +112,13 @@ __device__ inline int cp_flag_load_early(const int* f) {
 __device__ inline void cp_flag_wait(int& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 // one lane: spin until *f == want; false = gave up (this spin timed out, or another workgroup of the system raised the error word)
 __device__ inline bool cp_poll(const int* f, int want, int* err, int code, bool patient) {
-  for (unsigned it = 0; it < CP_SPIN_MAX; ++it) {
+  long long t0 = 0;
+  for (unsigned it = 0;; ++it) {
     if (cp_flag_load(f) == want) return true;
-    if ((it & 31) == 31 && cp_flag_load(err) != 0) return false;
+    if ((it & 31) == 31) {
+      if (cp_flag_load(err) != 0) return false;
+      if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) break;
+    }
     if (patient) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
   }
   cp_flag_store(err, code);
@@ -118,10 +127,14 @@ __device__ inline bool cp_poll(const int* f, int want, int* err, int code, bool 
 
 // one lane: up to three flags polled together (their loads in flight at once: a poll is a round trip to the memory side)
 __device__ inline bool cp_poll3(const int* f0, const int* f1, const int* f2, int want, int* err, int code) {
-  for (unsigned it = 0; it < CP_SPIN_MAX; ++it) {
+  long long t0 = 0;
+  for (unsigned it = 0;; ++it) {
     const int a = cp_flag_load(f0), b = cp_flag_load(f1), c = cp_flag_load(f2);
     if (a == want && b == want && c == want) return true;
-    if ((it & 31) == 31 && cp_flag_load(err) != 0) return false;
+    if ((it & 31) == 31) {
+      if (cp_flag_load(err) != 0) return false;
+      if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) break;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
   cp_flag_store(err, code);
@@ -389,10 +402,12 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       // loads are in flight through the solve and the first product
       if (dl >= 0) {
         cp_flag_wait(dflag);
-        unsigned it = 0;
+        unsigned it = 0; long long t0 = 0;
         while (dflag != want_band) {
-          if (++it >= CP_SPIN_MAX) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
-          if ((it & 31) == 31 && cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+          if ((++it & 31) == 31) {
+            if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+            if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
+          }
           __builtin_amdgcn_s_sleep(1);
           dflag = cp_flag_load(flags + a.nslots + i2);
         }
@@ -546,11 +561,20 @@ k_chol_persist(CpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
   const int q = blockIdx.x % a.nsys, role = blockIdx.x / a.nsys;
   if (role == 0) { cp_critical(a, q, cp_lds); return; }
-  // worker `role - 1` of the system takes the helpers role - 1, role - 1 + nworkers, ... of the dependency-ordered list, one after the
-  // other: a bounded number of resident workgroups whatever the number of tiles (no reliance on dispatch order: everything a
-  // worker waits for is held by the critical workgroup or by a worker further ahead in the same order), and a footprint that leaves
-  // the rest of the chip to whatever runs beside the factorisation
-  for (int h = role - 1; h < a.nhelpers; h += a.nworkers) {
+  // Workers CLAIM the entries of the dependency-ordered helper list one after the other (round 5; round 4 dealt them statically,
+  // worker w taking w, w + nworkers, ..., which only made progress if every workgroup of the launch was resident at once).  An entry
+  // waits only for entries before it in the list and for the critical workgroup (blocks 0 .. nsys-1, dispatched first); entries are
+  // claimed by workgroups that are running, in list order, so whatever an entry waits for is held by a running workgroup: the launch
+  // makes progress with ANY number of resident workers -- a partitioned or shared device, a second handle factoring beside this one,
+  // the tracker's kernels in between.  Which worker computes a tile does not change a bit of it.
+  // (Measured and dropped: asking for the NEXT entry before starting on the current one, to hide the claim's round trip -- the
+  //  factorisation went from 0.233 to 0.33 ms per solve: an entry that is ready sits behind its holder's spin on an earlier one.)
+  int* ctl = (int*)(cp_lds + 2*CP_TILE);
+  for (;;) {
+    if (threadIdx.x == 0) ctl[1] = __hip_atomic_fetch_add(a.claim + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int h = ctl[1];
+    if (h >= a.nhelpers) return;
     if (!cp_helper(a, q, h, cp_lds)) return;
     __syncthreads();
   }
@@ -593,14 +617,16 @@ __device__ inline void cp_back_far(const CpBackArgs& a, int q, int cidx, double*
     if (f + 1 < f1) load_tile(f + 1, nv);
     const double* xi = xb + a.far_row[f]*CH_NB + 4*rg;
     double xv[4];
-    unsigned it = 0;
+    unsigned it = 0; long long t0 = 0;
     for (;;) {
       bool ready = true;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { xv[e] = cp_tagged_load(xi + e); ready &= !cp_is_sent(xv[e]); }
       if (ready) break;
-      if (++it >= CP_SPIN_MAX) { cp_flag_store(err, 0x400 | (cidx << 12)); return; }
-      if ((it & 31) == 31 && cp_flag_load(err) != 0) return;
+      if ((++it & 31) == 31) {
+        if (cp_flag_load(err) != 0) return;
+        if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { cp_flag_store(err, 0x400 | (cidx << 12)); return; }
+      }
       __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
@@ -668,10 +694,12 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
     if (lane < 32) {
       double f = g.f;
       if (e[CPB_FAR]) {
-        unsigned it = 0;
+        unsigned it = 0; long long t0 = 0;
         while (cp_is_sent(f)) {
-          if (++it >= CP_SPIN_MAX) { cp_flag_store(err, 0x500 | (k << 12)); ctl[0] = 0; break; }
-          if ((it & 31) == 31 && cp_flag_load(err) != 0) { ctl[0] = 0; break; }
+          if ((++it & 31) == 31) {
+            if (cp_flag_load(err) != 0) { ctl[0] = 0; break; }
+            if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { cp_flag_store(err, 0x500 | (k << 12)); ctl[0] = 0; break; }
+          }
           __builtin_amdgcn_s_sleep(1);
           f = cp_tagged_load(fb + k*CH_NB + lane);
         }
@@ -735,6 +763,7 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
   __syncthreads();
   if (t == 0) {
     a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
+    a.claim[q] = 0;                       // ... and an untouched helper list
     if (cp_flag_load(err) != 0 && a.fail) atomicOr(a.fail + q, 4);      // a hand-off timed out somewhere: the host falls back to the per-step kernels
   }
   if (!ctl[0]) return;
@@ -742,7 +771,7 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
 }
 
 // a factorisation that is not followed by k_chol_back2 (debug hook) closes its epoch itself
-__global__ void k_cp_bump(int* epoch, int nsys) { if (threadIdx.x < (unsigned)nsys) epoch[threadIdx.x] += 1; }
+__global__ void k_cp_bump(int* epoch, int* claim, int nsys) { if (threadIdx.x < (unsigned)nsys) { epoch[threadIdx.x] += 1; claim[threadIdx.x] = 0; } }
 
 __global__ void __launch_bounds__(CP_THREADS)
 k_chol_back2(CpBackArgs a) {
@@ -753,6 +782,34 @@ k_chol_back2(CpBackArgs a) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
+__global__ void k_chol_persist(CpArgs a);
+__global__ void k_chol_back2(CpBackArgs a);
+constexpr int CP_PERSIST_LDS_MAX = CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 2)*CP_STEP_INTS*(int)sizeof(int);
+// Per device, once: the kernels' LDS attributes, how many workgroups of k_chol_persist the device holds at a time (occupancy query x
+// compute units: 512 on a whole MI355X, a fraction of that on a partitioned one), the spin deadline in wall-clock ticks.  Progress
+// does not depend on the launch being resident (workers claim their work), the footprint does: a launch is sized to leave room.
+struct CpDevice { bool ok = false; int capacity = 0; bool disabled = false; int real_fallbacks = 0; };
+inline CpDevice& cp_device(int dev = -1) {
+  static std::mutex mu; static std::map<int, CpDevice> tab;
+  if (dev < 0) (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tab.find(dev);
+  if (it != tab.end()) return it->second;
+  CpDevice d;
+  int nb = 0, ncu = 0, rate_khz = 100000;
+  d.ok = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_PERSIST_LDS_MAX) == hipSuccess &&
+         hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (6*CP_TILE + 700 + CH_SOLVE_MAX + 64)*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 4)*8*(int)sizeof(int)) == hipSuccess;
+  if (d.ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_chol_persist, CP_THREADS, (size_t)CP_LDS_DOUBLES*sizeof(double) + 40*CP_STEP_INTS*sizeof(int)) == hipSuccess &&
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) d.capacity = nb*ncu;
+  if (const char* e = getenv("MCP_BA_CHOL_CAPACITY")) d.capacity = atoi(e);      // (test hook: pretend to be a partition of that many workgroup slots)
+  (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+  double ms = 20.0; if (const char* e = getenv("MCP_BA_CHOL_DEADLINE_MS")) ms = std::max(0.01, atof(e));
+  const long long ticks = (long long)(ms*rate_khz);
+  if (d.ok) d.ok = hipMemcpyToSymbol(HIP_SYMBOL(cp_deadline), &ticks, sizeof ticks) == hipSuccess;
+  (void)hipGetLastError();
+  return tab.emplace(dev, d).first->second;
+}
+
 struct CholPersist {
   static constexpr int max_sys = 4;
   int n = 0, ntc = 0, nslots = 0, nbslots = 0, nflags = 0, nhelpers = 0, nfarcols = 0;
@@ -904,6 +961,11 @@ struct CholPersist {
       const int per_col = (nhelpers + ntc - 1)/std::max(ntc, 1);
       nworkers = e && atoi(e) > 0 ? atoi(e) : std::max(16, std::min(126, 10*per_col));
       nworkers = std::min(nworkers, std::max(nhelpers, 1));
+      // ... and no more than the device holds beside a reserve of an eighth of its slots (what else is running -- the tracker thread's
+      // frames, the speculative stream -- finds room; a second handle's factorisation shares the workers' slots and both go on)
+      const CpDevice& dv = cp_device();
+      if (!dv.ok || dv.disabled || dv.capacity < 2*max_sys) { release(); return 0; }       // (no one-launch plan on this device: ok stays false, the per-step kernels run)
+      nworkers = std::max(1, std::min(nworkers, (dv.capacity - dv.capacity/8)/max_sys - 1));
     }
     { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
     ok = true;
@@ -914,20 +976,13 @@ struct CholPersist {
 
 // one launch: factor systems [q0, q0 + nsys) of the batch (S + q * sys_stride); L tiles, L_kk^-1 and y land in P.d_Lt
 inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, int* fail, int nsys, size_t sys_stride, int q0) {
-  static std::atomic<unsigned long long> attr_mask{0};
-  int dev = 0; (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
-    if (hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 2)*CP_STEP_INTS*(int)sizeof(int)) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (6*CP_TILE + 700 + CH_SOLVE_MAX + 64)*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 4)*8*(int)sizeof(int)) != hipSuccess) return -1;
-    attr_mask.fetch_or(bit, std::memory_order_relaxed);
-  }
+  if (!cp_device().ok) return -1;          // (attributes, capacity and deadline of this device: set once)
   CpArgs a;
   a.S = S + q0*sys_stride; a.sys_stride = sys_stride; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.nhelpers = P.nhelpers; a.nworkers = P.nworkers;
   a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.delta_of = P.d_delta_of; a.steps = P.d_steps; a.helpers = P.d_helpers; a.upd = P.d_upd;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.Bt = P.d_Bt + q0*P.bt_stride; a.bt_stride = P.bt_stride;
   a.flags = P.d_flags + (size_t)q0*P.nflags; a.nslots = P.nslots; a.nflags = P.nflags; a.err = P.d_err + q0; a.fail = fail + q0;
-  a.epoch = P.d_epoch + q0; P.fail_ptr = fail;
+  a.epoch = P.d_epoch + q0; P.fail_ptr = fail; a.claim = P.d_err + CholPersist::max_sys + q0;
   a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
   hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
@@ -939,7 +994,7 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.slot_of = P.d_slot_of; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.ncols = P.ntc;
   a.far_start = P.d_far_start; a.far_slot = P.d_far_slot; a.far_row = P.d_far_row; a.back_tab = P.d_back_tab;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
-  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0; a.fail = P.fail_ptr ? P.fail_ptr + q0 : nullptr;
+  a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0; a.fail = P.fail_ptr ? P.fail_ptr + q0 : nullptr; a.claim = P.d_err + CholPersist::max_sys + q0;
   static_assert(CP_BACK_NEAR == 3 && CPB_INTS == 8, "the chain workgroup's column table holds three near tiles");
   const size_t lds = (size_t)(6*CP_TILE + 3*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double) + (size_t)(P.ntc*CPB_INTS + 18)*sizeof(int);
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);

@@ -64,6 +64,7 @@ struct DevProblem {
   const unsigned char* blk_pair;  // [nblk] local pose pair of the block, la << 4 | lb (la >= lb)
   const int* blk_dst;             // [nblk] where the block is staged: position in the destination-ordered staging array
   const int* rhs_dst;             // [ngroup*GRP_LMAX] staged rhs row of (group, local pose), or -1
+  const int* sp_unk;              // [nsp] free-point index of the sorted point (-1: fixed, or a point of the generic path) = pt_unk[sp_pt[sp]]
 };
 constexpr int MAXC = MCP_MAX_CHAIN;             // links per pose chain; per-chain arrays are strided by it
 constexpr int MAXC_LOG = 3;

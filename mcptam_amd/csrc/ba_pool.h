@@ -38,10 +38,10 @@ class DevCache {
     int cls; const size_t cb = class_bytes(bytes, &cls);
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev_out) *dev_out = dev;
-    if (enabled_ && cls < NCLS) {
+    if (enabled_ && cls < NCLS && dev < NDEV) {      // (a device ordinal beyond the table -- CPX mode exposes up to 64 -- bypasses the cache: plain hipMalloc / hipFree)
       std::lock_guard<std::mutex> lk(mu_);
-      auto& v = free_[dev & (NDEV - 1)][cls];
-      if (!v.empty()) { void* p = v.back(); v.pop_back(); cached_[dev & (NDEV - 1)] -= cb; *cap = cb; poison(p, cb, cls); return p; }
+      auto& v = free_[dev][cls];
+      if (!v.empty()) { void* p = v.back(); v.pop_back(); cached_[dev] -= cb; *cap = cb; poison(p, cb, cls); return p; }
     }
     void* p = nullptr;
     if (hipMalloc(&p, cb) != hipSuccess) {
@@ -59,18 +59,19 @@ class DevCache {
     if (dev < 0) dev = cur;
     if (!quiesced()) { if (dev != cur) (void)hipSetDevice(dev); (void)hipDeviceSynchronize(); if (dev != cur) (void)hipSetDevice(cur); }
     int cls; const size_t cb = class_bytes(cap, &cls);
-    if (enabled_ && cb == cap && cls < NCLS) {
+    if (enabled_ && cb == cap && cls < NCLS && dev < NDEV) {
       std::lock_guard<std::mutex> lk(mu_);
-      if (cached_[dev & (NDEV - 1)] + cb <= budget_) { free_[dev & (NDEV - 1)][cls].push_back(p); cached_[dev & (NDEV - 1)] += cb; return; }
+      if (cached_[dev] + cb <= budget_) { free_[dev][cls].push_back(p); cached_[dev] += cb; return; }
     }
     (void)hipFree(p);
   }
   void trim(int dev) {
+    if (dev < 0 || dev >= NDEV) return;
     std::vector<void*> all;
-    { std::lock_guard<std::mutex> lk(mu_); for (auto& v : free_[dev & (NDEV - 1)]) { all.insert(all.end(), v.begin(), v.end()); v.clear(); } cached_[dev & (NDEV - 1)] = 0; }
+    { std::lock_guard<std::mutex> lk(mu_); for (auto& v : free_[dev]) { all.insert(all.end(), v.begin(), v.end()); v.clear(); } cached_[dev] = 0; }
     for (void* p : all) (void)hipFree(p);
   }
-  size_t cached_bytes(int dev) { std::lock_guard<std::mutex> lk(mu_); return cached_[dev & (NDEV - 1)]; }
+  size_t cached_bytes(int dev) { if (dev < 0 || dev >= NDEV) return 0; std::lock_guard<std::mutex> lk(mu_); return cached_[dev]; }
   // the calling thread has waited for everything that could touch the blocks it is about to put()
   struct Quiesced { Quiesced() { ++depth(); } ~Quiesced() { --depth(); } };
  private:
@@ -94,7 +95,7 @@ class DevCache {
     if (const char* e = getenv("MCP_DEV_CACHE_LOG")) log_ = atoi(e) != 0;
     if (const char* e = getenv("MCP_DEV_CACHE_MB")) { const long mb = atol(e); if (mb <= 0) enabled_ = false; else budget_ = (size_t)mb << 20; }
   }
-  static constexpr int NDEV = 16, NCLS = 4*40;
+  static constexpr int NDEV = 64, NCLS = 4*40;      // free lists by the REAL device ordinal (no masking: ordinal 16 is not device 0)
   std::mutex mu_;
   std::vector<void*> free_[NDEV][NCLS];
   size_t cached_[NDEV] = {0};

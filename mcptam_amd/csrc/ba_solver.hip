@@ -30,6 +30,7 @@
 #include "ba_select.h"
 #include "ba_chol.h"
 #include "ba_group.h"
+#include "ba_schur4.h"
 #include "ba_comm.h"
 #include "ba_trial.h"
 #include "ba_small.h"
@@ -366,6 +367,15 @@ struct mcp_ba {
     return (nsp <= small_pts) ? LIN_QUAD_PTS : GRP_PTS;
   }
   bool fail_clean = false;        // d_fail was cleared by the linearisation kernel and no system has been built since
+  // round 5 (ba_schur4.h): all systems of a batch in one Schur workgroup.  Groups are closed at S4_LMAX poses (a single point
+  // that sees more keeps its group beyond that: then no group of the map takes the new kernel, sch4_ok = false)
+  static bool env_on(const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; }
+  bool point_order_refine = env_on("MCP_BA_POINT_ORDER", true);     // secondary point order (refine_point_order)
+  int grp_lmax_pol = env_on("MCP_BA_GROUP_LMAX13", true) ? S4_LMAX : GRP_LMAX;
+  bool sch4_on = env_on("MCP_BA_SCHUR4", true), sch4_ok = false;
+  double schur_mfma = 0, schur_flops = 0;       // (profile only) what one system's Schur launch executes / stands for: mcp_ba_timing
+  DevBuf<int> d_g_order, d_sp_unk;              // launch order of the groups in k_schur4 (heaviest first; only when they outnumber the slots), free-point index per sorted point
+  bool sch4_order = false;
   bool asm_long = false;          // the pose pairs' lists of staged blocks are long (a few free poses staged by every group): k_assemble_long
   int grp_inc_max = 0;            // most point-pose incidences of any group (the W area of k_linearize_quad)
   size_t nstage = 0;        // staged 6x6 blocks over all groups
@@ -692,6 +702,29 @@ PrepScratch& prep_scratch() { static PrepScratch s; return s; }
 // blocks, the tile pattern of the reduced system.  Every phase that touches the measurements runs on the worker pool over
 // disjoint ranges and writes to positions that are known beforehand, so the arrays are those of the serial reference
 // implementation (prepare_legacy, MCP_BA_PREPARE_LEGACY=1; tests/test_ba_gpu.py compares the two) whatever the thread count.
+// Secondary point order (round 5).  Points are sorted by the pose they are expressed in; inside one such pose, points that are seen
+// from the same poses now lie next to each other: key = (largest observer pose, sum of the observer poses over the point's
+// measurements), ties by point index.  A group of 64 consecutive points -- and a 16-point chunk of k_schur4 -- then touches fewer
+// poses: at the metric size 10 % fewer staged blocks and 23 % fewer non-empty 16 x 16 tile pairs in the Schur products.
+// `order` holds the points bucketed by `pkey` (ascending); buckets [b0, b1) of it are sorted here.
+static void refine_point_order(std::vector<int>& order, const std::vector<int>& pkey, const int* smax, const int* ssum, size_t i0, size_t i1) {
+  size_t a = i0;
+  while (a < i1) {
+    size_t b = a + 1;
+    while (b < i1 && pkey[order[b]] == pkey[order[a]]) ++b;
+    std::sort(order.begin() + a, order.begin() + b, [&](int x, int y) {
+      if (smax[x] != smax[y]) return smax[x] < smax[y];
+      if (ssum[x] != ssum[y]) return ssum[x] < ssum[y];
+      return x < y; });
+    a = b;
+  }
+}
+// first free pose of a chain (the pose a point's coordinates / a measurement's observer hang off), or -1
+static int chain_first_free(const HChain& c, const std::vector<HPose>& poses) {
+  for (int k = 0; k < c.len; ++k) if (poses[c.v[k]].unk >= 0) return poses[c.v[k]].unk;
+  return -1;
+}
+
 int mcp_ba::prepare() {
   if (getenv("MCP_BA_PREPARE_LEGACY")) return prepare_legacy();
   auto t0 = std::chrono::steady_clock::now();
@@ -775,6 +808,29 @@ int mcp_ba::prepare() {
     for (int k = 0; k <= nfp; ++k) kc[k + 1] += kc[k];
     order.resize(kc[nfp + 1]);
     for (int i = 0; i < npoint; ++i) if (pkey[i] >= 0) order[kc[pkey[i]]++] = i;
+    // ... and inside a pose by which poses see the point (refine_point_order): observer keys per chain, max / sum per point over the
+    // measurements in add order (order-free integer atomics), buckets sorted by ranges of the pool
+    if (point_order_refine) {
+      std::vector<int> ckey(nch, -1), smax(std::max(npoint, 1), 0), ssum(std::max(npoint, 1), 0);
+      for (size_t c = 0; c < nch; ++c) if (chain_used[c]) ckey[c] = chain_first_free(chains[c], poses);
+      par([&](int tid) {
+        const int* mc = meas_chain.data(); const int* mp = meas_point.data();
+        for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
+          const int k = ckey[mc[i]] + 1;
+          if (!k) continue;
+          const int p = mp[i];
+          __atomic_fetch_add(&ssum[p], k, __ATOMIC_RELAXED);
+          int cur = __atomic_load_n(&smax[p], __ATOMIC_RELAXED);
+          while (cur < k && !__atomic_compare_exchange_n(&smax[p], &cur, k, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
+      });
+      // (kc[k] is now the end of bucket k: thread ranges cut at bucket boundaries)
+      par([&](int tid) {
+        const int k0 = (int)lo_of(tid, nfp + 1), k1 = (int)lo_of(tid + 1, nfp + 1);
+        const size_t i0 = k0 ? (size_t)kc[k0 - 1] : 0, i1 = k1 ? (size_t)kc[k1 - 1] : 0;
+        refine_point_order(order, pkey, smax.data(), ssum.data(), i0, i1);
+      });
+    }
   }
   nsp = (int)order.size();
   // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
@@ -953,7 +1009,7 @@ int mcp_ba::prepare() {
       const int* q = sp_q.data() + sp_q0[sp]; const int nq = big ? 0 : sp_q0[sp + 1] - sp_q0[sp];
       int fresh = 0;
       for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) ++fresh;
-      if ((int)curset.size() + fresh > GRP_LMAX || sp - start >= grp_pts) close(sp);
+      if ((int)curset.size() + fresh > grp_lmax_pol || sp - start >= grp_pts) close(sp);
       for (int k = 0; k < nq; ++k) if (stamp[q[k]] != gid) { stamp[q[k]] = gid; curset.push_back(q[k]); }
     }
     close(nsp);
@@ -1111,6 +1167,15 @@ int mcp_ba::prepare_legacy() {
     order.push_back(i);
   }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pkey[a] < pkey[b]; });
+  if (point_order_refine) {      // (the same secondary order as the threaded builder's)
+    std::vector<int> smax(std::max(npoint, 1), 0), ssum(std::max(npoint, 1), 0);
+    for (int i = 0; i < nmeas; ++i) {
+      const int k = chain_first_free(chains[meas[i].chain], poses) + 1;
+      if (!k) continue;
+      ssum[meas_point[i]] += k; smax[meas_point[i]] = std::max(smax[meas_point[i]], k);
+    }
+    refine_point_order(order, pkey, smax.data(), ssum.data(), 0, order.size());
+  }
   nsp = (int)order.size();
   // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
   const size_t nch = chains.size();
@@ -1265,7 +1330,7 @@ int mcp_ba::prepare_legacy() {
       if (sp_big[sp]) ++nbig;
       std::vector<int> merged = curset;
       for (int u : q) if (std::find(merged.begin(), merged.end(), u) == merged.end()) merged.push_back(u);
-      if ((int)merged.size() > GRP_LMAX || sp - start >= grp_pts) { close(sp); merged = q; }
+      if ((int)merged.size() > grp_lmax_pol || sp - start >= grp_pts) { close(sp); merged = q; }
       curset = merged;
     }
     close(nsp);
@@ -1394,6 +1459,29 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
   for (int i = 0; i < npose; ++i) pose_unk[i] = poses[i].unk;
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
+  // k_schur4 holds a group's local tile as 5 x 5 16-row tiles: every group must fit S4_LMAX poses
+  sch4_ok = ngroup > 0;
+  for (int gi = 0; gi < ngroup && sch4_ok; ++gi) if (H.g_pose[(size_t)gi*GRP_LMAX + S4_LMAX] >= 0) sch4_ok = false;
+  schur_mfma = schur_flops = 0;
+  if (prm.profile && ngroup) {
+    // the work of one system's Schur launch, for the bench line: non-empty 16-row tiles of every 16-point chunk -> tile pairs x 12
+    // instructions (k_schur4 skips empty tiles; k_schur_group multiplies every tile of the group's poses), and the structural flops
+    for (int gi = 0; gi < ngroup; ++gi) {
+      int npl = 0; for (int k = 0; k < GRP_LMAX; ++k) if (H.g_pose[(size_t)gi*GRP_LMAX + k] >= 0) npl = k + 1;
+      const int ntile = (6*npl + 15)/16;
+      for (int s0 = H.g_sp0[gi]; s0 < H.g_sp0[gi + 1]; s0 += 16) {
+        unsigned tm = 0;
+        for (int sp = s0; sp < std::min(s0 + 16, H.g_sp0[gi + 1]); ++sp) {
+          if (H.sp_big[sp]) continue;
+          const int k = H.sp_i[sp + 1] - H.sp_i[sp];
+          schur_flops += 324.0*k*(k + 1)/2;
+          for (int i = H.sp_i[sp]; i < H.sp_i[sp + 1]; ++i) { tm |= 1u << ((6*H.inc_lp[i]) >> 4); tm |= 1u << ((6*H.inc_lp[i] + 5) >> 4); }
+        }
+        const int nt = (sch4_on && sch4_ok) ? __builtin_popcount(tm) : (tm ? ntile : 0);
+        schur_mfma += 12.0*nt*(nt + 1)/2;
+      }
+    }
+  }
   {
     // long lists of staged blocks per pose pair (mean >= 48: a handful of free poses that every group stages) go through k_assemble_long
     const size_t npairs = H.pr_start.empty() ? 0 : H.pr_start.size() - 1;
@@ -1429,6 +1517,24 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     add(d_inc_lp, H.inc_lp, true); add(d_inc_mixed, H.inc_mixed, true); add(d_g_blk0, H.g_blk0, true); add(d_blk_pair, H.blk_pair, true);
     add(d_asm_tiles, plan.all_tiles, false); add(d_pair_id, H.pair_id, true); add(d_pr_start, H.pr_start, true); add(d_blk_dst, H.blk_dst, true);
     add(d_po_start, H.po_start, true); add(d_rhs_dst, H.rhs_dst, true);
+    // k_schur4: free-point index per sorted point (one index hop less at the head of every workgroup), and -- when the groups
+    // outnumber the workgroup slots of the device (2 per compute unit) -- the order in which they are launched: heaviest first
+    // (tile pairs x chunks), so that the second round of workgroups is made of the light ones and the launch ends evenly
+    std::vector<int> sp_unk(nsp), g_order;
+    for (int sp = 0; sp < nsp; ++sp) sp_unk[sp] = H.sp_big[sp] ? -1 : pt_unk[H.sp_pt[sp]];
+    sch4_order = sch4_on && sch4_ok && ngroup > 512 && env_on("MCP_BA_SCHUR4_ORDER", true);
+    if (sch4_order) {
+      std::vector<int> cost(ngroup);
+      for (int gi = 0; gi < ngroup; ++gi) {
+        int npl = 0; for (int k = 0; k < GRP_LMAX; ++k) if (H.g_pose[(size_t)gi*GRP_LMAX + k] >= 0) npl = k + 1;
+        const int nt = (6*npl + 15)/16;
+        cost[gi] = nt*(nt + 1)/2*((H.g_sp0[gi + 1] - H.g_sp0[gi] + 15)/16);
+      }
+      g_order.resize(ngroup);
+      for (int gi = 0; gi < ngroup; ++gi) g_order[gi] = gi;
+      std::stable_sort(g_order.begin(), g_order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    }
+    add(d_sp_unk, sp_unk, false); add(d_g_order, g_order, false);
     if (d_struct.alloc(total)) return -1;
     char* const base = d_struct.p;
     auto fix = [&](auto& dbuf) { dbuf.p = reinterpret_cast<decltype(dbuf.p)>(base + reinterpret_cast<size_t>(dbuf.p)); };
@@ -1437,7 +1543,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     fix(d_slot_unk); fix(d_slot_inc); fix(d_l_i0); fix(d_l_i1); fix(d_inc_unk); fix(d_fl_point); fix(d_sp_pt); fix(d_sp_m);
     fix(d_sp_i); fix(d_sp_big); fix(d_m_sp); fix(d_l_sp); fix(d_g_sp0); fix(d_g_pose); fix(d_slot_lp); fix(d_slot_first);
     fix(d_inc_lp); fix(d_inc_mixed); fix(d_g_blk0); fix(d_blk_pair); fix(d_asm_tiles); fix(d_pair_id); fix(d_pr_start); fix(d_blk_dst);
-    fix(d_po_start); fix(d_rhs_dst);
+    fix(d_po_start); fix(d_rhs_dst); fix(d_sp_unk); fix(d_g_order);
     // the small ones: contiguous runs of staged items are contiguous in the device block too -- one copy per run
     char* stage = staged ? (char*)pinned_arena().alloc(staged) : nullptr;
     size_t so = 0;
@@ -1506,7 +1612,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
   P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
-  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p; P.blk_dst = d_blk_dst.p; P.rhs_dst = d_rhs_dst.p;
+  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p; P.blk_dst = d_blk_dst.p; P.rhs_dst = d_rhs_dst.p; P.sp_unk = d_sp_unk.p;
   A.nfp = nfp; A.ntiles = (int)plan.all_tiles.size(); A.tiles = d_asm_tiles.p; A.pair_id = d_pair_id.p;
   A.pr_start = d_pr_start.p; A.po_start = d_po_start.p;
   // the staging arrays of a group that stages nothing for a slot are never read; slots are always fully written
@@ -1822,7 +1928,9 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
   double* Sq = d_red.p + q0*red_stride; double* Vq = d_Vinv.p + q0*vinv_stride;
   double* stSq = d_stS.p + q0*sb.ststride; double* strq = d_str.p + q0*sb.strstride; int* failq = d_fail.p + q0;
   if (main_stream) tic(ST_SCHUR);
-  if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, s, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, stSq, strq, failq, sb);
+  if (nfl && ngroup && sch4_on && sch4_ok)      // every system of the batch in one workgroup per group (ba_schur4.h)
+    hipLaunchKernelGGL(k_schur4, dim3(ngroup), dim3(256), S4_LDS_BYTES, s, P, nsys, (const int*)(sch4_order ? d_g_order.p : nullptr), (const double*)d_V.p, (const double*)d_g.p, (const double*)d_W.p, Vq, stSq, strq, failq, sb);
+  else if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, s, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, stSq, strq, failq, sb);
   else if (ngroup && nstage) {      // no free point: nothing is eliminated, the staged Schur blocks are zero
     HIPCK(hipMemsetAsync(stSq, 0, (size_t)nsys*nstage*36*sizeof(double), s));
     HIPCK(hipMemsetAsync(strq, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), s));
@@ -1838,9 +1946,12 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
     HIPCK(hipStreamSynchronize(s));
     unsigned long long pr[64]; hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sch_prof), sizeof pr);
     double a[8] = {0}; int cnt = 0;
-    for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[7]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
-    if (cnt) fprintf(stderr, "[sch prof] prologue %.0f  inverse+barrier %.0f  scatter %.0f  prefetch+barrier %.0f  mfma %.0f  rhs %.0f  barrier+clear %.0f  flush %.0f  (cycles, %d groups)\n",
-                     a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, a[6]/cnt, a[7]/cnt, cnt);
+    for (int b2 = 0; b2 < 8; ++b2) { const unsigned long long* q = pr + 8*b2; if (!q[0]) continue; for (int i2 = 0; i2 < 8; ++i2) a[i2] += (double)q[i2]; ++cnt; }
+    if (cnt && sch4_on && sch4_ok)
+      fprintf(stderr, "[sch4 prof] prologue %.0f  clear+scatter %.0f  barrier %.0f  prefetch+mfma %.0f  barrier %.0f  flush %.0f  (cycles of wavefront 0, %d systems, %d groups)\n",
+              a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, nsys, cnt);
+    else if (cnt) fprintf(stderr, "[sch prof] prologue %.0f  inverse+barrier %.0f  scatter %.0f  prefetch+barrier %.0f  mfma %.0f  rhs %.0f  barrier+clear %.0f  flush %.0f  (cycles, %d systems, %d groups)\n",
+                     a[0]/cnt, a[1]/cnt, a[2]/cnt, a[3]/cnt, a[4]/cnt, a[5]/cnt, a[6]/cnt, a[7]/cnt, nsys, cnt);
   }
 #endif
   if (np && multi()) {
@@ -2112,7 +2223,7 @@ int mcp_ba::persist_fallback(double lam, bool& ok2, double ni) {
   if (join_spec()) return -1;
   HIPCK(hipStreamSynchronize(st));
   if (st2) HIPCK(hipStreamSynchronize(st2));
-  HIPCK(hipMemsetAsync(plan.persist.d_err, 0, sizeof(int)*CholPersist::max_sys, st));
+  HIPCK(hipMemsetAsync(plan.persist.d_err, 0, 2*sizeof(int)*CholPersist::max_sys, st));      // (error words and claim counters)
   timing.n_persist_fallbacks++;
   return solve_trial(lam, ok2, ni);
 }
@@ -2129,6 +2240,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   outliers.clear(); logs.clear();
   int conv_mag = 0, conv_res = 0;
   if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
+  timing.schur_mfma_per_system = schur_mfma; timing.schur_flops_structural = schur_flops;
   converged = 0; total_iterations = 0;
   int nCounter = 0;
   // emptiness is decided on the GLOBAL totals: a rank whose shard holds no measurement (or no free point) still runs every
@@ -2803,7 +2915,7 @@ int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out
   CholPersist& P = plan.persist;
   if (!plan.use_persist || !P.ok) { set_err("mcp_chol_debug_factor: the persistent factorisation is switched off"); return -1; }
   if (chol_persist_factor(nullptr, P, d.p, f.p, 1, 0, 0)) { set_err("mcp_chol_debug_factor: launch failed"); return -1; }
-  hipLaunchKernelGGL(k_cp_bump, dim3(1), dim3(64), 0, nullptr, P.d_epoch, 1);
+  hipLaunchKernelGGL(k_cp_bump, dim3(1), dim3(64), 0, nullptr, P.d_epoch, P.d_err + CholPersist::max_sys, 1);
   HIPCK(hipDeviceSynchronize());
   std::vector<double> lt(P.lt_stride);
   HIPCK(hipMemcpy(lt.data(), P.d_Lt, P.lt_stride*8, hipMemcpyDeviceToHost));

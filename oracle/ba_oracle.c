@@ -187,7 +187,12 @@ static void gen_field(int i, const double* p, double* o) {
  * double by a different route (double-double arithmetic, mcptam_amd/csrc/atan_cr.h).  tests/test_oracle_cpu.py pins it
  * against libm (never more than 1 ulp apart). */
 #include <quadmath.h>
-double orc_atan(double x) { return (double)atanq((__float128)x); }
+/* Oracle-only switch (round 5): the platform's libm atan instead -- what a real MCPTAM build calls (src/TaylorCamera.cc:216-217
+ * uses ::atan).  Not a parity mode of the product (the device cannot reproduce a particular libm); scripts/oracle_sensitivity.py
+ * uses it to bound what the deliberate "correctly rounded" deviation can move: template bytes, found positions, LM state. */
+static int g_atan_libm = 0;
+void orc_set_atan_libm(int on) { g_atan_libm = on; }
+double orc_atan(double x) { return g_atan_libm ? atan(x) : (double)atanq((__float128)x); }
 
 /* TaylorCamera::PolyVal, TaylorCamera.cc:472-486 */
 static double polyval(const double* c, int n, double x) {

@@ -125,6 +125,7 @@ double orc_ba_debug_robust_chi2(orc_ba*, double* sigma_sq_raw);
 
 /* camera primitives */
 double orc_atan(double x);      /* correctly rounded arctangent (binary128 atanq rounded once) */
+void orc_set_atan_libm(int on); /* oracle-only: 1 = the platform's libm atan (what the reference calls), 0 = correctly rounded (default) */
 int  orc_cam_project(const orc_camera*, const double xc[3], double uv[2], double D[4]);
 void orc_cam_sphere_deriv(const double xc[3], double dtheta[3], double dphi[3]);
 /* TooN [3P-memory] */

@@ -20,6 +20,13 @@ for v in "$@"; do
     sch4) build sch4 -DSCH_WAVES=4 & ;;                    # k_schur_group held to 128 registers: four workgroups per CU (1024 slots >= 785 groups)
     sch2) build sch2 -DSCH_WAVES=2 & ;;
     linabl3) build linabl3 -DLIN_ABL=3 & ;;                # timing ablation: no W block stores in k_linearize_group (results wrong)
+    schprof) build schprof -DMCP_SCH_PROF & ;;             # phase stamps of k_schur4 / k_schur_group (wavefront 0 of sampled groups)
+    s4d1) build s4d1 -DS4_DEPHASE=1 & ;;                  # k_schur4: odd-slot workgroup starts 2 k cycles late
+    s4d2) build s4d2 -DS4_DEPHASE=2 & ;;
+    s4d3) build s4d3 -DS4_DEPHASE=3 & ;;
+    s4d2p) build s4d2p -DS4_DEPHASE=2 -DMCP_SCH_PROF & ;;
+    cpabl1) build cpabl1 -DMCP_CP_PROF=4 -DCH_ABL=1 & ;;    # persistent factorisation, wave 0 stamps, panel without bulk updates (timing only)
+    s4w1) build s4w1 -DS4_WAVES=1 & ;;                     # k_schur4 with 512 registers: one workgroup per compute unit
     proflin) build proflin -DMCP_LIN_PROF & ;;             # phase stamps of k_linearize_group
     proflin2) build proflin2 -DMCP_LIN_PROF -DLIN_WAVES=2 & ;;                    # k_linearize_group held to 256 registers (two wavefronts per SIMD)                      # second-order rsqrt correction in the panel chain
     hsprof) build hsprof -DMCP_HS_PROF=1 & ;;                # phase stamps of k_head_small (ba_small.h)

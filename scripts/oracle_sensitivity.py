@@ -31,6 +31,7 @@ def ba_runs(config, iters):
         ("rejection rule lambda *= 2 (no growing ni)", [(2, 1)]),
         ("acceptance rule lambda *= 1/3 always", [(3, 1)]),
         ("acceptance rule without the 2/3 cap", [(3, 2)]),
+        ("TaylorCamera::Project with the platform's libm atan (what the reference calls) instead of the correctly rounded one", [("atan_libm", 1)]),
     ]
     rows, base = [], None
     for name, sw in variants:
@@ -40,10 +41,17 @@ def ba_runs(config, iters):
             o.SetSolver(2, min(8, os.cpu_count() or 1))     # Schur + OpenMP: same numbers to ~1e-12, minutes instead of an hour
         except Exception:
             pass
+        from oracle import img_lib
+        atan_libm = any(k == "atan_libm" for k, _ in sw)
         for k, v in sw:
-            o.SetVariant(k, v)
+            if k != "atan_libm":
+                o.SetVariant(k, v)
+        img_lib().orc_set_atan_libm(1 if atan_libm else 0)          # (process-wide oracle switch: the BA oracle and the tracker oracle share orc_atan)
         t0 = time.time()
-        r = run_bundle(o, p, iters)
+        try:
+            r = run_bundle(o, p, iters)
+        finally:
+            img_lib().orc_set_atan_libm(0)
         dt = time.time() - t0
         if base is None:
             base = r
@@ -85,11 +93,13 @@ def tracker_rows():
     I = (np.eye(3), np.zeros(3))
     rows, base = [], None
     L = img_lib()
-    for name, kw, nonmax, tround in (("default (halfSample truncating mean, fast_nonmax on the FAST-10 score, transform truncating)", {}, 0, 0),
-                                     ("halfSample = cascaded pavgb (libCVD SSE2 byte path)", {"pavgb": True}, 0, 0),
-                                     ("fast_nonmax on the ring-SAD corner_score", {}, 1, 0),
-                                     ("CVD::transform byte conversion rounding half up", {}, 0, 1)):
+    for name, kw, nonmax, tround, alibm in (("default (halfSample truncating mean, fast_nonmax on the FAST-10 score, transform truncating, correctly rounded atan)", {}, 0, 0, 0),
+                                     ("halfSample = cascaded pavgb (libCVD SSE2 byte path)", {"pavgb": True}, 0, 0, 0),
+                                     ("fast_nonmax on the ring-SAD corner_score", {}, 1, 0, 0),
+                                     ("CVD::transform byte conversion rounding half up", {}, 0, 1, 0),
+                                     ("TaylorCamera::Project with the platform's libm atan (glibc here) instead of the correctly rounded one", {}, 0, 0, 1)):
         L.orc_img_set_variant(0, tround)
+        L.orc_set_atan_libm(alibm)
         A, B = OracleKeyFrame(640, 480, **kw), OracleKeyFrame(640, 480, **kw)
         A.MakeKeyFrame_Lite(sc["imgA"]); B.MakeKeyFrame_Lite(sc["imgB"])
         A.MakeKeyFrame_Rest(nonmax_score=nonmax)
@@ -108,6 +118,7 @@ def tracker_rows():
         rows.append((name, " ".join(map(str, px)), " ".join(map(str, corners)), " ".join(map(str, cands)),
                      "%d / %d" % (rec["found"], rec["npts"]), "n/a (other candidates)" if tb < 0 else str(tb), "n/a" if not same_pts else "%.3f" % fp))
     L.orc_img_set_variant(0, 0)
+    L.orc_set_atan_libm(0)
     return rows
 
 

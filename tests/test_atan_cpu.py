@@ -45,3 +45,23 @@ def test_oracle_atan_is_within_one_ulp_of_libm():
     assert diff < 0.005 * len(xs)
     for x, want in ((0.0, 0.0), (1.0, math.pi / 4), (float("inf"), math.pi / 2), (-1.0, -math.pi / 4)):
         assert L.orc_atan(x) == want
+
+
+def test_oracle_libm_atan_switch_is_off_by_default_and_is_libm():
+    """The oracle-only switch behind the 'libm atan' rows of profiles/r05/oracle_sensitivity.md: what a real MCPTAM build calls
+    (/root/reference/src/TaylorCamera.cc:216-217) instead of the correctly rounded value; default = correctly rounded."""
+    import oracle
+    L = oracle.lib()
+    L.orc_atan.restype = ctypes.c_double
+    L.orc_atan.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(11)
+    xs = np.tan((rng.random(100000) - 0.5) * 3.0)
+    cr = [L.orc_atan(float(x)) for x in xs]
+    L.orc_set_atan_libm(1)
+    try:
+        lm = [L.orc_atan(float(x)) for x in xs]
+    finally:
+        L.orc_set_atan_libm(0)
+    assert lm == [math.atan(float(x)) for x in xs]
+    assert [L.orc_atan(float(x)) for x in xs[:1000]] == cr[:1000]          # switched back
+    assert 0 < sum(a != b for a, b in zip(cr, lm)) < 0.005 * len(xs)       # the two definitions do differ (in the last ulp, rarely)
