@@ -204,6 +204,14 @@ int mcp_dense_spd_solve(const double* A, int n, const double* b, double* x);
  * batched launch chain, `reps` times from the same device-resident input; x (nsys*n) receives the first repetition's
  * solutions and *n_mismatch the number of later repetitions whose solutions differ from it in any bit. */
 int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int reps, double* x, int* n_mismatch);
+/* Structure cache (round 5).  MCPTAM builds a fresh ChainBundle per BundleAdjust call (src/BundleAdjusterMulti.cc:75) and calls
+ * again while the map has not converged (src/MapMaker.cc run loop): a handle whose TOPOLOGY -- chains, which point hangs off which
+ * chain, who measures what, what is fixed -- equals that of an earlier Prepare() on this device adopts that Prepare()'s structure
+ * (host results + a device-to-device clone of the packed structure block) and uploads only its own numbers.  Results are bit for
+ * bit those of a cold Prepare().  MCP_BA_STRUCT_CACHE=0 switches it off, MCP_BA_STRUCT_CACHE_MB sets the budget (default 512).
+ * The two entries below are diagnostics: hits / misses so far in this process; drop every entry. */
+void mcp_ba_struct_cache_stats(long long* hits, long long* misses);
+void mcp_ba_struct_cache_clear(void);
 /* the one-launch factorisation (ba_chol2.h) seen from outside: L (n*n row-major, lower; its diagonal 32x32 BLOCKS hold
  * L_kk^-1, which is what the kernels keep), y = L^-1 b (n), info[0] = hand-off error word, info[1] = failure flag */
 int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out, double* y_out, int* info);

@@ -58,6 +58,7 @@ BA_SYMBOLS = [
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
     "mcp_dense_spd_stress", "mcp_ba_debug_system", "mcp_chol_debug_factor", "mcp_chol_time",
+    "mcp_ba_struct_cache_stats", "mcp_ba_struct_cache_clear",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce", "mcp_comm_allreduce_lane",
 ]
 
@@ -169,6 +170,21 @@ def dense_spd_solve(A, b):
     if lib().mcp_dense_spd_solve(_dp(A), A.shape[0], _dp(b), _dp(x)) != 0:
         raise RuntimeError("mcp_dense_spd_solve failed: " + last_error())
     return x
+
+
+def struct_cache_stats():
+    """(hits, misses) of the structure cache so far in this process (include/mcp_ba.h)."""
+    h, m = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    L = lib()
+    L.mcp_ba_struct_cache_stats.restype = None
+    L.mcp_ba_struct_cache_stats(ctypes.byref(h), ctypes.byref(m))
+    return int(h.value), int(m.value)
+
+
+def struct_cache_clear():
+    L = lib()
+    L.mcp_ba_struct_cache_clear.restype = None
+    L.mcp_ba_struct_cache_clear()
 
 
 def chol_debug_factor(A, b):

@@ -537,6 +537,7 @@ struct CholPlan {
   double* d_diag = nullptr; size_t diag_stride = 0; static constexpr int max_sys = 4;     // factored diagonal tiles
   // the one-launch factorisation + chain back-substitution of ba_chol2.h (MCP_BA_CHOL_PERSIST=0: the per-step kernels below)
   mutable CholPersist persist; bool use_persist = false;
+  const char* launch_failed = nullptr;      // name of a kernel of this plan whose launch the runtime refused (the solver reports it)
   int persist_min_ntc = 3;      // smallest system (in tiles) the one-launch plan is built for (the test hooks set 1)
   ~CholPlan() { release(); }
   int arena_dev = -1;
@@ -635,7 +636,7 @@ inline void chol_factor(hipStream_t st, CholPlan& plan, double* S, int* fail, in
 }
 // row n: y -> x = L^-T y
 inline void chol_back(hipStream_t st, CholPlan& plan, double* S, int nsys = 1, size_t sys_stride = 0, int q0 = 0) {
-  if (plan.use_persist && plan.persist.ok) { (void)chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0); return; }      // (always returns 0: a plain launch)
+  if (plan.use_persist && plan.persist.ok) { if (chol_persist_back(st, plan.persist, S, nsys, sys_stride, q0)) plan.launch_failed = "k_chol_back2"; return; }
   if (plan.fuse_single()) return;      // (k_chol_step has left x in row n)
   const int n = plan.n;
   S += q0*sys_stride;

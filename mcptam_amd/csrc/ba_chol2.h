@@ -986,7 +986,7 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
   hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
-  return 0;
+  return hipGetLastError() == hipSuccess ? 0 : -1;       // (a launch the runtime refuses -- its LDS or grid does not fit this device -- is reported here, by name, not at the end of the solve)
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)
 inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys, size_t sys_stride, int q0) {
@@ -998,7 +998,7 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   static_assert(CP_BACK_NEAR == 3 && CPB_INTS == 8, "the chain workgroup's column table holds three near tiles");
   const size_t lds = (size_t)(6*CP_TILE + 3*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double) + (size_t)(P.ntc*CPB_INTS + 18)*sizeof(int);
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
-  return 0;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 }  // namespace mcp

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <list>
 #include <map>
 #include <string>
 #include <vector>
@@ -277,6 +278,72 @@ static SolverStreams& solver_streams(int device) {
   return P;
 }
 
+// ---- structure cache (round 5) ---------------------------------------------------------------------------------------------------
+// MCPTAM builds a fresh ChainBundle per BundleAdjust call (src/BundleAdjusterMulti.cc:75) and calls again and again while the map has
+// not converged (MapMaker::run: `if (!mbBundleConverged_Full) BundleAdjustAll()`, likewise the recent window) -- on a map whose
+// TOPOLOGY (which chains, which point hangs off which chain, who measures what, what is fixed) is that of the call before, only the
+// numbers have moved.  Everything Prepare() builds from the topology -- point order, slots, incidences, groups, staging plan, the
+// packed device block -- is kept here, keyed by a 128-bit hash of the topology: a handle that brings the same topology adopts the
+// host-side results, clones the device block (a device-to-device copy) and uploads only its own numbers (cameras, measurement
+// values; poses and points go up as always).  A cached Prepare() leaves bit for bit the device state of a cold one.
+struct StructKey {
+  unsigned long long h0 = 0, h1 = 0; int npose = 0, npoint = 0, nmeas = 0, nchain = 0, dev = 0, flags = 0;
+  bool operator==(const StructKey& o) const { return h0 == o.h0 && h1 == o.h1 && npose == o.npose && npoint == o.npoint && nmeas == o.nmeas && nchain == o.nchain && dev == o.dev && flags == o.flags; }
+};
+struct StructEntry {
+  StructKey key;
+  std::vector<int> pose_unk, pt_unk, fp_pose, fl_point, perm;
+  std::vector<unsigned char> pose_active, pt_active, pat;
+  int nfp = 0, nfl = 0, np = 0, nx = 0, nsp = 0, ninc = 0, nslot = 0, ngroup = 0, nbig = 0, grp_pts = 0, grp_blk_max = 0, grp_inc_max = 0, nrhs_rows = 0;
+  size_t nstage = 0; bool asm_long = false, sch4_ok = false, sch4_order = false;
+  double m_total = 0, nfl_total = 0, schur_mfma = 0, schur_flops = 0;
+  std::vector<size_t> counts;            // element count of every array of the packed block, in layout order
+  char* dblock = nullptr; size_t dbytes = 0, dcap = 0; int ddev = -1;      // the device clone (DevCache block)
+  size_t host_bytes() const { return (pose_unk.size() + pt_unk.size() + fp_pose.size() + fl_point.size() + perm.size())*4 + pose_active.size() + pt_active.size() + pat.size(); }
+  ~StructEntry() { if (dblock) DevCache::get().put(dblock, dcap, ddev); }
+};
+class StructCache {
+ public:
+  static StructCache& get() { static StructCache* c = new StructCache(); return *c; }      // (never destroyed: the HIP runtime may be gone at exit)
+  bool enabled() const { return budget_ > 0; }
+  std::shared_ptr<StructEntry> find(const StructKey& k) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = lru_.begin(); it != lru_.end(); ++it) if ((*it)->key == k) { auto e = *it; lru_.erase(it); lru_.push_front(e); ++hits_; return e; }
+    ++misses_;
+    return nullptr;
+  }
+  void insert(std::shared_ptr<StructEntry> e) {
+    std::vector<std::shared_ptr<StructEntry>> dropped;          // (released outside the lock: dropping a device block may wait for the device)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (auto it = lru_.begin(); it != lru_.end(); ++it) if ((*it)->key == e->key) { dropped.push_back(*it); lru_.erase(it); break; }
+      lru_.push_front(e);
+      size_t tot = 0; int n = 0;
+      for (auto it = lru_.begin(); it != lru_.end(); ) {
+        tot += (*it)->dcap + (*it)->host_bytes(); ++n;
+        if (n > 1 && (tot > budget_ || n > max_entries_)) { dropped.push_back(*it); it = lru_.erase(it); } else ++it;
+      }
+    }
+  }
+  void clear() { std::vector<std::shared_ptr<StructEntry>> d; { std::lock_guard<std::mutex> lk(mu_); d.assign(lru_.begin(), lru_.end()); lru_.clear(); } }
+  void stats(long long* h, long long* m) { std::lock_guard<std::mutex> lk(mu_); *h = hits_; *m = misses_; }
+ private:
+  StructCache() { if (const char* e = getenv("MCP_BA_STRUCT_CACHE_MB")) budget_ = (size_t)std::max(0L, atol(e)) << 20; if (const char* e = getenv("MCP_BA_STRUCT_CACHE")) if (atoi(e) == 0) budget_ = 0; }
+  std::mutex mu_; std::list<std::shared_ptr<StructEntry>> lru_;
+  size_t budget_ = (size_t)512 << 20; int max_entries_ = 32; long long hits_ = 0, misses_ = 0;
+};
+// two independent 64-bit hashes of an int array, block by block (the value does not depend on how the work is split over threads)
+static inline unsigned long long mix64(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+static void hash_block(const int* p, size_t n, size_t stride_ints, unsigned long long seed, unsigned long long& a, unsigned long long& b) {
+  unsigned long long x = 0x9e3779b97f4a7c15ull ^ seed, y = 0xc2b2ae3d27d4eb4full + seed;
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned long long v = (unsigned int)p[i*stride_ints];
+    x = (x ^ v)*0x100000001b3ull; x ^= x >> 29;
+    y = (y + v)*0x9fb21c651e98df25ull; y ^= y >> 31;
+  }
+  a = mix64(x); b = mix64(y);
+}
+
 struct mcp_ba {
   int device = 0;
   hipStream_t st = nullptr;
@@ -374,6 +441,11 @@ struct mcp_ba {
   int grp_lmax_pol = env_on("MCP_BA_GROUP_LMAX13", true) ? S4_LMAX : GRP_LMAX;
   bool sch4_on = env_on("MCP_BA_SCHUR4", true), sch4_ok = false;
   double schur_mfma = 0, schur_flops = 0;       // (profile only) what one system's Schur launch executes / stands for: mcp_ba_timing
+  std::vector<unsigned char> last_pat;          // tile occupancy the factorisation plan was built from (kept for the structure cache)
+  std::string launch_err;          // first launch of this solve that the runtime refused: "kernel: reason" (note_launch)
+  void note_launch(const char* k) { const hipError_t e = hipGetLastError(); if (e != hipSuccess && e != hipErrorNotReady && launch_err.empty()) launch_err = std::string(k) + ": " + hipGetErrorString(e); }
+  std::shared_ptr<StructEntry> pending_entry;
+  StructKey cache_key; bool cache_insert = false;      // a cold Prepare() of a cacheable map leaves its results in the structure cache
   DevBuf<int> d_g_order, d_sp_unk;              // launch order of the groups in k_schur4 (heaviest first; only when they outnumber the slots), free-point index per sorted point
   bool sch4_order = false;
   bool asm_long = false;          // the pose pairs' lists of staged blocks are long (a few free poses staged by every group): k_assemble_long
@@ -611,7 +683,7 @@ struct mcp_ba {
   };
   int prepare();
   int prepare_legacy();
-  int finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace);
+  int finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace, const StructEntry* hit = nullptr);
   int upload_state();
   int download_state();
   void launch_chains(int which);
@@ -719,9 +791,10 @@ static void refine_point_order(std::vector<int>& order, const std::vector<int>& 
     a = b;
   }
 }
-// first free pose of a chain (the pose a point's coordinates / a measurement's observer hang off), or -1
-static int chain_first_free(const HChain& c, const std::vector<HPose>& poses) {
-  for (int k = 0; k < c.len; ++k) if (poses[c.v[k]].unk >= 0) return poses[c.v[k]].unk;
+// first movable (not fixed) pose of a chain -- the pose a measurement's observer hangs off -- as an index into the pose array, or -1.
+// (The pose array index, not the unknown number: it is known before the activity pass and orders the poses the same way.)
+static int chain_first_movable(const HChain& c, const std::vector<HPose>& poses) {
+  for (int k = 0; k < c.len; ++k) if (!poses[c.v[k]].fixed) return c.v[k];
   return -1;
 }
 
@@ -739,32 +812,101 @@ int mcp_ba::prepare() {
   auto par = [&](const std::function<void(int)>& fn) { if (T == 1) fn(0); else pool.run(fn); };
   auto lo_of = [&](int tid, long n) { return (long)(n*tid/T); };
   lap("  entry");
+  // ---- the same topology as an earlier call's (structure cache, above)?  128-bit hash over what the structure is built from
+  cache_insert = false;
+  if (StructCache::get().enabled() && !multi() && nmeas > 0) {
+    constexpr size_t HB = 8192;
+    const size_t nbm = ((size_t)nmeas + HB - 1)/HB;
+    std::vector<unsigned long long> ha(3*nbm + 4), hb(3*nbm + 4);
+    par([&](int tid) {
+      for (size_t b = (size_t)lo_of(tid, (long)nbm), e = (size_t)lo_of(tid + 1, (long)nbm); b < e; ++b) {
+        const size_t i0 = b*HB, n = std::min(HB, (size_t)nmeas - i0);
+        hash_block(meas_chain.data() + i0, n, 1, 1, ha[3*b], hb[3*b]);
+        hash_block(meas_point.data() + i0, n, 1, 2, ha[3*b + 1], hb[3*b + 1]);
+        hash_block(&meas[i0].cam, n, sizeof(HMeas)/sizeof(int), 3, ha[3*b + 2], hb[3*b + 2]);
+      }
+    });
+    static_assert(sizeof(HMeas) % sizeof(int) == 0 && sizeof(HPoint) % sizeof(int) == 0 && sizeof(HPose) % sizeof(int) == 0 && sizeof(HChain) == (1 + MCP_MAX_CHAIN)*sizeof(int), "strided hashing");
+    if (npose) hash_block(&poses[0].fixed, npose, sizeof(HPose)/sizeof(int), 4, ha[3*nbm], hb[3*nbm]);
+    if (nch) hash_block(&chains[0].len, nch*(1 + MCP_MAX_CHAIN), 1, 5, ha[3*nbm + 1], hb[3*nbm + 1]);
+    if (npoint) { hash_block(&points[0].fixed, npoint, sizeof(HPoint)/sizeof(int), 6, ha[3*nbm + 2], hb[3*nbm + 2]); hash_block(&points[0].chain, npoint, sizeof(HPoint)/sizeof(int), 7, ha[3*nbm + 3], hb[3*nbm + 3]); }
+    StructKey key;
+    for (size_t i = 0; i < ha.size(); ++i) { key.h0 = mix64(key.h0 ^ ha[i]) + i; key.h1 = mix64(key.h1 + hb[i]) ^ (i*0x9e3779b97f4a7c15ull); }
+    key.npose = npose; key.npoint = npoint; key.nmeas = nmeas; key.nchain = (int)nch; key.dev = device;
+    // (what else decides the structure: the grouping policy and its run-time switches)
+    const char* e_al = getenv("MCP_BA_ASM_LONG");
+    key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
+                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16);
+    cache_key = key;
+    std::shared_ptr<StructEntry> hit = StructCache::get().find(key);
+    lap("  topology hash");
+    if (hit) {
+      // adopt: the host-side results of the structure build, then the device block (finish_prepare)
+      for (int i = 0; i < npose; ++i) { poses[i].unk = hit->pose_unk[i]; poses[i].active = hit->pose_active[i]; }
+      for (int i = 0; i < npoint; ++i) { points[i].unk = hit->pt_unk[i]; points[i].active = hit->pt_active[i]; }
+      fp_pose = hit->fp_pose; fl_point = hit->fl_point; perm = hit->perm;
+      nfp = hit->nfp; nfl = hit->nfl; np = hit->np; nx = hit->nx; nsp = hit->nsp; ninc = hit->ninc; nslot = hit->nslot; ngroup = hit->ngroup; nbig = hit->nbig;
+      grp_pts = hit->grp_pts; grp_blk_max = hit->grp_blk_max; grp_inc_max = hit->grp_inc_max; nrhs_rows = hit->nrhs_rows; nstage = hit->nstage;
+      m_total = hit->m_total; nfl_total = hit->nfl_total;
+      if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
+      std::unique_lock<std::mutex> arena_lock(pinned_arena().mutex());
+      ArenaGuard arena_guard{st};
+      HostStruct H;
+      last_pat = hit->pat;
+      if (np > 0) { if (plan.build(np, last_pat)) { set_err("Cholesky plan allocation failed"); return -1; } }
+      else plan.all_tiles.clear();
+      lap("  adopted (cache hit)");
+      return finish_prepare(H, t0, tlast, trace, hit.get());
+    }
+    cache_insert = true;
+  }
   // ---- one pass over the measurements in add order, a range per thread: which chains are used, and how many measurements of
   // every point the range holds (private counters: no shared writes)
   std::vector<unsigned char> chain_used(nch, 0);
   struct SMeas { int chain, cam, mi, pad_; double u, v, omega; };
   PrepScratch& scratch = prep_scratch();
   std::unique_lock<std::mutex> scratch_lock(scratch.m);
-  scratch.reset(sizeof(int)*(size_t)T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + 256);
+  // (with the secondary point order: per point also the largest observer pose and the sum of the observer poses -- the key of
+  //  refine_point_order -- in the same private way: a first version added them up with atomics on shared arrays, 6 ms of cache-line
+  //  ping-pong between the threads)
+  const bool refine = point_order_refine;
+  scratch.reset(sizeof(int)*(size_t)(refine ? 3 : 1)*T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + 256);
   int* const cnt_t = scratch.take<int>((size_t)T*std::max(npoint, 1));
+  int* const sig_t = refine ? scratch.take<int>((size_t)2*T*std::max(npoint, 1)) : nullptr;      // [thread][max | sum][point]
   SMeas* const sorted = scratch.take<SMeas>(std::max(nmeas, 1));
+  std::vector<int> ckey;
+  if (refine) { ckey.resize(nch); for (size_t c = 0; c < nch; ++c) ckey[c] = chain_first_movable(chains[c], poses) + 1; }
   {
     std::vector<unsigned char> cu_all((size_t)T*nch, 0);
     par([&](int tid) {
       unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t + (size_t)tid*npoint;
       std::memset(ct, 0, sizeof(int)*(size_t)npoint);
       const int* mc = meas_chain.data(); const int* mp = meas_point.data();
-      for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; }
+      if (!refine) { for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; } return; }
+      int* mx = sig_t + (size_t)2*tid*npoint; int* sm = mx + npoint;
+      std::memset(mx, 0, sizeof(int)*(size_t)2*npoint);
+      const int* ck = ckey.data();
+      for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
+        const int c = mc[i], pt = mp[i], k = ck[c];
+        cu[c] = 1; ct[pt]++;
+        sm[pt] += k; if (k > mx[pt]) mx[pt] = k;
+      }
     });
     for (int t = 0; t < T; ++t) for (size_t c = 0; c < nch; ++c) chain_used[c] |= cu_all[(size_t)t*nch + c];
   }
   // per point: total, and the rank at which every thread's measurements of it start (add order = thread order, then index order)
-  std::vector<int> cnt(npoint + 1, 0);
+  std::vector<int> cnt(npoint + 1, 0), smax, ssum;
+  if (refine) { smax.resize(std::max(npoint, 1)); ssum.resize(std::max(npoint, 1)); }
   par([&](int tid) {
     for (long p = lo_of(tid, npoint), e = lo_of(tid + 1, npoint); p < e; ++p) {
       int tot = 0;
       for (int t = 0; t < T; ++t) { int& c = cnt_t[(size_t)t*npoint + p]; const int v = c; c = tot; tot += v; }
       cnt[p + 1] = tot;
+      if (refine) {
+        int m = 0, sum = 0;
+        for (int t = 0; t < T; ++t) { m = std::max(m, sig_t[(size_t)2*t*npoint + p]); sum += sig_t[(size_t)(2*t + 1)*npoint + p]; }
+        smax[p] = m; ssum[p] = sum;
+      }
     }
   });
   lap("  counts (threads)");
@@ -808,23 +950,9 @@ int mcp_ba::prepare() {
     for (int k = 0; k <= nfp; ++k) kc[k + 1] += kc[k];
     order.resize(kc[nfp + 1]);
     for (int i = 0; i < npoint; ++i) if (pkey[i] >= 0) order[kc[pkey[i]]++] = i;
-    // ... and inside a pose by which poses see the point (refine_point_order): observer keys per chain, max / sum per point over the
-    // measurements in add order (order-free integer atomics), buckets sorted by ranges of the pool
-    if (point_order_refine) {
-      std::vector<int> ckey(nch, -1), smax(std::max(npoint, 1), 0), ssum(std::max(npoint, 1), 0);
-      for (size_t c = 0; c < nch; ++c) if (chain_used[c]) ckey[c] = chain_first_free(chains[c], poses);
-      par([&](int tid) {
-        const int* mc = meas_chain.data(); const int* mp = meas_point.data();
-        for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
-          const int k = ckey[mc[i]] + 1;
-          if (!k) continue;
-          const int p = mp[i];
-          __atomic_fetch_add(&ssum[p], k, __ATOMIC_RELAXED);
-          int cur = __atomic_load_n(&smax[p], __ATOMIC_RELAXED);
-          while (cur < k && !__atomic_compare_exchange_n(&smax[p], &cur, k, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-        }
-      });
-      // (kc[k] is now the end of bucket k: thread ranges cut at bucket boundaries)
+    // ... and inside a pose by which poses see the point (refine_point_order; its keys were taken in the counting pass): buckets sorted
+    // by ranges of the pool (kc[k] is now the end of bucket k: thread ranges cut at bucket boundaries)
+    if (refine) {
       par([&](int tid) {
         const int k0 = (int)lo_of(tid, nfp + 1), k1 = (int)lo_of(tid + 1, nfp + 1);
         const size_t i0 = k0 ? (size_t)kc[k0 - 1] : 0, i1 = k1 ? (size_t)kc[k1 - 1] : 0;
@@ -1044,8 +1172,9 @@ int mcp_ba::prepare() {
     }
     lap("  covisibility");
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
+    last_pat = std::move(pat);
     lap("  symbolic plan");
-  } else plan.all_tiles.clear();
+  } else { plan.all_tiles.clear(); last_pat.clear(); }
   // ---- per group (threads over ranges of groups): local pose indices of slots and incidences, and which local pose pairs the
   // group's points co-observe (one bit per pair of the 16 x 17 / 2)
   H.slot_lp.assign(nslot + 1, 0); H.inc_lp.assign(ninc + 1, 0); H.inc_mixed.assign(ninc + 1, 0);
@@ -1114,6 +1243,7 @@ int mcp_ba::prepare() {
 }
 
 int mcp_ba::prepare_legacy() {
+  cache_insert = false;            // (the serial builder neither consults nor fills the structure cache)
   auto t0 = std::chrono::steady_clock::now();
   auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
   auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
@@ -1170,8 +1300,7 @@ int mcp_ba::prepare_legacy() {
   if (point_order_refine) {      // (the same secondary order as the threaded builder's)
     std::vector<int> smax(std::max(npoint, 1), 0), ssum(std::max(npoint, 1), 0);
     for (int i = 0; i < nmeas; ++i) {
-      const int k = chain_first_free(chains[meas[i].chain], poses) + 1;
-      if (!k) continue;
+      const int k = chain_first_movable(chains[meas[i].chain], poses) + 1;
       ssum[meas_point[i]] += k; smax[meas_point[i]] = std::max(smax[meas_point[i]], k);
     }
     refine_point_order(order, pkey, smax.data(), ssum.data(), 0, order.size());
@@ -1451,7 +1580,7 @@ int mcp_ba::prepare_legacy() {
 }
 
 // allocation + upload of a finished host structure (common to both builders)
-int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace) {
+int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace, const StructEntry* hit) {
   auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
   const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
@@ -1461,9 +1590,11 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   for (int i = 0; i < npoint; ++i) { pt_chain[i] = points[i].chain; pt_unk[i] = points[i].unk; pt_fixed[i] = (unsigned char)points[i].fixed; }
   // k_schur4 holds a group's local tile as 5 x 5 16-row tiles: every group must fit S4_LMAX poses
   sch4_ok = ngroup > 0;
-  for (int gi = 0; gi < ngroup && sch4_ok; ++gi) if (H.g_pose[(size_t)gi*GRP_LMAX + S4_LMAX] >= 0) sch4_ok = false;
+  if (hit) sch4_ok = hit->sch4_ok;
+  else for (int gi = 0; gi < ngroup && sch4_ok; ++gi) if (H.g_pose[(size_t)gi*GRP_LMAX + S4_LMAX] >= 0) sch4_ok = false;
   schur_mfma = schur_flops = 0;
-  if (prm.profile && ngroup) {
+  if (hit) { schur_mfma = hit->schur_mfma; schur_flops = hit->schur_flops; }
+  else if ((prm.profile || cache_insert) && ngroup) {       // (a Prepare() that fills the structure cache computes it for whoever adopts the entry)
     // the work of one system's Schur launch, for the bench line: non-empty 16-row tiles of every 16-point chunk -> tile pairs x 12
     // instructions (k_schur4 skips empty tiles; k_schur_group multiplies every tile of the group's poses), and the structural flops
     for (int gi = 0; gi < ngroup; ++gi) {
@@ -1482,7 +1613,8 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       }
     }
   }
-  {
+  if (hit) asm_long = hit->asm_long;
+  else {
     // long lists of staged blocks per pose pair (mean >= 48: a handful of free poses that every group stages) go through k_assemble_long
     const size_t npairs = H.pr_start.empty() ? 0 : H.pr_start.size() - 1;
     asm_long = npairs > 0 && nstage >= 48*npairs;
@@ -1496,13 +1628,19 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     std::vector<Item> items; items.reserve(48);
     size_t total = 0, staged = 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // (a cache hit brings no host arrays: the layout is replayed from the element counts the cold Prepare() recorded, in the same order)
+    std::vector<size_t> counts; counts.reserve(48);
+    size_t nadd = 0;
     auto add = [&](auto& dbuf, const auto& vec, bool pinned) {
       using E = typename std::remove_reference<decltype(vec)>::type::value_type;
-      const size_t bytes = vec.size()*sizeof(E);
+      const size_t cnt = hit ? hit->counts[nadd] : vec.size();
+      ++nadd;
+      const size_t bytes = cnt*sizeof(E);
       dbuf.release();
-      dbuf.alias = true; dbuf.n = std::max<size_t>(vec.size(), 1); dbuf.p = reinterpret_cast<decltype(dbuf.p)>(total);      // (offset for now)
+      dbuf.alias = true; dbuf.n = std::max<size_t>(cnt, 1); dbuf.p = reinterpret_cast<decltype(dbuf.p)>(total);      // (offset for now)
       const bool direct = pinned && bytes >= 16384;
-      items.push_back({vec.data(), bytes, total, direct});
+      counts.push_back(cnt);
+      items.push_back({hit ? nullptr : (const void*)vec.data(), bytes, total, direct});
       if (!direct) staged += al(std::max<size_t>(bytes, 1));
       total += al(std::max<size_t>(bytes, 1));
     };
@@ -1520,10 +1658,10 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     // k_schur4: free-point index per sorted point (one index hop less at the head of every workgroup), and -- when the groups
     // outnumber the workgroup slots of the device (2 per compute unit) -- the order in which they are launched: heaviest first
     // (tile pairs x chunks), so that the second round of workgroups is made of the light ones and the launch ends evenly
-    std::vector<int> sp_unk(nsp), g_order;
-    for (int sp = 0; sp < nsp; ++sp) sp_unk[sp] = H.sp_big[sp] ? -1 : pt_unk[H.sp_pt[sp]];
-    sch4_order = sch4_on && sch4_ok && ngroup > 512 && env_on("MCP_BA_SCHUR4_ORDER", true);
-    if (sch4_order) {
+    std::vector<int> sp_unk(hit ? 0 : nsp), g_order;
+    if (!hit) for (int sp = 0; sp < nsp; ++sp) sp_unk[sp] = H.sp_big[sp] ? -1 : pt_unk[H.sp_pt[sp]];
+    sch4_order = hit ? hit->sch4_order : (sch4_on && sch4_ok && ngroup > 512 && env_on("MCP_BA_SCHUR4_ORDER", true));
+    if (sch4_order && !hit) {
       std::vector<int> cost(ngroup);
       for (int gi = 0; gi < ngroup; ++gi) {
         int npl = 0; for (int k = 0; k < GRP_LMAX; ++k) if (H.g_pose[(size_t)gi*GRP_LMAX + k] >= 0) npl = k + 1;
@@ -1544,10 +1682,37 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     fix(d_sp_i); fix(d_sp_big); fix(d_m_sp); fix(d_l_sp); fix(d_g_sp0); fix(d_g_pose); fix(d_slot_lp); fix(d_slot_first);
     fix(d_inc_lp); fix(d_inc_mixed); fix(d_g_blk0); fix(d_blk_pair); fix(d_asm_tiles); fix(d_pair_id); fix(d_pr_start); fix(d_blk_dst);
     fix(d_po_start); fix(d_rhs_dst); fix(d_sp_unk); fix(d_g_order);
+    if (hit) {
+      // the cached clone of the block, then this handle's own numbers over it: the cameras and the measurement values (u, v, the
+      // weight), gathered into sorted order through the permutation the structure build left
+      if (hit->dbytes != total) { set_err("structure cache: layout mismatch"); return -1; }
+      HIPCK(hipMemcpyAsync(base, hit->dblock, total, hipMemcpyDeviceToDevice, st));
+      const size_t nm = (size_t)nmeas;
+      double* vals = (double*)pinned_arena().alloc((3*nm + 1)*sizeof(double));
+      {
+        HostPool& pool = host_pool();
+        const int T = (nmeas >= 32768) ? pool.size() : 1;
+        const int* pm = perm.data(); const HMeas* ms = meas.data();
+        auto body = [&](int tid) {
+          for (size_t j = nm*tid/T, e = nm*(tid + 1)/T; j < e; ++j) { const HMeas& m = ms[pm[j]]; vals[j] = m.u; vals[nm + j] = m.v; vals[2*nm + j] = m.omega; }
+        };
+        if (T == 1) body(0); else pool.run(body);
+      }
+      if (nm) {
+        HIPCK(hipMemcpyAsync(d_m_u.p, vals, nm*sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d_m_v.p, vals + nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(d_m_omega.p, vals + 2*nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
+      }
+      if (!cams.empty()) {
+        mcp_camera* cs = (mcp_camera*)pinned_arena().alloc(cams.size()*sizeof(mcp_camera));
+        std::memcpy(cs, cams.data(), cams.size()*sizeof(mcp_camera));
+        HIPCK(hipMemcpyAsync(d_cams.p, cs, cams.size()*sizeof(mcp_camera), hipMemcpyHostToDevice, st));
+      }
+    }
     // the small ones: contiguous runs of staged items are contiguous in the device block too -- one copy per run
-    char* stage = staged ? (char*)pinned_arena().alloc(staged) : nullptr;
+    char* stage = (staged && !hit) ? (char*)pinned_arena().alloc(staged) : nullptr;
     size_t so = 0;
-    for (size_t i = 0; i < items.size(); ) {
+    for (size_t i = 0; i < items.size() && !hit; ) {
       if (items[i].direct) { if (items[i].bytes) HIPCK(hipMemcpyAsync(base + items[i].off, items[i].src, items[i].bytes, hipMemcpyHostToDevice, st)); ++i; continue; }
       const size_t run_off = items[i].off, run_so = so;
       size_t run_bytes = 0;
@@ -1556,6 +1721,26 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
         const size_t a = al(std::max<size_t>(items[i].bytes, 1)); so += a; run_bytes += a;
       }
       HIPCK(hipMemcpyAsync(base + run_off, stage + run_so, run_bytes, hipMemcpyHostToDevice, st));
+    }
+    if (!hit && cache_insert) {
+      // leave the results in the structure cache: host-side members + a device clone of the block (behind the uploads, on this stream;
+      // whoever adopts it waits for nothing: an entry becomes visible only after this Prepare()'s final synchronisation, below)
+      auto e = std::make_shared<StructEntry>();
+      e->key = cache_key;
+      e->pose_unk.resize(npose); e->pose_active.resize(npose); e->pt_unk.resize(npoint); e->pt_active.resize(npoint);
+      for (int i = 0; i < npose; ++i) { e->pose_unk[i] = poses[i].unk; e->pose_active[i] = (unsigned char)poses[i].active; }
+      for (int i = 0; i < npoint; ++i) { e->pt_unk[i] = points[i].unk; e->pt_active[i] = (unsigned char)points[i].active; }
+      e->fp_pose = fp_pose; e->fl_point = fl_point; e->perm = perm; e->pat = last_pat;
+      e->nfp = nfp; e->nfl = nfl; e->np = np; e->nx = nx; e->nsp = nsp; e->ninc = ninc; e->nslot = nslot; e->ngroup = ngroup; e->nbig = nbig;
+      e->grp_pts = grp_pts; e->grp_blk_max = grp_blk_max; e->grp_inc_max = grp_inc_max; e->nrhs_rows = nrhs_rows; e->nstage = nstage;
+      e->asm_long = asm_long; e->sch4_ok = sch4_ok; e->sch4_order = sch4_order; e->m_total = m_total; e->nfl_total = nfl_total;
+      e->schur_mfma = schur_mfma; e->schur_flops = schur_flops; e->counts = counts;
+      e->dblock = (char*)DevCache::get().take(std::max<size_t>(total, 1), &e->dcap, &e->ddev);
+      if (e->dblock) {
+        e->dbytes = total;
+        HIPCK(hipMemcpyAsync(e->dblock, base, total, hipMemcpyDeviceToDevice, st));
+        pending_entry = e;
+      }
     }
   }
   const size_t nc = chains.size();
@@ -1628,6 +1813,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   lap("alloc+upload");
   if (upload_state()) return -1;
   HIPCK(hipStreamSynchronize(st));
+  if (pending_entry) { StructCache::get().insert(pending_entry); pending_entry.reset(); }
   lap("state");
   dirty = false;
   timing.structure_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1897,8 +2083,9 @@ int mcp_ba::linearize() {
     hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), quad_lds, st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36, d_fail.p);
   else if (ngroup)
-    hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
+    hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), getenv("MCP_BA_TEST_REFUSE_LAUNCH") ? ((size_t)1 << 20) /* test hook: more LDS than a compute unit has */ : (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, d_fail.p);
+  if (ngroup) note_launch("k_linearize_group / k_linearize_quad");
   fail_clean = ngroup > 0;            // (the group kernel has cleared the failure flags: the first solve of this linearisation needs no fill)
 #ifdef MCP_LIN_PROF
   {
@@ -1931,6 +2118,7 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
   if (nfl && ngroup && sch4_on && sch4_ok)      // every system of the batch in one workgroup per group (ba_schur4.h)
     hipLaunchKernelGGL(k_schur4, dim3(ngroup), dim3(256), S4_LDS_BYTES, s, P, nsys, (const int*)(sch4_order ? d_g_order.p : nullptr), (const double*)d_V.p, (const double*)d_g.p, (const double*)d_W.p, Vq, stSq, strq, failq, sb);
   else if (nfl && ngroup) hipLaunchKernelGGL(k_schur_group, dim3(ngroup, nsys), dim3(256), SCH_LDS_BYTES, s, P, sb.lambda[0], d_V.p, d_g.p, d_W.p, Vq, stSq, strq, failq, sb);
+  if (nfl && ngroup) note_launch("k_schur4 / k_schur_group");
   else if (ngroup && nstage) {      // no free point: nothing is eliminated, the staged Schur blocks are zero
     HIPCK(hipMemsetAsync(stSq, 0, (size_t)nsys*nstage*36*sizeof(double), s));
     HIPCK(hipMemsetAsync(strq, 0, (size_t)nsys*nrhs_rows*6*sizeof(double), s));
@@ -2231,7 +2419,7 @@ int mcp_ba::persist_fallback(double lam, bool& ok2, double ni) {
 int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_lambda) {
   auto t_begin = std::chrono::steady_clock::now();
   HIPCK(hipSetDevice(device));
-  (void)hipGetLastError();                 // (the check at the end is about THIS solve's launches)
+  (void)hipGetLastError(); launch_err.clear(); plan.launch_failed = nullptr;      // (launch checks below are about THIS solve)
   std::memset(&timing, 0, sizeof timing);
   evs.clear(); ev_used = 0;
   if (n_iter < 0) n_iter = prm.max_iterations;      // 0 runs nothing, as g2o optimize(0) (-> -1 unless externally aborted)
@@ -2427,12 +2615,11 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   if (download_state()) return MCP_ERR_RUNTIME;
   // A launch the runtime refused (a configuration a kernel cannot run with) leaves no trace in the stream: the state simply stays
   // what it was.  Kernel launches are not checked one by one; whatever one of them reported is still the thread's last error here.
-  {
-    // (one rank only: a collective library probes the runtime on the caller's thread -- peer access that is already on, and the like --
-    //  and what it leaves behind is not ours to judge)
-    const hipError_t le = hipGetLastError();
-    if (!multi() && le != hipSuccess && le != hipErrorNotReady) { set_err(std::string("a launch of this solve failed: ") + hipGetErrorString(le)); return MCP_ERR_RUNTIME; }
-  }
+  // The launches whose configuration a device can refuse (dynamic LDS, persistent grids) are checked where they are made
+  // (note_launch / chol_persist_*): the first refusal is reported here by kernel name.  (Round 4 looked at the thread's sticky last
+  // error at this point, which also caught benign leftovers of unrelated runtime calls and blamed "a launch".)
+  if (plan.launch_failed && launch_err.empty()) launch_err = std::string(plan.launch_failed) + ": launch refused";
+  if (!launch_err.empty()) { set_err("a launch of this solve failed: " + launch_err); launch_err.clear(); plan.launch_failed = nullptr; return MCP_ERR_RUNTIME; }
   // stage timings
   if (prm.profile) {
     (void)hipStreamSynchronize(st);
@@ -2633,11 +2820,15 @@ int mcp_ba_add_meas(mcp_ba* h, const int* chain, int n, int point_id, const doub
 }
 int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, int stride, const int* chain_len,
                       const unsigned char* fixed, int* ids_out) {
+  static const bool trace = getenv("MCP_BA_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  h->points.reserve(h->points.size() + count); h->id_kind.reserve(h->id_kind.size() + count); h->id_index.reserve(h->id_index.size() + count);
   for (int i = 0; i < count; ++i) {
     int id = mcp_ba_add_point(h, x + 3*(size_t)i, chains + (size_t)stride*i, chain_len[i], fixed ? fixed[i] : 0);
     if (id < 0) return -1;
     if (ids_out) ids_out[i] = id;
   }
+  if (trace) fprintf(stderr, "[mcp_ba add] %d points %.3f ms\n", count, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return 0;
 }
 int mcp_ba_add_measurements(mcp_ba* h, int count, const int* chains, int stride, const int* chain_len, const int* point_ids,
@@ -2648,8 +2839,12 @@ int mcp_ba_add_measurements(mcp_ba* h, int count, const int* chains, int stride,
   // resolved read-only by the threads; rows with a new chain are completed afterwards in row order, so chains are numbered as
   // a serial replay numbers them.
   if (count <= 0) return 0;
+  static const bool trace = getenv("MCP_BA_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Tr { bool on; int n; std::chrono::steady_clock::time_point t0; double sized = 0; ~Tr() { if (on) fprintf(stderr, "[mcp_ba add] %d measurements %.3f ms (arrays sized after %.3f)\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), sized); } } tr{trace, count, t0};
   const size_t n0 = h->meas.size();
   h->meas.resize(n0 + count); h->meas_point.resize(n0 + count); h->meas_chain.resize(n0 + count);
+  tr.sized = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   HMeas* mo = h->meas.data() + n0; int* po = h->meas_point.data() + n0; int* co = h->meas_chain.data() + n0;
   const int ncam = (int)h->cams.size(), next_id = h->next_id;
   const int* kind = h->id_kind.data(); const int* index = h->id_index.data();
@@ -2900,6 +3095,10 @@ int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int 
   if (n_mismatch) *n_mismatch = bad;
   return 0;
 }
+
+// structure cache (test / diagnostic hooks): hits and misses so far in this process; drop every entry
+void mcp_ba_struct_cache_stats(long long* hits, long long* misses) { long long h = 0, m = 0; StructCache::get().stats(&h, &m); if (hits) *hits = h; if (misses) *misses = m; }
+void mcp_ba_struct_cache_clear(void) { StructCache::get().clear(); }
 
 // the one-launch factorisation of ba_chol2.h looked at from outside (test hook): L (n x n, row-major, lower triangle; the
 // diagonal BLOCKS hold L_kk^-1, which is what the kernels keep) and y = L^-1 b; info[0] = error word, info[1] = failure flag

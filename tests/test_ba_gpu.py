@@ -968,6 +968,68 @@ def test_threaded_prepare_builds_the_serial_structure(gpu_required, cfg, iters, 
     assert np.array_equal(new["R"], old["R"]) and np.array_equal(new["t"], old["t"]) and np.array_equal(new["X"], old["X"])
 
 
+def test_a_refused_launch_is_reported_by_kernel_name(gpu_required, monkeypatch):
+    """A launch the runtime refuses (here: the linearisation asked for more LDS than a compute unit has -- a test hook) leaves no trace
+    in the stream; Compute() must not return the untouched state as a result.  The check sits at the launch site, so the message names
+    the kernel, and the next solve on a healthy configuration is not affected by anything sticky."""
+    from mcptam_amd import synth, chain_bundle
+    p = synth.make_config("c2", n_mkf=20, n_points=20000)      # (large-map layout: k_linearize_group)
+    monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")
+    monkeypatch.setenv("MCP_BA_TEST_REFUSE_LAUNCH", "1")
+    g = _gpu(p.cams, disable_convergence=True)
+    p.populate(g)
+    with pytest.raises(RuntimeError) as ei:
+        g.Compute(2)
+    assert "k_linearize" in str(ei.value)
+    monkeypatch.delenv("MCP_BA_TEST_REFUSE_LAUNCH")
+    r = run_bundle(_gpu(p.cams, disable_convergence=True), p, 2)
+    assert r["rc"] == 2
+
+
+@pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 6), ("calib", 6), ("c2", 5), ("metric", 4)])
+def test_cached_prepare_equals_a_cold_one(gpu_required, cfg, iters):
+    """Structure cache (include/mcp_ba.h): a handle that brings the topology of an earlier Prepare() adopts that structure (host
+    results + a device clone of the packed block) and uploads only its numbers.  The reduced system, iteration logs, poses, points and
+    outlier list of a cached Prepare() equal a cold one's bit for bit -- also when the NUMBERS differ between the call that filled
+    the cache and the call that hits it (other measurement noise, other initial state), which is how MCPTAM repeats an adjustment
+    (/root/reference/src/BundleAdjusterMulti.cc:75: a fresh bundle per call; src/MapMaker.cc: called again until converged)."""
+    from mcptam_amd import synth, chain_bundle
+    p = synth.make_config(cfg)
+    q = synth.make_config(cfg)                         # same topology, other numbers
+    rng = np.random.default_rng(5)
+    q.ms_uv = q.ms_uv + rng.normal(size=q.ms_uv.shape) * 0.05
+    q.pt_x = q.pt_x * (1.0 + 1e-3 * rng.normal(size=(q.n_points, 1)))
+    q.base_t = q.base_t + 1e-4 * rng.normal(size=q.base_t.shape) * (~q.base_fixed)[:, None]
+
+    def solve(prob, cold=False):
+        if cold:
+            chain_bundle.struct_cache_clear()
+        g = _gpu(prob.cams, disable_convergence=True)
+        prob.populate(g)
+        S = g.DebugSystem(1e-3)
+        if cold:
+            chain_bundle.struct_cache_clear()
+        return S, run_bundle(_gpu(prob.cams, disable_convergence=True), prob, iters)
+
+    chain_bundle.struct_cache_clear()
+    h0, m0 = chain_bundle.struct_cache_stats()
+    cold_q = solve(q)                                    # fills the cache with q's numbers
+    h1, m1 = chain_bundle.struct_cache_stats()
+    assert m1 == m0 + 1 and h1 == h0 + 1                 # (the second handle of solve() already hits)
+    warm_p = solve(p)                                    # cached structure (built from q), p's numbers
+    h2, m2 = chain_bundle.struct_cache_stats()
+    assert h2 == h1 + 2 and m2 == m1
+    cold_p = solve(p, cold=True)                         # the same two Prepare() calls, each on an empty cache
+    h3, m3 = chain_bundle.struct_cache_stats()
+    assert h3 == h2 and m3 == m2 + 2
+    for a, b in zip(cold_p[0], warm_p[0]):
+        assert np.array_equal(a, b)
+    a, b = cold_p[1], warm_p[1]
+    assert a["logs"] == b["logs"] and a["outliers"] == b["outliers"]
+    assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"]) and np.array_equal(a["X"], b["X"])
+    assert not np.array_equal(a["X"], cold_q[1]["X"])    # (the two problems do differ)
+
+
 @pytest.mark.parametrize("k,max_trials", [(4, 100), (2, 2)])
 def test_failed_factorisation_applies_the_stale_step_like_g2o(gpu_required, k, max_trials, monkeypatch):
     """When the linear solver fails, g2o's x keeps the last successful solve's content, update(x) applies it, the trial is rejected
