@@ -233,13 +233,6 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf
   bool bad = !(piv0 > 0.0);
   double inv = rsqrt(piv0);
   if (lane == 0) CP_STAMP(s, 9);
-#if defined(CP_EXP) && CP_EXP == 5
-  asm volatile(".p2align 6");
-#elif defined(CP_EXP) && CP_EXP == 6
-  asm volatile("s_nop 0");
-#elif defined(CP_EXP) && CP_EXP == 7
-  asm volatile(".p2align 6\n\ts_nop 0");
-#endif
   chol_panel_pivots(d, inv, bad, colbuf, std::make_integer_sequence<int, CH_NB>());
   if (lane == 0) CP_STAMP(s, 10);
   if (bad && lane == 0) atomicOr(fail, 2);
@@ -264,7 +257,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   int* err = a.err + q; int* fail = a.fail + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
   const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
-  const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of; const int* delta_of = a.delta_of;
+  const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of;
   const int epoch4 = a.epoch[q] << 2, want_band = epoch4 | 1, done_l = epoch4 | 2;
   const int code = 0x100;
   int* stp = ctl + 16;                       // the step table
@@ -309,17 +302,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       if (t == 0) CP_STAMP(s, 1);
       if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, fail, q, s);
       if (t == 0) CP_STAMP(s, 2);
-#if defined(CP_EXP) && CP_EXP == 2
-      __builtin_amdgcn_s_sleep(2);
-#endif
       cp_barrier();
-#if defined(CP_EXP) && CP_EXP == 1
-      __builtin_amdgcn_s_sleep(2);
-#elif defined(CP_EXP) && CP_EXP == 3
-      { unsigned long long tt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory"); }
-#elif defined(CP_EXP) && CP_EXP == 4
-      if (t == 0) a.err[8 + q] = s;
-#endif
       if (t == 0) CP_STAMP(s, 8);
       if (!ctl[1]) return;
       dcur ^= 1;

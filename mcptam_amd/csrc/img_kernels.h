@@ -1210,10 +1210,16 @@ __device__ inline void prm_barrier(PrmScratch* G, unsigned int& epoch, unsigned 
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(&G->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int want = (epoch + 1)*nwg;
-    unsigned long long spins = 0;
+    // bounded in wall-clock time (s_memrealtime, 100 MHz): a workgroup of this launch that is not resident yet -- the device is shared
+    // with the map maker's kernels -- arrives within microseconds to a fraction of a millisecond; after 50 ms the call gives up and is
+    // redone in one workgroup (img_api.hip).  (Round 4 counted 2^24 polls: seconds.)
+    unsigned int spins = 0; long long t0 = 0;
     while (prm_ld(&G->sync) < want) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1ull << 24) || prm_ld(&G->err)) { __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if ((++spins & 63) == 63) {
+        if (prm_ld(&G->err)) break;
+        if (!t0) t0 = wall_clock64(); else if (wall_clock64() - t0 > 5000000ll) { __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
     }
   }
   ++epoch;

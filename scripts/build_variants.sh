@@ -34,13 +34,6 @@ for v in "$@"; do
     cpprof2) build cpprof2 -DMCP_CP_PROF=2 & ;;
     cpprof3) build cpprof3 -DMCP_CP_PROF=3 & ;;
     cpprof4) build cpprof4 -DMCP_CP_PROF=4 & ;;
-    cpexp1) build cpexp1 -DCP_EXP=1 & ;;
-    cpexp2) build cpexp2 -DCP_EXP=2 & ;;
-    cpexp3) build cpexp3 -DCP_EXP=3 & ;;
-    cpexp4) build cpexp4 -DCP_EXP=4 & ;;
-    cpexp5) build cpexp5 -DCP_EXP=5 & ;;
-    cpexp6) build cpexp6 -DCP_EXP=6 & ;;
-    cpexp7) build cpexp7 -DCP_EXP=7 & ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done

@@ -7,6 +7,8 @@ from mcptam_amd import synth, chain_bundle
 
 def run(name, p, reps=3):
     for r in range(reps):
+        if os.environ.get("SETUP_COLD"):
+            chain_bundle.struct_cache_clear()          # every repetition on an empty structure cache (a topology the process has not seen)
         b = chain_bundle.ChainBundle(p.cams, True, True, False, disable_convergence=True)
         t0 = time.perf_counter(); p.populate(b); t1 = time.perf_counter()
         b.Prepare(); t2 = time.perf_counter()
