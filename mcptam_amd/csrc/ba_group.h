@@ -637,6 +637,8 @@ struct AsmPlan {
 #ifndef ASM_NT
 #define ASM_NT 1024      // one entry of the 32 x 32 tile per thread: every entry's walk over its staged contributions is a chain of memory round trips,
 #endif                   // and four times the threads have four times the walks in flight (256: 810-813, 512: 804-821, 1024: 822-825 it/s)
+// (Round 5 measured one thread per entry for ALL systems of a batch -- the pose-pose sum and the list walk shared, a quarter of the
+//  workgroups: 2.87 vs 2.34 ms of Schur + assembly per 20 iterations.  Fewer, longer walks hide less latency; dropped.)
 __global__ void __launch_bounds__(ASM_NT)
 k_assemble(AsmPlan A, int np, const double* __restrict__ stU, const double* __restrict__ stb,
            const double* __restrict__ stS, const double* __restrict__ str,

@@ -2406,6 +2406,13 @@ int mcp_ba::persist_fallback(double lam, bool& ok2, double ni) {
   static std::atomic<int> warned{0};
   if (!warned.exchange(1)) fprintf(stderr, "mcptam_hip: a hand-off of the one-launch Cholesky factorisation timed out; falling back to the per-step kernels\n");
   plan.use_persist = false;
+  // A real time-out (not the test hook's) is remembered per device: after the second one the plans of later handles do not take the
+  // one-launch path on this device any more -- a handle lives for one BundleAdjust call, and paying the deadline again in every call
+  // would be worse than the per-step kernels.  (With claimed work a time-out needs a device that stays saturated for 20 ms.)
+  if (plan.persist.test_fail_launch < 0) {
+    CpDevice& dv = cp_device(device);
+    if (++dv.real_fallbacks >= 2 && !dv.disabled) { dv.disabled = true; fprintf(stderr, "mcptam_hip: device %d: one-launch Cholesky factorisation switched off for this process after %d hand-off time-outs\n", device, dv.real_fallbacks); }
+  }
   spec_ok = false;
   if (cancel_spec_trials()) return -1;
   if (join_spec()) return -1;
