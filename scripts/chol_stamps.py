@@ -1,8 +1,8 @@
 """Stamps of the one-launch factorisation at the metric map's shape (n = 1194, banded + bordered plan): needs a library built with
 -DMCP_CP_PROF (scripts/build_variants.sh cpprof4 / cpabl1), selected through MCP_HIP_LIB."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from mcptam_amd import chain_bundle as cb
 from gpu_chol2 import spd
