@@ -124,7 +124,7 @@ MCP_ATAN_HD dd dd_div(dd a, dd b) { MCP_NOCONTRACT
 // the final additions lose < 2^-104 V.  |r| <= V, and for |x| > 1 the result is >= pi/4 >= what it is subtracted from.
 #define MCP_C9 0x1.c71c71c71c71cp-4
 #define MCP_C11 0x1.745d1745d1746p-4
-MCP_ATAN_HD bool atan_fast(double ax, bool inv, double* out) { MCP_NOCONTRACT
+MCP_ATAN_HD bool atan_fast(double ax, bool inv, double* out, const double* tab_hi = kAtanHi, const double* tab_lo = kAtanLo) { MCP_NOCONTRACT
   // c = k/64 near u = ax (or 1/ax): any k within a hair of the nearest one keeps |r| <= 1/128 + 2^-22
   double rh, rl; int k;
   if (inv) {
@@ -163,9 +163,9 @@ MCP_ATAN_HD bool atan_fast(double ax, bool inv, double* out) { MCP_NOCONTRACT
   const double wh = rh*sh, wl = __builtin_fma(rh, sh, -wh) + (rh*sl + rl*sh);               // r^3
   const double th = wh*MCP_C3_HI, tl = __builtin_fma(wh, MCP_C3_HI, -th) + (wh*MCP_C3_LO + wl*MCP_C3_HI);      // r^3/3
   const double q = (wh*sh)*(MCP_C5_HI + sh*(-MCP_C7_HI + sh*(MCP_C9 - sh*MCP_C11)));       // r^5/5 - r^7/7 + r^9/9 - r^11/11
-  const dd s1 = two_sum(kAtanHi[k], rh);
+  const dd s1 = two_sum(tab_hi[k], rh);
   const dd s2 = two_sum(s1.hi, -th);
-  const double low = s2.lo + (s1.lo + ((kAtanLo[k] + rl) + (q - tl)));
+  const double low = s2.lo + (s1.lo + ((tab_lo[k] + rl) + (q - tl)));
   dd res = fast_two_sum(s2.hi, low);
   if (inv) {
     const dd p1 = two_sum(MCP_PIO2_HI, -res.hi);
@@ -177,7 +177,9 @@ MCP_ATAN_HD bool atan_fast(double ax, bool inv, double* out) { MCP_NOCONTRACT
   return a == b;
 }
 
-MCP_ATAN_HD double atan_cr(double x) { MCP_NOCONTRACT
+// (tab_hi / tab_lo: the 65-entry table; a kernel that keeps a copy in LDS passes it, so that the two look-ups of an arctangent are LDS
+//  reads and do not queue behind the kernel's global stores in the vector-memory counter)
+MCP_ATAN_HD double atan_cr(double x, const double* tab_hi = kAtanHi, const double* tab_lo = kAtanLo) { MCP_NOCONTRACT
   if (x != x) return x;
   const double ax = x < 0 ? -x : x;
   if (ax == 0.0) return x;
@@ -188,7 +190,7 @@ MCP_ATAN_HD double atan_cr(double x) { MCP_NOCONTRACT
     return x < 0 ? -r : r;
   }
 #if !defined(MCP_ATAN_NO_FAST)
-  { double fast; if (atan_fast(ax, inv, &fast)) return x < 0 ? -fast : fast; }
+  { double fast; if (atan_fast(ax, inv, &fast, tab_hi, tab_lo)) return x < 0 ? -fast : fast; }
 #endif
   if (inv) { dd one; one.hi = 1.0; one.lo = 0.0; dd t; t.hi = ax; t.lo = 0.0; u = dd_div(one, t); }
   else { u.hi = ax; u.lo = 0.0; }
@@ -216,7 +218,7 @@ MCP_ATAN_HD double atan_cr(double x) { MCP_NOCONTRACT
   h = dd_mul(s, h);
   h = dd_add_d(h, tail);
   dd a = dd_add(r, dd_mul(r, h));
-  dd tk; tk.hi = kAtanHi[k]; tk.lo = kAtanLo[k];
+  dd tk; tk.hi = tab_hi[k]; tk.lo = tab_lo[k];
   a = dd_add(tk, a);
   if (inv) { dd p; p.hi = MCP_PIO2_HI; p.lo = MCP_PIO2_LO; a = dd_add(p, dd_neg(a)); }
   const double res = a.hi + a.lo;

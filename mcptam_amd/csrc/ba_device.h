@@ -129,12 +129,13 @@ struct Projection { double u, v; double D[4]; int invalid; };
 
 // Project + GetProjectionDerivs fused (the reference calls them back to back, ChainBundle.cc:390-392)
 template <bool WITH_DERIVS>
-__host__ __device__ inline void cam_project(const mcp_camera& cam, const double* xc, Projection& P) {
+__host__ __device__ inline void cam_project(const mcp_camera& cam, const double* xc, Projection& P,
+                                            const double* atan_hi = mcp_atan::kAtanHi, const double* atan_lo = mcp_atan::kAtanLo /* the arctangent's table, or a copy of it in LDS */) {
   const double n = sqrt(xc[0]*xc[0] + xc[1]*xc[1]);
   double theta, rho, cphi, sphi;
   if (n == 0.0) { theta = 1.57079632679489661923; rho = 0.0; cphi = 0.0; sphi = 0.0; }
   else {
-    theta = mcp_atan::atan_cr(xc[2]/n);      // correctly rounded: the one platform-independent value (atan_cr.h)
+    theta = mcp_atan::atan_cr(xc[2]/n, atan_hi, atan_lo);      // correctly rounded: the one platform-independent value (atan_cr.h)
     const double ts = (theta - cam.theta_mean)/cam.theta_std;
     if (cam.n_inv > 0) rho = poly_low_first(cam.inv_coeffs, cam.n_inv, ts);
     else {

@@ -53,16 +53,17 @@ __device__ inline void flush_group_blocks(const double* Sl, const double* bl, in
 // added to, the upper entries stay zero): the tile is the staging layout, so the flush is a straight copy, the LDS a group
 // needs is what its blocks need (22 blocks = 6 KB on average at the metric size instead of the 37 KB of the packed
 // 96 x 96 triangle), and more groups share a compute unit.  pslot[la*16 + lb] (la >= lb) = block slot of the local pair.
+// (sdst / srd: the group's blk_dst and rhs_dst entries, fetched into LDS at the head of the kernel.  Read from global memory here, every
+//  pass of the loop was a look-up, a wait and a store: 70 k of a group's 305 k cycles at the metric size.)
 template <int NT>
-__device__ inline void flush_compact_blocks(const double* Sc, const double* bl, int grp, const DevProblem& P,
+__device__ inline void flush_compact_blocks(const double* Sc, const double* bl, int nb, const int* sdst, const int* srd,
                                             double* __restrict__ st_blocks, double* __restrict__ st_rhs) {
-  const int b0 = P.g_blk0[grp], nb = P.g_blk0[grp + 1] - b0;
   for (int e = threadIdx.x; e < nb*36; e += NT) {
     const int slot = e/36, w = e - 36*slot;
-    st_blocks[(size_t)P.blk_dst[b0 + slot]*36 + w] = Sc[e];
+    st_blocks[(size_t)sdst[slot]*36 + w] = Sc[e];
   }
   for (int i = threadIdx.x; i < GRP_DOF; i += NT) {
-    const int d = P.rhs_dst[grp*GRP_LMAX + i/6];
+    const int d = srd[i/6];
     if (d >= 0) st_rhs[(size_t)d*6 + i%6] = bl[i];
   }
 }
@@ -106,6 +107,9 @@ __device__ unsigned long long g_lin_prof[8*8];
 #else
 #define LIN_STAMP(i) do {} while (0)
 #endif
+#ifndef LIN_LDS_CAMS
+#define LIN_LDS_CAMS 8      // cameras kept in LDS by the linearisation kernels (3.4 KB); a rig with more reads the rest from global memory
+#endif
 #ifndef LIN_WAVES
 #define LIN_WAVES 0   // > 0: wavefronts per SIMD the register allocation is held to
 #endif
@@ -115,7 +119,35 @@ __device__ unsigned long long g_lin_prof[8*8];
 // falls from 8 dependent measurements to 2.  What a lane kept in registers per point (V, g, the source pose's blocks) is summed over
 // the point's lanes at the end (butterfly inside the quad: same value on every lane, fixed order); W blocks that several
 // measurements of a point contribute to are accumulated in LDS (wl_off = offset of that area in doubles) and go out once.
-template <int LPP>
+// make_slot (ba_kernels.h) with the chain transforms already in registers: F = first[chain link], R2 = second[observer chain link]
+struct SlotPre { Se3 F; double R2[9]; };
+__device__ inline void slot_from_pre(int side, const SlotPre& sp, const double* A /*2x3*/, const double* xw, const double* Robs_last, SlotGeom& s) {
+  se3_apply(sp.F, xw, s.base);
+  if (side == 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.B[3*r+c] = A[3*r]*sp.R2[c] + A[3*r+1]*sp.R2[3+c] + A[3*r+2]*sp.R2[6+c];
+    s.sign = 1.0;
+  } else {
+    double Rrel[9];
+    mat3_mul_t(Robs_last, sp.F.R, Rrel);          // R(T_obs * T_src_i^-1)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.B[3*r+c] = A[3*r]*Rrel[c] + A[3*r+1]*Rrel[3+c] + A[3*r+2]*Rrel[6+c];
+    s.sign = -1.0;
+  }
+}
+// what the measurement loop needs of a measurement that can be fetched by its index alone (one round ahead)
+struct MeasHead { int oc, mask, cam, last, s0, s1; double u, v, om; };      // (raw loads only: nothing here may be looked at before the next round)
+__device__ inline void load_head(const DevProblem& P, int m, MeasHead& h) {
+  h.oc = P.m_chain[m]; h.mask = P.m_mask[m]; h.cam = P.m_cam[m]; h.last = P.m_last[m];
+  h.s0 = P.slot_start[m]; h.s1 = P.slot_start[m + 1];
+  h.u = P.m_u[m]; h.v = P.m_v[m]; h.om = P.m_omega[m];
+}
+
+template <int LPP, bool PIPE = false>
 __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const double* __restrict__ pt_x, const double* __restrict__ first,
                     const double* __restrict__ second, const double* __restrict__ sigma,
                     double* __restrict__ stU /* staged pose-pose blocks */, double* __restrict__ stb /* staged local rhs */,
@@ -125,13 +157,23 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
   extern __shared__ double Sc[];                 // the group's blocks, 36 doubles each (launch: 288 B x the largest block count of any group)
   __shared__ double bl[GRP_DOF];
   __shared__ unsigned char pslot[GRP_LMAX*16];
+  __shared__ int sdst[GRP_LMAX*(GRP_LMAX + 1)/2], srd[GRP_LMAX];
+  __shared__ double satan[130];                  // the arctangent's table (atan_cr.h), likewise
+  __shared__ mcp_camera scam[LIN_LDS_CAMS];      // the cameras: read per measurement by cam_project -- from LDS they do not queue behind the W stores in the vector-memory counter
   const int grp = blockIdx.x, lane = threadIdx.x;
   LIN_STAMP(0);
+  const int nb_grp = P.g_blk0[grp + 1] - P.g_blk0[grp];
   {
-    const int b0 = P.g_blk0[grp], nb = P.g_blk0[grp + 1] - b0;
+    const int b0 = P.g_blk0[grp], nb = nb_grp;
     for (int i = lane; i < nb*36; i += 64) Sc[i] = 0.0;
     for (int i = lane; i < GRP_DOF; i += 64) bl[i] = 0.0;
-    for (int i = lane; i < nb; i += 64) pslot[P.blk_pair[b0 + i]] = (unsigned char)i;      // (pairs outside the list are never looked up)
+    for (int i = lane; i < nb; i += 64) { pslot[P.blk_pair[b0 + i]] = (unsigned char)i; sdst[i] = P.blk_dst[b0 + i]; }      // (pairs outside the list are never looked up)
+    if (lane < GRP_LMAX) srd[lane] = P.rhs_dst[grp*GRP_LMAX + lane];
+    const int ncl = P.ncam < LIN_LDS_CAMS ? P.ncam : LIN_LDS_CAMS;
+    const double* src = reinterpret_cast<const double*>(P.cams); double* dst = reinterpret_cast<double*>(scam);
+    static_assert(sizeof(mcp_camera) % sizeof(double) == 0, "camera copied as doubles");
+    for (int i = lane; i < ncl*(int)(sizeof(mcp_camera)/sizeof(double)); i += 64) dst[i] = src[i];
+    for (int i = lane; i < 65; i += 64) { satan[i] = mcp_atan::kAtanHi[i]; satan[65 + i] = mcp_atan::kAtanLo[i]; }
   }
   double* const Wl = Sc + wl_off;                // LPP > 1: the group's W blocks, 18 doubles per incidence
   const int inc0 = (LPP > 1) ? P.sp_i[P.g_sp0[grp]] : 0;
@@ -173,6 +215,178 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
     double Vp[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
     const bool fixed_neg = P.pt_fixed[pt] && P.robust;
     LIN_STAMP(2);
+    if constexpr (PIPE) {
+    // ---- round 5: the measurement loop with every load of a round issued at its head.  Vector loads and stores share one in-order
+    // counter on gfx950: a load issued behind the 144-byte W block of the measurement before is only known to have arrived when that
+    // store has been acknowledged, and a measurement is a chain of index hops (chain -> link -> transform; slot range -> local pose /
+    // incidence): 23 k cycles per measurement, 6 k of them arithmetic.  Here (a) what can be fetched by the measurement index alone is
+    // fetched one round ahead (MeasHead; m_last = the observer chain's last link, one hop less), (b) the transforms and slot records of
+    // this round are all requested at its head, (c) the W block of the round before leaves AFTER them (deferred in registers; an
+    // accumulating block as a no-return atomic add: a lane's blocks are its own, so it is the same single addition), (d) the
+    // arithmetic follows.  Same operations on the same numbers as the loop below: the same bits.
+    static_assert(LPP == 1, "the quad form keeps W in LDS: nothing to defer");
+    const int mend = P.sp_m[sp + 1];
+    int m = P.sp_m[sp];
+    MeasHead nxt;
+    if (m < mend) load_head(P, m, nxt);
+    double Wd[18]; double* Wd_ptr = nullptr; bool Wd_acc = false;
+    for (; m < mend; ++m) {
+      const MeasHead cur = nxt;
+      if (m + 1 < mend) load_head(P, m + 1, nxt);
+      const int oc = cur.oc, mask = cur.mask;
+      // (b) this round's loads
+      Se3 To;
+      load_se3(first + 12*(size_t)cur.last, To);
+      const int bitA = mask ? __builtin_ctz(mask) : 0, mask2 = mask & (mask - 1), bitB = mask2 ? __builtin_ctz(mask2) : 0;
+      SlotPre preA, preB;
+      {
+        const int sideA = bitA >> MAXC_LOG, sideB = bitB >> MAXC_LOG;
+        const size_t ia_ = (size_t)((sideA ? sc : oc)*MAXC + (bitA & (MAXC - 1))), ib_ = (size_t)((sideB ? sc : oc)*MAXC + (bitB & (MAXC - 1)));
+        load_se3(first + 12*ia_, preA.F); load_se3(first + 12*ib_, preB.F);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { preA.R2[k] = second[9*ia_ + k]; preB.R2[k] = second[9*ib_ + k]; }
+      }
+#if defined(LIN_ABL) && LIN_ABL == 2
+      const int s0 = cur.s0, ns = 0;                                      // timing ablation only: no pose slots
+#else
+      const int s0 = cur.s0, ns = cur.s1 - cur.s0;
+#endif
+      const int sA = ns > 0 ? s0 : 0, sB = ns > 1 ? s0 + 1 : sA;          // (always a valid index: fetched whether or not the slot exists)
+      const int lpA = P.slot_lp[sA], lpB = P.slot_lp[sB], incA = P.slot_inc[sA], incB = P.slot_inc[sB];
+      const int firstA = P.slot_first[sA], firstB = P.slot_first[sB];
+      // (c) the deferred W block of the round before
+      if (Wd_ptr) {
+        if (Wd_acc) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) unsafeAtomicAdd(Wd_ptr + k, Wd[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Wd_ptr[k] = Wd[k];
+        }
+        Wd_ptr = nullptr;
+      }
+      if (mask == 0 && lpt < 0) continue;
+      // (d) the arithmetic of the loop below
+      double xc[3];
+      se3_apply(To, xw, xc);
+      Projection pr;
+      { const int ci = cur.cam; if (ci < LIN_LDS_CAMS) cam_project<true>(scam[ci], xc, pr, satan, satan + 65); else cam_project<true>(P.cams[ci], xc, pr, satan, satan + 65); }
+      const double e0 = cur.u - pr.u, e1 = cur.v - pr.v;
+      const double omega = cur.om;
+      double c2 = omega*(e0*e0 + e1*e1);
+      if (fixed_neg) c2 = -c2;
+      double w = omega;
+      if (P.robust) { double r0, r1; robustify(c2, sigma[1], sigma[2], r0, r1); w *= r1; }
+      double dT[3], dP[3];
+      cam_sphere_deriv(xc, dT, dP);
+      double A[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        A[c]     = -(pr.D[0]*dT[c] + pr.D[1]*dP[c]);
+        A[3 + c] = -(pr.D[2]*dT[c] + pr.D[3]*dP[c]);
+      }
+      double Jp[6] = {0, 0, 0, 0, 0, 0};
+      if (lpt >= 0) {
+        double Rcs[9], AR[6];
+        mat3_mul_t(To.R, Ts.R, Rcs);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) AR[3*r+c] = A[3*r]*Rcs[c] + A[3*r+1]*Rcs[3+c] + A[3*r+2]*Rcs[6+c];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          Jp[3*r]   = AR[3*r]*c0[0]  + AR[3*r+1]*c0[1]  + AR[3*r+2]*c0[2];
+          Jp[3*r+1] = AR[3*r]*c1[0]  + AR[3*r+1]*c1[1]  + AR[3*r+2]*c1[2];
+          Jp[3*r+2] = AR[3*r]*c2v[0] + AR[3*r+1]*c2v[1] + AR[3*r+2]*c2v[2];
+        }
+        Vp[0] += w*(Jp[0]*Jp[0] + Jp[3]*Jp[3]); Vp[1] += w*(Jp[0]*Jp[1] + Jp[3]*Jp[4]); Vp[2] += w*(Jp[0]*Jp[2] + Jp[3]*Jp[5]);
+        Vp[3] += w*(Jp[1]*Jp[1] + Jp[4]*Jp[4]); Vp[4] += w*(Jp[1]*Jp[2] + Jp[4]*Jp[5]); Vp[5] += w*(Jp[2]*Jp[2] + Jp[5]*Jp[5]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gp[c] += -w*(Jp[c]*e0 + Jp[3+c]*e1);
+      }
+      int ia = 0;
+      for (int bit_a = 0; bit_a < 2*MAXC && ia < ns; ++bit_a) {
+        if (!(mask & (1 << bit_a))) continue;
+        SlotGeom sa; double Ja[12];
+        if (ia == 0) slot_from_pre(bit_a >> MAXC_LOG, preA, A, xw, To.R, sa);
+        else if (ia == 1) slot_from_pre(bit_a >> MAXC_LOG, preB, A, xw, To.R, sa);      // (keeping the Jacobian the cross term below computed for this slot: measured, no gain)
+        else make_slot(bit_a >> MAXC_LOG, bit_a & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sa);
+        slot_jacobian(sa, Ja);
+        const int la = ia == 0 ? lpA : (ia == 1 ? lpB : (int)P.slot_lp[s0 + ia]);
+        if (bit_a == MAXC) {            // first source link: private accumulators, reduced across the wave below
+          ls = la;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) bs[r] += -w*(Ja[r]*e0 + Ja[6+r]*e1);
+          int q = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) { Uss[q] += w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]); ++q; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) lds_add(bl + 6*la + r, -w*(Ja[r]*e0 + Ja[6+r]*e1));
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) lds_add(Sc + 36*(int)pslot[17*la] + 6*r + c, w*(Ja[r]*Ja[c] + Ja[6+r]*Ja[6+c]));
+        }
+#if defined(LIN_ABL) && LIN_ABL == 3
+        if (false) {                 // timing ablation only: no W blocks
+#else
+        if (lpt >= 0) {
+#endif
+          const int inc = ia == 0 ? incA : (ia == 1 ? incB : P.slot_inc[s0 + ia]);
+          if (bit_a == MAXC) {          // the source pose's block collects one term per measurement: keep it in registers
+            wss_inc = inc;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) Wss[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+          } else {
+            const int isfirst = ia == 0 ? firstA : (ia == 1 ? firstB : (int)P.slot_first[s0 + ia]);
+            double* Wb = W + 18*(size_t)inc;
+            if (!Wd_ptr) {              // deferred: leaves at the head of the next round (or behind the loop)
+              Wd_ptr = Wb; Wd_acc = !isfirst;
+#pragma unroll
+              for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Wd[3*r + c] = w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+            } else if (isfirst) {       // (a second non-source slot of one measurement -- long chains: written at once, as the loop below does)
+#pragma unroll
+              for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Wb[3*r + c] = w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+            } else {                    // (no load of W anywhere in this form of the kernel: an accumulating block is always an atomic add)
+#pragma unroll
+              for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) unsafeAtomicAdd(Wb + 3*r + c, w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]));
+            }
+          }
+        }
+        int ib = ia + 1;
+        for (int bit_b = bit_a + 1; bit_b < 2*MAXC && ib < ns; ++bit_b) {
+          if (!(mask & (1 << bit_b))) continue;
+          SlotGeom sb; double Jb[12];
+          if (ib == 1) slot_from_pre(bit_b >> MAXC_LOG, preB, A, xw, To.R, sb);
+          else make_slot(bit_b >> MAXC_LOG, bit_b & (MAXC - 1), A, xw, first, second, oc, sc, To.R, sb);
+          slot_jacobian(sb, Jb);
+          tile_add_cross(Sc, pslot, la, ib == 1 ? lpB : (int)P.slot_lp[s0 + ib], Ja, Jb, w);
+          ++ib;
+        }
+        ++ia;
+      }
+    }
+    if (Wd_ptr) {
+      if (Wd_acc) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) unsafeAtomicAdd(Wd_ptr + k, Wd[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Wd_ptr[k] = Wd[k];
+      }
+    }
+    } else
     for (int m = P.sp_m[sp] + sub; m < P.sp_m[sp + 1]; m += LPP) {
       const int oc = P.m_chain[m], olen = P.chain_len[oc];
       const int mask = P.m_mask[m];
@@ -182,7 +396,7 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
       double xc[3];
       se3_apply(To, xw, xc);
       Projection pr;
-      cam_project<true>(P.cams[P.m_cam[m]], xc, pr);
+      { const int ci = P.m_cam[m]; if (ci < LIN_LDS_CAMS) cam_project<true>(scam[ci], xc, pr, satan, satan + 65); else cam_project<true>(P.cams[ci], xc, pr, satan, satan + 65); }
       const double e0 = P.m_u[m] - pr.u, e1 = P.m_v[m] - pr.v;
       const double omega = P.m_omega[m];
       double c2 = omega*(e0*e0 + e1*e1);
@@ -329,8 +543,13 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
       if (wss_inc >= 0) {
         double* Wb = W + 18*(size_t)wss_inc;
         if (P.inc_mixed[wss_inc]) {
+          if constexpr (PIPE) {
 #pragma unroll
-          for (int k = 0; k < 18; ++k) Wb[k] += Wss[k];
+            for (int k = 0; k < 18; ++k) unsafeAtomicAdd(Wb + k, Wss[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) Wb[k] += Wss[k];
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < 18; ++k) Wb[k] = Wss[k];
@@ -372,7 +591,7 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
   __syncthreads();
   LIN_STAMP(5);
   // flush the local tile to the group's staging slots (k_assemble sums them in group order)
-  flush_compact_blocks<64>(Sc, bl, grp, P, stU, stb);
+  flush_compact_blocks<64>(Sc, bl, nb_grp, sdst, srd, stU, stb);
   LIN_STAMP(6);
 }
 #if LIN_WAVES > 0      // (the bound is a promise of at most 128 threads -- the launch has 64; with a one-wavefront bound the compiler ignores the occupancy request)
@@ -384,6 +603,13 @@ k_linearize_group(DevProblem P, const double* __restrict__ pt_x, const double* _
                   const double* __restrict__ second, const double* __restrict__ sigma,
                   double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int* __restrict__ fail_zero) {
   linearize_group_body<1>(P, pt_x, first, second, sigma, stU, stb, V, g, W, 0, fail_zero);
+}
+// the same with the measurement loop software-pipelined (loads of a round at its head, the W block of the round before behind them)
+__global__ void __launch_bounds__(64)
+k_linearize_pipe(DevProblem P, const double* __restrict__ pt_x, const double* __restrict__ first,
+                 const double* __restrict__ second, const double* __restrict__ sigma,
+                 double* __restrict__ stU, double* __restrict__ stb, double* __restrict__ V, double* __restrict__ g, double* __restrict__ W, int* __restrict__ fail_zero) {
+  linearize_group_body<1, true>(P, pt_x, first, second, sigma, stU, stb, V, g, W, 0, fail_zero);
 }
 constexpr int LIN_QUAD_PTS = 16;           // points per group when the quad form runs (64 lanes / 4)
 __global__ void __launch_bounds__(64)

@@ -18,7 +18,7 @@ namespace mcp {
 // device-resident problem description (SoA, sorted by point)
 struct DevProblem {
   // cameras
-  const mcp_camera* cams;
+  const mcp_camera* cams; int ncam;
   // chains
   int nchain;
   const int* chain_len;       // [nchain]
@@ -64,6 +64,7 @@ struct DevProblem {
   const unsigned char* blk_pair;  // [nblk] local pose pair of the block, la << 4 | lb (la >= lb)
   const int* blk_dst;             // [nblk] where the block is staged: position in the destination-ordered staging array
   const int* rhs_dst;             // [ngroup*GRP_LMAX] staged rhs row of (group, local pose), or -1
+  const int* m_last;              // [nmeas] m_chain[m]*MAXC + chain_len - 1: the observer chain's last link (its transform from world) without the hop over chain_len
   const int* sp_unk;              // [nsp] free-point index of the sorted point (-1: fixed, or a point of the generic path) = pt_unk[sp_pt[sp]]
 };
 constexpr int MAXC = MCP_MAX_CHAIN;             // links per pose chain; per-chain arrays are strided by it

@@ -446,6 +446,8 @@ struct mcp_ba {
   void note_launch(const char* k) { const hipError_t e = hipGetLastError(); if (e != hipSuccess && e != hipErrorNotReady && launch_err.empty()) launch_err = std::string(k) + ": " + hipGetErrorString(e); }
   std::shared_ptr<StructEntry> pending_entry;
   StructKey cache_key; bool cache_insert = false;      // a cold Prepare() of a cacheable map leaves its results in the structure cache
+  DevBuf<int> d_m_last;                         // observer chain's last link per measurement (k_linearize_pipe)
+  bool lin_pipe = env_on("MCP_BA_LIN_PIPE", true);
   DevBuf<int> d_g_order, d_sp_unk;              // launch order of the groups in k_schur4 (heaviest first; only when they outnumber the slots), free-point index per sorted point
   bool sch4_order = false;
   bool asm_long = false;          // the pose pairs' lists of staged blocks are long (a few free poses staged by every group): k_assemble_long
@@ -1672,7 +1674,9 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       for (int gi = 0; gi < ngroup; ++gi) g_order[gi] = gi;
       std::stable_sort(g_order.begin(), g_order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     }
-    add(d_sp_unk, sp_unk, false); add(d_g_order, g_order, false);
+    std::vector<int> m_last(hit ? 0 : nmeas);
+    if (!hit) for (int j = 0; j < nmeas; ++j) { const int oc = H.m_chain[j]; m_last[j] = oc*MAXC + chains[oc].len - 1; }
+    add(d_sp_unk, sp_unk, false); add(d_g_order, g_order, false); add(d_m_last, m_last, false);
     if (d_struct.alloc(total)) return -1;
     char* const base = d_struct.p;
     auto fix = [&](auto& dbuf) { dbuf.p = reinterpret_cast<decltype(dbuf.p)>(base + reinterpret_cast<size_t>(dbuf.p)); };
@@ -1681,7 +1685,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     fix(d_slot_unk); fix(d_slot_inc); fix(d_l_i0); fix(d_l_i1); fix(d_inc_unk); fix(d_fl_point); fix(d_sp_pt); fix(d_sp_m);
     fix(d_sp_i); fix(d_sp_big); fix(d_m_sp); fix(d_l_sp); fix(d_g_sp0); fix(d_g_pose); fix(d_slot_lp); fix(d_slot_first);
     fix(d_inc_lp); fix(d_inc_mixed); fix(d_g_blk0); fix(d_blk_pair); fix(d_asm_tiles); fix(d_pair_id); fix(d_pr_start); fix(d_blk_dst);
-    fix(d_po_start); fix(d_rhs_dst); fix(d_sp_unk); fix(d_g_order);
+    fix(d_po_start); fix(d_rhs_dst); fix(d_sp_unk); fix(d_g_order); fix(d_m_last);
     if (hit) {
       // the cached clone of the block, then this handle's own numbers over it: the cameras and the measurement values (u, v, the
       // weight), gathered into sorted order through the permutation the structure build left
@@ -1788,7 +1792,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
   HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st)); sig_par = 0;
 
-  P.cams = d_cams.p; P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
+  P.cams = d_cams.p; P.ncam = (int)cams.size(); P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
   P.npose = npose; P.pose_unk = d_pose_unk.p; P.npoint = npoint; P.pt_chain = d_pt_chain.p; P.pt_unk = d_pt_unk.p;
   P.pt_fixed = d_pt_fixed.p; P.nmeas = nmeas; P.m_pt = d_m_pt.p; P.m_chain = d_m_chain.p; P.m_cam = d_m_cam.p;
   P.m_mask = d_m_mask.p; P.m_u = d_m_u.p; P.m_v = d_m_v.p; P.m_omega = d_m_omega.p; P.slot_start = d_slot_start.p;
@@ -1797,7 +1801,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   P.nsp = nsp; P.ngroup = ngroup; P.sp_pt = d_sp_pt.p; P.sp_m = d_sp_m.p; P.sp_i = d_sp_i.p; P.sp_big = d_sp_big.p;
   P.m_sp = d_m_sp.p; P.l_sp = d_l_sp.p; P.g_sp0 = d_g_sp0.p; P.g_pose = d_g_pose.p; P.slot_lp = d_slot_lp.p;
   P.slot_first = d_slot_first.p; P.inc_lp = d_inc_lp.p; P.inc_mixed = d_inc_mixed.p;
-  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p; P.blk_dst = d_blk_dst.p; P.rhs_dst = d_rhs_dst.p; P.sp_unk = d_sp_unk.p;
+  P.g_blk0 = d_g_blk0.p; P.blk_pair = d_blk_pair.p; P.blk_dst = d_blk_dst.p; P.rhs_dst = d_rhs_dst.p; P.sp_unk = d_sp_unk.p; P.m_last = d_m_last.p;
   A.nfp = nfp; A.ntiles = (int)plan.all_tiles.size(); A.tiles = d_asm_tiles.p; A.pair_id = d_pair_id.p;
   A.pr_start = d_pr_start.p; A.po_start = d_po_start.p;
   // the staging arrays of a group that stages nothing for a slot are never read; slots are always fully written
@@ -2079,9 +2083,12 @@ int mcp_ba::linearize() {
   //  one-lane-per-point kernel, which handles groups of any size up to 64 points)
   const size_t quad_lds = ((size_t)std::max(grp_blk_max, 1)*36 + (size_t)std::max(grp_inc_max, 1)*18)*sizeof(double);
   static const bool quad_on = [] { const char* e = getenv("MCP_BA_LIN_QUAD"); return !(e && atoi(e) == 0); }();
-  if (ngroup && grp_pts <= LIN_QUAD_PTS && quad_on && quad_lds <= 60*1024)
+  if (ngroup && grp_pts <= LIN_QUAD_PTS && quad_on && quad_lds <= 58*1024)      // (+ 5 KB of static LDS: tables and cameras)
     hipLaunchKernelGGL(k_linearize_quad, dim3(ngroup), dim3(64), quad_lds, st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, std::max(grp_blk_max, 1)*36, d_fail.p);
+  else if (ngroup && lin_pipe && !getenv("MCP_BA_TEST_REFUSE_LAUNCH"))
+    hipLaunchKernelGGL(k_linearize_pipe, dim3(ngroup), dim3(64), (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
+                       d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, d_fail.p);
   else if (ngroup)
     hipLaunchKernelGGL(k_linearize_group, dim3(ngroup), dim3(64), getenv("MCP_BA_TEST_REFUSE_LAUNCH") ? ((size_t)1 << 20) /* test hook: more LDS than a compute unit has */ : (size_t)std::max(grp_blk_max, 1)*36*sizeof(double), st, P,
                        d_pt[cur].p, d_first[cur].p, d_second[cur].p, sig(), d_stU.p, d_stb.p, d_V.p, d_g.p, d_W.p, d_fail.p);

@@ -27,6 +27,9 @@ for v in "$@"; do
     s4d2p) build s4d2p -DS4_DEPHASE=2 -DMCP_SCH_PROF & ;;
     cpabl1) build cpabl1 -DMCP_CP_PROF=4 -DCH_ABL=1 & ;;    # persistent factorisation, wave 0 stamps, panel without bulk updates (timing only)
     s4w1) build s4w1 -DS4_WAVES=1 & ;;                     # k_schur4 with 512 registers: one workgroup per compute unit
+    linabl1p) build linabl1p -DMCP_LIN_PROF -DLIN_ABL=1 & ;;   # timing ablations of the linearisation with stamps (results wrong): no LDS adds
+    linabl2p) build linabl2p -DMCP_LIN_PROF -DLIN_ABL=2 & ;;   # no pose slots
+    linabl3p) build linabl3p -DMCP_LIN_PROF -DLIN_ABL=3 & ;;   # no W blocks
     proflin) build proflin -DMCP_LIN_PROF & ;;             # phase stamps of k_linearize_group
     proflin2) build proflin2 -DMCP_LIN_PROF -DLIN_WAVES=2 & ;;                    # k_linearize_group held to 256 registers (two wavefronts per SIMD)                      # second-order rsqrt correction in the panel chain
     hsprof) build hsprof -DMCP_HS_PROF=1 & ;;                # phase stamps of k_head_small (ba_small.h)

@@ -928,11 +928,12 @@ def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeyp
 
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
                                  dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
-                                 dict(MCP_BA_STREAM_POOL="0")])
+                                 dict(MCP_BA_STREAM_POOL="0"), dict(MCP_BA_SCHUR4_ORDER="0")])
 def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
     """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox and graph replay are
     scheduling: the same kernels see the same inputs whichever of them is on, so iteration logs, poses and points are identical
-    to the default configuration's, bit for bit (the knobs are read when the handle is created)."""
+    to the default configuration's, bit for bit (the knobs are read when the handle is created).  Likewise the launch order of the
+    Schur groups."""
     from mcptam_amd import synth
     p = synth.make_config("metric")
     base = run_bundle(_gpu(p.cams, disable_convergence=True), p, 7)
@@ -944,6 +945,24 @@ def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypa
     assert base["logs"] == alt["logs"]
     assert np.array_equal(base["R"], alt["R"]) and np.array_equal(base["t"], alt["t"]) and np.array_equal(base["X"], alt["X"])
     assert base["outliers"] == alt["outliers"] and base["sigma_sq"] == alt["sigma_sq"] and base["lam"] == alt["lam"]
+
+
+@pytest.mark.parametrize("cfg,iters", [("c2", 6), ("metric", 6)])
+def test_pipelined_linearisation_agrees_with_the_plain_loop(gpu_required, cfg, iters, monkeypatch):
+    """k_linearize_pipe issues every load of a measurement at the head of its round and lets the W block of the round before leave
+    behind them (an accumulating block as a no-return atomic add); k_linearize_group is the plain loop.  The same operations on the
+    same numbers -- but two compilations contract multiply-adds differently, so the two agree to rounding, not bit for bit: same
+    accept / reject sequence, state to 1e-9 (each of them is bit-reproducible on its own)."""
+    from mcptam_amd import synth
+    monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")         # (the large-map layout at both sizes: the quad form has no global W stores in its loop)
+    p = synth.make_config(cfg)
+    pipe = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    pipe2 = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    monkeypatch.setenv("MCP_BA_LIN_PIPE", "0")
+    plain = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    assert pipe["logs"] == pipe2["logs"] and np.array_equal(pipe["X"], pipe2["X"])
+    assert [(l["trials"], l["accepted"]) for l in pipe["logs"]] == [(l["trials"], l["accepted"]) for l in plain["logs"]]
+    assert rel_err_elem(pipe["R"], plain["R"]) < 1e-9 and rel_err_elem(pipe["t"], plain["t"]) < 1e-9 and rel_err_elem(pipe["X"], plain["X"]) < 1e-9
 
 
 @pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 8), ("calib", 6), ("c2", 6), ("metric", 5)])
