@@ -40,7 +40,7 @@ def load_traffic():
 
 
 STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ; count -1 = number of 32-column Cholesky steps
-    "linearize": [("mcp::k_linearize_group", 1)],
+    "linearize": [("mcp::k_linearize_pipe", 1)],          # round 5: the software-pipelined measurement loop (k_linearize_group: MCP_BA_LIN_PIPE=0)
     "schur": [("mcp::k_schur4", 1), ("mcp::k_assemble", 1)],      # round 5: every system of the batch in one workgroup per group (ba_schur4.h)
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
