@@ -835,6 +835,7 @@ int mcp_ba::prepare() {
     StructKey key;
     for (size_t i = 0; i < ha.size(); ++i) { key.h0 = mix64(key.h0 ^ ha[i]) + i; key.h1 = mix64(key.h1 + hb[i]) ^ (i*0x9e3779b97f4a7c15ull); }
     key.npose = npose; key.npoint = npoint; key.nmeas = nmeas; key.nchain = (int)nch; key.dev = device;
+    key.h1 = mix64(key.h1 ^ (unsigned long long)cams.size());          // (the camera table is part of the packed block's layout)
     // (what else decides the structure: the grouping policy and its run-time switches)
     const char* e_al = getenv("MCP_BA_ASM_LONG");
     key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
