@@ -345,7 +345,12 @@ __device__ __forceinline__ void linearize_group_body(const DevProblem& P, const 
           } else {
             const int isfirst = ia == 0 ? firstA : (ia == 1 ? firstB : (int)P.slot_first[s0 + ia]);
             double* Wb = W + 18*(size_t)inc;
-            if (!Wd_ptr) {              // deferred: leaves at the head of the next round (or behind the loop)
+            if (Wd_ptr == Wb) {         // a second slot of this measurement on the block that is waiting (one pose vertex at two positions of the edge): joins it
+#pragma unroll
+              for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Wd[3*r + c] += w*(Ja[r]*Jp[c] + Ja[6+r]*Jp[3+c]);
+            } else if (!Wd_ptr) {       // deferred: leaves at the head of the next round (or behind the loop)
               Wd_ptr = Wb; Wd_acc = !isfirst;
 #pragma unroll
               for (int r = 0; r < 6; ++r)

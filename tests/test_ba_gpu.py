@@ -237,11 +237,16 @@ def test_point_seen_from_many_poses_uses_generic_path(gpu_required):
     compare_runs(gpu, ref)
 
 
-def test_calibration_chain_shapes(gpu_required):
+@pytest.mark.parametrize("layout", ["auto", "large"])
+def test_calibration_chain_shapes(gpu_required, layout, monkeypatch):
     """BundleAdjusterCalib's problem (src/BundleAdjusterCalib.cc:118-219): free relative camera poses that sit as the
     *second* link of every chain of that camera (a dense block row of the reduced system), chains of length 1 for the
-    first camera, fixed board points on a world chain, Compute(abort, 10)."""
+    first camera, fixed board points on a world chain, Compute(abort, 10).  layout "large": the kernels of a large map (groups of
+    64 points, k_linearize_pipe with its deferred W blocks -- here one pose vertex sits at two positions of an edge, i.e. two slots
+    of one measurement feed the same block) instead of the quarter-size groups a map of 600 points gets."""
     from mcptam_amd import synth
+    if layout == "large":
+        monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")
     p = synth.make_config("calib")
     g, o = _gpu(p.cams), _orc(p.cams)
     p.populate(g)
@@ -535,12 +540,15 @@ def test_speculative_solves_do_not_change_the_iteration(gpu_required, monkeypatc
         assert r["outliers"] == base["outliers"]
 
 
+@pytest.mark.parametrize("layout", ["auto", "large"])
 @pytest.mark.parametrize("extra_links", [0, 2, 4])
-def test_long_chains_with_mixed_fixed_and_free_links(gpu_required, extra_links):
+def test_long_chains_with_mixed_fixed_and_free_links(gpu_required, extra_links, layout, monkeypatch):
     """Generic pose chains (the reference accepts any length, src/ChainBundle.cc:1220-1230; here up to MCP_MAX_CHAIN = 8, any
     link fixed or free): chain {base_k, arm (free, shared by all), mount (fixed), [joints: free / fixed alternating],
     camera_c (c = 0 free, c = 1 fixed)} -- 4, 6 and 8 links.  PoseChainHelper's first/second transforms, MoveTogether's
     structural zeros and the Jacobians of inner links (src/ChainBundle.cc:120-199, 485-586) against the oracle."""
+    if layout == "large":
+        monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")          # (groups of 64 points: k_linearize_pipe, more than two slots per measurement)
     from mcptam_amd import synth
     from mcptam_amd.taylor_camera import TaylorCamera
     rng = np.random.default_rng(11)
@@ -652,11 +660,16 @@ def _plan_mask(S_gpu):
     return np.tril(np.ones_like(S_gpu, dtype=bool))
 
 
+@pytest.mark.parametrize("layout", ["auto", "large"])
 @pytest.mark.parametrize("cfg", ["tiny", "c1", "c2small", "c2"])
-def test_reduced_system_matches_oracle_and_is_reproducible(gpu_required, cfg):
+def test_reduced_system_matches_oracle_and_is_reproducible(gpu_required, cfg, layout, monkeypatch):
     """S = U + lambda I - W V^-1 W^T and its right-hand side, entry by entry against the oracle's reduced system, and
-    bit-identical between two independent builds (staged group blocks summed in ascending group order)."""
+    bit-identical between two independent builds (staged group blocks summed in ascending group order).  layout "large": through
+    the kernels of a large map (groups of 64 points, k_linearize_pipe, four-chunk groups in k_schur4) instead of the quarter-size
+    groups these maps get on their own."""
     from mcptam_amd import synth
+    if layout == "large":
+        monkeypatch.setenv("MCP_BA_SMALL_POINTS", "0")
     p = synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg)
     o = _orc(p.cams)
     p.populate(o)
