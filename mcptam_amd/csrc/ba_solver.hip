@@ -1600,21 +1600,31 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   else if ((prm.profile || cache_insert) && ngroup) {       // (a Prepare() that fills the structure cache computes it for whoever adopts the entry)
     // the work of one system's Schur launch, for the bench line: non-empty 16-row tiles of every 16-point chunk -> tile pairs x 12
     // instructions (k_schur4 skips empty tiles; k_schur_group multiplies every tile of the group's poses), and the structural flops
-    for (int gi = 0; gi < ngroup; ++gi) {
-      int npl = 0; for (int k = 0; k < GRP_LMAX; ++k) if (H.g_pose[(size_t)gi*GRP_LMAX + k] >= 0) npl = k + 1;
-      const int ntile = (6*npl + 15)/16;
-      for (int s0 = H.g_sp0[gi]; s0 < H.g_sp0[gi + 1]; s0 += 16) {
-        unsigned tm = 0;
-        for (int sp = s0; sp < std::min(s0 + 16, H.g_sp0[gi + 1]); ++sp) {
-          if (H.sp_big[sp]) continue;
-          const int k = H.sp_i[sp + 1] - H.sp_i[sp];
-          schur_flops += 324.0*k*(k + 1)/2;
-          for (int i = H.sp_i[sp]; i < H.sp_i[sp + 1]; ++i) { tm |= 1u << ((6*H.inc_lp[i]) >> 4); tm |= 1u << ((6*H.inc_lp[i] + 5) >> 4); }
+    // (ranges of groups on the worker pool, partial sums added in thread order: integers in doubles, any order gives the same value)
+    HostPool& pool = host_pool();
+    const int T = (nmeas >= 32768) ? pool.size() : 1;
+    std::vector<double> pm(T, 0.0), pf(T, 0.0);
+    auto body = [&](int tid) {
+      double sm = 0, sf = 0;
+      for (int gi = (int)((long)ngroup*tid/T), ge = (int)((long)ngroup*(tid + 1)/T); gi < ge; ++gi) {
+        int npl = 0; for (int k = 0; k < GRP_LMAX; ++k) if (H.g_pose[(size_t)gi*GRP_LMAX + k] >= 0) npl = k + 1;
+        const int ntile = (6*npl + 15)/16;
+        for (int s0 = H.g_sp0[gi]; s0 < H.g_sp0[gi + 1]; s0 += 16) {
+          unsigned tm = 0;
+          for (int sp = s0; sp < std::min(s0 + 16, H.g_sp0[gi + 1]); ++sp) {
+            if (H.sp_big[sp]) continue;
+            const int k = H.sp_i[sp + 1] - H.sp_i[sp];
+            sf += 324.0*k*(k + 1)/2;
+            for (int i = H.sp_i[sp]; i < H.sp_i[sp + 1]; ++i) { tm |= 1u << ((6*H.inc_lp[i]) >> 4); tm |= 1u << ((6*H.inc_lp[i] + 5) >> 4); }
+          }
+          const int nt = (sch4_on && sch4_ok) ? __builtin_popcount(tm) : (tm ? ntile : 0);
+          sm += 12.0*nt*(nt + 1)/2;
         }
-        const int nt = (sch4_on && sch4_ok) ? __builtin_popcount(tm) : (tm ? ntile : 0);
-        schur_mfma += 12.0*nt*(nt + 1)/2;
       }
-    }
+      pm[tid] = sm; pf[tid] = sf;
+    };
+    if (T == 1) body(0); else pool.run(body);
+    for (int t2 = 0; t2 < T; ++t2) { schur_mfma += pm[t2]; schur_flops += pf[t2]; }
   }
   if (hit) asm_long = hit->asm_long;
   else {
@@ -1675,8 +1685,13 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       for (int gi = 0; gi < ngroup; ++gi) g_order[gi] = gi;
       std::stable_sort(g_order.begin(), g_order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     }
-    std::vector<int> m_last(hit ? 0 : nmeas);
-    if (!hit) for (int j = 0; j < nmeas; ++j) { const int oc = H.m_chain[j]; m_last[j] = oc*MAXC + chains[oc].len - 1; }
+    std::vector<int, NoInitAlloc<int>> m_last(hit ? 0 : nmeas);
+    if (!hit) {
+      HostPool& pool = host_pool();
+      const int T = (nmeas >= 32768) ? pool.size() : 1;
+      auto body = [&](int tid) { for (long j = (long)nmeas*tid/T, e = (long)nmeas*(tid + 1)/T; j < e; ++j) { const int oc = H.m_chain[j]; m_last[j] = oc*MAXC + chains[oc].len - 1; } };
+      if (T == 1) body(0); else pool.run(body);
+    }
     add(d_sp_unk, sp_unk, false); add(d_g_order, g_order, false); add(d_m_last, m_last, false);
     if (d_struct.alloc(total)) return -1;
     char* const base = d_struct.p;
