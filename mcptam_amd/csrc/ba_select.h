@@ -152,6 +152,158 @@ __device__ inline unsigned long long lds_radix_select_1024(int m, unsigned long 
   return lds_radix_select<1024>(m, k, pass0, prefix0, keyfn, hist, sc, st);
 }
 
+// ---- register-held keys, one workgroup: the rank-k key by VOTES, without shared counters -------------------------------
+// NT threads hold up to PPT keys each (bit patterns of non-negative doubles; ok[] marks the live ones).  The search keeps a
+// bracket [lo, lo + 16 * 2^s) of KEY space (the bit pattern is monotone in the value, so any split of key space is a valid split
+// of the values): a key's bin is (key - lo) >> s, the 16 bins are counted by ballots (bin p's count is a scalar; lane p keeps
+// it), summed over the wavefronts through a small table in LDS and scanned by every wavefront itself -- one barrier per step,
+// no atomics.  The bin holding rank k becomes the next bracket (s - 4).  The first bracket is the caller's guess: s = 52 makes
+// the bins binades, s = 49 eighths of a binade around the last median.  As soon as the bracket holds <= SELV_MAXC keys they are
+// compacted into LDS and ranked (count of smaller keys; the wavefronts share the comparisons).
+// Returns false (out untouched) when rank k lies outside the first bracket: the caller widens it or falls back to histogram passes.
+// Exact for any input: equal keys share a bracket down to s = 0, where a bin IS a key.
+// has[q]: wavefront-uniform "some lane holds a live key in slot q" (slots no lane of the wavefront uses cost nothing).
+// vt: [2][NT/64][SELV_NB + 1] words, cand: SELV_MAXC keys, rk: SELV_MAXC words (LDS; NT >= SELV_MAXC, NT/64 >= SELV_MAXC/8).  Uniform result; contains barriers (all threads call it).
+constexpr int SELV_NB = 16, SELV_MAXC = 64;
+#ifdef MCP_PRR_PROF
+__device__ unsigned long long g_selv_prof[8];      // last call: entry, votes of step 0 done, its barrier passed, its scan done, loop left, gather barrier passed, ranked; [7] = steps
+#define SELV_STAMP(i) do { if (threadIdx.x == 0) g_selv_prof[i] = clock64(); } while (0)
+#else
+#define SELV_STAMP(i) do {} while (0)
+#endif
+template <int NT, int PPT>
+__device__ inline bool regs_vote_select(const unsigned long long (&key)[PPT], const bool (&ok)[PPT], const bool (&has)[PPT], unsigned int kk,
+                                        unsigned long long lo, int s,
+                                        unsigned int (*vt)[NT/64][SELV_NB + 1], unsigned long long* cand, unsigned int* rk, unsigned long long& out) {
+  constexpr int NW = NT/64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int buf = 0, p = 0;
+  unsigned int cnt = 0u;
+  bool hs[PPT];                                     // (made scalar for the compiler: the counts below stay in scalar registers)
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) hs[q] = __builtin_amdgcn_readfirstlane((int)has[q]) != 0;
+  SELV_STAMP(0);
+  for (int step = 0; ; ++step) {
+    // bin of a key: 0..15 inside the bracket, 16 below it (first step only: later brackets hold the rank by construction), 99 not counted
+    const unsigned long long width = (unsigned long long)SELV_NB << s;         // (s <= 52: no overflow)
+    int d[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const unsigned long long rel = key[q] - lo;
+      d[q] = !ok[q] ? 99 : (key[q] < lo ? SELV_NB : (rel < width ? (int)(rel >> s) : 99));
+    }
+    // Counting without a round trip through the scalar unit per bin: every lane adds 1 to its key's bin in four dwords of packed
+    // 8-bit counters (a wavefront holds at most 64 PPT < 256 keys), the dwords are summed over the wavefront by DPP (row scans, then
+    // row_bcast:15 / :31 -- the total lands in lane 63), and lane p extracts bin p's byte.
+    static_assert(64*PPT < 256, "8-bit packed counters");
+    unsigned int pk[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) if (hs[q]) {
+      const unsigned int one = d[q] < SELV_NB ? 1u << ((d[q] & 3) << 3) : 0u;
+      const int j = d[q] >> 2;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) pk[x] += (j == x) ? one : 0u;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      int v = (int)pk[x];
+      v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+      v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+      v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2 and 3
+      pk[x] = (unsigned int)__builtin_amdgcn_readlane(v, 63);
+    }
+    const unsigned int word = (lane >> 2) == 0 ? pk[0] : (lane >> 2) == 1 ? pk[1] : (lane >> 2) == 2 ? pk[2] : pk[3];
+    int mine = (int)((word >> ((lane & 3) << 3)) & 0xffu);
+    if (step == 0) {                                 // the keys below the first bracket: lane SELV_NB
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < PPT; ++q) if (hs[q]) c += __popcll(__ballot(d[q] == SELV_NB));
+      if (lane == SELV_NB) mine = c;
+    }
+    if (step == 0) SELV_STAMP(1);
+    if (lane <= SELV_NB) vt[buf][wave][lane] = (unsigned int)mine;
+    __syncthreads();
+    if (step == 0) SELV_STAMP(2);
+    unsigned int sum = 0u;
+    if (lane <= SELV_NB) {
+      unsigned int pw[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) pw[w] = vt[buf][w][lane];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += pw[w];
+    }
+    const unsigned int below = (step == 0) ? (unsigned int)__builtin_amdgcn_readlane((int)sum, SELV_NB) : 0u;
+    // inclusive scan over the 16 bins = one DPP row (row_shr with zero fill), no LDS crossbar
+    int inc = lane < SELV_NB ? (int)sum : 0;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+    const unsigned int incl = below + (unsigned int)inc, excl = incl - sum;
+    const unsigned long long hit = __ballot(lane < SELV_NB && excl <= kk && kk < incl);
+    if (!hit) return false;                          // (only the first bracket can miss)
+    p = __ffsll((long long)hit) - 1;
+    cnt = (unsigned int)__builtin_amdgcn_readlane((int)sum, p);
+    kk -= (unsigned int)__builtin_amdgcn_readlane((int)excl, p);
+    lo += (unsigned long long)p << s;                // the bin [lo, lo + 2^s) is the new bracket
+    if (step == 0) SELV_STAMP(3);
+#ifdef MCP_PRR_PROF
+    if (threadIdx.x == 0) g_selv_prof[7] = (unsigned long long)(step + 1) | ((unsigned long long)cnt << 32);
+#endif
+    if (cnt <= (unsigned int)SELV_MAXC) break;
+    if (s == 0) { out = lo; return true; }           // more than SELV_MAXC keys equal in every bit
+    const int ns = s >= 4 ? s - 4 : 0;               // 16 bins of 2^ns cover the 2^s keys of the bracket (s < 4: with room to spare)
+    s = ns;
+    buf ^= 1;
+  }
+  // the bracket is [lo, lo + 2^s_final) where s_final is the bin width of the LAST step: compact its keys (wavefront order, then key
+  // slot, then lane) behind a padding of all-ones keys, rank them
+  SELV_STAMP(4);
+  const unsigned long long bw = 1ull << s;
+  unsigned int off = 0u;
+  {
+    unsigned int pw[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) pw[w] = vt[buf][w][p];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) if (w < wave) off += pw[w];
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    if (!hs[q]) continue;
+    const bool c = ok[q] && key[q] >= lo && key[q] - lo < bw;
+    const unsigned long long m = __ballot(c);
+    if (c) cand[off + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = key[q];
+    off += (unsigned int)__popcll(m);
+  }
+  if (threadIdx.x >= cnt && threadIdx.x < ((cnt + 7u) & ~7u)) cand[threadIdx.x] = ~0ull;
+  if (threadIdx.x < (unsigned int)SELV_MAXC) rk[threadIdx.x] = 0u;
+  __syncthreads();
+  SELV_STAMP(5);
+  // lane j of every wavefront holds candidate j; wavefront w counts, of the candidates 8 w .. 8 w + 7, those below it (low half) and those
+  // not above it (high half); the counts meet in LDS.  Rank k belongs to the key with  #below <= k < #not-above  (equal keys all qualify).
+  const unsigned long long mykey = (unsigned int)lane < cnt ? cand[lane] : ~0ull;
+  if ((unsigned int)(8*wave) < cnt) {
+    unsigned long long ci[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ci[j] = cand[8*wave + j];
+    unsigned int add = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add += (ci[j] < mykey ? 1u : 0u) + (ci[j] <= mykey ? 0x10000u : 0u);
+    if ((unsigned int)lane < cnt) atomicAdd(&rk[lane], add);
+  }
+  __syncthreads();
+  const unsigned int rv = (unsigned int)lane < cnt ? rk[lane] : 0u;
+  const unsigned long long hit = __ballot((unsigned int)lane < cnt && (rv & 0xffffu) <= kk && kk < (rv >> 16));
+  const int L = __ffsll((long long)hit) - 1;
+  out = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(mykey >> 32), L) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)mykey, L);
+  SELV_STAMP(6);
+  return true;
+}
+
 // pass kernel: derive state[pass] from state[pass-1] and hist[pass-1], then histogram digit `pass`
 // of the elements that match the prefix.  hist: SEL_PASSES x SEL_BINS doubles, zeroed beforehand.
 static __global__ void __launch_bounds__(SEL_BLOCK)

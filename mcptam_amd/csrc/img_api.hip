@@ -364,10 +364,10 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   const unsigned long long dbit = 1ull << (cur_dev & 63);
   if (!(regs_set_mask & dbit)) {
     regs_set_mask |= dbit;
-    if (hipFuncSetAttribute((const void*)k_pose_refine_regs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12*PRR_THREADS*PRR_PPT*sizeof(double))) == hipSuccess) regs_ok_mask |= dbit;
+    if (hipFuncSetAttribute((const void*)k_pose_refine_regs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PRR_DYN_LDS) == hipSuccess) regs_ok_mask |= dbit;
     else (void)hipGetLastError();
   }
-  bool regs = use_regs && (regs_ok_mask & dbit) && n <= PRR_THREADS*PRR_PPT;          // the points fit the register-resident kernel
+  bool regs = use_regs && (regs_ok_mask & dbit) && n <= PRR_THREADS*PRR_PPT && ncam <= PRR_CAMS;          // the points fit the register-resident kernel, the rig its LDS
   // many points: the iterations over several workgroups (k_pose_refine_multi); MCP_TRACK_REFINE_MULTI = 0 never, 1 whenever the
   // points do not fit the register-resident kernel (default), 2 always
   const int use_multi = [] { const char* e = getenv("MCP_TRACK_REFINE_MULTI"); return e ? atoi(e) : 1; }();
@@ -390,8 +390,8 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   const double* d_ov = reinterpret_cast<const double*>(rs.dblk.p + o_ov); const double* d_cfb = reinterpret_cast<const double*>(rs.dblk.p + o_cfb);
   const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
   if (regs) {
-    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), (size_t)12*PRR_THREADS*PRR_PPT*sizeof(double), st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p, est);
-    if (hipGetLastError() != hipSuccess) {       // the launch was refused (96 KB of dynamic LDS): the plain kernel does the same work from global memory
+    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), PRR_DYN_LDS, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p, est, ncam);
+    if (hipGetLastError() != hipSuccess) {       // the launch was refused (123 KB of dynamic LDS): the plain kernel does the same work from global memory
       regs = false; regs_ok_mask &= ~dbit;
       if (alloc_plain()) return -1;
     }
@@ -426,10 +426,14 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
 #ifdef MCP_PRR_PROF
   if (regs) {
     ICK(hipStreamSynchronize(st));
-    unsigned long long pr[16*8]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prr_prof), sizeof pr);
+    unsigned long long pr[16*8 + 8]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_prr_prof), sizeof pr);
+    { unsigned long long sv[8]; (void)hipMemcpyFromSymbol(sv, HIP_SYMBOL(g_selv_prof), sizeof sv);
+      fprintf(stderr, "[prr prof] last vote select: votes %llu  barrier %llu  scan %llu  further steps %llu  gather+barrier %llu  rank %llu  (steps %llu, %llu keys ranked)\n",
+              sv[1] - sv[0], sv[2] - sv[1], sv[3] - sv[2], sv[4] - sv[3], sv[5] - sv[4], sv[6] - sv[5], sv[7] & 0xffffffffull, sv[7] >> 32); }
+    fprintf(stderr, "[prr prof] kernel: entry to first iteration %llu  iterations %llu  write-back %llu  (cycles)\n", pr[129] - pr[128], pr[130] - pr[129], pr[131] - pr[130]);
     for (int it = 0; it < n_iter && it < 16; ++it) { const unsigned long long* q = pr + 8*it;
-      fprintf(stderr, "[prr prof] it %d%s: points %llu  select %llu  accumulate+reduce %llu  solve %llu  barrier %llu  (cycles)\n", it, nonlinear[it] ? " (re-projection)" : "",
-              q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4]); }
+      fprintf(stderr, "[prr prof] it %d%s: points %llu  select %llu  accumulate %llu  reduce-scatter+barrier %llu  sum+barrier %llu  solve %llu  barrier %llu  (cycles)\n", it, nonlinear[it] ? " (re-projection)" : "",
+              q[1] - q[0], q[2] - q[1], q[6] - q[2], q[7] - q[6], q[3] - q[7], q[4] - q[3], q[5] - q[4]); }
   }
 #endif
   ICK(hipGetLastError());

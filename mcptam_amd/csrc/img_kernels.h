@@ -1024,6 +1024,83 @@ k_sbi_iterate(const float* __restrict__ me, const float* __restrict__ ot_templ, 
 }
 
 
+// One Gauss-Newton step from the 27 sums of the weighted normal equations (21 of the lower triangle row by row, 6 of the vector):
+// prior 100 on the diagonal, 6x6 Cholesky, mu, BaseFromWorld <- exp(mu) BaseFromWorld (Tracker::CalcPoseUpdate, src/Tracker.cc:1499-1512:
+// TooN's Cholesky<6> backsub).  One lane: a pivot costs its reciprocal square root only (v_rsq_f64 + one third-order correction, 6 dependent
+// instructions; sqrt followed by a division is ~50) -- results within an ulp or two of the sqrt / divide form.
+__device__ inline double rsqrt_h3(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(y0*(-x), y0, 1.0);
+  return __builtin_fma(y0*e, __builtin_fma(e, 0.375, 0.5), y0);
+}
+// exp of the step: A = sin t / t, B = (1 - cos t) / t^2, C = (1 - A) / t^2 are entire functions of t^2 -- below t^2 = 1/4 (a pose step of
+// half a radian) their series to 2^-60 (no square root, no division, no sin / cos: ~25 fused multiply-adds where libm's pair costs ~150
+// instructions on the one lane everything waits for); above, the closed forms of se3_exp (TooN SE3<>::exp, what the oracle evaluates);
+// below 1e-6 TooN's truncated forms, as the oracle.
+__device__ __forceinline__ void se3_exp_step(const double* mu, Se3& T) {
+#pragma clang fp contract(fast)
+  const double* w = mu + 3;
+  const double x = w[0]*w[0] + w[1]*w[1] + w[2]*w[2];
+  if (!(x < 0.25)) { se3_exp(mu, T); return; }
+  const double cx = w[1]*mu[2] - w[2]*mu[1], cy = w[2]*mu[0] - w[0]*mu[2], cz = w[0]*mu[1] - w[1]*mu[0];
+  double A, B;
+  if (x < 1e-8) {                                  // (TooN's own truncations below 1e-8 and 1e-6: the reference's values, not better ones)
+    A = 1.0 - x*(1.0/6.0); B = 0.5;
+    T.t[0] = mu[0] + 0.5*cx; T.t[1] = mu[1] + 0.5*cy; T.t[2] = mu[2] + 0.5*cz;
+  } else {
+    double C;
+    if (x < 1e-6) { C = (1.0/6.0)*(1.0 - (1.0/20.0)*x); A = 1.0 - x*C; B = 0.5 - 0.25*(1.0/6.0)*x; }
+    else {
+      // 1/n! for n = 1 .. 19, alternating by the index of the term
+      A = 1.0 + x*(-1.0/6 + x*(1.0/120 + x*(-1.0/5040 + x*(1.0/362880 + x*(-1.0/39916800 + x*(1.0/6227020800.0 + x*(-1.0/1307674368000.0 + x*(1.0/355687428096000.0))))))));
+      B = 0.5 + x*(-1.0/24 + x*(1.0/720 + x*(-1.0/40320 + x*(1.0/3628800 + x*(-1.0/479001600 + x*(1.0/87178291200.0 + x*(-1.0/20922789888000.0 + x*(1.0/6402373705728000.0))))))));
+      C = 1.0/6 + x*(-1.0/120 + x*(1.0/5040 + x*(-1.0/362880 + x*(1.0/39916800 + x*(-1.0/6227020800.0 + x*(1.0/1307674368000.0 + x*(-1.0/355687428096000.0)))))));
+    }
+    const double dx = w[1]*cz - w[2]*cy, dy = w[2]*cx - w[0]*cz, dz = w[0]*cy - w[1]*cx;
+    T.t[0] = mu[0] + B*cx + C*dx; T.t[1] = mu[1] + B*cy + C*dy; T.t[2] = mu[2] + B*cz + C*dz;
+  }
+  rodrigues(w, A, B, T.R);
+}
+__device__ __forceinline__ void pose_step_from_sums(const double* tot, double* pose, double* v6) {
+#pragma clang fp contract(fast)                   // (this translation unit is built with -ffp-contract=off for the bit-exact image paths; the pose step is compared to rounding)
+  double C[36], v[6], mu[6], rd[6];
+  int q = 0;
+#pragma unroll
+  for (int x = 0; x < 6; ++x)
+#pragma unroll
+    for (int y = 0; y <= x; ++y) { C[6*x + y] = tot[q]; ++q; }
+#pragma unroll
+  for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = C[7*j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
+#ifdef PRR_OLD_SOLVE
+    rd[j] = 1.0/sqrt(d);
+#else
+    rd[j] = rsqrt_h3(d);
+#endif
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
+  Se3 E, T, R;
+  se3_exp_step(mu, E);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
+  T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
+  se3_compose(E, T, R);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
+  pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+}
+
 // ---- the ten Gauss-Newton pose iterations of Tracker::TrackMap in one launch ----------------------------------------
 //   src/Tracker.cc:775-838 (PoseUpdateStep / PoseUpdateStepLinear), 1038-1075 (schedule), 1386-1512 (CalcPoseUpdate)
 // One workgroup; the points stay on the device between iterations (image position, camera derivatives, 2x6 Jacobian), so
@@ -1132,36 +1209,7 @@ k_pose_refine(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restr
     if (t < 27) { double sum = 0.0; for (int wv = 0; wv < PR_THREADS/64; ++wv) sum += red[wv][t]; tot[t] = sum; }      // the wavefronts' partials in wavefront order
     __syncthreads();
     if (t == 0) {
-      double C[36], v[6], mu[6], rd[6];
-      int q = 0;
-#pragma unroll
-      for (int x = 0; x < 6; ++x)
-#pragma unroll
-        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
-#pragma unroll
-      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
-      // 6x6 Cholesky; the divisions by a column's pivot share one reciprocal (a lane alone pays ~40 dependent instructions per fp64 division)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double d = C[7*j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
-        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
-#pragma unroll
-      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
-      Se3 E, T, R;
-      se3_exp(mu, E);
-      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
-      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
-      se3_compose(E, T, R);
-      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
-      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
-      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+      pose_step_from_sums(tot, pose, v6);
     }
     __syncthreads();
   }
@@ -1386,35 +1434,7 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
     if (t < 27) { double sum = 0.0; for (unsigned int g = 0; g < nwg; ++g) sum += prm_ldd(&G->acc[it][g][t]); tot[t] = sum; }      // workgroup order: the same sum everywhere
     __syncthreads();
     if (t == 0) {
-      double C[36], v[6], mu[6], rd[6];
-      int q = 0;
-#pragma unroll
-      for (int x = 0; x < 6; ++x)
-#pragma unroll
-        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
-#pragma unroll
-      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double d = C[7*j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
-        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
-#pragma unroll
-      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
-      Se3 E, T, R;
-      se3_exp(mu, E);
-      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
-      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
-      se3_compose(E, T, R);
-      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
-      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
-      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+      pose_step_from_sums(tot, pose, v6);
     }
     __syncthreads();
   }
@@ -1436,119 +1456,169 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
 #endif                  // (two wavefronts per SIMD at 255 registers overlap each other's latencies), 1024 x 1: 176.7 (eight-wavefront barriers, spills)
 constexpr int PRR_THREADS = PRR_NT, PRR_PPT = 1024/PRR_NT;
 #ifdef MCP_PRR_PROF
-__device__ unsigned long long g_prr_prof[16*8];
+__device__ unsigned long long g_prr_prof[16*8 + 8];
 #define PRR_STAMP(i) do { if (threadIdx.x == 0 && it < 16) g_prr_prof[it*8 + (i)] = clock64(); } while (0)
+#define PRR_STAMP_K(i) do { if (threadIdx.x == 0) g_prr_prof[16*8 + (i)] = clock64(); } while (0)      // kernel entry, first iteration, after the last, exit
 #else
 #define PRR_STAMP(i) do {} while (0)
+#define PRR_STAMP_K(i) do {} while (0)
 #endif
+constexpr int PRR_CAMS = 8;           // cameras whose models and CamFromBase poses are staged in LDS (a c5 rig has 8); more: the plain kernels
+// dynamic LDS of k_pose_refine_regs: the Jacobians [12][1024], the world positions [3][1024], the arctangent's table, CamFromBase, camera models
+constexpr size_t PRR_DYN_LDS = sizeof(double)*((12 + 3)*(size_t)PRR_THREADS*PRR_PPT + 130 + 12*PRR_CAMS) + sizeof(mcp_camera)*PRR_CAMS;
 __global__ void __launch_bounds__(PRR_THREADS)
 k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
                    double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
-                   double* __restrict__ mu_out, double* __restrict__ w_out, int est) {
+                   double* __restrict__ mu_out, double* __restrict__ w_out, int est, int ncam) {
+#pragma clang fp contract(fast)                   // (the sums and the linear updates; the camera model keeps its own uncontracted arithmetic)
   constexpr int NT = PRR_THREADS, NW = NT/64, BPT = SEL_BINS/NT;
+  PRR_STAMP_K(0);
   __shared__ unsigned int hist[SEL_BINS];
-  __shared__ unsigned int wtot[NW], wtot2[NW], sres[3];
+  __shared__ unsigned int wtot[NW], sres[3];
   __shared__ unsigned long long skey;
+  __shared__ unsigned int vt[2][NW][SELV_NB + 1];
+  __shared__ unsigned long long cand[SELV_MAXC], wsamp[NW];
+  __shared__ unsigned int rk[SELV_MAXC];
   __shared__ double red[NW][28];
   __shared__ double pose[12], v6[6], tot[27];
-  __shared__ int nf_s;
+  __shared__ int wcnt[PRR_PPT][NW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  unsigned int pred_d0 = 0xffffffffu;            // digit 0 of the last median (none yet)
-  for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;          // every digit pass leaves it zero again
-  bool fnd[PRR_PPT]; int camk[PRR_PPT];
-  double fpos[PRR_PPT][2], sinv[PRR_PPT], img[PRR_PPT][2], cd[PRR_PPT][4], ex[PRR_PPT][2], e2[PRR_PPT];
   extern __shared__ double Jl[];                 // [12][NT*PPT]: a point's 2x6 Jacobian, one column of 12 per point (lane-consecutive: no bank conflicts)
   constexpr int JS = PRR_THREADS*PRR_PPT;
-  int nf_loc = 0;
+  // what the re-projecting iterations read, staged once:
+  double* const wpl = Jl + 12*JS;                // [3][JS] world positions
+  double* const satan = wpl + 3*JS;              // the arctangent's table (atan_cr.h): hi[65], lo[65]
+  double* const cfbl = satan + 130;              // [ncam][12] CamFromBase
+  mcp_camera* const caml = reinterpret_cast<mcp_camera*>(cfbl + 12*PRR_CAMS);
+  __shared__ double sov[32];
+  __shared__ unsigned char snl[32];
+  // The FOUND points, compacted: a frame finds 60-80 % of its points, and a slot (t + k NT) no lane of a wavefront fills costs that
+  // wavefront nothing in any pass -- 700 found points are 11 wavefront passes where 1000 slots are 16.  Order: slot-major, as given.
+  int* const perm = reinterpret_cast<int*>(hist);        // (the histogram's 8 KB, before they are zeroed)
+  bool fnd[PRR_PPT]; int src[PRR_PPT];
 #pragma unroll
-  for (int k = 0; k < PRR_PPT; ++k) {
-    const int i = t + k*NT;
-    fnd[k] = false; camk[k] = 0; sinv[k] = 0.0; e2[k] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { fpos[k][q] = 0.0; img[k][q] = 0.0; ex[k][q] = 0.0; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cd[k][q] = 0.0;
-    if (i < n) {
-      const mcp_pose_point& p = pts[i];
-      fnd[k] = p.found != 0; camk[k] = p.cam; sinv[k] = p.sqrt_inv_noise;
-      fpos[k][0] = p.found_pos[0]; fpos[k][1] = p.found_pos[1]; img[k][0] = p.image[0]; img[k][1] = p.image[1];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cd[k][q] = p.cam_derivs[q];
-      nf_loc += fnd[k] ? 1 : 0;
-    }
-  }
+  for (int k = 0; k < PRR_PPT; ++k) { const int i = t + k*NT; fnd[k] = i < n && pts[i].found != 0; }
+  for (int i = t; i < 65; i += NT) { satan[i] = mcp_atan::kAtanHi[i]; satan[65 + i] = mcp_atan::kAtanLo[i]; }
+  for (int i = t; i < 12*ncam; i += NT) cfbl[i] = cfb_all[i];
+  { const double* srcd = reinterpret_cast<const double*>(cams); double* dst = reinterpret_cast<double*>(caml);
+    for (int i = t; i < (int)(sizeof(mcp_camera)/sizeof(double))*ncam; i += NT) dst[i] = srcd[i]; }
+  if (t < 32 && t < n_iter) { sov[t] = override_sigma[t]; snl[t] = nonlinear[t]; }
   if (t < 12) pose[t] = bfw_io[t];
   if (t < 6) v6[t] = 0.0;
-  if (t == 0) nf_s = 0;
-  __syncthreads();
+  unsigned long long fm[PRR_PPT];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nf_loc += __shfl_xor(nf_loc, o, 64);
-  if (lane == 0) atomicAdd(&nf_s, nf_loc);
+  for (int k = 0; k < PRR_PPT; ++k) { fm[k] = __ballot(fnd[k]); if (lane == 0) wcnt[k][wave] = __popcll(fm[k]); }
   __syncthreads();
-  const int nf = nf_s;
+  int nf = 0;
+#pragma unroll
+  for (int k = 0; k < PRR_PPT; ++k) {
+    int base = nf;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int c = wcnt[k][w]; if (w < wave) base += c; nf += c; }
+    if (fnd[k]) perm[base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(fm[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)fm[k], 0u))] = t + k*NT;
+  }
+  __syncthreads();
+  int camk[PRR_PPT]; bool has[PRR_PPT];
+  double fpos[PRR_PPT][2], sinv[PRR_PPT], img[PRR_PPT][2], ex[PRR_PPT][2];      // (the camera derivatives live only while a point's Jacobian is
+                                                                                // built: read from / written to the record in those iterations)
+#pragma unroll
+  for (int k = 0; k < PRR_PPT; ++k) {
+    const int col = t + k*NT;
+    fnd[k] = col < nf; src[k] = fnd[k] ? perm[col] : 0; camk[k] = 0; sinv[k] = 0.0;
+    has[k] = wave*64 + k*NT < nf;                // (wavefront-uniform: its first lane's slot is filled)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { fpos[k][q] = 0.0; img[k][q] = 0.0; ex[k][q] = 0.0; }
+    if (fnd[k]) {
+      const mcp_pose_point& p = pts[src[k]];
+      camk[k] = p.cam; sinv[k] = p.sqrt_inv_noise;
+      fpos[k][0] = p.found_pos[0]; fpos[k][1] = p.found_pos[1]; img[k][0] = p.image[0]; img[k][1] = p.image[1];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wpl[q*JS + col] = p.world_pos[q];
+    }
+  }
+  __syncthreads();                               // (perm is read: the histogram may be zeroed)
+  for (int b = t; b < SEL_BINS; b += NT) hist[b] = 0u;          // every digit pass leaves it zero again
+  unsigned long long prev_key = 0ull, prev_dk = ~0ull; bool have_prev = false;      // the last median and how far it had moved
+  __syncthreads();
   for (int it = 0; it < n_iter; ++it) {
     if (nf == 0) { if (t < 6) v6[t] = 0.0; __syncthreads(); continue; }           // no valid measurements: null update
-    const bool nl = nonlinear[it] != 0;
+    const bool nl = (it < 32 ? snl[it] : nonlinear[it]) != 0;
+    if (it == 0) PRR_STAMP_K(1);
     PRR_STAMP(0);
 #pragma unroll
     for (int k = 0; k < PRR_PPT; ++k) {
       if (!fnd[k]) continue;
       const int i = t + k*NT;
       if (nl) {
-        const double* cfb = cfb_all + 12*(size_t)camk[k];
-        const double wp[3] = { pts[i].world_pos[0], pts[i].world_pos[1], pts[i].world_pos[2] };
+        const double* cfb = cfbl + 12*camk[k];
+        const double wp[3] = { wpl[i], wpl[JS + i], wpl[2*JS + i] };
         double xb[3], xc[3];
         mat3_vec(pose, wp, xb); xb[0] += pose[9]; xb[1] += pose[10]; xb[2] += pose[11];
         mat3_vec(cfb, xb, xc); xc[0] += cfb[9]; xc[1] += cfb[10]; xc[2] += cfb[11];
+        double cd[4];
+        mcp_pose_point& rec = pts[src[k]];
         if (it != 0) {
-          Projection pr; cam_project<true>(cams[camk[k]], xc, pr);
-          img[k][0] = pr.u; img[k][1] = pr.v; cd[k][0] = pr.D[0]; cd[k][1] = pr.D[1]; cd[k][2] = pr.D[2]; cd[k][3] = pr.D[3];
+          Projection pr; cam_project<true>(caml[camk[k]], xc, pr, satan, satan + 65);
+          img[k][0] = pr.u; img[k][1] = pr.v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { cd[q] = pr.D[q]; rec.cam_derivs[q] = pr.D[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cd[q] = rec.cam_derivs[q];       // the search stage's derivatives
         }
         double dT[3], dP[3]; cam_sphere_deriv(xc, dT, dP);
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
           double mb[3], mc[3]; generator(m, xb, mb); mat3_vec(cfb, mb, mc);
           const double s0 = dT[0]*mc[0] + dT[1]*mc[1] + dT[2]*mc[2], s1 = dP[0]*mc[0] + dP[1]*mc[1] + dP[2]*mc[2];
-          Jl[m*JS + i] = cd[k][0]*s0 + cd[k][1]*s1; Jl[(6 + m)*JS + i] = cd[k][2]*s0 + cd[k][3]*s1;
+          Jl[m*JS + i] = cd[0]*s0 + cd[1]*s1; Jl[(6 + m)*JS + i] = cd[2]*s0 + cd[3]*s1;
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 2; ++r) { double a = 0.0; for (int q = 0; q < 6; ++q) a += Jl[(6*r + q)*JS + i]*v6[q]; img[k][r] += a; }
       }
       ex[k][0] = sinv[k]*(fpos[k][0] - img[k][0]); ex[k][1] = sinv[k]*(fpos[k][1] - img[k][1]);
-      e2[k] = ex[k][0]*ex[k][0] + ex[k][1]*ex[k][1];
     }
     PRR_STAMP(1);
-    double s2 = override_sigma[it];
+    double s2 = it < 32 ? sov[it] : override_sigma[it];
     if (!(s2 > 0)) {
       // Tukey::FindSigmaSquared: exact [nf/2] order statistic of the squared errors, MSD radix select over the register-held keys.
       // Three barriers per digit: the histogram's owner threads read and clear their bins in one go (it is zero again for the
       // next digit), counts are scanned in 32 bits, prefix and rank travel in registers.
       unsigned long long key[PRR_PPT];
 #pragma unroll
-      for (int k = 0; k < PRR_PPT; ++k) key[k] = (unsigned long long)__double_as_longlong(fabs(e2[k]));
+      for (int k = 0; k < PRR_PPT; ++k) key[k] = (unsigned long long)__double_as_longlong(fabs(ex[k][0]*ex[k][0] + ex[k][1]*ex[k][1]));
       unsigned long long prefix = 0ull; unsigned int kk = (unsigned int)(nf/2);
-      int pass0 = 0;
-      if (pred_d0 < (unsigned int)SEL_BINS) {
-        // Digit 0 (sign + exponent bits) without a histogram: the median of the last iteration's squared errors names the digit the
-        // new median most likely has; how many keys lie below that digit and how many share it are two votes per key and one
-        // barrier (a histogram pass is atomics on the same few counters, an owner scan and three barriers).  A wrong guess: pass 0 as before.
-        const int sh0 = sel_shift(0);
-        unsigned int cl = 0u, ce = 0u;
-#pragma unroll
-        for (int k = 0; k < PRR_PPT; ++k) {
-          const unsigned int b0 = (unsigned int)(key[k] >> sh0) & (SEL_BINS - 1);
-          cl += (unsigned int)__popcll(__ballot(fnd[k] && b0 < pred_d0));
-          ce += (unsigned int)__popcll(__ballot(fnd[k] && b0 == pred_d0));
+      // By votes first (regs_vote_select, ba_select.h), in brackets of key space around a guess: once the median has moved by less than
+      // half a binade between two iterations, 16 eighths of a binade around the last one (usually <= 64 keys share the median's
+      // eighth: ONE counted step, then they are ranked in LDS); else 16 binades -- 11 below the last median and 4 above (the errors
+      // mostly shrink), in the first iteration 8 below and 7 above the first found point's error -- and 4 more bits per step.  One
+      // barrier per step and no shared counters; a histogram pass is LDS atomics on a few hot counters, an owner scan and three
+      // barriers.  A bracket that misses the rank: the next wider one, at last the histogram passes below from digit 0.
+      bool have = false;
+#ifndef PRR_NO_VOTE
+      {
+        unsigned long long r = 0ull;
+        if (have_prev && prev_dk < (1ull << 51)) {
+          const unsigned long long half = 8ull << 49;
+          have = regs_vote_select<NT, PRR_PPT>(key, fnd, has, kk, prev_key > half ? prev_key - half : 0ull, 49, vt, cand, rk, r);
         }
-        if (lane == 0) { wtot[wave] = cl; wtot2[wave] = ce; }
-        __syncthreads();
-        unsigned int below = 0u, equal = 0u;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { below += wtot[w]; equal += wtot2[w]; }
-        __syncthreads();                               // (wtot is the scan's scratch below)
-        if (below <= kk && kk < below + equal && equal > 1u) { prefix = (unsigned long long)pred_d0 << sh0; kk -= below; pass0 = 1; }
+        if (!have) {
+          int e_lo;
+          if (have_prev) e_lo = (int)(prev_key >> 52) - 11;
+          else {
+            // (slot 0 of wavefront 0 holds the first found point: the points are compacted)
+            e_lo = (int)((unsigned int)__builtin_amdgcn_readfirstlane((int)(key[0] >> 32)) >> 20);
+            if (lane == 0) wsamp[wave] = (unsigned long long)e_lo;
+            __syncthreads();
+            e_lo = (int)wsamp[0] - 8;
+          }
+          have = regs_vote_select<NT, PRR_PPT>(key, fnd, has, kk, (unsigned long long)(e_lo < 0 ? 0 : e_lo) << 52, 52, vt, cand, rk, r);
+        }
+        if (have) prefix = r;
       }
+#endif
+      const int pass0 = have ? SEL_PASSES : 0;
       for (int pass = pass0; pass < SEL_PASSES; ++pass) {
         const int sh = sel_shift(pass);
         const unsigned int dmask = (1u << sel_nbits(pass)) - 1u;
@@ -1589,7 +1659,8 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
         }
       }
       const double med = __longlong_as_double((long long)prefix);
-      pred_d0 = (unsigned int)(prefix >> sel_shift(0)) & (SEL_BINS - 1);
+      prev_dk = have_prev ? (prefix > prev_key ? prefix - prev_key : prev_key - prefix) : ~0ull;
+      prev_key = prefix; have_prev = true;
       s2 = mest_sigma_sq(est, (double)nf, med);
     }
     PRR_STAMP(2);
@@ -1601,9 +1672,9 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
 #pragma unroll
     for (int k = 0; k < PRR_PPT; ++k) {
       const int i = t + k*NT;
-      if (!fnd[k]) { if (last && w_out && i < n) w_out[i] = 0.0; continue; }
-      const double w = mest_weight(est, e2[k], s2);
-      if (last && w_out) w_out[i] = w;
+      if (!fnd[k]) continue;                       // (the weights of the points not found: zeroed by the host before the launch)
+      const double w = mest_weight(est, ex[k][0]*ex[k][0] + ex[k][1]*ex[k][1], s2);
+      if (last && w_out) w_out[src[k]] = w;
       if (w == 0.0) continue;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -1620,6 +1691,7 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
         }
       }
     }
+    PRR_STAMP(6);
     {
       // the 27 sums over the wavefront as a reduce-scatter: at every butterfly step a lane hands half of its entries to its partner
       // and adds the partner's half of the entries it keeps -- 16 + 8 + 4 + 2 + 1 + 1 exchanges instead of 27 x 6, in a fixed tree
@@ -1630,55 +1702,29 @@ k_pose_refine_regs(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __
       if (!(lane & 1) && idx < 27) red[wave][idx] = total;
     }
     __syncthreads();
+    PRR_STAMP(7);
     if (t < 27) { double sum = 0.0; for (int wv = 0; wv < NW; ++wv) sum += red[wv][t]; tot[t] = sum; }
-    __syncthreads();
+    // (the totals go from lanes 0..26 to lane 0 of the SAME wavefront: its LDS operations complete in order, no workgroup barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PRR_STAMP(3);
     if (t == 0) {
-      double C[36], v[6], mu[6], rd[6];
-      int q = 0;
-#pragma unroll
-      for (int x = 0; x < 6; ++x)
-#pragma unroll
-        for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = tot[q]; ++q; }
-#pragma unroll
-      for (int x = 0; x < 6; ++x) { v[x] = tot[21 + x]; C[7*x] += 100.0; }    // add_prior(100)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double d = C[7*j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
-        const double l = sqrt(d); C[7*j] = l; rd[j] = 1.0/l;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum*rd[i]; }
-#pragma unroll
-      for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum*rd[i]; }
-      Se3 E, T, R;
-      se3_exp(mu, E);
-      for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
-      T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
-      se3_compose(E, T, R);
-      for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
-      pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
-      for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+      pose_step_from_sums(tot, pose, v6);
     }
     PRR_STAMP(4);
     __syncthreads();
     PRR_STAMP(5);
   }
+  PRR_STAMP_K(2);
 #pragma unroll
   for (int k = 0; k < PRR_PPT; ++k) {
-    const int i = t + k*NT;
-    if (i < n && fnd[k]) {
-      pts[i].image[0] = img[k][0]; pts[i].image[1] = img[k][1];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pts[i].cam_derivs[q] = cd[k][q];
+    if (fnd[k]) {
+      mcp_pose_point& p = pts[src[k]];
+      p.image[0] = img[k][0]; p.image[1] = img[k][1];
     }
   }
   if (t < 12) bfw_io[t] = pose[t];
   if (t < 6) mu_out[t] = v6[t];
+  PRR_STAMP_K(3);
 }
 
 
@@ -1796,21 +1842,7 @@ __global__ void k_pr_solve(const double* __restrict__ acc, const double* __restr
   double nf = 0.0;
   for (int r = 0; r < world; ++r) nf += counts[r];
   if (nf == 0.0) { for (int k = 0; k < 6; ++k) v6[k] = 0.0; return; }
-  double C[36], v[6], mu[6];
-  int q = 0;
-  for (int x = 0; x < 6; ++x) for (int y = 0; y <= x; ++y) { C[6*x + y] = C[6*y + x] = acc[q]; ++q; }
-  for (int x = 0; x < 6; ++x) { v[x] = acc[21 + x]; C[7*x] += 100.0; }
-  for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = (i == j) ? sqrt(sum) : sum/C[6*j + j]; }
-  for (int i = 0; i < 6; ++i) { double sum = v[i]; for (int k = 0; k < i; ++k) sum -= C[6*i + k]*mu[k]; mu[i] = sum/C[6*i + i]; }
-  for (int i = 5; i >= 0; --i) { double sum = mu[i]; for (int k = i + 1; k < 6; ++k) sum -= C[6*k + i]*mu[k]; mu[i] = sum/C[6*i + i]; }
-  Se3 E, T, R;
-  se3_exp(mu, E);
-  for (int k = 0; k < 9; ++k) T.R[k] = pose[k];
-  T.t[0] = pose[9]; T.t[1] = pose[10]; T.t[2] = pose[11];
-  se3_compose(E, T, R);
-  for (int k = 0; k < 9; ++k) pose[k] = R.R[k];
-  pose[9] = R.t[0]; pose[10] = R.t[1]; pose[11] = R.t[2];
-  for (int k = 0; k < 6; ++k) v6[k] = mu[k];
+  pose_step_from_sums(acc, pose, v6);
 }
 
 }  // namespace mcp

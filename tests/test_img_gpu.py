@@ -878,6 +878,66 @@ def test_pose_update_and_refine_with_the_other_m_estimators(gpu_required, est):
     assert np.abs(pt[1] - pg[1]).max() > 1e-9          # another estimator, another pose
 
 
+def _median_cases(rng, n):
+    """(name, error magnitudes): the squared-error populations the Tukey median of the register-held pose iterations has to select from."""
+    z = rng.uniform(0.1, 3.0, n); z[rng.random(n) < 0.4] = 0.0
+    zz = rng.uniform(0.1, 3.0, n); zz[rng.random(n) < 0.6] = 0.0      # median 0: sigma 0, weights 0/0 in the reference too
+    return [("ties", rng.choice([0.5, 1.0, 2.0], n)),
+            ("sixty_binades", 2.0**rng.uniform(-30, 30, n)),
+            ("all_equal", np.full(n, 0.75)),
+            ("many_zero", z), ("zero_median", zz),
+            ("lognormal", np.exp(rng.normal(0.0, 1.0, n))),
+            ("dense_cluster", 1.0 + np.arange(n)*2.0**-50),
+            ("outlier_first", np.concatenate([[2.0**20], rng.uniform(0.5, 1.5, n - 1)])),
+            ("tiny_first", np.concatenate([[2.0**-20], rng.uniform(0.5, 1.5, n - 1)]))]
+
+
+def test_vote_select_unit_against_sort(gpu_required, tmp_path):
+    """regs_vote_select (csrc/ba_select.h) alone, in a 512-thread kernel of its own (tests/cpp/vote_select_check.hip): the rank-k key of up to
+    1024 register-held keys for k = 0, n/2, n - 1 over eight populations (ties, sixty binades, zeros, a dense cluster ...), with and
+    without dead slots, with the window of binades starting below, at and above the answer -- the answer must equal std::sort's whenever the
+    window holds it, and the routine must say so when it does not (1944 launches, three calls each on the same LDS tables)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "vote_select_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "mcptam_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "vote_select_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok "), out.stdout[-2000:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("n", [1000, 1024, 130, 3, 1])
+def test_pose_iterations_take_the_exact_median_of_hard_populations(gpu_required, n):
+    """k_pose_refine_regs selects Tukey's median (MEstimator.h:194-204: element [size/2] of the sorted squared errors) by votes over a
+    window of binades around a guess, falling back to histogram passes (ba_select.h regs_vote_select): ties, populations spread over
+    sixty binades, a guess far off (first point an outlier / tiny), many errors exactly zero, a thousand keys that
+    differ in their last mantissa bits only, and the unfound gaps in between -- every one against the oracle's sort, after one, two
+    and three iterations (the first guess is a sample, the later ones the previous median)."""
+    import test_oracle_cpu as toc
+    from mcptam_amd.keyframe import track_pose_refine
+    from oracle import oracle_track_pose_refine
+    cam, cfbs, bfw, recs0 = toc._refine_scene()
+    rng = np.random.default_rng(n)
+    recs = np.tile(recs0[recs0["found"] != 0], n//8 + 1)[:n].copy()
+    for name, err in _median_cases(rng, n):
+        r = recs.copy()
+        r["sqrt_inv_noise"] = 1.0
+        r["found_pos"] = r["image"] + np.stack([err, np.zeros(n)], axis=1)
+        if n > 100:
+            r["found"][rng.random(n) < 0.15] = 0
+        for nit in (1, 2, 3):
+            nl = np.array([1, 0, 0][:nit], dtype=np.uint8)
+            pg, mg, wg, og = track_pose_refine(r, [cam, cam], cfbs, bfw, nonlinear=nl, override_sigma=np.zeros(nit))
+            po, mo, wo, oo = oracle_track_pose_refine(r, [cam, cam], cfbs, bfw, nonlinear=nl, override_sigma=np.zeros(nit))
+            ok = np.isfinite(wo).all() and np.isfinite(mo).all()
+            if not ok:                                # (a zero median: the call has to come back, with a non-finite update like the reference's)
+                assert not np.isfinite(mg).all(), (name, nit)
+                continue
+            assert np.array_equal(wg == 0, wo == 0), (name, nit)
+            assert np.allclose(wg, wo, rtol=1e-9, atol=1e-12), (name, nit, np.abs(wg - wo).max())
+            assert np.allclose(mg, mo, rtol=1e-6, atol=1e-9*max(1.0, np.abs(mo).max())), (name, nit)
+
+
 @pytest.mark.parametrize("est", ["Tukey", "Huber"])
 def test_pose_refine_over_many_workgroups_matches_oracle(gpu_required, est, monkeypatch):
     """k_pose_refine_multi: the pose iterations with the points sliced over workgroups (frames with thousands of tracked points,
