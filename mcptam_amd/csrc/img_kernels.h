@@ -1076,11 +1076,7 @@ __device__ __forceinline__ void pose_step_from_sums(const double* tot, double* p
     double d = C[7*j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= C[6*j + k]*C[6*j + k];
-#ifdef PRR_OLD_SOLVE
-    rd[j] = 1.0/sqrt(d);
-#else
     rd[j] = rsqrt_h3(d);
-#endif
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) { double sum = C[6*i + j]; for (int k = 0; k < j; ++k) sum -= C[6*i + k]*C[6*j + k]; C[6*i + j] = sum*rd[j]; }
   }
@@ -1445,12 +1441,20 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
 }
 
 
-// ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT) -----------------------------
-// One workgroup of 512 threads = two wavefronts per SIMD at up to 256 registers each: a thread's two points' found position,
-// noise, image position, camera derivatives and errors live there across all iterations, their 2x6 Jacobians in LDS (96 KB) -- no global round trips
-// inside an iteration (world position and camera model are re-read only by the re-projecting iterations), eight-wavefront barriers,
-// the Tukey median selected from the register-held squared errors.  Same arithmetic per point as k_pose_refine; the order of the
-// 27 sums differs (PRR_PPT points per thread, PRR_THREADS/64 wavefronts), i.e. results agree to rounding, the median exactly.
+// ---- the same ten iterations with the points held in registers (n <= PRR_THREADS*PRR_PPT, ncam <= PRR_CAMS) ----------------
+// One workgroup of 512 threads = two wavefronts per SIMD at up to 256 registers each.  The FOUND points are compacted into the slots
+// (thread t: slots t and t + 512): a thread's points' found position, noise, image position and errors live in registers across all
+// iterations, their 2x6 Jacobians in LDS (96 KB), and what the re-projecting iterations read besides -- world positions, camera models,
+// CamFromBase, the arctangent's table -- in LDS too (29 KB): no global reads inside an iteration.  Eight-wavefront barriers; the Tukey
+// median is selected from the register-held squared errors by votes (regs_vote_select, ba_select.h), the 6x6 step is solved on one lane
+// with reciprocal-square-root pivots and the exponential's series (pose_step_from_sums).  Same arithmetic per point as k_pose_refine
+// up to fused multiply-adds; the order of the 27 sums differs (compacted slots, PRR_THREADS/64 wavefronts), i.e. results agree to
+// rounding (tests: 1e-10 on the pose), the median exactly (tests/cpp/vote_select_check.hip, the hard populations of tests/test_img_gpu.py).
+// Ten iterations at c3 (1000 points, 696 found): 94 -> 64 us in round 5.  Stamps (-DMCP_PRR_PROF, scripts/prr_prof.sh; cycles): entry to
+// the first iteration 12 k (two dependent trips to cold global memory, ~5 k each for one compute unit), a re-projecting pass 16 k (three
+// wavefront passes of ~1100 instructions per point on the busiest SIMD: the camera model with its correctly rounded arctangent),
+// a linear pass 1.8 k, the median 4.6 k (one counted step of eighths of a binade + <= 64 keys ranked) to 6.5 k (binade steps),
+// the 27 sums 2.0 k + their reduction 1.2-1.9 k, the step 2.0 k.
 #ifndef PRR_NT
 #define PRR_NT 512      // threads; 1024/PRR_NT points each.  256 x 4: 125.8 us per ten iterations at c3 (one wavefront per SIMD, 512 registers), 512 x 2: 102.4
 #endif                  // (two wavefronts per SIMD at 255 registers overlap each other's latencies), 1024 x 1: 176.7 (eight-wavefront barriers, spills)

@@ -8,8 +8,13 @@ mkdir -p ../../variants
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result"
 [ -f img_api.o ] || make img_api.o
 build() { name=$1; shift; /opt/rocm/bin/hipcc $FL "$@" -c -o /tmp/ba_$name.o ba_solver.hip && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so /tmp/ba_$name.o img_api.o -ldl && echo "built variants/lib_$name.so ($*)"; }
+# variants of the image library (tracker kernels): img_api.hip with extra flags, linked with the product's ba_solver.o
+[ -f ba_solver.o ] || make ba_solver.o
+build_img() { name=$1; shift; /opt/rocm/bin/hipcc $FL -ffp-contract=off "$@" -c -o /tmp/img_$name.o img_api.hip && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so ba_solver.o /tmp/img_$name.o -ldl && echo "built variants/lib_$name.so ($*)"; }
 for v in "$@"; do
   case $v in
+    prrprof) build_img prrprof -DMCP_PRR_PROF & ;;          # phase stamps of k_pose_refine_regs and of its last vote select (scripts/prr_prof.sh prints them)
+    prrnovote) build_img prrnovote -DPRR_NO_VOTE & ;;        # the Tukey median by histogram passes only (the fallback of the vote select, always)
     panel2) build panel2 -DMCP_CHOL_PANEL2=1 & ;;          # panel split over two wavefronts by column halves
     rsq2) build rsq2 -DCH_RSQ2=1 & ;;
     ld16) build ld16 -DCH_LOAD16=1 & ;;                  # k_chol_step: 16-byte tile loads
