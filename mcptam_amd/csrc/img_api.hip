@@ -80,6 +80,7 @@ struct mcp_kf {
   Buf<SearchCam> stab; Buf<DevTdIn> bt_in; Buf<mcp_td_out> bt_out;      // batched search: camera table + points of all cameras
   Buf<PfTargetDev> pf_tab; Buf<PfItemDev> pf_items; Buf<int> pf_seq; Buf<mcp_pf_state> pf_state;      // mcp_patch_sequences
   PinBuf<SearchCam> h_stab; PinBuf<DevTdIn> h_bt_in;                                                   // host staging of the batched search ...
+  PinBuf<mcp_td_out> h_bt_out;                                                                         // ... and, for mcp_track_frame, its results: the search kernel writes them here as well
   PinBuf<PfTargetDev> h_pf_tab; PinBuf<PfItemDev> h_pf_items; PinBuf<int> h_pf_seq; PinBuf<mcp_pf_state> h_pf_state;      // ... and of mcp_track_frame's finder sequences
   hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
@@ -126,8 +127,11 @@ void mcp_kf_destroy(mcp_kf* k) { if (k) { (void)hipSetDevice(k->device); delete 
 // MakeKeyFrame_Lite of every camera of a frame in one submission (the loop of Tracker::TrackFrame, src/Tracker.cc:303-318): the
 // uploads, three launches for all levels of all cameras (k_pyr_fast, k_row_count, k_row_compact) and one wait.
 // (enqueue on kfs[0]->st without waiting; lite_batch_finish after the stream has been waited for)
+// (ride: called after k_pyr_fast has been launched -- host work done here overlaps it -- to name up to two pinned-host -> device copies that
+//  k_row_count's grid then carries in one more z-slice, FrameBatch::up_*)
+struct FrameRide { int (*fn)(void* ctx, FrameBatch& B); void* ctx; };
 static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
-                              const uint8_t* const* const* masks) {
+                              const uint8_t* const* const* masks, const FrameRide* ride = nullptr) {
   if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !kfs || !imgs || !strides) return img_fail("mcp_kf_make_lite_batch: bad arguments");
   for (int c = 0; c < ncam; ++c) {
     if (!kfs[c] || !imgs[c] || kfs[c]->device != kfs[0]->device) return img_fail("mcp_kf_make_lite_batch: keyframes must live on one device");
@@ -181,7 +185,10 @@ static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const
       hipLaunchKernelGGL(k_glare_mask, dim3((unsigned)((npx + 255)/256)), dim3(256), 0, st, src, internal, L.mask.p, (int)npx);
     }
   }
-  hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
+  if (ride && ride->fn(ride->ctx, B)) return -1;
+  const int up = (B.up_n8[0] > 0 || B.up_n8[1] > 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam + up), dim3(256), 0, st, B);
+  B.up_n8[0] = B.up_n8[1] = 0;
   hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
   ICK(hipGetLastError());
   return 0;
@@ -339,7 +346,10 @@ int mcp_track_pose_refine(int n, mcp_pose_point* pts, int ncam, const mcp_camera
 // device scratch of the pose iterations, reused across calls.  The small inputs travel in ONE block (bytes): [BaseFromWorld 12 d | mu 6 d |
 // pad 6 d | override sigma n_iter d | CamFromBase 12 ncam d | camera models | nonlinear flags], the results [BaseFromWorld | mu] come back
 // in one copy: 2 uploads + 2-3 downloads per call instead of 6 + 4.
-struct RefineScratch { Buf<mcp_pose_point> dp, dp_keep; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; bool last_multi = false; };
+struct RefineScratch { Buf<mcp_pose_point> dp, dp_keep; Buf<uint8_t> dblk; Buf<double> dJ, dex, de2, dw; Buf<PrmScratch> dprm; Buf<double> de2all; std::vector<uint8_t> hblk; bool last_multi = false;
+                       // k_pose_refine_regs reads the block and leaves BaseFromWorld | mu and the weights in PINNED HOST memory: no upload of the
+                       // block, no fill of the weights, no copy back (three copy-engine operations and their queue switches per frame)
+                       PinBuf<uint8_t> pblk; PinBuf<double> pw; bool res_pinned = false; };
 // one scratch per (thread, device): the buffers live on the device that was current when they were allocated, and a thread that serves
 // keyframes on two devices must not hand one device's kernels the other's pointers
 static RefineScratch& refine_scratch() {
@@ -384,17 +394,26 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   std::memcpy(rs.hblk.data() + o_cam, cams, sizeof(mcp_camera)*(size_t)ncam);
   std::memcpy(rs.hblk.data() + o_nl, nonlinear, (size_t)n_iter);
   if (host_pts) ICK(hipMemcpyAsync(rs.dp.p, host_pts, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), blk, hipMemcpyHostToDevice, st));
-  ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
-  double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
-  const double* d_ov = reinterpret_cast<const double*>(rs.dblk.p + o_ov); const double* d_cfb = reinterpret_cast<const double*>(rs.dblk.p + o_cfb);
-  const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
+  rs.res_pinned = false;
   if (regs) {
-    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), PRR_DYN_LDS, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, d_mu, rs.dw.p, est, ncam);
+    if (rs.pblk.alloc(blk) || rs.pw.alloc(n)) return -1;
+    std::memcpy(rs.pblk.p, rs.hblk.data(), blk);
+    std::memset(rs.pw.p, 0, 8*(size_t)n);                       // weights stay zero when a point was not found
+    uint8_t* b = rs.pblk.p;
+    double* p_bfw = reinterpret_cast<double*>(b);
+    hipLaunchKernelGGL(k_pose_refine_regs, dim3(1), dim3(PRR_THREADS), PRR_DYN_LDS, st, n, rs.dp.p, reinterpret_cast<const mcp_camera*>(b + o_cam), reinterpret_cast<const double*>(b + o_cfb),
+                       p_bfw, n_iter, (const uint8_t*)(b + o_nl), reinterpret_cast<const double*>(b + o_ov), p_bfw + 12, rs.pw.p, est, ncam);
     if (hipGetLastError() != hipSuccess) {       // the launch was refused (123 KB of dynamic LDS): the plain kernel does the same work from global memory
       regs = false; regs_ok_mask &= ~dbit;
       if (alloc_plain()) return -1;
-    }
+    } else rs.res_pinned = true;
+  }
+  double* d_bfw = reinterpret_cast<double*>(rs.dblk.p); double* d_mu = d_bfw + 12;
+  const double* d_ov = reinterpret_cast<const double*>(rs.dblk.p + o_ov); const double* d_cfb = reinterpret_cast<const double*>(rs.dblk.p + o_cfb);
+  const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
+  if (!regs) {
+    ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), blk, hipMemcpyHostToDevice, st));
+    ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
   }
   *prm_err = 0;
   if (multi) {
@@ -439,11 +458,25 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   ICK(hipGetLastError());
   return 0;
 }
+// BaseFromWorld | mu (18 doubles) and the last weights to the caller: copies enqueued where the results are on the device; where the kernel
+// left them in pinned host memory they are taken from there once the stream has been waited for
+static int refine_results_enqueue(RefineScratch& rs, int n, double* back, double* weights_last, hipStream_t st) {
+  if (rs.res_pinned) return 0;
+  ICK(hipMemcpyAsync(back, rs.dblk.p, 18*sizeof(double), hipMemcpyDeviceToHost, st));
+  if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+  return 0;
+}
+static void refine_results_finish(RefineScratch& rs, int n, double* back, double* weights_last) {
+  if (!rs.res_pinned) return;
+  std::memcpy(back, rs.pblk.p, 18*sizeof(double));
+  if (weights_last) std::memcpy(weights_last, rs.pw.p, 8*(size_t)n);
+}
 // the multi-workgroup iterations gave up (prm_err): the same iterations again in ONE workgroup, from the kept copy of the points and the
 // parameter block still in the scratch's host image; results where refine_enqueue leaves them.  The stream has been waited for.
 static int refine_redo_single(int n, int n_iter, int ncam, int est, hipStream_t st) {
   RefineScratch& rs = refine_scratch();
   if (!rs.dp_keep.p || rs.hblk.empty()) return img_fail("pose iterations: nothing kept to redo them from");
+  rs.res_pinned = false;
   const size_t o_ov = 24*sizeof(double), o_cfb = o_ov + 8*(size_t)n_iter, o_cam = o_cfb + 96*(size_t)ncam, o_nl = o_cam + sizeof(mcp_camera)*(size_t)ncam;
   ICK(hipMemcpyAsync(rs.dp.p, rs.dp_keep.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToDevice, st));
   ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), rs.hblk.size(), hipMemcpyHostToDevice, st));
@@ -470,14 +503,13 @@ int mcp_track_pose_refine_m(int n, mcp_pose_point* pts, int ncam, const mcp_came
   RefineScratch& rs = refine_scratch();
   double back[18];
   ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
-  ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
-  if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+  if (refine_results_enqueue(rs, n, back, weights_last, st)) return -1;
   ICK(hipStreamSynchronize(st));
+  refine_results_finish(rs, n, back, weights_last);
   if (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP"))) {
     if (refine_redo_single(n, n_iter, ncam, est, st)) return -1;
     ICK(hipMemcpyAsync(pts, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToHost, st));
-    ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
-    if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)n, hipMemcpyDeviceToHost, st));
+    if (refine_results_enqueue(rs, n, back, weights_last, st)) return -1;
     ICK(hipStreamSynchronize(st));
   }
   std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48);
@@ -692,12 +724,12 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12]
   return 0;
 }
 
-// SearchForPoints of every camera of a frame in one launch (the per-camera loops of Tracker::TrackMap, src/Tracker.cc:985-1030, 1299-1384)
-// (the launch on targets[0]->st, results left in targets[0]->bt_out in camera-major order; *total_out = points of all cameras)
-static int search_batch_enqueue(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
-                                const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out, int* total_out) {
-  *total_out = 0;
-  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
+// pack: arguments checked, the camera table and the points of all cameras written to the pinned staging (targets[0]->h_stab / h_bt_in), device
+// buffers sized.  launch: the two uploads (unless something else has carried them: `uploaded`) and the kernel.
+static int search_batch_pack(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double* cfb, const int* n, const mcp_td_in* const* in,
+                             mcp_td_out* const* out, int* total_out, int* maxn_out) {
+  *total_out = 0; *maxn_out = 0;
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
   int total = 0, maxn = 0;
   for (int c = 0; c < ncam; ++c) {
     if (!targets[c] || n[c] < 0 || !cam_ok(&cams[c]) || targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || !out[c]))) return img_fail("mcp_track_search_batch: bad arguments");
@@ -722,12 +754,33 @@ static int search_batch_enqueue(int ncam, mcp_kf* const* targets, const mcp_came
     first += n[c];
   }
   if (k0->stab.alloc(MCP_MAX_FRAME_CAMS) || k0->bt_in.alloc(total) || k0->bt_out.alloc(total)) return -1;
+  *total_out = total; *maxn_out = maxn;
+  return 0;
+}
+static int search_batch_launch(int ncam, mcp_kf* k0, int total, int maxn, const double bfw[12], int range, int subpix_its, int exhaustive, bool uploaded,
+                               mcp_td_out* host_out, mcp_pose_point* pose_pts) {
+  static_assert(sizeof(SearchCam) % 8 == 0 && sizeof(DevTdIn) % 8 == 0, "the frame's upload slice copies 8-byte words");
   hipStream_t st = k0->st;
-  ICK(hipMemcpyAsync(k0->stab.p, tab, sizeof(SearchCam)*(size_t)ncam, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(k0->bt_in.p, h, sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
+  if (!uploaded) {
+    ICK(hipMemcpyAsync(k0->stab.p, k0->h_stab.p, sizeof(SearchCam)*(size_t)ncam, hipMemcpyHostToDevice, st));
+    ICK(hipMemcpyAsync(k0->bt_in.p, k0->h_bt_in.p, sizeof(DevTdIn)*(size_t)total, hipMemcpyHostToDevice, st));
+  }
   Se3 Bw; std::memcpy(Bw.R, bfw, 72); std::memcpy(Bw.t, bfw + 9, 24);
-  hipLaunchKernelGGL(k_track_search_batch, dim3(maxn, ncam), dim3(64), 0, st, (const SearchCam*)k0->stab.p, Bw, (const DevTdIn*)k0->bt_in.p, range, subpix_its, exhaustive, k0->bt_out.p);
+  hipLaunchKernelGGL(k_track_search_batch, dim3(maxn, ncam), dim3(64), 0, st, (const SearchCam*)k0->stab.p, Bw, (const DevTdIn*)k0->bt_in.p, range, subpix_its, exhaustive, k0->bt_out.p,
+                     host_out, pose_pts);
   ICK(hipGetLastError());
+  return 0;
+}
+// SearchForPoints of every camera of a frame in one launch (the per-camera loops of Tracker::TrackMap, src/Tracker.cc:985-1030, 1299-1384)
+// (the launch on targets[0]->st, results left in targets[0]->bt_out in camera-major order; *total_out = points of all cameras)
+static int search_batch_enqueue(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                                const mcp_td_in* const* in, int range, int subpix_its, int exhaustive, mcp_td_out* const* out, int* total_out) {
+  int total = 0, maxn = 0;
+  *total_out = 0;
+  if (!bfw) return img_fail("mcp_track_search_batch: bad arguments");
+  if (search_batch_pack(ncam, targets, cams, cfb, n, in, out, &total, &maxn)) return -1;
+  if (total == 0) return 0;
+  if (search_batch_launch(ncam, targets[0], total, maxn, bfw, range, subpix_its, exhaustive, false, nullptr, nullptr)) return -1;
   *total_out = total;
   return 0;
 }
@@ -829,39 +882,60 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   // ... and whatever fails after it waits for the stream before the stack variables the copies write to (back, prm_err) go away
   struct DrainOnError { hipStream_t st; bool armed; int ncam; mcp_kf* const* targets; bool lite; ~DrainOnError() { if (armed) { (void)hipStreamSynchronize(st); if (lite) (void)lite_batch_finish(ncam, targets); (void)hipGetLastError(); } } };
   DrainOnError drain{st, true, ncam, targets, imgs != nullptr};
-  if (imgs && lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks)) return -1;
-  int total = 0;
-  if (state) { if (track_sequences_enqueue(ncam, targets, cams, bfw, cfb, n, in, point_key, state, range, subpix_its, exhaustive, &total)) return -1; }
-  else if (search_batch_enqueue(ncam, targets, cams, bfw, cfb, n, in, range, subpix_its, exhaustive, out, &total)) return -1;
+  int total = 0, maxn = 0;
+  bool rode = false;              // the batched search's inputs went to the device inside k_row_count's launch
+  if (!state && imgs) {
+    // the search's camera table and points are packed on the host while the pyramids run, and ride to the device in the next launch
+    struct Ctx { int ncam; mcp_kf* const* targets; const mcp_camera* cams; const double* cfb; const int* n; const mcp_td_in* const* in; mcp_td_out* const* out; int* total; int* maxn; };
+    Ctx ctx{ncam, targets, cams, cfb, n, in, out, &total, &maxn};
+    FrameRide ride{[](void* c_, FrameBatch& B) -> int {
+      Ctx& c = *static_cast<Ctx*>(c_);
+      if (search_batch_pack(c.ncam, c.targets, c.cams, c.cfb, c.n, c.in, c.out, c.total, c.maxn)) return -1;
+      if (*c.total == 0) return 0;
+      mcp_kf* k0 = c.targets[0];
+      B.up_src[0] = reinterpret_cast<const unsigned long long*>(k0->h_stab.p); B.up_dst[0] = reinterpret_cast<unsigned long long*>(k0->stab.p); B.up_n8[0] = (int)(sizeof(SearchCam)*(size_t)c.ncam/8);
+      B.up_src[1] = reinterpret_cast<const unsigned long long*>(k0->h_bt_in.p); B.up_dst[1] = reinterpret_cast<unsigned long long*>(k0->bt_in.p); B.up_n8[1] = (int)(sizeof(DevTdIn)*(size_t)*c.total/8);
+      return 0; }, &ctx};
+    if (lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks, &ride)) return -1;
+    rode = true;
+  } else if (imgs && lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks)) return -1;
   ICK(hipSetDevice(k0->device));
+  RefineScratch& rs = refine_scratch();
+  bool out_pinned = false;        // the search kernel wrote the TrackerData results to pinned host memory as well
+  if (state) { if (track_sequences_enqueue(ncam, targets, cams, bfw, cfb, n, in, point_key, state, range, subpix_its, exhaustive, &total)) return -1; }
+  else {
+    if (!rode && search_batch_pack(ncam, targets, cams, cfb, n, in, out, &total, &maxn)) return -1;
+    if (total > 0) {
+      // the search leaves its results in pinned host memory too and writes the pose iterations' records itself (no packing launch)
+      if (k0->h_bt_out.alloc(total) || rs.dp.alloc(total)) return -1;
+      if (search_batch_launch(ncam, k0, total, maxn, bfw, range, subpix_its, exhaustive, rode, k0->h_bt_out.p, rs.dp.p)) return -1;
+      out_pinned = true;
+    }
+  }
   unsigned int prm_err = 0;
   double back[18];
-  RefineScratch& rs = refine_scratch();
   const bool iterate = total > 0 && n_iter > 0;
   if (total > 0) {
     if (rs.dp.alloc(total)) return -1;
     if (state) hipLaunchKernelGGL(k_pack_pose_points_items, dim3((total + 255)/256), dim3(256), 0, st, total, (const PfItemDev*)k0->pf_items.p, (const mcp_td_out*)k0->bt_out.p, rs.dp.p);
-    else hipLaunchKernelGGL(k_pack_pose_points, dim3((total + 255)/256), dim3(256), 0, st, total, (const SearchCam*)k0->stab.p, ncam, (const DevTdIn*)k0->bt_in.p,
-                            (const mcp_td_out*)k0->bt_out.p, rs.dp.p);
     if (iterate && refine_enqueue(total, nullptr, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, est, st, &prm_err)) return -1;
-    if (search_batch_copy_out(ncam, k0, n, out, total)) return -1;
+    if (!out_pinned && search_batch_copy_out(ncam, k0, n, out, total)) return -1;
     if (state) ICK(hipMemcpyAsync(k0->h_pf_state.p, k0->pf_state.p, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyDeviceToHost, st));
     if (pts_out) ICK(hipMemcpyAsync(pts_out, rs.dp.p, sizeof(mcp_pose_point)*(size_t)total, hipMemcpyDeviceToHost, st));
-    if (iterate) {
-      ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
-      if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)total, hipMemcpyDeviceToHost, st));
-    } else if (weights_last) std::memset(weights_last, 0, 8*(size_t)total);
+    if (iterate) { if (refine_results_enqueue(rs, total, back, weights_last, st)) return -1; }
+    else if (weights_last) std::memset(weights_last, 0, 8*(size_t)total);
   }
   ICK(hipStreamSynchronize(st));
   drain.armed = false;
   if (imgs && lite_batch_finish(ncam, targets)) return -1;
+  if (out_pinned) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(out[c], k0->h_bt_out.p + first, sizeof(mcp_td_out)*(size_t)n[c]); first += n[c]; } }
+  if (iterate) refine_results_finish(rs, total, back, weights_last);
   if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
   if (iterate && (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP")))) {
     // a workgroup of the multi-workgroup iterations gave up waiting for the others: the frame is not lost, one workgroup redoes them
     if (refine_redo_single(total, n_iter, ncam, est, st)) return -1;
     if (pts_out) ICK(hipMemcpyAsync(pts_out, rs.dp.p, sizeof(mcp_pose_point)*(size_t)total, hipMemcpyDeviceToHost, st));
-    ICK(hipMemcpyAsync(back, rs.dblk.p, sizeof back, hipMemcpyDeviceToHost, st));
-    if (weights_last) ICK(hipMemcpyAsync(weights_last, rs.dw.p, 8*(size_t)total, hipMemcpyDeviceToHost, st));
+    if (refine_results_enqueue(rs, total, back, weights_last, st)) return -1;
     ICK(hipStreamSynchronize(st));
   }
   if (iterate) { std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48); }

@@ -174,7 +174,11 @@ struct FrameCam {             // one camera of a frame: everything the three ker
   LevelInfo* host_info;                          // pinned, device-visible: the four levels' bookkeeping lands on the host with the frame
   int* work; int cap[MCP_LEVELS];
 };
-struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; int detect_t[MCP_LEVELS]; };
+struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; int detect_t[MCP_LEVELS];
+                    // mcp_track_frame: the search's small inputs (camera table, tracked points; pinned host memory) are copied to the device by
+                    // one more z-slice of k_row_count's grid, beside the pyramid's own work: no copy-engine operation (and its two
+                    // ~8 us switches between compute and copy queue) between the corner tables and the search
+                    const unsigned long long* up_src[2]; unsigned long long* up_dst[2]; int up_n8[2]; };
 
 __global__ void __launch_bounds__(PYR_NT)
 k_pyr_fast(const FrameBatch B) {
@@ -279,6 +283,12 @@ __device__ inline bool corner_kept(const FrameCam& C, int l, int wl, int x, int 
 }
 __global__ void __launch_bounds__(256)
 k_row_count(const FrameBatch B) {
+  if ((int)blockIdx.z == B.ncam) {               // the upload slice
+    const int nth = (int)(gridDim.x*gridDim.y)*256, t0 = (int)(blockIdx.y*gridDim.x + blockIdx.x)*256 + (int)threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) for (int i = t0; i < B.up_n8[r]; i += nth) B.up_dst[r][i] = B.up_src[r][i];
+    return;
+  }
   const int l = blockIdx.y; const FrameCam& C = B.c[blockIdx.z];
   const int wl = C.w >> l, hl = C.h >> l, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x*4 >= hl) return;
@@ -517,7 +527,9 @@ __device__ __forceinline__ int pf_iterate(const uint8_t* __restrict__ limg, int 
 // one item of one finder, one wavefront (control flow is wave-uniform: every lane computes the geometry redundantly)
 __device__ __forceinline__ void patch_item(int mode, const DevKfView& T, const uint8_t* __restrict__ mask0, const mcp_camera& cam, const Se3& bfw, const Se3& cfb,
                                            const DevTdIn& P, int point_key, double start_x, double start_y, PfRegs& S, uint8_t* tmpl, uint8_t* jtmpl,
-                                           mcp_td_out& O, int range, int subpix_its, int exhaustive, double (*dprod)[36], int lane) {
+                                           mcp_td_out& O, int range, int subpix_its, int exhaustive, double (*dprod)[36], int lane,
+                                           mcp_td_out* O2 = nullptr /* a second copy of the record (pinned host memory), or null */,
+                                           mcp_pose_point* PP = nullptr /* the record the pose iterations read (k_pack_pose_points), or null */, int cam_index = 0) {
   const int MAXSSD = 8*8*250;
   Se3 cfw; se3_compose(cfb, bfw, cfw);
   double xc[3]; se3_apply(cfw, P.world_pos, xc);
@@ -684,14 +696,36 @@ __device__ __forceinline__ void patch_item(int mode, const DevKfView& T, const u
     O.in_image = in_image; O.search_level = level; O.template_bad = template_bad; O.searched = searched;
     O.found = found; O.did_subpix = did_subpix; O.coarse_x = bx; O.coarse_y = by; O.score = best;
   }
+  if (O2) {
+    O2->templ[lane] = have_templ ? tmpl[lane] : (uint8_t)0;
+    if (lane == 0) {
+      O2->image[0] = pr.u; O2->image[1] = pr.v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { O2->cam_derivs[k] = pr.D[k]; O2->warp_inverse[k] = WI[k]; }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) O2->jacobian[k] = J[k];
+      O2->found_pos[0] = fpos[0]; O2->found_pos[1] = fpos[1]; O2->sqrt_inv_noise = sinv;
+      O2->in_image = in_image; O2->search_level = level; O2->template_bad = template_bad; O2->searched = searched;
+      O2->found = found; O2->did_subpix = did_subpix; O2->coarse_x = bx; O2->coarse_y = by; O2->score = best;
+    }
+  }
+  if (PP && lane == 0) {
+    PP->world_pos[0] = P.world_pos[0]; PP->world_pos[1] = P.world_pos[1]; PP->world_pos[2] = P.world_pos[2];
+    PP->found_pos[0] = fpos[0]; PP->found_pos[1] = fpos[1]; PP->sqrt_inv_noise = sinv;
+    PP->image[0] = pr.u; PP->image[1] = pr.v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) PP->cam_derivs[k] = pr.D[k];
+    PP->cam = cam_index; PP->found = found;
+  }
 }
 
 // one tracked point, one wavefront: Tracker::SearchForPoints with a PatchFinder that has seen nothing yet (the per-frame batch
 // entries; a caller that keeps the finders across frames uses k_patch_sequences)
 __device__ __forceinline__ void track_search_point(const DevKfView& T, const mcp_camera& cam, const Se3& bfw, const Se3& cfb, const DevTdIn& P, mcp_td_out& O,
-                                                   int range, int subpix_its, int exhaustive, uint8_t* tmpl, uint8_t* jtmpl, double (*dprod)[36], int lane) {
+                                                   int range, int subpix_its, int exhaustive, uint8_t* tmpl, uint8_t* jtmpl, double (*dprod)[36], int lane,
+                                                   mcp_td_out* O2 = nullptr, mcp_pose_point* PP = nullptr, int cam_index = 0) {
   PfRegs S; S.valid = 0; S.key = -1; S.bad = 0; S.jvalid = 0; S.lw[0] = S.lw[1] = S.lw[2] = S.lw[3] = 0.0; S.mean = 0.0;
-  patch_item(PF_TRACK, T, nullptr, cam, bfw, cfb, P, 0, 0.0, 0.0, S, tmpl, jtmpl, O, range, subpix_its, exhaustive, dprod, lane);
+  patch_item(PF_TRACK, T, nullptr, cam, bfw, cfb, P, 0, 0.0, 0.0, S, tmpl, jtmpl, O, range, subpix_its, exhaustive, dprod, lane, O2, PP, cam_index);
 }
 __global__ void __launch_bounds__(64)
 k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTdIn* __restrict__ in, int range,
@@ -706,13 +740,16 @@ k_track_search(DevKfView T, mcp_camera cam, Se3 bfw, Se3 cfb, int n, const DevTd
 struct SearchCam { DevKfView T; mcp_camera cam; Se3 cfb; int n, first; };
 __global__ void __launch_bounds__(64)
 k_track_search_batch(const SearchCam* __restrict__ tab, Se3 bfw, const DevTdIn* __restrict__ in, int range, int subpix_its, int exhaustive,
-                     mcp_td_out* __restrict__ out) {
+                     mcp_td_out* __restrict__ out, mcp_td_out* __restrict__ host_out /* the results once more, in pinned host memory (mcp_track_frame: no
+                     copy back), or null */, mcp_pose_point* __restrict__ pose_pts /* the pose iterations' records (in place of k_pack_pose_points), or null */) {
   __shared__ uint8_t tmpl[64], jtmpl[64];
   __shared__ double dprod[3][36];
   const SearchCam& S = tab[blockIdx.y];
   const int pi = blockIdx.x;
   if (pi >= S.n) return;
-  track_search_point(S.T, S.cam, bfw, S.cfb, in[S.first + pi], out[S.first + pi], range, subpix_its, exhaustive, tmpl, jtmpl, dprod, threadIdx.x);
+  const int idx = S.first + pi;
+  track_search_point(S.T, S.cam, bfw, S.cfb, in[idx], out[idx], range, subpix_its, exhaustive, tmpl, jtmpl, dprod, threadIdx.x,
+                     host_out ? host_out + idx : nullptr, pose_pts ? pose_pts + idx : nullptr, (int)blockIdx.y);
 }
 // Sequences of items through stateful finders: one wavefront per sequence, items in order, the finder's members in registers /
 // LDS between them and in `state` before and after.  tab: the targets (keyframe view, camera, poses; SearchCam::n / first unused).

@@ -62,6 +62,10 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
         return sum(int(o_["found"].sum()) for o_ in outs)
 
     assert fused_frame() == found
+    if os.environ.get("TRK_FUSED_ONLY"):               # (scripts/gpu_trk_trace.sh: a clean trace of the one-submission frames)
+        for _ in range(frames):
+            fused_frame()
+        return {"fused_only": frames}
     t0 = time.perf_counter()
     in_lib = 0.0
     for _ in range(frames):
