@@ -413,7 +413,7 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
   const mcp_camera* d_cam = reinterpret_cast<const mcp_camera*>(rs.dblk.p + o_cam); const uint8_t* d_nl = rs.dblk.p + o_nl;
   if (!regs) {
     ICK(hipMemcpyAsync(rs.dblk.p, rs.hblk.data(), blk, hipMemcpyHostToDevice, st));
-    ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
+    if (!multi) ICK(hipMemsetAsync(rs.dw.p, 0, 8*(size_t)n, st));             // weights stay zero when no point was found
   }
   *prm_err = 0;
   if (multi) {
@@ -436,9 +436,13 @@ static int refine_enqueue(int n, const mcp_pose_point* host_pts, int ncam, const
     // caller redoes the iterations with the single-workgroup kernel from this copy of the points (refine_redo_single)
     if (rs.dp_keep.alloc(n)) return -1;
     ICK(hipMemcpyAsync(rs.dp_keep.p, rs.dp.p, sizeof(mcp_pose_point)*(size_t)n, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), dyn, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est, rs.dprm.p,
-                       gather ? rs.de2all.p : (double*)nullptr);
+    // (the parameters stay in device memory -- this kernel reads the camera models inside its iterations --, the results go to pinned host memory)
+    if (rs.pblk.alloc(blk) || rs.pw.alloc(n)) return -1;
+    std::memset(rs.pw.p, 0, 8*(size_t)n);
+    hipLaunchKernelGGL(k_pose_refine_multi, dim3(nwg), dim3(PRM_THREADS), dyn, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.pw.p, est, rs.dprm.p,
+                       gather ? rs.de2all.p : (double*)nullptr, reinterpret_cast<double*>(rs.pblk.p));
     ICK(hipGetLastError());
+    rs.res_pinned = true;
     ICK(hipMemcpyAsync(prm_err, &rs.dprm.p->err, sizeof *prm_err, hipMemcpyDeviceToHost, st));
   } else if (!regs)
     hipLaunchKernelGGL(k_pose_refine, dim3(1), dim3(PR_THREADS), 0, st, n, rs.dp.p, d_cam, d_cfb, d_bfw, n_iter, d_nl, d_ov, rs.dJ.p, rs.dex.p, rs.de2.p, d_mu, rs.dw.p, est);

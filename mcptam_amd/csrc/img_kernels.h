@@ -1310,7 +1310,8 @@ __global__ void __launch_bounds__(PRM_THREADS)
 k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* __restrict__ cams, const double* __restrict__ cfb_all,
                     double* __restrict__ bfw_io, int n_iter, const uint8_t* __restrict__ nonlinear, const double* __restrict__ override_sigma,
                     double* __restrict__ J, double* __restrict__ ex /* 2n */, double* __restrict__ e2s, double* __restrict__ mu_out, double* __restrict__ w_out,
-                    int est, PrmScratch* __restrict__ G, double* __restrict__ e2_all /* 2 x n, or null: per-digit global histograms */) {
+                    int est, PrmScratch* __restrict__ G, double* __restrict__ e2_all /* 2 x n, or null: per-digit global histograms */,
+                    double* __restrict__ res_host /* BaseFromWorld | mu once more, for pinned host memory (no copy back), or null */) {
   extern __shared__ double sh_e2[];            // gather mode: everybody's squared errors
   __shared__ unsigned int hist[SEL_BINS];
   __shared__ unsigned long long sel_sc[1024/64 + 3], sel_st[2];
@@ -1474,6 +1475,7 @@ k_pose_refine_multi(int n, mcp_pose_point* __restrict__ pts, const mcp_camera* _
   if (wg == 0) {
     if (t < 12) bfw_io[t] = pose[t];
     if (t < 6) mu_out[t] = v6[t];
+    if (res_host) { if (t < 12) res_host[t] = pose[t]; if (t < 6) res_host[12 + t] = v6[t]; }
   }
 }
 
