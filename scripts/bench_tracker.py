@@ -95,7 +95,7 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
            "gpu_ms_per_frame_three_calls": gdt3*1e3, "gpu_ms_per_frame_in_library": in_lib*1e3, "found_per_frame": found,
            "cpu_oracle_frames_per_s": 1/cdt, "cpu_cores": 1,
            "algorithmic_bytes_per_frame": int(px*(1.64 + 1.33) + npts*1500),
-           "note": "one submission per frame (mcp_track_frame): 3 launches for the pyramids + FAST of all cameras and levels, 1 for the searches, 1 packing the pose points on the device, 1 for the ten pose iterations, one wait; images resident in HBM (the PCIe-inclusive time is reported beside it).  gpu_ms_per_frame_in_library = the mcp_track_frame call alone (what a native caller pays; the rest is the Python harness); gpu_ms_per_frame_three_calls = the same work as mcp_kf_make_lite_batch + mcp_track_search_batch + host packing + mcp_track_pose_refine (identical results)"}
+           "note": "one submission per frame (mcp_track_frame): 3 launches for the pyramids + FAST of all cameras and levels (the second carries the search's inputs to the device), 1 for the searches (results also to pinned host memory, pose records written in place), 1 for the ten pose iterations (parameters from, pose and weights to pinned host memory), one wait, no copy-engine operation; images resident in HBM (the PCIe-inclusive time is reported beside it).  gpu_ms_per_frame_in_library = the mcp_track_frame call alone (what a native caller pays; the rest is the Python harness); gpu_ms_per_frame_three_calls = the same work as mcp_kf_make_lite_batch + mcp_track_search_batch + host packing + mcp_track_pose_refine (identical results)"}
     res["hbm_roofline"] = {"bound": "hbm", "achieved": res["algorithmic_bytes_per_frame"]/gdt/1e9, "peak": 8000.0, "unit": "GB/s",
                            "frac": res["algorithmic_bytes_per_frame"]/gdt/1e9/8000.0}
     res["speedup_vs_cpu_1thread"] = cdt/gdt
