@@ -12,6 +12,7 @@
 //   k_backsub / k_update_poses   back-substitution + oplus        :82-86, :237-281
 #pragma once
 #include "ba_device.h"
+#include "ba_select.h"
 
 namespace mcp {
 
@@ -611,6 +612,30 @@ __global__ void k_tukey_flags(int n, const double* __restrict__ chi2, double s2,
   const double e = fabs(chi2[m]);
   const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
   flag[m] = (sq*sq == 0.0) ? 1 : 0;
+}
+
+// The same with the threshold taken on the device from the median the head of the last iteration left in the result block (res[med_idx]):
+// Tukey::FindSigmaSquared (MEstimator.h:109-124) with the floor of ChainBundle.cc:1377-1383, the host's expression operation for operation --
+// the flags need no round trip through the host between the median and this kernel.
+__global__ void k_tukey_flags_dev(int n, const double* __restrict__ chi2, const double* __restrict__ res, int med_idx, double m_total, double min_sigma,
+                                  unsigned char* __restrict__ flag) {
+  const int m = blockIdx.x*blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  double s = 1.4826*(1 + 5.0/mest_denom(m_total))*sqrt(res[med_idx]);
+  s = 4.6851*s;
+  double s2 = s*s;
+  const double mins = min_sigma*min_sigma;
+  if (s2 < mins) s2 = mins;
+  const double e = fabs(chi2[m]);
+  const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
+  flag[m] = (sq*sq == 0.0) ? 1 : 0;
+}
+// the state of a solve (poses 12 doubles each, points 3) to ONE destination -- pinned host memory: two copies into pageable vectors were
+// ~90 us of copy-engine operations and queue switches at the end of every BundleAdjustRecent call
+__global__ void k_export_state(size_t nps, size_t npt, const double* __restrict__ pose, const double* __restrict__ pt, double* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
+  if (i < nps) dst[i] = pose[i];
+  else if (i < nps + npt) dst[i] = pt[i - nps];
 }
 
 // (2,2) entry of each free point's marginal covariance: Vi[2][2] + u^T Sinv u, u = W Vi[:,2]

@@ -167,6 +167,10 @@ class PinnedArena {
     void* r = (char*)blocks_.back().p + used_; used_ += bytes; total_ += bytes;
     return r;
   }
+  bool is_pinned(const void* p) const {      // (device-visible: a kernel may read it in place)
+    for (auto& b : blocks_) if ((const char*)p >= (const char*)b.p && (const char*)p < (const char*)b.p + b.size) return b.pinned;
+    return false;
+  }
   void reset() {      // nothing of the arena is in use any more
     if (blocks_.size() > 1) {      // settle on one block that holds a whole build
       size_t sum = 0; for (auto& b : blocks_) { sum += b.size; if (b.pinned) (void)hipHostFree(b.p); else std::free(b.p); }
@@ -196,6 +200,27 @@ template <class T> using avec = std::vector<T, ArenaAlloc<T>>;
 // end of a build (any exit path): the copies out of the arena have to be done before it is handed to the next build
 struct ArenaGuard { hipStream_t st; ~ArenaGuard() { if (st) (void)hipStreamSynchronize(st); pinned_arena().reset(); } };
 static HostPool& host_pool() { static HostPool p(std::min(16, usable_cores())); return p; }
+
+// Small uploads and fills of a Prepare() as ONE launch: up to eight ranges of 8-byte words, each copied from pinned host memory (read in place
+// over the bus) or -- source null -- zeroed.  A copy-engine operation between kernels costs its 4-9 us plus ~9 us of queue switch on either
+// side; a BundleAdjustRecent window made eleven of them per call.  Large uploads stay with the copy engine (UPSET_MAX_BYTES).
+struct UploadSet { const unsigned long long* src[8]; unsigned long long* dst[8]; unsigned long long n8[8]; int n; };
+constexpr size_t UPSET_MAX_BYTES = (size_t)1 << 20;
+__global__ void k_upload_set(UploadSet U) {
+  const int r = blockIdx.y;
+  const size_t nth = (size_t)gridDim.x*blockDim.x;
+  const unsigned long long* sp = U.src[r]; unsigned long long* dp = U.dst[r];
+  for (size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x; i < U.n8[r]; i += nth) dp[i] = sp ? sp[i] : 0ull;
+}
+static void upload_set_add(UploadSet& U, const void* src, void* dst, size_t bytes) {
+  U.src[U.n] = (const unsigned long long*)src; U.dst[U.n] = (unsigned long long*)dst; U.n8[U.n] = (bytes + 7)/8; ++U.n;
+}
+static void upload_set_launch(const UploadSet& U, hipStream_t st) {
+  if (U.n == 0) return;
+  size_t mx = 0; for (int r = 0; r < U.n; ++r) mx = std::max<size_t>(mx, U.n8[r]);
+  const unsigned bx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (mx + 255)/256));
+  hipLaunchKernelGGL(k_upload_set, dim3(bx, U.n), dim3(256), 0, st, U);
+}
 
 // std::allocator whose resize(n) leaves new elements uninitialised (bulk entries size the arrays once and fill every record)
 template <class T> struct NoInitAlloc : std::allocator<T> {
@@ -470,6 +495,15 @@ struct mcp_ba {
   DevBuf<int> d_fail;
   static constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
   double* h_res = nullptr;  // pinned, device-visible; [32..63] is the mailbox k_final_sums writes (ticket at 32 + MAIL_TICKET)
+  unsigned char* h_exp = nullptr; size_t h_exp_cap = 0; bool exported = false;      // pinned: the state [poses | points] and the Tukey flags of a finished solve, written by kernels (final_stats)
+  int ensure_export(size_t bytes) {
+    if (bytes <= h_exp_cap) return 0;
+    if (h_exp) mcp::PinnedCache::get().put(h_exp, h_exp_cap, hipHostMallocMapped | hipHostMallocCoherent, device);
+    size_t cap = 65536; while (cap < bytes) cap <<= 1;               // (size classes: the next handle of a similar map finds it in the cache)
+    h_exp = (unsigned char*)mcp::PinnedCache::get().take(cap, hipHostMallocMapped | hipHostMallocCoherent); h_exp_cap = h_exp ? cap : 0;
+    if (!h_exp) { set_err("hipHostMalloc failed"); return -1; }
+    return 0;
+  }
   unsigned long long mail_ticket = 0; int use_mailbox = 1; double* h_mail_dev = nullptr;
   int* h_fail = nullptr;    // pinned
 
@@ -524,6 +558,7 @@ struct mcp_ba {
     drain();
     for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q] && !pooled) (void)hipStreamDestroy(st_tr[q]);
     if (h_res) mcp::PinnedCache::get().put(h_res, HRES*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, device);
+    if (h_exp) mcp::PinnedCache::get().put(h_exp, h_exp_cap, hipHostMallocMapped | hipHostMallocCoherent, device);
     if (h_fail) mcp::PinnedCache::get().put(h_fail, 4*sizeof(int), hipHostMallocDefault, device);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) (void)hipGraphExecDestroy(chol_exec[q]);
@@ -1718,15 +1753,21 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
         };
         if (T == 1) body(0); else pool.run(body);
       }
-      if (nm) {
-        HIPCK(hipMemcpyAsync(d_m_u.p, vals, nm*sizeof(double), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_m_v.p, vals + nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
-        HIPCK(hipMemcpyAsync(d_m_omega.p, vals + 2*nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
-      }
-      if (!cams.empty()) {
-        mcp_camera* cs = (mcp_camera*)pinned_arena().alloc(cams.size()*sizeof(mcp_camera));
-        std::memcpy(cs, cams.data(), cams.size()*sizeof(mcp_camera));
-        HIPCK(hipMemcpyAsync(d_cams.p, cs, cams.size()*sizeof(mcp_camera), hipMemcpyHostToDevice, st));
+      mcp_camera* cs = cams.empty() ? nullptr : (mcp_camera*)pinned_arena().alloc(cams.size()*sizeof(mcp_camera));
+      if (cs) std::memcpy(cs, cams.data(), cams.size()*sizeof(mcp_camera));
+      static_assert(sizeof(mcp_camera) % 8 == 0, "k_upload_set copies 8-byte words");
+      if (3*nm*sizeof(double) <= UPSET_MAX_BYTES && pinned_arena().is_pinned(vals) && (!cs || pinned_arena().is_pinned(cs))) {
+        UploadSet V; V.n = 0;             // a small bundle: the kernel reads the pinned values in place
+        if (nm) { upload_set_add(V, vals, d_m_u.p, nm*sizeof(double)); upload_set_add(V, vals + nm, d_m_v.p, nm*sizeof(double)); upload_set_add(V, vals + 2*nm, d_m_omega.p, nm*sizeof(double)); }
+        if (cs) upload_set_add(V, cs, d_cams.p, cams.size()*sizeof(mcp_camera));
+        upload_set_launch(V, st);
+      } else {
+        if (nm) {
+          HIPCK(hipMemcpyAsync(d_m_u.p, vals, nm*sizeof(double), hipMemcpyHostToDevice, st));
+          HIPCK(hipMemcpyAsync(d_m_v.p, vals + nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
+          HIPCK(hipMemcpyAsync(d_m_omega.p, vals + 2*nm, nm*sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        if (cs) HIPCK(hipMemcpyAsync(d_cams.p, cs, cams.size()*sizeof(mcp_camera), hipMemcpyHostToDevice, st));
       }
     }
     // the small ones: contiguous runs of staged items are contiguous in the device block too -- one copy per run
@@ -1804,9 +1845,18 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   for (int q = 1; q < MAX_SYS; ++q)
     if (d_sxp[q].alloc(np) || d_sxl[q].alloc((size_t)nfl*3) || d_sp0[q].alloc(nblk) || d_sp1[q].alloc(nblk) || d_sp2[q].alloc(nblk)) return -1;
   if (!h_fail) { h_fail = (int*)mcp::PinnedCache::get().take(4*sizeof(int), hipHostMallocDefault); if (!h_fail) { set_err("hipHostMalloc failed"); return -1; } }
-  HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));       // x = 0 before the first solve
-  HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
-  HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st)); sig_par = 0;
+  if (((size_t)np + (size_t)nfl*3)*sizeof(double) <= UPSET_MAX_BYTES) {      // x = 0 before the first solve, no sigma block yet: one launch
+    UploadSet Z; Z.n = 0;
+    upload_set_add(Z, nullptr, d_xp_good.p, std::max<size_t>(np, 1)*sizeof(double));
+    upload_set_add(Z, nullptr, d_xl_good.p, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double));
+    upload_set_add(Z, nullptr, d_sigma.p, 16*sizeof(double));
+    upload_set_launch(Z, st);
+  } else {
+    HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));
+    HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
+    HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st));
+  }
+  sig_par = 0;
 
   P.cams = d_cams.p; P.ncam = (int)cams.size(); P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
   P.npose = npose; P.pose_unk = d_pose_unk.p; P.npoint = npoint; P.pt_chain = d_pt_chain.p; P.pt_unk = d_pt_unk.p;
@@ -1843,15 +1893,15 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
 // poses and points of the host state into every state buffer (current + one per trial candidate): fixed poses and points are never
 // written by a trial, so every buffer has to hold them.  One staged copy through the pinned arena (the caller, prepare(), holds it
 // until its final stream synchronisation) and one kernel that fans it out -- ten pageable hipMemcpyAsync were 0.2 ms of a window's set-up.
-struct StateFan { double* pose[MAX_SYS]; double* pt[MAX_SYS]; };
+struct StateFan { double* pose[MAX_SYS + 1]; double* pt[MAX_SYS + 1]; int first; };
 __global__ void k_fan_state(size_t npose_d, size_t npt_d, const double* __restrict__ pose0, const double* __restrict__ pt0, StateFan f) {
   const size_t i = blockIdx.x*(size_t)blockDim.x + threadIdx.x;
   if (i < npose_d) { const double v = pose0[i];
 #pragma unroll
-    for (int b = 0; b < MAX_SYS; ++b) f.pose[b][i] = v; }
+    for (int b = 0; b <= MAX_SYS; ++b) if (b >= f.first) f.pose[b][i] = v; }
   if (i < npt_d) { const double v = pt0[i];
 #pragma unroll
-    for (int b = 0; b < MAX_SYS; ++b) f.pt[b][i] = v; }
+    for (int b = 0; b <= MAX_SYS; ++b) if (b >= f.first) f.pt[b][i] = v; }
 }
 int mcp_ba::upload_state() {
   const size_t nps = poses.size()*12, npt = points.size()*3;
@@ -1859,15 +1909,27 @@ int mcp_ba::upload_state() {
   for (size_t i = 0; i < poses.size(); ++i) std::memcpy(stage + i*12, poses[i].T, 96);
   for (size_t i = 0; i < points.size(); ++i) std::memcpy(stage + nps + i*3, points[i].x, 24);
   cur = 0;
-  if (nps) HIPCK(hipMemcpyAsync(d_pose[0].p, stage, nps*8, hipMemcpyHostToDevice, st));
-  if (npt) HIPCK(hipMemcpyAsync(d_pt[0].p, stage + nps, npt*8, hipMemcpyHostToDevice, st));
-  StateFan f;
-  for (int b = 0; b < MAX_SYS; ++b) { f.pose[b] = d_pose[b + 1].p; f.pt[b] = d_pt[b + 1].p; }
+  // a small state is read by the fan-out kernel straight from the pinned stage (no copy-engine operation); a large one is copied first
+  const bool in_place = (nps + npt)*8 <= UPSET_MAX_BYTES && pinned_arena().is_pinned(stage);
+  if (!in_place) {
+    if (nps) HIPCK(hipMemcpyAsync(d_pose[0].p, stage, nps*8, hipMemcpyHostToDevice, st));
+    if (npt) HIPCK(hipMemcpyAsync(d_pt[0].p, stage + nps, npt*8, hipMemcpyHostToDevice, st));
+  }
+  StateFan f; f.first = in_place ? 0 : 1;
+  for (int b = 0; b <= MAX_SYS; ++b) { f.pose[b] = d_pose[b].p; f.pt[b] = d_pt[b].p; }
   const size_t nmax = std::max(nps, npt);
-  if (nmax) hipLaunchKernelGGL(k_fan_state, dim3((unsigned)((nmax + 255)/256)), dim3(256), 0, st, nps, npt, (const double*)d_pose[0].p, (const double*)d_pt[0].p, f);
+  if (nmax) hipLaunchKernelGGL(k_fan_state, dim3((unsigned)((nmax + 255)/256)), dim3(256), 0, st, nps, npt, in_place ? (const double*)stage : (const double*)d_pose[0].p,
+                               in_place ? (const double*)(stage + nps) : (const double*)d_pt[0].p, f);
   return 0;
 }
 int mcp_ba::download_state() {
+  if (exported) {                                  // final_stats() had the state written to pinned host memory, and has waited for it
+    exported = false;
+    const double* ps = reinterpret_cast<const double*>(h_exp); const double* pt = ps + poses.size()*12;
+    for (size_t i = 0; i < poses.size(); ++i) std::memcpy(poses[i].T, ps + i*12, 96);
+    for (size_t i = 0; i < points.size(); ++i) std::memcpy(points[i].x, pt + i*3, 24);
+    return 0;
+  }
   std::vector<double> pt((size_t)points.size()*3), ps((size_t)poses.size()*12);
   if (!ps.empty()) HIPCK(hipMemcpyAsync(ps.data(), d_pose[cur].p, ps.size()*8, hipMemcpyDeviceToHost, st));
   if (!pt.empty()) HIPCK(hipMemcpyAsync(pt.data(), d_pt[cur].p, pt.size()*8, hipMemcpyDeviceToHost, st));
@@ -2664,14 +2726,30 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
 
 // ChainBundle.cc:1339-1345 (final sigma^2), :1368-1399 (Tukey outliers), :1401-1448 (depth covariance)
 int mcp_ba::final_stats(int nCounter) {
+  exported = false;
   if (m_total == 0 || dirty) { max_cov = 0; return 0; }
+  // Behind the kernels that leave the median in the result block, and BEFORE the one wait for that block: the Tukey flags (threshold from the
+  // median on the device) and the state, both written to pinned host memory by kernels -- one wait at the end of a solve instead of three,
+  // no copy into pageable memory.
+  const size_t exp_state = (poses.size()*12 + points.size()*3)*sizeof(double);
+  const bool flags_dev = tukey && nCounter != 0 && P.nmeas > 0;
+  auto enqueue_export = [&](int med_idx) -> int {
+    if (ensure_export(exp_state + (size_t)P.nmeas)) return -1;
+    if (flags_dev) hipLaunchKernelGGL(k_tukey_flags_dev, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, (const double*)d_res.p, med_idx, (double)m_total,
+                                      prm.min_mestimator_sigma, h_exp + exp_state);
+    const size_t nps = poses.size()*12, npt = points.size()*3;
+    if (nps + npt) hipLaunchKernelGGL(k_export_state, dim3((unsigned)((nps + npt + 255)/256)), dim3(256), 0, st, nps, npt, (const double*)d_pose[cur].p, (const double*)d_pt[cur].p, reinterpret_cast<double*>(h_exp));
+    return 0;
+  };
   // a trial evaluated ahead that nobody consumed may still be running on the second stream and reads the sigma block of the parity
   // median_sigma() is about to rewrite: order everything behind it first (it had only ever been joined by the next solve)
   if (join_spec()) return -2;
   if (small_mode() && robust) {
     // small bundle: median, sigma block and robust chi2 of the final state in one launch (ba_small.h), one read-back
     if (head_small(cur)) return -2;
+    if (enqueue_export(28)) return -2;
     if (read_results(29)) return -2;
+    exported = true;
     h_res[0] = h_res[24];
     for (int i = 0; i < 4; ++i) h_res[9 + i] = h_res[25 + i];
   } else {
@@ -2681,7 +2759,9 @@ int mcp_ba::final_stats(int nCounter) {
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
   if (allreduce(d_res.p, 1, 0, false, "final robust chi2")) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (enqueue_export(12)) return -2;
   if (read_results(13)) return -2;
+  exported = true;
   }
   if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
   mean_chi2 = h_res[0]/m_total;
@@ -2693,10 +2773,8 @@ int mcp_ba::final_stats(int nCounter) {
     double s2 = s*s;
     const double mins = prm.min_mestimator_sigma*prm.min_mestimator_sigma;
     if (s2 < mins) s2 = mins;
-    if (P.nmeas) hipLaunchKernelGGL(k_tukey_flags, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, s2, d_flags.p);
-    std::vector<unsigned char> fl(P.nmeas);
-    HIPCK(hipMemcpyAsync(fl.data(), d_flags.p, P.nmeas, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
+    (void)s2;                                      // (the flags were taken on the device with this very threshold: k_tukey_flags_dev, above)
+    const unsigned char* fl = h_exp + exp_state;
     std::vector<unsigned char> by_add(P.nmeas, 0);
     for (int j = 0; j < P.nmeas; ++j) if (fl[j]) by_add[perm[j]] = 1;
     for (int i = 0; i < P.nmeas; ++i) if (by_add[i]) {
