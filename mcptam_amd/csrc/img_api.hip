@@ -81,7 +81,7 @@ struct mcp_kf {
   Buf<PfTargetDev> pf_tab; Buf<PfItemDev> pf_items; Buf<int> pf_seq; Buf<mcp_pf_state> pf_state;      // mcp_patch_sequences
   PinBuf<SearchCam> h_stab; PinBuf<DevTdIn> h_bt_in;                                                   // host staging of the batched search ...
   PinBuf<mcp_td_out> h_bt_out;                                                                         // ... and, for mcp_track_frame, its results: the search kernel writes them here as well
-  PinBuf<PfTargetDev> h_pf_tab; PinBuf<PfItemDev> h_pf_items; PinBuf<int> h_pf_seq; PinBuf<mcp_pf_state> h_pf_state;      // ... and of mcp_track_frame's finder sequences
+  PinBuf<PfTargetDev> h_pf_tab; PinBuf<PfItemDev> h_pf_items; PinBuf<int> h_pf_seq; PinBuf<mcp_pf_state> h_pf_state, h_pf_state_out;      // ... and of mcp_track_frame's finder sequences (states in / out)
   hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
   Buf<uint8_t> sbi_small; Buf<float> sbi_templ, sbi_jacs; bool has_sbi = false;
@@ -186,9 +186,9 @@ static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const
     }
   }
   if (ride && ride->fn(ride->ctx, B)) return -1;
-  const int up = (B.up_n8[0] > 0 || B.up_n8[1] > 0) ? 1 : 0;
+  const int up = (B.up_n8[0] > 0 || B.up_n8[1] > 0 || B.up_n8[2] > 0 || B.up_n8[3] > 0) ? 1 : 0;
   hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam + up), dim3(256), 0, st, B);
-  B.up_n8[0] = B.up_n8[1] = 0;
+  B.up_n8[0] = B.up_n8[1] = B.up_n8[2] = B.up_n8[3] = 0;
   hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
   ICK(hipGetLastError());
   return 0;
@@ -820,9 +820,8 @@ int mcp_track_search_batch(int ncam, mcp_kf* const* targets, const mcp_camera* c
 // (mcp_track_search_batch, or -- with finder states -- mcp_patch_sequences in MCP_PF_TRACK mode, one single-item sequence per point) and
 // mcp_track_pose_refine_m back to back on the frame's stream, the TrackerData -> pose-point packing in between done on the device, one wait at
 // the end.  Same kernels on the same data as the three calls: identical results.
-static int track_sequences_enqueue(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
-                                   const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state, int range, int subpix_its,
-                                   int exhaustive, int* total_out) {
+static int track_sequences_pack(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double bfw[12], const double* cfb, const int* n,
+                                const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state, int* total_out) {
   *total_out = 0;
   int total = 0;
   for (int c = 0; c < ncam; ++c) {
@@ -831,7 +830,7 @@ static int track_sequences_enqueue(int ncam, mcp_kf* const* targets, const mcp_c
   }
   if (total == 0) return 0;
   mcp_kf* k0 = targets[0];
-  if (k0->h_pf_tab.alloc(MCP_MAX_FRAME_CAMS) || k0->h_pf_items.alloc(total) || k0->h_pf_seq.alloc(total + 1) || k0->h_pf_state.alloc(total)) return -1;
+  if (k0->h_pf_tab.alloc(MCP_MAX_FRAME_CAMS) || k0->h_pf_items.alloc(total) || k0->h_pf_seq.alloc(total + 2) || k0->h_pf_state.alloc(total) || k0->h_pf_state_out.alloc(total)) return -1;
   PfTargetDev* tab = k0->h_pf_tab.p; PfItemDev* h = k0->h_pf_items.p; int* seq = k0->h_pf_seq.p; mcp_pf_state* hs = k0->h_pf_state.p;
   for (int c = 0; c < ncam; ++c) {
     PfTargetDev& D = tab[c];
@@ -853,17 +852,25 @@ static int track_sequences_enqueue(int ncam, mcp_kf* const* targets, const mcp_c
     first += n[c];
   }
   for (int i = 0; i <= total; ++i) seq[i] = i;
+  seq[total + 1] = 0;                              // (padding: the ride copies 8-byte words)
   ICK(hipSetDevice(k0->device));
-  hipStream_t st = k0->st;
-  if (k0->pf_tab.alloc(ncam) || k0->pf_items.alloc(total) || k0->pf_seq.alloc(total + 1) || k0->pf_state.alloc(total) || k0->bt_out.alloc(total)) return -1;
-  ICK(hipMemcpyAsync(k0->pf_tab.p, tab, sizeof(PfTargetDev)*(size_t)ncam, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(k0->pf_items.p, h, sizeof(PfItemDev)*(size_t)total, hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(k0->pf_seq.p, seq, sizeof(int)*(size_t)(total + 1), hipMemcpyHostToDevice, st));
-  ICK(hipMemcpyAsync(k0->pf_state.p, hs, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_patch_sequences, dim3(total), dim3(64), 0, st, (int)MCP_PF_TRACK, (const PfTargetDev*)k0->pf_tab.p, total, (const int*)k0->pf_seq.p,
-                     (const PfItemDev*)k0->pf_items.p, k0->pf_state.p, range, subpix_its, exhaustive, k0->bt_out.p);
-  ICK(hipGetLastError());
+  if (k0->pf_tab.alloc(MCP_MAX_FRAME_CAMS) || k0->pf_items.alloc(total) || k0->pf_seq.alloc(total + 2) || k0->pf_state.alloc(total) || k0->bt_out.alloc(total)) return -1;
   *total_out = total;
+  return 0;
+}
+static int track_sequences_launch(int ncam, mcp_kf* k0, int total, int range, int subpix_its, int exhaustive, bool uploaded, mcp_td_out* host_out, mcp_pf_state* host_state,
+                                  mcp_pose_point* pose_pts) {
+  static_assert(sizeof(PfTargetDev) % 8 == 0 && sizeof(PfItemDev) % 8 == 0 && sizeof(mcp_pf_state) % 8 == 0, "the frame's upload slice copies 8-byte words");
+  hipStream_t st = k0->st;
+  if (!uploaded) {
+    ICK(hipMemcpyAsync(k0->pf_tab.p, k0->h_pf_tab.p, sizeof(PfTargetDev)*(size_t)ncam, hipMemcpyHostToDevice, st));
+    ICK(hipMemcpyAsync(k0->pf_items.p, k0->h_pf_items.p, sizeof(PfItemDev)*(size_t)total, hipMemcpyHostToDevice, st));
+    ICK(hipMemcpyAsync(k0->pf_seq.p, k0->h_pf_seq.p, sizeof(int)*(size_t)(total + 1), hipMemcpyHostToDevice, st));
+    ICK(hipMemcpyAsync(k0->pf_state.p, k0->h_pf_state.p, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(k_patch_sequences, dim3(total), dim3(64), 0, st, (int)MCP_PF_TRACK, (const PfTargetDev*)k0->pf_tab.p, total, (const int*)k0->pf_seq.p,
+                     (const PfItemDev*)k0->pf_items.p, k0->pf_state.p, range, subpix_its, exhaustive, k0->bt_out.p, host_out, host_state, pose_pts);
+  ICK(hipGetLastError());
   return 0;
 }
 int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
@@ -887,27 +894,47 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   struct DrainOnError { hipStream_t st; bool armed; int ncam; mcp_kf* const* targets; bool lite; ~DrainOnError() { if (armed) { (void)hipStreamSynchronize(st); if (lite) (void)lite_batch_finish(ncam, targets); (void)hipGetLastError(); } } };
   DrainOnError drain{st, true, ncam, targets, imgs != nullptr};
   int total = 0, maxn = 0;
-  bool rode = false;              // the batched search's inputs went to the device inside k_row_count's launch
-  if (!state && imgs) {
-    // the search's camera table and points are packed on the host while the pyramids run, and ride to the device in the next launch
-    struct Ctx { int ncam; mcp_kf* const* targets; const mcp_camera* cams; const double* cfb; const int* n; const mcp_td_in* const* in; mcp_td_out* const* out; int* total; int* maxn; };
-    Ctx ctx{ncam, targets, cams, cfb, n, in, out, &total, &maxn};
-    FrameRide ride{[](void* c_, FrameBatch& B) -> int {
+  bool rode = false;              // the search's inputs went to the device inside k_row_count's launch
+  // the search's tables and points are packed on the host while the pyramids run, and ride to the device in the next launch
+  struct Ctx { int ncam; mcp_kf* const* targets; const mcp_camera* cams; const double* bfw; const double* cfb; const int* n; const mcp_td_in* const* in; const int* const* point_key;
+               mcp_pf_state* const* state; mcp_td_out* const* out; int* total; int* maxn; };
+  Ctx ctx{ncam, targets, cams, bfw, cfb, n, in, point_key, state, out, &total, &maxn};
+  auto words = [](size_t bytes) { return (int)((bytes + 7)/8); };
+  if (imgs) {
+    FrameRide ride{nullptr, &ctx};
+    if (!state) ride.fn = [](void* c_, FrameBatch& B) -> int {
       Ctx& c = *static_cast<Ctx*>(c_);
       if (search_batch_pack(c.ncam, c.targets, c.cams, c.cfb, c.n, c.in, c.out, c.total, c.maxn)) return -1;
       if (*c.total == 0) return 0;
       mcp_kf* k0 = c.targets[0];
       B.up_src[0] = reinterpret_cast<const unsigned long long*>(k0->h_stab.p); B.up_dst[0] = reinterpret_cast<unsigned long long*>(k0->stab.p); B.up_n8[0] = (int)(sizeof(SearchCam)*(size_t)c.ncam/8);
       B.up_src[1] = reinterpret_cast<const unsigned long long*>(k0->h_bt_in.p); B.up_dst[1] = reinterpret_cast<unsigned long long*>(k0->bt_in.p); B.up_n8[1] = (int)(sizeof(DevTdIn)*(size_t)*c.total/8);
-      return 0; }, &ctx};
+      return 0; };
+    else ride.fn = [](void* c_, FrameBatch& B) -> int {
+      Ctx& c = *static_cast<Ctx*>(c_);
+      if (track_sequences_pack(c.ncam, c.targets, c.cams, c.bfw, c.cfb, c.n, c.in, c.point_key, c.state, c.total)) return -1;
+      if (*c.total == 0) return 0;
+      mcp_kf* k0 = c.targets[0]; const size_t t = (size_t)*c.total;
+      const void* src[4] = { k0->h_pf_tab.p, k0->h_pf_items.p, k0->h_pf_seq.p, k0->h_pf_state.p };
+      void* dst[4] = { k0->pf_tab.p, k0->pf_items.p, k0->pf_seq.p, k0->pf_state.p };
+      const size_t bytes[4] = { sizeof(PfTargetDev)*(size_t)c.ncam, sizeof(PfItemDev)*t, sizeof(int)*(t + 1), sizeof(mcp_pf_state)*t };
+      for (int r = 0; r < 4; ++r) { B.up_src[r] = static_cast<const unsigned long long*>(src[r]); B.up_dst[r] = static_cast<unsigned long long*>(dst[r]); B.up_n8[r] = (int)((bytes[r] + 7)/8); }
+      return 0; };
     if (lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks, &ride)) return -1;
     rode = true;
-  } else if (imgs && lite_batch_enqueue(ncam, targets, imgs, strides, imgs_on_device, masks)) return -1;
+  }
+  (void)words;
   ICK(hipSetDevice(k0->device));
   RefineScratch& rs = refine_scratch();
-  bool out_pinned = false;        // the search kernel wrote the TrackerData results to pinned host memory as well
-  if (state) { if (track_sequences_enqueue(ncam, targets, cams, bfw, cfb, n, in, point_key, state, range, subpix_its, exhaustive, &total)) return -1; }
-  else {
+  bool out_pinned = false;        // the search kernel wrote the TrackerData results (and the finder states) to pinned host memory as well
+  if (state) {
+    if (!rode && track_sequences_pack(ncam, targets, cams, bfw, cfb, n, in, point_key, state, &total)) return -1;
+    if (total > 0) {
+      if (k0->h_bt_out.alloc(total) || rs.dp.alloc(total)) return -1;
+      if (track_sequences_launch(ncam, k0, total, range, subpix_its, exhaustive, rode, k0->h_bt_out.p, k0->h_pf_state_out.p, rs.dp.p)) return -1;
+      out_pinned = true;
+    }
+  } else {
     if (!rode && search_batch_pack(ncam, targets, cams, cfb, n, in, out, &total, &maxn)) return -1;
     if (total > 0) {
       // the search leaves its results in pinned host memory too and writes the pose iterations' records itself (no packing launch)
@@ -920,11 +947,8 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   double back[18];
   const bool iterate = total > 0 && n_iter > 0;
   if (total > 0) {
-    if (rs.dp.alloc(total)) return -1;
-    if (state) hipLaunchKernelGGL(k_pack_pose_points_items, dim3((total + 255)/256), dim3(256), 0, st, total, (const PfItemDev*)k0->pf_items.p, (const mcp_td_out*)k0->bt_out.p, rs.dp.p);
     if (iterate && refine_enqueue(total, nullptr, ncam, cams, cfb, bfw, n_iter, nonlinear, override_sigma, est, st, &prm_err)) return -1;
     if (!out_pinned && search_batch_copy_out(ncam, k0, n, out, total)) return -1;
-    if (state) ICK(hipMemcpyAsync(k0->h_pf_state.p, k0->pf_state.p, sizeof(mcp_pf_state)*(size_t)total, hipMemcpyDeviceToHost, st));
     if (pts_out) ICK(hipMemcpyAsync(pts_out, rs.dp.p, sizeof(mcp_pose_point)*(size_t)total, hipMemcpyDeviceToHost, st));
     if (iterate) { if (refine_results_enqueue(rs, total, back, weights_last, st)) return -1; }
     else if (weights_last) std::memset(weights_last, 0, 8*(size_t)total);
@@ -934,7 +958,7 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   if (imgs && lite_batch_finish(ncam, targets)) return -1;
   if (out_pinned) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(out[c], k0->h_bt_out.p + first, sizeof(mcp_td_out)*(size_t)n[c]); first += n[c]; } }
   if (iterate) refine_results_finish(rs, total, back, weights_last);
-  if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
+  if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state_out.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
   if (iterate && (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP")))) {
     // a workgroup of the multi-workgroup iterations gave up waiting for the others: the frame is not lost, one workgroup redoes them
     if (refine_redo_single(total, n_iter, ncam, est, st)) return -1;

@@ -178,7 +178,7 @@ struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; i
                     // mcp_track_frame: the search's small inputs (camera table, tracked points; pinned host memory) are copied to the device by
                     // one more z-slice of k_row_count's grid, beside the pyramid's own work: no copy-engine operation (and its two
                     // ~8 us switches between compute and copy queue) between the corner tables and the search
-                    const unsigned long long* up_src[2]; unsigned long long* up_dst[2]; int up_n8[2]; };
+                    const unsigned long long* up_src[4]; unsigned long long* up_dst[4]; int up_n8[4]; };
 
 __global__ void __launch_bounds__(PYR_NT)
 k_pyr_fast(const FrameBatch B) {
@@ -286,7 +286,7 @@ k_row_count(const FrameBatch B) {
   if ((int)blockIdx.z == B.ncam) {               // the upload slice
     const int nth = (int)(gridDim.x*gridDim.y)*256, t0 = (int)(blockIdx.y*gridDim.x + blockIdx.x)*256 + (int)threadIdx.x;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) for (int i = t0; i < B.up_n8[r]; i += nth) B.up_dst[r][i] = B.up_src[r][i];
+    for (int r = 0; r < 4; ++r) for (int i = t0; i < B.up_n8[r]; i += nth) B.up_dst[r][i] = B.up_src[r][i];
     return;
   }
   const int l = blockIdx.y; const FrameCam& C = B.c[blockIdx.z];
@@ -529,7 +529,7 @@ __device__ __forceinline__ void patch_item(int mode, const DevKfView& T, const u
                                            const DevTdIn& P, int point_key, double start_x, double start_y, PfRegs& S, uint8_t* tmpl, uint8_t* jtmpl,
                                            mcp_td_out& O, int range, int subpix_its, int exhaustive, double (*dprod)[36], int lane,
                                            mcp_td_out* O2 = nullptr /* a second copy of the record (pinned host memory), or null */,
-                                           mcp_pose_point* PP = nullptr /* the record the pose iterations read (k_pack_pose_points), or null */, int cam_index = 0) {
+                                           mcp_pose_point* PP = nullptr /* the record the pose iterations read (what the loops of Tracker::TrackMap take from vTD after SearchForPoints, src/Tracker.cc:1040-1075: world position, found position, noise, projection + camera derivatives at the search pose, camera, found flag), or null */, int cam_index = 0) {
   const int MAXSSD = 8*8*250;
   Se3 cfw; se3_compose(cfb, bfw, cfw);
   double xc[3]; se3_apply(cfw, P.world_pos, xc);
@@ -741,7 +741,7 @@ struct SearchCam { DevKfView T; mcp_camera cam; Se3 cfb; int n, first; };
 __global__ void __launch_bounds__(64)
 k_track_search_batch(const SearchCam* __restrict__ tab, Se3 bfw, const DevTdIn* __restrict__ in, int range, int subpix_its, int exhaustive,
                      mcp_td_out* __restrict__ out, mcp_td_out* __restrict__ host_out /* the results once more, in pinned host memory (mcp_track_frame: no
-                     copy back), or null */, mcp_pose_point* __restrict__ pose_pts /* the pose iterations' records (in place of k_pack_pose_points), or null */) {
+                     copy back), or null */, mcp_pose_point* __restrict__ pose_pts /* the pose iterations' records, or null */) {
   __shared__ uint8_t tmpl[64], jtmpl[64];
   __shared__ double dprod[3][36];
   const SearchCam& S = tab[blockIdx.y];
@@ -757,7 +757,9 @@ struct PfItemDev { DevTdIn p; int point_key, target; double start_x, start_y; };
 struct PfTargetDev { DevKfView T; const uint8_t* mask0; mcp_camera cam; Se3 bfw, cfb; };
 __global__ void __launch_bounds__(64)
 k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, const int* __restrict__ seq_start, const PfItemDev* __restrict__ items,
-                  mcp_pf_state* __restrict__ state, int range, int subpix_its, int exhaustive, mcp_td_out* __restrict__ out) {
+                  mcp_pf_state* __restrict__ state, int range, int subpix_its, int exhaustive, mcp_td_out* __restrict__ out,
+                  mcp_td_out* __restrict__ host_out = nullptr /* mcp_track_frame: the results and ... */, mcp_pf_state* __restrict__ host_state = nullptr /* ... the finders' states once more,
+                  in pinned host memory (no copies back) */, mcp_pose_point* __restrict__ pose_pts = nullptr /* the pose iterations' records */) {
   __shared__ uint8_t tmpl[64], jtmpl[64];
   __shared__ double dprod[3][36];
   const int sq = blockIdx.x, lane = threadIdx.x;
@@ -770,7 +772,8 @@ k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, cons
   for (int i = seq_start[sq]; i < seq_start[sq + 1]; ++i) {
     const PfItemDev& I = items[i];
     const PfTargetDev& Tg = tab[I.target];
-    patch_item(mode, Tg.T, Tg.mask0, Tg.cam, Tg.bfw, Tg.cfb, I.p, I.point_key, I.start_x, I.start_y, S, tmpl, jtmpl, out[i], range, subpix_its, exhaustive, dprod, lane);
+    patch_item(mode, Tg.T, Tg.mask0, Tg.cam, Tg.bfw, Tg.cfb, I.p, I.point_key, I.start_x, I.start_y, S, tmpl, jtmpl, out[i], range, subpix_its, exhaustive, dprod, lane,
+               host_out ? host_out + i : nullptr, pose_pts ? pose_pts + i : nullptr, I.target);
     __syncthreads();
   }
   G.templ[lane] = tmpl[lane]; G.jac_templ[lane] = jtmpl[lane];
@@ -778,41 +781,14 @@ k_patch_sequences(int mode, const PfTargetDev* __restrict__ tab, int n_seq, cons
     G.valid = S.valid; G.point_key = S.key; G.template_bad = S.bad; G.jacs_valid = S.jvalid; G.mean_diff = S.mean;
     G.last_warp[0] = S.lw[0]; G.last_warp[1] = S.lw[1]; G.last_warp[2] = S.lw[2]; G.last_warp[3] = S.lw[3];
   }
-}
-
-// TrackerData -> the records the pose iterations read (what the loops of Tracker::TrackMap take from vTD after SearchForPoints,
-// src/Tracker.cc:1040-1075): world position, found position, noise, projection + camera derivatives at the search pose, camera, found flag.
-// `tab` is the batched search's camera table (first point / count per camera), `in` / `o` its inputs and results in camera-major order.
-__global__ void __launch_bounds__(256)
-k_pack_pose_points(int total, const SearchCam* __restrict__ tab, int ncam, const DevTdIn* __restrict__ in, const mcp_td_out* __restrict__ o,
-                   mcp_pose_point* __restrict__ p) {
-  const int i = blockIdx.x*256 + threadIdx.x;
-  if (i >= total) return;
-  int c = 0;
-  while (c + 1 < ncam && i >= tab[c + 1].first) ++c;          // the last camera that starts at or before i (empty cameras share a start with their successor)
-  mcp_pose_point q;
-  q.world_pos[0] = in[i].world_pos[0]; q.world_pos[1] = in[i].world_pos[1]; q.world_pos[2] = in[i].world_pos[2];
-  q.found_pos[0] = o[i].found_pos[0]; q.found_pos[1] = o[i].found_pos[1];
-  q.sqrt_inv_noise = o[i].sqrt_inv_noise;
-  q.image[0] = o[i].image[0]; q.image[1] = o[i].image[1];
-  q.cam_derivs[0] = o[i].cam_derivs[0]; q.cam_derivs[1] = o[i].cam_derivs[1]; q.cam_derivs[2] = o[i].cam_derivs[2]; q.cam_derivs[3] = o[i].cam_derivs[3];
-  q.cam = c; q.found = o[i].found;
-  p[i] = q;
-}
-
-// the same from the items of k_patch_sequences run as one single-item sequence per tracked point (item i = point i; camera = its target)
-__global__ void __launch_bounds__(256)
-k_pack_pose_points_items(int total, const PfItemDev* __restrict__ items, const mcp_td_out* __restrict__ o, mcp_pose_point* __restrict__ p) {
-  const int i = blockIdx.x*256 + threadIdx.x;
-  if (i >= total) return;
-  mcp_pose_point q;
-  q.world_pos[0] = items[i].p.world_pos[0]; q.world_pos[1] = items[i].p.world_pos[1]; q.world_pos[2] = items[i].p.world_pos[2];
-  q.found_pos[0] = o[i].found_pos[0]; q.found_pos[1] = o[i].found_pos[1];
-  q.sqrt_inv_noise = o[i].sqrt_inv_noise;
-  q.image[0] = o[i].image[0]; q.image[1] = o[i].image[1];
-  q.cam_derivs[0] = o[i].cam_derivs[0]; q.cam_derivs[1] = o[i].cam_derivs[1]; q.cam_derivs[2] = o[i].cam_derivs[2]; q.cam_derivs[3] = o[i].cam_derivs[3];
-  q.cam = items[i].target; q.found = o[i].found;
-  p[i] = q;
+  if (host_state) {
+    mcp_pf_state& H = host_state[sq];
+    H.templ[lane] = tmpl[lane]; H.jac_templ[lane] = jtmpl[lane];
+    if (lane == 0) {
+      H.valid = S.valid; H.point_key = S.key; H.template_bad = S.bad; H.jacs_valid = S.jvalid; H.mean_diff = S.mean;
+      H.last_warp[0] = S.lw[0]; H.last_warp[1] = S.lw[1]; H.last_warp[2] = S.lw[2]; H.last_warp[3] = S.lw[3];
+    }
+  }
 }
 
 // ---- Tracker::CalcPoseUpdate ------------------------------------------------------------------------

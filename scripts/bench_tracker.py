@@ -78,6 +78,19 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
     for _ in range(frames):
         fused_frame(True)
     gdt_pcie = (time.perf_counter() - t0)/frames
+    # the same frame with the PatchFinders kept from frame to frame (mcp_pf_state per (point, camera): what Tracker::TrackMap's persistent
+    # finders are; the shim's Tracker uses this form): states up and down every frame
+    tfs = TrackFrame(cur, carr, cfb_arr, packed, stateful=True)
+
+    def stateful_frame():
+        outs, _recs, _pose, _mu, _w = tfs.run(ring, sc["poseB"], 10, 8, on_device=True, want_points=False)
+        return sum(int(o_["found"].sum()) for o_ in outs)
+
+    stateful_frame()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        stateful_frame()
+    gdt_state = (time.perf_counter() - t0)/frames
     ocur = [OracleKeyFrame(*size) for _ in range(cams)]
     t0 = time.perf_counter()
     for _ in range(cpu_frames):
@@ -92,7 +105,7 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
     px = cams*size[0]*size[1]
     res = {"metric": "Tracker frames/s (%s: %d x %dx%d, %d tracked points/frame, 10 pose iterations)" % (label, cams, size[0], size[1], npts),
            "gpu_frames_per_s": 1/gdt, "gpu_ms_per_frame": gdt*1e3, "gpu_ms_per_frame_with_pcie_upload": gdt_pcie*1e3,
-           "gpu_ms_per_frame_three_calls": gdt3*1e3, "gpu_ms_per_frame_in_library": in_lib*1e3, "found_per_frame": found,
+           "gpu_ms_per_frame_three_calls": gdt3*1e3, "gpu_ms_per_frame_in_library": in_lib*1e3, "gpu_ms_per_frame_stateful_finders": gdt_state*1e3, "found_per_frame": found,
            "cpu_oracle_frames_per_s": 1/cdt, "cpu_cores": 1,
            "algorithmic_bytes_per_frame": int(px*(1.64 + 1.33) + npts*1500),
            "note": "one submission per frame (mcp_track_frame): 3 launches for the pyramids + FAST of all cameras and levels (the second carries the search's inputs to the device), 1 for the searches (results also to pinned host memory, pose records written in place), 1 for the ten pose iterations (parameters from, pose and weights to pinned host memory), one wait, no copy-engine operation; images resident in HBM (the PCIe-inclusive time is reported beside it).  gpu_ms_per_frame_in_library = the mcp_track_frame call alone (what a native caller pays; the rest is the Python harness); gpu_ms_per_frame_three_calls = the same work as mcp_kf_make_lite_batch + mcp_track_search_batch + host packing + mcp_track_pose_refine (identical results)"}
