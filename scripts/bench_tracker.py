@@ -46,9 +46,9 @@ def main(frames=20, cpu_frames=2, size=(640, 480), cams=4, per_level=(100, 80, 5
         pose, mu, w, _ = track_pose_refine(recs, carr, cfb_arr, sc["poseB"])      # all 10 iterations, one launch
         return found
 
-    gpu_frame()
+    found = gpu_frame()
     t0 = time.perf_counter()
-    for _ in range(frames):
+    for _ in range(0 if os.environ.get("TRK_FUSED_ONLY") else frames):
         found = gpu_frame()
     gdt3 = (time.perf_counter() - t0)/frames
     # the same frame through mcp_track_frame: one submission, the pose points packed on the device (bit-identical results,
