@@ -267,7 +267,9 @@ int mcp_track_pose_refine_sharded_m(int n, mcp_pose_point* pts, int ncam, const 
  *   mcp_track_pose_refine_m(total, ..., n_iter, nonlinear, override_sigma, ..., estimator) over the points of all cameras.
  * Same kernels on the same data as the separate calls: out[c] (n[c] results), pts_out (total records as the iterations left them,
  * may be NULL), base_from_world (in: the prior, out: refined), mu_last, weights_last (total, camera-major; may be NULL) are bit-identical
- * to theirs.  n_iter = 0: search only.  The two host round trips between the three calls are what it saves. */
+ * to theirs.  n_iter = 0: search only.  It saves the two host round trips between the three calls, and with a fresh frame (imgs != NULL) every
+ * copy-engine operation: the small inputs ride to the device inside the pyramids' second launch, the results are written to pinned host memory
+ * by the kernels that produce them and copied into the caller's arrays after the one wait (five kernels back to back on the device). */
 int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs, const int* strides, int imgs_on_device,
                     const uint8_t* const* const* masks, const mcp_camera* cams, double base_from_world[12], const double* cam_from_base /* ncam x 12 */,
                     const int* n, const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state,
