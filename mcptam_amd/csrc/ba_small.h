@@ -41,6 +41,10 @@ __device__ unsigned long long g_hs_prof[16];
 #endif
 constexpr int HS_AGG = 6;
 constexpr int HS_CAND = 2048;
+// the elements that share the guessed digit 0 (sign + ten exponent bits: two binades, a third to a half of a chi2 array) are kept in LDS as the
+// first sweep finds them: the second sweep -- the same 155 KB through ONE compute unit's ~128 cache lines in flight, 11 k cycles -- then runs over
+// that stash (dynamic LDS, one region per wavefront; a region that overflows: the sweep over the array, as before)
+constexpr int HS_STASH = 14336;
 // sum over the wavefront in the association of `for (o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64)` (lane 0's value; the other
 // lanes hold partial trees), without the LDS crossbar: lanes i+32 and i+16 through v_permlane32_swap / v_permlane16_swap, the four
 // steps inside a 16-lane row through DPP row shifts
@@ -102,6 +106,8 @@ k_head_small(int n, int robust, const double* __restrict__ chi2, unsigned long l
   __shared__ double s_sig[2];
   __shared__ double red[4];
   __shared__ double wpart[SMALL_MEAS/64];
+  __shared__ unsigned int nstash;
+  extern __shared__ double stash[];              // HS_STASH doubles
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   HS_STAMP(0);
   if (robust) {
@@ -113,25 +119,34 @@ k_head_small(int n, int robust, const double* __restrict__ chi2, unsigned long l
     const double guess = (sig_prev[3] != 0.0) ? sig_prev[3] : chi2[n/2];
     const unsigned int pred = (unsigned int)(((unsigned long long)__double_as_longlong(fabs(guess))) >> sh0) & (SEL_BINS - 1);
     for (int b = t; b < SEL_BINS; b += 1024) hist1[b] = 0u;
-    if (t == 0) ncand = 0u;
+    if (t == 0) { ncand = 0u; nstash = 0u; }
     __syncthreads();
-    unsigned int cl = 0u, ce = 0u;                   // (wavefront-uniform)
+    unsigned int cl = 0u, ce = 0u, mystash = 0u;     // (wavefront-uniform)
     hs_sweep(chi2, n, [&](bool valid, double v) {
       const unsigned long long key = (unsigned long long)__double_as_longlong(fabs(v));
       const unsigned int b0 = (unsigned int)(key >> sh0) & (SEL_BINS - 1);
       cl += (unsigned int)__popcll(__ballot(valid && b0 < pred));
-      ce += (unsigned int)__popcll(__ballot(valid && b0 == pred));
-      if (valid && b0 == pred) atomicAdd(&hist1[(unsigned int)(key >> sh1) & (SEL_BINS - 1)], 1u);
+      const unsigned long long me = __ballot(valid && b0 == pred);
+      ce += (unsigned int)__popcll(me);
+      if (valid && b0 == pred) {
+        atomicAdd(&hist1[(unsigned int)(key >> sh1) & (SEL_BINS - 1)], 1u);
+        // the wavefront's own region of the stash, its lanes' slots by their rank in the vote: no shared counter, no wait
+        const unsigned int slot = mystash + __builtin_amdgcn_mbcnt_hi((unsigned int)(me >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)me, 0u));
+        if (slot < (unsigned int)(HS_STASH/16)) stash[wave*(HS_STASH/16) + slot] = fabs(v);
+      }
+      mystash += (unsigned int)__popcll(me);
     });
-    if (lane == 0) { wcnt[wave][0] = cl; wcnt[wave][1] = ce; }
+    if (lane == 0) { wcnt[wave][0] = cl; wcnt[wave][1] = ce; if (mystash > (unsigned int)(HS_STASH/16)) atomicOr(&nstash, 1u); }      // (nstash: "a region overflowed")
     __syncthreads();
     HS_STAMP(1);
     unsigned long long below = 0ull, equal = 0ull;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { below += wcnt[w][0]; equal += wcnt[w][1]; }
     int bin0 = (int)pred; unsigned long long k1 = k - below;
+    bool stashed = nstash == 0u;                     // (uniform; complete: the barrier above)
     HS_STAMP(2);
     if (!(below <= k && k < below + equal)) {         // (uniform) the guess was wrong: both digits the long way
+      stashed = false;
       for (int b = t; b < SEL_BINS; b += 1024) { hist0[b] = 0u; hist1[b] = 0u; }
       __syncthreads();
       hs_sweep(chi2, n, [&](bool valid, double v) {
@@ -153,6 +168,16 @@ k_head_small(int n, int robust, const double* __restrict__ chi2, unsigned long l
     HS_STAMP(4);
     const unsigned long long prefix = ((unsigned long long)bin0 << sh0) | ((unsigned long long)bin1 << sh1);
     const unsigned long long himask = ~0ull << sh1;
+    if (stashed) {
+      const unsigned int ns = wcnt[wave][1];           // (this wavefront's matches = the fill of its region)
+      for (unsigned int i = lane; i < ns; i += 64u) {
+        const double a = stash[wave*(HS_STASH/16) + i];
+        if ((((unsigned long long)__double_as_longlong(a)) & himask) == prefix) {
+          const unsigned int idx = atomicAdd(&ncand, 1u);
+          if (idx < (unsigned int)HS_CAND) cand[idx] = a;
+        }
+      }
+    } else
     hs_sweep(chi2, n, [&](bool valid, double v) {
       const double a = fabs(v);
       if (valid && (((unsigned long long)__double_as_longlong(a)) & himask) == prefix) {
@@ -164,7 +189,20 @@ k_head_small(int n, int robust, const double* __restrict__ chi2, unsigned long l
     HS_STAMP(5);
     const unsigned int nc = ncand;
     unsigned long long sel;
-    if (nc <= (unsigned int)HS_CAND)
+    if (nc <= 64u) {
+      // a handful of candidates (the usual case): candidate j's rank is the number of candidates below it (equal ones by position); the
+      // one of rank k2 is the median -- no histogram passes for a wavefront's worth of keys
+      if (t == 0) s_st[0] = 0ull;
+      __syncthreads();
+      if (t < (int)nc) {
+        const unsigned long long mine = (unsigned long long)__double_as_longlong(cand[t]);
+        unsigned int r = 0u;
+        for (unsigned int j = 0; j < nc; ++j) { const unsigned long long o = (unsigned long long)__double_as_longlong(cand[j]); r += (o < mine || (o == mine && j < (unsigned int)t)) ? 1u : 0u; }
+        if ((unsigned long long)r == k2) s_st[0] = mine;
+      }
+      __syncthreads();
+      sel = s_st[0];
+    } else if (nc <= (unsigned int)HS_CAND)
       sel = lds_radix_select<1024>((int)nc, k2, 2, prefix, [&](int i, unsigned long long& key) { key = (unsigned long long)__double_as_longlong(cand[i]); return true; }, hist0, sc, s_st);
     else      // thousands of values equal in their top 22 bits: the remaining digits over the array itself
       sel = lds_radix_select<1024>(n, k2, 2, prefix, [&](int i, unsigned long long& key) { key = (unsigned long long)__double_as_longlong(fabs(chi2[i])); return true; }, hist0, sc, s_st);

@@ -2251,8 +2251,17 @@ int mcp_ba::head_small(int w, bool sum_aside) {
   // a sum still on its way on the second stream (the head of a trial that was then rejected) writes the same d_res[24]: it must not
   // land after the one this launch takes itself
   if (!aside && join_sum()) return -1;
-  hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), 0, st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, (unsigned long long)(m_total/2), m_total,
+  {
+    static std::atomic<unsigned long long> hs_attr{0};
+    const unsigned long long bit = 1ull << (device & 63);
+    if (!(hs_attr.load(std::memory_order_relaxed) & bit)) {
+      HIPCK(hipFuncSetAttribute((const void*)k_head_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HS_STASH*sizeof(double))));
+      hs_attr.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), HS_STASH*sizeof(double), st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, (unsigned long long)(m_total/2), m_total,
                      prm.min_mestimator_sigma*prm.min_mestimator_sigma, prev, d_res.p + 8, sig(), d_res.p + 25, d_res.p, 24, aside ? 0 : 1);
+  note_launch("k_head_small");
   if (aside) { HIPCK(hipEventRecord(ev_head, st)); sum_w = w; sum_sig = sig(); }      // (the second stream's part: sum_aside(), once the caller has queued what else it has for that stream)
   toc();
   return 0;
