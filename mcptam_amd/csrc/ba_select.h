@@ -427,10 +427,12 @@ static __global__ void k_select_publish(const unsigned int* __restrict__ cnt, in
 // one workgroup: passes 2..5 over the gathered candidates (or, if they overflowed the buffer -- tens of thousands of
 // values equal in their top 22 bits -- over the original array with the prefix filter), then the sigma block
 static __global__ void __launch_bounds__(1024)
-k_select_small(int n, const double* __restrict__ x, const unsigned int* __restrict__ cnt, const double* __restrict__ vals,
+k_select_small(int n, const double* __restrict__ x, const unsigned int* cnt, const double* __restrict__ vals,
                const SelState* __restrict__ state, double n_total, double min_sigma_sq, double* __restrict__ med_out,
                double* __restrict__ sig, double* __restrict__ sig_copy,
-               const double* __restrict__ slot_counts = nullptr, int nslot = 0, int slot_cap = 0) {
+               const double* __restrict__ slot_counts = nullptr, int nslot = 0, int slot_cap = 0,
+               double* clear = nullptr, int nclear = 0 /* the histograms + gather counter of this selection (cnt lies inside): left zero for the
+               next one, which then needs no fill launch in front of it */) {
   __shared__ unsigned int hist[SEL_BINS];
   __shared__ unsigned long long sc[1024/64 + 3];
   __shared__ unsigned long long s_st[2];
@@ -457,6 +459,8 @@ k_select_small(int n, const double* __restrict__ x, const unsigned int* __restri
       if (sig_copy) { sig_copy[0] = s2; sig_copy[1] = lim; sig_copy[2] = sqrt(lim); sig_copy[3] = md; }
     }
   }
+  // (every thread has read cnt[0] long ago: the select above is full of barriers)
+  for (int i = t; i < nclear; i += 1024) clear[i] = 0.0;
 }
 
 }  // namespace mcp

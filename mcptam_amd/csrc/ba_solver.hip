@@ -486,6 +486,7 @@ struct mcp_ba {
   int sel_cap = 4096;           // candidates per rank slot (MCP_BA_SELECT_CAP)
   DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
+  bool hist_clean = false;          // the single-GPU median left its two histograms + counter zero (k_select_small's last act): no fill in front of the next one
   // The sigma block is double-buffered by median: a trial evaluated ahead on the speculative stream that nobody consumes may
   // still be reading its iteration's block when the next iteration's median writes the new one (the two streams only meet
   // again in linearize()'s join_spec()); the block after that is written behind that join.
@@ -1822,6 +1823,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   sel_src = -1; pred_bin = -1;
   for (int q = 0; q <= MAX_SYS; ++q) if (chol_exec[q]) { (void)hipGraphExecDestroy(chol_exec[q]); chol_exec[q] = nullptr; }      // plan and buffers may have changed
   for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) { (void)hipGraphExecDestroy(chain_exec[q][r]); chain_exec[q][r] = nullptr; }
+  hist_clean = false;                              // (the histogram block may be a fresh one)
   if ((nbig && d_ubig.alloc(n2 + np)) || d_stU.alloc(nstage*36) || d_stb.alloc((size_t)nrhs_rows*6) || d_stS.alloc(MAX_SYS*nstage*36) ||
       d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
@@ -1956,17 +1958,19 @@ int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out
   const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
   if (!multi()) {
     // single GPU: two full histogram passes, gather, one-workgroup finish (which also writes the Huber sigma block if asked)
-    HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)(2*SEL_BINS + 1)*sizeof(double), st));        // two histograms + the gather counter behind them
+    if (!hist_clean) HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)(2*SEL_BINS + 1)*sizeof(double), st));        // two histograms + the gather counter behind them
     unsigned int* cnt = reinterpret_cast<unsigned int*>(d_hist.p + 2*SEL_BINS);
     for (int p = 0; p < 2; ++p) hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
     hipLaunchKernelGGL(k_select_gather, dim3(grid), dim3(SEL_BLOCK), 0, st, n, x, (const double*)d_hist.p, d_selstate.p, cnt, d_selvals.p);
     hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_selvals.p, (const SelState*)d_selstate.p,
                        m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma, out_dev, huber_sigma ? sig() : (double*)nullptr,
-                       huber_sigma ? d_res.p + 25 : (double*)nullptr);
+                       huber_sigma ? d_res.p + 25 : (double*)nullptr, (const double*)nullptr, 0, 0, d_hist.p, 2*SEL_BINS + 1);
+    hist_clean = true;
     return 0;
   }
   // several ranks: two all-reduced histogram passes, then the few candidates of every rank are gathered through a
   // zero-filled (ranks x sel_cap) table summed over the ranks, and each rank finishes locally: 3 collectives
+  hist_clean = false;
   HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)SEL_PASSES*SEL_BINS*sizeof(double), st));
   for (int p = 0; p < 2; ++p) {
     hipLaunchKernelGGL(k_select_pass, dim3(grid), dim3(SEL_BLOCK), 0, st, p, n, x, d_hist.p, d_selstate.p, k);
