@@ -608,6 +608,11 @@ struct mcp_ba {
   bool start_rides = false;        // the iteration-start chi2 still has to be summed over the ranks
   int sys_cur = 0; bool spec_ok = false; int batch_n = 0; double batch_lambda[MAX_SYS] = {0, 0, 0, 0};
   int speculate = 3;                 // speculative systems per solve at most; MCP_BA_SPECULATE=0 turns them off
+  // Small bundles (ba_small.h) speculate only while trials are being rejected: a BundleAdjustRecent window accepts every first trial, and the
+  // three systems solved beside it were 16 launches per iteration for nobody (compute 1.09 -> 1.01 ms without them).  A rejection arms the
+  // speculation for the re-solve that follows and the next iterations; MCP_BA_SPECULATE_ADAPT=0: always, as large bundles do.
+  int spec_adapt = 1, spec_hot = 0;
+  int spec_now() const { return (spec_adapt && small_mode() && spec_hot <= 0) ? 0 : speculate; }
   int lin_join_full = 0;             // MCP_BA_LIN_JOIN=1: linearize() waits for everything the speculative stream has in flight (round 2's behaviour)
   int use_graph = 0;                 // MCP_BA_GRAPH=1: replay the factorisation chain from a captured hipGraph
   hipGraphExec_t chol_exec[MAX_SYS + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1813,6 +1818,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   const int nblk = (std::max(nmeas, nfl) + 255)/256 + 1;
   red_stride = n2 + 2*(size_t)np; vinv_stride = (size_t)nfl*6; spec_ok = false; sys_cur = 0;
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
+  { const char* e = getenv("MCP_BA_SPECULATE_ADAPT"); if (e) spec_adapt = atoi(e); }
   { const char* e = getenv("MCP_BA_LIN_JOIN"); if (e) lin_join_full = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
@@ -2356,7 +2362,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   } else {
     sys_cur = 0;
     // the lambdas of the rejection branch of the LM schedule: lambda *= ni; ni *= 2 (same operations as compute())
-    const int nsys = (ni > 0) ? 1 + std::max(0, std::min(speculate, MAX_SYS - 1)) : 1;
+    const int nsys = (ni > 0) ? 1 + std::max(0, std::min(spec_now(), MAX_SYS - 1)) : 1;
     SysBatch sb; std::memset(&sb, 0, sizeof sb);
     { double l = lam, f = ni; for (int q = 0; q < nsys; ++q) { batch_lambda[q] = sb.lambda[q] = l; sb.lambda_init[q] = (rank == 0) ? l : 0.0; l *= f; f *= 2; } }
     batch_n = nsys;
@@ -2534,7 +2540,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   int conv_mag = 0, conv_res = 0;
   if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
   timing.schur_mfma_per_system = schur_mfma; timing.schur_flops_structural = schur_flops;
-  converged = 0; total_iterations = 0;
+  converged = 0; total_iterations = 0; spec_hot = 0;
   int nCounter = 0;
   // emptiness is decided on the GLOBAL totals: a rank whose shard holds no measurement (or no free point) still runs every
   // kernel with zero-size inputs and joins every collective, or the other ranks would wait in them for ever
@@ -2668,6 +2674,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           sel_src = (multi() && ok2) ? sys_cur : -1;
         } else {
           lambda *= ni; ni *= 2; accepted = 0;       // pop: the current buffers were never touched
+          spec_hot = 4;                              // (small bundles: from here on the rejection branch's systems are solved ahead again)
         }
         ++qmax;
       } while (rho < 0 && qmax < prm.max_trials_after_failure && !terminate());
@@ -2691,6 +2698,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         last_chi2_action = curchi;
         lg.chi2_end = curchi;
       }
+      if (qmax == 1 && spec_hot > 0) --spec_hot;     // (an iteration that accepted its first trial)
       total_iterations += qmax;
       lg.lambda_end = lambda; lg.trials = qmax; lg.accepted = accepted; lg.rms_update = rms;
       logs.push_back(lg);

@@ -857,7 +857,7 @@ def test_bench_two_rank_path_end_to_end(gpu_required):
     assert "debug" in d["config"] and d["config"]["chi2_last"] < d["config"]["chi2_first"]
 
 
-@pytest.mark.parametrize("knob", ["MCP_BA_SMALL", "MCP_BA_CHOL_FUSE1"])
+@pytest.mark.parametrize("knob", ["MCP_BA_SMALL", "MCP_BA_CHOL_FUSE1", "MCP_BA_SPECULATE_ADAPT"])
 @pytest.mark.parametrize("cfg,iters", [("c1", 12), ("c2small", 10), ("window", 10)])
 def test_small_bundle_scheduling_does_not_change_a_single_bit(gpu_required, cfg, iters, knob, monkeypatch):
     """A small bundle (BundleAdjustRecent's window) gets the trial's pose update and chain transforms in one launch and the next
@@ -865,7 +865,8 @@ def test_small_bundle_scheduling_does_not_change_a_single_bit(gpu_required, cfg,
     (ba_small.h, mcp_ba::head_ahead); a reduced system of one tile (<= 5 free poses) is factored and back-substituted in one launch
     (k_chol_step, fuse_back).  Scheduling only: with MCP_BA_SMALL=0 / MCP_BA_CHOL_FUSE1=0 the same problem runs the general
     sequence of launches and must give the same iteration logs, poses, points and outliers, bit for bit -- rejected trials (whose
-    head is thrown away) included."""
+    head is thrown away) included.  MCP_BA_SPECULATE_ADAPT=0: the rejection branch's systems solved ahead in every iteration, not
+    only after a trial has been rejected (what a small bundle does by default)."""
     from mcptam_amd import synth
     p = (synth.recent_window(synth.make_config("metric")) if cfg == "window" else
          synth.make_config("c2", n_mkf=12, n_points=1500) if cfg == "c2small" else synth.make_config(cfg))
