@@ -40,7 +40,8 @@ constexpr int CP_TQ = CH_NB*CH_NB;            // doubles per tile in global memo
 __device__ long long cp_deadline = 2000000;
 __device__ inline bool cp_expired(long long t0) { return wall_clock64() - t0 > cp_deadline; }
 constexpr int CP_BACK_NEAR = 3;               // rows k+1 .. k+CP_BACK_NEAR of column k stay with the chain workgroup
-constexpr unsigned long long CP_SENT = 0xFFFDEADBEEF5A5A5ull;      // "not written yet" (a NaN payload arithmetic never yields)
+constexpr unsigned int CP_SENT32 = 0xFFF5A5A5u;
+constexpr unsigned long long CP_SENT = ((unsigned long long)CP_SENT32 << 32) | CP_SENT32;      // "not written yet": a NaN payload arithmetic never yields (both halves alike: hipMemsetD32 fills a buffer with it)
 
 struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
 // kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
@@ -100,6 +101,22 @@ __device__ inline void cp_st4(__amdgpu_buffer_rsrc_t r, unsigned off, const chol
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_u4, y), r, off + 16, 0, 16);
 }
 #define CP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// Data-tagged chunks (round 6): a band tile travels from its helper to the critical workgroup WITHOUT a flag -- the helper stores the
+// chunks and is done (no drain, no flag store), the consumer loads them and looks at the data itself: a chunk is two untorn 16-byte
+// stores, so "first double of either half is the sentinel" = not there yet.  The consumer (the only reader of a band slot) stores the
+// sentinel back once it has the tile, so the next launch finds the slot armed; a plan's slots are armed when it is built, and a launch
+// that ends in a time-out is the last one of its plan (the handle falls back to the per-step kernels for good).  One hop = one round
+// trip (store -> visible -> load) instead of drain + flag store + flag poll + payload load: ~0.8 us instead of ~2.2 us.
+__device__ inline bool cp_chunk_missing(const chol_d4& v) {
+  return (unsigned long long)__double_as_longlong(v[0]) == CP_SENT || (unsigned long long)__double_as_longlong(v[2]) == CP_SENT;
+}
+__device__ inline void cp_chunk_arm(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const cp_u4 x = {CP_SENT32, CP_SENT32, CP_SENT32, CP_SENT32};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, off, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, off + 16, 0, 16);
+}
+// wavefront-uniform: does any lane of this wavefront still miss (part of) one of its chunks?
+__device__ inline bool cp_wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
 __device__ inline int cp_flag_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void cp_flag_store(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a flag load that is ISSUED here (the compiler may not sink it to its use) and waited for by cp_flag_wait: the round trip to the
@@ -213,22 +230,19 @@ __device__ inline void cp_pair_sync(int* ctr, int& target, int lane) {      // t
 }
 // wavefront 0: L L^T = D (a diagonal tile arrives with the identity beyond the matrix), L^-1 -> Dinv (row-major); the pivot loop
 // is ba_chol.h's panel: lanes 0..31 carry the tile's rows, lanes 32..63 the identity through the same column operations
-__device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf, int* fail, int q, int s) {
+__device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf, const double* zvec, int* fail, int q, int s) {
   const int lane = threadIdx.x;
   int rr = lane & 31;
-  asm volatile("" : "+v"(rr));       // opaque per call: the identity rows' 32 compares stay here (hoisted out of the step loop they were spilled)
+  asm volatile("" : "+v"(rr));       // opaque per call
   const bool low = lane >= 32;
   double d[CH_NB];
-  const double* src = &D[rr][0];
-  // every lane reads its row (32 loads in flight, one wait), THEN the upper lanes swap in the identity: written as one select per
-  // entry the compiler made 32 branches of it, each with its own LDS round trip (1.4 us per step)
+  // lanes 0..31 read their row of the tile, lanes 32..63 their row of the identity -- the SAME 32 loads with another base address:
+  // zvec[0..62] is zero but for zvec[31] = 1, so zvec + 31 - r is row r of the identity.  (Round 5 loaded the tile on every lane and
+  // swapped the identity in with a compare and a select per entry: 130 instructions, 0.35 us of the 0.52 us this entry took.)
+  const double* src = low ? zvec + (CH_NB - 1 - rr) : &D[rr][0];
 #pragma unroll
   for (int c = 0; c < CH_NB; ++c) d[c] = src[c];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (low) {
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) d[c] = (c == rr) ? 1.0 : 0.0;
-  }
   const double piv0 = readlane_f64(d[0], 0);
   bool bad = !(piv0 > 0.0);
   double inv = rsqrt(piv0);
@@ -236,10 +250,11 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf
   chol_panel_pivots(d, inv, bad, colbuf, std::make_integer_sequence<int, CH_NB>());
   if (lane == 0) CP_STAMP(s, 10);
   if (bad && lane == 0) atomicOr(fail, 2);
-  // lane 32 + r ends with row r of L^-T = column r of L^-1
+  // lane 32 + r ends with row r of L^-T = column r of L^-1.  Its entries left of the diagonal ARE zero (0 - 0 m = 0 through every
+  // column operation), so the row leaves as it is (round 5 selected 0.0 per entry: 100 more instructions on the critical wavefront).
   if (low) {
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) Dinv[c][rr] = (c >= rr) ? d[c] : 0.0;
+    for (int c = 0; c < CH_NB; ++c) Dinv[c][rr] = d[c];
   }
 }
 
@@ -252,34 +267,43 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   const cp_tile Tc = (cp_tile)(lds + 4*CP_TILE), T2 = (cp_tile)(lds + 5*CP_TILE);
   auto Dt = [&](int i) { return (cp_tile)(lds + (6 + (i & 1))*CP_TILE); };
   double* colbuf = lds + 8*CP_TILE;
-  int* ctl = (int*)(colbuf + 64);            // [0] team counter, [1] ok / abort word
+  double* zvec = colbuf + 64;                // [63]: rows of the identity for the panel's upper lanes (cp_potrf)
+  int* ctl = (int*)(zvec + 64);              // [0] team counter, [1] ok / abort word
   int* flags = a.flags + (size_t)q*a.nflags;
   int* err = a.err + q; int* fail = a.fail + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
   const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
   const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of;
-  const int epoch4 = a.epoch[q] << 2, want_band = epoch4 | 1, done_l = epoch4 | 2;
+  const int epoch4 = a.epoch[q] << 2, done_l = epoch4 | 2;
   const int code = 0x100;
   int* stp = ctl + 16;                       // the step table
   for (int i = t; i < (ntc + 1)*CP_STEP_INTS; i += CP_THREADS) stp[i] = a.steps[i];
   if (t == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; }
+  if (t < 64) zvec[t] = (t == CH_NB - 1) ? 1.0 : 0.0;
   __syncthreads();
-  // ---- prologue: rows 0 and 1 of the band (their helpers pass A through), diagonal tile 0 factored
+  // ---- prologue: rows 0 and 1 of the band (their helpers pass A through) arrive as data-tagged chunks: wavefront w takes quadrant w of
+  //      tiles (0,0), (1,0) and (1,1)
   const bool row1_diag = 1 < ntc;
-  if (t == 0) {
-    const int* fb = flags + slot_of[1*ntc + 0];
-    if (!cp_poll3(flags + slot_of[0], fb, row1_diag ? flags + slot_of[1*ntc + 1] : fb, want_band, err, code | 1)) ctl[1] = 0;
+  {
+    const unsigned o0 = cp_chunk_off(bslot_of[0], wave, lane), o1 = cp_chunk_off(bslot_of[1*ntc + 0], wave, lane);
+    const unsigned o2 = row1_diag ? cp_chunk_off(bslot_of[1*ntc + 1], wave, lane) : o1;
+    chol_d4 p0, p1, p2;
+    unsigned it = 0; long long t0 = 0;
+    for (;;) {
+      p0 = cp_ld4(rB, o0); p1 = cp_ld4(rB, o1); p2 = cp_ld4(rB, o2);
+      if (!cp_wave_any(cp_chunk_missing(p0) || cp_chunk_missing(p1) || cp_chunk_missing(p2))) break;
+      if ((++it & 15) == 15) {
+        if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+        if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 1); ctl[1] = 0; break; }
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    cp_regs_to_lds(Dt(0), wave, lane, p0); cp_regs_to_lds(Tc, wave, lane, p1);
+    if (row1_diag) cp_regs_to_lds(Dt(1), wave, lane, p2);
+    cp_chunk_arm(rB, o0); cp_chunk_arm(rB, o1); if (row1_diag) cp_chunk_arm(rB, o2);      // the next launch finds the slots armed
   }
   __syncthreads();
   if (!ctl[1]) return;
-  for (int j = wave; j < 12; j += 4) {
-    const int which = j >> 2, qd = j & 3;
-    if (which == 2 && !row1_diag) continue;
-    const int bs = which == 0 ? bslot_of[0] : (which == 1 ? bslot_of[1*ntc + 0] : bslot_of[1*ntc + 1]);
-    const chol_d4 v = cp_ld4(rB, cp_chunk_off(bs, qd, lane));
-    cp_regs_to_lds(which == 0 ? Dt(0) : (which == 1 ? Tc : Dt(1)), qd, lane, v);
-  }
-  __syncthreads();
   // Two loops, one per role, with the same barriers: what the team carries from step to step (the band row fetched ahead) and what
   // the panel keeps in registers never share a live range that way (one loop with a branch per role spilled 63 registers).
   if (wave == 0) {
@@ -300,7 +324,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         cp_barrier();
       }
       if (t == 0) CP_STAMP(s, 1);
-      if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, fail, q, s);
+      if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, zvec, fail, q, s);
       if (t == 0) CP_STAMP(s, 2);
       cp_barrier();
       if (t == 0) CP_STAMP(s, 8);
@@ -310,29 +334,23 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
     return;
   }
   int dcur = 0;
-  int team_target = 0, pair_target = 0;
+  int team_target = 0;
   // The loop body starts where the team asks for the band row it needs a step later and ends where it has used it: the request and
   // its use sit in ONE iteration (carried around the loop the compiler waited for the loads at the loop head, i.e. hid nothing).
   // `s` is the step that is ending (-1: the lead-in, wavefront 0 factors diagonal tile 0).
   for (int s = -1; s < ntc; ++s) {
     chol_d4 v0 = {0.0, 0.0, 0.0, 0.0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0;       // wavefronts 2, 3: band row s+3
-    {
-      // the row after next into registers (wavefronts 2, 3; also in the lead-in step): its helpers finished it a step ago
-      if (wave >= 2 && s + 3 <= R && ctl[1]) {
-        const int* se = stp + (s + 1)*CP_STEP_INTS;
-        if (t == 128) {
-          if (!cp_poll3(flags + se[CPS_F0], flags + se[CPS_F1], flags + se[CPS_F2], want_band, err, code | 4)) ctl[1] = 0;
-          CP_STAMP(s, 4);
-        }
-        cp_pair_sync(ctl + 2, pair_target, lane);
-        if (ctl[1]) {
-          const int b0 = se[CPS_B0], b1 = se[CPS_B1], b2 = se[CPS_B2];
-          const int h = wave - 2;                    // 0: quadrants 0, 1   1: quadrants 2, 3
-          v0 = cp_ld4(rB, cp_chunk_off(b0, 2*h, lane)); v1 = cp_ld4(rB, cp_chunk_off(b0, 2*h + 1, lane));
-          v2 = cp_ld4(rB, cp_chunk_off(b1, 2*h, lane)); v3 = cp_ld4(rB, cp_chunk_off(b1, 2*h + 1, lane));
-          v4 = cp_ld4(rB, cp_chunk_off(b2, 2*h, lane)); v5 = cp_ld4(rB, cp_chunk_off(b2, 2*h + 1, lane));
-        }
-      }
+    unsigned ob0 = 0, ob1 = 0, ob2 = 0;
+    if (wave >= 2 && s + 3 <= R && ctl[1]) {
+      // the row after next into registers (wavefronts 2, 3; also in the lead-in step), as late in the step as can be and WITHOUT asking
+      // first: the chunks are data-tagged, whether they had arrived is looked at where they are used (P3 of the next step)
+      const int* se = stp + (s + 1)*CP_STEP_INTS;
+      const int h = wave - 2;                    // 0: quadrants 0, 1   1: quadrants 2, 3
+      ob0 = cp_chunk_off(se[CPS_B0], 2*h, lane); ob1 = cp_chunk_off(se[CPS_B1], 2*h, lane); ob2 = cp_chunk_off(se[CPS_B2], 2*h, lane);
+      v0 = cp_ld4(rB, ob0); v1 = cp_ld4(rB, ob0 + 2048);
+      v2 = cp_ld4(rB, ob1); v3 = cp_ld4(rB, ob1 + 2048);
+      v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
+      if (t == 128) CP_STAMP(s, 4);
     }
     cp_barrier();                      // end of step s
     if (!ctl[1]) return;
@@ -344,60 +362,63 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       const int s = sn;               // (the body below was written in terms of the step it works on)
       const int i1 = s + 1, i2 = s + 2;
       const cp_tile Ds = Dv(s);
+      const int tw = wave - 1;
+      const bool row2 = i2 <= R, diag2 = i2 < ntc;
+      const int* se = stp + (s + 1)*CP_STEP_INTS;
+      const int sd = se[CPS_SD], s1 = se[CPS_S1];
+      // ---- L_ss^-1 leaves the moment the step begins (round 6; round 5 published it from P3, 1.9 us into the step): it has been in LDS
+      //      since the panel ended, and the helpers of band row s+3 -- the longest chain that hangs on this step -- start from its flag.
+      //      Wavefront 1 stores quadrants (0,0) and (0,1) (zeros; the back-substitution reads the whole tile), 2 and 3 the lower ones.
+      if (tw == 0) { cp_st4(rL, cp_chunk_off(sd, 0, lane), cp_lds_to_regs(Ds, 0, lane)); cp_st4(rL, cp_chunk_off(sd, 1, lane), cp_lds_to_regs(Ds, 1, lane)); }
+      else cp_st4(rL, cp_chunk_off(sd, wave, lane), cp_lds_to_regs(Ds, wave, lane));
       // ---- P1: X1 = A'(s+1, s) L_ss^-T (all four wavefronts, a quadrant each)
       cp_regs_to_lds(Xb0, wave, lane, cp_trsm_quadrant(Tc, Ds, wave, lane));
       cp_barrier();
-      // ---- P2: A'(s+1, s+1) -= X1 X1^T
-      if (i1 < ntc) {
+      // ---- P2: A'(s+1, s+1) -= X1 X1^T on wavefronts 0, 2, 3 (the panel never reads quadrant (0, 1)); wavefront 1 sends L(s+1, s) off instead
+      if (wave == 1) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
+      } else if (i1 < ntc) {
         chol_d4 acc = cp_lds_to_regs(Dt(dcur), wave, lane);
         cp_mma<true>(acc, Xb0, Xb0, wave, lane);
         cp_regs_to_lds(Dt(dcur), wave, lane, acc);
       }
       cp_barrier();
       // ---- P3: wavefront 0 factors the next diagonal tile; the team finishes column s
-      const int tw = wave - 1;
-      const bool row2 = i2 <= R, diag2 = i2 < ntc;
-      const int* se = stp + (s + 1)*CP_STEP_INTS;
-      const int sd = se[CPS_SD], s1 = se[CPS_S1];
       const int dl = (row2 && ctl[1]) ? se[CPS_DL] : -1;        // band slot of row s+2's late product, -1 = none
-      chol_d4 dq0 = {0.0, 0.0, 0.0, 0.0}, dq1 = dq0;
       if (a.test_fail_step == s && t == 64) { cp_flag_store(err, code | 0xf); ctl[1] = 0; }
-      // the late product's flag: asked for first (it was raised a step ago), looked at after the work below
-      int dflag = want_band;
-      if (dl >= 0) dflag = cp_flag_load_early(flags + a.nslots + i2);
-      if (tw == 0) {
-        // (a) wavefront 1 publishes L_ss^-1 and L(s+1, s) first thing: the helpers of row s+3 hang on these two flags
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(sd, qd, lane), cp_lds_to_regs(Ds, qd, lane));
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
-        CP_DRAIN();
-        if (lane == 0) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
-      } else if (row2 && ctl[1]) {
-        // (b) wavefronts 2, 3: row s+2 of the band was fetched into registers while the previous step ended; now that X1 is out of
-        //     Tc it goes to LDS
+      if (tw >= 1 && row2 && ctl[1]) {
+        // wavefronts 2, 3: row s+2 of the band was asked for while the previous step ended; had it arrived?  (It nearly always has: its
+        // helpers start from L_ss^-1's flag of the PREVIOUS step.)  If not, ask again until it has.
+        unsigned it = 0; long long t0 = 0;
+        while (cp_wave_any(cp_chunk_missing(v0) || cp_chunk_missing(v1) || cp_chunk_missing(v2) || cp_chunk_missing(v3) || cp_chunk_missing(v4) || cp_chunk_missing(v5))) {
+          if ((++it & 15) == 15) {
+            if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+            if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 4); ctl[1] = 0; break; }
+          }
+          __builtin_amdgcn_s_sleep(1);
+          v0 = cp_ld4(rB, ob0); v1 = cp_ld4(rB, ob0 + 2048); v2 = cp_ld4(rB, ob1); v3 = cp_ld4(rB, ob1 + 2048); v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
+        }
+        // now that X1 is out of Tc the row goes to LDS
         const int h = tw - 1;
         cp_regs_to_lds(T2, 2*h, lane, v0); cp_regs_to_lds(T2, 2*h + 1, lane, v1);
         cp_regs_to_lds(Tc, 2*h, lane, v2); cp_regs_to_lds(Tc, 2*h + 1, lane, v3);
         if (diag2) { cp_regs_to_lds(Dt(dcur ^ 1), 2*h, lane, v4); cp_regs_to_lds(Dt(dcur ^ 1), 2*h + 1, lane, v5); }
       }
-      // the late product of tile (s+2, s+1): every wavefront fetches the quadrants it will update (U1 below: 0 | 1 | 2, 3); the
-      // loads are in flight through the solve and the first product
-      if (dl >= 0) {
-        cp_flag_wait(dflag);
-        unsigned it = 0; long long t0 = 0;
-        while (dflag != want_band) {
-          if ((++it & 31) == 31) {
-            if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
-            if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
-          }
-          __builtin_amdgcn_s_sleep(1);
-          dflag = cp_flag_load(flags + a.nslots + i2);
-        }
-        dq0 = cp_ld4(rB, cp_chunk_off(dl, tw, lane));
-        if (tw == 2) dq1 = cp_ld4(rB, cp_chunk_off(dl, 3, lane));
-      }
+      CP_DRAIN();                      // every wavefront's share of L_ss^-1 / L(s+1, s) has landed
       cp_team_sync(ctl, team_target, lane);
+      if (t == 64) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
+      // the late product of tile (s+2, s+1), data-tagged as well: every wavefront asks for the quadrants it will update (U1 below:
+      // 0 | 1 | 2, 3) and looks at them after its products.  (Round 5 waited for the product's flag HERE, before the solve: the solve
+      // then started when the product's helper was done, which in turn hung on the previous step's last flag -- a cycle one step long.)
+      chol_d4 dq0 = {0.0, 0.0, 0.0, 0.0}, dq1 = dq0;
+      const unsigned odq = dl >= 0 ? cp_chunk_off(dl, tw == 2 ? 2 : tw, lane) : 0u;
+      if (dl >= 0) { dq0 = cp_ld4(rB, odq); if (tw == 2) dq1 = cp_ld4(rB, odq + 2048); }
+      if (tw >= 1 && row2 && ctl[1]) {
+        // (the band row's slots are armed for the next launch: stores nobody waits for)
+        cp_chunk_arm(rB, ob0); cp_chunk_arm(rB, ob0 + 2048); cp_chunk_arm(rB, ob1); cp_chunk_arm(rB, ob1 + 2048);
+        if (diag2) { cp_chunk_arm(rB, ob2); cp_chunk_arm(rB, ob2 + 2048); }
+      }
       if (t == 64) CP_STAMP(s, 5);
       if (row2 && ctl[1]) {
         // (c) X2 = A'(s+2, s) L_ss^-T: the two right quadrants take 8 matrix instructions each, the two left ones 4 each
@@ -406,38 +427,51 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         else { cp_regs_to_lds(Xb1, 0, lane, cp_trsm_quadrant(T2, Ds, 0, lane)); cp_regs_to_lds(Xb1, 2, lane, cp_trsm_quadrant(T2, Ds, 2, lane)); }
         cp_team_sync(ctl, team_target, lane);
         if (t == 64) CP_STAMP(s, 6);
-        // (d) L(s+2, s) leaves first (its stores fly during the products), then A'(s+2, s+1) -= X2 X1^T + late product,
-        //     A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1))
+        // (d) L(s+2, s) leaves first, ALL of it from wavefront 1, which can then raise its flag alone the moment its own products are done
+        //     (round 5 split the stores over the team and flagged after everybody's products: 1.7 us later -- and the late product of the
+        //     NEXT step hangs on this flag); then A'(s+2, s+1) -= X2 X1^T + late product, A'(s+2, s+2) -= X2 X2^T (lower triangle's
+        //     quadrants: the panel never reads (0, 1))
         const int s2 = se[CPS_S2];
-        for (int qd = tw; qd < 4; qd += 3) cp_st4(rL, cp_chunk_off(s2, qd, lane), cp_lds_to_regs(Xb1, qd, lane));
-        if (t == 64) CP_STAMP(s, 11);
-        {
-          chol_d4 acc = cp_lds_to_regs(Tc, tw, lane);                    // U1 quadrant tw
-          cp_mma<true>(acc, Xb1, Xb0, tw, lane);
-          if (dl >= 0) acc += dq0;                                       // (the helper summed -L(s+2,s-1) L(s+1,s-1)^T)
-          cp_regs_to_lds(Tc, tw, lane, acc);
+        if (tw == 0) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s2, qd, lane), cp_lds_to_regs(Xb1, qd, lane));
         }
-        if (tw == 2) {
-          chol_d4 acc = cp_lds_to_regs(Tc, 3, lane);                     // U1 quadrant 3
-          cp_mma<true>(acc, Xb1, Xb0, 3, lane);
-          if (dl >= 0) acc += dq1;
-          cp_regs_to_lds(Tc, 3, lane, acc);
-        } else if (diag2) {
+        if (t == 64) CP_STAMP(s, 11);
+        const int qa = tw == 2 ? 2 : tw;
+        chol_d4 acc = cp_lds_to_regs(Tc, qa, lane), accb = {0.0, 0.0, 0.0, 0.0};       // U1 quadrant 0 | 1 | 2 and 3
+        cp_mma<true>(acc, Xb1, Xb0, qa, lane);
+        if (tw == 2) { accb = cp_lds_to_regs(Tc, 3, lane); cp_mma<true>(accb, Xb1, Xb0, 3, lane); }
+        else if (diag2) {
           const int qd = tw == 0 ? 0 : 2;                                // U2 quadrants 0 | 2, then 3 with wavefront 2
-          chol_d4 acc = cp_lds_to_regs(Dt(dcur ^ 1), qd, lane);
-          cp_mma<true>(acc, Xb1, Xb1, qd, lane);
-          cp_regs_to_lds(Dt(dcur ^ 1), qd, lane, acc);
+          chol_d4 acc2 = cp_lds_to_regs(Dt(dcur ^ 1), qd, lane);
+          cp_mma<true>(acc2, Xb1, Xb1, qd, lane);
+          cp_regs_to_lds(Dt(dcur ^ 1), qd, lane, acc2);
           if (tw == 1) {
             chol_d4 acc3 = cp_lds_to_regs(Dt(dcur ^ 1), 3, lane);
             cp_mma<true>(acc3, Xb1, Xb1, 3, lane);
             cp_regs_to_lds(Dt(dcur ^ 1), 3, lane, acc3);
           }
         }
+        if (dl >= 0) {
+          unsigned it = 0; long long t0 = 0;
+          while (cp_wave_any(cp_chunk_missing(dq0) || (tw == 2 && cp_chunk_missing(dq1)))) {
+            if ((++it & 15) == 15) {
+              if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+              if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+            dq0 = cp_ld4(rB, odq); if (tw == 2) dq1 = cp_ld4(rB, odq + 2048);
+          }
+          cp_chunk_arm(rB, odq); if (tw == 2) cp_chunk_arm(rB, odq + 2048);
+          acc += dq0; accb += dq1;                                       // (the helper summed -L(s+2,s-1) L(s+1,s-1)^T)
+        }
+        cp_regs_to_lds(Tc, qa, lane, acc);
+        if (tw == 2) cp_regs_to_lds(Tc, 3, lane, accb);
         if (t == 64) CP_STAMP(s, 12);
-        CP_DRAIN();
-        if (t == 64) CP_STAMP(s, 13);
-        cp_team_sync(ctl, team_target, lane);
-        if (t == 64) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
+        if (tw == 0) {
+          CP_DRAIN();
+          if (lane == 0) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
+        }
       }
     }
   }
@@ -516,11 +550,9 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
     __syncthreads();
     if (t == 0) cp_flag_store(flags + h.pre_flag, epoch4 | 1);
   }
-  if (h.kind == 1) {          // band tile: the partial sum goes to the critical workgroup
+  if (h.kind == 1) {          // band tile / late product: the sum goes to the critical workgroup, data-tagged -- no drain, no flag (CP_DRAIN's note)
     cp_st4(rB, cp_chunk_off(h.dslot, wave, lane), acc);        // (dslot of a band tile = its band slot)
-    CP_DRAIN();
-    __syncthreads();
-    if (t == 0) { cp_flag_store(flags + h.slot, epoch4 | 1); CP_HSTAMP(3); }
+    if (t == 0) CP_HSTAMP(3);
     return true;
   }
   // far tile: X = acc L_jj^-T
@@ -538,7 +570,7 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   return true;
 }
 
-constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 8;          // + the step table of the critical workgroup behind it
+constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 64 + 8;          // + the step table of the critical workgroup behind it
 __global__ void __launch_bounds__(CP_THREADS, 2)
 k_chol_persist(CpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
@@ -932,9 +964,12 @@ struct CholPersist {
     d_flags = (int*)(arena + off); off += flag_bytes;
     d_err = (int*)(arena + off); off += err_bytes;
     d_epoch = (int*)(arena + off); { int* e = (int*)(stage.data() + off); for (int q = 0; q < max_sys; ++q) e[q] = 1; } off += ep_bytes;
+    d_Lt = (double*)(arena + off); d_Bt = (double*)(arena + off + lt_bytes);
+    // every band slot starts armed (the sentinel in every double; ba_chol2.h, CP_DRAIN's note): the null stream's fill is done before the
+    // blocking copy behind it returns
+    if (hipMemsetD32Async((hipDeviceptr_t)d_Bt, (int)CP_SENT32, bt_bytes/4, nullptr) != hipSuccess) return -1;
     if (hipMemcpy(arena, stage.data(), off, hipMemcpyHostToDevice) != hipSuccess) return -1;      // (tables, zeroed flags and error words, epochs = 1)
-    d_Lt = (double*)(arena + off); off += lt_bytes;
-    d_Bt = (double*)(arena + off); off += bt_bytes;
+    off += lt_bytes; off += bt_bytes;
     d_x = (double*)(arena + off); off += vec_bytes;
     d_f = (double*)(arena + off); off += vec_bytes;
     {
