@@ -70,16 +70,21 @@ struct CpBackArgs {
 };
 
 #ifdef MCP_CP_PROF
+#define MCP_CP_PROF_ARRIVE (MCP_CP_PROF == 5)
 // phase stamps (100 MHz wall clock, the same on every compute unit) of system 0: critical workgroup [step + 1][16], helpers [index][4]
 __device__ unsigned long long g_cp_prof[256*16];
 __device__ unsigned long long g_cp_hprof[8192*4];
+__device__ unsigned int g_cp_miss[8];          // [0] band row asked again, [1] late product asked again (system 0, last launch)
+#define CP_MISS(i) do { if (q == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_cp_miss[i], 1u); } while (0)
 // MCP_CP_PROF = 1: everything; 2: critical workgroup only; 3: step start / end only (0x101 mask); 4: wavefront 0's stamps only
-#define CP_STAMP_ON(i) (MCP_CP_PROF == 1 || MCP_CP_PROF == 2 || (MCP_CP_PROF == 3 && ((i) == 0 || (i) == 8)) || (MCP_CP_PROF == 4 && ((i) <= 2 || (i) >= 8 && (i) <= 10)))
-#define CP_STAMP(step, i) do { if (CP_STAMP_ON(i) && q == 0 && (step) + 1 < 256) g_cp_prof[((step) + 1)*16 + (i)] = wall_clock64(); } while (0)
+#define CP_STAMP_ON(i) ((MCP_CP_PROF == 5 && ((i) == 0 || (i) == 2 || (i) == 8 || (i) == 3 || (i) == 12 || (i) == 11 || (i) == 21 || (i) == 22 || (i) == 23 || ((i) >= 16 && (i) <= 19))) || MCP_CP_PROF == 1 || MCP_CP_PROF == 2 || (MCP_CP_PROF == 3 && ((i) == 0 || (i) == 8)) || (MCP_CP_PROF == 4 && ((i) <= 2 || ((i) >= 8 && (i) <= 10) || (i) >= 14)))
+#define CP_STAMP(step, i) do { if (CP_STAMP_ON(i) && q == 0 && (step) + 1 < 256) g_cp_prof[((step) + 1)*16 + ((i) >= 21 ? (i) - 8 : (i) >= 16 ? (i) - 12 : (i))] = wall_clock64(); } while (0)      // (16..19: a wavefront's arrival at the step's last barrier, kept in slots 4..7)
 #define CP_HSTAMP(i) do { if (MCP_CP_PROF == 1 && q == 0 && hidx < 8192) g_cp_hprof[hidx*4 + (i)] = wall_clock64(); } while (0)
 #else
 #define CP_STAMP(step, i) do {} while (0)
 #define CP_HSTAMP(i) do {} while (0)
+#define CP_MISS(i) do {} while (0)
+#define MCP_CP_PROF_ARRIVE 0
 #endif
 typedef unsigned int cp_u4 __attribute__((ext_vector_type(4)));
 typedef double (*cp_tile)[CP_LD];
@@ -103,9 +108,12 @@ __device__ inline void cp_st4(__amdgpu_buffer_rsrc_t r, unsigned off, const chol
 #define CP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // Data-tagged chunks (round 6): a band tile travels from its helper to the critical workgroup WITHOUT a flag -- the helper stores the
 // chunks and is done (no drain, no flag store), the consumer loads them and looks at the data itself: a chunk is two untorn 16-byte
-// stores, so "first double of either half is the sentinel" = not there yet.  The consumer (the only reader of a band slot) stores the
-// sentinel back once it has the tile, so the next launch finds the slot armed; a plan's slots are armed when it is built, and a launch
-// that ends in a time-out is the last one of its plan (the handle falls back to the per-step kernels for good).  One hop = one round
+// stores, so "first double of either half is the sentinel" = not there yet.  Band slots exist twice, a copy per parity of the launch
+// count (epoch): a launch's helpers write -- and its critical workgroup reads -- the copy of its parity, and the helper that fills a
+// slot also stores the sentinel into the slot's OTHER copy, which the previous launch is done with and the next one will poll (the
+// critical workgroup armed its own slots at first: 16 more stores per wavefront and step on the one in-order memory counter of the
+// wavefronts whose flags everybody waits for).  Both copies are armed when a plan is built, and a launch that ends in a time-out is
+// the last one of its plan (the handle falls back to the per-step kernels for good).  One hop = one round
 // trip (store -> visible -> load) instead of drain + flag store + flag poll + payload load: ~0.8 us instead of ~2.2 us.
 __device__ inline bool cp_chunk_missing(const chol_d4& v) {
   return (unsigned long long)__double_as_longlong(v[0]) == CP_SENT || (unsigned long long)__double_as_longlong(v[2]) == CP_SENT;
@@ -172,15 +180,18 @@ __device__ inline chol_d4 cp_lds_to_regs(cp_tile T, int qd, int l) {
   for (int g = 0; g < 4; ++g) v[g] = T[r + 4*g][c];
   return v;
 }
-// acc (+/-)= Pi[rows of the quadrant] Pj[columns of the quadrant]^T over K = 32
+// acc (+/-)= Pi[rows of the quadrant] Pj[columns of the quadrant]^T over K = 32.  All 2 KMAX/4 operands are asked for BEFORE the first
+// matrix instruction (round 6): left to itself the compiler reused two operand registers per pair of instructions, so every pair waited
+// for its own LDS round trip -- 8 instructions took ~920 cycles instead of ~512 + one round trip.
 template <bool NEG, int KMAX = CH_NB>
 __device__ inline void cp_mma(chol_d4& acc, cp_tile Pi, cp_tile Pj, int qd, int l) {
   const int ri = 16*(qd >> 1) + (l & 15), rj = 16*(qd & 1) + (l & 15), rq = l >> 4;
+  double x[KMAX/4], y[KMAX/4];
 #pragma unroll
-  for (int kk = 0; kk < KMAX; kk += 4) {
-    const double x = Pi[ri][kk + rq];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -x : x, Pj[rj][kk + rq], acc, 0, 0, 0);
-  }
+  for (int i = 0; i < KMAX/4; ++i) { x[i] = Pi[ri][4*i + rq]; y[i] = Pj[rj][4*i + rq]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < KMAX/4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -x[i] : x[i], y[i], acc, 0, 0, 0);
 }
 __device__ inline unsigned cp_chunk_off(int slot, int qd, int l) { return (unsigned)(((size_t)slot*CP_TQ + (size_t)(qd*64 + l)*4)*sizeof(double)); }
 
@@ -228,26 +239,160 @@ __device__ inline void cp_pair_sync(int* ctr, int& target, int lane) {      // t
   while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
-// wavefront 0: L L^T = D (a diagonal tile arrives with the identity beyond the matrix), L^-1 -> Dinv (row-major); the pivot loop
-// is ba_chol.h's panel: lanes 0..31 carry the tile's rows, lanes 32..63 the identity through the same column operations
-__device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf, const double* zvec, int* fail, int q, int s) {
+// ---- the split panel (round 6) ---------------------------------------------------------------------------------------------
+// Round 5's panel cost wavefront 0 ~42 instructions per pivot of which ~22 were the bulk rank-1 updates of the columns >= J + 3 (one
+// fp64 multiply-add and half a broadcast read per column, ~2.3 ns each for a lone wavefront): 3.0 of the step's 4.9 us.  Now the
+// columns >= CP_SPLIT are NOT wavefront 0's during the first CP_SPLIT pivots: it writes each finished column J < CP_SPLIT (all 64 lanes:
+// the tile's rows and the identity's) to LDS -- as it always did, but each to its own place, Lcol[J][lane] -- and a FOLLOWER (wavefront
+// 1, holding the same 64 rows' columns CP_SPLIT .. 31 in registers) applies it to those columns as it appears, in the same order and
+// with the same multiply-adds wavefront 0 would have issued: every entry's arithmetic is unchanged, bit for bit.  After pivot
+// CP_SPLIT - 1 the follower hands its 16 columns over through LDS and wavefront 0 goes on with a 16-column panel.  Wavefront 0's bulk:
+// 435 -> 182 multiply-adds; the price is the hand-over on the chain (follower's last column, its 16 stores, wavefront 0's 16 loads).
+// Lcol lives in the LDS tile that will take L^-1 at the panel's END (free until then); the hand-over buffer aliases Lcol.
+constexpr int CP_SPLIT = 16;
+#define CP_SB() __builtin_amdgcn_sched_barrier(0)
+template <int K, int G> struct CpBulkA {       // first half: group G (of 6) of the bulk update by column K on columns [K + 3, CP_SPLIT)
+  static constexpr int n = (CP_SPLIT - K - 3 > 0) ? CP_SPLIT - K - 3 : 0;
+  static constexpr int lo = K + 3 + (n*G)/6, hi = K + 3 + (n*(G + 1))/6;
+  static __device__ inline void fm(double* d, const double* m) {
+#pragma unroll
+    for (int c = lo; c < hi; ++c) d[c] -= d[K]*m[c];
+  }
+};
+// the rsqrt of the next pivot: v_rsq_f64 + one third-order correction (the sequence of ba_chol.h's panel, so that the numbers are its)
+__device__ inline double cp_rsq3(double pn) {
+  const double y0 = __builtin_amdgcn_rsq(pn);
+  const double t = y0*(-pn);
+  const double e = __builtin_fma(t, y0, 1.0);
+  const double u = y0*e;
+  const double q = __builtin_fma(e, 0.375, 0.5);
+  return __builtin_fma(u, q, y0);
+}
+// pivots 0 .. CP_SPLIT - 1 on wavefront 0 (ba_chol.h's chol_panel_pivot restricted to the columns < CP_SPLIT)
+template <int J>
+__device__ inline void cp_pivot_a(double* d, double& inv, bool& bad, double* mE, double* mO, double* lcol /* Lcol + lane */, const double* lrow /* Lcol */, int* prog, int pbase) {
+  double* cur = (J & 1) ? mO : mE;
+  double* prev = (J & 1) ? mE : mO;
+  d[J] *= inv;
+  lcol[J*64] = d[J];
+  __hip_atomic_store(prog + threadIdx.x, pbase + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ("column J is there": LDS takes a wavefront's operations in order.  Every lane its OWN word -- 64 lanes storing to one word is a 64-way bank conflict that stalls the whole compute unit's LDS; the follower reads word 0)
+  CP_SB();
+  if constexpr (J + 1 < CP_SPLIT) {
+    const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
+    const double l1 = readlane_f64(d[J], J + 1);
+    double l2 = 0.0;
+    if constexpr (J + 2 < CP_SPLIT) l2 = readlane_f64(d[J], J + 2);
+    const double pn = readlane_f64(w, J + 1);
+    bad |= !(pn > 0.0);
+    if constexpr (J + 3 < CP_SPLIT) {
+#pragma unroll
+      for (int c = J + 3; c < CP_SPLIT; ++c) cur[c] = lrow[J*64 + c];
+    }
+    CP_SB();
+    const double y0 = __builtin_amdgcn_rsq(pn);
+    CP_SB(); if constexpr (J >= 1) CpBulkA<J - 1, 0>::fm(d, prev); CP_SB();
+    const double t = y0*(-pn);
+    CP_SB(); if constexpr (J >= 1) CpBulkA<J - 1, 1>::fm(d, prev); CP_SB();
+    const double e = __builtin_fma(t, y0, 1.0);
+    CP_SB(); if constexpr (J >= 1) CpBulkA<J - 1, 2>::fm(d, prev); CP_SB();
+    const double u = y0*e;
+    const double q = __builtin_fma(e, 0.375, 0.5);
+    CP_SB(); if constexpr (J >= 1) CpBulkA<J - 1, 3>::fm(d, prev); CP_SB();
+    inv = __builtin_fma(u, q, y0);
+    CP_SB(); if constexpr (J >= 1) CpBulkA<J - 1, 4>::fm(d, prev); CP_SB();
+    d[J + 1] -= d[J]*l1;
+    if constexpr (J >= 1) CpBulkA<J - 1, 5>::fm(d, prev);
+    CP_SB();
+    if constexpr (J + 2 < CP_SPLIT) d[J + 2] -= d[J]*l2;
+    CP_SB();
+  }
+}
+// pivots CP_SPLIT .. 31 on wavefront 0: ba_chol.h's chol_panel_pivot, but column CP_SPLIT - 1's bulk update is not wavefront 0's
+template <int J>
+__device__ inline void cp_pivot_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf) {
+  double* cur = (J & 1) ? mO : mE;
+  double* prev = (J & 1) ? mE : mO;
+  constexpr bool BULK = J >= CP_SPLIT + 1;
+  d[J] *= inv;
+  if constexpr (J + 3 < CH_NB) colbuf[threadIdx.x] = d[J];
+  CP_SB();
+  if constexpr (J + 1 < CH_NB) {
+    const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
+    const double l1 = readlane_f64(d[J], J + 1);
+    double l2 = 0.0;
+    if constexpr (J + 2 < CH_NB) l2 = readlane_f64(d[J], J + 2);
+    const double pn = readlane_f64(w, J + 1);
+    bad |= !(pn > 0.0);
+    if constexpr (J + 3 < CH_NB) {
+#pragma unroll
+      for (int c = J + 3; c < CH_NB; ++c) cur[c] = colbuf[c];
+    }
+    CP_SB();
+    const double y0 = __builtin_amdgcn_rsq(pn);
+    CP_SB(); if constexpr (BULK) ChBulk<J - 1, 0>::fm(d, prev); CP_SB();
+    const double t = y0*(-pn);
+    CP_SB(); if constexpr (BULK) ChBulk<J - 1, 1>::fm(d, prev); CP_SB();
+    const double e = __builtin_fma(t, y0, 1.0);
+    CP_SB(); if constexpr (BULK) ChBulk<J - 1, 2>::fm(d, prev); CP_SB();
+    const double u = y0*e;
+    const double q = __builtin_fma(e, 0.375, 0.5);
+    CP_SB(); if constexpr (BULK) ChBulk<J - 1, 3>::fm(d, prev); CP_SB();
+    inv = __builtin_fma(u, q, y0);
+    CP_SB(); if constexpr (BULK) ChBulk<J - 1, 4>::fm(d, prev); CP_SB();
+    d[J + 1] -= d[J]*l1;
+    if constexpr (BULK) ChBulk<J - 1, 5>::fm(d, prev);
+    CP_SB();
+    if constexpr (J + 2 < CH_NB) d[J + 2] -= d[J]*l2;
+    CP_SB();
+  }
+}
+#undef CP_SB
+template <int... Js>
+__device__ inline void cp_pivots_a(double* d, double& inv, bool& bad, double* mE, double* mO, double* lcol, const double* lrow, int* prog, int pbase, std::integer_sequence<int, Js...>) {
+  (cp_pivot_a<Js>(d, inv, bad, mE, mO, lcol, lrow, prog, pbase), ...);
+}
+template <int... Js>
+__device__ inline void cp_pivots_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf, std::integer_sequence<int, Js...>) {
+  (cp_pivot_b<CP_SPLIT + Js>(d, inv, bad, mE, mO, colbuf), ...);
+}
+__device__ inline int cp_lds_word(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// wavefront 0: L L^T = D (a diagonal tile arrives with the identity beyond the matrix), L^-1 -> Dinv (row-major): lanes 0..31 carry
+// the tile's rows, lanes 32..63 the identity through the same column operations.  Dinv doubles as Lcol / the hand-over buffer while the
+// panel runs; ctlw[0..63] = the columns published so far (monotonic over the steps: 16 k + J + 1; a word per lane), ctlw[64..127] = the follower's hand-overs.
+__device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf, const double* zvec, int* ctlw, int k, int* fail, int q, int s) {
   const int lane = threadIdx.x;
   int rr = lane & 31;
   asm volatile("" : "+v"(rr));       // opaque per call
   const bool low = lane >= 32;
   double d[CH_NB];
-  // lanes 0..31 read their row of the tile, lanes 32..63 their row of the identity -- the SAME 32 loads with another base address:
+  // lanes 0..31 read their row of the tile, lanes 32..63 their row of the identity -- the SAME loads with another base address:
   // zvec[0..62] is zero but for zvec[31] = 1, so zvec + 31 - r is row r of the identity.  (Round 5 loaded the tile on every lane and
   // swapped the identity in with a compare and a select per entry: 130 instructions, 0.35 us of the 0.52 us this entry took.)
   const double* src = low ? zvec + (CH_NB - 1 - rr) : &D[rr][0];
 #pragma unroll
-  for (int c = 0; c < CH_NB; ++c) d[c] = src[c];
+  for (int c = 0; c < CP_SPLIT; ++c) d[c] = src[c];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  double* Lcol = &Dinv[0][0];
   const double piv0 = readlane_f64(d[0], 0);
   bool bad = !(piv0 > 0.0);
   double inv = rsqrt(piv0);
   if (lane == 0) CP_STAMP(s, 9);
-  chol_panel_pivots(d, inv, bad, colbuf, std::make_integer_sequence<int, CH_NB>());
+  double mE[CH_NB], mO[CH_NB];
+  cp_pivots_a(d, inv, bad, mE, mO, Lcol + lane, Lcol, ctlw, CP_SPLIT*k, std::make_integer_sequence<int, CP_SPLIT>());
+  if (lane == 0) CP_STAMP(s, 14);
+  // the follower's columns
+  while (cp_lds_word(ctlw + 64) != k + 1) __builtin_amdgcn_s_sleep(0);
+#pragma unroll
+  for (int c = 0; c < CH_NB - CP_SPLIT; ++c) d[CP_SPLIT + c] = Lcol[c*64 + lane];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const double pn = readlane_f64(d[CP_SPLIT], CP_SPLIT);
+    bad |= !(pn > 0.0);
+    inv = cp_rsq3(pn);
+  }
+  if (lane == 0) CP_STAMP(s, 15);
+  cp_pivots_b(d, inv, bad, mE, mO, colbuf, std::make_integer_sequence<int, CH_NB - CP_SPLIT>());
   if (lane == 0) CP_STAMP(s, 10);
   if (bad && lane == 0) atomicOr(fail, 2);
   // lane 32 + r ends with row r of L^-T = column r of L^-1.  Its entries left of the diagonal ARE zero (0 - 0 m = 0 through every
@@ -256,6 +401,54 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) Dinv[c][rr] = d[c];
   }
+}
+// the follower (wavefront 1): columns CP_SPLIT .. 31 of the same 64 rows; applies the columns wavefront 0 publishes, hands over.
+// Column K's words are asked for together with the progress word (read FIRST: LDS serves a wavefront in order, so a progress value
+// that says "column K is there" vouches for the data read behind it), one column ahead of the multiply-adds; scheduling barriers keep
+// the compiler from asking for ALL the columns at once (it did: 400 spills, a hand-over of 10 us).
+constexpr int CP_NC = CH_NB - CP_SPLIT;
+struct CpCol { int pw; double own; double m[CP_NC]; };
+__device__ __forceinline__ void cp_follow_ask(CpCol& c, const double* Lcol, const int* prog, int K, int lane) {
+  c.pw = cp_lds_word(prog);
+  c.own = Lcol[K*64 + lane];
+#pragma unroll
+  for (int i = 0; i < CP_NC; ++i) c.m[i] = Lcol[K*64 + CP_SPLIT + i];
+}
+template <int K>
+__device__ __forceinline__ void cp_follow_col(double* dh, CpCol& cur, CpCol& nxt, const double* Lcol, const int* prog, int pbase, int lane) {
+  while (cur.pw - pbase <= K) { __builtin_amdgcn_s_sleep(0); cp_follow_ask(cur, Lcol, prog, K, lane); }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (K + 1 < CP_SPLIT) cp_follow_ask(nxt, Lcol, prog, K + 1, lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < CP_NC; ++i) dh[i] -= cur.own*cur.m[i];
+  // (pins the multiply-adds HERE: their results are only read at the hand-over, and the compiler sank all 256 of them behind the
+  //  last column's poll loop, keeping sixteen columns of multipliers alive in scratch)
+#pragma unroll
+  for (int i = 0; i < CP_NC; ++i) asm volatile("" : "+v"(dh[i]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int... Ks>
+__device__ __forceinline__ void cp_follow_cols(double* dh, CpCol& ca, CpCol& cb, const double* Lcol, const int* prog, int pbase, int lane, std::integer_sequence<int, Ks...>) {
+  ((Ks & 1 ? cp_follow_col<Ks>(dh, cb, ca, Lcol, prog, pbase, lane) : cp_follow_col<Ks>(dh, ca, cb, Lcol, prog, pbase, lane)), ...);
+}
+__device__ __forceinline__ void cp_follow(cp_tile D, cp_tile Dinv, const double* zvec, int* ctlw, int k) {
+  const int lane = threadIdx.x & 63;
+  const int rr = lane & 31;
+  const bool low = lane >= 32;
+  double dh[CP_NC];
+  const double* src = low ? zvec + (CH_NB - 1 - rr) : &D[rr][0];
+#pragma unroll
+  for (int c = 0; c < CP_NC; ++c) dh[c] = src[CP_SPLIT + c];
+  double* Lcol = &Dinv[0][0];
+  CpCol ca, cb;
+  cp_follow_ask(ca, Lcol, ctlw, 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  cp_follow_cols(dh, ca, cb, Lcol, ctlw, CP_SPLIT*k, lane, std::make_integer_sequence<int, CP_SPLIT>());
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < CP_NC; ++c) Lcol[c*64 + lane] = dh[c];
+  __hip_atomic_store(ctlw + 64 + lane, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (a word per lane, as the progress words)
 }
 
 __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
@@ -268,17 +461,19 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   auto Dt = [&](int i) { return (cp_tile)(lds + (6 + (i & 1))*CP_TILE); };
   double* colbuf = lds + 8*CP_TILE;
   double* zvec = colbuf + 64;                // [63]: rows of the identity for the panel's upper lanes (cp_potrf)
-  int* ctl = (int*)(zvec + 64);              // [0] team counter, [1] ok / abort word
+  int* pwords = (int*)(zvec + 64);           // [128]: the split panel's progress / hand-over words
+  int* ctl = pwords + 128;                   // [0] team counter, [1] ok / abort word
   int* flags = a.flags + (size_t)q*a.nflags;
   int* err = a.err + q; int* fail = a.fail + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
-  const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
+  const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride + (size_t)(a.epoch[q] & 1)*(a.bt_stride/2), (a.bt_stride/2)*sizeof(double));      // (this launch's copy of the band slots)
   const int* slot_of = a.slot_of; const int* bslot_of = a.bslot_of;
   const int epoch4 = a.epoch[q] << 2, done_l = epoch4 | 2;
   const int code = 0x100;
   int* stp = ctl + 16;                       // the step table
   for (int i = t; i < (ntc + 1)*CP_STEP_INTS; i += CP_THREADS) stp[i] = a.steps[i];
   if (t == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; }
+  if (t < 128) pwords[t] = 0;
   if (t < 64) zvec[t] = (t == CH_NB - 1) ? 1.0 : 0.0;
   __syncthreads();
   // ---- prologue: rows 0 and 1 of the band (their helpers pass A through) arrive as data-tagged chunks: wavefront w takes quadrant w of
@@ -300,7 +495,6 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
     }
     cp_regs_to_lds(Dt(0), wave, lane, p0); cp_regs_to_lds(Tc, wave, lane, p1);
     if (row1_diag) cp_regs_to_lds(Dt(1), wave, lane, p2);
-    cp_chunk_arm(rB, o0); cp_chunk_arm(rB, o1); if (row1_diag) cp_chunk_arm(rB, o2);      // the next launch finds the slots armed
   }
   __syncthreads();
   if (!ctl[1]) return;
@@ -324,7 +518,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         cp_barrier();
       }
       if (t == 0) CP_STAMP(s, 1);
-      if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, zvec, fail, q, s);
+      if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, zvec, pwords, i1, fail, q, s);
       if (t == 0) CP_STAMP(s, 2);
       cp_barrier();
       if (t == 0) CP_STAMP(s, 8);
@@ -334,7 +528,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
     return;
   }
   int dcur = 0;
-  int team_target = 0;
+  int team_target = 0, pair_target = 0;
   // The loop body starts where the team asks for the band row it needs a step later and ends where it has used it: the request and
   // its use sit in ONE iteration (carried around the loop the compiler waited for the loads at the loop head, i.e. hid nothing).
   // `s` is the step that is ending (-1: the lead-in, wavefront 0 factors diagonal tile 0).
@@ -352,6 +546,8 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
       if (t == 128) CP_STAMP(s, 4);
     }
+    if (s < 0 && wave == 1) cp_follow(Dt(0), Dv(0), zvec, pwords, 0);      // (the lead-in: diagonal tile 0's panel has its follower too)
+    if (MCP_CP_PROF_ARRIVE && lane == 0) CP_STAMP(s, 16 + wave);
     cp_barrier();                      // end of step s
     if (!ctl[1]) return;
     dcur ^= 1;
@@ -374,14 +570,15 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       // ---- P1: X1 = A'(s+1, s) L_ss^-T (all four wavefronts, a quadrant each)
       cp_regs_to_lds(Xb0, wave, lane, cp_trsm_quadrant(Tc, Ds, wave, lane));
       cp_barrier();
-      // ---- P2: A'(s+1, s+1) -= X1 X1^T on wavefronts 0, 2, 3 (the panel never reads quadrant (0, 1)); wavefront 1 sends L(s+1, s) off instead
-      if (wave == 1) {
+      // ---- P2: A'(s+1, s+1) -= X1 X1^T, quadrants 0 | 3 | 2 on wavefronts 0, 1, 2 (the panel never reads quadrant (0, 1)); wavefront 3 sends L(s+1, s) off instead
+      if (wave == 3) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
       } else if (i1 < ntc) {
-        chol_d4 acc = cp_lds_to_regs(Dt(dcur), wave, lane);
-        cp_mma<true>(acc, Xb0, Xb0, wave, lane);
-        cp_regs_to_lds(Dt(dcur), wave, lane, acc);
+        const int qd = wave == 1 ? 3 : wave;
+        chol_d4 acc = cp_lds_to_regs(Dt(dcur), qd, lane);
+        cp_mma<true>(acc, Xb0, Xb0, qd, lane);
+        cp_regs_to_lds(Dt(dcur), qd, lane, acc);
       }
       cp_barrier();
       // ---- P3: wavefront 0 factors the next diagonal tile; the team finishes column s
@@ -397,6 +594,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
             if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 4); ctl[1] = 0; break; }
           }
           __builtin_amdgcn_s_sleep(1);
+          CP_MISS(0);
           v0 = cp_ld4(rB, ob0); v1 = cp_ld4(rB, ob0 + 2048); v2 = cp_ld4(rB, ob1); v3 = cp_ld4(rB, ob1 + 2048); v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
         }
         // now that X1 is out of Tc the row goes to LDS
@@ -406,71 +604,71 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         if (diag2) { cp_regs_to_lds(Dt(dcur ^ 1), 2*h, lane, v4); cp_regs_to_lds(Dt(dcur ^ 1), 2*h + 1, lane, v5); }
       }
       CP_DRAIN();                      // every wavefront's share of L_ss^-1 / L(s+1, s) has landed
-      cp_team_sync(ctl, team_target, lane);
-      if (t == 64) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
-      // the late product of tile (s+2, s+1), data-tagged as well: every wavefront asks for the quadrants it will update (U1 below:
-      // 0 | 1 | 2, 3) and looks at them after its products.  (Round 5 waited for the product's flag HERE, before the solve: the solve
-      // then started when the product's helper was done, which in turn hung on the previous step's last flag -- a cycle one step long.)
+      if (tw == 0) {
+        // wavefront 1 checks in without waiting and follows the panel's first half (cp_follow); it is back for the products
+        team_target += 3;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (i1 < ntc) cp_follow(Dt(dcur), Dv(i1), zvec, pwords, i1);
+      } else cp_team_sync(ctl, team_target, lane);
+      if (t == 128) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
+      // the late product of tile (s+2, s+1), data-tagged as well: wavefronts 2, 3 ask for the two quadrants each will update (U1 below)
+      // and look at them after their products.  (Round 5 waited for the product's flag HERE, before the solve: the solve then started
+      // when the product's helper was done, which in turn hung on the previous step's last flag -- a cycle one step long.)
       chol_d4 dq0 = {0.0, 0.0, 0.0, 0.0}, dq1 = dq0;
-      const unsigned odq = dl >= 0 ? cp_chunk_off(dl, tw == 2 ? 2 : tw, lane) : 0u;
-      if (dl >= 0) { dq0 = cp_ld4(rB, odq); if (tw == 2) dq1 = cp_ld4(rB, odq + 2048); }
-      if (tw >= 1 && row2 && ctl[1]) {
-        // (the band row's slots are armed for the next launch: stores nobody waits for)
-        cp_chunk_arm(rB, ob0); cp_chunk_arm(rB, ob0 + 2048); cp_chunk_arm(rB, ob1); cp_chunk_arm(rB, ob1 + 2048);
-        if (diag2) { cp_chunk_arm(rB, ob2); cp_chunk_arm(rB, ob2 + 2048); }
-      }
+      const unsigned odq = (dl >= 0 && tw >= 1) ? cp_chunk_off(dl, 2*(tw - 1), lane) : 0u;
+      if (dl >= 0 && tw >= 1) { dq0 = cp_ld4(rB, odq); dq1 = cp_ld4(rB, odq + 2048); }
       if (t == 64) CP_STAMP(s, 5);
       if (row2 && ctl[1]) {
-        // (c) X2 = A'(s+2, s) L_ss^-T: the two right quadrants take 8 matrix instructions each, the two left ones 4 each
-        if (tw == 0) cp_regs_to_lds(Xb1, 1, lane, cp_trsm_quadrant(T2, Ds, 1, lane));
-        else if (tw == 1) cp_regs_to_lds(Xb1, 3, lane, cp_trsm_quadrant(T2, Ds, 3, lane));
-        else { cp_regs_to_lds(Xb1, 0, lane, cp_trsm_quadrant(T2, Ds, 0, lane)); cp_regs_to_lds(Xb1, 2, lane, cp_trsm_quadrant(T2, Ds, 2, lane)); }
-        cp_team_sync(ctl, team_target, lane);
-        if (t == 64) CP_STAMP(s, 6);
-        // (d) L(s+2, s) leaves first, ALL of it from wavefront 1, which can then raise its flag alone the moment its own products are done
-        //     (round 5 split the stores over the team and flagged after everybody's products: 1.7 us later -- and the late product of the
-        //     NEXT step hangs on this flag); then A'(s+2, s+1) -= X2 X1^T + late product, A'(s+2, s+2) -= X2 X2^T (lower triangle's
-        //     quadrants: the panel never reads (0, 1))
         const int s2 = se[CPS_S2];
-        if (tw == 0) {
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s2, qd, lane), cp_lds_to_regs(Xb1, qd, lane));
-        }
-        if (t == 64) CP_STAMP(s, 11);
-        const int qa = tw == 2 ? 2 : tw;
-        chol_d4 acc = cp_lds_to_regs(Tc, qa, lane), accb = {0.0, 0.0, 0.0, 0.0};       // U1 quadrant 0 | 1 | 2 and 3
-        cp_mma<true>(acc, Xb1, Xb0, qa, lane);
-        if (tw == 2) { accb = cp_lds_to_regs(Tc, 3, lane); cp_mma<true>(accb, Xb1, Xb0, 3, lane); }
-        else if (diag2) {
-          const int qd = tw == 0 ? 0 : 2;                                // U2 quadrants 0 | 2, then 3 with wavefront 2
-          chol_d4 acc2 = cp_lds_to_regs(Dt(dcur ^ 1), qd, lane);
-          cp_mma<true>(acc2, Xb1, Xb1, qd, lane);
-          cp_regs_to_lds(Dt(dcur ^ 1), qd, lane, acc2);
-          if (tw == 1) {
-            chol_d4 acc3 = cp_lds_to_regs(Dt(dcur ^ 1), 3, lane);
-            cp_mma<true>(acc3, Xb1, Xb1, 3, lane);
-            cp_regs_to_lds(Dt(dcur ^ 1), 3, lane, acc3);
+        if (tw >= 1) {
+          // (c) X2 = A'(s+2, s) L_ss^-T on wavefronts 2, 3 (a right quadrant, 8 matrix instructions, and a left one, 4, each)
+          const int qr = 2*tw - 1, ql = 2*tw - 2;          // 1, 0 | 3, 2
+          {
+            // (d) L(s+2, s) leaves the moment it exists, each wavefront its own two quadrants straight from the registers (the late product
+            //     of the NEXT step hangs on its flag); the slots this step has emptied are armed only AFTER that flag: on the one in-order
+            //     memory counter every store issued before L(s+2, s)'s delays the flag by its own round trip
+            const chol_d4 xr = cp_trsm_quadrant(T2, Ds, qr, lane), xl = cp_trsm_quadrant(T2, Ds, ql, lane);
+            cp_st4(rL, cp_chunk_off(s2, qr, lane), xr); cp_st4(rL, cp_chunk_off(s2, ql, lane), xl);
+            cp_regs_to_lds(Xb1, qr, lane, xr); cp_regs_to_lds(Xb1, ql, lane, xl);
           }
-        }
-        if (dl >= 0) {
-          unsigned it = 0; long long t0 = 0;
-          while (cp_wave_any(cp_chunk_missing(dq0) || (tw == 2 && cp_chunk_missing(dq1)))) {
-            if ((++it & 15) == 15) {
-              if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
-              if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
+          if (MCP_CP_PROF_ARRIVE && lane == 0) CP_STAMP(s, 20 + tw);
+          cp_pair_sync(ctl + 2, pair_target, lane);
+          if (t == 128) { CP_STAMP(s, 6); CP_STAMP(s, 11); }
+          // then A'(s+2, s+1) -= X2 X1^T + late product, two quadrants per wavefront
+          chol_d4 acc = cp_lds_to_regs(Tc, ql, lane), accb = cp_lds_to_regs(Tc, qr, lane);
+          cp_mma<true>(acc, Xb1, Xb0, ql, lane);
+          cp_mma<true>(accb, Xb1, Xb0, qr, lane);
+          if (dl >= 0) {
+            unsigned it = 0; long long t0 = 0;
+            while (cp_wave_any(cp_chunk_missing(dq0) || cp_chunk_missing(dq1))) {
+              if ((++it & 15) == 15) {
+                if (cp_flag_load(err) != 0) { ctl[1] = 0; break; }
+                if (!t0) t0 = wall_clock64(); else if (cp_expired(t0)) { if (lane == 0) cp_flag_store(err, code | 7); ctl[1] = 0; break; }
+              }
+              __builtin_amdgcn_s_sleep(1);
+              CP_MISS(1);
+              dq0 = cp_ld4(rB, odq); dq1 = cp_ld4(rB, odq + 2048);
             }
-            __builtin_amdgcn_s_sleep(1);
-            dq0 = cp_ld4(rB, odq); if (tw == 2) dq1 = cp_ld4(rB, odq + 2048);
+            acc += dq0; accb += dq1;                                     // (the helper summed -L(s+2,s-1) L(s+1,s-1)^T)
           }
-          cp_chunk_arm(rB, odq); if (tw == 2) cp_chunk_arm(rB, odq + 2048);
-          acc += dq0; accb += dq1;                                       // (the helper summed -L(s+2,s-1) L(s+1,s-1)^T)
-        }
-        cp_regs_to_lds(Tc, qa, lane, acc);
-        if (tw == 2) cp_regs_to_lds(Tc, 3, lane, accb);
-        if (t == 64) CP_STAMP(s, 12);
-        if (tw == 0) {
+          cp_regs_to_lds(Tc, ql, lane, acc); cp_regs_to_lds(Tc, qr, lane, accb);
+          if (t == 128) CP_STAMP(s, 12);
+          // both wavefronts' stores have landed -> one flag
           CP_DRAIN();
-          if (lane == 0) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
+          cp_pair_sync(ctl + 2, pair_target, lane);
+          if (t == 128) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
+        } else {
+          // wavefront 1, back from the panel: A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1)) once
+          // the solve is complete (it usually has been for a while)
+          while (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target + 2) __builtin_amdgcn_s_sleep(1);
+          pair_target += 4;                // (the pair meets twice per step: after its solve and before L(s+2, s)'s flag)
+          asm volatile("" ::: "memory");
+          if (diag2) {
+            chol_d4 a0 = cp_lds_to_regs(Dt(dcur ^ 1), 0, lane), a2 = cp_lds_to_regs(Dt(dcur ^ 1), 2, lane), a3 = cp_lds_to_regs(Dt(dcur ^ 1), 3, lane);
+            cp_mma<true>(a0, Xb1, Xb1, 0, lane); cp_mma<true>(a2, Xb1, Xb1, 2, lane); cp_mma<true>(a3, Xb1, Xb1, 3, lane);
+            cp_regs_to_lds(Dt(dcur ^ 1), 0, lane, a0); cp_regs_to_lds(Dt(dcur ^ 1), 2, lane, a2); cp_regs_to_lds(Dt(dcur ^ 1), 3, lane, a3);
+          }
         }
       }
     }
@@ -486,7 +684,9 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   int* flags = a.flags + (size_t)q*a.nflags;
   int* err = a.err + q;
   const __amdgpu_buffer_rsrc_t rL = cp_rsrc(a.Lt + q*a.lt_stride, a.lt_stride*sizeof(double));
-  const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride, a.bt_stride*sizeof(double));
+  const int par = a.epoch[q] & 1;
+  const __amdgpu_buffer_rsrc_t rB = cp_rsrc(a.Bt + q*a.bt_stride + (size_t)par*(a.bt_stride/2), (a.bt_stride/2)*sizeof(double));
+  const __amdgpu_buffer_rsrc_t rBo = cp_rsrc(a.Bt + q*a.bt_stride + (size_t)(par ^ 1)*(a.bt_stride/2), (a.bt_stride/2)*sizeof(double));      // (the NEXT launch's copy)
   const double* S = a.S + q*a.sys_stride;
   const int epoch4 = a.epoch[q] << 2, done_l = epoch4 | 2;
   const int code = 0x200 | (hidx << 12);
@@ -552,6 +752,7 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   }
   if (h.kind == 1) {          // band tile / late product: the sum goes to the critical workgroup, data-tagged -- no drain, no flag (CP_DRAIN's note)
     cp_st4(rB, cp_chunk_off(h.dslot, wave, lane), acc);        // (dslot of a band tile = its band slot)
+    cp_chunk_arm(rBo, cp_chunk_off(h.dslot, wave, lane));      // ... and the slot's other copy is armed for the next launch (below)
     if (t == 0) CP_HSTAMP(3);
     return true;
   }
@@ -570,7 +771,7 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   return true;
 }
 
-constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 64 + 8;          // + the step table of the critical workgroup behind it
+constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 64 + 64 + 8;          // + the step table of the critical workgroup behind it
 __global__ void __launch_bounds__(CP_THREADS, 2)
 k_chol_persist(CpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
@@ -944,7 +1145,7 @@ struct CholPersist {
       e[4] = slot_of[(size_t)ntc*ntc + k];
       e[5] = far_start[ntc - 1 - k + 1] > far_start[ntc - 1 - k] ? 1 : 0;
     }
-    lt_stride = (size_t)nslots*CP_TQ; bt_stride = (size_t)std::max(nbslots, 1)*CP_TQ; vec_stride = ntc*CH_NB;
+    lt_stride = (size_t)nslots*CP_TQ; bt_stride = (size_t)2*std::max(nbslots, 1)*CP_TQ; vec_stride = ntc*CH_NB;
     // lay the arena out (every part 256-byte aligned), stage the tables in one host block, one upload
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     struct Part { const void* src; size_t bytes; void** dst; };

@@ -3316,13 +3316,23 @@ int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, i
     std::vector<unsigned long long> pr(256*16), hp(8192*4);
     (void)hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_cp_prof), pr.size()*8); (void)hipMemcpyFromSymbol(hp.data(), HIP_SYMBOL(g_cp_hprof), hp.size()*8);
     const CholPersist& P = plan.persist;
+    { unsigned int ms[8] = {0}; (void)hipMemcpyFromSymbol(ms, HIP_SYMBOL(g_cp_miss), sizeof ms); fprintf(stderr, "[cp prof] over %d launches: band rows asked for again %u times, late products %u times (per wavefront)\n", reps, ms[0], ms[1]); }
     auto us = [&](unsigned long long a, unsigned long long b0) { return a && b0 ? ((double)a - (double)b0)*0.01 : -1.0; };
     fprintf(stderr, "[cp prof] n=%d ntc=%d helpers=%d   (us from the start of P3: wave 0 reads D | pivots | writes L^-1;  team: flags of L^-1, L(s+1,s) | [next row polled, measured from P3 as well] | staged row in LDS | trsm | last flag;  step)\n", n, P.ntc, P.nhelpers);
+#if MCP_CP_PROF == 5
+    { double a[4] = {0, 0, 0, 0}, st = 0, w2[6] = {0, 0, 0, 0, 0, 0}; int c5 = 0;
+      for (int s = 2; s + 3 < P.ntc; ++s, ++c5) { const unsigned long long* q0 = &pr[(s + 1)*16]; a[0] += us(q0[2], q0[0]); for (int w = 1; w < 4; ++w) a[w] += us(q0[4 + w], q0[0]); st += us(q0[8], q0[0]);
+        w2[0] += us(q0[3], q0[0]); w2[1] += us(q0[11], q0[0]); w2[2] += us(q0[12], q0[0]); w2[3] += us(q0[13], q0[0]); w2[4] += us(q0[14], q0[0]); w2[5] += us(q0[15], q0[0]); }
+      if (c5) fprintf(stderr, "  solve done and L(s+2,s) on its way: wave 2 %.2f  wave 3 %.2f\n", w2[3]/c5, w2[4]/c5);
+      if (c5) fprintf(stderr, "  wave 2, us from the step's start: flags of L^-1 / L(s+1,s) %.2f  solve done, X2 stores issued %.2f  products done %.2f\n", w2[0]/c5, w2[1]/c5, w2[2]/c5);
+      if (c5) fprintf(stderr, "  arrival at the step's last barrier, us from the step's start (mean over %d steps): wave 0 %.2f  wave 1 %.2f  wave 2 %.2f  wave 3 %.2f | step %.2f\n", c5, a[0]/c5, a[1]/c5, a[2]/c5, a[3]/c5, st/c5); }
+#endif
     double sum[10] = {0}; int c2 = 0;
     for (int s = 2; s + 3 < P.ntc; ++s, ++c2) {
       const unsigned long long* q0 = &pr[(s + 1)*16];
       const double v[10] = {us(q0[1], q0[0]), us(q0[9], q0[1]), us(q0[10], q0[9]), us(q0[2], q0[10]), us(q0[3], q0[1]), us(q0[4], q0[1]), us(q0[5], q0[1]), us(q0[6], q0[1]), us(q0[7], q0[1]), us(q0[8], q0[0])};
       for (int i = 0; i < 10; ++i) sum[i] += v[i];
+      if (s == 10) fprintf(stderr, "  step 10, panel: first half %.2f  hand-over %.2f  second half %.2f\n", us(q0[14], q0[9]), us(q0[15], q0[14]), us(q0[10], q0[15]));
       if (s == 10) fprintf(stderr, "  step 10, wave 1 after the trsm: X2 stores issued %+.2f  products done %+.2f  drained %+.2f  flag %+.2f\n", us(q0[11], q0[6]), us(q0[12], q0[6]), us(q0[13], q0[6]), us(q0[7], q0[6]));
       if (s >= 10 && s < 13) {
         fprintf(stderr, "  step %2d: P1+P2 %5.2f | D in %5.2f pivots %5.2f L^-1 out %5.2f | published %5.2f polled %5.2f in LDS %5.2f trsm %5.2f flag %5.2f | step %5.2f\n", s, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);

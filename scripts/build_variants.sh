@@ -42,6 +42,7 @@ for v in "$@"; do
     cpprof2) build cpprof2 -DMCP_CP_PROF=2 & ;;
     cpprof3) build cpprof3 -DMCP_CP_PROF=3 & ;;
     cpprof4) build cpprof4 -DMCP_CP_PROF=4 & ;;
+    cpprof5) build cpprof5 -DMCP_CP_PROF=5 & ;;            # only each wavefront's arrival at the step's last barrier
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
