@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = "r05"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
+ROUND = "r06"                # profiles/<ROUND>/ holds this round's rocprofv3 summaries; files of other rounds are never read
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # fp64 vector == matrix rate on MI355X (SURVEY.md 8(d) nominal; not in the guide's table)
 
@@ -93,6 +93,11 @@ def stage_rooflines(tm, M, N, np_, n_lin, n_trials, n_solves):
             ach = useful * flops / dur / 1e12
             out[name] = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
                              traffic=None, avg_ms=tm[key] / n_solves, launches=n_solves, flops_per_launch=useful * flops)
+            if name == "cholesky" and tm.get("chol_flops_plan", 0) > 0:
+                # SURVEY 8(d)'s basis above is the DENSE (6P)^3 / 3; the plan only touches the tiles a banded trajectory fills
+                pl = useful * tm["chol_flops_plan"] / dur / 1e12
+                out[name]["plan_basis"] = {"flops_per_factorisation": tm["chol_flops_plan"], "dense_flops": flops, "achieved": pl, "frac": pl / FP64_PEAK_TFLOPS,
+                                           "note": "tile operations of the block-sparse plan after symbolic fill (mcp_ba_timing.chol_flops_plan); `achieved` / `frac` above keep the dense basis of SURVEY 8(d)"}
     traffic = load_traffic()
     steps = (np_ + 31) // 32
     for name, r in out.items():
@@ -371,7 +376,7 @@ def main():
             result["config"]["reduced_system_solves"] = tm["n_solves"]
             result["config"]["trials_served_speculatively"] = tm["n_spec_hits"]
             result["config"]["persist_fallbacks"] = tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"]      # 0 in a healthy run (one-launch factorisation never timed out)
-            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic", "limited_by", "mfma_executed") if kk in v} for k, v in roofs.items()}}
+            result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic", "limited_by", "mfma_executed", "plan_basis") if kk in v} for k, v in roofs.items()}}
     # CPU baselines on this box's host cores, same map, same run; the oracle's iteration log doubles as the
     # parity check of the GPU run that was just timed
     if rank == 0 and world == 1 and args.cpu_iters > 0:
@@ -477,6 +482,20 @@ def main():
                                        "ms_median": {k: float(np.median(v)) for k, v in parts.items()}, "calls_timed": len(calls)}
         except Exception as exc:
             result["recent_window"] = {"error": repr(exc)}
+    # secondary lines: the other ChainBundle configurations of BASELINE.json on this one device -- c2, c4 as a whole map, and one rank's
+    # eighth of c4 through the multi-rank machine (scripts/bench_secondary.py); the inputs of DESIGN.md 6's scaling model
+    if rank == 0 and world == 1 and args.config == "metric" and args.cpu_iters > 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_secondary
+            result["secondary"] = {}
+            for name_ in ("c2", "c4", "c4_rank_shard"):
+                try:
+                    result["secondary"][name_] = bench_secondary.run(name_, steps=10, device=local_rank)
+                except Exception as exc:
+                    result["secondary"][name_] = {"error": repr(exc)}
+        except Exception as exc:
+            result["secondary"] = {"error": repr(exc)}
     # secondary line: the per-frame Tracker path (BASELINE config c3), GPU through the C ABI next to the scalar CPU port
     if rank == 0 and world == 1 and not args.no_tracker and args.cpu_iters > 0:
         try:

@@ -98,6 +98,10 @@ typedef struct mcp_ba_timing {
    * structurally non-zero 6x3 . 3x3 . 3x6 block products it stands for (sum over the free points of k (k + 1) / 2 x 324, k = poses
    * that see the point: SURVEY 8(d)) */
   double schur_mfma_per_system, schur_flops_structural;
+  /* flops of ONE factorisation as its plan executes it: 32 x 32 tile operations of the block-sparse plan after symbolic fill (a product
+   * 2 x 32^3, a triangular solve 32^3, a diagonal tile's factorisation + inverse 2/3 x 32^3); the dense (6P)^3 / 3 of SURVEY 8(d) is
+   * the upper bound a banded trajectory stays well below (0 if no plan was built) */
+  double chol_flops_plan;
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);
@@ -137,8 +141,15 @@ int mcp_ba_add_measurements(mcp_ba*, int count, const int* chains, int stride,
  * n_iter < 0 selects params.max_iterations; n_iter == 0 runs no iteration (g2o optimize(0)), which the reference
  * reports as -1 unless the abort flag is up.  Return value as the reference: number of outer iterations run (>0),
  * 0 = aborted before any step, -1 = no iteration could be run (:1355-1366).  MCP_BA_ERR_RUNTIME (-2) is NOT a
- * reference outcome: a HIP / RCCL call failed (mcp_last_error() says which), the state was not written back. */
+ * reference outcome: a HIP / RCCL call failed (mcp_last_error() says which), the state was not written back.
+ *
+ * A SIZE LIMIT THE REFERENCE DOES NOT HAVE: the reduced pose system is factored as one dense-in-tiles matrix whose solution vector
+ * the back-substitution keeps in LDS, so a map may hold at most MCP_BA_MAX_FREE_POSES free poses (6 P <= 6144 unknowns; every
+ * BASELINE configuration is below it: c4 has 499).  Beyond it mcp_ba_prepare returns -1 and mcp_ba_compute MCP_BA_ERR_RUNTIME, with
+ * "too many free poses ..." in mcp_last_error() and nothing is solved (g2o + CHOLMOD would go on, src/ChainBundle.cc:1150-1158); the
+ * caller's remedy is what MCPTAM does anyway for large maps -- BundleAdjustRecent's window with the rest of the poses fixed. */
 #define MCP_BA_ERR_RUNTIME (-2)
+#define MCP_BA_MAX_FREE_POSES 1024
 int mcp_ba_compute(mcp_ba*, volatile unsigned char* abort_flag, int n_iter, double user_lambda);
 
 int    mcp_ba_converged(mcp_ba*);                 /* Converged()          ChainBundle.h:146 */

@@ -1039,6 +1039,7 @@ struct CholPersist {
   double *d_Lt = nullptr, *d_Bt = nullptr, *d_x = nullptr, *d_f = nullptr;
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
   int nworkers = 0;                      // helper workgroups per system (MCP_BA_CHOL_WORKERS)
+  double flops = 0;                      // of one factorisation as this plan executes it (tile operations; mcp_ba_timing.chol_flops_plan)
   int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
   ~CholPersist() { release(); }
   // One device arena per plan: [tables (one upload) | flags, error words, epochs | L tiles | band tiles | x | f], a block of the
@@ -1120,6 +1121,13 @@ struct CholPersist {
       helpers.push_back(h);
     }
     nhelpers = (int)helpers.size();
+    {
+      const double t3 = (double)CH_NB*CH_NB*CH_NB;
+      int nfar = 0; for (const CpHelper& h : helpers) if (h.kind == 0) ++nfar;
+      // helpers: a product per list entry, a triangular solve per far tile; critical workgroup per block column: two solves (rows s+1, s+2),
+      // three products (the band's updates), a diagonal tile's factorisation + inverse
+      flops = 2.0*t3*(double)upd.size() + t3*nfar + (double)ntc*(2.0*t3 + 3.0*2.0*t3 + 2.0*t3/3.0);
+    }
     steps.assign((size_t)(ntc + 1)*CP_STEP_INTS, -1);
     for (int st = -1; st < ntc; ++st) {
       int* e = &steps[(size_t)(st + 1)*CP_STEP_INTS];
@@ -1204,8 +1212,9 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   a.epoch = P.d_epoch + q0; P.fail_ptr = fail; a.claim = P.d_err + CholPersist::max_sys + q0;
   a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
+  (void)hipGetLastError();          // (a leftover of an earlier, unrelated runtime call -- a stream query's hipErrorNotReady -- is not this launch's refusal)
   hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;       // (a launch the runtime refuses -- its LDS or grid does not fit this device -- is reported here, by name, not at the end of the solve)
+  { const hipError_t e = hipGetLastError(); return (e == hipSuccess || e == hipErrorNotReady) ? 0 : -1; }       // (a launch the runtime refuses -- its LDS or grid does not fit this device -- is reported here, by name, not at the end of the solve)
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)
 inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys, size_t sys_stride, int q0) {
@@ -1216,8 +1225,9 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   a.xout = S + q0*sys_stride + (size_t)P.n*P.n; a.sys_stride = sys_stride; a.err = P.d_err + q0; a.epoch = P.d_epoch + q0; a.fail = P.fail_ptr ? P.fail_ptr + q0 : nullptr; a.claim = P.d_err + CholPersist::max_sys + q0;
   static_assert(CP_BACK_NEAR == 3 && CPB_INTS == 8, "the chain workgroup's column table holds three near tiles");
   const size_t lds = (size_t)(6*CP_TILE + 3*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double) + (size_t)(P.ntc*CPB_INTS + 18)*sizeof(int);
+  (void)hipGetLastError();
   hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  { const hipError_t e = hipGetLastError(); return (e == hipSuccess || e == hipErrorNotReady) ? 0 : -1; }
 }
 
 }  // namespace mcp

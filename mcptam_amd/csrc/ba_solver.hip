@@ -46,6 +46,7 @@ void mcp_set_error(const char* s) { g_err = s; }      // shared with img_api.hip
 // MCP_ERR_RUNTIME (-2): HIP / RCCL failure.  Kept apart from -1, which mcp_ba_compute also uses for the reference's
 // legitimate "no iteration ran" outcome (ChainBundle.cc:1355-1366); the wrappers raise on -2.
 constexpr int MCP_ERR_RUNTIME = -2;
+static_assert(MCP_BA_MAX_FREE_POSES*6 == mcp::CH_SOLVE_MAX, "include/mcp_ba.h documents the solver's size limit");
 #define HIPCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
   set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return MCP_ERR_RUNTIME; } } while (0)
 #define HIPCKV(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -219,7 +220,7 @@ static void upload_set_launch(const UploadSet& U, hipStream_t st) {
   if (U.n == 0) return;
   size_t mx = 0; for (int r = 0; r < U.n; ++r) mx = std::max<size_t>(mx, U.n8[r]);
   const unsigned bx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (mx + 255)/256));
-  hipLaunchKernelGGL(k_upload_set, dim3(bx, U.n), dim3(256), 0, st, U);
+  hipLaunchKernelGGL(k_upload_set, dim3(bx, U.n), dim3(256), 0, st, U);      // (callers follow with note_launch("k_upload_set"))
 }
 
 // std::allocator whose resize(n) leaves new elements uninitialised (bulk entries size the arrays once and fill every record)
@@ -446,6 +447,8 @@ struct mcp_ba {
   int head_ahead_for = -1;        // state buffer whose iteration head is already on the main stream (small bundles), or -1
   bool head_ahead_want = false; int dbg_head_ahead = 0;
   int head_ahead(int w);
+  int large_head_ahead = 1;       // MCP_BA_HEAD_AHEAD: the same for maps beyond the small-bundle limit (round 6)
+  int head_ahead_large(int w);
   int head_small(int w, bool sum_aside = false);
   int join_sum();
   int sum_aside(); int sum_w = -1; const double* sum_sig = nullptr;
@@ -1625,6 +1628,7 @@ int mcp_ba::prepare_legacy() {
 
 // allocation + upload of a finished host structure (common to both builders)
 int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace, const StructEntry* hit) {
+  pending_entry.reset();          // (whatever an earlier, failed Prepare() of this handle left behind is not this call's to publish)
   auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
   const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
@@ -1766,7 +1770,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
         UploadSet V; V.n = 0;             // a small bundle: the kernel reads the pinned values in place
         if (nm) { upload_set_add(V, vals, d_m_u.p, nm*sizeof(double)); upload_set_add(V, vals + nm, d_m_v.p, nm*sizeof(double)); upload_set_add(V, vals + 2*nm, d_m_omega.p, nm*sizeof(double)); }
         if (cs) upload_set_add(V, cs, d_cams.p, cams.size()*sizeof(mcp_camera));
-        upload_set_launch(V, st);
+        upload_set_launch(V, st); note_launch("k_upload_set");
       } else {
         if (nm) {
           HIPCK(hipMemcpyAsync(d_m_u.p, vals, nm*sizeof(double), hipMemcpyHostToDevice, st));
@@ -1858,7 +1862,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     upload_set_add(Z, nullptr, d_xp_good.p, std::max<size_t>(np, 1)*sizeof(double));
     upload_set_add(Z, nullptr, d_xl_good.p, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double));
     upload_set_add(Z, nullptr, d_sigma.p, 16*sizeof(double));
-    upload_set_launch(Z, st);
+    upload_set_launch(Z, st); note_launch("k_upload_set");
   } else {
     HIPCK(hipMemsetAsync(d_xp_good.p, 0, std::max<size_t>(np, 1)*sizeof(double), st));
     HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
@@ -1889,8 +1893,17 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     }
   }
   lap("alloc+upload");
-  if (upload_state()) return -1;
-  HIPCK(hipStreamSynchronize(st));
+  if (upload_state()) { pending_entry.reset(); return -1; }
+  {
+    const hipError_t es = hipStreamSynchronize(st);
+    //  an entry enters the process-wide structure cache only when everything that fills its device clone has COMPLETED;
+    // on any failure it is dropped here, not left for the handle's next successful Prepare() to publish under the old key
+    if (es != hipSuccess || !launch_err.empty()) {
+      pending_entry.reset();
+      if (es != hipSuccess) { set_err(std::string("Prepare: ") + hipGetErrorString(es)); return -1; }
+      set_err("Prepare: a launch was refused: " + launch_err); launch_err.clear(); return -1;
+    }
+  }
   if (pending_entry) { StructCache::get().insert(pending_entry); pending_entry.reset(); }
   lap("state");
   dirty = false;
@@ -1928,6 +1941,7 @@ int mcp_ba::upload_state() {
   const size_t nmax = std::max(nps, npt);
   if (nmax) hipLaunchKernelGGL(k_fan_state, dim3((unsigned)((nmax + 255)/256)), dim3(256), 0, st, nps, npt, in_place ? (const double*)stage : (const double*)d_pose[0].p,
                                in_place ? (const double*)(stage + nps) : (const double*)d_pt[0].p, f);
+  if (nmax) note_launch("k_fan_state");                // (reads the pinned stage: a refused launch would leave the device state unset and nothing else would say so)
   return 0;
 }
 int mcp_ba::download_state() {
@@ -2307,6 +2321,23 @@ int mcp_ba::head_ahead(int w) {
   return 0;
 }
 
+// The same for a map beyond the small-bundle limit (round 6; SURVEY 8(a) a10/a11, src/ChainBundle.cc:810-833, 913-917): the median of
+// the trial state's |chi2| (two histogram passes, gather, one-workgroup finish that writes the sigma block), the robust chi2 at that
+// sigma and the block the host reads with the next trial, enqueued behind the trial's own kernels on the main stream.  Round 5 started
+// this chain when the host had seen the trial's result and decided: 65 us between an accepted trial and the next linearisation, of
+// which the host's turn-around was 20-30 and the chain itself the rest; now the chain runs DURING the turn-around, and the next
+// iteration finds sigma^2 in the other parity's block.  A rejected trial's block is never looked at (head_ahead()'s note).
+int mcp_ba::head_ahead_large(int w) {
+  for (int q = 1; q < MAX_SYS; ++q) if (ev_tr[q]) HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));
+  if (robust) { if (median_sigma(w)) return -1; }      // (flips to the fresh sigma block)
+  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[w].p, (const double*)sig(), d_part0.p);
+  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 24, (const int*)nullptr);
+  if (robust) sig_par ^= 1;                            // ... which becomes the current one only if the trial is accepted (compute())
+  head_ahead_for = w;
+  return 0;
+}
+
 // one LM trial up to and including the evaluation of the trial state.
 // factorisation + back-substitution of systems [q0, q0 + n) of the batch on stream s: ~40 dependent launches, or -- with
 // MCP_BA_GRAPH=1 -- one launch of a graph captured the first time this sub-batch shape occurs (same buffers, same plan every time).
@@ -2471,7 +2502,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   }
   toc();
   mark("trial_end", st);
-  if (head_ahead_want && mailbox && !multi()) { if (head_ahead(tr)) return -1; mark("head_ahead", st); }
+  if (head_ahead_want && mailbox && !multi()) { if (small ? head_ahead(tr) : head_ahead_large(tr)) return -1; mark("head_ahead", st); }
   if (defer_nsys) {
     const int n2 = defer_n2;
     if (solve_chain(st2, n2, defer_n1)) return -1;
@@ -2540,6 +2571,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   int conv_mag = 0, conv_res = 0;
   if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
   timing.schur_mfma_per_system = schur_mfma; timing.schur_flops_structural = schur_flops;
+  timing.chol_flops_plan = (np > 0 && plan.persist.ok) ? plan.persist.flops : 0.0;
   converged = 0; total_iterations = 0; spec_hot = 0;
   int nCounter = 0;
   // emptiness is decided on the GLOBAL totals: a rank whose shard holds no measurement (or no free point) still runs every
@@ -2558,7 +2590,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       //  would be accepted -- head_ahead(); all that is left is to make its sigma block the current one)
       const bool head_done = (it > 0 && head_ahead_for == cur);
       head_ahead_for = -1;
-      head_ahead_want = small_mode() && use_mailbox && !prm.profile && it + 1 < n_iter;
+      head_ahead_want = (small_mode() || (large_head_ahead && !multi())) && use_mailbox && !prm.profile && it + 1 < n_iter;
       if (head_done) { if (robust) sig_par ^= 1; ++dbg_head_ahead; }
       else if (small_mode()) { if (head_small(cur)) return MCP_ERR_RUNTIME; }
       else {
@@ -2759,8 +2791,12 @@ int mcp_ba::final_stats(int nCounter) {
     if (flags_dev) hipLaunchKernelGGL(k_tukey_flags_dev, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, (const double*)d_res.p, med_idx, (double)m_total,
                                       prm.min_mestimator_sigma, h_exp + exp_state);
     const size_t nps = poses.size()*12, npt = points.size()*3;
+    if (flags_dev) note_launch("k_tukey_flags_dev");
     if (nps + npt) hipLaunchKernelGGL(k_export_state, dim3((unsigned)((nps + npt + 255)/256)), dim3(256), 0, st, nps, npt, (const double*)d_pose[cur].p, (const double*)d_pt[cur].p, reinterpret_cast<double*>(h_exp));
-    return 0;
+    if (nps + npt) note_launch("k_export_state");
+    // (these two write the pinned block download_state() and the outlier list read; a launch the runtime refused must not
+    //  pass for an export -- compute() then reports launch_err, and `exported` stays false so nothing is read from the stale block)
+    return launch_err.empty() ? 0 : -1;
   };
   // a trial evaluated ahead that nobody consumed may still be running on the second stream and reads the sigma block of the parity
   // median_sigma() is about to rewrite: order everything behind it first (it had only ever been joined by the next solve)
@@ -2888,6 +2924,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_MAIN_SYS"); if (e) h->main_sys = atoi(e); }
   { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
+  { const char* e = getenv("MCP_BA_HEAD_AHEAD"); if (e) h->large_head_ahead = atoi(e); }
   { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
   { const char* e = getenv("MCP_BA_TEST_FAIL_TRIAL"); if (e) h->test_fail_trial = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_DELAY"); if (e) h->spec_delay = atoi(e); }
@@ -2951,7 +2988,10 @@ int mcp_ba_add_points(mcp_ba* h, int count, const double* x, const int* chains, 
                       const unsigned char* fixed, int* ids_out) {
   static const bool trace = getenv("MCP_BA_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  h->points.reserve(h->points.size() + count); h->id_kind.reserve(h->id_kind.size() + count); h->id_index.reserve(h->id_index.size() + count);
+  // (reserve(size + count) allocates exactly that much with libstdc++ -- an adapter adding points in many small batches would
+  //  reallocate and copy the whole arrays every call; grow geometrically instead, and only when the batch does not fit)
+  auto grow = [&](auto& v) { const size_t need = v.size() + (size_t)count; if (need > v.capacity()) v.reserve(std::max(need, 2*v.capacity())); };
+  grow(h->points); grow(h->id_kind); grow(h->id_index);
   for (int i = 0; i < count; ++i) {
     int id = mcp_ba_add_point(h, x + 3*(size_t)i, chains + (size_t)stride*i, chain_len[i], fixed ? fixed[i] : 0);
     if (id < 0) return -1;

@@ -112,6 +112,27 @@ def test_non_robust_and_verbose_modes(gpu_required):
         assert gpu["outliers"] == ref["outliers"]
 
 
+def test_more_free_poses_than_the_reduced_solver_takes_is_an_error_not_a_wrong_answer(gpu_required):
+    """include/mcp_ba.h, MCP_BA_MAX_FREE_POSES: the reduced system is dense in tiles with its solution vector in LDS, so 6 P <= 6144.
+    A map with more free poses (the reference has no such limit: CHOLMOD goes on, src/ChainBundle.cc:1150-1158) must come back as an
+    error with a message that says so -- from Prepare() and from Compute() -- and one pose less must still solve."""
+    from mcptam_amd import synth
+    for n_free, ok in ((1025, False), (1024, True)):
+        p = synth.make_problem(n_cams=4, n_mkf=n_free + 1, n_points=3000, per_point=4, mode="multi", outlier_frac=0.0)
+        assert int((~p.base_fixed).sum()) == n_free
+        g = _gpu(p.cams, disable_convergence=True)
+        p.populate(g)
+        if ok:
+            assert g.Prepare() == 6 * n_free + 3 * p.n_points
+            assert g.Compute(2) == 2
+        else:
+            with pytest.raises(RuntimeError, match="too many free poses"):
+                g.Prepare()
+            with pytest.raises(RuntimeError, match="too many free poses"):
+                g.Compute(2)
+        g.close()
+
+
 def test_fixed_points_and_single_chain(gpu_required):
     """Calibration-style fixed points use the chain {world} and chi2 < 0 forces weight 1 (ChainBundle.cc:401-417)."""
     from mcptam_amd import synth
@@ -942,9 +963,10 @@ def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeyp
 
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
                                  dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
-                                 dict(MCP_BA_STREAM_POOL="0"), dict(MCP_BA_SCHUR4_ORDER="0")])
+                                 dict(MCP_BA_STREAM_POOL="0"), dict(MCP_BA_SCHUR4_ORDER="0"), dict(MCP_BA_HEAD_AHEAD="0")])
 def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
-    """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox and graph replay are
+    """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox, graph replay and the
+    iteration head (median, sigma^2, robust chi2) enqueued behind a trial before the host has accepted it are
     scheduling: the same kernels see the same inputs whichever of them is on, so iteration logs, poses and points are identical
     to the default configuration's, bit for bit (the knobs are read when the handle is created).  Likewise the launch order of the
     Schur groups."""
