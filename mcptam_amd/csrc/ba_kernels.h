@@ -216,7 +216,7 @@ k_robust_sum(int n, int robust, const double* __restrict__ chi2, const double* _
 constexpr int MAIL_TICKET = 31;
 __device__ __forceinline__ void final_sums_body(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
              double* __restrict__ out, int off, const int* __restrict__ fail, double* mail, int mail_count, unsigned long long ticket,
-             const double* ride_src, int ride_dst) {
+             const double* ride_src, int ride_dst, const double* start_src = nullptr /* entries [24, 29) of the mailbox from here instead of out */) {
   __shared__ double lds[4];
   const double* ps[3] = { p0, p1, p2 }; const int ns[3] = { n0, n1, n2 };
   for (int a = 0; a < 3; ++a) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void final_sums_body(int n0, const double* p0, int n1
   if (ride_src && threadIdx.x == 0) out[ride_dst] = ride_src[0];
   if (mail) {
     __syncthreads();                                 // thread 0's stores to `out` above; the other entries come from earlier kernels of the stream
-    for (int i = threadIdx.x; i < mail_count; i += 256) mail[i] = out[i];
+    for (int i = threadIdx.x; i < mail_count; i += 256) mail[i] = (start_src && i >= 24 && i < 29) ? start_src[i - 24] : out[i];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store((unsigned long long*)(mail + MAIL_TICKET), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -241,8 +241,9 @@ __device__ __forceinline__ void final_sums_body(int n0, const double* p0, int n1
 __global__ void __launch_bounds__(256)
 k_final_sums(int n0, const double* p0, int n1, const double* p1, int n2, const double* p2,
              double* __restrict__ out, int off, const int* __restrict__ fail, double* mail = nullptr, int mail_count = 0, unsigned long long ticket = 0,
-             const double* ride_src = nullptr, int ride_dst = 0 /* out[ride_dst] = ride_src[0]: a value of an earlier kernel joins this block's all-reduce */) {
-  final_sums_body(n0, p0, n1, p1, n2, p2, out, off, fail, mail, mail_count, ticket, ride_src, ride_dst);
+             const double* ride_src = nullptr, int ride_dst = 0 /* out[ride_dst] = ride_src[0]: a value of an earlier kernel joins this block's all-reduce */,
+             const double* start_src = nullptr /* the iteration-start block forwarded to the host lives here (a per-trial head's, ba_solver.hip enqueue_head) */) {
+  final_sums_body(n0, p0, n1, p1, n2, p2, out, off, fail, mail, mail_count, ticket, ride_src, ride_dst, start_src);
 }
 
 // ------------------------------------------------------------------------------------------

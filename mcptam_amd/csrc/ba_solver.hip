@@ -34,6 +34,7 @@
 #include "ba_schur4.h"
 #include "ba_comm.h"
 #include "ba_trial.h"
+#include "ba_head.h"
 #include "ba_small.h"
 
 using namespace mcp;
@@ -447,15 +448,36 @@ struct mcp_ba {
   int head_ahead_for = -1;        // state buffer whose iteration head is already on the main stream (small bundles), or -1
   bool head_ahead_want = false; int dbg_head_ahead = 0;
   int head_ahead(int w);
-  int large_head_ahead = 1;       // MCP_BA_HEAD_AHEAD: the same for maps beyond the small-bundle limit (round 6)
-  int head_ahead_large(int w);
+  // The same for maps beyond the small-bundle limit (round 6, MCP_BA_HEAD_AHEAD; ba_head.h): EVERY trial of an iteration -- the one on
+  // the main stream and the ones evaluated ahead on the second -- counts the digit histograms of its |chi2| while it evaluates them
+  // and is followed by ONE kernel that finishes the median and writes the sigma block of the iteration its acceptance would start,
+  // each trial into its own scratch and its own sigma / start block: slot [parity of the iteration][q].  The accepted trial's blocks
+  // become the current ones (sig_idx, start_blk); the others are never looked at.
+  // MEASURED (profiles/r06/README.md): with the heads on, a one-trial iteration reaches its linearisation 11 us after it starts (65 without)
+  // and every iteration finds its sigma^2 ready -- but the two extra launches + events per trial on the host and the heads' kernels
+  // beside the trials' cost more than that saves on the metric map: 1290-1335 it/s with them, 1335-1385 without, same box and run.
+  // So the default is OFF; MCP_BA_HEAD_AHEAD=1 switches every trial's head on, =2 only the main stream's.  Bit-identical either way.
+  int large_head_ahead = 0;
+  struct HeadScratch { unsigned int* hist = nullptr; double* vals = nullptr; double* part = nullptr; double* out = nullptr; double* rs = nullptr; };
+  HeadScratch hsc[2*MAX_SYS]; DevBuf<double> d_headbuf;
+  hipStream_t st_h = nullptr; bool st_h_own = false;      // the heads of trials evaluated ahead run here: the second stream stays free for the NEXT trial ahead
+  hipEvent_t head_ev[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
+  bool head_enq[MAX_SYS] = {false, false, false, false}; int head_state[MAX_SYS] = {-1, -1, -1, -1};
+  unsigned long long head_ticket[MAX_SYS] = {0, 0, 0, 0}, head_ticket_ctr = 0;
+  int head_par = 0, acc_head_q = -1, dbg_head_miss = 0;
+  const double* start_blk = nullptr;      // the iteration-start block the first trial forwards to the host (nullptr: d_res[24..28])
+  unsigned int* head_hist(int q) { return hsc[head_par*MAX_SYS + q].hist; }
+  int enqueue_head(hipStream_t s, int q, int w, bool side);
+  int wait_head(int q);
+  bool large_heads() const { return large_head_ahead && robust && !multi() && !small_mode() && d_headbuf.p != nullptr; }
   int head_small(int w, bool sum_aside = false);
   int join_sum();
   int sum_aside(); int sum_w = -1; const double* sum_sig = nullptr;
   hipEvent_t ev_head = nullptr, ev_sum = nullptr; bool sum_pending = false;
   DevBuf<double> d_parth;         // partial sums of the robust chi2 taken on the second stream (head_small)
   int small_on = 1;               // MCP_BA_SMALL=0: a small bundle runs the same launches as a large one (ba_small.h)
-  bool small_mode() const { return small_on && !multi() && P.nmeas > 0 && P.nmeas <= SMALL_MEAS && P.nchain <= SMALL_CHAINS; }
+  bool small_mode_for(int nmeas_, int nchain_) const { return small_on && !multi() && nmeas_ > 0 && nmeas_ <= SMALL_MEAS && nchain_ <= SMALL_CHAINS; }
+  bool small_mode() const { return small_mode_for(P.nmeas, P.nchain); }
   int grp_pts = GRP_PTS;          // points per group: GRP_PTS, or LIN_QUAD_PTS for a map of few points (k_linearize_quad: four lanes per point)
   static int group_points(int nsp) {
     const char* e = getenv("MCP_BA_SMALL_POINTS"); const int small_pts = e ? atoi(e) : 16384;      // (0: the large-map layout for every map)
@@ -493,11 +515,17 @@ struct mcp_ba {
   // The sigma block is double-buffered by median: a trial evaluated ahead on the speculative stream that nobody consumes may
   // still be reading its iteration's block when the next iteration's median writes the new one (the two streams only meet
   // again in linearize()'s join_spec()); the block after that is written behind that join.
-  int sig_par = 0;
-  double* sig() { return d_sigma.p + 8*sig_par; }
+  // sigma blocks: 0, 1 = the pair the iteration head alternates between (a fresh block: stragglers of the last iteration keep reading
+  // theirs); 2 + parity*MAX_SYS + q = the block of a large map's per-trial head (above)
+  static constexpr int N_SIG = 2 + 2*MAX_SYS;
+  int sig_idx = 0;
+  double* sig_block(int i) { return d_sigma.p + 8*i; }
+  double* sig() { return sig_block(sig_idx); }
+  void flip_sig() { sig_idx = (sig_idx == 0) ? 1 : 0; }
   DevBuf<SelState> d_selstate;
   DevBuf<int> d_fail;
-  static constexpr size_t HRES = 32 + 32*MAX_SYS + 8;
+  static constexpr size_t HRES = 32 + 32*MAX_SYS + 8 + 2*MAX_SYS;      // ... + the status word and ticket of every per-trial head (ba_head.h)
+  static constexpr size_t HEAD_MAIL = 32 + 32*MAX_SYS + 8;
   double* h_res = nullptr;  // pinned, device-visible; [32..63] is the mailbox k_final_sums writes (ticket at 32 + MAIL_TICKET)
   unsigned char* h_exp = nullptr; size_t h_exp_cap = 0; bool exported = false;      // pinned: the state [poses | points] and the Tukey flags of a finished solve, written by kernels (final_stats)
   int ensure_export(size_t bytes) {
@@ -554,6 +582,7 @@ struct mcp_ba {
     if (st) (void)hipStreamSynchronize(st);
     if (st2) (void)hipStreamSynchronize(st2);
     if (st3) (void)hipStreamSynchronize(st3);
+    if (st_h) (void)hipStreamSynchronize(st_h);
     for (int q = 0; q < MAX_SYS; ++q) if (st_tr[q]) (void)hipStreamSynchronize(st_tr[q]);
     (void)hipStreamSynchronize(nullptr);          // (synchronous copies and the debug hooks use the null stream)
   }
@@ -569,6 +598,8 @@ struct mcp_ba {
     for (int q = 0; q <= MAX_SYS; ++q) for (int r = 0; r < MAX_SYS; ++r) if (chain_exec[q][r]) (void)hipGraphExecDestroy(chain_exec[q][r]);
     if (st2) { (void)hipStreamSynchronize(st2); if (!pooled) (void)hipStreamDestroy(st2); }
     if (st3) { (void)hipStreamSynchronize(st3); if (!pooled) (void)hipStreamDestroy(st3); }
+    if (st_h && st_h_own) (void)hipStreamDestroy(st_h);
+    for (int q = 0; q < MAX_SYS; ++q) if (head_ev[q]) (void)hipEventDestroy(head_ev[q]);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_head) (void)hipEventDestroy(ev_head);
     if (ev_sum) (void)hipEventDestroy(ev_sum);
@@ -1838,8 +1869,26 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       d_str.alloc(MAX_SYS*(size_t)nrhs_rows*6) || d_udiag.alloc(np) || d_red.alloc(MAX_SYS*(n2 + 2*(size_t)np)) || d_V.alloc((size_t)nfl*6) || d_g.alloc((size_t)nfl*3) ||
       d_W.alloc((size_t)ninc*18) || d_Vinv.alloc(MAX_SYS*(size_t)nfl*6) || d_xl.alloc((size_t)nfl*3) ||
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
-      d_part2.alloc(nblk) || d_parth.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(16) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
+      d_part2.alloc(nblk) || d_parth.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(8*N_SIG) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
+  {
+    // scratch of the per-trial iteration heads (ba_head.h): per slot [parity][q] the digit histograms + counters, the candidates,
+    // the robust chi2's partial sums, the median and the iteration-start block
+    for (auto& H : hsc) H = HeadScratch();
+    if (large_head_ahead && robust && !multi() && !small_mode_for(nmeas, (int)nc) && nmeas > 0) {
+      auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
+      const size_t n_hist = al((HEAD_HIST + HEAD_CTL + 1)/2), n_vals = al(HEAD_CAND), n_part = al(std::max<size_t>(nblk, 1)), per = n_hist + n_vals + n_part + 32;
+      if (d_headbuf.alloc(per*2*MAX_SYS)) return -1;
+      for (int i = 0; i < 2*MAX_SYS; ++i) {
+        double* b = d_headbuf.p + per*i;
+        hsc[i].hist = reinterpret_cast<unsigned int*>(b); hsc[i].vals = b + n_hist; hsc[i].part = hsc[i].vals + n_vals;
+        hsc[i].out = hsc[i].part + n_part; hsc[i].rs = hsc[i].out + 8;
+        HIPCK(hipMemsetAsync(hsc[i].hist, 0, (HEAD_HIST + HEAD_CTL)*sizeof(unsigned int), st));       // (every head leaves them zero again)
+      }
+    } else d_headbuf.release();
+    for (int q = 0; q < MAX_SYS; ++q) { head_enq[q] = false; head_state[q] = -1; }
+    acc_head_q = -1; start_blk = nullptr;
+  }
   if (const char* e = getenv("MCP_BA_DEBUG_POISON_RED")) {      // test aid: "q,lo,hi" -- the reduced-system buffer zeroed, doubles [lo, hi) of system q set to NaN
     int q = 0; long lo = 0, hi = 0;
     if (std::sscanf(e, "%d,%ld,%ld", &q, &lo, &hi) == 3 && q >= 0 && q < MAX_SYS && lo >= 0 && hi <= (long)(n2 + 2*(size_t)np) && lo < hi) {
@@ -1868,7 +1917,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
     HIPCK(hipMemsetAsync(d_xl_good.p, 0, std::max<size_t>((size_t)nfl*3, 1)*sizeof(double), st));
     HIPCK(hipMemsetAsync(d_sigma.p, 0, 16*sizeof(double), st));
   }
-  sig_par = 0;
+  sig_idx = 0;
 
   P.cams = d_cams.p; P.ncam = (int)cams.size(); P.nchain = (int)nc; P.chain_len = d_chain_len.p; P.chain_pose = d_chain_pose.p;
   P.npose = npose; P.pose_unk = d_pose_unk.p; P.npoint = npoint; P.pt_chain = d_pt_chain.p; P.pt_unk = d_pt_unk.p;
@@ -2031,7 +2080,7 @@ int mcp_ba::select_gather_finish(const double* x, int n, const double* hist, Sel
 // RobustKernelData::RecomputeNow on the chi2 array of buffer `w`
 int mcp_ba::median_sigma(int w) {
   tic(ST_SELECT);
-  sig_par ^= 1;                                                      // a fresh block: stragglers of the last iteration keep reading theirs
+  flip_sig();                                                        // a fresh block: stragglers of the last iteration keep reading theirs
   const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
   // several ranks, and the state is the one an accepted trial left: that trial's all-reduce carried the first two digit histograms
   // of this very chi2 array (ba_trial.h) -- if its prediction held and the selected bin fits the gather table, the median costs
@@ -2123,6 +2172,7 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   HIPCK(hipEventRecord(ev_wf[q], s));                     // the linearisation's outputs are not read below this line (join_spec_lin)
   if (P.nchain && !small) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
+  const bool with_head = head_ahead_want && !small && large_heads() && large_head_ahead != 2 && nbe > 0;      // (MCP_BA_HEAD_AHEAD=2: only the main stream's trial carries a head)
   if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
                               (const double*)sig(), d_sp0[q].p);
   pre_ticket[q] = ++mail_ticket;
@@ -2133,6 +2183,7 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
                      nbb, (const double*)(nfl ? d_sp2[q].p : nullptr), resq, 0, (const int*)d_fail.p + q, h_mail_dev + 32*q, 6, pre_ticket[q]);
   HIPCK(hipEventRecord(ev_tr[q], s));
   pre_run[q] = true; ahead_enq[q] = true;
+  if (with_head) { if (enqueue_head(s, q, slot, true)) return -1; }
   return 0;
 }
 // the iteration has decided (or starts a new solve): a trial evaluated ahead that nobody asked for is simply never looked at
@@ -2268,7 +2319,7 @@ int mcp_ba::build_system(int nsys, SysBatch& sbfull, int q0, hipStream_t on) {
 int mcp_ba::head_small(int w, bool sum_aside) {
   tic(ST_SELECT);
   const double* prev = sig();
-  if (robust) { sig_par ^= 1; sel_src = -1; }
+  if (robust) { flip_sig(); sel_src = -1; }
   // sum_aside: linearize() needs the sigma block, nobody on the device needs the robust chi2 (the host reads it with the next
   // trial's results): that sum -- a third of this kernel's time -- goes to the second stream, next to the linearisation
   const bool aside = sum_aside && st2 && ev_head && ev_sum && d_parth.p;
@@ -2316,26 +2367,46 @@ int mcp_ba::join_sum() {
 int mcp_ba::head_ahead(int w) {
   for (int q = 1; q < MAX_SYS; ++q) if (ev_tr[q]) HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));
   if (head_small(w, true)) return -1;                // (flips to the fresh sigma block)
-  if (robust) sig_par ^= 1;                          // ... which becomes the current one only if the trial is accepted (compute())
+  if (robust) flip_sig();                            // ... which becomes the current one only if the trial is accepted (compute())
   head_ahead_for = w;
   return 0;
 }
 
-// The same for a map beyond the small-bundle limit (round 6; SURVEY 8(a) a10/a11, src/ChainBundle.cc:810-833, 913-917): the median of
-// the trial state's |chi2| (two histogram passes, gather, one-workgroup finish that writes the sigma block), the robust chi2 at that
-// sigma and the block the host reads with the next trial, enqueued behind the trial's own kernels on the main stream.  Round 5 started
-// this chain when the host had seen the trial's result and decided: 65 us between an accepted trial and the next linearisation, of
-// which the host's turn-around was 20-30 and the chain itself the rest; now the chain runs DURING the turn-around, and the next
-// iteration finds sigma^2 in the other parity's block.  A rejected trial's block is never looked at (head_ahead()'s note).
-int mcp_ba::head_ahead_large(int w) {
-  for (int q = 1; q < MAX_SYS; ++q) if (ev_tr[q]) HIPCK(hipStreamWaitEvent(st, ev_tr[q], 0));
-  if (robust) { if (median_sigma(w)) return -1; }      // (flips to the fresh sigma block)
-  const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
-  if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[w].p, (const double*)sig(), d_part0.p);
-  hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 24, (const int*)nullptr);
-  if (robust) sig_par ^= 1;                            // ... which becomes the current one only if the trial is accepted (compute())
-  head_ahead_for = w;
+// The head of the iteration that accepting trial q would start, for a map beyond the small-bundle limit (round 6; SURVEY 8(a) a10 / a11,
+// src/ChainBundle.cc:810-833, 913-917, MEstimator.h:194-204; kernels in ba_head.h): TWO launches behind the trial's result block count
+// the first digits of its |chi2|, finish the median and write slot [head_par][q]'s sigma block, and tell the host through a pinned
+// status word whether they could.  Round 5 started the selection (four launches) when
+// the host had seen an accepted trial's result: 65 us between that trial and the next linearisation; now the next iteration starts at
+// its linearisation.  The robust chi2 at the new sigma -- which only the HOST needs, with the first trial's result -- is summed beside
+// the linearisation on the second stream (compute()).
+int mcp_ba::enqueue_head(hipStream_t s_trial, int q, int w, bool side) {
+  HeadScratch& H = hsc[head_par*MAX_SYS + q];
+  // a trial evaluated ahead: its head forks off its last kernel (ev_tr[q]) onto the head stream -- on the second stream it would sit in
+  // front of the next trial ahead (measured: +38 us per rejected trial, more than the heads save)
+  hipStream_t s = (side && st_h) ? st_h : s_trial;
+  if (s != s_trial) HIPCK(hipStreamWaitEvent(s, ev_tr[q], 0));
+  head_ticket[q] = ++head_ticket_ctr;
+  hipLaunchKernelGGL(k_head_hist, dim3(HEAD_GRID), dim3(HEAD_THREADS), 0, s, P.nmeas, (const double*)d_chi2[w].p, (const double*)sig(), H.hist);
+  hipLaunchKernelGGL(k_head_finish, dim3(HEAD_GRID), dim3(HEAD_THREADS), 0, s, P.nmeas, (const double*)d_chi2[w].p, H.hist, H.vals, (const double*)sig(),
+                     (unsigned long long)(m_total/2), m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma,
+                     sig_block(2 + head_par*MAX_SYS + q), H.rs + 1, H.out, h_mail_dev - 32 + HEAD_MAIL + 2*q, head_ticket[q]);
+  note_launch("k_head_finish");
+  HIPCK(hipEventRecord(head_ev[q], s));
+  head_enq[q] = true; head_state[q] = w;
   return 0;
+}
+// the status word of trial q's head: 1 = its sigma block is written, 2 = it could not (prediction missed: plain selection), -1 = error
+int mcp_ba::wait_head(int q) {
+  const double* box = h_res + HEAD_MAIL + 2*q;
+  volatile unsigned long long* tk = (volatile unsigned long long*)(box + 1);
+  const auto w0 = std::chrono::steady_clock::now();
+  for (unsigned long long spins = 0; __atomic_load_n(tk, __ATOMIC_ACQUIRE) != head_ticket[q]; ++spins) {
+    if ((spins & 0xfff) == 0xfff) {
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count() > timeout_ms) return watchdog_fail("the status word of an iteration head");
+      std::this_thread::yield();
+    }
+  }
+  return box[0] == 1.0 ? 1 : 2;
 }
 
 // one LM trial up to and including the evaluation of the trial state.
@@ -2488,6 +2559,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   const bool mailbox = use_mailbox && !prm.profile;
   mail_ticket0 = ++mail_ticket;
+  const bool with_head = head_ahead_want && mailbox && !small && large_heads();
   launch_eval(tr, true, nullptr);
   if (multi()) {
     // (several ranks: the sums are rank-local until the trial's all-reduce; k_trial_post writes the block and the mailbox)
@@ -2497,12 +2569,12 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (join_sum()) return -1;                       // (this launch forwards d_res[24..28], the head of the iteration, to the host)
     hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, nbb, (const double*)(nfl ? d_part1.p : nullptr),
                        nbb, (const double*)(nfl ? d_part2.p : nullptr), d_res.p, 0, (const int*)d_fail.p + sys_cur,
-                       mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0);
+                       mailbox ? h_mail_dev : (double*)nullptr, 29, mail_ticket0, (const double*)nullptr, 0, start_blk);
     if (!nfl) HIPCK(hipMemsetAsync(d_res.p + 1, 0, 2*sizeof(double), st));
   }
   toc();
   mark("trial_end", st);
-  if (head_ahead_want && mailbox && !multi()) { if (small ? head_ahead(tr) : head_ahead_large(tr)) return -1; mark("head_ahead", st); }
+  if (head_ahead_want && mailbox && !multi() && small) { if (head_ahead(tr)) return -1; mark("head_ahead", st); }
   if (defer_nsys) {
     const int n2 = defer_n2;
     if (solve_chain(st2, n2, defer_n1)) return -1;
@@ -2520,6 +2592,9 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
     if (run_ahead(1)) return -1;
     if (spec_trials >= 2 && !multi()) for (int q = 2; q < defer_nsys; ++q) if (run_ahead(q)) return -1;
   } else if (ahead_single) { if (run_ahead(1)) return -1; }
+  // (the head of this trial's state goes out AFTER the next trial ahead has been handed to the second stream: the device needs ~70 us
+  //  for the trial's own kernels, the host ~4 us per launch -- the trial ahead must not wait for the host to get through the head's)
+  if (with_head && mailbox && !multi()) { if (enqueue_head(st, sys_cur, tr, false)) return -1; mark("head_ahead", st); }
   if (sum_aside()) return -1;
   if (mailbox) {
     // the block (trial results [0..7], iteration-start block [24..28]) is already on its way to the host
@@ -2588,10 +2663,40 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
       // (small bundle: the head of this iteration was enqueued behind the trial that produced this state, before the host knew it
       //  would be accepted -- head_ahead(); all that is left is to make its sigma block the current one)
-      const bool head_done = (it > 0 && head_ahead_for == cur);
+      bool head_done = (it > 0 && head_ahead_for == cur);
       head_ahead_for = -1;
-      head_ahead_want = (small_mode() || (large_head_ahead && !multi())) && use_mailbox && !prm.profile && it + 1 < n_iter;
-      if (head_done) { if (robust) sig_par ^= 1; ++dbg_head_ahead; }
+      if (head_done) { if (robust) flip_sig(); ++dbg_head_ahead; }
+      start_blk = nullptr;
+      bool lin_done = false;
+      if (it > 0 && large_heads() && acc_head_q >= 0 && head_enq[acc_head_q] && head_state[acc_head_q] == cur) {
+        // The accepted trial brought its head along (enqueue_head).  The linearisation goes out behind it AT ONCE, on the assumption that
+        // the head could finish the median (it nearly always can); only then does the host look at the head's status word -- if the
+        // prediction missed (nothing was written to the block), the plain selection runs and the linearisation is simply redone.
+        const int q = acc_head_q, keep = sig_idx;
+        HeadScratch& H = hsc[head_par*MAX_SYS + q];
+        HIPCK(hipStreamWaitEvent(st, head_ev[q], 0));          // (a trial evaluated ahead: its head ran on the head stream)
+        sig_idx = 2 + head_par*MAX_SYS + q;
+        start_rides = false;
+        if (linearize()) return MCP_ERR_RUNTIME;
+        const int hs = wait_head(q);
+        if (hs < 0) return MCP_ERR_RUNTIME;
+        if (hs == 1) {
+          start_blk = H.rs;
+          // the robust chi2 of the new current state at the new sigma: the host's business (it arrives with the first trial's result), so
+          // it is summed BESIDE the linearisation, on the second stream if there is one
+          hipStream_t ss = (st2 && ev_sum) ? st2 : st;
+          if (ss != st) HIPCK(hipStreamWaitEvent(ss, head_ev[q], 0));
+          if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, ss, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), H.part);
+          hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, ss, nbe, (const double*)H.part, 0, (const double*)nullptr, 0, (const double*)nullptr, H.rs, 0, (const int*)nullptr);
+          if (ss != st) { HIPCK(hipEventRecord(ev_sum, ss)); sum_pending = true; }
+          head_done = true; lin_done = true; ++dbg_head_ahead;
+        } else { sig_idx = keep; ++dbg_head_miss; }
+      }
+      acc_head_q = -1;
+      for (int q = 0; q < MAX_SYS; ++q) head_enq[q] = false;      // (what this iteration's trials enqueue goes to the other parity's slots)
+      head_par = it & 1;
+      head_ahead_want = (small_mode() || large_heads()) && use_mailbox && !prm.profile && it + 1 < n_iter;
+      if (head_done) { }
       else if (small_mode()) { if (head_small(cur)) return MCP_ERR_RUNTIME; }
       else {
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
@@ -2607,7 +2712,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       // the first iteration needs it before its first trial
       if (it == 0) { if (allreduce(d_res.p + RS, 1, 0, false, "iteration-start chi2")) return MCP_ERR_RUNTIME; }
       start_rides = (it > 0 && multi());
-      if (linearize()) return MCP_ERR_RUNTIME;
+      if (!lin_done) { if (linearize()) return MCP_ERR_RUNTIME; }
       if (it == 0 && !(user_lambda > 0)) {
         // computeLambdaInit [g2o]: 1e-5 * max |H_jj| over the pose and point diagonals; the pose diagonal is summed from
         // the staged blocks (and over the ranks), the point diagonals are rank-local (maximum over ranks taken below)
@@ -2661,6 +2766,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           tempChi = DBL_MAX;
           scale = 0; ss = 0;
           head_ahead_for = -1;                       // (the state is about to be rewritten with the stale step)
+          for (int q = 0; q < MAX_SYS; ++q) head_enq[q] = false;
           std::vector<double> xp(np), xl((size_t)nfl*3), bpv(np), gv((size_t)nfl*3);
           if (np) { HIPCK(hipMemcpy(xp.data(), d_xp_good.p, (size_t)np*8, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(bpv.data(), bp(), (size_t)np*8, hipMemcpyDeviceToHost)); }
           if (nfl) { HIPCK(hipMemcpy(xl.data(), d_xl_good.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); HIPCK(hipMemcpy(gv.data(), d_g.p, (size_t)nfl*24, hipMemcpyDeviceToHost)); }
@@ -2701,6 +2807,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
           const double sf = std::max(1./3., alpha);
           lambda *= sf; ni = 2; currentChi = tempChi; accepted = 1;
           cur = last_tr;                             // discardTop: the trial state becomes current
+          acc_head_q = ok2 ? sys_cur : -1;           // (its head, if one was enqueued behind it, is for exactly this state)
           // ... and the digit histograms that rode on its all-reduce describe the new chi2 array -- unless the factorisation had failed:
           // then the accepted state is the STALE step's (negative scale), whose chi2 never rode on anything
           sel_src = (multi() && ok2) ? sys_cur : -1;
@@ -2739,7 +2846,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   }
   if (join_spec()) return MCP_ERR_RUNTIME;
   if (join_sum()) return MCP_ERR_RUNTIME;
-  if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d\n", dbg_head_ahead); dbg_head_ahead = 0; }
+  if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d (median prediction missed: %d)\n", dbg_head_ahead, dbg_head_miss); dbg_head_ahead = 0; dbg_head_miss = 0; }
 #ifdef MCP_HS_PROF
   if (evt_debug) {
     (void)hipDeviceSynchronize();
@@ -2796,7 +2903,8 @@ int mcp_ba::final_stats(int nCounter) {
     if (nps + npt) note_launch("k_export_state");
     // (these two write the pinned block download_state() and the outlier list read; a launch the runtime refused must not
     //  pass for an export -- compute() then reports launch_err, and `exported` stays false so nothing is read from the stale block)
-    return launch_err.empty() ? 0 : -1;
+    if (!launch_err.empty()) { set_err("a launch of this solve failed: " + launch_err); return -1; }      // (the first refusal of the solve, by kernel name)
+    return 0;
   };
   // a trial evaluated ahead that nobody consumed may still be running on the second stream and reads the sigma block of the parity
   // median_sigma() is about to rewrite: order everything behind it first (it had only ever been joined by the next solve)
@@ -2941,6 +3049,13 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   } else {
     if (h->spec_trials >= 2) for (int q = 2; q < mcp::MAX_SYS; ++q) if (hipStreamCreateWithFlags(&h->st_tr[q], hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); delete h; return nullptr; }
     if (h->overlap_spec && (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || (h->overlap_spec >= 2 && hipStreamCreateWithFlags(&h->st3, hipStreamNonBlocking) != hipSuccess))) { set_err("second stream could not be created"); delete h; return nullptr; }
+  }
+  if (h->large_head_ahead) {
+    // the head stream: the pool's fourth side stream (measured to overlap with the main one if a hardware queue was left), else an own one
+    if (h->pooled && pool->spec3 && pool->spec3 != h->st3) h->st_h = pool->spec3;
+    else if (hipStreamCreateWithFlags(&h->st_h, hipStreamNonBlocking) == hipSuccess) h->st_h_own = true;
+    else { (void)hipGetLastError(); h->st_h = nullptr; }
+    for (int q = 0; q < mcp::MAX_SYS; ++q) if (hipEventCreateWithFlags(&h->head_ev[q], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return nullptr; }
   }
   if (h->overlap_spec && (
                           hipEventCreateWithFlags(&h->ev_spec3, hipEventDisableTiming) != hipSuccess ||
