@@ -322,6 +322,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the adjustment MCPTAM makes NEXT (src/MapMaker.cc:225-230, 283-287): the outliers this adjustment flagged are erased
+    # (MapMakerServerBase::HandleOutliers, src/MapMakerServerBase.cc:1198-1238), poses and points stay where it left them, and a fresh
+    # ChainBundle adjusts again -- a topology the structure cache has NOT seen, but a subset of one it has (include/mcp_ba.h, near miss)
+    after_removal = None
+    if world == 1 and args.warmup > 0:
+        try:
+            import copy
+            import numpy as _np
+            b1 = chain_bundle.ChainBundle(problem.cams, True, True, False, disable_convergence=True, device=local_rank)
+            ids1 = problem.populate(b1)
+            b1.Compute(args.steps)
+            outs = b1.GetOutlierMeasurements()
+            R1, t1_ = b1.GetPoses(ids1["mkf"]); X1 = b1.GetPoints(ids1["point"])
+            b1.close()
+            q = synth.erase_measurements(problem, outs, ids1)
+            q.base_R, q.base_t, q.pt_x = _np.array(R1), _np.array(t1_), _np.array(X1)
+            near0 = chain_bundle.struct_cache_near_hits()
+            calls, preps, its = [], [], []
+            for _ in range(4):
+                b2 = chain_bundle.ChainBundle(q.cams, True, True, False, disable_convergence=True, device=local_rank)
+                q.populate(b2)
+                ta = time.perf_counter(); b2.Prepare(); tb = time.perf_counter(); rc2 = b2.Compute(args.steps); tc = time.perf_counter()
+                calls.append(b2.abi_seconds + (tc - ta)); preps.append((tb - ta) * 1e3); its.append((tc - tb) * 1e3)
+                b2.close()
+            med = float(_np.median(calls[1:]))
+            after_removal = {"value": args.steps / med, "unit": "LM iterations/s over a whole call of %d iterations" % args.steps, "measurements_erased": len(outs),
+                             "measurements": q.n_meas, "prepare_ms": float(_np.median(preps[1:])), "iterations_ms": float(_np.median(its[1:])), "iterations_run": rc2,
+                             "structure_adopted_from_the_superset": chain_bundle.struct_cache_near_hits() - near0, "calls_timed": len(calls) - 1,
+                             "note": "call 2 of {call 1; erase call 1's Tukey outliers as MapMakerServerBase::HandleOutliers does; call 2 from call 1's state}: "
+                                     "bulk replay through the C ABI + Prepare() (near miss: the cached structure of the un-erased map, erased measurements weighted 0) + the iterations"}
+        except Exception as exc:
+            after_removal = {"error": repr(exc)}
+
     result = None
     if rank == 0:
         strong = args.scaling == "strong" and world > 1
@@ -348,6 +381,8 @@ def main():
             result["value_including_setup"]["value_cold_structure"] = world * args.steps / cold_s
             result["value_including_setup"]["setup_cold_ms"] = setup_ms["populate_in_library_ms"] + setup_ms["prepare_cold_ms"]
             result["value_including_setup"]["note"] = "value: the call repeats the topology of the call before (structure cache hit); value_cold_structure: a topology this process has not seen"
+        if after_removal is not None:
+            result["value_after_outlier_removal"] = after_removal
         if world > 1:
             # what the LM loop put on the wire, per iteration (the first iteration's extras and the final statistics included):
             # main lane = the collectives the trial path waits for, speculative lane = beside it on the second stream

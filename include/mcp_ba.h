@@ -220,8 +220,16 @@ int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int 
  * chain, who measures what, what is fixed -- equals that of an earlier Prepare() on this device adopts that Prepare()'s structure
  * (host results + a device-to-device clone of the packed structure block) and uploads only its own numbers.  Results are bit for
  * bit those of a cold Prepare().  MCP_BA_STRUCT_CACHE=0 switches it off, MCP_BA_STRUCT_CACHE_MB sets the budget (default 512).
- * The two entries below are diagnostics: hits / misses so far in this process; drop every entry. */
+ * NEAR MISS (round 6): MCPTAM erases the measurements an adjustment flagged as outliers and adjusts again
+ * (/root/reference/src/MapMaker.cc:225-230, 283-287 -> MapMakerServerBase::HandleOutliers, src/MapMakerServerBase.cc:1198-1238), so the
+ * next ChainBundle brings the poses, points and chains of the call before and its measurements MINUS a few, in the same order.  Such a
+ * handle adopts the cached structure of the superset (if no pose or point lost its last measurement); the erased measurements keep
+ * their place in the device arrays with weight 0.  The mathematics is that of a cold Prepare() of the smaller map, the order of some
+ * floating-point sums is the superset's: results agree with a cold Prepare() to rounding, not bit for bit (MCP_BA_NEAR_MISS=0: off).
+ * A map that GAINED poses, points or measurements (a new keyframe) is built cold.
+ * The entries below are diagnostics: hits / misses so far in this process (a near miss counts as a miss AND in near_hits); drop every entry. */
 void mcp_ba_struct_cache_stats(long long* hits, long long* misses);
+long long mcp_ba_struct_cache_near_hits(void);
 void mcp_ba_struct_cache_clear(void);
 /* the one-launch factorisation (ba_chol2.h) seen from outside: L (n*n row-major, lower; its diagonal 32x32 BLOCKS hold
  * L_kk^-1, which is what the kernels keep), y = L^-1 b (n), info[0] = hand-off error word, info[1] = failure flag */

@@ -59,7 +59,7 @@ BA_SYMBOLS = [
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
     "mcp_dense_spd_stress", "mcp_ba_debug_system", "mcp_chol_debug_factor", "mcp_chol_time",
-    "mcp_ba_struct_cache_stats", "mcp_ba_struct_cache_clear",
+    "mcp_ba_struct_cache_stats", "mcp_ba_struct_cache_near_hits", "mcp_ba_struct_cache_clear",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce", "mcp_comm_allreduce_lane",
 ]
 
@@ -180,6 +180,13 @@ def struct_cache_stats():
     L.mcp_ba_struct_cache_stats.restype = None
     L.mcp_ba_struct_cache_stats(ctypes.byref(h), ctypes.byref(m))
     return int(h.value), int(m.value)
+
+
+def struct_cache_near_hits():
+    """Prepare() calls so far that adopted the cached structure of a SUPERSET of their measurements (include/mcp_ba.h, near miss)."""
+    L = lib()
+    L.mcp_ba_struct_cache_near_hits.restype = ctypes.c_longlong
+    return int(L.mcp_ba_struct_cache_near_hits())
 
 
 def struct_cache_clear():

@@ -201,7 +201,12 @@ template <class T> struct ArenaAlloc {
 template <class T> using avec = std::vector<T, ArenaAlloc<T>>;
 // end of a build (any exit path): the copies out of the arena have to be done before it is handed to the next build
 struct ArenaGuard { hipStream_t st; ~ArenaGuard() { if (st) (void)hipStreamSynchronize(st); pinned_arena().reset(); } };
-static HostPool& host_pool() { static HostPool p(std::min(16, usable_cores())); return p; }
+// MCP_BA_HOST_THREADS: worker threads of the structure build (default: up to 16 of the cores this process may use; measured on a
+// 256-thread host, cold Prepare() of the metric map: see profiles/r06/README.md)
+static HostPool& host_pool() {
+  static HostPool p([] { const char* e = getenv("MCP_BA_HOST_THREADS"); const int want = e ? atoi(e) : 16; return std::min(std::max(want, 1), usable_cores()); }());
+  return p;
+}
 
 // Small uploads and fills of a Prepare() as ONE launch: up to eight ranges of 8-byte words, each copied from pinned host memory (read in place
 // over the bus) or -- source null -- zeroed.  A copy-engine operation between kernels costs its 4-9 us plus ~9 us of queue switch on either
@@ -325,8 +330,13 @@ struct StructEntry {
   size_t nstage = 0; bool asm_long = false, sch4_ok = false, sch4_order = false;
   double m_total = 0, nfl_total = 0, schur_mfma = 0, schur_flops = 0;
   std::vector<size_t> counts;            // element count of every array of the packed block, in layout order
+  // for the adoption of this structure by a map that holds the same poses, points and chains and a SUBSET of these measurements (the
+  // map after MCPTAM erased the outliers of the adjustment before: prepare(), "near miss"): the key without the measurements, and
+  // the measurements' (point, chain, camera) in add order
+  StructKey base;
+  std::vector<int> add_point, add_chain, add_cam;
   char* dblock = nullptr; size_t dbytes = 0, dcap = 0; int ddev = -1;      // the device clone (DevCache block)
-  size_t host_bytes() const { return (pose_unk.size() + pt_unk.size() + fp_pose.size() + fl_point.size() + perm.size())*4 + pose_active.size() + pt_active.size() + pat.size(); }
+  size_t host_bytes() const { return (pose_unk.size() + pt_unk.size() + fp_pose.size() + fl_point.size() + perm.size() + add_point.size() + add_chain.size() + add_cam.size())*4 + pose_active.size() + pt_active.size() + pat.size(); }
   ~StructEntry() { if (dblock) DevCache::get().put(dblock, dcap, ddev); }
 };
 class StructCache {
@@ -339,6 +349,15 @@ class StructCache {
     ++misses_;
     return nullptr;
   }
+  // entries over the same poses / points / chains that hold MORE measurements than `nmeas` (most recently used first)
+  std::vector<std::shared_ptr<StructEntry>> find_supersets(const StructKey& base, int nmeas) {
+    std::vector<std::shared_ptr<StructEntry>> out;
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& e : lru_) if (e->base == base && e->key.nmeas > nmeas && !e->add_point.empty()) out.push_back(e);
+    return out;
+  }
+  void touch(const std::shared_ptr<StructEntry>& e) { std::lock_guard<std::mutex> lk(mu_); for (auto it = lru_.begin(); it != lru_.end(); ++it) if (*it == e) { lru_.erase(it); lru_.push_front(e); ++near_; break; } }
+  long long near_hits() { std::lock_guard<std::mutex> lk(mu_); return near_; }
   void insert(std::shared_ptr<StructEntry> e) {
     std::vector<std::shared_ptr<StructEntry>> dropped;          // (released outside the lock: dropping a device block may wait for the device)
     {
@@ -357,7 +376,7 @@ class StructCache {
  private:
   StructCache() { if (const char* e = getenv("MCP_BA_STRUCT_CACHE_MB")) budget_ = (size_t)std::max(0L, atol(e)) << 20; if (const char* e = getenv("MCP_BA_STRUCT_CACHE")) if (atoi(e) == 0) budget_ = 0; }
   std::mutex mu_; std::list<std::shared_ptr<StructEntry>> lru_;
-  size_t budget_ = (size_t)512 << 20; int max_entries_ = 32; long long hits_ = 0, misses_ = 0;
+  size_t budget_ = (size_t)512 << 20; int max_entries_ = 32; long long hits_ = 0, misses_ = 0, near_ = 0;
 };
 // two independent 64-bit hashes of an int array, block by block (the value does not depend on how the work is split over threads)
 static inline unsigned long long mix64(unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
@@ -495,7 +514,11 @@ struct mcp_ba {
   std::string launch_err;          // first launch of this solve that the runtime refused: "kernel: reason" (note_launch)
   void note_launch(const char* k) { const hipError_t e = hipGetLastError(); if (e != hipSuccess && e != hipErrorNotReady && launch_err.empty()) launch_err = std::string(k) + ": " + hipGetErrorString(e); }
   std::shared_ptr<StructEntry> pending_entry;
-  StructKey cache_key; bool cache_insert = false;      // a cold Prepare() of a cacheable map leaves its results in the structure cache
+  StructKey cache_key, cache_base; bool cache_insert = false;      // a cold Prepare() of a cacheable map leaves its results in the structure cache
+  // near miss: the structure of a superset of this map's measurements was adopted; the n_masked measurements this map lacks stay in the
+  // device arrays with weight 0 (chi2 = 0: they sit below every real value in the median's order, contribute nothing anywhere else)
+  int n_masked = 0; int near_miss_on = 1;      // MCP_BA_NEAR_MISS=0: a map that lost measurements is built cold
+  unsigned long long med_rank() const { return (unsigned long long)n_masked + (unsigned long long)(m_total/2); }      // vErrorSquared[size/2] among the real measurements
   DevBuf<int> d_m_last;                         // observer chain's last link per measurement (k_linearize_pipe)
   bool lin_pipe = env_on("MCP_BA_LIN_PIPE", true);
   DevBuf<int> d_g_order, d_sp_unk;              // launch order of the groups in k_schur4 (heaviest first; only when they outnumber the slots), free-point index per sorted point
@@ -916,16 +939,57 @@ int mcp_ba::prepare() {
     key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
                 ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16);
     cache_key = key;
+    {
+      // the same key without the measurements (near miss, below)
+      StructKey b = key; b.h0 = b.h1 = 0; b.nmeas = 0;
+      for (size_t i = 3*nbm, r = 0; i < ha.size(); ++i, ++r) { b.h0 = mix64(b.h0 ^ ha[i]) + r; b.h1 = mix64(b.h1 + hb[i]) ^ (r*0x9e3779b97f4a7c15ull); }      // (r, not i: the number of measurement blocks must not enter)
+      b.h1 = mix64(b.h1 ^ (unsigned long long)cams.size());
+      cache_base = b;
+    }
+    n_masked = 0;
     std::shared_ptr<StructEntry> hit = StructCache::get().find(key);
     lap("  topology hash");
+    std::vector<int> present;          // near miss: cached add index -> this map's add index, -1 = this map does not have it
+    if (!hit && near_miss_on) {
+      // NEAR MISS (round 6): MCPTAM erases the measurements an adjustment flagged as outliers and adjusts again
+      // (/root/reference/src/MapMaker.cc:225-230, 283-287 -> MapMakerServerBase::HandleOutliers, src/MapMakerServerBase.cc:1198-1238:
+      // kf.EraseMeasurementOfPoint) -- the next ChainBundle holds the poses, points and chains of the call before and its measurements
+      // MINUS a few, in the same order.  If the cache holds such a superset and no pose or point loses its last measurement (activity,
+      // hence the unknowns, unchanged), its structure is adopted as on a hit; the erased measurements keep their place in the device
+      // arrays with weight 0.  Same mathematics as a cold Prepare() of the smaller map; the order of some floating-point sums differs
+      // (the cold build would group the points by their NEW observer sets), so the two agree to rounding, not bit for bit.
+      for (auto& c : StructCache::get().find_supersets(cache_base, nmeas)) {
+        const int nc2 = c->key.nmeas;
+        present.assign(nc2, -1);
+        const int* ep = c->add_point.data(); const int* ec = c->add_chain.data(); const int* em = c->add_cam.data();
+        const int* mp = meas_point.data(); const int* mc = meas_chain.data();
+        int j = 0;
+        for (int i = 0; i < nc2 && j < nmeas; ++i) if (ep[i] == mp[j] && ec[i] == mc[j] && em[i] == meas[j].cam) present[i] = j++;
+        if (j != nmeas) continue;
+        // activity: every point / pose that was active must still be (and none can have become active)
+        std::vector<unsigned char> pa(npoint, 0), cu(nch, 0), qa(npose, 0);
+        for (int i = 0; i < nmeas; ++i) { pa[mp[i]] = 1; cu[mc[i]] = 1; }
+        for (int i = 0; i < npoint; ++i) if (pa[i]) cu[points[i].chain] = 1;
+        for (size_t ch = 0; ch < nch; ++ch) if (cu[ch]) for (int k2 = 0; k2 < chains[ch].len; ++k2) qa[chains[ch].v[k2]] = 1;
+        bool same = true;
+        for (int i = 0; i < npoint && same; ++i) same = pa[i] == c->pt_active[i];
+        for (int i = 0; i < npose && same; ++i) same = qa[i] == c->pose_active[i];
+        if (!same) continue;
+        hit = c; n_masked = nc2 - nmeas;
+        StructCache::get().touch(c);
+        break;
+      }
+      lap("  near miss search");
+    }
     if (hit) {
       // adopt: the host-side results of the structure build, then the device block (finish_prepare)
       for (int i = 0; i < npose; ++i) { poses[i].unk = hit->pose_unk[i]; poses[i].active = hit->pose_active[i]; }
       for (int i = 0; i < npoint; ++i) { points[i].unk = hit->pt_unk[i]; points[i].active = hit->pt_active[i]; }
       fp_pose = hit->fp_pose; fl_point = hit->fl_point; perm = hit->perm;
+      if (n_masked) for (auto& v : perm) v = present[v];          // sorted position -> THIS map's add index, -1 = erased here
       nfp = hit->nfp; nfl = hit->nfl; np = hit->np; nx = hit->nx; nsp = hit->nsp; ninc = hit->ninc; nslot = hit->nslot; ngroup = hit->ngroup; nbig = hit->nbig;
       grp_pts = hit->grp_pts; grp_blk_max = hit->grp_blk_max; grp_inc_max = hit->grp_inc_max; nrhs_rows = hit->nrhs_rows; nstage = hit->nstage;
-      m_total = hit->m_total; nfl_total = hit->nfl_total;
+      m_total = n_masked ? (double)nmeas : hit->m_total; nfl_total = hit->nfl_total;
       if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
       std::unique_lock<std::mutex> arena_lock(pinned_arena().mutex());
       ArenaGuard arena_guard{st};
@@ -933,7 +997,7 @@ int mcp_ba::prepare() {
       last_pat = hit->pat;
       if (np > 0) { if (plan.build(np, last_pat)) { set_err("Cholesky plan allocation failed"); return -1; } }
       else plan.all_tiles.clear();
-      lap("  adopted (cache hit)");
+      lap(n_masked ? "  adopted (near miss)" : "  adopted (cache hit)");
       return finish_prepare(H, t0, tlast, trace, hit.get());
     }
     cache_insert = true;
@@ -1661,7 +1725,8 @@ int mcp_ba::prepare_legacy() {
 int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point t0, std::chrono::steady_clock::time_point tlast, bool trace, const StructEntry* hit) {
   pending_entry.reset();          // (whatever an earlier, failed Prepare() of this handle left behind is not this call's to publish)
   auto lap = [&](const char* what) { if (!trace) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[mcp_ba prepare] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tlast).count()); tlast = n; };
-  const int npose = (int)poses.size(), npoint = (int)points.size(), nmeas = (int)meas.size();
+  const int npose = (int)poses.size(), npoint = (int)points.size();
+  const int nmeas = hit ? hit->key.nmeas : (int)meas.size();          // (near miss: the device arrays keep the adopted structure's length)
   std::vector<int> chain_len(chains.size()), chain_pose(chains.size()*MAXC), pose_unk(npose), pt_chain(npoint), pt_unk(npoint);
   std::vector<unsigned char> pt_fixed(npoint);
   for (size_t c = 0; c < chains.size(); ++c) { chain_len[c] = chains[c].len; for (int i = 0; i < MAXC; ++i) chain_pose[c*MAXC + i] = chains[c].v[i]; }
@@ -1790,7 +1855,10 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
         const int T = (nmeas >= 32768) ? pool.size() : 1;
         const int* pm = perm.data(); const HMeas* ms = meas.data();
         auto body = [&](int tid) {
-          for (size_t j = nm*tid/T, e = nm*(tid + 1)/T; j < e; ++j) { const HMeas& m = ms[pm[j]]; vals[j] = m.u; vals[nm + j] = m.v; vals[2*nm + j] = m.omega; }
+          for (size_t j = nm*tid/T, e = nm*(tid + 1)/T; j < e; ++j) {
+            if (pm[j] < 0) { vals[j] = 0.0; vals[nm + j] = 0.0; vals[2*nm + j] = 0.0; continue; }      // (near miss: a measurement this map does not have -- weight 0)
+            const HMeas& m = ms[pm[j]]; vals[j] = m.u; vals[nm + j] = m.v; vals[2*nm + j] = m.omega;
+          }
         };
         if (T == 1) body(0); else pool.run(body);
       }
@@ -1828,7 +1896,9 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       // leave the results in the structure cache: host-side members + a device clone of the block (behind the uploads, on this stream;
       // whoever adopts it waits for nothing: an entry becomes visible only after this Prepare()'s final synchronisation, below)
       auto e = std::make_shared<StructEntry>();
-      e->key = cache_key;
+      e->key = cache_key; e->base = cache_base;
+      e->add_point.assign(meas_point.begin(), meas_point.end()); e->add_chain.assign(meas_chain.begin(), meas_chain.end());
+      e->add_cam.resize(meas.size()); for (size_t i = 0; i < meas.size(); ++i) e->add_cam[i] = meas[i].cam;
       e->pose_unk.resize(npose); e->pose_active.resize(npose); e->pt_unk.resize(npoint); e->pt_active.resize(npoint);
       for (int i = 0; i < npose; ++i) { e->pose_unk[i] = poses[i].unk; e->pose_active[i] = (unsigned char)poses[i].active; }
       for (int i = 0; i < npoint; ++i) { e->pt_unk[i] = points[i].unk; e->pt_active[i] = (unsigned char)points[i].active; }
@@ -2081,7 +2151,7 @@ int mcp_ba::select_gather_finish(const double* x, int n, const double* hist, Sel
 int mcp_ba::median_sigma(int w) {
   tic(ST_SELECT);
   flip_sig();                                                        // a fresh block: stragglers of the last iteration keep reading theirs
-  const unsigned long long k = (unsigned long long)(m_total/2);      // vErrorSquared[size/2]
+  const unsigned long long k = med_rank();                           // vErrorSquared[size/2]
   // several ranks, and the state is the one an accepted trial left: that trial's all-reduce carried the first two digit histograms
   // of this very chi2 array (ba_trial.h) -- if its prediction held and the selected bin fits the gather table, the median costs
   // ONE collective and no host wait
@@ -2334,7 +2404,7 @@ int mcp_ba::head_small(int w, bool sum_aside) {
       hs_attr.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), HS_STASH*sizeof(double), st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, (unsigned long long)(m_total/2), m_total,
+  hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), HS_STASH*sizeof(double), st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, med_rank(), m_total,
                      prm.min_mestimator_sigma*prm.min_mestimator_sigma, prev, d_res.p + 8, sig(), d_res.p + 25, d_res.p, 24, aside ? 0 : 1);
   note_launch("k_head_small");
   if (aside) { HIPCK(hipEventRecord(ev_head, st)); sum_w = w; sum_sig = sig(); }      // (the second stream's part: sum_aside(), once the caller has queued what else it has for that stream)
@@ -2388,7 +2458,7 @@ int mcp_ba::enqueue_head(hipStream_t s_trial, int q, int w, bool side) {
   head_ticket[q] = ++head_ticket_ctr;
   hipLaunchKernelGGL(k_head_hist, dim3(HEAD_GRID), dim3(HEAD_THREADS), 0, s, P.nmeas, (const double*)d_chi2[w].p, (const double*)sig(), H.hist);
   hipLaunchKernelGGL(k_head_finish, dim3(HEAD_GRID), dim3(HEAD_THREADS), 0, s, P.nmeas, (const double*)d_chi2[w].p, H.hist, H.vals, (const double*)sig(),
-                     (unsigned long long)(m_total/2), m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma,
+                     med_rank(), m_total, prm.min_mestimator_sigma*prm.min_mestimator_sigma,
                      sig_block(2 + head_par*MAX_SYS + q), H.rs + 1, H.out, h_mail_dev - 32 + HEAD_MAIL + 2*q, head_ticket[q]);
   note_launch("k_head_finish");
   HIPCK(hipEventRecord(head_ev[q], s));
@@ -2940,9 +3010,9 @@ int mcp_ba::final_stats(int nCounter) {
     if (s2 < mins) s2 = mins;
     (void)s2;                                      // (the flags were taken on the device with this very threshold: k_tukey_flags_dev, above)
     const unsigned char* fl = h_exp + exp_state;
-    std::vector<unsigned char> by_add(P.nmeas, 0);
-    for (int j = 0; j < P.nmeas; ++j) if (fl[j]) by_add[perm[j]] = 1;
-    for (int i = 0; i < P.nmeas; ++i) if (by_add[i]) {
+    std::vector<unsigned char> by_add(meas.size(), 0);
+    for (int j = 0; j < P.nmeas; ++j) if (fl[j] && perm[j] >= 0) by_add[perm[j]] = 1;      // (perm < 0: a measurement this map does not have -- near miss; its chi2 is 0)
+    for (size_t i = 0; i < meas.size(); ++i) if (by_add[i]) {
       const HMeas& m = meas[i];
       outliers.push_back(points[m.point].id);
       outliers.push_back(poses[chains[m.chain].v[0]].id);      // vertices().front(), :1394
@@ -3033,6 +3103,7 @@ mcp_ba* mcp_ba_create(const mcp_camera* cams, int ncam, int use_robust, int use_
   { const char* e = getenv("MCP_BA_EVT"); if (e) h->evt_debug = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_TRIALS"); if (e) h->spec_trials = atoi(e); }
   { const char* e = getenv("MCP_BA_HEAD_AHEAD"); if (e) h->large_head_ahead = atoi(e); }
+  { const char* e = getenv("MCP_BA_NEAR_MISS"); if (e) h->near_miss_on = atoi(e); }
   { const char* e = getenv("MCP_BA_FORCE_MULTI"); if (e) h->force_multi = atoi(e); }
   { const char* e = getenv("MCP_BA_TEST_FAIL_TRIAL"); if (e) h->test_fail_trial = atoi(e); }
   { const char* e = getenv("MCP_BA_SPEC_DELAY"); if (e) h->spec_delay = atoi(e); }
@@ -3276,6 +3347,7 @@ int mcp_ba_eval(mcp_ba* h, double* chi2_out, double* err_out) {
   HIPCK(hipStreamSynchronize(h->st));
   for (int j = 0; j < n; ++j) {
     const int i = h->perm[j];
+    if (i < 0) continue;               // (near miss: not a measurement of this map)
     if (chi2_out) chi2_out[i] = c[j];
     if (err_out) { err_out[2*(size_t)i] = e[2*(size_t)j]; err_out[2*(size_t)i + 1] = e[2*(size_t)j + 1]; }
   }
@@ -3382,6 +3454,7 @@ int mcp_dense_spd_stress(const double* A, int n, const double* b, int nsys, int 
 
 // structure cache (test / diagnostic hooks): hits and misses so far in this process; drop every entry
 void mcp_ba_struct_cache_stats(long long* hits, long long* misses) { long long h = 0, m = 0; StructCache::get().stats(&h, &m); if (hits) *hits = h; if (misses) *misses = m; }
+long long mcp_ba_struct_cache_near_hits(void) { return StructCache::get().near_hits(); }
 void mcp_ba_struct_cache_clear(void) { StructCache::get().clear(); }
 
 // the one-launch factorisation of ba_chol2.h looked at from outside (test hook): L (n x n, row-major, lower triangle; the

@@ -390,6 +390,27 @@ CONFIGS = {
 }
 
 
+def erase_measurements(p, outliers, ids=None):
+    """The map after MapMakerServerBase::HandleOutliers (/root/reference/src/MapMakerServerBase.cc:1198-1238: kf.EraseMeasurementOfPoint for
+    every measurement the adjustment flagged): the listed (point id, MKF id, camera index) measurements -- what GetOutlierMeasurements()
+    returns -- erased, everything else, the ORDER included, as it was.  `ids`: the id dict populate() returned (default p.ids)."""
+    import copy
+    ids = p.ids if ids is None else ids
+    if not outliers:
+        return copy.copy(p)
+    P, C = p.n_mkf, len(p.cams)
+    pt_of = np.full(int(np.max(ids["point"])) + 1, -1, dtype=np.int64); pt_of[ids["point"]] = np.arange(p.n_points)
+    kf_of = np.full(int(np.max(ids["mkf"])) + 1, -1, dtype=np.int64); kf_of[ids["mkf"]] = np.arange(P)
+    o = np.asarray(outliers, dtype=np.int64).reshape(-1, 3)
+    gone = (pt_of[o[:, 0]] * P + kf_of[o[:, 1]]) * C + o[:, 2]
+    key = (p.ms_pt.astype(np.int64) * P + p.ms_mkf.astype(np.int64)) * C + p.ms_cam.astype(np.int64)
+    keep = ~np.isin(key, gone)
+    q = copy.copy(p)
+    q.ms_mkf, q.ms_cam, q.ms_pt, q.ms_uv, q.ms_level = p.ms_mkf[keep], p.ms_cam[keep], p.ms_pt[keep], p.ms_uv[keep], p.ms_level[keep]
+    q.ids = {}
+    return q
+
+
 def recent_window(p, n_recent=3, newest=None):
     """The local bundle BundleAdjusterBase::BundleAdjustRecent builds from a map (src/BundleAdjusterBase.cc:188-265): the newest
     MKF and its `n_recent` closest MKFs, of which only the movable ones are kept (snRecentNum, :47), are adjusted; the points are

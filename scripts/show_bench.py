@@ -8,6 +8,6 @@ print("stage totals ms:", {k: round(v, 3) for k, v in st.get("ms_total", {}).ite
 ps = st.get("per_stage", {})
 print("per launch ms:", {k: round(v.get("avg_ms", 0), 4) for k, v in ps.items() if isinstance(v, dict)})
 print("roofline:", d.get("roofline"))
-for k in ("value_including_setup", "recent_window", "secondary"):
+for k in ("value_including_setup", "value_after_outlier_removal", "recent_window", "secondary"):
     if k in d: print(k, json.dumps(d[k])[:600])
 print("config:", {k: d["config"].get(k) for k in ("reduced_system_solves", "trials_served_speculatively", "persist_fallbacks")})

@@ -1041,6 +1041,57 @@ def test_a_refused_launch_is_reported_by_kernel_name(gpu_required, monkeypatch):
     assert r["rc"] == 2
 
 
+@pytest.mark.parametrize("cfg,iters", [("c1", 6), ("c2", 6), ("metric", 5)])
+def test_a_map_that_lost_its_outliers_adopts_the_cached_structure_of_the_call_before(gpu_required, cfg, iters, monkeypatch):
+    """Near miss (include/mcp_ba.h): MCPTAM erases the measurements an adjustment flagged (MapMakerServerBase::HandleOutliers,
+    /root/reference/src/MapMakerServerBase.cc:1198-1238) and adjusts again -- same poses, points, chains, the measurements minus a few.
+    The second call adopts the first one's cached structure, the erased measurements staying in the device arrays with weight 0.  Against
+    a COLD Prepare() of the smaller map (MCP_BA_NEAR_MISS=0): the same accept / reject sequence, state, sigma^2 and chi2 to rounding
+    (the order of some sums is the superset's), the same outlier list, chi2 per measurement in the smaller map's add order -- and against
+    the oracle on the smaller map within the usual tolerance."""
+    from mcptam_amd import synth, chain_bundle
+    p = synth.make_config(cfg)
+    chain_bundle.struct_cache_clear()
+    first = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
+    assert len(first["outliers"]) > 0
+    q = synth.erase_measurements(p, first["outliers"], first["ids"])
+    assert q.n_meas == p.n_meas - len(first["outliers"])
+    n0 = chain_bundle.struct_cache_near_hits()
+    g = _gpu(q.cams, disable_convergence=True)
+    near = run_bundle(g, q, iters)
+    assert chain_bundle.struct_cache_near_hits() == n0 + 1
+    chi_near, _ = g.Eval(q.n_meas)
+    g.close()
+    monkeypatch.setenv("MCP_BA_NEAR_MISS", "0")
+    g2 = _gpu(q.cams, disable_convergence=True)
+    cold = run_bundle(g2, q, iters)
+    chi_cold, _ = g2.Eval(q.n_meas)
+    g2.close()
+    assert chain_bundle.struct_cache_near_hits() == n0 + 1
+    assert near["rc"] == cold["rc"] == iters
+    assert [(l["trials"], l["accepted"]) for l in near["logs"]] == [(l["trials"], l["accepted"]) for l in cold["logs"]]
+    for a, b in zip(near["logs"], cold["logs"]):
+        assert abs(a["chi2_end"] - b["chi2_end"]) <= 1e-9 * abs(b["chi2_end"]) and abs(a["sigma_sq"] - b["sigma_sq"]) <= 1e-9 * abs(b["sigma_sq"])
+    assert rel_err_elem(near["R"], cold["R"]) < 1e-9 and rel_err_elem(near["t"], cold["t"]) < 1e-9 and rel_err_elem(near["X"], cold["X"]) < 1e-9
+    assert abs(near["sigma_sq"] - cold["sigma_sq"]) <= 1e-9 * cold["sigma_sq"] and abs(near["mean_chi2"] - cold["mean_chi2"]) <= 1e-9 * cold["mean_chi2"]
+    assert sorted(near["outliers"]) == sorted(cold["outliers"])
+    assert np.allclose(chi_near, chi_cold, rtol=1e-7, atol=1e-12)
+    if cfg != "metric":
+        o = _orc(q.cams)
+        o.DisableConvergence(True)
+        ref = run_bundle(o, q, iters)
+        rep = compare_runs(near, ref)
+        assert rep["branch_flips"] == 0, rep
+    # a map that lost ALL measurements of a point is not a near miss (its unknowns differ): built cold, still correct
+    monkeypatch.setenv("MCP_BA_NEAR_MISS", "1")
+    pt0 = int(q.ms_pt[0])
+    gone = [(int(first["ids"]["point"][pt0]), int(first["ids"]["mkf"][int(k)]), int(c)) for k, c in zip(q.ms_mkf[q.ms_pt == pt0], q.ms_cam[q.ms_pt == pt0])]
+    r = synth.erase_measurements(q, gone, first["ids"])
+    n1 = chain_bundle.struct_cache_near_hits()
+    lone = run_bundle(_gpu(r.cams, disable_convergence=True), r, 2)
+    assert lone["rc"] == 2 and chain_bundle.struct_cache_near_hits() == n1
+
+
 @pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 6), ("calib", 6), ("c2", 5), ("metric", 4)])
 def test_cached_prepare_equals_a_cold_one(gpu_required, cfg, iters):
     """Structure cache (include/mcp_ba.h): a handle that brings the topology of an earlier Prepare() adopts that structure (host
