@@ -275,6 +275,14 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
                     const int* n, const mcp_td_in* const* in, const int* const* point_key, mcp_pf_state* const* state,
                     int range, int subpix_its, int exhaustive, int n_iter, const uint8_t* nonlinear, const double* override_sigma, int estimator,
                     mcp_td_out* const* out, mcp_pose_point* pts_out, double mu_last[6], double* weights_last);
+/* ZERO-COPY RESULTS (round 6).  The search kernel writes the TrackerData results into a pinned block of the library; with caller arrays
+ * (`out` != NULL) mcp_track_frame copies them out after its one wait -- 300 bytes per point, ~25 us of the host's time per 640x480 x 4
+ * frame.  A native caller that only walks the results once (Tracker::TrackMap updating its TrackerData, src/Tracker.cc:1040-1075) passes
+ * out = NULL and reads them in place:
+ *     const mcp_td_out* r = mcp_track_frame_view(targets[0], c, &count);      // count == n[c]
+ * valid until the next mcp_track_frame / mcp_track_search_batch call whose first target is targets[0]; NULL (count 0) for a camera
+ * without points, NULL + mcp_last_error() for a camera index the last frame did not have. */
+const mcp_td_out* mcp_track_frame_view(const mcp_kf* first_target, int cam, int* count);
 
 #ifdef __cplusplus
 }

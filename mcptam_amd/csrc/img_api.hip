@@ -43,6 +43,7 @@ struct Level {
   Buf<mcp_int2> corners, cand_pos;
   Buf<uint8_t> score8;                             // FAST score per pixel at the detection threshold (0 = no corner), scratch of MakeKeyFrame_Lite
   Buf<int> lut, rowcnt, blk_cnt, score_img;
+  Buf<unsigned long long> scan;                    // k_row_tables: per 4-row workgroup, (epoch << 32 | kept corners)
   Buf<double> cand_score;
   Buf<LevelInfo> info;
   bool has_mask = false;
@@ -77,10 +78,12 @@ struct mcp_kf {
   LevelInfo* h_info = nullptr;      // pinned, device-visible: the kernels leave the four levels' bookkeeping here (one wait per frame)
   Buf<int> work;                    // threshold histogram + detected-corner count per level; k_row_compact leaves it zero again
   bool work_dirty = true;
+  unsigned int scan_epoch = 0;        // k_row_tables: this frame's tag
   Buf<SearchCam> stab; Buf<DevTdIn> bt_in; Buf<mcp_td_out> bt_out;      // batched search: camera table + points of all cameras
   Buf<PfTargetDev> pf_tab; Buf<PfItemDev> pf_items; Buf<int> pf_seq; Buf<mcp_pf_state> pf_state;      // mcp_patch_sequences
   PinBuf<SearchCam> h_stab; PinBuf<DevTdIn> h_bt_in;                                                   // host staging of the batched search ...
   PinBuf<mcp_td_out> h_bt_out;                                                                         // ... and, for mcp_track_frame, its results: the search kernel writes them here as well
+  int view_first[MCP_MAX_FRAME_CAMS + 1] = {0}; int view_ncam = 0;                                     // mcp_track_frame_view: where camera c's results of the last frame start in h_bt_out
   PinBuf<PfTargetDev> h_pf_tab; PinBuf<PfItemDev> h_pf_items; PinBuf<int> h_pf_seq; PinBuf<mcp_pf_state> h_pf_state, h_pf_state_out;      // ... and of mcp_track_frame's finder sequences (states in / out)
   hipEvent_t ev = nullptr;
   // SmallBlurryImage of the frame currently held (KeyFrame::mpSBI): thumbnail, zero-mean blurred template, gradient image
@@ -116,9 +119,10 @@ mcp_kf* mcp_kf_create(int w, int h, const mcp_kf_params* params) {
   for (int l = 0; l < MCP_LEVELS; ++l) {
     Level& L = k->lev[l]; L.w = w >> l; L.h = h >> l; L.cap = std::max(1024, L.w*L.h/2);
     const size_t npx = (size_t)L.w*L.h; const int nblk = (L.cap + FAST_BLOCK - 1)/FAST_BLOCK + 2;
-    if (L.img.alloc(npx) || L.mask.alloc(npx) || L.score8.alloc(npx) || L.rowcnt.alloc(L.h) || L.corners.alloc(L.cap) ||
+    if (L.img.alloc(npx) || L.mask.alloc(npx) || L.score8.alloc(npx) || L.rowcnt.alloc(L.h) || L.scan.alloc((L.h + 3)/4 + 1) || L.corners.alloc(L.cap) ||
         L.lut.alloc(L.h) || L.blk_cnt.alloc(nblk) || L.info.alloc(1) || L.cand_pos.alloc(L.cap) || L.cand_score.alloc(L.cap)) { delete k; return nullptr; }
     (void)hipMemset(L.info.p, 0, sizeof(LevelInfo));
+    (void)hipMemset(L.scan.p, 0, ((size_t)(L.h + 3)/4 + 1)*sizeof(unsigned long long));      // (epoch 0 = never written; frames count from 1)
   }
   return k;
 }
@@ -157,12 +161,12 @@ static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const
     k->work_dirty = true;                         // until k_row_compact of this frame has run to the end
     FrameCam& C = B.c[c];
     const Level& L0 = k->lev[0];
-    C.w = L0.w; C.h = L0.h; C.work = k->work.p; C.host_info = k->h_info;
+    C.w = L0.w; C.h = L0.h; C.work = k->work.p; C.host_info = k->h_info; C.epoch = ++k->scan_epoch;
     if (imgs_on_device) { C.src = imgs[c]; C.src_stride = strides[c]; }
     else { ICK(hipMemcpy2DAsync(L0.img.p, L0.w, imgs[c], strides[c], L0.w, L0.h, hipMemcpyHostToDevice, st)); C.src = L0.img.p; C.src_stride = L0.w; }
     for (int l = 0; l < MCP_LEVELS; ++l) {
       Level& L = k->lev[l];
-      C.img[l] = L.img.p; C.score[l] = L.score8.p; C.corners[l] = L.corners.p; C.lut[l] = L.lut.p; C.rowcnt[l] = L.rowcnt.p; C.info[l] = L.info.p; C.cap[l] = L.cap;
+      C.img[l] = L.img.p; C.score[l] = L.score8.p; C.corners[l] = L.corners.p; C.lut[l] = L.lut.p; C.rowcnt[l] = L.rowcnt.p; C.scan[l] = L.scan.p; C.info[l] = L.info.p; C.cap[l] = L.cap;
       const uint8_t* m = masks && masks[c] ? masks[c][l] : nullptr;
       if (m) ICK(hipMemcpyAsync(L.mask.p, m, (size_t)L.w*L.h, hipMemcpyHostToDevice, st));
       C.mask[l] = (m || k->prm.glare_masking) ? L.mask.p : nullptr;
@@ -187,9 +191,13 @@ static int lite_batch_enqueue(int ncam, mcp_kf* const* kfs, const uint8_t* const
   }
   if (ride && ride->fn(ride->ctx, B)) return -1;
   const int up = (B.up_n8[0] > 0 || B.up_n8[1] > 0 || B.up_n8[2] > 0 || B.up_n8[3] > 0) ? 1 : 0;
-  hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam + up), dim3(256), 0, st, B);
-  B.up_n8[0] = B.up_n8[1] = B.up_n8[2] = B.up_n8[3] = 0;
-  hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
+  static const bool one_launch = [] { const char* e = getenv("MCP_IMG_ROW_TABLES"); return e ? atoi(e) != 0 : true; }();      // (0: k_row_count + k_row_compact, the round-5 pair)
+  if (one_launch) hipLaunchKernelGGL(k_row_tables, dim3((maxh + 3)/4, MCP_LEVELS, ncam + up), dim3(256), 0, st, B);
+  else {
+    hipLaunchKernelGGL(k_row_count, dim3((maxh + 3)/4, MCP_LEVELS, ncam + up), dim3(256), 0, st, B);
+    B.up_n8[0] = B.up_n8[1] = B.up_n8[2] = B.up_n8[3] = 0;
+    hipLaunchKernelGGL(k_row_compact, dim3((maxh + 3)/4, MCP_LEVELS, ncam), dim3(256), 0, st, B);
+  }
   ICK(hipGetLastError());
   return 0;
 }
@@ -731,12 +739,12 @@ int mcp_track_search(mcp_kf* target, const mcp_camera* cam, const double bfw[12]
 // pack: arguments checked, the camera table and the points of all cameras written to the pinned staging (targets[0]->h_stab / h_bt_in), device
 // buffers sized.  launch: the two uploads (unless something else has carried them: `uploaded`) and the kernel.
 static int search_batch_pack(int ncam, mcp_kf* const* targets, const mcp_camera* cams, const double* cfb, const int* n, const mcp_td_in* const* in,
-                             mcp_td_out* const* out, int* total_out, int* maxn_out) {
+                             mcp_td_out* const* out, int* total_out, int* maxn_out, bool view = false /* mcp_track_frame's view mode: no caller arrays */) {
   *total_out = 0; *maxn_out = 0;
-  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !cfb || !n || !in || !out) return img_fail("mcp_track_search_batch: bad arguments");
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !cfb || !n || !in || (!out && !view)) return img_fail("mcp_track_search_batch: bad arguments");
   int total = 0, maxn = 0;
   for (int c = 0; c < ncam; ++c) {
-    if (!targets[c] || n[c] < 0 || !cam_ok(&cams[c]) || targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || !out[c]))) return img_fail("mcp_track_search_batch: bad arguments");
+    if (!targets[c] || n[c] < 0 || !cam_ok(&cams[c]) || targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || (!view && !out[c])))) return img_fail("mcp_track_search_batch: bad arguments");
     total += n[c]; maxn = std::max(maxn, n[c]);
   }
   if (total == 0) return 0;
@@ -880,9 +888,10 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
                     double mu_last[6], double* weights_last) {
   if (!mu_last) return img_fail("mcp_track_frame: bad arguments");
   for (int k = 0; k < 6; ++k) mu_last[k] = 0;
-  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || !out || n_iter < 0 || !est_ok(est) ||
+  const bool view = (out == nullptr);       // results stay in the library's pinned block: mcp_track_frame_view (include/mcp_img.h)
+  if (ncam < 1 || ncam > MCP_MAX_FRAME_CAMS || !targets || !cams || !bfw || !cfb || !n || !in || n_iter < 0 || !est_ok(est) ||
       (n_iter > 0 && (!nonlinear || !override_sigma)) || (imgs && !strides) || (state && !point_key)) return img_fail("mcp_track_frame: bad arguments");
-  for (int c = 0; c < ncam; ++c) if (!targets[c] || !cam_ok(&cams[c]) || n[c] < 0 || (n[c] > 0 && !out[c])) return img_fail("mcp_track_frame: bad arguments");
+  for (int c = 0; c < ncam; ++c) if (!targets[c] || !cam_ok(&cams[c]) || n[c] < 0 || (n[c] > 0 && !view && !out[c])) return img_fail("mcp_track_frame: bad arguments");
   // every per-point argument is checked BEFORE the first enqueue: an input rejected later would leave launches and copies in flight
   for (int c = 0; c < ncam; ++c) {
     if (targets[c]->device != targets[0]->device || (n[c] > 0 && (!in[c] || (state && (!state[c] || !point_key[c]))))) return img_fail("mcp_track_frame: bad arguments");
@@ -904,7 +913,7 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
     FrameRide ride{nullptr, &ctx};
     if (!state) ride.fn = [](void* c_, FrameBatch& B) -> int {
       Ctx& c = *static_cast<Ctx*>(c_);
-      if (search_batch_pack(c.ncam, c.targets, c.cams, c.cfb, c.n, c.in, c.out, c.total, c.maxn)) return -1;
+      if (search_batch_pack(c.ncam, c.targets, c.cams, c.cfb, c.n, c.in, c.out, c.total, c.maxn, c.out == nullptr)) return -1;
       if (*c.total == 0) return 0;
       mcp_kf* k0 = c.targets[0];
       B.up_src[0] = reinterpret_cast<const unsigned long long*>(k0->h_stab.p); B.up_dst[0] = reinterpret_cast<unsigned long long*>(k0->stab.p); B.up_n8[0] = (int)(sizeof(SearchCam)*(size_t)c.ncam/8);
@@ -935,7 +944,7 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
       out_pinned = true;
     }
   } else {
-    if (!rode && search_batch_pack(ncam, targets, cams, cfb, n, in, out, &total, &maxn)) return -1;
+    if (!rode && search_batch_pack(ncam, targets, cams, cfb, n, in, out, &total, &maxn, view)) return -1;
     if (total > 0) {
       // the search leaves its results in pinned host memory too and writes the pose iterations' records itself (no packing launch)
       if (k0->h_bt_out.alloc(total) || rs.dp.alloc(total)) return -1;
@@ -956,7 +965,9 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   ICK(hipStreamSynchronize(st));
   drain.armed = false;
   if (imgs && lite_batch_finish(ncam, targets)) return -1;
-  if (out_pinned) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(out[c], k0->h_bt_out.p + first, sizeof(mcp_td_out)*(size_t)n[c]); first += n[c]; } }
+  { int first = 0; for (int c = 0; c < ncam; ++c) { k0->view_first[c] = first; first += n[c]; } k0->view_first[ncam] = first; k0->view_ncam = (out_pinned || total == 0) ? ncam : 0; }
+  if (out_pinned && !view) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(out[c], k0->h_bt_out.p + first, sizeof(mcp_td_out)*(size_t)n[c]); first += n[c]; } }
+  if (view && !out_pinned && total > 0) return img_fail("mcp_track_frame: results were not written to the pinned block (view mode needs a search of at least one point)");
   if (iterate) refine_results_finish(rs, total, back, weights_last);
   if (state && total > 0) { int first = 0; for (int c = 0; c < ncam; ++c) { if (n[c]) std::memcpy(state[c], k0->h_pf_state_out.p + first, sizeof(mcp_pf_state)*(size_t)n[c]); first += n[c]; } }
   if (iterate && (prm_err || (rs.last_multi && getenv("MCP_TRACK_TEST_PRM_GIVEUP")))) {
@@ -968,6 +979,15 @@ int mcp_track_frame(int ncam, mcp_kf* const* targets, const uint8_t* const* imgs
   }
   if (iterate) { std::memcpy(bfw, back, 96); std::memcpy(mu_last, back + 12, 48); }
   return 0;
+}
+
+// the results of camera `cam` of the last mcp_track_frame on this first target, in the library's pinned block (include/mcp_img.h)
+const mcp_td_out* mcp_track_frame_view(const mcp_kf* first_target, int cam, int* count) {
+  if (count) *count = 0;
+  if (!first_target || cam < 0 || cam >= first_target->view_ncam) { img_fail("mcp_track_frame_view: no frame's results for that camera"); return nullptr; }
+  const int first = first_target->view_first[cam], m = first_target->view_first[cam + 1] - first;
+  if (count) *count = m;
+  return m > 0 ? first_target->h_bt_out.p + first : nullptr;
 }
 
 // PatchFinder with its members carried from call to call (include/mcp_img.h MCP_PF_*): sequences of items, one finder each

@@ -173,6 +173,7 @@ struct FrameCam {             // one camera of a frame: everything the three ker
   mcp_int2* corners[MCP_LEVELS]; int* lut[MCP_LEVELS]; int* rowcnt[MCP_LEVELS]; LevelInfo* info[MCP_LEVELS];
   LevelInfo* host_info;                          // pinned, device-visible: the four levels' bookkeeping lands on the host with the frame
   int* work; int cap[MCP_LEVELS];
+  unsigned long long* scan[MCP_LEVELS]; unsigned int epoch;      // k_row_tables: kept corners per 4-row workgroup, tagged with the frame's epoch
 };
 struct FrameBatch { FrameCam c[MCP_MAX_FRAME_CAMS]; int ncam, adaptive, pavgb; int detect_t[MCP_LEVELS];
                     // mcp_track_frame: the search's small inputs (camera table, tracked points; pinned host memory) are copied to the device by
@@ -355,6 +356,100 @@ k_row_compact(const FrameBatch B) {
     H->n_all = I->n_all; H->n_corners = I->n_corners; H->thresh = I->thresh; H->n_cand = 0; H->overflow = I->overflow;
     for (int q = 0; q < 32; ++q) H->hist[q] = I->hist[q];
   }
+}
+
+// k_row_count + k_row_compact in ONE launch (round 6): a workgroup counts its four rows, publishes the sum (tagged with the frame's epoch: no
+// clearing between frames), adds up the sums of the workgroups above it as they appear -- every workgroup publishes BEFORE it looks at
+// anybody else's, and the ones it waits for have lower block indices, i.e. were dispatched before it: no chain, no deadlock -- and writes
+// its rows' corners at the resulting offset.  The exclusive prefix over the rows is vCornerRowLUT as before; the corner order, the
+// threshold and the bookkeeping are those of the two kernels, bit for bit.  Saves a launch boundary and k_row_compact's prologue (its
+// own walk over the row counts) per frame.
+constexpr unsigned long long ROWSCAN_TAG_SHIFT = 32;
+__global__ void __launch_bounds__(256)
+k_row_tables(const FrameBatch B) {
+  if ((int)blockIdx.z == B.ncam) {               // the upload slice
+    const int nth = (int)(gridDim.x*gridDim.y)*256, t0 = (int)(blockIdx.y*gridDim.x + blockIdx.x)*256 + (int)threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) for (int i = t0; i < B.up_n8[r]; i += nth) B.up_dst[r][i] = B.up_src[r][i];
+    return;
+  }
+  const int l = blockIdx.y; const FrameCam& C = B.c[blockIdx.z];
+  const int wl = C.w >> l, hl = C.h >> l, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = blockIdx.x*4, nblk = (hl + 3) >> 2;
+  if (y0 >= hl) return;
+  __shared__ int th_s;
+  __shared__ int cum[32];
+  __shared__ int rc[4];
+  __shared__ int s_off;
+  if (threadIdx.x < 32) {
+    int c = 0;
+    if ((int)threadIdx.x >= MCP_MIN_FAST_THRESH) for (int q = threadIdx.x; q <= MCP_MAX_FAST_THRESH; ++q) c += C.work[l*32 + q];
+    cum[threadIdx.x] = c;
+  }
+  if (threadIdx.x < 4) rc[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) th_s = B.adaptive ? knee_threshold(cum, wl, hl) : B.detect_t[l];
+  __syncthreads();
+  const int th = th_s;
+  const int n_all = C.work[MCP_LEVELS*32 + l];
+  if (blockIdx.x == 0) {
+    LevelInfo* I = C.info[l];
+    if (threadIdx.x < 32) I->hist[threadIdx.x] = cum[threadIdx.x];
+    if (threadIdx.x == 0) { I->thresh = th; I->n_all = n_all; I->n_cand = 0; }
+  }
+  const int y = y0 + wave;
+  const bool use_mask = B.adaptive && C.mask[l] != nullptr;
+  int cnt = 0;
+  if (y < hl) for (int x = lane; x < wl; x += 64) cnt += corner_kept(C, l, wl, x, y, th, use_mask) ? 1 : 0;
+  cnt = wave_sum_i(cnt);
+  if (lane == 0) rc[wave] = cnt;
+  __syncthreads();
+  const unsigned long long tag = (unsigned long long)C.epoch << ROWSCAN_TAG_SHIFT;
+  unsigned long long* scan = C.scan[l];
+  if (threadIdx.x == 0) __hip_atomic_store(scan + blockIdx.x, tag | (unsigned int)(rc[0] + rc[1] + rc[2] + rc[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wave == 0) {
+    // the sums of the workgroups above, 64 at a time
+    int off = 0; long long t0 = 0; unsigned int it = 0; bool dead = false;
+    for (int base = 0; base < (int)blockIdx.x && !dead; base += 64) {
+      const int j = base + lane;
+      const bool mine = j < (int)blockIdx.x;
+      unsigned long long v = tag;
+      for (;;) {
+        if (mine) v = __hip_atomic_load(scan + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__builtin_amdgcn_ballot_w64((v >> ROWSCAN_TAG_SHIFT) != C.epoch)) break;
+        if ((++it & 63) == 63) { if (!t0) t0 = wall_clock64(); else if (wall_clock64() - t0 > 2000000ll) { dead = true; break; } }      // 20 ms: give up (overflow is raised below)
+        __builtin_amdgcn_s_sleep(1);
+      }
+      off += wave_sum_i(mine ? (int)(unsigned int)v : 0);
+    }
+    if (lane == 0) s_off = dead ? -1 : off;
+  }
+  __syncthreads();
+  int off = s_off;
+  const bool dead = off < 0;
+  if (dead) off = 0;
+  if (y >= hl) return;
+  for (int j = 0; j < wave; ++j) off += rc[j];
+  if (lane == 0) C.lut[l][y] = off;
+  int run = off;
+  for (int x0 = 0; x0 < wl; x0 += 64) {
+    const int x = x0 + lane;
+    const bool keep = x < wl && corner_kept(C, l, wl, x, y, th, use_mask);
+    const unsigned long long bal = __ballot(keep);
+    if (keep) { const int o = run + __popcll(bal & ((1ull << lane) - 1ull)); if (o < C.cap[l]) { C.corners[l][o].x = x; C.corners[l][o].y = y; } }
+    run += __popcll(bal);
+  }
+  if (y == hl - 1 && lane == 0) {
+    // the last row: every workgroup of the level has published, i.e. has read the histogram accumulators -- they are left zero for the next frame
+    for (int q = 0; q < 32; ++q) C.work[l*32 + q] = 0;
+    C.work[MCP_LEVELS*32 + l] = 0;
+    LevelInfo* I = C.info[l];
+    I->n_corners = min(run, C.cap[l]); I->overflow = (run > C.cap[l]) || dead;
+    LevelInfo* H = C.host_info + l;
+    H->n_all = n_all; H->n_corners = I->n_corners; H->thresh = th; H->n_cand = 0; H->overflow = I->overflow;
+    for (int q = 0; q < 32; ++q) H->hist[q] = cum[q];
+  }
+  (void)nblk;
 }
 
 // ---- MakeKeyFrame_Rest -----------------------------------------------------------------------

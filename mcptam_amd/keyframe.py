@@ -43,7 +43,7 @@ IMG_SYMBOLS = [
     "mcp_kf_create", "mcp_kf_destroy", "mcp_kf_make_lite", "mcp_kf_make_lite_batch", "mcp_track_search_batch", "mcp_kf_level_size", "mcp_kf_get_image", "mcp_kf_num_corners",
     "mcp_kf_get_corners", "mcp_kf_get_row_lut", "mcp_kf_fast_thresh", "mcp_kf_get_fast_frequency", "mcp_kf_make_rest",
     "mcp_kf_num_prev", "mcp_kf_num_candidates", "mcp_kf_get_candidates", "mcp_minipatch_find", "mcp_track_search", "mcp_track_pose_update",
-    "mcp_patch_sequences", "mcp_track_frame", "mcp_track_pose_update_m", "mcp_track_pose_refine_m", "mcp_track_pose_refine_sharded_m", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
+    "mcp_patch_sequences", "mcp_track_frame", "mcp_track_frame_view", "mcp_track_pose_update_m", "mcp_track_pose_refine_m", "mcp_track_pose_refine_sharded_m", "mcp_track_pose_refine", "mcp_track_pose_refine_sharded", "mcp_kf_make_sbi", "mcp_kf_get_sbi", "mcp_sbi_score", "mcp_sbi_iterate", "mcp_sbi_iterate_last", "mcp_sbi_se3_from_se2",
 ]
 _BOUND = False
 
@@ -505,7 +505,9 @@ class TrackFrame:
             self.kp = (ctypes.c_void_p * n)(*[k_.ctypes.data for k_ in self.keys])
 
     def run(self, imgs, base_from_world, rng, subpix_its, exhaustive=False, nonlinear=FINE_NONLINEAR, override_sigma=FINE_OVERRIDE, estimator="Tukey",
-            on_device=False, strides=None, want_points=True):
+            on_device=False, strides=None, want_points=True, view=False):
+        """view=True: the TrackerData results are not copied into this object's arrays; the returned per-camera arrays are views of the
+        library's pinned block (mcp_track_frame_view), valid until the next frame."""
         n = self.n
         ip = st = None
         keep = None
@@ -525,10 +527,22 @@ class TrackFrame:
         t0 = _time.perf_counter()
         rc = fn(n, self.hs, ip, st, int(on_device), None, ctypes.cast(self.cs, ctypes.c_void_p), bfw.ctypes.data, self.cfb.ctypes.data, self.ns, self.ins,
                 self.kp, self.sp, int(rng), int(subpix_its), int(exhaustive), len(nl), nl.ctypes.data, ov.ctypes.data, MEST[estimator],
-                self.ops, self.pts.ctypes.data if want_points else None, self.mu.ctypes.data, self.w.ctypes.data)
+                None if view else self.ops, self.pts.ctypes.data if want_points else None, self.mu.ctypes.data, self.w.ctypes.data)
         self.abi_seconds = _time.perf_counter() - t0          # the C call alone: what a native caller pays for the frame
         _chk(rc, "track_frame")
-        outs = [self.whole[self.offs[c]:self.offs[c + 1]] for c in range(n)]
+        if view:
+            L = lib()
+            L.mcp_track_frame_view.restype = ctypes.c_void_p
+            L.mcp_track_frame_view.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+            outs = []
+            for c in range(n):
+                cnt = ctypes.c_int(0)
+                ptr = L.mcp_track_frame_view(self.kfs[0]._h, c, ctypes.byref(cnt))
+                if cnt.value != self.lens[c]:
+                    raise RuntimeError("mcp_track_frame_view: " + _cb.last_error())
+                outs.append(np.frombuffer((ctypes.c_char * (cnt.value * TD_OUT_DTYPE.itemsize)).from_address(ptr), dtype=TD_OUT_DTYPE) if cnt.value else np.zeros(0, dtype=TD_OUT_DTYPE))
+        else:
+            outs = [self.whole[self.offs[c]:self.offs[c + 1]] for c in range(n)]
         return outs, (self.pts[:self.total] if want_points else None), (bfw[:9].reshape(3, 3).copy(), bfw[9:].copy()), self.mu.copy(), self.w[:self.total]
 
 

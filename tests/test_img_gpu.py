@@ -1031,6 +1031,16 @@ def test_track_frame_in_one_submission_equals_the_three_calls(gpu_required, scen
         for f in recs_p.dtype.names:
             assert np.array_equal(recs[f], recs_p[f]), f
         assert sum(int(o_["found"].sum()) for o_ in outs) > 150 and np.abs(mu_f).max() > 0
+    # zero-copy results (out = NULL + mcp_track_frame_view, include/mcp_img.h): the same bytes, read in place in the library's pinned block
+    if not stateful:
+        outs_c, _, pose_c, mu_c, w_c = tf.run(frames[1], poses[1], 10, 8)
+        outs_c = [o_.copy() for o_ in outs_c]
+        outs_v, _, pose_v, mu_v, w_v = tf.run(frames[1], poses[1], 10, 8, view=True)
+        for c in range(ncam):
+            assert len(outs_v[c]) == len(lists[c])
+            for f in kf.TD_OUT_DTYPE.names:
+                assert np.array_equal(outs_c[c][f], outs_v[c][f], equal_nan=outs_c[c][f].dtype.kind == "f"), (c, f)
+        assert np.array_equal(pose_c[0], pose_v[0]) and np.array_equal(pose_c[1], pose_v[1]) and np.array_equal(mu_c, mu_v)
     # search only (n_iter = 0): the pose stays, the weights are zero
     outs, recs, pose0, mu0, w0 = tf.run(None, poses[1], 10, 8, nonlinear=np.zeros(0, dtype=np.uint8), override_sigma=np.zeros(0))
     assert np.array_equal(pose0[0], poses[1][0]) and not mu0.any() and not w0.any()
