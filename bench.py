@@ -201,6 +201,11 @@ def main():
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    # stdout carries ONE line, the result: whatever a library prints there on its own (RCCL's version banner when a communicator is
+    # created) goes to stderr instead -- file descriptor 1 is pointed at stderr for the run, the result line is written to the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -524,7 +529,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             import bench_secondary
             result["secondary"] = {}
-            for name_ in ("c2", "c4", "c4_rank_shard"):
+            for name_ in ("c2", "c4", "c4_rank_shard", "metric_forced_multi"):
                 try:
                     result["secondary"][name_] = bench_secondary.run(name_, steps=10, device=local_rank)
                 except Exception as exc:
@@ -543,8 +548,9 @@ def main():
             result["tracker_c5"] = bench_tracker.main_c5(frames=10, cpu_frames=1)       # eight 1280x960 cameras, 8k points, on this one device
         except Exception as exc:
             result["tracker_c5"] = {"error": repr(exc)}
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(result))
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

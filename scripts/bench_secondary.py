@@ -3,6 +3,7 @@
 
   c2             4-cam, 50 MKF, 10k points, 80k measurements (BASELINE configs[1])
   c4             4-cam, 500 MKF, 100k points, 800k measurements, the WHOLE map on one device (configs[3] without its sharding)
+  metric_forced_multi  the headline map driven through the multi-rank machine on the native one-rank RCCL communicator
   c4_rank_shard  one rank's eighth of that map (synth.partition(c4, 8, 0): 500 poses replicated, ~12.5k points, ~100k measurements)
                  driven through the whole multi-rank machine on the native one-rank RCCL communicator (MCP_BA_FORCE_MULTI=1): what
                  ONE of the eight ranks of configs[3] executes per LM iteration, minus the time the other seven's bytes take on the wire
@@ -27,9 +28,11 @@ def run(name, steps=10, warm=6, device=0):
     import bench as B
     from mcptam_amd import chain_bundle, synth
     shard = name == "c4_rank_shard"
-    cfg = "c4" if name.startswith("c4") else name
+    forced = name == "metric_forced_multi"       # the headline map through the multi-rank machine on a one-rank communicator: what the machinery itself costs a rank
+    cfg = "c4" if name.startswith("c4") else ("metric" if forced else name)
     whole = synth.make_config(cfg)
     problem = synth.partition(whole, 8, 0) if shard else whole
+    shard = shard or forced
     comm = None
     old = os.environ.get("MCP_BA_FORCE_MULTI")
     if shard:
@@ -76,7 +79,7 @@ def run(name, steps=10, warm=6, device=0):
     trials = sum(l["trials"] for l in logs)
     out = {"workload": "%s: %d cams, %d MKF (%d free poses, %d unknowns in the reduced system), %d points, %d measurements%s" % (
                name, len(problem.cams), problem.n_mkf, np_ // 6, np_, problem.n_points, problem.n_meas,
-               " -- rank 0's share of the c4 map split over 8 ranks, one-rank RCCL communicator, every collective of the multi-rank path executed" if shard else ""),
+               (" -- the headline map on a one-rank RCCL communicator, every collective of the multi-rank path executed (MCP_BA_FORCE_MULTI=1)" if forced else " -- rank 0's share of the c4 map split over 8 ranks, one-rank RCCL communicator, every collective of the multi-rank path executed") if shard else ""),
            "value": steps / dt, "unit": "LM iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "trials_per_iteration": trials / steps,
            "reduced_system_solves": tm["n_solves"], "prepare_ms": prep_ms, "persist_fallbacks": tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"],
            "stages_ms_per_launch": {k: round(v["avg_ms"], 5) for k, v in roofs.items()},
@@ -93,17 +96,19 @@ def run(name, steps=10, warm=6, device=0):
 
 
 def main():
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c4", "c4_rank_shard"]
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c2", "c4", "c4_rank_shard", "metric_forced_multi"]
     steps = 10
     if "--steps" in sys.argv:
         steps = int(sys.argv[sys.argv.index("--steps") + 1]); names = [n for n in names if n != str(steps)]
     out = {}
+    sys.stdout.flush(); real = os.dup(1); os.dup2(2, 1)          # (RCCL prints its version banner to stdout: the result line stays alone there)
     for n in names:
         try:
             out[n] = run(n, steps=steps)
         except Exception as exc:
             out[n] = {"error": repr(exc)}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(real, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the judged summaries from gpurun_out/ (scratch) into profiles/$ROUND/ (tracked)
 set -e
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 cd "$(dirname "$0")/.."
 mkdir -p profiles/$ROUND
 cp gpurun_out/traffic.json profiles/$ROUND/pmc_traffic_per_launch.json

@@ -2,7 +2,7 @@
 # Round-end measurement pass on the MI355X box: full GPU test suite, PMC traffic (two separate rocprofv3 --pmc passes, as
 # MI355X_MICROARCH.md prescribes), rocprofv3 kernel stats of the bench, the bench line (incl. CPU baselines and the tracker line).
 # Everything lands in gpurun_out/ (scratch, merged back); scripts/collect_profiles.sh copies the summaries into profiles/$ROUND/.
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd $R
