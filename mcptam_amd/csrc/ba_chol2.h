@@ -43,6 +43,10 @@ constexpr int CP_BACK_NEAR = 3;               // rows k+1 .. k+CP_BACK_NEAR of c
 constexpr unsigned int CP_SENT32 = 0xFFF5A5A5u;
 constexpr unsigned long long CP_SENT = ((unsigned long long)CP_SENT32 << 32) | CP_SENT32;      // "not written yet": a NaN payload arithmetic never yields (both halves alike: hipMemsetD32 fills a buffer with it)
 
+#ifndef CP_HELPER_BATCH
+#define CP_HELPER_BATCH 1
+#endif
+constexpr int CP_HB = 4;              // tiles a helper keeps in flight ahead of its products (batched updates)
 struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
 // kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
 // index pre_flag), so that the band tiles of row i, whose last update needs L(i, i - CP_W), need not wait for this tile's own
@@ -699,7 +703,59 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
   if (t == 0) CP_HSTAMP(0);
   if (h.in_s) acc = cp_load_A(S, a.n, a.ntc, h.ti, h.tj, wave, lane);
   const int nplain = (h.kind == 1 && h.pre >= 0) ? h.nupd - 1 : h.nupd;
-  for (int u = 0; u < nplain; ++u) {
+  // The leading updates whose operands were published long ago -- nearly all of them for an entry claimed late, i.e. whenever the
+  // workers are few -- are taken in a batch: ONE look at their flags (a lane per update), then their tiles stream in CP_HB updates
+  // ahead of the products, through two LDS tile pairs with one barrier per update.  One update at a time this was a table read, a
+  // poll and a tile load in a row (three round trips to the memory side per update, ~2.5 us).  Same products in the same order.
+  int u_first = 0;
+#if CP_HELPER_BATCH
+  if (nplain > 1) {
+    int2* ulist = (int2*)(lds + 5*CP_TILE);
+    if (wave == 0) {
+      const int nb = min(nplain, 64);
+      bool late = false;
+      if (lane < nb) {
+        const int2 sl = a.upd[h.upd0 + lane];
+        ulist[lane] = sl;
+        const int fx = cp_flag_load(flags + sl.x), fy = cp_flag_load(flags + sl.y);
+        late = fx != done_l || fy != done_l;
+      }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(late);
+      if (lane == 0) ctl[2] = m ? min(nb, (int)__builtin_ctzll(m)) : nb;
+    }
+    __syncthreads();
+    const int nready = ctl[2];
+    if (nready > 1) {
+      chol_d4 va[CP_HB], vb[CP_HB];
+#pragma unroll
+      for (int k = 0; k < CP_HB; ++k) if (k < nready) {
+        const int2 sl = ulist[k];
+        va[k] = cp_ld4(rL, cp_chunk_off(sl.x, wave, lane));
+        vb[k] = cp_ld4(rL, cp_chunk_off(sl.y, wave, lane));
+      }
+      for (int base = 0; base < nready; base += CP_HB) {
+#pragma unroll
+        for (int k = 0; k < CP_HB; ++k) {
+          const int u = base + k;
+          if (u < nready) {
+            cp_tile Qa = (cp_tile)(lds + ((u & 1) ? 3*CP_TILE : 0)), Qb = (cp_tile)(lds + ((u & 1) ? 4*CP_TILE : CP_TILE));
+            cp_regs_to_lds(Qa, wave, lane, va[k]); cp_regs_to_lds(Qb, wave, lane, vb[k]);
+            if (u + CP_HB < nready) {
+              const int2 sl = ulist[u + CP_HB];
+              va[k] = cp_ld4(rL, cp_chunk_off(sl.x, wave, lane));
+              vb[k] = cp_ld4(rL, cp_chunk_off(sl.y, wave, lane));
+            }
+            cp_barrier();
+            cp_mma<true>(acc, Qa, Qb, wave, lane);
+          }
+        }
+      }
+      u_first = nready;
+      __syncthreads();
+    }
+  }
+#endif
+  for (int u = u_first; u < nplain; ++u) {
     const int2 sl = a.upd[h.upd0 + u];
     if (t == 0) {
       const bool patient = u + 3 < h.nupd;           // far behind the frontier of this tile: poll gently
@@ -1004,7 +1060,7 @@ constexpr int CP_PERSIST_LDS_MAX = CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLV
 // Per device, once: the kernels' LDS attributes, how many workgroups of k_chol_persist the device holds at a time (occupancy query x
 // compute units: 512 on a whole MI355X, a fraction of that on a partitioned one), the spin deadline in wall-clock ticks.  Progress
 // does not depend on the launch being resident (workers claim their work), the footprint does: a launch is sized to leave room.
-struct CpDevice { bool ok = false; int capacity = 0; bool disabled = false; int real_fallbacks = 0; };
+struct CpDevice { bool ok = false; int capacity = 0, ncu = 0; bool disabled = false; int real_fallbacks = 0; };
 inline CpDevice& cp_device(int dev = -1) {
   static std::mutex mu; static std::map<int, CpDevice> tab;
   if (dev < 0) (void)hipGetDevice(&dev);
@@ -1016,7 +1072,7 @@ inline CpDevice& cp_device(int dev = -1) {
   d.ok = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_PERSIST_LDS_MAX) == hipSuccess &&
          hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (6*CP_TILE + 700 + CH_SOLVE_MAX + 64)*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 4)*8*(int)sizeof(int)) == hipSuccess;
   if (d.ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_chol_persist, CP_THREADS, (size_t)CP_LDS_DOUBLES*sizeof(double) + 40*CP_STEP_INTS*sizeof(int)) == hipSuccess &&
-      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) d.capacity = nb*ncu;
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) { d.capacity = nb*ncu; d.ncu = ncu; }
   if (const char* e = getenv("MCP_BA_CHOL_CAPACITY")) d.capacity = atoi(e);      // (test hook: pretend to be a partition of that many workgroup slots)
   (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
   double ms = 20.0; if (const char* e = getenv("MCP_BA_CHOL_DEADLINE_MS")) ms = std::max(0.01, atof(e));
@@ -1039,6 +1095,8 @@ struct CholPersist {
   double *d_Lt = nullptr, *d_Bt = nullptr, *d_x = nullptr, *d_f = nullptr;
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
   int nworkers = 0;                      // helper workgroups per system (MCP_BA_CHOL_WORKERS)
+  int batch_sys = 0;                     // systems the caller has in flight beside each other, over all its streams (0 = just this launch's)
+  bool spread = true;                    // MCP_BA_CHOL_SPREAD=0: the workers of a launch are not cut to one workgroup per compute unit
   double flops = 0;                      // of one factorisation as this plan executes it (tile operations; mcp_ba_timing.chol_flops_plan)
   int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
   ~CholPersist() { release(); }
@@ -1194,6 +1252,7 @@ struct CholPersist {
       if (!dv.ok || dv.disabled || dv.capacity < 2*max_sys) { release(); return 0; }       // (no one-launch plan on this device: ok stays false, the per-step kernels run)
       nworkers = std::max(1, std::min(nworkers, (dv.capacity - dv.capacity/8)/max_sys - 1));
     }
+    { const char* e = getenv("MCP_BA_CHOL_SPREAD"); spread = !(e && atoi(e) == 0) && !getenv("MCP_BA_CHOL_WORKERS"); }
     { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
     ok = true;
     return 0;
@@ -1212,8 +1271,17 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   a.epoch = P.d_epoch + q0; P.fail_ptr = fail; a.claim = P.d_err + CholPersist::max_sys + q0;
   a.test_fail_step = (++P.n_launch == P.test_fail_launch) ? std::min(5, P.ntc - 1) : -1;
   a.xbuf = P.d_x + (size_t)q0*P.vec_stride; a.fbuf = P.d_f + (size_t)q0*P.vec_stride; a.vec_stride = P.vec_stride;
+  // Workers per system of THIS launch: two workgroups fit a compute unit, but a critical workgroup that shares its unit -- and a
+  // worker that shares one -- is slower than the same work spread out (four systems x 111 workers: 201 us, x 55: 188 us, one system
+  // alone: 186 us; round 6, after the workers' batched updates made 55 of them enough).  So when more than two systems are in
+  // flight together the launch is cut to what gives every workgroup of the batch a unit of its own, an eighth of the device left free.
+  {
+    const CpDevice& dv = cp_device();
+    const int batch = std::max(P.batch_sys, nsys);
+    if (P.spread && batch > 2 && dv.ncu > 0) a.nworkers = std::max(1, std::min(P.nworkers, std::max(8, (dv.ncu - dv.ncu/8)/batch - 1)));
+  }
   (void)hipGetLastError();          // (a leftover of an earlier, unrelated runtime call -- a stream query's hipErrorNotReady -- is not this launch's refusal)
-  hipLaunchKernelGGL(k_chol_persist, dim3((1 + P.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
+  hipLaunchKernelGGL(k_chol_persist, dim3((1 + a.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
   { const hipError_t e = hipGetLastError(); return (e == hipSuccess || e == hipErrorNotReady) ? 0 : -1; }       // (a launch the runtime refuses -- its LDS or grid does not fit this device -- is reported here, by name, not at the end of the solve)
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)

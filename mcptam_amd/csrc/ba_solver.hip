@@ -2593,6 +2593,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       // never waits for the other stream (its system comes out of the same launches as the first trial's)
       const int n1 = std::min(std::max(main_sys, 1), nsys - 1);
       HIPCK(hipEventRecord(ev_fork, st));
+      plan.persist.batch_sys = nsys;
       mark("fork", st);
       if (build_system(n1, sb, 0, st)) return -1;
       mark("main_built", st);
@@ -2615,6 +2616,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
       }
       defer_n1 = n1; defer_nsys = nsys;
     } else {
+    plan.persist.batch_sys = nsys;
     if (build_system(nsys, sb)) return -1;
     if (np) {
       if (use_graph && !prm.profile) {
