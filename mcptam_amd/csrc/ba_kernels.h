@@ -619,17 +619,23 @@ __global__ void k_tukey_flags(int n, const double* __restrict__ chi2, double s2,
 // Tukey::FindSigmaSquared (MEstimator.h:109-124) with the floor of ChainBundle.cc:1377-1383, the host's expression operation for operation --
 // the flags need no round trip through the host between the median and this kernel.
 __global__ void k_tukey_flags_dev(int n, const double* __restrict__ chi2, const double* __restrict__ res, int med_idx, double m_total, double min_sigma,
-                                  unsigned char* __restrict__ flag) {
+                                  unsigned long long* __restrict__ mask) {
+  // one BIT per measurement, a 64-bit word per wavefront (round 6: a byte per measurement was 400 KB for the host to walk through at the
+  // end of every solve -- 0.5 ms of a 15 ms call at the metric size; the words of a map that size are 50 KB, and the host visits set bits only)
   const int m = blockIdx.x*blockDim.x + threadIdx.x;
-  if (m >= n) return;
-  double s = 1.4826*(1 + 5.0/mest_denom(m_total))*sqrt(res[med_idx]);
-  s = 4.6851*s;
-  double s2 = s*s;
-  const double mins = min_sigma*min_sigma;
-  if (s2 < mins) s2 = mins;
-  const double e = fabs(chi2[m]);
-  const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
-  flag[m] = (sq*sq == 0.0) ? 1 : 0;
+  bool out = false;
+  if (m < n) {
+    double s = 1.4826*(1 + 5.0/mest_denom(m_total))*sqrt(res[med_idx]);
+    s = 4.6851*s;
+    double s2 = s*s;
+    const double mins = min_sigma*min_sigma;
+    if (s2 < mins) s2 = mins;
+    const double e = fabs(chi2[m]);
+    const double sq = (e > s2) ? 0.0 : 1.0 - (e/s2);
+    out = sq*sq == 0.0;
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(out);
+  if ((threadIdx.x & 63) == 0 && m < n) mask[m >> 6] = b;
 }
 // the state of a solve (poses 12 doubles each, points 3) to ONE destination -- pinned host memory: two copies into pageable vectors were
 // ~90 us of copy-engine operations and queue switches at the end of every BundleAdjustRecent call

@@ -2754,6 +2754,8 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   // Initialize(), ChainBundle.cc:1284-1298
   outliers.clear(); logs.clear();
   int conv_mag = 0, conv_res = 0;
+  auto t_first_end = t_begin;
+  static const bool trace_compute = [] { const char* e = getenv("MCP_BA_TRACE"); return e && atoi(e) >= 2; }();
   if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
   timing.schur_mfma_per_system = schur_mfma; timing.schur_flops_structural = schur_flops;
   timing.chol_flops_plan = (np > 0 && plan.persist.ok) ? plan.persist.flops : 0.0;
@@ -2951,9 +2953,11 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       total_iterations += qmax;
       lg.lambda_end = lambda; lg.trials = qmax; lg.accepted = accepted; lg.rms_update = rms;
       logs.push_back(lg);
+      if (it == 0) t_first_end = std::chrono::steady_clock::now();
     }
     nCounter = cj;
   }
+  const auto t_loop_end = std::chrono::steady_clock::now();
   if (join_spec()) return MCP_ERR_RUNTIME;
   if (join_sum()) return MCP_ERR_RUNTIME;
   if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d (median prediction missed: %d)\n", dbg_head_ahead, dbg_head_miss); dbg_head_ahead = 0; dbg_head_miss = 0; }
@@ -2968,6 +2972,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   if (evt_debug) { fprintf(stderr, "[evt] trials evaluated ahead and used: %d; host wait on mailbox: own trials %.0f us, ahead trials %.0f us\n", dbg_pre, dbg_wait_us[0], dbg_wait_us[1]); dbg_pre = 0; dbg_wait_us[0] = dbg_wait_us[1] = 0; }
   evt_flush();
   int rc = final_stats(nCounter);
+  const auto t_stats_end = std::chrono::steady_clock::now();
   if (rc == MCP_ERR_RUNTIME) return rc;
   converged = (conv_mag || conv_res);
   bool external_abort = terminate() && !converged;
@@ -2991,6 +2996,11 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
     timing.schur_ms = acc[ST_SCHUR]; timing.cholesky_ms = acc[ST_CHOL]; timing.solve_ms = acc[ST_SOLVE]; timing.update_ms = acc[ST_UPDATE];
   }
   timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (trace_compute) {
+    auto ms = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[compute] %d iterations: to the end of the first %.3f ms, the others %.3f ms, final statistics + export %.3f ms, state and outliers on the host %.3f ms; total %.3f ms\n",
+            nCounter, ms(t_begin, t_first_end), ms(t_first_end, t_loop_end), ms(t_loop_end, t_stats_end), ms(t_stats_end, std::chrono::steady_clock::now()), timing.total_ms);
+  }
   return rc;
 }
 
@@ -3004,9 +3014,9 @@ int mcp_ba::final_stats(int nCounter) {
   const size_t exp_state = (poses.size()*12 + points.size()*3)*sizeof(double);
   const bool flags_dev = tukey && nCounter != 0 && P.nmeas > 0;
   auto enqueue_export = [&](int med_idx) -> int {
-    if (ensure_export(exp_state + (size_t)P.nmeas)) return -1;
+    if (ensure_export(exp_state + ((size_t)P.nmeas + 63)/64*8)) return -1;
     if (flags_dev) hipLaunchKernelGGL(k_tukey_flags_dev, dim3((P.nmeas + 255)/256), dim3(256), 0, st, P.nmeas, (const double*)d_chi2[cur].p, (const double*)d_res.p, med_idx, (double)m_total,
-                                      prm.min_mestimator_sigma, h_exp + exp_state);
+                                      prm.min_mestimator_sigma, reinterpret_cast<unsigned long long*>(h_exp + exp_state));
     const size_t nps = poses.size()*12, npt = points.size()*3;
     if (flags_dev) note_launch("k_tukey_flags_dev");
     if (nps + npt) hipLaunchKernelGGL(k_export_state, dim3((unsigned)((nps + npt + 255)/256)), dim3(256), 0, st, nps, npt, (const double*)d_pose[cur].p, (const double*)d_pt[cur].p, reinterpret_cast<double*>(h_exp));
@@ -3028,6 +3038,7 @@ int mcp_ba::final_stats(int nCounter) {
     h_res[0] = h_res[24];
     for (int i = 0; i < 4; ++i) h_res[9 + i] = h_res[25 + i];
   } else {
+  const auto tf0 = std::chrono::steady_clock::now();
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
@@ -3035,8 +3046,11 @@ int mcp_ba::final_stats(int nCounter) {
   if (allreduce(d_res.p, 1, 0, false, "final robust chi2")) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, st));
   if (enqueue_export(12)) return -2;
+  const auto tf1 = std::chrono::steady_clock::now();
   if (read_results(13)) return -2;
   exported = true;
+  { static const bool tr = [] { const char* e = getenv("MCP_BA_TRACE"); return e && atoi(e) >= 2; }();
+    if (tr) fprintf(stderr, "[final] median + sums + export enqueued in %.3f ms, waited for %.3f ms\n", std::chrono::duration<double, std::milli>(tf1 - tf0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count()); }
   }
   if (robust) { sigma_sq = h_res[9]; sigma_sq_lim = h_res[10]; }
   mean_chi2 = h_res[0]/m_total;
@@ -3049,15 +3063,46 @@ int mcp_ba::final_stats(int nCounter) {
     const double mins = prm.min_mestimator_sigma*prm.min_mestimator_sigma;
     if (s2 < mins) s2 = mins;
     (void)s2;                                      // (the flags were taken on the device with this very threshold: k_tukey_flags_dev, above)
-    const unsigned char* fl = h_exp + exp_state;
-    std::vector<unsigned char> by_add(meas.size(), 0);
-    for (int j = 0; j < P.nmeas; ++j) if (fl[j] && perm[j] >= 0) by_add[perm[j]] = 1;      // (perm < 0: a measurement this map does not have -- near miss; its chi2 is 0)
-    for (size_t i = 0; i < meas.size(); ++i) if (by_add[i]) {
-      const HMeas& m = meas[i];
-      outliers.push_back(points[m.point].id);
-      outliers.push_back(poses[chains[m.chain].v[0]].id);      // vertices().front(), :1394
-      outliers.push_back(m.cam);
+    // The flags arrive as one bit per measurement in the structure's order.  Set bits only are visited: structure order -> add order
+    // through a bit map of the add indices (the list is in add order, as the reference's walk over its edges), then the three
+    // numbers of every outlier with the look-ups requested a few entries ahead -- each is a miss in a 16 MB array on a cold cache.
+    // (Round 6: byte flags walked one by one + the list built on demand misses took 2.3 ms of a 15 ms call at the metric size.)
+    const auto tq0 = std::chrono::steady_clock::now();
+    const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(h_exp + exp_state);
+    const int nw = (P.nmeas + 63)/64;
+    std::vector<unsigned long long> addmask((meas.size() + 63)/64, 0ull);
+    size_t nout = 0;
+    for (int w = 0; w < nw; ++w) {
+      unsigned long long bts = mk[w];
+      while (bts) {
+        const int j = w*64 + __builtin_ctzll(bts); bts &= bts - 1;
+        const int a = perm[j];
+        if (a >= 0) { addmask[(size_t)a >> 6] |= 1ull << (a & 63); ++nout; }      // (perm < 0: a measurement this map does not have -- near miss; its chi2 is 0)
+      }
     }
+    const auto tq1 = std::chrono::steady_clock::now();
+    std::vector<int> idx; idx.reserve(nout);
+    for (size_t w = 0; w < addmask.size(); ++w) {
+      unsigned long long bts = addmask[w];
+      while (bts) { idx.push_back((int)(w*64 + __builtin_ctzll(bts))); bts &= bts - 1; }
+    }
+    const auto tq2 = std::chrono::steady_clock::now();
+    outliers.resize(3*idx.size());
+    const size_t no = idx.size();
+    constexpr size_t AHEAD = 16;
+    for (size_t k = 0; k < std::min(no, AHEAD); ++k) __builtin_prefetch(&meas[idx[k]]);
+    for (size_t k = 0; k < std::min(no, AHEAD/2); ++k) __builtin_prefetch(&points[meas[idx[k]].point]);
+    for (size_t k = 0; k < no; ++k) {
+      if (k + AHEAD < no) __builtin_prefetch(&meas[idx[k + AHEAD]]);
+      if (k + AHEAD/2 < no) __builtin_prefetch(&points[meas[idx[k + AHEAD/2]].point]);
+      const HMeas& m = meas[idx[k]];
+      outliers[3*k] = points[m.point].id;
+      outliers[3*k + 1] = poses[chains[m.chain].v[0]].id;      // vertices().front(), :1394
+      outliers[3*k + 2] = m.cam;
+    }
+    { static const bool tr = [] { const char* e = getenv("MCP_BA_TRACE"); return e && atoi(e) >= 2; }();
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      if (tr) fprintf(stderr, "[final] outliers: set bits to add order %.3f ms, index list %.3f ms, %zu triples %.3f ms\n", ms(tq0, tq1), ms(tq1, tq2), no, ms(tq2, std::chrono::steady_clock::now())); }
   }
   // depth covariance only when fewer than 3 free poses (:1419); Hessian of the last buildSystem, no lambda
   if (nfp < 3 && nCounter > 0) {

@@ -7,7 +7,7 @@ def main(path):
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("mcp::", "").replace("void ", ""),
                  r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows)
-    lin = [i for i, e in enumerate(ev) if e[2] == "k_linearize_group"]
+    lin = [i for i, e in enumerate(ev) if e[2].startswith("k_linearize")]
     if len(lin) < 22:
         print("too few iterations in trace"); return
     i0 = lin[-20]
@@ -17,7 +17,7 @@ def main(path):
     streams = collections.defaultdict(list)
     for s, e, n, q in seg:
         streams[q].append((s, e, n))
-    main_q = max(streams, key=lambda q: sum(1 for x in streams[q] if x[2] == "k_linearize_group"))
+    main_q = max(streams, key=lambda q: sum(1 for x in streams[q] if x[2].startswith("k_linearize")))
     for q, L in streams.items():
         busy = sum(e - s for s, e, _ in L)
         print("stream %s%s: %d kernels, busy %.3f ms" % (q, " (main)" if q == main_q else "", len(L), busy/1e6))
@@ -39,7 +39,7 @@ def main(path):
         print("  %-22s -> %-22s n=%4d total %8.1f us avg %6.2f us" % (k[0], k[1], c, t/1e3, t/c/1e3))
     print("  all gaps: %.1f us" % (sum(t for _, t in gaps.values())/1e3))
     # last iteration timeline
-    j0 = max(i for i, x in enumerate(L) if x[2] == "k_linearize_group")
+    j0 = max(i for i, x in enumerate(L) if x[2].startswith("k_linearize"))
     base = L[j0][0]
     print("-- last iteration, main stream (start us, duration us)")
     last = None; run = 0
