@@ -257,36 +257,55 @@ k_head_small(int n, int robust, const double* __restrict__ chi2, unsigned long l
 #endif
 }
 
-// one workgroup: T_trial = exp(x) * T_cur for the free poses, the pose part of sum x(lambda x + b) and sum x^2 (as k_update_poses),
-// then the chain transforms of the trial state (as k_chains).  The poses written in the first half are read back by other
-// threads of the same workgroup in the second: nothing has cached those lines before (a kernel starts with a clean L1).
-__device__ __forceinline__ void update_chains_body(const DevProblem& P, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
+// T_trial = exp(x) * T_cur for the free poses, the pose part of sum x(lambda x + b) and sum x^2 (as k_update_poses), then the chain
+// transforms of the trial state (as k_chains).  One workgroup (ncb = 1: small bundles), or ncb of them with TA_CHAINS chains each
+// (round 6, large maps): EVERY chain workgroup computes all trial poses into its LDS (a pose is ~1 us of arithmetic for one thread,
+// and there are at most TA_MAX_POSES of them) and takes the chains' links from there; workgroup 0 also stores the poses and their
+// two sums.  Nothing crosses a workgroup, so the pose update, the chain transforms and the points' back-substitution -- three
+// dependent launches before -- run side by side in one.  Same arithmetic per pose and per chain as the separate kernels.
+constexpr int TA_CHAINS = 64;             // chains per chain workgroup when there are several
+constexpr int TA_MAX_POSES = 256;         // poses a chain workgroup keeps in LDS (24 KB); beyond: the separate kernels
+__device__ __forceinline__ void update_chains_body(const DevProblem& P, int cb, int ncb, double* __restrict__ tl, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
                 const double* __restrict__ T_cur, double* T_trial, double* __restrict__ out /*[2]*/, double* __restrict__ xp_keep,
                 double* __restrict__ first, double* __restrict__ second, double* __restrict__ last) {
   __shared__ double lds[4];
   double sc = 0.0, ss = 0.0;
-  for (int i = threadIdx.x; i < P.np; i += 256) xp_keep[i] = xp[i];
+  if (cb == 0) for (int i = threadIdx.x; i < P.np; i += 256) xp_keep[i] = xp[i];
   for (int i = threadIdx.x; i < P.npose; i += 256) {
     const int u = P.pose_unk[i];
-    if (u < 0) continue;
+    double* tp = tl + 12*(size_t)i;
+    if (u < 0) {          // (a fixed pose: every candidate state holds it)
+      const double* p = T_trial + 12*(size_t)i;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) tp[k] = p[k];
+      continue;
+    }
     const double* d = xp + 6*(size_t)u;
     Se3 E, T, R;
     se3_exp(d, E);
     load_se3(T_cur + 12*(size_t)i, T);
     se3_compose(E, T, R);
-    double* o = T_trial + 12*(size_t)i;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[k] = R.R[k];
-    o[9] = R.t[0]; o[10] = R.t[1]; o[11] = R.t[2];
-    for (int k = 0; k < 6; ++k) { sc += d[k]*(lambda*d[k] + bp[6*(size_t)u + k]); ss += d[k]*d[k]; }
+    for (int k = 0; k < 9; ++k) tp[k] = R.R[k];
+    tp[9] = R.t[0]; tp[10] = R.t[1]; tp[11] = R.t[2];
+    if (cb == 0) {
+      double* o = T_trial + 12*(size_t)i;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o[k] = R.R[k];
+      o[9] = R.t[0]; o[10] = R.t[1]; o[11] = R.t[2];
+      for (int k = 0; k < 6; ++k) { sc += d[k]*(lambda*d[k] + bp[6*(size_t)u + k]); ss += d[k]*d[k]; }
+    }
   }
-  const double t0 = block_sum<256>(sc, lds);
-  const double t1 = block_sum<256>(ss, lds);
-  if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; }
-  __threadfence();
+  if (cb == 0) {
+    const double t0 = block_sum<256>(sc, lds);
+    const double t1 = block_sum<256>(ss, lds);
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = t1; }
+  }
   __syncthreads();
-  const double* pose_T = T_trial;
-  for (int c = threadIdx.x; c < P.nchain; c += 256) {
+  const double* pose_T = tl;
+  const int c_lo = ncb == 1 ? 0 : cb*TA_CHAINS, c_hi = ncb == 1 ? P.nchain : min(P.nchain, (cb + 1)*TA_CHAINS);
+  if (ncb > 1 && threadIdx.x >= TA_CHAINS) return;
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
     const int len = P.chain_len[c];
     Se3 acc; se3_identity(acc);
     for (int i = 0; i < len; ++i) {
@@ -319,18 +338,20 @@ __device__ __forceinline__ void update_chains_body(const DevProblem& P, double l
   }
 }
 
-// The step of a trial applied in ONE launch: workgroup 0 updates the poses and recomputes the chain transforms (above), workgroups
-// 1.. back-substitute and update the points (k_backsub's body) -- the two halves read the same solution vector and touch disjoint
-// state, so nothing orders them; k_eval, which needs both, is the next launch of the stream.
+// The step of a trial applied in ONE launch: workgroups [0, ncb) update the poses and recompute the chain transforms (above), the
+// others back-substitute and update the points (k_backsub's body) -- the two halves read the same solution vector and touch
+// disjoint state, so nothing orders them; k_eval, which needs both, is the next launch of the stream.
+// Dynamic LDS: 12 npose doubles.
 static_assert(BS_BLOCK == 256, "k_trial_apply runs both bodies with 256 threads");
 __global__ void __launch_bounds__(256)
-k_trial_apply(DevProblem P, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
+k_trial_apply(DevProblem P, int ncb, double lambda, const double* __restrict__ xp, const double* __restrict__ bp,
               const double* __restrict__ T_cur, double* T_trial, double* __restrict__ out /*[2]*/, double* __restrict__ xp_keep,
               double* __restrict__ first, double* __restrict__ second, double* __restrict__ last,
               const double* __restrict__ g, const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ pt_cur,
               double* __restrict__ pt_trial, double* __restrict__ xl, double* __restrict__ part_scale, double* __restrict__ part_ss) {
-  if (blockIdx.x == 0) update_chains_body(P, lambda, xp, bp, T_cur, T_trial, out, xp_keep, first, second, last);
-  else backsub_body(P, (int)blockIdx.x - 1, lambda, xp, g, W, Vinv, pt_cur, pt_trial, xl, part_scale, part_ss);
+  extern __shared__ __attribute__((aligned(16))) double ta_poses[];
+  if ((int)blockIdx.x < ncb) update_chains_body(P, (int)blockIdx.x, ncb, ta_poses, lambda, xp, bp, T_cur, T_trial, out, xp_keep, first, second, last);
+  else backsub_body(P, (int)blockIdx.x - ncb, lambda, xp, g, W, Vinv, pt_cur, pt_trial, xl, part_scale, part_ss);
 }
 
 }  // namespace mcp

@@ -673,6 +673,14 @@ struct mcp_ba {
   // everything the second stream still has in flight reads the current linearisation (W, V, g, staged blocks): the main stream
   // must not overwrite any of it, nor consume a speculative solution, before that work is done
   // q < 0: everything; otherwise only the stream that produces system q of the batch
+  // The step of a trial in one launch (ba_small.h k_trial_apply): chain workgroups of that launch, 0 = the separate kernels (a map with
+  // more poses than a chain workgroup keeps in LDS; MCP_BA_TRIAL_FUSE=0).  Small bundles: one workgroup for all chains, as before.
+  int trial_fuse = 1;
+  int trial_chain_blocks() const {
+    if (P.npose > TA_MAX_POSES) return 0;
+    if (small_mode()) return 1;
+    return trial_fuse ? std::max(1, (P.nchain + TA_CHAINS - 1)/TA_CHAINS) : 0;
+  }
   int join_spec(int q = -1) {
     if (spec_pending && (q < 0 || (q >= spec2_from && q < spec3_from))) { HIPCK(hipStreamWaitEvent(st, ev_spec, 0)); spec_pending = false; }
     if (spec3_pending && (q < 0 || q >= spec3_from)) { HIPCK(hipStreamWaitEvent(st, ev_spec3, 0)); spec3_pending = false; }
@@ -1963,6 +1971,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   { const char* e = getenv("MCP_BA_SPECULATE"); if (e) speculate = atoi(e); }
   { const char* e = getenv("MCP_BA_SPECULATE_ADAPT"); if (e) spec_adapt = atoi(e); }
   { const char* e = getenv("MCP_BA_LIN_JOIN"); if (e) lin_join_full = atoi(e); }
+  { const char* e = getenv("MCP_BA_TRIAL_FUSE"); if (e) trial_fuse = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (multi()) {
@@ -2269,16 +2278,17 @@ int mcp_ba::enqueue_spec_trial(hipStream_t s, int q) {
   double* resq = d_res.p + 32 + 8*q;
   const bool small = small_mode();
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
-  if (small) hipLaunchKernelGGL(k_trial_apply, dim3(1 + (nfl ? nbb : 0)), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p,
+  const int ncb = trial_chain_blocks();
+  if (ncb) { hipLaunchKernelGGL(k_trial_apply, dim3(ncb + (nfl ? nbb : 0)), dim3(256), (size_t)P.npose*12*sizeof(double), s, P, ncb, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p,
                                 d_first[slot].p, d_second[slot].p, d_last[slot].p, (const double*)d_g.p, (const double*)d_W.p, (const double*)(d_Vinv.p + q*vinv_stride),
-                                (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
+                                (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p); note_launch("k_trial_apply"); }
   else {
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, P, lam, (const double*)rhsq, (const double*)(rhsq + np), (const double*)d_pose[cur].p, d_pose[slot].p, resq + 4, d_sxp[q].p);
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, s, P, lam, (const double*)rhsq, (const double*)d_g.p, (const double*)d_W.p,
                               (const double*)(d_Vinv.p + q*vinv_stride), (const double*)d_pt[cur].p, d_pt[slot].p, d_sxl[q].p, d_sp1[q].p, d_sp2[q].p);
   }
   HIPCK(hipEventRecord(ev_wf[q], s));                     // the linearisation's outputs are not read below this line (join_spec_lin)
-  if (P.nchain && !small) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
+  if (P.nchain && !ncb) hipLaunchKernelGGL(k_chains, dim3((P.nchain + 63)/64), dim3(64), 0, s, P, (const double*)d_pose[slot].p, d_first[slot].p, d_second[slot].p, d_last[slot].p);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   const bool with_head = head_ahead_want && !small && large_heads() && large_head_ahead != 2 && nbe > 0;      // (MCP_BA_HEAD_AHEAD=2: only the main stream's trial carries a head)
   if (nbe) hipLaunchKernelGGL((k_eval<true>), dim3(nbe), dim3(EVAL_BLOCK), 0, s, P, (const double*)d_pt[slot].p, (const double*)d_last[slot].p, d_chi2[slot].p, (double*)nullptr,
@@ -2655,9 +2665,10 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   tic(ST_UPDATE);
   const bool small = small_mode();
   const int nbb = (nfl*BS_TPP + BS_BLOCK - 1)/BS_BLOCK;
-  if (small) hipLaunchKernelGGL(k_trial_apply, dim3(1 + (nfl ? nbb : 0)), dim3(256), 0, st, P, lam, (const double*)rhs(), bp_glob, (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p,
+  const int ncb = trial_chain_blocks();
+  if (ncb) { hipLaunchKernelGGL(k_trial_apply, dim3(ncb + (nfl ? nbb : 0)), dim3(256), (size_t)P.npose*12*sizeof(double), st, P, ncb, lam, (const double*)rhs(), bp_glob, (const double*)d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p,
                                 d_first[tr].p, d_second[tr].p, d_last[tr].p, (const double*)d_g.p, (const double*)d_W.p, (const double*)Vinv(),
-                                (const double*)d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p);
+                                (const double*)d_pt[cur].p, d_pt[tr].p, d_xl.p, d_part1.p, d_part2.p); note_launch("k_trial_apply"); }
   else {
   hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, st, P, lam, rhs(), bp_glob, d_pose[cur].p, d_pose[tr].p, d_res.p + 6, d_xp_cand.p);
   if (nfl) hipLaunchKernelGGL(k_backsub, dim3(nbb), dim3(BS_BLOCK), 0, st, P, lam, rhs(), d_g.p, d_W.p, Vinv(),
@@ -2665,7 +2676,7 @@ int mcp_ba::solve_trial(double lam, bool& ok2, double ni) {
   }
   toc();
   tic(ST_EVAL);
-  if (!small) launch_chains(tr);
+  if (!ncb) launch_chains(tr);
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   const bool mailbox = use_mailbox && !prm.profile;
   mail_ticket0 = ++mail_ticket;
