@@ -1208,18 +1208,24 @@ int mcp_ba::prepare() {
   // count), each into its own arrays with range-relative indices; concatenated below with the offsets fixed up
   std::vector<unsigned char> cov((size_t)std::max(nfp, 1)*std::max(nfp, 1), 0);        // pose-pair co-visibility, a >= b
   struct Chunk { int sp0 = 0, sp1 = 0; std::vector<int> slot_unk, slot_inc, inc_unk, slot_cnt, sp_ninc, q_n, q_data; std::vector<unsigned char> slot_first, inc_state; };
-  std::vector<Chunk> chunks(T);
+  // (eight chunks per thread (MCP_BA_PREP_CHUNKS), claimed one after the other: equal measurement counts are not equal times -- 1.0 to 1.6 ms per thread
+  //  at the metric size with one chunk each -- and the concatenation below is by chunk index, so who built a chunk changes nothing)
+  static const int chunks_per_thread = [] { const char* e = getenv("MCP_BA_PREP_CHUNKS"); return e ? std::max(1, atoi(e)) : 8; }();
+  const int NC = T > 1 ? chunks_per_thread*T : 1;
+  std::vector<Chunk> chunks(NC);
   const avec<int>& sp_m = H.sp_m;
-  for (int t = 0; t < T; ++t) {
-    const long m0 = (long)nmeas*t/T, m1 = (long)nmeas*(t + 1)/T;
+  for (int t = 0; t < NC; ++t) {
+    const long m0 = (long)nmeas*t/NC, m1 = (long)nmeas*(t + 1)/NC;
     chunks[t].sp0 = (t == 0) ? 0 : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m0) - sp_m.begin());
-    chunks[t].sp1 = (t == T - 1) ? nsp : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m1) - sp_m.begin());
+    chunks[t].sp1 = (t == NC - 1) ? nsp : (int)(std::lower_bound(sp_m.begin(), sp_m.begin() + nsp, (int)m1) - sp_m.begin());
   }
   std::vector<double> thr_ms(T, 0.0);
+  std::atomic<int> next_chunk{0};
   par([&](int tid) {
     const auto tt0 = std::chrono::steady_clock::now();
     struct Stamp { double* d; std::chrono::steady_clock::time_point t; ~Stamp() { *d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } stamp_{&thr_ms[tid], tt0};
-    Chunk& C = chunks[tid];
+    for (int ci; (ci = next_chunk.fetch_add(1, std::memory_order_relaxed)) < NC;) {
+    Chunk& C = chunks[ci];
     const size_t nm_chunk = (size_t)(sp_m[C.sp1] - sp_m[C.sp0]);
     C.slot_unk.reserve(nm_chunk*2 + 16); C.slot_inc.reserve(nm_chunk*2 + 16); C.slot_first.reserve(nm_chunk*2 + 16);
     C.inc_unk.reserve(nm_chunk + 16); C.inc_state.reserve(nm_chunk + 16); C.q_data.reserve(nm_chunk + 16);
@@ -1268,16 +1274,19 @@ int mcp_ba::prepare() {
       if ((int)q.size() > GRP_LMAX) H.sp_big[sp] = 1;
       for (int a : q) for (int b2 : q) if (a >= b2 && !__atomic_load_n(covp + (size_t)a*nfp + b2, __ATOMIC_RELAXED)) __atomic_store_n(covp + (size_t)a*nfp + b2, (unsigned char)1, __ATOMIC_RELAXED);
     }
+    }
   });
   lap("  slot threads");
   if (trace) { fprintf(stderr, "[mcp_ba prepare]   per-thread ms:"); for (double v : thr_ms) fprintf(stderr, " %.2f", v); fprintf(stderr, "\n"); }
   std::vector<int> sp_q0(nsp + 1, 0), sp_q;           // distinct pose unknowns touched by every sorted point
   std::vector<unsigned char> inc_state;
   {
-    std::vector<size_t> soff(T + 1, 0), ioff(T + 1, 0), qoff(T + 1, 0);
-    for (int t = 0; t < T; ++t) { soff[t + 1] = soff[t] + chunks[t].slot_unk.size(); ioff[t + 1] = ioff[t] + chunks[t].inc_unk.size(); qoff[t + 1] = qoff[t] + chunks[t].q_data.size(); }
-    H.slot_unk.resize(soff[T]); H.slot_inc.resize(soff[T]); H.slot_first.resize(soff[T]); H.inc_unk.resize(ioff[T]); inc_state.resize(ioff[T]); sp_q.resize(qoff[T]);
-    par([&](int tid) {
+    std::vector<size_t> soff(NC + 1, 0), ioff(NC + 1, 0), qoff(NC + 1, 0);
+    for (int t = 0; t < NC; ++t) { soff[t + 1] = soff[t] + chunks[t].slot_unk.size(); ioff[t + 1] = ioff[t] + chunks[t].inc_unk.size(); qoff[t + 1] = qoff[t] + chunks[t].q_data.size(); }
+    H.slot_unk.resize(soff[NC]); H.slot_inc.resize(soff[NC]); H.slot_first.resize(soff[NC]); H.inc_unk.resize(ioff[NC]); inc_state.resize(ioff[NC]); sp_q.resize(qoff[NC]);
+    next_chunk.store(0);
+    par([&](int) {
+      for (int tid; (tid = next_chunk.fetch_add(1, std::memory_order_relaxed)) < NC;) {
       const Chunk& C = chunks[tid];
       const int io = (int)ioff[tid];
       int so = (int)soff[tid];
@@ -1297,10 +1306,11 @@ int mcp_ba::prepare() {
         if (lpt >= 0) { H.l_i0[lpt] = ib; H.l_i1[lpt] = ib + C.sp_ninc[sp - C.sp0]; H.l_sp[lpt] = sp; }
         ib += C.sp_ninc[sp - C.sp0]; qb += C.q_n[sp - C.sp0];
       }
+      }
     });
-    sp_q0[nsp] = (int)qoff[T];
-    H.sp_i[nsp] = (int)ioff[T];
-    H.slot_start[nmeas] = (int)soff[T];
+    sp_q0[nsp] = (int)qoff[NC];
+    H.sp_i[nsp] = (int)ioff[NC];
+    H.slot_start[nmeas] = (int)soff[NC];
   }
   ninc = (int)H.inc_unk.size(); nslot = (int)H.slot_unk.size();
   lap("sort+slots");

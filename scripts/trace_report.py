@@ -7,13 +7,18 @@ def main(path):
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("mcp::", "").replace("void ", ""),
                  r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows)
-    lin = [i for i, e in enumerate(ev) if e[2].startswith("k_linearize")]
-    if len(lin) < 22:
-        print("too few iterations in trace"); return
-    i0 = lin[-20]
-    seg = ev[i0:]
+    # a Compute call ends with k_export_state: bench.py's calls are prewarm (40 iterations), warm-up, the timed one, ...
+    ends = [i for i, e in enumerate(ev) if e[2] == "k_export_state"]
+    call = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    if len(ends) <= call:
+        print("too few Compute calls in trace"); return
+    seg = ev[ends[call - 1] + 1:ends[call] + 1]
+    seg = [e for e in seg if not e[2].startswith("__amd_rocclr_fill") and e[2] not in ("k_upload_set", "k_fan_state")]
+    lin = [i for i, e in enumerate(seg) if e[2].startswith("k_linearize")]
+    seg = seg[max(0, lin[0] - 8):]
+    print("Compute call %d of the trace: %d linearisations" % (call, len(lin)))
     t0, t1 = seg[0][0], max(e[1] for e in seg)
-    print("timed region (last 20 iterations): %.3f ms" % ((t1 - t0)/1e6))
+    print("device span of the call: %.3f ms" % ((t1 - t0)/1e6))
     streams = collections.defaultdict(list)
     for s, e, n, q in seg:
         streams[q].append((s, e, n))
