@@ -36,6 +36,7 @@
 #include "ba_trial.h"
 #include "ba_head.h"
 #include "ba_small.h"
+#include "ba_headl.h"
 
 using namespace mcp;
 
@@ -572,6 +573,13 @@ struct mcp_ba {
   int sel_cap = 4096;           // candidates per rank slot (MCP_BA_SELECT_CAP)
   DevBuf<double> d_xp_cand;     // pose update of the trial in flight; swapped with d_xp_good (as d_xl with d_xl_good) when the solve succeeded
   DevBuf<double> d_part0, d_part1, d_part2, d_res, d_sigma, d_hist, d_cov;
+  // the head of an iteration of a large map in one launch (ba_headl.h, MCP_BA_HEAD_LARGE=1): scratch (left zeroed by every launch).  Default off:
+  // measured equal to the six launches at the metric size (1611 / 1603 vs 1606 / 1611 it/s) -- 39 us alone on the device against ~50, but its 64
+  // fat workgroups wait for room beside the trials evaluated ahead on the other stream, which six small launches slip past
+  DevBuf<unsigned char> d_headl; bool headl_clean = false; int head_large_on = 0; int hl_grid = 0;
+  bool use_head_large() const { return head_large_on && robust && !multi() && !small_mode() && P.nmeas > 0 && hl_grid > 0 && d_headl.p != nullptr; }
+  int head_large(int w, int off, double* sig_copy2);
+  bool head_failed = false;
   bool hist_clean = false;          // the single-GPU median left its two histograms + counter zero (k_select_small's last act): no fill in front of the next one
   // The sigma block is double-buffered by median: a trial evaluated ahead on the speculative stream that nobody consumes may
   // still be reading its iteration's block when the next iteration's median writes the new one (the two streams only meet
@@ -1982,6 +1990,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
   { const char* e = getenv("MCP_BA_SPECULATE_ADAPT"); if (e) spec_adapt = atoi(e); }
   { const char* e = getenv("MCP_BA_LIN_JOIN"); if (e) lin_join_full = atoi(e); }
   { const char* e = getenv("MCP_BA_TRIAL_FUSE"); if (e) trial_fuse = atoi(e); }
+  { const char* e = getenv("MCP_BA_HEAD_LARGE"); if (e) head_large_on = atoi(e); }
   { const char* e = getenv("MCP_BA_GRAPH"); if (e) use_graph = atoi(e); }
   { const char* e = getenv("MCP_BA_SELECT_CAP"); if (e) sel_cap = std::max(1, atoi(e)); }
   if (multi()) {
@@ -1998,6 +2007,16 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       d_xp_good.alloc(np) || d_xp_cand.alloc(np) || d_selvals.alloc(SEL_GATHER_CAP) || d_xl_good.alloc((size_t)nfl*3) || d_part0.alloc(nblk) || d_part1.alloc(nblk) ||
       d_part2.alloc(nblk) || d_parth.alloc(nblk) || d_res.alloc(32 + 8*MAX_SYS) || d_sigma.alloc(8*N_SIG) || d_hist.alloc((size_t)SEL_PASSES*SEL_BINS) ||
       d_selstate.alloc(SEL_PASSES + 1) || d_fail.alloc(4) || d_flags.alloc(nmeas) || d_cov.alloc(nfl)) return -1;
+  if (head_large_on && robust && !multi() && nmeas > 0) {
+    if (d_headl.alloc(sizeof(HeadLScratch))) return -1;
+    headl_clean = false;                           // (the block may be a fresh one: zeroed in front of the first head)
+    if (!hl_grid) {
+      int nb = 0, ncu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_head_large, HL_THREADS, 0) == hipSuccess &&
+          hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) hl_grid = std::min(HL_GRID, std::max(0, nb*ncu/2));      // (co-resident with room to spare)
+      (void)hipGetLastError();
+    }
+  } else d_headl.release();
   {
     // scratch of the per-trial iteration heads (ba_head.h): per slot [parity][q] the digit histograms + counters, the candidates,
     // the robust chi2's partial sums, the median and the iteration-start block
@@ -2202,6 +2221,22 @@ int mcp_ba::select_gather_finish(const double* x, int n, const double* hist, Sel
   }
   hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, st, n, x, (const unsigned int*)cnt, (const double*)d_seltab.p, (const SelState*)state,
                      m_total, 0.0, out_dev, (double*)nullptr, (double*)nullptr, (const double*)(d_seltab.p + tab + 1), world, sel_cap);
+  return 0;
+}
+// median + sigma block + robust chi2 of buffer `w` in one launch (ba_headl.h): the sigma block to sig() and d_res[25..28] (and to
+// sig_copy2), the median to d_res[8], the robust chi2 to d_res[off]
+int mcp_ba::head_large(int w, int off, double* sig_copy2) {
+  tic(ST_SELECT);
+  flip_sig();
+  if (!headl_clean) { HIPCK(hipMemsetAsync(d_headl.p, 0, offsetof(HeadLScratch, cand), st)); headl_clean = true; }
+  const int n = P.nmeas;
+  const int grid = std::max(1, std::min(hl_grid, (n + HL_THREADS*2 - 1)/(HL_THREADS*2)));
+  hipLaunchKernelGGL(k_head_large, dim3(grid), dim3(HL_THREADS), 0, st, n, (const double*)d_chi2[w].p, med_rank(), m_total,
+                     prm.min_mestimator_sigma*prm.min_mestimator_sigma, sig(), d_res.p + 25, sig_copy2, d_res.p + 8, d_part0.p, d_res.p, off,
+                     reinterpret_cast<HeadLScratch*>(d_headl.p));
+  note_launch("k_head_large");
+  sel_src = -1;
+  toc();
   return 0;
 }
 // RobustKernelData::RecomputeNow on the chi2 array of buffer `w`
@@ -2831,6 +2866,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       head_ahead_want = (small_mode() || large_heads()) && use_mailbox && !prm.profile && it + 1 < n_iter;
       if (head_done) { }
       else if (small_mode()) { if (head_small(cur)) return MCP_ERR_RUNTIME; }
+      else if (use_head_large()) { if (head_large(cur, RS, nullptr)) return MCP_ERR_RUNTIME; }
       else {
       if (robust) { if (median_sigma(cur)) return MCP_ERR_RUNTIME; }
       tic(ST_EVAL);
@@ -2859,11 +2895,13 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
       bool start_pending = true;
       auto take_start = [&]() {
         currentChi = tempChi = h_res[RS];
+        { unsigned long long b; std::memcpy(&b, &h_res[RS], 8); if (b == HL_FAILED_BITS) head_failed = true; }
         if (robust) { sigma_sq = h_res[RS + 1]; sigma_sq_lim = h_res[RS + 2]; pred_bin = sel_coarse_bin(h_res[RS + 4]); }
         lg.chi2_start = currentChi; lg.sigma_sq = sigma_sq;
         start_pending = false;
       };
       if (it == 0) { if (read_results(RS + 5)) return MCP_ERR_RUNTIME; take_start(); }
+      if (head_failed) { head_failed = false; set_err("the head of an iteration (k_head_large) gave up at a barrier"); return MCP_ERR_RUNTIME; }
       if (it == 0) {
         if (user_lambda > 0) lambda = user_lambda;
         else {
@@ -2885,6 +2923,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         bool ok2 = true;
         if (solve_trial(lambda, ok2, ni)) return MCP_ERR_RUNTIME;
         if (start_pending) take_start();
+        if (head_failed) { head_failed = false; set_err("the head of an iteration (k_head_large) gave up at a barrier"); return MCP_ERR_RUNTIME; }
         if (test_fail_trial > 0 && ++test_trial_no == test_fail_trial) ok2 = false;      // (test hook: this trial's factorisation "failed")
         double scale, ss;
         trial_chi_raw = h_res[0];
@@ -2982,6 +3021,18 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   if (join_spec()) return MCP_ERR_RUNTIME;
   if (join_sum()) return MCP_ERR_RUNTIME;
   if (evt_debug) { fprintf(stderr, "[evt] iteration heads enqueued ahead and used: %d (median prediction missed: %d)\n", dbg_head_ahead, dbg_head_miss); dbg_head_ahead = 0; dbg_head_miss = 0; }
+#ifdef MCP_HL_PROF
+  if (evt_debug) {
+    (void)hipDeviceSynchronize();
+    long long pr[16]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_hl_prof), sizeof pr);
+    fprintf(stderr, "[hl prof] workgroup 0 (10 ns ticks): A %lld | barrier %lld | B %lld | barrier %lld | C %lld | barrier %lld | D %lld | barrier %lld | E %lld | last workgroup done +%lld\n",
+            pr[1] - pr[0], pr[2] - pr[1], pr[3] - pr[2], pr[4] - pr[3], pr[5] - pr[4], pr[6] - pr[5], pr[7] - pr[6], pr[8] - pr[7], pr[9] - pr[8], pr[10] - pr[9]);
+    static long long wgs[256][4]; (void)hipMemcpyFromSymbol(wgs, HIP_SYMBOL(g_hl_wg), sizeof wgs);
+    long long lo[3] = {1ll << 62, 1ll << 62, 1ll << 62}, hi[3] = {0, 0, 0};
+    for (int w = 0; w < std::min(256, hl_grid); ++w) for (int j = 0; j < 3; ++j) { lo[j] = std::min(lo[j], wgs[w][j] - pr[0]); hi[j] = std::max(hi[j], wgs[w][j] - pr[0]); }
+    fprintf(stderr, "[hl prof] over the workgroups, ticks from workgroup 0's start: local histogram done %lld..%lld, flushed %lld..%lld, barrier passed %lld..%lld\n", lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
+  }
+#endif
 #ifdef MCP_HS_PROF
   if (evt_debug) {
     (void)hipDeviceSynchronize();
@@ -3060,15 +3111,19 @@ int mcp_ba::final_stats(int nCounter) {
     for (int i = 0; i < 4; ++i) h_res[9 + i] = h_res[25 + i];
   } else {
   const auto tf0 = std::chrono::steady_clock::now();
+  if (use_head_large()) { if (head_large(cur, 0, d_res.p + 9)) return -2; }      // (the sigma block lands in d_res[9..12] too: no copy behind it)
+  else {
   if (median_sigma(cur)) return -2;
   const int nbe = (P.nmeas + EVAL_BLOCK - 1)/EVAL_BLOCK;
   if (nbe) hipLaunchKernelGGL(k_robust_sum, dim3(nbe), dim3(EVAL_BLOCK), 0, st, P.nmeas, robust, (const double*)d_chi2[cur].p, (const double*)sig(), d_part0.p);
   hipLaunchKernelGGL(k_final_sums, dim3(1), dim3(256), 0, st, nbe, (const double*)d_part0.p, 0, (const double*)nullptr, 0, (const double*)nullptr, d_res.p, 0, (const int*)nullptr);
   if (allreduce(d_res.p, 1, 0, false, "final robust chi2")) return -2;
   HIPCK(hipMemcpyAsync(d_res.p + 9, sig(), 4*sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   if (enqueue_export(12)) return -2;
   const auto tf1 = std::chrono::steady_clock::now();
   if (read_results(13)) return -2;
+  { unsigned long long b; std::memcpy(&b, &h_res[0], 8); if (b == HL_FAILED_BITS) { set_err("the final statistics (k_head_large) gave up at a barrier"); return -2; } }
   exported = true;
   { static const bool tr = [] { const char* e = getenv("MCP_BA_TRACE"); return e && atoi(e) >= 2; }();
     if (tr) fprintf(stderr, "[final] median + sums + export enqueued in %.3f ms, waited for %.3f ms\n", std::chrono::duration<double, std::milli>(tf1 - tf0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf1).count()); }

@@ -42,7 +42,10 @@ for v in "$@"; do
     cpprof2) build cpprof2 -DMCP_CP_PROF=2 & ;;
     cpprof3) build cpprof3 -DMCP_CP_PROF=3 & ;;
     cpprof4) build cpprof4 -DMCP_CP_PROF=4 & ;;
-    cpprof5) build cpprof5 -DMCP_CP_PROF=5 & ;;            # only each wavefront's arrival at the step's last barrier
+    cpprof5) build cpprof5 -DMCP_CP_PROF=5 & ;;
+    hl32) build hl32 -DHL_GRID_N=32 & ;;
+    hl128) build hl128 -DHL_GRID_N=128 & ;;
+    hlprof) build hlprof -DMCP_HL_PROF & ;;                 # phase stamps of k_head_large (workgroup 0), printed with MCP_BA_EVT=1            # only each wavefront's arrival at the step's last barrier
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
