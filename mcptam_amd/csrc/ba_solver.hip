@@ -2170,7 +2170,8 @@ void mcp_ba::launch_eval(int w, bool sum, double* err_out) {
 
 // exact k-th smallest |x| (global over ranks when a hook is installed); result left at out_dev[0]
 int mcp_ba::select_kth(const double* x, int n, unsigned long long k, double* out_dev, bool huber_sigma) {
-  const int grid = std::max(1, std::min(1024, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
+  static const int grid_max = [] { const char* e = getenv("MCP_BA_SELECT_GRID"); return e ? std::max(1, atoi(e)) : 1024; }();
+  const int grid = std::max(1, std::min(grid_max, (n + SEL_BLOCK*4 - 1)/(SEL_BLOCK*4)));
   if (!multi()) {
     // single GPU: two full histogram passes, gather, one-workgroup finish (which also writes the Huber sigma block if asked)
     if (!hist_clean) HIPCK(hipMemsetAsync(d_hist.p, 0, (size_t)(2*SEL_BINS + 1)*sizeof(double), st));        // two histograms + the gather counter behind them

@@ -26,6 +26,11 @@ cd /tmp; rm -rf $R/gpurun_out/trk5_prof
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/trk5_prof -- python $R/scripts/bench_tracker.py c5 > $R/gpurun_out/trk5_prof.json 2> $R/gpurun_out/trk5_prof.err
 f=$(find $R/gpurun_out/trk5_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/trk5_kernel_stats.csv
 find $R/gpurun_out/trk5_prof -name '*kernel_trace.csv' -delete; cd $R
+# kernel stats of the c4 map (500 MKF, 100k points, 800k measurements) as a whole on this one device
+cd /tmp; rm -rf $R/gpurun_out/prof_c4
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c4 -- python $R/scripts/bench_secondary.py c4 > $R/gpurun_out/prof_c4.json 2> $R/gpurun_out/prof_c4.err
+f=$(find $R/gpurun_out/prof_c4 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $R/gpurun_out/c4_kernel_stats.csv
+find $R/gpurun_out/prof_c4 -name '*kernel_trace.csv' -delete; cd $R
 # kernel stats + whole-call times of the BundleAdjustRecent window (the call MCPTAM makes most)
 cd /tmp; rm -rf $R/gpurun_out/prof_window
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_window -- python $R/scripts/bench_window.py --calls 10 > $R/gpurun_out/prof_window.log 2>&1
