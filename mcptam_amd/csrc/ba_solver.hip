@@ -488,11 +488,12 @@ struct mcp_ba {
   bool pre_run[MAX_SYS] = {false, false, false, false}, ahead_enq[MAX_SYS] = {false, false, false, false}; unsigned long long pre_ticket[MAX_SYS] = {0, 0, 0, 0};
   hipEvent_t ev_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_wf[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};      // trial q evaluated ahead: its last reader of the linearisation (k_backsub) is through
-  // MCP_BA_SPEC_TRIALS: 0 = trials strictly in sequence; 1 (default) = one trial ahead on the stream that solved it; 2 = the steps
-  // of ALL speculatively solved systems are applied and evaluated as soon as their solutions exist, each on its own stream
-  // (st_tr[q], behind the speculative chain's event).  Measured, same box and run: 819 / 835 it/s (1) vs 733 / 743 (2) -- three
-  // trial evaluations at once take the compute units from the trial the host is waiting for.
-  int spec_trials = 1;
+  // MCP_BA_SPEC_TRIALS: 0 = trials strictly in sequence; 1 = one trial ahead on the stream that solved it; 2 (default since round 6)
+  // = the steps of ALL speculatively solved systems are applied and evaluated as soon as their solutions exist, each on its own
+  // stream (st_tr[q], behind the speculative chain's event).  Round 3 measured 819 / 835 it/s (1) vs 733 / 743 (2) -- three trial
+  // evaluations at once took the compute units from the trial the host was waiting for; with a trial's step in one launch and the
+  // evaluation at 17 us the balance has turned: 1518 / 1519 / 1610 (1) vs 1543 / 1538 / 1629 (2), pairs within one run.
+  int spec_trials = 2;
   hipStream_t st_tr[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t tr_stream[MAX_SYS] = {nullptr, nullptr, nullptr, nullptr};      // where the trial ahead of system q was enqueued
   // system

@@ -964,7 +964,7 @@ def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeyp
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
                                  dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
                                  dict(MCP_BA_STREAM_POOL="0"), dict(MCP_BA_SCHUR4_ORDER="0"), dict(MCP_BA_HEAD_AHEAD="1"), dict(MCP_BA_HEAD_AHEAD="2"),
-                                 dict(MCP_BA_TRIAL_FUSE="0"), dict(MCP_BA_SPEC_TRIALS="2"), dict(MCP_BA_CHOL_SPREAD="0"), dict(MCP_BA_HEAD_LARGE="1")])
+                                 dict(MCP_BA_TRIAL_FUSE="0"), dict(MCP_BA_SPEC_TRIALS="1"), dict(MCP_BA_CHOL_SPREAD="0"), dict(MCP_BA_HEAD_LARGE="1")])
 def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
     """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox, graph replay and the
     iteration head (median, sigma^2 -- ba_head.h) enqueued behind every trial before the host has accepted one are
