@@ -531,7 +531,7 @@ def main():
             result["secondary"] = {}
             for name_ in ("c2", "c4", "c4_rank_shard", "metric_forced_multi"):
                 try:
-                    result["secondary"][name_] = bench_secondary.run(name_, steps=10, device=local_rank)
+                    result["secondary"][name_] = bench_secondary.run(name_, steps=(args.steps if name_ == "metric_forced_multi" else 10), device=local_rank)      # (the machine's overhead against the headline: same iteration count)
                 except Exception as exc:
                     result["secondary"][name_] = {"error": repr(exc)}
         except Exception as exc:
