@@ -254,6 +254,9 @@ __device__ inline void cp_pair_sync(int* ctr, int& target, int lane) {      // t
 // 435 -> 182 multiply-adds; the price is the hand-over on the chain (follower's last column, its 16 stores, wavefront 0's 16 loads).
 // Lcol lives in the LDS tile that will take L^-1 at the panel's END (free until then); the hand-over buffer aliases Lcol.
 constexpr int CP_SPLIT = 16;
+#ifndef CP_SWAP
+#define CP_SWAP 1      // the follower finishes the panel (no hand-over), wavefront 0 takes its product of the step
+#endif
 #define CP_SB() __builtin_amdgcn_sched_barrier(0)
 template <int K, int G> struct CpBulkA {       // first half: group G (of 6) of the bulk update by column K on columns [K + 3, CP_SPLIT)
   static constexpr int n = (CP_SPLIT - K - 3 > 0) ? CP_SPLIT - K - 3 : 0;
@@ -313,12 +316,12 @@ __device__ inline void cp_pivot_a(double* d, double& inv, bool& bad, double* mE,
 }
 // pivots CP_SPLIT .. 31 on wavefront 0: ba_chol.h's chol_panel_pivot, but column CP_SPLIT - 1's bulk update is not wavefront 0's
 template <int J>
-__device__ inline void cp_pivot_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf) {
+__device__ inline void cp_pivot_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf, int lane) {
   double* cur = (J & 1) ? mO : mE;
   double* prev = (J & 1) ? mE : mO;
   constexpr bool BULK = J >= CP_SPLIT + 1;
   d[J] *= inv;
-  if constexpr (J + 3 < CH_NB) colbuf[threadIdx.x] = d[J];
+  if constexpr (J + 3 < CH_NB) colbuf[lane] = d[J];
   CP_SB();
   if constexpr (J + 1 < CH_NB) {
     const double w = __builtin_fma(-d[J], d[J], d[J + 1]);
@@ -356,8 +359,8 @@ __device__ inline void cp_pivots_a(double* d, double& inv, bool& bad, double* mE
   (cp_pivot_a<Js>(d, inv, bad, mE, mO, lcol, lrow, prog, pbase), ...);
 }
 template <int... Js>
-__device__ inline void cp_pivots_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf, std::integer_sequence<int, Js...>) {
-  (cp_pivot_b<CP_SPLIT + Js>(d, inv, bad, mE, mO, colbuf), ...);
+__device__ inline void cp_pivots_b(double* d, double& inv, bool& bad, double* mE, double* mO, double* colbuf, int lane, std::integer_sequence<int, Js...>) {
+  (cp_pivot_b<CP_SPLIT + Js>(d, inv, bad, mE, mO, colbuf, lane), ...);
 }
 __device__ inline int cp_lds_word(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -385,6 +388,18 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf
   double mE[CH_NB], mO[CH_NB];
   cp_pivots_a(d, inv, bad, mE, mO, Lcol + lane, Lcol, ctlw, CP_SPLIT*k, std::make_integer_sequence<int, CP_SPLIT>());
   if (lane == 0) CP_STAMP(s, 14);
+#if CP_SWAP
+  // The follower goes on with the pivots CP_SPLIT .. 31 itself (cp_follow): the columns they work on are the ones it holds.  Wavefront
+  // 0's part of L^-1 -- its 16 columns of the identity's rows -- goes out once the follower has read the last published column (Lcol
+  // and L^-1 share the tile), off the chain.
+  while (cp_lds_word(ctlw + 64) != k + 1) __builtin_amdgcn_s_sleep(1);
+  if (bad && lane == 0) atomicOr(fail, 2);
+  if (low) {
+#pragma unroll
+    for (int c = 0; c < CP_SPLIT; ++c) Dinv[c][rr] = d[c];
+  }
+  return;
+#endif
   // the follower's columns
   while (cp_lds_word(ctlw + 64) != k + 1) __builtin_amdgcn_s_sleep(0);
 #pragma unroll
@@ -396,7 +411,7 @@ __device__ __forceinline__ void cp_potrf(cp_tile D, cp_tile Dinv, double* colbuf
     inv = cp_rsq3(pn);
   }
   if (lane == 0) CP_STAMP(s, 15);
-  cp_pivots_b(d, inv, bad, mE, mO, colbuf, std::make_integer_sequence<int, CH_NB - CP_SPLIT>());
+  cp_pivots_b(d, inv, bad, mE, mO, colbuf, lane, std::make_integer_sequence<int, CH_NB - CP_SPLIT>());
   if (lane == 0) CP_STAMP(s, 10);
   if (bad && lane == 0) atomicOr(fail, 2);
   // lane 32 + r ends with row r of L^-T = column r of L^-1.  Its entries left of the diagonal ARE zero (0 - 0 m = 0 through every
@@ -436,11 +451,16 @@ template <int... Ks>
 __device__ __forceinline__ void cp_follow_cols(double* dh, CpCol& ca, CpCol& cb, const double* Lcol, const int* prog, int pbase, int lane, std::integer_sequence<int, Ks...>) {
   ((Ks & 1 ? cp_follow_col<Ks>(dh, cb, ca, Lcol, prog, pbase, lane) : cp_follow_col<Ks>(dh, ca, cb, Lcol, prog, pbase, lane)), ...);
 }
-__device__ __forceinline__ void cp_follow(cp_tile D, cp_tile Dinv, const double* zvec, int* ctlw, int k) {
+__device__ __forceinline__ void cp_follow(cp_tile D, cp_tile Dinv, const double* zvec, int* ctlw, int k, double* colbuf, int* fail, int q, int s) {
   const int lane = threadIdx.x & 63;
   const int rr = lane & 31;
   const bool low = lane >= 32;
+#if CP_SWAP
+  double d[CH_NB];                       // (columns CP_SPLIT .. 31 only: the lower half is never touched)
+  double* dh = d + CP_SPLIT;
+#else
   double dh[CP_NC];
+#endif
   const double* src = low ? zvec + (CH_NB - 1 - rr) : &D[rr][0];
 #pragma unroll
   for (int c = 0; c < CP_NC; ++c) dh[c] = src[CP_SPLIT + c];
@@ -450,9 +470,33 @@ __device__ __forceinline__ void cp_follow(cp_tile D, cp_tile Dinv, const double*
   __builtin_amdgcn_sched_barrier(0);
   cp_follow_cols(dh, ca, cb, Lcol, ctlw, CP_SPLIT*k, lane, std::make_integer_sequence<int, CP_SPLIT>());
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if CP_SWAP
+  // Round 6, second half: the follower does NOT hand its 16 columns back (16 stores, a flag, wavefront 0's poll and 16 loads: 0.56 us on
+  // the chain of every step) -- it IS the panel from here on: pivots CP_SPLIT .. 31 touch no other column.  Same instructions on the
+  // same numbers as wavefront 0 would have issued.  Wavefront 0 is told that the last published column has been read (it may now
+  // overwrite Lcol with its part of L^-1) and takes over this wavefront's product of the step (cp_critical).
+  __hip_atomic_store(ctlw + 64 + lane, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (a word per lane, as the progress words)
+  bool bad = false;
+  double inv;
+  {
+    const double pn = readlane_f64(d[CP_SPLIT], CP_SPLIT);
+    bad |= !(pn > 0.0);
+    inv = cp_rsq3(pn);
+  }
+  if (lane == 0) CP_STAMP(s, 15);
+  double mE[CH_NB], mO[CH_NB];
+  cp_pivots_b(d, inv, bad, mE, mO, colbuf, lane, std::make_integer_sequence<int, CH_NB - CP_SPLIT>());
+  if (lane == 0) CP_STAMP(s, 10);
+  if (bad && lane == 0) atomicOr(fail, 2);
+  if (low) {
+#pragma unroll
+    for (int c = CP_SPLIT; c < CH_NB; ++c) Dinv[c][rr] = d[c];
+  }
+#else
 #pragma unroll
   for (int c = 0; c < CP_NC; ++c) Lcol[c*64 + lane] = dh[c];
   __hip_atomic_store(ctlw + 64 + lane, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (a word per lane, as the progress words)
+#endif
 }
 
 __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
@@ -506,6 +550,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   // the panel keeps in registers never share a live range that way (one loop with a branch per role spilled 63 registers).
   if (wave == 0) {
     int dcur = 0;               // Dt(dcur): diagonal tile (s+1, s+1), updated through column s - 1
+    int pair_target0 = 0;
     // s = -1 is the lead-in: only the factorisation of diagonal tile 0 (the one call site of the panel code)
     for (int s = -1; s < ntc; ++s) {
       const int i1 = s + 1;
@@ -524,6 +569,20 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       if (t == 0) CP_STAMP(s, 1);
       if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, zvec, pwords, i1, fail, q, s);
       if (t == 0) CP_STAMP(s, 2);
+#if CP_SWAP
+      if (s >= 0 && s + 2 <= R && ctl[1]) {
+        // A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1)) once wavefronts 2, 3 have completed the solve:
+        // wavefront 1's product until it became the panel's second half
+        while (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target0 + 2 && ctl[1]) __builtin_amdgcn_s_sleep(1);
+        pair_target0 += 4;               // (the pair meets twice per step: after its solve and before L(s+2, s)'s flag)
+        asm volatile("" ::: "memory");
+        if (s + 2 < ntc && ctl[1]) {
+          chol_d4 a0 = cp_lds_to_regs(Dt(dcur ^ 1), 0, lane), a2 = cp_lds_to_regs(Dt(dcur ^ 1), 2, lane), a3 = cp_lds_to_regs(Dt(dcur ^ 1), 3, lane);
+          cp_mma<true>(a0, Xb1, Xb1, 0, lane); cp_mma<true>(a2, Xb1, Xb1, 2, lane); cp_mma<true>(a3, Xb1, Xb1, 3, lane);
+          cp_regs_to_lds(Dt(dcur ^ 1), 0, lane, a0); cp_regs_to_lds(Dt(dcur ^ 1), 2, lane, a2); cp_regs_to_lds(Dt(dcur ^ 1), 3, lane, a3);
+        }
+      }
+#endif
       cp_barrier();
       if (t == 0) CP_STAMP(s, 8);
       if (!ctl[1]) return;
@@ -550,7 +609,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
       if (t == 128) CP_STAMP(s, 4);
     }
-    if (s < 0 && wave == 1) cp_follow(Dt(0), Dv(0), zvec, pwords, 0);      // (the lead-in: diagonal tile 0's panel has its follower too)
+    if (s < 0 && wave == 1) cp_follow(Dt(0), Dv(0), zvec, pwords, 0, colbuf, fail, q, s);      // (the lead-in: diagonal tile 0's panel has its follower too)
     if (MCP_CP_PROF_ARRIVE && lane == 0) CP_STAMP(s, 16 + wave);
     cp_barrier();                      // end of step s
     if (!ctl[1]) return;
@@ -607,13 +666,16 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         cp_regs_to_lds(Tc, 2*h, lane, v2); cp_regs_to_lds(Tc, 2*h + 1, lane, v3);
         if (diag2) { cp_regs_to_lds(Dt(dcur ^ 1), 2*h, lane, v4); cp_regs_to_lds(Dt(dcur ^ 1), 2*h + 1, lane, v5); }
       }
+      // (Measured and dropped, round 6: wavefronts 2, 3 computing quadrants of the solve BEFORE this drain, wavefront 1 storing nothing --
+      //  the flag of L_ss^-1 then comes 0.7 us later, the band row of step s+2 is late (1038-1551 re-asks per 30 launches instead of ~100)
+      //  and the step grows from 4.5 to 4.9-5.1 us: the helpers of row s+3 hang on that flag.)
       CP_DRAIN();                      // every wavefront's share of L_ss^-1 / L(s+1, s) has landed
       if (tw == 0) {
-        // wavefront 1 checks in without waiting and follows the panel's first half (cp_follow); it is back for the products
+        // wavefront 1 checks in without waiting, follows the panel's first half and does its second (cp_follow)
         team_target += 3;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (i1 < ntc) cp_follow(Dt(dcur), Dv(i1), zvec, pwords, i1);
+        if (i1 < ntc) cp_follow(Dt(dcur), Dv(i1), zvec, pwords, i1, colbuf, fail, q, s);
       } else cp_team_sync(ctl, team_target, lane);
       if (t == 128) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
       // the late product of tile (s+2, s+1), data-tagged as well: wavefronts 2, 3 ask for the two quadrants each will update (U1 below)
@@ -662,7 +724,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
           CP_DRAIN();
           cp_pair_sync(ctl + 2, pair_target, lane);
           if (t == 128) { cp_flag_store(flags + s2, done_l); CP_STAMP(s, 7); }
-        } else {
+        } else if (!CP_SWAP) {
           // wavefront 1, back from the panel: A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1)) once
           // the solve is complete (it usually has been for a while)
           while (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target + 2) __builtin_amdgcn_s_sleep(1);
