@@ -666,6 +666,8 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         cp_regs_to_lds(Tc, 2*h, lane, v2); cp_regs_to_lds(Tc, 2*h + 1, lane, v3);
         if (diag2) { cp_regs_to_lds(Dt(dcur ^ 1), 2*h, lane, v4); cp_regs_to_lds(Dt(dcur ^ 1), 2*h + 1, lane, v5); }
       }
+      // (Measured and dropped, round 6: wavefront 0 -- idle once the panel's first half is done -- sending L(s+2, s) off and raising its flag
+      //  instead of wavefronts 2, 3: the flag comes ~0.15 us later, 1569 re-asks, 189.6 vs 185 us.  And:)
       // (Measured and dropped, round 6: wavefronts 2, 3 computing quadrants of the solve BEFORE this drain, wavefront 1 storing nothing --
       //  the flag of L_ss^-1 then comes 0.7 us later, the band row of step s+2 is late (1038-1551 re-asks per 30 launches instead of ~100)
       //  and the step grows from 4.5 to 4.9-5.1 us: the helpers of row s+3 hang on that flag.)
