@@ -2890,6 +2890,11 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         if (np && asm_long) hipLaunchKernelGGL(k_udiag_long, dim3((np*ASML_LPE + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
         else if (np) hipLaunchKernelGGL(k_udiag, dim3((np + 255)/256), dim3(256), 0, st, A, np, (const double*)d_stU.p, (const double*)Ubig(), d_udiag.p);
         if (multi() && np) { if (allreduce(d_udiag.p, np, 0, false, "pose diagonal for the initial lambda")) return MCP_ERR_RUNTIME; }
+        const int nbm = std::min(256, (std::max(np, nfl) + 1023)/1024);
+        if (nbm > 1) {          // (d_part1: the trials' partial sums live there later; nothing of this iteration has used it yet)
+          hipLaunchKernelGGL(k_max_diag_part, dim3(nbm), dim3(256), 0, st, np, (const double*)d_udiag.p, 1, nfl, (const double*)d_V.p, d_part1.p);
+          hipLaunchKernelGGL(k_max_of, dim3(1), dim3(256), 0, st, nbm, (const double*)d_part1.p, d_res.p + 5);
+        } else
         hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(256), 0, st, np, (const double*)d_udiag.p, 1, nfl, (const double*)d_V.p, d_res.p + 5);
       }
       static_assert(RS + 1 == 25, "median_sigma() writes the sigma block to d_res + 25");
