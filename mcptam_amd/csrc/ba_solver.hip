@@ -954,6 +954,20 @@ static int chain_first_movable(const HChain& c, const std::vector<HPose>& poses)
 }
 
 int mcp_ba::prepare() {
+  HIPCK(hipSetDevice(device));
+  {
+    // k_head_small keeps its candidates in 112 KB of dynamic LDS: a device (or partition) that does not grant that runs small bundles through
+    // the general launches instead (the refusal used to fail every robust small-bundle solve).  Per device: asked once.
+    static std::mutex hs_mu; static std::map<int, bool> hs_ok;
+    std::lock_guard<std::mutex> lk(hs_mu);
+    auto it = hs_ok.find(device);
+    if (it == hs_ok.end()) {
+      const bool ok = hipFuncSetAttribute((const void*)k_head_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HS_STASH*sizeof(double))) == hipSuccess;
+      (void)hipGetLastError();
+      it = hs_ok.emplace(device, ok).first;
+    }
+    if (!it->second) small_on = 0;
+  }
   if (getenv("MCP_BA_PREPARE_LEGACY")) return prepare_legacy();
   auto t0 = std::chrono::steady_clock::now();
   auto tlast = t0; const bool trace = getenv("MCP_BA_TRACE") != nullptr;
@@ -2491,14 +2505,6 @@ int mcp_ba::head_small(int w, bool sum_aside) {
   // a sum still on its way on the second stream (the head of a trial that was then rejected) writes the same d_res[24]: it must not
   // land after the one this launch takes itself
   if (!aside && join_sum()) return -1;
-  {
-    static std::atomic<unsigned long long> hs_attr{0};
-    const unsigned long long bit = 1ull << (device & 63);
-    if (!(hs_attr.load(std::memory_order_relaxed) & bit)) {
-      HIPCK(hipFuncSetAttribute((const void*)k_head_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HS_STASH*sizeof(double))));
-      hs_attr.fetch_or(bit, std::memory_order_relaxed);
-    }
-  }
   hipLaunchKernelGGL(k_head_small, dim3(1), dim3(1024), HS_STASH*sizeof(double), st, P.nmeas, robust ? 1 : 0, (const double*)d_chi2[w].p, med_rank(), m_total,
                      prm.min_mestimator_sigma*prm.min_mestimator_sigma, prev, d_res.p + 8, sig(), d_res.p + 25, d_res.p, 24, aside ? 0 : 1);
   note_launch("k_head_small");
