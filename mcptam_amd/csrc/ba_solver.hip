@@ -1449,6 +1449,13 @@ int mcp_ba::prepare() {
     }
     H.pr_start.assign(npairs + 1, 0);
     for (int i = 0; i < npairs; ++i) H.pr_start[i + 1] = H.pr_start[i] + cnt_pair[i];
+    if (trace) {
+      // (list lengths of the assembly's walks: diagonal pairs against the rest)
+      long nd = 0, sd = 0, md = 0, no = 0, so = 0, mo = 0;
+      for (int a = 0; a < nfp; ++a) for (int b = 0; b <= a; ++b) { const int pid = H.pair_id[(size_t)a*nfp + b]; if (pid < 0) continue; const long c = cnt_pair[pid];
+        if (a == b) { ++nd; sd += c; md = std::max(md, c); } else { ++no; so += c; mo = std::max(mo, c); } }
+      fprintf(stderr, "[mcp_ba prepare] staged blocks per pose pair: diagonal %ld pairs, mean %.1f, max %ld; off-diagonal %ld pairs, mean %.1f, max %ld\n", nd, nd ? (double)sd/nd : 0.0, md, no, no ? (double)so/no : 0.0, mo);
+    }
     // destination-ordered staging: the blocks of one pose pair are consecutive, in ascending group order (blocks are
     // numbered group by group, so walking them in order fills every pair's run in that order)
     { std::vector<int> pos(H.pr_start.begin(), H.pr_start.end() - 1);
