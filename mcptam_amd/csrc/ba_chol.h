@@ -538,6 +538,7 @@ struct CholPlan {
   // the one-launch factorisation + chain back-substitution of ba_chol2.h (MCP_BA_CHOL_PERSIST=0: the per-step kernels below)
   mutable CholPersist persist; bool use_persist = false;
   const char* launch_failed = nullptr;      // name of a kernel of this plan whose launch the runtime refused (the solver reports it)
+  std::vector<int> persist_segs;      // first block column of every chain of the one-launch plan (ba_chol2.h CholPersist::build); empty = one chain
   int persist_min_ntc = 3;      // smallest system (in tiles) the one-launch plan is built for (the test hooks set 1)
   ~CholPlan() { release(); }
   int arena_dev = -1;
@@ -606,7 +607,7 @@ struct CholPlan {
     }
     { const char* e = getenv("MCP_BA_CHOL_PERSIST"); use_persist = !(e && atoi(e) == 0); }
     // (a reduced system of one or two tiles -- the BundleAdjustRecent window, <= 5 free poses -- is two launches either way: no plan for it)
-    if (use_persist && ntc >= persist_min_ntc && persist.build(n, pattern, pattern.empty() ? std::vector<int>() : all_tiles)) return -1;
+    if (use_persist && ntc >= persist_min_ntc && persist.build(n, pattern, pattern.empty() ? std::vector<int>() : all_tiles, persist_segs)) return -1;
     return 0;
   }
   size_t tile_updates() const { return step_tiles.size(); }

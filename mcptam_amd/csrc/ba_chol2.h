@@ -47,6 +47,7 @@ constexpr unsigned long long CP_SENT = ((unsigned long long)CP_SENT32 << 32) | C
 #define CP_HELPER_BATCH 1
 #endif
 constexpr int CP_HB = 4;              // tiles a helper keeps in flight ahead of its products (batched updates)
+constexpr int CP_MAX_SEG = 4;
 struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
 // kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
 // index pre_flag), so that the band tiles of row i, whose last update needs L(i, i - CP_W), need not wait for this tile's own
@@ -58,6 +59,7 @@ constexpr int CP_STEP_INTS = 12;
 enum { CPS_SD = 0, CPS_S1, CPS_S2, CPS_DL, CPS_F0, CPS_F1, CPS_F2, CPS_B0, CPS_B1, CPS_B2 };
 struct CpArgs {
   const double* S; size_t sys_stride; int n, ntc, nsys, nhelpers, nworkers;
+  int nseg; int seg_start[CP_MAX_SEG + 1];      // block columns [seg_start[g], seg_start[g+1]) are critical workgroup g's (round 6: independent chains side by side)
   const int* slot_of; const int* bslot_of; const int* delta_of; const int* steps; const CpHelper* helpers; const int2* upd;
   double* Lt; size_t lt_stride;               // published L tiles / L_kk^-1, per system
   double* Bt; size_t bt_stride;               // band tiles handed to the critical workgroup, per system
@@ -499,9 +501,16 @@ __device__ __forceinline__ void cp_follow(cp_tile D, cp_tile Dinv, const double*
 #endif
 }
 
-__device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
+template <bool SEG>        // (false: one chain from column 0 to the right-hand side -- the constants fold as they did before there were segments)
+__device__ inline void cp_critical(const CpArgs& a, int q, double* lds, int seg) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int ntc = a.ntc, R = a.ntc;
+  // This workgroup's chain: block columns [c0, ntc).  The LAST segment ends with the right-hand-side row (row a.ntc) as the matrix does;
+  // any other ends where its columns end -- nothing below them is this chain's (what couples to them are far tiles: helpers' work) --
+  // i.e. it is walked as a matrix of `ntc` block columns without a right-hand side whose last row is R = ntc - 1.
+  const int c0 = SEG ? a.seg_start[seg] : 0;
+  const bool last_seg = SEG ? seg + 1 == a.nseg : true;
+  const int ntc = SEG ? a.seg_start[seg + 1] : a.ntc, R = last_seg ? a.ntc : ntc - 1;
+  const int ntc_all = a.ntc;
   // LDS tiles (pointers computed, never kept in an indexed array: that would live in scratch)
   auto Dv = [&](int i) { return (cp_tile)(lds + (i & 1)*CP_TILE); };             // L_kk^-1 of block k in Dv(k)
   const cp_tile Xb0 = (cp_tile)(lds + 2*CP_TILE), Xb1 = (cp_tile)(lds + 3*CP_TILE);
@@ -519,17 +528,17 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   const int epoch4 = a.epoch[q] << 2, done_l = epoch4 | 2;
   const int code = 0x100;
   int* stp = ctl + 16;                       // the step table
-  for (int i = t; i < (ntc + 1)*CP_STEP_INTS; i += CP_THREADS) stp[i] = a.steps[i];
+  for (int i = t; i < (ntc_all + 1)*CP_STEP_INTS; i += CP_THREADS) stp[i] = a.steps[i];
   if (t == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; }
   if (t < 128) pwords[t] = 0;
   if (t < 64) zvec[t] = (t == CH_NB - 1) ? 1.0 : 0.0;
   __syncthreads();
   // ---- prologue: rows 0 and 1 of the band (their helpers pass A through) arrive as data-tagged chunks: wavefront w takes quadrant w of
   //      tiles (0,0), (1,0) and (1,1)
-  const bool row1_diag = 1 < ntc;
+  const bool row1_diag = c0 + 1 < ntc;
   {
-    const unsigned o0 = cp_chunk_off(bslot_of[0], wave, lane), o1 = cp_chunk_off(bslot_of[1*ntc + 0], wave, lane);
-    const unsigned o2 = row1_diag ? cp_chunk_off(bslot_of[1*ntc + 1], wave, lane) : o1;
+    const unsigned o0 = cp_chunk_off(bslot_of[(size_t)c0*ntc_all + c0], wave, lane), o1 = cp_chunk_off(bslot_of[(size_t)(c0 + 1)*ntc_all + c0], wave, lane);
+    const unsigned o2 = row1_diag ? cp_chunk_off(bslot_of[(size_t)(c0 + 1)*ntc_all + c0 + 1], wave, lane) : o1;
     chol_d4 p0, p1, p2;
     unsigned it = 0; long long t0 = 0;
     for (;;) {
@@ -552,11 +561,11 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
     int dcur = 0;               // Dt(dcur): diagonal tile (s+1, s+1), updated through column s - 1
     int pair_target0 = 0;
     // s = -1 is the lead-in: only the factorisation of diagonal tile 0 (the one call site of the panel code)
-    for (int s = -1; s < ntc; ++s) {
+    for (int s = c0 - 1; s < ntc; ++s) {
       const int i1 = s + 1;
       const cp_tile Ds = Dv(s);
       if (t == 0) CP_STAMP(s, 0);
-      if (s >= 0) {
+      if (s >= c0) {
         cp_regs_to_lds(Xb0, 0, lane, cp_trsm_quadrant(Tc, Ds, 0, lane));      // P1, quadrant 0
         cp_barrier();
         if (i1 < ntc) {                                                          // P2, quadrant 0
@@ -570,7 +579,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       if (i1 < ntc) cp_potrf(Dt(dcur), Dv(i1), colbuf, zvec, pwords, i1, fail, q, s);
       if (t == 0) CP_STAMP(s, 2);
 #if CP_SWAP
-      if (s >= 0 && s + 2 <= R && ctl[1]) {
+      if (s >= c0 && s + 2 <= R && ctl[1]) {
         // A'(s+2, s+2) -= X2 X2^T (lower triangle's quadrants: the panel never reads (0, 1)) once wavefronts 2, 3 have completed the solve:
         // wavefront 1's product until it became the panel's second half
         while (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_target0 + 2 && ctl[1]) __builtin_amdgcn_s_sleep(1);
@@ -595,7 +604,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
   // The loop body starts where the team asks for the band row it needs a step later and ends where it has used it: the request and
   // its use sit in ONE iteration (carried around the loop the compiler waited for the loads at the loop head, i.e. hid nothing).
   // `s` is the step that is ending (-1: the lead-in, wavefront 0 factors diagonal tile 0).
-  for (int s = -1; s < ntc; ++s) {
+  for (int s = c0 - 1; s < ntc; ++s) {
     chol_d4 v0 = {0.0, 0.0, 0.0, 0.0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0;       // wavefronts 2, 3: band row s+3
     unsigned ob0 = 0, ob1 = 0, ob2 = 0;
     if (wave >= 2 && s + 3 <= R && ctl[1]) {
@@ -609,7 +618,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       v4 = cp_ld4(rB, ob2); v5 = cp_ld4(rB, ob2 + 2048);
       if (t == 128) CP_STAMP(s, 4);
     }
-    if (s < 0 && wave == 1) cp_follow(Dt(0), Dv(0), zvec, pwords, 0, colbuf, fail, q, s);      // (the lead-in: diagonal tile 0's panel has its follower too)
+    if (s < c0 && wave == 1) cp_follow(Dt(0), Dv(c0), zvec, pwords, c0, colbuf, fail, q, s);      // (the lead-in: diagonal tile 0's panel has its follower too)
     if (MCP_CP_PROF_ARRIVE && lane == 0) CP_STAMP(s, 16 + wave);
     cp_barrier();                      // end of step s
     if (!ctl[1]) return;
@@ -635,8 +644,10 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
       cp_barrier();
       // ---- P2: A'(s+1, s+1) -= X1 X1^T, quadrants 0 | 3 | 2 on wavefronts 0, 1, 2 (the panel never reads quadrant (0, 1)); wavefront 3 sends L(s+1, s) off instead
       if (wave == 3) {
+        if (i1 <= R) {                    // (a chain that is not the last ends without a row below its last column)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
+          for (int qd = 0; qd < 4; ++qd) cp_st4(rL, cp_chunk_off(s1, qd, lane), cp_lds_to_regs(Xb0, qd, lane));
+        }
       } else if (i1 < ntc) {
         const int qd = wave == 1 ? 3 : wave;
         chol_d4 acc = cp_lds_to_regs(Dt(dcur), qd, lane);
@@ -679,7 +690,7 @@ __device__ inline void cp_critical(const CpArgs& a, int q, double* lds) {
         if (lane == 0) __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (i1 < ntc) cp_follow(Dt(dcur), Dv(i1), zvec, pwords, i1, colbuf, fail, q, s);
       } else cp_team_sync(ctl, team_target, lane);
-      if (t == 128) { cp_flag_store(flags + sd, done_l); cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
+      if (t == 128) { cp_flag_store(flags + sd, done_l); if (i1 <= R) cp_flag_store(flags + s1, done_l); CP_STAMP(s, 3); }
       // the late product of tile (s+2, s+1), data-tagged as well: wavefronts 2, 3 ask for the two quadrants each will update (U1 below)
       // and look at them after their products.  (Round 5 waited for the product's flag HERE, before the solve: the solve then started
       // when the product's helper was done, which in turn hung on the previous step's last flag -- a cycle one step long.)
@@ -892,11 +903,14 @@ __device__ inline bool cp_helper(const CpArgs& a, int q, int hidx, double* lds) 
 }
 
 constexpr int CP_LDS_DOUBLES = 8*CP_TILE + 64 + 64 + 64 + 8;          // + the step table of the critical workgroup behind it
-__global__ void __launch_bounds__(CP_THREADS, 2)
-k_chol_persist(CpArgs a) {
+// (two kernels, not one with a branch: the critical workgroup's loops are ~50 KB of instructions and share a 64 KB instruction cache with
+//  the helper on the neighbouring compute unit -- with both forms of the critical code in one kernel the single-chain factorisation
+//  went from 181 to 210 us)
+template <bool SEG>
+__device__ __forceinline__ void cp_persist_body(const CpArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
-  const int q = blockIdx.x % a.nsys, role = blockIdx.x / a.nsys;
-  if (role == 0) { cp_critical(a, q, cp_lds); return; }
+  const int q = blockIdx.x % a.nsys, role0 = blockIdx.x / a.nsys;
+  if (role0 < (SEG ? a.nseg : 1)) { cp_critical<SEG>(a, q, cp_lds, role0); return; }
   // Workers CLAIM the entries of the dependency-ordered helper list one after the other (round 5; round 4 dealt them statically,
   // worker w taking w, w + nworkers, ..., which only made progress if every workgroup of the launch was resident at once).  An entry
   // waits only for entries before it in the list and for the critical workgroup (blocks 0 .. nsys-1, dispatched first); entries are
@@ -915,6 +929,8 @@ k_chol_persist(CpArgs a) {
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(CP_THREADS, 2) k_chol_persist(CpArgs a) { cp_persist_body<false>(a); }
+__global__ void __launch_bounds__(CP_THREADS, 2) k_chol_persist_seg(CpArgs a) { cp_persist_body<true>(a); }      // several chains side by side (CpArgs::nseg > 1)
 
 // ---- back-substitution ----------------------------------------------------------------------------------------------------------
 __device__ inline double cp_tagged_load(const double* p) {
@@ -1119,6 +1135,7 @@ k_chol_back2(CpBackArgs a) {
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 __global__ void k_chol_persist(CpArgs a);
+__global__ void k_chol_persist_seg(CpArgs a);
 __global__ void k_chol_back2(CpBackArgs a);
 constexpr int CP_PERSIST_LDS_MAX = CP_LDS_DOUBLES*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 2)*CP_STEP_INTS*(int)sizeof(int);
 // Per device, once: the kernels' LDS attributes, how many workgroups of k_chol_persist the device holds at a time (occupancy query x
@@ -1134,6 +1151,7 @@ inline CpDevice& cp_device(int dev = -1) {
   CpDevice d;
   int nb = 0, ncu = 0, rate_khz = 100000;
   d.ok = hipFuncSetAttribute((const void*)k_chol_persist, hipFuncAttributeMaxDynamicSharedMemorySize, CP_PERSIST_LDS_MAX) == hipSuccess &&
+         hipFuncSetAttribute((const void*)k_chol_persist_seg, hipFuncAttributeMaxDynamicSharedMemorySize, CP_PERSIST_LDS_MAX) == hipSuccess &&
          hipFuncSetAttribute((const void*)k_chol_back2, hipFuncAttributeMaxDynamicSharedMemorySize, (6*CP_TILE + 700 + CH_SOLVE_MAX + 64)*(int)sizeof(double) + (CH_SOLVE_MAX/CH_NB + 4)*8*(int)sizeof(int)) == hipSuccess;
   if (d.ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_chol_persist, CP_THREADS, (size_t)CP_LDS_DOUBLES*sizeof(double) + 40*CP_STEP_INTS*sizeof(int)) == hipSuccess &&
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) { d.capacity = nb*ncu; d.ncu = ncu; }
@@ -1176,16 +1194,29 @@ struct CholPersist {
   int arena_get(size_t bytes) { arena = (char*)DevCache::get().take(bytes, &arena_bytes, &arena_dev); return arena ? 0 : -1; }
   // pattern: ntc x ntc lower-triangular tile occupancy of S (empty = dense); in_old: the tiles the assembly writes (ti << 16 | tj),
   // with the right-hand side inside block row n / 32 as ba_chol.h's plan has it
-  int build(int n_, const std::vector<unsigned char>& pattern, const std::vector<int>& old_tiles) {
+  // segs: first block column of every chain (ascending, segs[0] = 0; empty = one chain).  The caller has ordered the unknowns so that the
+  // chains before the last do not couple with each other: what couples to them from the last chain's rows are far tiles.
+  std::vector<int> seg_start;            // [nseg + 1]
+  int nseg = 1;
+  int build(int n_, const std::vector<unsigned char>& pattern, const std::vector<int>& old_tiles, const std::vector<int>& segs = std::vector<int>()) {
     release();
     n = n_; ntc = (n + CH_NB - 1)/CH_NB;
     if (ntc < 1) return 0;
     const int R = ntc, nr = ntc + 1;
+    seg_start.assign(1, 0);
+    for (size_t g = 1; g < segs.size() && (int)seg_start.size() < CP_MAX_SEG; ++g) if (segs[g] >= seg_start.back() + CP_W && segs[g] + CP_W <= ntc) seg_start.push_back(segs[g]);
+    nseg = (int)seg_start.size(); seg_start.push_back(ntc);
+    std::vector<int> seg_of(nr, nseg - 1), loc_of(nr, 0);
+    int maxlen = 0;
+    for (int g = 0; g < nseg; ++g) { for (int c = seg_start[g]; c < seg_start[g + 1]; ++c) { seg_of[c] = g; loc_of[c] = c - seg_start[g]; } if (g + 1 < nseg) maxlen = std::max(maxlen, seg_start[g + 1] - seg_start[g]); }
+    loc_of[R] = seg_start[nseg] - seg_start[nseg - 1];
+    auto in_band = [&](int i, int j) { return i - j < CP_W && seg_of[i] == seg_of[j]; };       // (a chain's own tiles: its critical workgroup keeps them)
+    auto order_key = [&](int c) { return seg_of[c] + 1 < nseg ? loc_of[c] : maxlen + loc_of[c]; };      // chains side by side: by the step inside the chain; the last chain behind them
     std::vector<unsigned char> P((size_t)nr*ntc, 0), inS((size_t)nr*ntc, 0);
     for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) P[(size_t)i*ntc + j] = pattern.empty() ? 1 : pattern[(size_t)i*ntc + j];
     for (int tp : old_tiles) { const int i = tp >> 16, j = tp & 0xffff; if (i < ntc && j < ntc) inS[(size_t)i*ntc + j] = 1; }
     if (old_tiles.empty()) for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) inS[(size_t)i*ntc + j] = 1;      // dense test matrices: S is all there
-    for (int i = 0; i < ntc; ++i) for (int j = std::max(0, i - CP_W + 1); j <= i; ++j) P[(size_t)i*ntc + j] = 1;      // the band is the critical workgroup's: always there
+    for (int i = 0; i < ntc; ++i) for (int j = std::max(0, i - CP_W + 1); j <= i; ++j) if (in_band(i, j)) P[(size_t)i*ntc + j] = 1;      // the band is the critical workgroup's: always there
     for (int j = 0; j < ntc; ++j) { P[(size_t)R*ntc + j] = 1; inS[(size_t)R*ntc + j] = 1; }
     for (int k = 0; k < ntc; ++k) {                                // symbolic fill-in
       std::vector<int> rows;
@@ -1196,25 +1227,26 @@ struct CholPersist {
     nslots = 0; nbslots = 0;
     for (int i = 0; i < nr; ++i) for (int j = 0; j < ntc && j <= i; ++j) if (P[(size_t)i*ntc + j]) {
       slot_of[(size_t)i*ntc + j] = nslots++;
-      if (i - j < CP_W) bslot_of[(size_t)i*ntc + j] = nbslots++;
+      if (in_band(i, j)) bslot_of[(size_t)i*ntc + j] = nbslots++;
     }
     // The last update of band tile (i, i-1), column m = i - 3, needs L(i-1, i-3): the critical workgroup's own tile of the step before
     // the row is taken in -- a round trip through a helper on the critical cycle.  That one product travels apart ("delta"): its own
     // helper, its own band slot and flag (index nslots + i); the critical workgroup subtracts it a step later, when it has long arrived.
     delta_of.assign(nr, -1);
-    for (int i = CP_W; i < nr; ++i) if (i - 1 < ntc && slot_of[(size_t)i*ntc + i - CP_W] >= 0 && slot_of[(size_t)(i - 1)*ntc + i - CP_W] >= 0) delta_of[i] = nbslots++;
+    for (int i = CP_W; i < nr; ++i) if (i - 1 < ntc && seg_of[i - CP_W] == seg_of[i] && slot_of[(size_t)i*ntc + i - CP_W] >= 0 && slot_of[(size_t)(i - 1)*ntc + i - CP_W] >= 0) delta_of[i] = nbslots++;
     // ... and the far tile (i, i - CP_W) hands its sum to the band tiles of its row before its own solve (CpHelper): flag index nslots + nr + i
     std::vector<int> pre_of(nr, -1);
-    for (int i = CP_W; i < nr; ++i) if (slot_of[(size_t)i*ntc + i - CP_W] >= 0) pre_of[i] = nbslots++;
+    for (int i = CP_W; i < nr; ++i) if (seg_of[i - CP_W] == seg_of[i] && slot_of[(size_t)i*ntc + i - CP_W] >= 0) pre_of[i] = nbslots++;
     nflags = nslots + 2*nr;
     // helpers, in the order of the column that completes them: far tile (i, j) -> j; band tile (i, j) -> i - CP_W; delta of row i -> i - CP_W
     struct Key { int key, kind, i, j; };
     std::vector<Key> ks;
     for (int i = 0; i < nr; ++i) for (int j = 0; j < ntc && j <= i; ++j) if (P[(size_t)i*ntc + j]) {
-      const bool band = i - j < CP_W;
-      ks.push_back({band ? i - CP_W : j, band ? 1 : 0, i, j});
+      const bool band = in_band(i, j);
+      // (a band tile is complete when column i - CP_W is; at the head of a chain that is before the chain starts: with the last of the other chains' columns)
+      ks.push_back({band ? (nseg == 1 ? i - CP_W : std::max(order_key(i) - CP_W, seg_of[i] + 1 < nseg ? -CP_W : maxlen)) : order_key(j), band ? 1 : 0, i, j});
     }
-    for (int i = 0; i < nr; ++i) if (delta_of[i] >= 0) ks.push_back({i - CP_W, 2, i, i - 1});
+    for (int i = 0; i < nr; ++i) if (delta_of[i] >= 0) ks.push_back({order_key(i) - CP_W, 2, i, i - 1});
     std::stable_sort(ks.begin(), ks.end(), [](const Key& x, const Key& y) { if (x.key != y.key) return x.key < y.key; if (x.kind != y.kind) return x.kind < y.kind; return x.i < y.i; });
     helpers.clear(); upd.clear();
     for (const Key& k : ks) {
@@ -1227,11 +1259,14 @@ struct CholPersist {
         h.kind = k.kind; h.slot = slot_of[(size_t)k.i*ntc + k.j];
         h.dslot = k.kind ? bslot_of[(size_t)k.i*ntc + k.j] : slot_of[(size_t)k.j*ntc + k.j];
         h.in_s = inS[(size_t)k.i*ntc + k.j];
-        int mlast = k.kind ? std::min(k.j - 1, k.i - CP_W) : k.j - 1;
-        if (k.kind == 1 && k.j == k.i - 1 && delta_of[k.i] >= 0) mlast = std::min(mlast, k.i - CP_W - 1);
-        for (int m = 0; m <= mlast; ++m) {
+        // the columns this helper applies: all before j -- but for a band tile not the ones its chain's critical workgroup applies itself
+        // (its own columns i - 2, i - 1), and not the one that travels as the row's late product
+        int mlast = -1;
+        for (int m = 0; m < k.j; ++m) {
+          if (k.kind == 1 && m > k.i - CP_W && seg_of[m] == seg_of[k.i]) continue;
+          if (k.kind == 1 && k.j == k.i - 1 && delta_of[k.i] >= 0 && m == k.i - CP_W) continue;
           const int sa = slot_of[(size_t)k.i*ntc + m], sb = slot_of[(size_t)k.j*ntc + m];
-          if (sa >= 0 && sb >= 0) upd.push_back(make_int2(sa, sb));
+          if (sa >= 0 && sb >= 0) { upd.push_back(make_int2(sa, sb)); mlast = m; }
         }
         const int mw = k.i - CP_W;          // the column whose far tile of this row feeds the row's band tiles
         if (k.kind == 0 && k.j == mw && pre_of[k.i] >= 0) { h.pre = pre_of[k.i]; h.pre_flag = nslots + nr + k.i; }
@@ -1314,7 +1349,7 @@ struct CholPersist {
       // frames, the speculative stream -- finds room; a second handle's factorisation shares the workers' slots and both go on)
       const CpDevice& dv = cp_device();
       if (!dv.ok || dv.disabled || dv.capacity < 2*max_sys) { release(); return 0; }       // (no one-launch plan on this device: ok stays false, the per-step kernels run)
-      nworkers = std::max(1, std::min(nworkers, (dv.capacity - dv.capacity/8)/max_sys - 1));
+      nworkers = std::max(1, std::min(nworkers, (dv.capacity - dv.capacity/8)/max_sys - nseg));
     }
     { const char* e = getenv("MCP_BA_CHOL_SPREAD"); spread = !(e && atoi(e) == 0) && !getenv("MCP_BA_CHOL_WORKERS"); }
     { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
@@ -1329,6 +1364,7 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   if (!cp_device().ok) return -1;          // (attributes, capacity and deadline of this device: set once)
   CpArgs a;
   a.S = S + q0*sys_stride; a.sys_stride = sys_stride; a.n = P.n; a.ntc = P.ntc; a.nsys = nsys; a.nhelpers = P.nhelpers; a.nworkers = P.nworkers;
+  a.nseg = P.nseg; for (int g = 0; g <= CP_MAX_SEG; ++g) a.seg_start[g] = g < (int)P.seg_start.size() ? P.seg_start[g] : P.ntc;
   a.slot_of = P.d_slot_of; a.bslot_of = P.d_bslot_of; a.delta_of = P.d_delta_of; a.steps = P.d_steps; a.helpers = P.d_helpers; a.upd = P.d_upd;
   a.Lt = P.d_Lt + q0*P.lt_stride; a.lt_stride = P.lt_stride; a.Bt = P.d_Bt + q0*P.bt_stride; a.bt_stride = P.bt_stride;
   a.flags = P.d_flags + (size_t)q0*P.nflags; a.nslots = P.nslots; a.nflags = P.nflags; a.err = P.d_err + q0; a.fail = fail + q0;
@@ -1342,10 +1378,11 @@ inline int chol_persist_factor(hipStream_t st, CholPersist& P, const double* S, 
   {
     const CpDevice& dv = cp_device();
     const int batch = std::max(P.batch_sys, nsys);
-    if (P.spread && batch > 2 && dv.ncu > 0) a.nworkers = std::max(1, std::min(P.nworkers, std::max(8, (dv.ncu - dv.ncu/8)/batch - 1)));
+    if (P.spread && batch > 2 && dv.ncu > 0) a.nworkers = std::max(1, std::min(P.nworkers, std::max(8, (dv.ncu - dv.ncu/8)/batch - P.nseg)));
   }
   (void)hipGetLastError();          // (a leftover of an earlier, unrelated runtime call -- a stream query's hipErrorNotReady -- is not this launch's refusal)
-  hipLaunchKernelGGL(k_chol_persist, dim3((1 + a.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
+  if (a.nseg > 1) hipLaunchKernelGGL(k_chol_persist_seg, dim3((a.nseg + a.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
+  else hipLaunchKernelGGL(k_chol_persist, dim3((1 + a.nworkers)*nsys), dim3(CP_THREADS), CP_LDS_DOUBLES*sizeof(double) + (size_t)(P.ntc + 1)*CP_STEP_INTS*sizeof(int), st, a);
   { const hipError_t e = hipGetLastError(); return (e == hipSuccess || e == hipErrorNotReady) ? 0 : -1; }       // (a launch the runtime refuses -- its LDS or grid does not fit this device -- is reported here, by name, not at the end of the solve)
 }
 // the second launch: x = L^-T y into row n of S (xout = S + n n)

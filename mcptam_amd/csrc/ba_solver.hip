@@ -3697,6 +3697,15 @@ int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, i
     const int ntc = (n + CH_NB - 1)/CH_NB;
     pattern.assign((size_t)ntc*ntc, 0);
     for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (i - j <= band || i >= ntc - band) pattern[(size_t)i*ntc + j] = 1;
+  } else if (band < 0) {
+    // a band of -band tiles DISSECTED: the caller's matrix is a banded one with its block rows / columns ordered
+    // [left half ascending | right half descending | the -band blocks between them] (scripts/gpu_chol2.py dissect()): two chains + a border
+    const int b = -band, ntc = (n + CH_NB - 1)/CH_NB, h = (ntc - b)/2;
+    if (n % CH_NB || h < 3 || ntc - b - h < 3) { set_err("mcp_chol_time: a dissected band needs whole tiles and halves of at least three"); return -1; }
+    auto orig = [&](int i) { return i < h ? i : (i < ntc - b ? (ntc - 1) - (i - h) : h + (i - (ntc - b))); };
+    pattern.assign((size_t)ntc*ntc, 0);
+    for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (std::abs(orig(i) - orig(j)) <= b) pattern[(size_t)i*ntc + j] = 1;
+    plan.persist_segs = {0, h, ntc - b};
   }
   if (plan.build(n, pattern)) { set_err("mcp_chol_time: plan allocation failed"); return -1; }
   std::vector<hipEvent_t> ev((size_t)3*reps);

@@ -23,6 +23,26 @@ def spd(n, seed=0, band=0):
     return A, rng.normal(size=n)
 
 
+def dissect(n, b=6, seed=0):
+    """A pure band of b tiles (n a multiple of 32), block rows / columns re-ordered [left half ascending | right half DEscending |
+    the b blocks between them]: two independent chains and a border (what mcp_chol_time's band = -b plan expects)."""
+    assert n % 32 == 0
+    ntc = n // 32
+    rng = np.random.default_rng(seed + n)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T
+    for i in range(ntc):
+        for j in range(ntc):
+            if abs(i - j) > b:
+                A[32 * i:32 * i + 32, 32 * j:32 * j + 32] = 0.0
+    A += 5 * n * np.eye(n)
+    h = (ntc - b) // 2
+    # original order: [left 0..h-1][separator h..h+b-1][right h+b..ntc-1]
+    order = list(range(h)) + list(range(ntc - 1, h + b - 1, -1)) + list(range(h, h + b))
+    idx = np.concatenate([np.arange(32 * o, 32 * o + 32) for o in order])
+    return A[np.ix_(idx, idx)], rng.normal(size=n)
+
+
 def check_factor(n):
     A, b = spd(n)
     L, y, err, fail = cb.chol_debug_factor(np.tril(A), b)
@@ -77,3 +97,13 @@ if __name__ == "__main__":
             print("time n=%d nsys=%d band=%d: factor %.1f us  back %.1f us  (rel err %.1e)  persist=%s" % (n, nsys, band, tf * 1e3, tb * 1e3, e, os.environ.get("MCP_BA_CHOL_PERSIST", "1")), flush=True)
         except Exception as exc:
             print("time n=%d nsys=%d band=%d: %r" % (n, nsys, band, exc), flush=True)
+    for n, nsys, b in ((1216, 1, 6), (1216, 4, 6), (3008, 1, 6)):
+        A, rhs = dissect(n, b)
+        A0, rhs0 = spd(n, band=b)
+        try:
+            tf, tb, x = cb.chol_time(np.tril(A), rhs, nsys=nsys, reps=30, band=-b)
+            e = max(np.abs(x[q] - np.linalg.solve(A + q * np.eye(n), rhs)).max() / np.abs(x[q]).max() for q in range(nsys))
+            tf0, tb0, _ = cb.chol_time(np.tril(A0), rhs0, nsys=nsys, reps=30, band=b)
+            print("dissected n=%d nsys=%d band=%d: factor %.1f us  back %.1f us  (rel err %.1e)   | one chain (banded + bordered): factor %.1f us  back %.1f us" % (n, nsys, b, tf * 1e3, tb * 1e3, e, tf0 * 1e3, tb0 * 1e3), flush=True)
+        except Exception as exc:
+            print("dissected n=%d nsys=%d band=%d: %r" % (n, nsys, b, exc), flush=True)
