@@ -102,6 +102,9 @@ typedef struct mcp_ba_timing {
    * 2 x 32^3, a triangular solve 32^3, a diagonal tile's factorisation + inverse 2/3 x 32^3); the dense (6P)^3 / 3 of SURVEY 8(d) is
    * the upper bound a banded trajectory stays well below (0 if no plan was built) */
   double chol_flops_plan;
+  /* chains of block columns the one-launch factorisation walks beside each other (1: the poses in add order; 3: a trajectory's band cut into
+   * two halves + the separator between them; 0 if no plan was built) */
+  int    chol_chains;
 } mcp_ba_timing;
 
 const char* mcp_last_error(void);

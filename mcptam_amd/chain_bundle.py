@@ -45,7 +45,7 @@ class McpBaTiming(ctypes.Structure):
                 ("collective_bytes_main", ctypes.c_double), ("collective_bytes_spec", ctypes.c_double),
                 ("n_median_fast", ctypes.c_int), ("n_persist_fallbacks", ctypes.c_int),
                 ("schur_mfma_per_system", ctypes.c_double), ("schur_flops_structural", ctypes.c_double),
-                ("chol_flops_plan", ctypes.c_double)]
+                ("chol_flops_plan", ctypes.c_double), ("chol_chains", ctypes.c_int)]
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)

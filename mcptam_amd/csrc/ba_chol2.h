@@ -1205,6 +1205,15 @@ struct CholPersist {
     const int R = ntc, nr = ntc + 1;
     seg_start.assign(1, 0);
     for (size_t g = 1; g < segs.size() && (int)seg_start.size() < CP_MAX_SEG; ++g) if (segs[g] >= seg_start.back() + CP_W && segs[g] + CP_W <= ntc) seg_start.push_back(segs[g]);
+    // (the promise checked: a tile between two chains before the last would make a band tile of the later chain wait for a far tile that
+    //  is behind it in the helpers' order -- such a plan is built as one chain, correct whatever the order of the unknowns)
+    if (seg_start.size() > 1 && !pattern.empty()) {
+      const int last0 = seg_start.back();
+      auto chain_of = [&](int c) { int g = 0; while (g + 1 < (int)seg_start.size() && seg_start[g + 1] <= c) ++g; return g; };
+      bool coupled = false;
+      for (int i = 0; i < last0 && !coupled; ++i) for (int j = 0; j < i; ++j) if (pattern[(size_t)i*ntc + j] && chain_of(i) != chain_of(j)) { coupled = true; break; }
+      if (coupled) seg_start.assign(1, 0);
+    }
     nseg = (int)seg_start.size(); seg_start.push_back(ntc);
     std::vector<int> seg_of(nr, nseg - 1), loc_of(nr, 0);
     int maxlen = 0;

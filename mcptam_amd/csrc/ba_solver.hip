@@ -365,6 +365,7 @@ struct StructEntry {
   StructKey key;
   std::vector<int> pose_unk, pt_unk, fp_pose, fl_point, perm;
   std::vector<unsigned char> pose_active, pt_active, pat;
+  std::vector<int> chol_segs;
   int nfp = 0, nfl = 0, np = 0, nx = 0, nsp = 0, ninc = 0, nslot = 0, ngroup = 0, nbig = 0, grp_pts = 0, grp_blk_max = 0, grp_inc_max = 0, nrhs_rows = 0;
   size_t nstage = 0; bool asm_long = false, sch4_ok = false, sch4_order = false;
   double m_total = 0, nfl_total = 0, schur_mfma = 0, schur_flops = 0;
@@ -685,6 +686,8 @@ struct mcp_ba {
   // The step of a trial in one launch (ba_small.h k_trial_apply): chain workgroups of that launch, 0 = the separate kernels (a map with
   // more poses than a chain workgroup keeps in LDS; MCP_BA_TRIAL_FUSE=0).  Small bundles: one workgroup for all chains, as before.
   int trial_fuse = 1;
+  int dissect_on = 1;                // MCP_BA_CHOL_CHAINS=1: one chain (the poses in add order), see prepare()
+  std::vector<int> chol_segs;        // first tile of every chain of the factorisation plan (empty: one)
   int trial_chain_blocks() const {
     if (P.npose > TA_MAX_POSES) return 0;
     if (small_mode()) return 1;
@@ -983,6 +986,7 @@ int mcp_ba::prepare() {
   lap("  entry");
   // ---- the same topology as an earlier call's (structure cache, above)?  128-bit hash over what the structure is built from
   cache_insert = false;
+  { const char* e = getenv("MCP_BA_CHOL_CHAINS"); dissect_on = !(e && atoi(e) == 1); }
   if (StructCache::get().enabled() && !multi() && nmeas > 0) {
     constexpr size_t HB = 8192;
     const size_t nbm = ((size_t)nmeas + HB - 1)/HB;
@@ -1006,7 +1010,8 @@ int mcp_ba::prepare() {
     // (what else decides the structure: the grouping policy and its run-time switches)
     const char* e_al = getenv("MCP_BA_ASM_LONG");
     key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
-                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16);
+                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16) | (dissect_on ? 1 << 18 : 0);
+    { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) key.flags ^= (unsigned)(atoi(e) & 0xff) << 19; }
     cache_key = key;
     {
       // the same key without the measurements (near miss, below)
@@ -1063,7 +1068,8 @@ int mcp_ba::prepare() {
       std::unique_lock<std::mutex> arena_lock(pinned_arena().mutex());
       ArenaGuard arena_guard{st};
       HostStruct H;
-      last_pat = hit->pat;
+      last_pat = hit->pat; chol_segs = hit->chol_segs;
+      plan.persist_segs = chol_segs;
       if (np > 0) { if (plan.build(np, last_pat)) { set_err("Cholesky plan allocation failed"); return -1; } }
       else plan.all_tiles.clear();
       lap(n_masked ? "  adopted (near miss)" : "  adopted (cache hit)");
@@ -1087,12 +1093,36 @@ int mcp_ba::prepare() {
   SMeas* const sorted = scratch.take<SMeas>(std::max(nmeas, 1));
   std::vector<int> ckey;
   if (refine) { ckey.resize(nch); for (size_t c = 0; c < nch; ++c) ckey[c] = chain_first_movable(chains[c], poses) + 1; }
+  // (for the chains of the factorisation, below: how far -- in poses of the add order, straight and round the ring -- an observer is from
+  //  the pose its point is expressed in, at most.  A chain with one movable pose is that pose here; the others go pair by pair.)
+  const bool want_reach = dissect_on && !multi() && npose >= 96;
+  std::vector<int> reach_t((size_t)T*2, 0), cpose, pchain;
+  if (want_reach) {
+    cpose.resize(nch); pchain.resize(std::max(npoint, 1));
+    for (size_t c = 0; c < nch; ++c) { int one = -1, nmov = 0; for (int k = 0; k < chains[c].len; ++k) if (!poses[chains[c].v[k]].fixed) { one = chains[c].v[k]; ++nmov; } cpose[c] = nmov == 1 ? one : nmov ? -2 : -1; }
+    for (int i = 0; i < npoint; ++i) pchain[i] = points[i].chain;
+  }
   {
     std::vector<unsigned char> cu_all((size_t)T*nch, 0);
     par([&](int tid) {
       unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t + (size_t)tid*npoint;
       std::memset(ct, 0, sizeof(int)*(size_t)npoint);
       const int* mc = meas_chain.data(); const int* mp = meas_point.data();
+      if (want_reach) {
+        int dl = 0, dc = 0;
+        const int* cp = cpose.data(); const int* pc = pchain.data();
+        for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
+          const int o = cp[mc[i]], s2 = cp[pc[mp[i]]];
+          if (o >= 0 && s2 >= 0) { const int d = std::abs(o - s2); dl = std::max(dl, d); dc = std::max(dc, std::min(d, npose - d)); }
+          else if (o != -1 && s2 != -1) {
+            const HChain& oc = chains[mc[i]]; const HChain& sc = chains[pc[mp[i]]];
+            for (int k = 0; k < oc.len; ++k) { if (poses[oc.v[k]].fixed) continue;
+              for (int l = 0; l < sc.len; ++l) { if (poses[sc.v[l]].fixed) continue;
+                const int d = std::abs(oc.v[k] - sc.v[l]); dl = std::max(dl, d); dc = std::max(dc, std::min(d, npose - d)); } }
+          }
+        }
+        reach_t[2*tid] = dl; reach_t[2*tid + 1] = dc;
+      }
       if (!refine) { for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; } return; }
       int* mx = sig_t + (size_t)2*tid*npoint; int* sm = mx + npoint;
       std::memset(mx, 0, sizeof(int)*(size_t)2*npoint);
@@ -1141,6 +1171,43 @@ int mcp_ba::prepare() {
   }
   fp_pose.clear(); fl_point.clear();
   for (int i = 0; i < npose; ++i) if (poses[i].active && !poses[i].fixed) { poses[i].unk = (int)fp_pose.size(); fp_pose.push_back(i); }
+  chol_segs.clear();
+  if (want_reach && (int)fp_pose.size() >= 96) {
+    // ---- several chains instead of one (round 6).  The reduced system of a trajectory is a band -- a pose couples with the
+    // poses that see a point it sees, a window of +- w around it in add order -- closed to a ring when the trajectory returns to its start.
+    // A band ordered [left half ascending | right half DEscending | the w poses between them] is two independent bands with a border on
+    // their LAST columns (no extra fill); a ring needs a second separator where it closes, [arc ascending | other arc descending | middle
+    // separator | closing separator], whose rows fill across the arcs as the closing rows of the add order do.  The one-launch factorisation
+    // then walks the halves with a critical workgroup each: ~(P/2 + separators) dependent block columns instead of P.
+    // w from the data: twice the farthest (observer, source pose) pair of any measurement -- two observers of a point are each within that
+    // distance of its source pose -- straight and round the ring, taken in the counting pass above in poses of the add order (fixed and unused
+    // poses included: an upper bound of the distance in unknowns).  The plan checks the promise (CholPersist::build: chains that couple
+    // after all are factorised as one).  Not worth it (halves under three tiles): add order, one chain.
+    const int nf = (int)fp_pose.size();
+    int dl = 0, dc = 0; for (int t = 0; t < T; ++t) { dl = std::max(dl, reach_t[2*t]); dc = std::max(dc, reach_t[2*t + 1]); }
+    dl = std::min(dl, nf); dc = std::min(dc, nf);
+    const bool ring = dc < dl;
+    const int w = 2*(ring ? dc : dl) + 1;
+    // a band: [0, m) | [m + w, nf) descending | [m, m + w).  a ring: [w, m) | [m + w, nf) descending | [m, m + w) | [0, w).  The first arc's
+    // length a multiple of 16 poses (6 x 16 unknowns = 3 tiles: the second starts on a tile boundary); a tile straddling the end of the second is the last chain's.
+    const int head = ring ? w : 0;
+    const int len1 = (((nf - head - w)/2 + 8)/16)*16, m = head + len1, len2 = nf - m - w;
+    const int t1 = 6*len1/CH_NB, t2 = 6*(len1 + len2)/CH_NB, t_all = (6*nf + CH_NB - 1)/CH_NB;
+    if (w > 1 && len1 >= 16 && len2 >= 16 && t2 - t1 >= 3 && t_all - t2 >= 1) {
+      std::vector<int> order; order.reserve(nf);
+      for (int u = head; u < m; ++u) order.push_back(fp_pose[u]);
+      for (int u = nf - 1; u >= m + w; --u) order.push_back(fp_pose[u]);
+      for (int u = m; u < m + w; ++u) order.push_back(fp_pose[u]);
+      for (int u = 0; u < head; ++u) order.push_back(fp_pose[u]);
+      fp_pose.swap(order);
+      for (int u = 0; u < nf; ++u) poses[fp_pose[u]].unk = u;
+      chol_segs = {0, t1, t2};
+      { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, t1 - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
+    }
+    if (trace) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses, farthest observer %d poses (%d round the ring) -> %s, separators of %d; tiles %d | %d | %d -> %s\n", nf, dl, dc, ring ? "a ring" : "a band", w,
+                       t1, t2 - t1, t_all - t2, chol_segs.empty() ? "one chain" : "two chains + the separators'");
+    lap("  pose order (chains)");
+  }
   for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
   nfp = (int)fp_pose.size(); nfl = (int)fl_point.size(); np = 6*nfp; nx = np + 3*nfl;
   if (np > CH_SOLVE_MAX) { set_err("too many free poses for the dense reduced solve (6P > 6144)"); return -1; }
@@ -1391,7 +1458,14 @@ int mcp_ba::prepare() {
       if (d_red_tiles.upload(rt, st) || d_pack.alloc(MAX_SYS*((size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np))) return -1;
       pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
     }
+    if (trace) {
+      std::string hs; std::vector<int> hd(ntc, 0); int tot = 0;
+      for (int i = 0; i < ntc; ++i) for (int j = 0; j <= i; ++j) if (pat[(size_t)i*ntc + j]) { ++hd[i - j]; ++tot; }
+      for (int d = 0; d < ntc; ++d) { char b[16]; snprintf(b, sizeof b, " %d", hd[d]); hs += b; }
+      fprintf(stderr, "[mcp_ba prepare]   tile pattern before fill-in: %d of %d lower tiles; by distance from the diagonal:%s\n", tot, ntc*(ntc + 1)/2, hs.c_str());
+    }
     lap("  covisibility");
+    plan.persist_segs = chol_segs;
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
     last_pat = std::move(pat);
     lap("  symbolic plan");
@@ -1728,6 +1802,7 @@ int mcp_ba::prepare_legacy() {
       pack_stride = (size_t)n_red_tiles*CH_NB*CH_NB + 2*(size_t)np;
     }
     lap("  covisibility");
+    chol_segs.clear(); plan.persist_segs.clear();      // (the serial builder keeps the poses in add order: one chain)
     if (plan.build(np, pat)) { set_err("Cholesky plan allocation failed"); return -1; }
     lap("  symbolic plan");
   } else plan.all_tiles.clear();
@@ -1988,7 +2063,7 @@ int mcp_ba::finish_prepare(HostStruct& H, std::chrono::steady_clock::time_point 
       e->pose_unk.resize(npose); e->pose_active.resize(npose); e->pt_unk.resize(npoint); e->pt_active.resize(npoint);
       for (int i = 0; i < npose; ++i) { e->pose_unk[i] = poses[i].unk; e->pose_active[i] = (unsigned char)poses[i].active; }
       for (int i = 0; i < npoint; ++i) { e->pt_unk[i] = points[i].unk; e->pt_active[i] = (unsigned char)points[i].active; }
-      e->fp_pose = fp_pose; e->fl_point = fl_point; e->perm = perm; e->pat = last_pat;
+      e->fp_pose = fp_pose; e->fl_point = fl_point; e->perm = perm; e->pat = last_pat; e->chol_segs = chol_segs;
       e->nfp = nfp; e->nfl = nfl; e->np = np; e->nx = nx; e->nsp = nsp; e->ninc = ninc; e->nslot = nslot; e->ngroup = ngroup; e->nbig = nbig;
       e->grp_pts = grp_pts; e->grp_blk_max = grp_blk_max; e->grp_inc_max = grp_inc_max; e->nrhs_rows = nrhs_rows; e->nstage = nstage;
       e->asm_long = asm_long; e->sch4_ok = sch4_ok; e->sch4_order = sch4_order; e->m_total = m_total; e->nfl_total = nfl_total;
@@ -2830,6 +2905,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
   if (dirty) { if (prepare()) return MCP_ERR_RUNTIME; }
   timing.schur_mfma_per_system = schur_mfma; timing.schur_flops_structural = schur_flops;
   timing.chol_flops_plan = (np > 0 && plan.persist.ok) ? plan.persist.flops : 0.0;
+  timing.chol_chains = (np > 0 && plan.persist.ok) ? plan.persist.nseg : 0;
   converged = 0; total_iterations = 0; spec_hot = 0;
   int nCounter = 0;
   // emptiness is decided on the GLOBAL totals: a rank whose shard holds no measurement (or no free point) still runs every

@@ -387,6 +387,12 @@ CONFIGS = {
     "metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi"),
     "c4": dict(n_cams=4, n_mkf=500, n_points=100000, per_point=8, mode="multi"),
     "tiny": dict(n_cams=2, n_mkf=6, n_points=60, per_point=4, mode="multi", arc_step=0.4),
+    # not BASELINE configurations: trajectories whose poses see the points of their neighbours only -- a banded reduced system (an open arc)
+    # and a cyclic band (a loop walked once) -- the maps the factorisation takes as two chains; `band_metric`: at the headline's sizes
+    "band": dict(n_cams=2, n_mkf=130, n_points=6000, per_point=4, mode="multi", radius=120.0, arc_step=2.0, k_near=5),
+    "ring": dict(n_cams=2, n_mkf=130, n_points=6000, per_point=4, mode="multi", radius=41.0, k_near=5),
+    "band_metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi", radius=400.0, arc_step=4.0, k_near=6),
+    "ring_metric": dict(n_cams=4, n_mkf=200, n_points=50000, per_point=8, mode="multi", radius=130.0, k_near=6),
 }
 
 

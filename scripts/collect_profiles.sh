@@ -14,5 +14,6 @@ ls -la profiles/$ROUND
 [ -f gpurun_out/trk_trace.txt ] && cp gpurun_out/trk_trace.txt profiles/$ROUND/tracker_c3_frame_timeline.txt
 [ -f gpurun_out/window_kernel_stats.csv ] && cp gpurun_out/window_kernel_stats.csv profiles/$ROUND/window_kernel_stats.csv
 [ -f gpurun_out/c4_kernel_stats.csv ] && cp gpurun_out/c4_kernel_stats.csv profiles/$ROUND/c4_kernel_stats.csv
+[ -s gpurun_out/band_bench.json ] && cp gpurun_out/band_bench.json profiles/$ROUND/band_bench.json
 [ -f gpurun_out/window.json ] && cp gpurun_out/window.json profiles/$ROUND/window_bench.json
 true

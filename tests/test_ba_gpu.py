@@ -1010,6 +1010,7 @@ def test_threaded_prepare_builds_the_serial_structure(gpu_required, cfg, iters, 
     the serial reference implementation stays behind MCP_BA_PREPARE_LEGACY=1.  Same arrays => the same solve, bit for bit:
     reduced system, iteration logs, poses, points, outlier list."""
     from mcptam_amd import synth
+    monkeypatch.setenv("MCP_BA_CHOL_CHAINS", "1")      # (the serial builder keeps the free poses in add order; the threaded one re-orders a long trajectory for two chains)
     p = synth.make_config(cfg)
     g = _gpu(p.cams, disable_convergence=True)
     p.populate(g)
@@ -1044,7 +1045,7 @@ def test_a_refused_launch_is_reported_by_kernel_name(gpu_required, monkeypatch):
     assert r["rc"] == 2
 
 
-@pytest.mark.parametrize("cfg,iters", [("c1", 6), ("c2", 6), ("metric", 5)])
+@pytest.mark.parametrize("cfg,iters", [("c1", 6), ("c2", 6), ("metric", 5), ("band", 6), ("ring", 6)])
 def test_a_map_that_lost_its_outliers_adopts_the_cached_structure_of_the_call_before(gpu_required, cfg, iters, monkeypatch):
     """Near miss (include/mcp_ba.h): MCPTAM erases the measurements an adjustment flagged (MapMakerServerBase::HandleOutliers,
     /root/reference/src/MapMakerServerBase.cc:1198-1238) and adjusts again -- same poses, points, chains, the measurements minus a few.
@@ -1057,6 +1058,11 @@ def test_a_map_that_lost_its_outliers_adopts_the_cached_structure_of_the_call_be
     chain_bundle.struct_cache_clear()
     first = run_bundle(_gpu(p.cams, disable_convergence=True), p, iters)
     assert len(first["outliers"]) > 0
+    # (a point all of whose measurements were flagged keeps them here: a map that lost a point is built cold, see the end of this test)
+    from collections import Counter
+    flagged = Counter(o[0] for o in first["outliers"])
+    per_point = p.n_meas // p.n_points
+    first["outliers"] = [o for o in first["outliers"] if flagged[o[0]] < per_point]
     q = synth.erase_measurements(p, first["outliers"], first["ids"])
     assert q.n_meas == p.n_meas - len(first["outliers"])
     n0 = chain_bundle.struct_cache_near_hits()
@@ -1095,7 +1101,7 @@ def test_a_map_that_lost_its_outliers_adopts_the_cached_structure_of_the_call_be
     assert lone["rc"] == 2 and chain_bundle.struct_cache_near_hits() == n1
 
 
-@pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 6), ("calib", 6), ("c2", 5), ("metric", 4)])
+@pytest.mark.parametrize("cfg,iters", [("tiny", 6), ("c1", 6), ("calib", 6), ("c2", 5), ("metric", 4), ("band", 5)])
 def test_cached_prepare_equals_a_cold_one(gpu_required, cfg, iters):
     """Structure cache (include/mcp_ba.h): a handle that brings the topology of an earlier Prepare() adopts that structure (host
     results + a device clone of the packed block) and uploads only its numbers.  The reduced system, iteration logs, poses, points and
@@ -1305,3 +1311,38 @@ def test_bench_spawns_its_own_ranks(gpu_required):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
     assert "5000 points, 40000 measurements per rank" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("shape", ["arc", "ring", "chains_that_couple"])
+def test_a_trajectory_band_is_factorised_as_two_chains(gpu_required, shape, monkeypatch):
+    """A trajectory whose poses see only points of their neighbours -- an open arc, or a loop walked once -- has a banded (cyclic-banded)
+    reduced system: prepare() orders its poses [one half | the other half, reversed | the poses between them (| where the ring closes)]
+    and the one-launch factorisation walks the two halves beside each other (CholPersist::build, k_chol_persist_seg).  Another elimination
+    order: the iteration agrees with the one-chain order's to rounding, not bit for bit -- same accept / reject sequence, state to 1e-8 --
+    and with the oracle's as every map does; each order is bit-reproducible.  A cut in the wrong place (forced here: the last two
+    tiles of the first half handed to the second) breaks the promise the plan was given -- chains that do not couple: it must notice and
+    build one chain, not hang or return another answer."""
+    from mcptam_amd import synth
+    p = synth.make_config("ring" if shape == "ring" else "band")
+    if shape == "chains_that_couple":
+        monkeypatch.setenv("MCP_BA_TEST_CHOL_CUT", "2")
+    b = _gpu(p.cams, disable_convergence=True)
+    two = run_bundle(b, p, 8)
+    assert b.Timing()["chol_chains"] == (1 if shape == "chains_that_couple" else 3)
+    two_again = run_bundle(_gpu(p.cams, disable_convergence=True), p, 8)
+    assert two["logs"] == two_again["logs"] and np.array_equal(two["X"], two_again["X"]) and np.array_equal(two["t"], two_again["t"])
+    monkeypatch.setenv("MCP_BA_CHOL_CHAINS", "1")
+    b1 = _gpu(p.cams, disable_convergence=True)
+    one = run_bundle(b1, p, 8)
+    assert b1.Timing()["chol_chains"] == 1
+    assert [(l["trials"], l["accepted"]) for l in two["logs"]] == [(l["trials"], l["accepted"]) for l in one["logs"]]
+    errs = (rel_err_elem(two["R"], one["R"]), rel_err_elem(two["t"], one["t"]), rel_err_elem(two["X"], one["X"]))
+    assert max(errs) < 1e-8, errs
+    assert two["outliers"] == one["outliers"]
+    o = _orc(p.cams)
+    o.DisableConvergence(True)
+    ref = run_bundle(o, p, 8)
+    rep = compare_runs(two, ref)
+    assert rep["branch_flips"] == 0
+    assert two["outliers"] == ref["outliers"]
+    assert abs(two["sigma_sq"] - ref["sigma_sq"]) <= 1e-9 * ref["sigma_sq"]
