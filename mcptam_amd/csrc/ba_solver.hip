@@ -1087,41 +1087,38 @@ int mcp_ba::prepare() {
   //  refine_point_order -- in the same private way: a first version added them up with atomics on shared arrays, 6 ms of cache-line
   //  ping-pong between the threads)
   const bool refine = point_order_refine;
-  scratch.reset(sizeof(int)*(size_t)(refine ? 3 : 1)*T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + 256);
+  // (for the chains of the factorisation, below: per point the poses that see it, as a 64-bit window per thread -- the adapters add the
+  //  measurements KeyFrame by KeyFrame, so a thread's range of the add order holds few observers, close together in pose index; a range
+  //  that does not fit the window is reported and the masks are taken again with atomics)
+  const bool want_graph = dissect_on && !multi() && npose >= 96 && npose <= 1024 + 64;
+  typedef unsigned long long u64;
+  scratch.reset(sizeof(int)*(size_t)(refine ? 3 : 1)*T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + (want_graph ? sizeof(u64)*(size_t)T*std::max(npoint, 1) : 0) + 512);
+  u64* const seen_t = want_graph ? scratch.take<u64>((size_t)T*std::max(npoint, 1)) : nullptr;
+  std::vector<int> seen_base(T, -1), cobs; std::vector<unsigned char> seen_over(T, 0);
+  if (want_graph) { cobs.resize(nch); for (size_t c = 0; c < nch; ++c) { int one = -1, nmov = 0; for (int k = 0; k < chains[c].len; ++k) if (!poses[chains[c].v[k]].fixed) { one = chains[c].v[k]; ++nmov; } cobs[c] = nmov == 1 ? one : nmov ? -2 : -1; } }
   int* const cnt_t = scratch.take<int>((size_t)T*std::max(npoint, 1));
   int* const sig_t = refine ? scratch.take<int>((size_t)2*T*std::max(npoint, 1)) : nullptr;      // [thread][max | sum][point]
   SMeas* const sorted = scratch.take<SMeas>(std::max(nmeas, 1));
   std::vector<int> ckey;
   if (refine) { ckey.resize(nch); for (size_t c = 0; c < nch; ++c) ckey[c] = chain_first_movable(chains[c], poses) + 1; }
-  // (for the chains of the factorisation, below: how far -- in poses of the add order, straight and round the ring -- an observer is from
-  //  the pose its point is expressed in, at most.  A chain with one movable pose is that pose here; the others go pair by pair.)
-  const bool want_reach = dissect_on && !multi() && npose >= 96;
-  std::vector<int> reach_t((size_t)T*2, 0), cpose, pchain;
-  if (want_reach) {
-    cpose.resize(nch); pchain.resize(std::max(npoint, 1));
-    for (size_t c = 0; c < nch; ++c) { int one = -1, nmov = 0; for (int k = 0; k < chains[c].len; ++k) if (!poses[chains[c].v[k]].fixed) { one = chains[c].v[k]; ++nmov; } cpose[c] = nmov == 1 ? one : nmov ? -2 : -1; }
-    for (int i = 0; i < npoint; ++i) pchain[i] = points[i].chain;
-  }
   {
     std::vector<unsigned char> cu_all((size_t)T*nch, 0);
     par([&](int tid) {
       unsigned char* cu = cu_all.data() + (size_t)tid*nch; int* ct = cnt_t + (size_t)tid*npoint;
       std::memset(ct, 0, sizeof(int)*(size_t)npoint);
       const int* mc = meas_chain.data(); const int* mp = meas_point.data();
-      if (want_reach) {
-        int dl = 0, dc = 0;
-        const int* cp = cpose.data(); const int* pc = pchain.data();
+      if (want_graph) {
+        u64* sn = seen_t + (size_t)tid*npoint;
+        std::memset(sn, 0, sizeof(u64)*(size_t)npoint);
+        const int* co = cobs.data(); int base = -1; bool over = false;
         for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
-          const int o = cp[mc[i]], s2 = cp[pc[mp[i]]];
-          if (o >= 0 && s2 >= 0) { const int d = std::abs(o - s2); dl = std::max(dl, d); dc = std::max(dc, std::min(d, npose - d)); }
-          else if (o != -1 && s2 != -1) {
-            const HChain& oc = chains[mc[i]]; const HChain& sc = chains[pc[mp[i]]];
-            for (int k = 0; k < oc.len; ++k) { if (poses[oc.v[k]].fixed) continue;
-              for (int l = 0; l < sc.len; ++l) { if (poses[sc.v[l]].fixed) continue;
-                const int d = std::abs(oc.v[k] - sc.v[l]); dl = std::max(dl, d); dc = std::max(dc, std::min(d, npose - d)); } }
-          }
+          const int ob = co[mc[i]];
+          if (ob < 0) { over |= ob == -2; continue; }
+          if (base < 0) base = std::max(0, ob - 8);
+          const unsigned d = (unsigned)(ob - base);
+          if (d < 64) sn[mp[i]] |= 1ull << d; else over = true;
         }
-        reach_t[2*tid] = dl; reach_t[2*tid + 1] = dc;
+        seen_base[tid] = base; seen_over[tid] = over;
       }
       if (!refine) { for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; } return; }
       int* mx = sig_t + (size_t)2*tid*npoint; int* sm = mx + npoint;
@@ -1172,40 +1169,147 @@ int mcp_ba::prepare() {
   fp_pose.clear(); fl_point.clear();
   for (int i = 0; i < npose; ++i) if (poses[i].active && !poses[i].fixed) { poses[i].unk = (int)fp_pose.size(); fp_pose.push_back(i); }
   chol_segs.clear();
-  if (want_reach && (int)fp_pose.size() >= 96) {
-    // ---- several chains instead of one (round 6).  The reduced system of a trajectory is a band -- a pose couples with the
-    // poses that see a point it sees, a window of +- w around it in add order -- closed to a ring when the trajectory returns to its start.
-    // A band ordered [left half ascending | right half DEscending | the w poses between them] is two independent bands with a border on
-    // their LAST columns (no extra fill); a ring needs a second separator where it closes, [arc ascending | other arc descending | middle
-    // separator | closing separator], whose rows fill across the arcs as the closing rows of the add order do.  The one-launch factorisation
-    // then walks the halves with a critical workgroup each: ~(P/2 + separators) dependent block columns instead of P.
-    // w from the data: twice the farthest (observer, source pose) pair of any measurement -- two observers of a point are each within that
-    // distance of its source pose -- straight and round the ring, taken in the counting pass above in poses of the add order (fixed and unused
-    // poses included: an upper bound of the distance in unknowns).  The plan checks the promise (CholPersist::build: chains that couple
-    // after all are factorised as one).  Not worth it (halves under three tiles): add order, one chain.
-    const int nf = (int)fp_pose.size();
-    int dl = 0, dc = 0; for (int t = 0; t < T; ++t) { dl = std::max(dl, reach_t[2*t]); dc = std::max(dc, reach_t[2*t + 1]); }
-    dl = std::min(dl, nf); dc = std::min(dc, nf);
-    const bool ring = dc < dl;
-    const int w = 2*(ring ? dc : dl) + 1;
-    // a band: [0, m) | [m + w, nf) descending | [m, m + w).  a ring: [w, m) | [m + w, nf) descending | [m, m + w) | [0, w).  The first arc's
-    // length a multiple of 16 poses (6 x 16 unknowns = 3 tiles: the second starts on a tile boundary); a tile straddling the end of the second is the last chain's.
-    const int head = ring ? w : 0;
-    const int len1 = (((nf - head - w)/2 + 8)/16)*16, m = head + len1, len2 = nf - m - w;
-    const int t1 = 6*len1/CH_NB, t2 = 6*(len1 + len2)/CH_NB, t_all = (6*nf + CH_NB - 1)/CH_NB;
-    if (w > 1 && len1 >= 16 && len2 >= 16 && t2 - t1 >= 3 && t_all - t2 >= 1) {
+  if (want_graph && (int)fp_pose.size() >= 96 && (int)fp_pose.size() <= 1024) {
+    // ---- several chains instead of one (round 6).  The one-launch factorisation walks the block columns of a chain one after
+    // the other on one critical workgroup; chains that do not couple are walked beside each other.  The reduced system of a trajectory is
+    // mostly a band in add order -- a pose couples with the poses that see a point it sees -- closed to a ring when the trajectory returns,
+    // plus the odd group of poses that sees points from across a loop.  Cut the ring of free poses (add order, cyclic) into two arcs A and B
+    // with two gaps between them; whatever still couples A with B goes to the separator too (greedily, the pose with the most such
+    // couplings first).  Ordered [A ascending | B DEscending | gap between their ends | gap where the ring closes | the cover] the arcs
+    // are two bands with a border on their last columns: ~(P/2 + separator) dependent block columns instead of P.  The cut is searched:
+    // where the ring opens (a stride of rotations; an open band = no closing gap, rotation 0), how wide the gaps are, where the middle gap
+    // sits so that A ends on a tile boundary (16 poses = 3 tiles), scored by the block columns on the longest path.
+    // The coupling graph: per point the set of free poses that see or carry it (atomic ORs into a bit row per point), every pair of a set
+    // an edge.  Fixed points are taken as coupling their observers too (they do not): a superset only costs separator.  The plan checks
+    // the promise against the true tile pattern (CholPersist::build: chains that couple after all are factorised as one).
+    const int nf = (int)fp_pose.size(), W = (nf + 63)/64;
+    bool windows = true; for (int t = 0; t < T; ++t) windows = windows && !seen_over[t];
+    if (getenv("MCP_BA_TEST_CHOL_ATOMIC")) windows = false;      // (tests: the masks of an add order whose observers do not fit the windows)
+    std::vector<u64> pmask, adj((size_t)nf*W, 0), adj_t((size_t)T*nf*W, 0);
+    const int* mp = meas_point.data(); const int* mc = meas_chain.data();
+    if (!windows) {
+      pmask.assign((size_t)std::max(npoint, 1)*W, 0);
+      par([&](int tid) {
+        for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
+          const HChain& oc = chains[mc[i]];
+          for (int k = 0; k < oc.len; ++k) { const int u = poses[oc.v[k]].unk; if (u >= 0) __atomic_fetch_or(&pmask[(size_t)mp[i]*W + (u >> 6)], 1ull << (u & 63), __ATOMIC_RELAXED); }
+        }
+      });
+    }
+    lap("  chains: point masks");
+    par([&](int tid) {
+      u64* at = adj_t.data() + (size_t)tid*nf*W; u64 row[16];
+      for (long p = lo_of(tid, npoint), e = lo_of(tid + 1, npoint); p < e; ++p) {
+        if (!points[p].active) continue;
+        if (windows) {
+          for (int k = 0; k < W; ++k) row[k] = 0;
+          for (int t = 0; t < T; ++t) for (u64 m = seen_t[(size_t)t*npoint + p]; m; m &= m - 1) { const int u = poses[seen_base[t] + __builtin_ctzll(m)].unk; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+        } else for (int k = 0; k < W; ++k) row[k] = pmask[(size_t)p*W + k];
+        const HChain& sc = chains[points[p].chain];
+        for (int k = 0; k < sc.len; ++k) { const int u = poses[sc.v[k]].unk; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+        for (int k = 0; k < W; ++k) for (u64 m = row[k]; m; m &= m - 1) { u64* a = at + (size_t)(64*k + __builtin_ctzll(m))*W; for (int q = 0; q < W; ++q) a[q] |= row[q]; }
+      }
+    });
+    for (int t = 0; t < T; ++t) for (size_t i = 0; i < adj.size(); ++i) adj[i] |= adj_t[(size_t)t*nf*W + i];
+    for (int u = 0; u < nf; ++u) adj[(size_t)u*W + (u >> 6)] &= ~(1ull << (u & 63));
+    auto tiles_of = [](int nposes) { return (6*nposes + CH_NB - 1)/CH_NB; };
+    auto set_range = [&](u64* m, int r, int lo, int hi) { for (int q = lo; q < hi; ++q) { const int u = (q + r) % nf; m[u >> 6] |= 1ull << (u & 63); } };      // positions [lo, hi) of the ring opened at r
+    auto touches = [&](int u, const u64* m) { const u64* a = &adj[(size_t)u*W]; int c = 0; for (int q = 0; q < W; ++q) c += __builtin_popcountll(a[q] & m[q]); return c; };
+    lap("  chains: coupling graph");
+    // stage 1: (rotation, gap, gap) with the arcs of equal length, scored with the smaller side of the crossing edges as the cover;
+    // the best four go on
+    static const int gaps[] = {0, 8, 16, 24, 32, 48};
+    struct Cut { int steps, sep, r, g1, g2, la; bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g1 != o.g1 ? g1 < o.g1 : g2 < o.g2; } };
+    constexpr int KEEP = 4;
+    const Cut none{1 << 30, 0, 0, 0, 0, 0};
+    const int rstride = std::max(1, nf/40), nrot = (nf + rstride - 1)/rstride;
+    std::vector<Cut> best_t((size_t)T*KEEP, none);
+    auto keep = [&](Cut* top, const Cut& c) { for (int k = 0; k < KEEP; ++k) if (c < top[k]) { for (int q = KEEP - 1; q > k; --q) top[q] = top[q - 1]; top[k] = c; break; } };
+    par([&](int tid) {
+      std::vector<u64> mA(W), mB(W);
+      Cut* top = &best_t[(size_t)tid*KEEP];
+      for (int ri = (int)lo_of(tid, nrot), re = (int)lo_of(tid + 1, nrot); ri < re; ++ri) {
+        const int r = ri*rstride;
+        for (int g1 : gaps) { if (g1 == 0) continue;
+          for (int g2 : gaps) {
+            if (g2 == 0 && r != 0) continue;
+            const int rest = nf - g1 - g2, la = rest/2, lb = rest - la;
+            if (la < 32) continue;
+            std::fill(mA.begin(), mA.end(), 0); std::fill(mB.begin(), mB.end(), 0);
+            set_range(mA.data(), r, 0, la); set_range(mB.data(), r, la + g1, la + g1 + lb);
+            int nA = 0, nB = 0;
+            for (int q = 0; q < la; ++q) nA += touches((q + r) % nf, mB.data()) != 0;
+            for (int q = la + g1; q < la + g1 + lb; ++q) nB += touches((q + r) % nf, mA.data()) != 0;
+            const int sep = g1 + g2 + std::min(nA, nB);
+            keep(top, Cut{tiles_of(std::max(la, lb)) + tiles_of(sep), sep, r, g1, g2, la});
+          } }
+      }
+    });
+    Cut top[KEEP] = {none, none, none, none};
+    for (const Cut& c : best_t) if (c.steps < (1 << 30)) keep(top, c);
+    lap("  chains: cuts");
+    // stage 2, per kept cut: the middle gap slid over +- 20 poses, the cover taken greedily (degrees kept up to date), A's length a
+    // multiple of 16 poses; a separator under three tiles takes the poses at B's end
+    struct Fine { int steps = 1 << 30, la = 0, cut = 0, ncover = 0; std::vector<int> A, B, S; };
+    std::vector<Fine> fine_t(T);
+    const int t_all = tiles_of(nf);
+    constexpr int SLIDE = 20;
+    par([&](int tid) {
+      std::vector<u64> mA(W), mB(W); std::vector<int> deg(nf), cover;
+      for (int item = tid; item < KEEP*(2*SLIDE + 1); item += T) {
+        const Cut& c = top[item/(2*SLIDE + 1)];
+        if (c.steps == (1 << 30)) continue;
+        const int la = c.la - SLIDE + item % (2*SLIDE + 1), lb = nf - c.g1 - c.g2 - la;
+        if (la < 16 || lb < 16) continue;
+        std::fill(mA.begin(), mA.end(), 0); std::fill(mB.begin(), mB.end(), 0);
+        set_range(mA.data(), c.r, 0, la); set_range(mB.data(), c.r, la + c.g1, la + c.g1 + lb);
+        auto in = [](const std::vector<u64>& m, int u) { return (m[u >> 6] >> (u & 63)) & 1; };
+        for (int u = 0; u < nf; ++u) deg[u] = in(mA, u) ? touches(u, mB.data()) : in(mB, u) ? touches(u, mA.data()) : 0;
+        cover.clear();
+        for (;;) {
+          int bv = -1, bd = 0;
+          for (int u = 0; u < nf; ++u) if (deg[u] > bd) { bd = deg[u]; bv = u; }
+          if (bv < 0) break;
+          std::vector<u64>& mine = in(mA, bv) ? mA : mB; const std::vector<u64>& other = in(mA, bv) ? mB : mA;
+          mine[bv >> 6] &= ~(1ull << (bv & 63)); deg[bv] = 0; cover.push_back(bv);
+          const u64* a = &adj[(size_t)bv*W];
+          for (int k = 0; k < W; ++k) for (u64 m = a[k] & other[k]; m; m &= m - 1) --deg[64*k + __builtin_ctzll(m)];
+        }
+        Fine f; f.la = la; f.cut = item/(2*SLIDE + 1); f.ncover = (int)cover.size();
+        for (int q = 0; q < la; ++q) { const int u = (q + c.r) % nf; if (in(mA, u)) f.A.push_back(u); }
+        for (int q = la + c.g1 + lb - 1; q >= la + c.g1; --q) { const int u = (q + c.r) % nf; if (in(mB, u)) f.B.push_back(u); }
+        if (f.A.size() % 16 || f.A.size() < 16) continue;
+        while (f.B.size() > 16 && t_all - 6*(int)(f.A.size() + f.B.size())/CH_NB < 3) { f.S.push_back(f.B.back()); f.B.pop_back(); }
+        for (int q = la; q < la + c.g1; ++q) f.S.push_back((q + c.r) % nf);
+        for (int q = la + c.g1 + lb; q < nf; ++q) f.S.push_back((q + c.r) % nf);
+        std::sort(cover.begin(), cover.end()); for (int u : cover) f.S.push_back(u);
+        const int t1 = 6*(int)f.A.size()/CH_NB, t2 = 6*(int)(f.A.size() + f.B.size())/CH_NB;
+        f.steps = std::max(t1, t2 - t1) + (t_all - t2);
+        if (t2 - t1 < 3 || t_all - t2 < 3) continue;
+        Fine& b2 = fine_t[tid];
+        if (f.steps < b2.steps || (f.steps == b2.steps && (f.cut < b2.cut || (f.cut == b2.cut && f.la < b2.la)))) b2 = std::move(f);
+      }
+    });
+    Fine* fb = nullptr;
+    for (auto& f : fine_t) if (f.steps < (1 << 30) && (!fb || f.steps < fb->steps || (f.steps == fb->steps && (f.cut < fb->cut || (f.cut == fb->cut && f.la < fb->la))))) fb = &f;
+    const Cut c1 = fb ? top[fb->cut] : none;
+    const bool take = fb && 10*fb->steps <= 8*t_all;        // (worth it from a fifth fewer dependent block columns)
+    if (take) {
       std::vector<int> order; order.reserve(nf);
-      for (int u = head; u < m; ++u) order.push_back(fp_pose[u]);
-      for (int u = nf - 1; u >= m + w; --u) order.push_back(fp_pose[u]);
-      for (int u = m; u < m + w; ++u) order.push_back(fp_pose[u]);
-      for (int u = 0; u < head; ++u) order.push_back(fp_pose[u]);
+      for (int u : fb->A) order.push_back(fp_pose[u]);
+      for (int u : fb->B) order.push_back(fp_pose[u]);
+      for (int u : fb->S) order.push_back(fp_pose[u]);
+      const int t1 = 6*(int)fb->A.size()/CH_NB, t2 = 6*(int)(fb->A.size() + fb->B.size())/CH_NB;
       fp_pose.swap(order);
       for (int u = 0; u < nf; ++u) poses[fp_pose[u]].unk = u;
       chol_segs = {0, t1, t2};
       { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, t1 - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
     }
-    if (trace) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses, farthest observer %d poses (%d round the ring) -> %s, separators of %d; tiles %d | %d | %d -> %s\n", nf, dl, dc, ring ? "a ring" : "a band", w,
-                       t1, t2 - t1, t_all - t2, chol_segs.empty() ? "one chain" : "two chains + the separators'");
+    if (trace) {
+      if (fb) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, gaps %d + %d; arcs %zu + %zu poses, separator %zu (%zu of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
+                      nf, c1.r, c1.g1, c1.g2, fb->A.size(), fb->B.size(), fb->S.size(), (size_t)fb->ncover, fb->steps, t_all, take ? "two chains + the separator's" : "one chain");
+      else fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; no cut found -> one chain\n", nf);
+    }
     lap("  pose order (chains)");
   }
   for (int i = 0; i < npoint; ++i) if (points[i].active && !points[i].fixed) { points[i].unk = (int)fl_point.size(); fl_point.push_back(i); }
