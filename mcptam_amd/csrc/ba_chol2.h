@@ -73,6 +73,9 @@ struct CpBackArgs {
   const int* far_start; const int* far_slot; const int* far_row;      // per block column: its far tiles, rows descending
   const int* back_tab;            // [ntc][CPB_INTS] (below)
   double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail; int* claim;
+  // chain workgroups of the back-substitution: [0] walks the last chain of the plan (the separator) and on through the chain before it,
+  // the others a chain each (their columns couple to the separator's through far tiles only): columns [ch_lo, ch_hi), right to left
+  int nchain; int ch_lo[4]; int ch_hi[4];
 };
 
 #ifdef MCP_CP_PROF
@@ -1002,9 +1005,10 @@ __device__ inline void cp_back_far(const CpBackArgs& a, int q, int cidx, double*
 // per block column k, for the chain workgroup (copied to LDS once): slots of L_kk^-1, of the near tiles (k+1..k+3, k), of y_k; far tiles?
 constexpr int CPB_INTS = 8;
 enum { CPB_D = 0, CPB_N1, CPB_N2, CPB_N3, CPB_Y, CPB_FAR };
-__device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
+__device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds, int ci) {
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int n = a.n, ntc = a.ntc;
+  const int klo = a.ch_lo[ci], khi = a.ch_hi[ci];       // (khi stands for the end of the matrix: no tile of these columns lies in rows khi .. khi + 2)
   const double* Lt = a.Lt + q*a.lt_stride;
   const double* fb = a.fbuf + (size_t)q*a.vec_stride;
   double* xb = a.xbuf + (size_t)q*a.vec_stride;
@@ -1030,7 +1034,7 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
     for (int qd = 0; qd < 4; ++qd) {
       g.d[qd] = *reinterpret_cast<const chol_d4*>(Dg + (qd*64 + lane)*4);
       g.u[qd] = (chol_d4){0.0, 0.0, 0.0, 0.0};
-      if (e[CPB_N1] >= 0) g.u[qd] = *reinterpret_cast<const chol_d4*>(Lt + (size_t)e[CPB_N1]*CP_TQ + (qd*64 + lane)*4);
+      if (e[CPB_N1] >= 0 && k + 1 < khi) g.u[qd] = *reinterpret_cast<const chol_d4*>(Lt + (size_t)e[CPB_N1]*CP_TQ + (qd*64 + lane)*4);
     }
     g.y = 0.0; g.f = 0.0;
     if (lane < 32) {
@@ -1065,7 +1069,7 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
     const int c = lane & 31, hh = lane >> 5;
     double sacc = 0.0;
     const int sl = tab[k*CPB_INTS + (w == 1 ? CPB_N2 : CPB_N3)];
-    if (sl >= 0) {
+    if (sl >= 0 && i < khi) {
       const double* T = Lt + (size_t)sl*CP_TQ;
       double v[16];
 #pragma unroll
@@ -1078,18 +1082,18 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
   // lead-in: columns ntc-1 and ntc-2 staged, the partial sums of column ntc-1 (no rows below it: zeros)
   if (wave == 3) {
     Staged g;
-    stage_load(ntc - 1, g); stage_store(ntc - 1, g);
-    if (ntc >= 2) { stage_load(ntc - 2, g); stage_store(ntc - 2, g); }
-  } else if (wave >= 1) pre[((ntc - 1) % 3)*192 + wave*64 + lane] = 0.0;
+    stage_load(khi - 1, g); stage_store(khi - 1, g);
+    if (khi - 2 >= klo) { stage_load(khi - 2, g); stage_store(khi - 2, g); }
+  } else if (wave >= 1) pre[((khi - 1) % 3)*192 + wave*64 + lane] = 0.0;
   __syncthreads();
-  for (int k = ntc - 1; k >= 0; --k) {
+  for (int k = khi - 1; k >= klo; --k) {
     if (!ctl[0]) break;
     Staged g;
     if (wave == 0) {
       const double* P = pre + (k % 3)*192;
       const int c = lane & 31, hh = lane >> 5;
       double sacc = 0.0;
-      if (k + 1 < ntc) {
+      if (k + 1 < khi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc = __builtin_fma(N1(k)[16*hh + r][c], xs[(k + 1)*CH_NB + 16*hh + r], sacc);
       }
@@ -1107,19 +1111,21 @@ __device__ inline void cp_back_chain(const CpBackArgs& a, int q, double* lds) {
         xs[k*CH_NB + lane] = x;
         cp_tagged_store(xb + k*CH_NB + lane, x);
       }
-    } else if (wave == 3) { if (k >= 2) stage_load(k - 2, g); }
-    else if (k >= 1) partial(k - 1, wave);
+    } else if (wave == 3) { if (k - 2 >= klo) stage_load(k - 2, g); }
+    else if (k - 1 >= klo) partial(k - 1, wave);
     cp_barrier();
-    if (wave == 3 && k >= 2) stage_store(k - 2, g);
+    if (wave == 3 && k - 2 >= klo) stage_store(k - 2, g);
   }
   __syncthreads();
   if (t == 0) {
-    a.epoch[q] = a.epoch[q] + 1;          // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
-    a.claim[q] = 0;                       // ... and an untouched helper list
+    if (ci == 0) {
+      a.epoch[q] = a.epoch[q] + 1;        // the next factorisation of this system sees fresh flags (nothing of this launch reads it)
+      a.claim[q] = 0;                     // ... and an untouched helper list
+    }
     if (cp_flag_load(err) != 0 && a.fail) atomicOr(a.fail + q, 4);      // a hand-off timed out somewhere: the host falls back to the per-step kernels
   }
   if (!ctl[0]) return;
-  for (int i = t; i < n; i += CP_THREADS) a.xout[q*a.sys_stride + i] = xs[i];
+  for (int i = klo*CH_NB + t; i < min(n, khi*CH_NB); i += CP_THREADS) a.xout[q*a.sys_stride + i] = xs[i];
 }
 
 // a factorisation that is not followed by k_chol_back2 (debug hook) closes its epoch itself
@@ -1129,8 +1135,8 @@ __global__ void __launch_bounds__(CP_THREADS)
 k_chol_back2(CpBackArgs a) {
   extern __shared__ __attribute__((aligned(16))) double cp_lds[];
   const int q = blockIdx.x % a.nsys, role = blockIdx.x / a.nsys;
-  if (role == 0) cp_back_chain(a, q, cp_lds);
-  else cp_back_far(a, q, role - 1, cp_lds);
+  if (role < a.nchain) cp_back_chain(a, q, cp_lds, role);
+  else cp_back_far(a, q, role - a.nchain, cp_lds);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -1178,6 +1184,7 @@ struct CholPersist {
   size_t lt_stride = 0, bt_stride = 0; int vec_stride = 0;
   int nworkers = 0;                      // helper workgroups per system (MCP_BA_CHOL_WORKERS)
   int batch_sys = 0;                     // systems the caller has in flight beside each other, over all its streams (0 = just this launch's)
+  bool back_chains = true;               // MCP_BA_CHOL_BACK_CHAINS=0: the back-substitution walks all block columns on one workgroup whatever the plan's chains
   bool spread = true;                    // MCP_BA_CHOL_SPREAD=0: the workers of a launch are not cut to one workgroup per compute unit
   double flops = 0;                      // of one factorisation as this plan executes it (tile operations; mcp_ba_timing.chol_flops_plan)
   int* fail_ptr = nullptr; int n_launch = 0, test_fail_launch = -1;      // (MCP_BA_TEST_PERSIST_FAIL=k: the k-th factorisation of this plan is made to time out)
@@ -1361,6 +1368,7 @@ struct CholPersist {
       nworkers = std::max(1, std::min(nworkers, (dv.capacity - dv.capacity/8)/max_sys - nseg));
     }
     { const char* e = getenv("MCP_BA_CHOL_SPREAD"); spread = !(e && atoi(e) == 0) && !getenv("MCP_BA_CHOL_WORKERS"); }
+    { const char* e = getenv("MCP_BA_CHOL_BACK_CHAINS"); back_chains = !(e && atoi(e) == 0); }
     { const char* e = getenv("MCP_BA_TEST_PERSIST_FAIL"); test_fail_launch = e ? atoi(e) : -1; n_launch = 0; }
     ok = true;
     return 0;
@@ -1404,7 +1412,13 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   static_assert(CP_BACK_NEAR == 3 && CPB_INTS == 8, "the chain workgroup's column table holds three near tiles");
   const size_t lds = (size_t)(6*CP_TILE + 3*3*64 + 32 + 8 + P.ntc*CH_NB)*sizeof(double) + (size_t)(P.ntc*CPB_INTS + 18)*sizeof(int);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(k_chol_back2, dim3((1 + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
+  // (a plan of several chains: the chains before the last do not couple, and what couples them to the last are far tiles)
+  a.nchain = std::max(1, P.nseg - 1);
+  for (int j = 0; j < 4; ++j) { a.ch_lo[j] = 0; a.ch_hi[j] = 0; }
+  a.ch_lo[0] = P.nseg >= 2 ? P.seg_start[P.nseg - 2] : 0; a.ch_hi[0] = P.ntc;
+  for (int j = 1; j < a.nchain; ++j) { a.ch_lo[j] = P.seg_start[P.nseg - 2 - j]; a.ch_hi[j] = P.seg_start[P.nseg - 1 - j]; }
+  if (!P.back_chains) { a.nchain = 1; a.ch_lo[0] = 0; }
+  hipLaunchKernelGGL(k_chol_back2, dim3((a.nchain + P.ntc)*nsys), dim3(CP_THREADS), lds, st, a);
   { const hipError_t e = hipGetLastError(); return (e == hipSuccess || e == hipErrorNotReady) ? 0 : -1; }
 }
 

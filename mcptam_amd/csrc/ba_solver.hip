@@ -1090,7 +1090,7 @@ int mcp_ba::prepare() {
   // (for the chains of the factorisation, below: per point the poses that see it, as a 64-bit window per thread -- the adapters add the
   //  measurements KeyFrame by KeyFrame, so a thread's range of the add order holds few observers, close together in pose index; a range
   //  that does not fit the window is reported and the masks are taken again with atomics)
-  const bool want_graph = dissect_on && !multi() && npose >= 96 && npose <= 1024 + 64;
+  const bool want_graph = dissect_on && npose >= 96 && npose <= 1024 + 64;
   typedef unsigned long long u64;
   scratch.reset(sizeof(int)*(size_t)(refine ? 3 : 1)*T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + (want_graph ? sizeof(u64)*(size_t)T*std::max(npoint, 1) : 0) + 512);
   u64* const seen_t = want_graph ? scratch.take<u64>((size_t)T*std::max(npoint, 1)) : nullptr;
@@ -1211,6 +1211,16 @@ int mcp_ba::prepare() {
       }
     });
     for (int t = 0; t < T; ++t) for (size_t i = 0; i < adj.size(); ++i) adj[i] |= adj_t[(size_t)t*nf*W + i];
+    if (multi()) {
+      // ranks hold different shards of the measurements: the union of their graphs, so that every rank finds the same cut
+      std::vector<double> bits((size_t)nf*nf);
+      for (int u = 0; u < nf; ++u) for (int v = 0; v < nf; ++v) bits[(size_t)u*nf + v] = (double)((adj[(size_t)u*W + (v >> 6)] >> (v & 63)) & 1);
+      DevBuf<double> tmp;
+      if (tmp.upload(bits, st)) return -1;
+      if (allreduce(tmp.p, bits.size(), 0, true, "set-up: pose coupling graph")) return -1;
+      HIPCK(hipMemcpy(bits.data(), tmp.p, bits.size()*sizeof(double), hipMemcpyDeviceToHost));
+      for (int u = 0; u < nf; ++u) for (int v = 0; v < nf; ++v) if (bits[(size_t)u*nf + v] > 0) adj[(size_t)u*W + (v >> 6)] |= 1ull << (v & 63);
+    }
     for (int u = 0; u < nf; ++u) adj[(size_t)u*W + (u >> 6)] &= ~(1ull << (u & 63));
     auto tiles_of = [](int nposes) { return (6*nposes + CH_NB - 1)/CH_NB; };
     auto set_range = [&](u64* m, int r, int lo, int hi) { for (int q = lo; q < hi; ++q) { const int u = (q + r) % nf; m[u >> 6] |= 1ull << (u & 63); } };      // positions [lo, hi) of the ring opened at r
@@ -1218,7 +1228,7 @@ int mcp_ba::prepare() {
     lap("  chains: coupling graph");
     // stage 1: (rotation, gap, gap) with the arcs of equal length, scored with the smaller side of the crossing edges as the cover;
     // the best four go on
-    static const int gaps[] = {0, 8, 16, 24, 32, 48};
+    static const int gaps[] = {0, 8, 16, 32};
     struct Cut { int steps, sep, r, g1, g2, la; bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g1 != o.g1 ? g1 < o.g1 : g2 < o.g2; } };
     constexpr int KEEP = 4;
     const Cut none{1 << 30, 0, 0, 0, 0, 0};

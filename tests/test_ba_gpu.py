@@ -964,15 +964,17 @@ def test_quarter_groups_agree_with_full_groups(gpu_required, cfg, iters, monkeyp
 @pytest.mark.parametrize("env", [dict(MCP_BA_SPEC_TRIALS="0"), dict(MCP_BA_MAILBOX="0"), dict(MCP_BA_OVERLAP="0"), dict(MCP_BA_SPECULATE="0"),
                                  dict(MCP_BA_GRAPH="1"), dict(MCP_BA_OVERLAP="2", MCP_BA_MAIN_SYS="2"), dict(MCP_BA_LIN_JOIN="1"),
                                  dict(MCP_BA_STREAM_POOL="0"), dict(MCP_BA_SCHUR4_ORDER="0"), dict(MCP_BA_HEAD_AHEAD="1"), dict(MCP_BA_HEAD_AHEAD="2"),
-                                 dict(MCP_BA_TRIAL_FUSE="0"), dict(MCP_BA_SPEC_TRIALS="1"), dict(MCP_BA_CHOL_SPREAD="0"), dict(MCP_BA_HEAD_LARGE="1")])
+                                 dict(MCP_BA_TRIAL_FUSE="0"), dict(MCP_BA_SPEC_TRIALS="1"), dict(MCP_BA_CHOL_SPREAD="0"), dict(MCP_BA_HEAD_LARGE="1"),
+                                 dict(MCP_BA_CHOL_BACK_CHAINS="0")])
 def test_scheduling_knobs_do_not_change_a_single_bit(gpu_required, env, monkeypatch):
     """Speculative multi-lambda solves, the second stream, the trial evaluated one ahead, the result mailbox, graph replay and the
     iteration head (median, sigma^2 -- ba_head.h) enqueued behind every trial before the host has accepted one are
     scheduling: the same kernels see the same inputs whichever of them is on, so iteration logs, poses and points are identical
     to the default configuration's, bit for bit (the knobs are read when the handle is created).  Likewise the launch order of the
     Schur groups, the step of a trial as one launch or three (k_trial_apply: same arithmetic per pose, chain and point), every trial
-    evaluated ahead on its own stream, the number of workers a factorisation is launched with, and the head of an iteration (median,
-    sigma^2, robust chi2) as one launch with grid barriers or six (ba_headl.h)."""
+    evaluated ahead on its own stream, the number of workers a factorisation is launched with, the head of an iteration (median,
+    sigma^2, robust chi2) as one launch with grid barriers or six (ba_headl.h), and the back-substitution of the reduced system with a
+    workgroup per chain of the plan or one for all block columns (the metric map is two chains + separator)."""
     from mcptam_amd import synth
     p = synth.make_config("metric")
     base = run_bundle(_gpu(p.cams, disable_convergence=True), p, 7)
