@@ -45,7 +45,7 @@ STAGE_KERNELS = {       # kernels launched per stage invocation: (name, count) ;
     "backsub_update": [("mcp::k_backsub", 1), ("mcp::k_update_poses", 1)],
     "eval": [("mcp::k_eval<true>", 1), ("mcp::k_chains", 1), ("mcp::k_final_sums", 1)],
     "select": [("mcp::k_select_pass", 2), ("mcp::k_select_gather", 1), ("mcp::k_select_small", 1)],
-    "cholesky": [("mcp::k_chol_persist", 1)],        # one persistent launch per solve (ba_chol2.h); MCP_BA_CHOL_PERSIST=0: k_chol_step x steps
+    "cholesky": [("mcp::k_chol_persist", 1)],        # one persistent launch per solve (ba_chol2.h; k_chol_persist_seg for a plan of several chains); MCP_BA_CHOL_PERSIST=0: k_chol_step x steps
     "tri_solve": [("mcp::k_chol_back2", 1)],
 }
 
@@ -104,6 +104,8 @@ def stage_rooflines(tm, M, N, np_, n_lin, n_trials, n_solves):
         t = 0.0
         ok = bool(traffic)
         for kname, cnt in STAGE_KERNELS.get(name, []):
+            if kname == "mcp::k_chol_persist" and tm.get("chol_chains", 1) > 1:
+                kname = "mcp::k_chol_persist_seg"          # the plan of several chains is walked by the segment-aware kernel (ba_chol2.h)
             if kname not in traffic:
                 ok = False
                 break

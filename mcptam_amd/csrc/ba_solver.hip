@@ -1268,7 +1268,7 @@ int mcp_ba::prepare() {
       std::vector<u64> mA(W), mB(W); std::vector<int> deg(nf), cover;
       for (int item = tid; item < KEEP*(2*SLIDE + 1); item += T) {
         const Cut& c = top[item/(2*SLIDE + 1)];
-        if (c.steps == (1 << 30)) continue;
+        if (c.steps == (1 << 30) || 10*c.steps > 9*t_all) continue;      // (nothing to gain by this cut: not refined)
         const int la = c.la - SLIDE + item % (2*SLIDE + 1), lb = nf - c.g1 - c.g2 - la;
         if (la < 16 || lb < 16) continue;
         std::fill(mA.begin(), mA.end(), 0); std::fill(mB.begin(), mB.end(), 0);
@@ -1276,15 +1276,18 @@ int mcp_ba::prepare() {
         auto in = [](const std::vector<u64>& m, int u) { return (m[u >> 6] >> (u & 63)) & 1; };
         for (int u = 0; u < nf; ++u) deg[u] = in(mA, u) ? touches(u, mB.data()) : in(mB, u) ? touches(u, mA.data()) : 0;
         cover.clear();
+        bool given_up = false;
         for (;;) {
           int bv = -1, bd = 0;
           for (int u = 0; u < nf; ++u) if (deg[u] > bd) { bd = deg[u]; bv = u; }
           if (bv < 0) break;
+          if ((int)cover.size() > nf/4) { given_up = true; break; }      // (a graph without a small separator: give this cut up)
           std::vector<u64>& mine = in(mA, bv) ? mA : mB; const std::vector<u64>& other = in(mA, bv) ? mB : mA;
           mine[bv >> 6] &= ~(1ull << (bv & 63)); deg[bv] = 0; cover.push_back(bv);
           const u64* a = &adj[(size_t)bv*W];
           for (int k = 0; k < W; ++k) for (u64 m = a[k] & other[k]; m; m &= m - 1) --deg[64*k + __builtin_ctzll(m)];
         }
+        if (given_up) continue;
         Fine f; f.la = la; f.cut = item/(2*SLIDE + 1); f.ncover = (int)cover.size();
         for (int q = 0; q < la; ++q) { const int u = (q + c.r) % nf; if (in(mA, u)) f.A.push_back(u); }
         for (int q = la + c.g1 + lb - 1; q >= la + c.g1; --q) { const int u = (q + c.r) % nf; if (in(mB, u)) f.B.push_back(u); }

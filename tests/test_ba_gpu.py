@@ -1355,3 +1355,17 @@ def test_a_trajectory_band_is_factorised_as_two_chains(gpu_required, shape, monk
     assert rep["branch_flips"] == 0
     assert two["outliers"] == ref["outliers"]
     assert abs(two["sigma_sq"] - ref["sigma_sq"]) <= 1e-9 * ref["sigma_sq"]
+
+
+def test_a_map_without_a_small_separator_stays_one_chain(gpu_required, monkeypatch):
+    """A tight loop whose poses all see the same points: every cut of the pose coupling graph needs a separator as large as the arcs, so
+    `Prepare()` keeps the add order and the one-chain plan -- the solve is the one `MCP_BA_CHOL_CHAINS=1` gives, bit for bit."""
+    from mcptam_amd import synth
+    p = synth.make_problem(n_cams=2, n_mkf=110, n_points=4000, per_point=6, radius=1.5, k_near=110)
+    b = _gpu(p.cams, disable_convergence=True)
+    auto = run_bundle(b, p, 6)
+    assert b.Timing()["chol_chains"] == 1
+    monkeypatch.setenv("MCP_BA_CHOL_CHAINS", "1")
+    one = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
+    assert auto["rc"] == one["rc"] == 6 and auto["logs"] == one["logs"]
+    assert np.array_equal(auto["R"], one["R"]) and np.array_equal(auto["t"], one["t"]) and np.array_equal(auto["X"], one["X"])
