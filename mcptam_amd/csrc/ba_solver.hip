@@ -687,6 +687,7 @@ struct mcp_ba {
   // more poses than a chain workgroup keeps in LDS; MCP_BA_TRIAL_FUSE=0).  Small bundles: one workgroup for all chains, as before.
   int trial_fuse = 1;
   int dissect_on = 1;                // MCP_BA_CHOL_CHAINS=1: one chain (the poses in add order), see prepare()
+  int chain_arcs = 3;                // MCP_BA_CHOL_ARCS=2: the cut has two arcs at most
   std::vector<int> chol_segs;        // first tile of every chain of the factorisation plan (empty: one)
   int trial_chain_blocks() const {
     if (P.npose > TA_MAX_POSES) return 0;
@@ -987,6 +988,7 @@ int mcp_ba::prepare() {
   // ---- the same topology as an earlier call's (structure cache, above)?  128-bit hash over what the structure is built from
   cache_insert = false;
   { const char* e = getenv("MCP_BA_CHOL_CHAINS"); dissect_on = !(e && atoi(e) == 1); }
+  { const char* e = getenv("MCP_BA_CHOL_ARCS"); chain_arcs = e ? atoi(e) : 3; }
   if (StructCache::get().enabled() && !multi() && nmeas > 0) {
     constexpr size_t HB = 8192;
     const size_t nbm = ((size_t)nmeas + HB - 1)/HB;
@@ -1010,8 +1012,8 @@ int mcp_ba::prepare() {
     // (what else decides the structure: the grouping policy and its run-time switches)
     const char* e_al = getenv("MCP_BA_ASM_LONG");
     key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
-                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16) | (dissect_on ? 1 << 18 : 0);
-    { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) key.flags ^= (unsigned)(atoi(e) & 0xff) << 19; }
+                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16) | (dissect_on ? chain_arcs << 18 : 0);
+    { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) key.flags ^= (unsigned)(atoi(e) & 0xff) << 21; }
     cache_key = key;
     {
       // the same key without the measurements (near miss, below)
@@ -1226,101 +1228,153 @@ int mcp_ba::prepare() {
     auto set_range = [&](u64* m, int r, int lo, int hi) { for (int q = lo; q < hi; ++q) { const int u = (q + r) % nf; m[u >> 6] |= 1ull << (u & 63); } };      // positions [lo, hi) of the ring opened at r
     auto touches = [&](int u, const u64* m) { const u64* a = &adj[(size_t)u*W]; int c = 0; for (int q = 0; q < W; ++q) c += __builtin_popcountll(a[q] & m[q]); return c; };
     lap("  chains: coupling graph");
-    // stage 1: (rotation, gap, gap) with the arcs of equal length, scored with the smaller side of the crossing edges as the cover;
-    // the best four go on
-    static const int gaps[] = {0, 8, 16, 32};
-    struct Cut { int steps, sep, r, g1, g2, la; bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g1 != o.g1 ? g1 < o.g1 : g2 < o.g2; } };
+    // A cut: the ring opened at r into k arcs (k = 2 or 3) of len[i] poses, gap g[i] behind arc i (the last gap closes the ring; 0 = an open band)
+    struct Cut { int steps, sep, k, r, g[3], len[3];
+                 bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : k != o.k ? k < o.k : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g[0] != o.g[0] ? g[0] < o.g[0] : g[1] < o.g[1]; } };
     constexpr int KEEP = 4;
-    const Cut none{1 << 30, 0, 0, 0, 0, 0};
+    const Cut none{1 << 30, 0, 0, 0, {0, 0, 0}, {0, 0, 0}};
+    auto arc_masks = [&](const Cut& c, u64* m /* [k][W] */) {
+      std::fill(m, m + (size_t)c.k*W, 0);
+      int p0 = 0;
+      for (int i = 0; i < c.k; ++i) { set_range(m + (size_t)i*W, c.r, p0, p0 + c.len[i]); p0 += c.len[i] + c.g[i]; }
+    };
+    // stage 1: (rotation, gaps) with arcs of equal length; the cover estimated as half the poses that have a coupling into another arc
+    // (two arcs: the smaller side); the best four go on
+    static const int gaps[] = {0, 8, 16, 32};
     const int rstride = std::max(1, nf/40), nrot = (nf + rstride - 1)/rstride;
     std::vector<Cut> best_t((size_t)T*KEEP, none);
     auto keep = [&](Cut* top, const Cut& c) { for (int k = 0; k < KEEP; ++k) if (c < top[k]) { for (int q = KEEP - 1; q > k; --q) top[q] = top[q - 1]; top[k] = c; break; } };
     par([&](int tid) {
-      std::vector<u64> mA(W), mB(W);
+      std::vector<u64> m((size_t)3*W), oth(W);
       Cut* top = &best_t[(size_t)tid*KEEP];
+      auto score = [&](Cut c) {
+        arc_masks(c, m.data());
+        int nx[3] = {0, 0, 0}, p0 = 0, lmax = 0;
+        for (int i = 0; i < c.k; ++i) {
+          for (int q = 0; q < W; ++q) { oth[q] = 0; for (int j = 0; j < c.k; ++j) if (j != i) oth[q] |= m[(size_t)j*W + q]; }
+          for (int q = p0; q < p0 + c.len[i]; ++q) nx[i] += touches((q + c.r) % nf, oth.data()) != 0;
+          p0 += c.len[i] + c.g[i]; lmax = std::max(lmax, c.len[i]);
+        }
+        const int cov = c.k == 2 ? std::min(nx[0], nx[1]) : (nx[0] + nx[1] + nx[2])/2;
+        c.sep = c.g[0] + c.g[1] + c.g[2] + cov;
+        c.steps = tiles_of(lmax) + tiles_of(c.sep);
+        keep(top, c);
+      };
       for (int ri = (int)lo_of(tid, nrot), re = (int)lo_of(tid + 1, nrot); ri < re; ++ri) {
         const int r = ri*rstride;
         for (int g1 : gaps) { if (g1 == 0) continue;
           for (int g2 : gaps) {
             if (g2 == 0 && r != 0) continue;
             const int rest = nf - g1 - g2, la = rest/2, lb = rest - la;
-            if (la < 32) continue;
-            std::fill(mA.begin(), mA.end(), 0); std::fill(mB.begin(), mB.end(), 0);
-            set_range(mA.data(), r, 0, la); set_range(mB.data(), r, la + g1, la + g1 + lb);
-            int nA = 0, nB = 0;
-            for (int q = 0; q < la; ++q) nA += touches((q + r) % nf, mB.data()) != 0;
-            for (int q = la + g1; q < la + g1 + lb; ++q) nB += touches((q + r) % nf, mA.data()) != 0;
-            const int sep = g1 + g2 + std::min(nA, nB);
-            keep(top, Cut{tiles_of(std::max(la, lb)) + tiles_of(sep), sep, r, g1, g2, la});
-          } }
+            if (la >= 32) score(Cut{0, 0, 2, r, {g1, g2, 0}, {la, lb, 0}});
+          }
+          if (chain_arcs >= 3 && g1 <= 16) {
+            const int rest = nf - 3*g1, l = rest/3;
+            if (l >= 32) score(Cut{0, 0, 3, r, {g1, g1, g1}, {l, l, rest - 2*l}});
+          }
+        }
       }
     });
     Cut top[KEEP] = {none, none, none, none};
     for (const Cut& c : best_t) if (c.steps < (1 << 30)) keep(top, c);
     lap("  chains: cuts");
-    // stage 2, per kept cut: the middle gap slid over +- 20 poses, the cover taken greedily (degrees kept up to date), A's length a
-    // multiple of 16 poses; a separator under three tiles takes the poses at B's end
-    struct Fine { int steps = 1 << 30, la = 0, cut = 0, ncover = 0; std::vector<int> A, B, S; };
-    std::vector<Fine> fine_t(T);
+    // stage 2, per kept cut: the gap behind the first arc slid over +- 20 poses (three arcs: then the gap behind the second, the first
+    // one where it was best), the cover taken greedily (most couplings into other arcs first, degrees kept up to date); every arc but the
+    // last a multiple of 16 poses; a separator under three tiles takes the poses at the last arc's end
+    struct Fine { int steps = 1 << 30, cut = 0, s0 = 0, s1 = 0, ncover = 0; std::vector<int> arc[3], S;
+                  bool better(const Fine& o) const { return steps != o.steps ? steps < o.steps : cut != o.cut ? cut < o.cut : s0 != o.s0 ? s0 < o.s0 : s1 < o.s1; } };
     const int t_all = tiles_of(nf);
     constexpr int SLIDE = 20;
-    par([&](int tid) {
-      std::vector<u64> mA(W), mB(W); std::vector<int> deg(nf), cover;
-      for (int item = tid; item < KEEP*(2*SLIDE + 1); item += T) {
-        const Cut& c = top[item/(2*SLIDE + 1)];
-        if (c.steps == (1 << 30) || 10*c.steps > 9*t_all) continue;      // (nothing to gain by this cut: not refined)
-        const int la = c.la - SLIDE + item % (2*SLIDE + 1), lb = nf - c.g1 - c.g2 - la;
-        if (la < 16 || lb < 16) continue;
-        std::fill(mA.begin(), mA.end(), 0); std::fill(mB.begin(), mB.end(), 0);
-        set_range(mA.data(), c.r, 0, la); set_range(mB.data(), c.r, la + c.g1, la + c.g1 + lb);
-        auto in = [](const std::vector<u64>& m, int u) { return (m[u >> 6] >> (u & 63)) & 1; };
-        for (int u = 0; u < nf; ++u) deg[u] = in(mA, u) ? touches(u, mB.data()) : in(mB, u) ? touches(u, mA.data()) : 0;
-        cover.clear();
-        bool given_up = false;
-        for (;;) {
-          int bv = -1, bd = 0;
-          for (int u = 0; u < nf; ++u) if (deg[u] > bd) { bd = deg[u]; bv = u; }
-          if (bv < 0) break;
-          if ((int)cover.size() > nf/4) { given_up = true; break; }      // (a graph without a small separator: give this cut up)
-          std::vector<u64>& mine = in(mA, bv) ? mA : mB; const std::vector<u64>& other = in(mA, bv) ? mB : mA;
-          mine[bv >> 6] &= ~(1ull << (bv & 63)); deg[bv] = 0; cover.push_back(bv);
-          const u64* a = &adj[(size_t)bv*W];
-          for (int k = 0; k < W; ++k) for (u64 m = a[k] & other[k]; m; m &= m - 1) --deg[64*k + __builtin_ctzll(m)];
-        }
-        if (given_up) continue;
-        Fine f; f.la = la; f.cut = item/(2*SLIDE + 1); f.ncover = (int)cover.size();
-        for (int q = 0; q < la; ++q) { const int u = (q + c.r) % nf; if (in(mA, u)) f.A.push_back(u); }
-        for (int q = la + c.g1 + lb - 1; q >= la + c.g1; --q) { const int u = (q + c.r) % nf; if (in(mB, u)) f.B.push_back(u); }
-        if (f.A.size() % 16 || f.A.size() < 16) continue;
-        while (f.B.size() > 16 && t_all - 6*(int)(f.A.size() + f.B.size())/CH_NB < 3) { f.S.push_back(f.B.back()); f.B.pop_back(); }
-        for (int q = la; q < la + c.g1; ++q) f.S.push_back((q + c.r) % nf);
-        for (int q = la + c.g1 + lb; q < nf; ++q) f.S.push_back((q + c.r) % nf);
-        std::sort(cover.begin(), cover.end()); for (int u : cover) f.S.push_back(u);
-        const int t1 = 6*(int)f.A.size()/CH_NB, t2 = 6*(int)(f.A.size() + f.B.size())/CH_NB;
-        f.steps = std::max(t1, t2 - t1) + (t_all - t2);
-        if (t2 - t1 < 3 || t_all - t2 < 3) continue;
-        Fine& b2 = fine_t[tid];
-        if (f.steps < b2.steps || (f.steps == b2.steps && (f.cut < b2.cut || (f.cut == b2.cut && f.la < b2.la)))) b2 = std::move(f);
+    auto refine_cut = [&](int ci, int s0, int s1, int need_aligned, Fine& out, std::vector<u64>& m, std::vector<int>& deg, std::vector<int>& arc_of, std::vector<int>& cover) -> bool {
+      Cut c = top[ci];
+      c.len[0] += s0; c.len[1] -= s0;
+      if (c.k == 3) { c.len[1] += s1; c.len[2] -= s1; }
+      for (int i = 0; i < c.k; ++i) if (c.len[i] < 16) return false;
+      arc_masks(c, m.data());
+      u64* all = m.data() + (size_t)3*W;            // union of the arcs
+      for (int q = 0; q < W; ++q) { all[q] = 0; for (int i = 0; i < c.k; ++i) all[q] |= m[(size_t)i*W + q]; }
+      std::fill(arc_of.begin(), arc_of.end(), -1);
+      for (int i = 0; i < c.k; ++i) for (int q = 0; q < W; ++q) for (u64 b = m[(size_t)i*W + q]; b; b &= b - 1) arc_of[64*q + __builtin_ctzll(b)] = i;
+      auto crossing = [&](int u) { const u64* a = &adj[(size_t)u*W]; const u64* mine = &m[(size_t)arc_of[u]*W]; int d = 0; for (int q = 0; q < W; ++q) d += __builtin_popcountll(a[q] & all[q] & ~mine[q]); return d; };
+      for (int u = 0; u < nf; ++u) deg[u] = arc_of[u] >= 0 ? crossing(u) : 0;
+      cover.clear();
+      for (;;) {
+        int bv = -1, bd = 0;
+        for (int u = 0; u < nf; ++u) if (deg[u] > bd) { bd = deg[u]; bv = u; }
+        if (bv < 0) break;
+        if ((int)cover.size() > nf/4) return false;            // (a graph without a small separator: give this cut up)
+        const u64* a = &adj[(size_t)bv*W]; const u64* mine = &m[(size_t)arc_of[bv]*W];
+        for (int q = 0; q < W; ++q) for (u64 b = a[q] & all[q] & ~mine[q]; b; b &= b - 1) --deg[64*q + __builtin_ctzll(b)];
+        m[(size_t)arc_of[bv]*W + (bv >> 6)] &= ~(1ull << (bv & 63)); all[bv >> 6] &= ~(1ull << (bv & 63));
+        arc_of[bv] = -1; deg[bv] = 0; cover.push_back(bv);
       }
-    });
+      Fine f; f.cut = ci; f.s0 = s0; f.s1 = s1; f.ncover = (int)cover.size();
+      int p0 = 0;
+      for (int i = 0; i < c.k; ++i) {
+        // two arcs: the second DEscending (both end at the gap between them; an open band's far end has nothing behind it)
+        if (c.k == 2 && i == 1) { for (int q = p0 + c.len[i] - 1; q >= p0; --q) { const int u = (q + c.r) % nf; if (arc_of[u] == i) f.arc[i].push_back(u); } }
+        else for (int q = p0; q < p0 + c.len[i]; ++q) { const int u = (q + c.r) % nf; if (arc_of[u] == i) f.arc[i].push_back(u); }
+        p0 += c.len[i] + c.g[i];
+      }
+      for (int i = 0; i < need_aligned; ++i) if (f.arc[i].size() % 16 || f.arc[i].size() < 16) return false;
+      if (need_aligned < c.k - 1) { out = std::move(f); out.steps = 0; return true; }      // (first pass of three arcs: only the first arc's length is looked at)
+      std::vector<int>& last = f.arc[c.k - 1];
+      int inarcs = 0; for (int i = 0; i < c.k; ++i) inarcs += (int)f.arc[i].size();
+      while (last.size() > 16 && t_all - 6*inarcs/CH_NB < 3) { f.S.push_back(last.back()); last.pop_back(); --inarcs; }
+      p0 = 0;
+      for (int i = 0; i < c.k; ++i) { for (int q = p0 + c.len[i]; q < p0 + c.len[i] + c.g[i]; ++q) f.S.push_back((q + c.r) % nf); p0 += c.len[i] + c.g[i]; }
+      std::sort(cover.begin(), cover.end()); for (int u : cover) f.S.push_back(u);
+      int tb[4] = {0, 0, 0, 0}, cum = 0, tmax = 0;
+      for (int i = 0; i < c.k; ++i) { cum += (int)f.arc[i].size(); tb[i + 1] = 6*cum/CH_NB; tmax = std::max(tmax, tb[i + 1] - tb[i]); if (tb[i + 1] - tb[i] < 3) return false; }
+      if (t_all - tb[c.k] < 3) return false;
+      f.steps = tmax + (t_all - tb[c.k]);
+      out = std::move(f);
+      return true;
+    };
+    std::vector<Fine> fine_t(T);
+    std::vector<Fine> first_t((size_t)T*KEEP);          // three arcs, first pass: per kept cut the best slide of the first gap (fewest poses in the cover)
+    for (int pass = 0; pass < 2; ++pass) {
+      int s0_of[KEEP] = {0, 0, 0, 0}; bool any3 = false;
+      if (pass == 1) {
+        for (int ci = 0; ci < KEEP; ++ci) {
+          if (top[ci].k != 3) continue;
+          const Fine* b = nullptr;
+          for (int t = 0; t < T; ++t) { const Fine& f = first_t[(size_t)t*KEEP + ci]; if (f.steps == 0 && (!b || f.ncover < b->ncover || (f.ncover == b->ncover && std::abs(f.s0) < std::abs(b->s0)) || (f.ncover == b->ncover && std::abs(f.s0) == std::abs(b->s0) && f.s0 < b->s0))) b = &f; }
+          if (b) { s0_of[ci] = b->s0; any3 = true; } else s0_of[ci] = 1 << 20;
+        }
+        if (!any3) break;
+      }
+      par([&](int tid) {
+        std::vector<u64> m((size_t)4*W); std::vector<int> deg(nf), arc_of(nf), cover;
+        for (int item = tid; item < KEEP*(2*SLIDE + 1); item += T) {
+          const int ci = item/(2*SLIDE + 1), sl = item % (2*SLIDE + 1) - SLIDE;
+          const Cut& c = top[ci];
+          if (c.steps == (1 << 30) || 10*c.steps > 9*t_all) continue;      // (nothing to gain by this cut: not refined)
+          Fine f;
+          if (pass == 0 && c.k == 2) { if (refine_cut(ci, sl, 0, 1, f, m, deg, arc_of, cover) && f.better(fine_t[tid])) fine_t[tid] = std::move(f); }
+          else if (pass == 0) { Fine& b = first_t[(size_t)tid*KEEP + ci];
+            if (refine_cut(ci, sl, 0, 1, f, m, deg, arc_of, cover) && (b.steps != 0 || f.ncover < b.ncover || (f.ncover == b.ncover && (std::abs(f.s0) < std::abs(b.s0) || (std::abs(f.s0) == std::abs(b.s0) && f.s0 < b.s0))))) b = std::move(f); }
+          else if (c.k == 3 && s0_of[ci] != (1 << 20)) { if (refine_cut(ci, s0_of[ci], sl, 2, f, m, deg, arc_of, cover) && f.better(fine_t[tid])) fine_t[tid] = std::move(f); }
+        }
+      });
+    }
     Fine* fb = nullptr;
-    for (auto& f : fine_t) if (f.steps < (1 << 30) && (!fb || f.steps < fb->steps || (f.steps == fb->steps && (f.cut < fb->cut || (f.cut == fb->cut && f.la < fb->la))))) fb = &f;
+    for (auto& f : fine_t) if (f.steps < (1 << 30) && (!fb || f.better(*fb))) fb = &f;
     const Cut c1 = fb ? top[fb->cut] : none;
     const bool take = fb && 10*fb->steps <= 8*t_all;        // (worth it from a fifth fewer dependent block columns)
     if (take) {
       std::vector<int> order; order.reserve(nf);
-      for (int u : fb->A) order.push_back(fp_pose[u]);
-      for (int u : fb->B) order.push_back(fp_pose[u]);
+      chol_segs.assign(1, 0);
+      int cum = 0;
+      for (int i = 0; i < c1.k; ++i) { for (int u : fb->arc[i]) order.push_back(fp_pose[u]); cum += (int)fb->arc[i].size(); chol_segs.push_back(6*cum/CH_NB); }
       for (int u : fb->S) order.push_back(fp_pose[u]);
-      const int t1 = 6*(int)fb->A.size()/CH_NB, t2 = 6*(int)(fb->A.size() + fb->B.size())/CH_NB;
       fp_pose.swap(order);
       for (int u = 0; u < nf; ++u) poses[fp_pose[u]].unk = u;
-      chol_segs = {0, t1, t2};
-      { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, t1 - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
+      { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, chol_segs[1] - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
     }
     if (trace) {
-      if (fb) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, gaps %d + %d; arcs %zu + %zu poses, separator %zu (%zu of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
-                      nf, c1.r, c1.g1, c1.g2, fb->A.size(), fb->B.size(), fb->S.size(), (size_t)fb->ncover, fb->steps, t_all, take ? "two chains + the separator's" : "one chain");
+      if (fb) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, %d arcs of %zu + %zu + %zu poses, gaps %d + %d + %d, separator %zu (%d of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
+                      nf, c1.r, c1.k, fb->arc[0].size(), fb->arc[1].size(), fb->arc[2].size(), c1.g[0], c1.g[1], c1.g[2], fb->S.size(), fb->ncover, fb->steps, t_all, take ? "chains + the separator's" : "one chain");
       else fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; no cut found -> one chain\n", nf);
     }
     lap("  pose order (chains)");
