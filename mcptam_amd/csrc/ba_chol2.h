@@ -47,7 +47,7 @@ constexpr unsigned long long CP_SENT = ((unsigned long long)CP_SENT32 << 32) | C
 #define CP_HELPER_BATCH 1
 #endif
 constexpr int CP_HB = 4;              // tiles a helper keeps in flight ahead of its products (batched updates)
-constexpr int CP_MAX_SEG = 4;
+constexpr int CP_MAX_SEG = 5;
 struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
 // kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
 // index pre_flag), so that the band tiles of row i, whose last update needs L(i, i - CP_W), need not wait for this tile's own
@@ -75,7 +75,7 @@ struct CpBackArgs {
   double* xbuf; double* fbuf; int vec_stride; double* xout; size_t sys_stride; int* err; int* epoch; int* fail; int* claim;
   // chain workgroups of the back-substitution: [0] walks the last chain of the plan (the separator) and on through the chain before it,
   // the others a chain each (their columns couple to the separator's through far tiles only): columns [ch_lo, ch_hi), right to left
-  int nchain; int ch_lo[4]; int ch_hi[4];
+  int nchain; int ch_lo[CP_MAX_SEG]; int ch_hi[CP_MAX_SEG];
 };
 
 #ifdef MCP_CP_PROF
@@ -1414,7 +1414,7 @@ inline int chol_persist_back(hipStream_t st, CholPersist& P, double* S, int nsys
   (void)hipGetLastError();
   // (a plan of several chains: the chains before the last do not couple, and what couples them to the last are far tiles)
   a.nchain = std::max(1, P.nseg - 1);
-  for (int j = 0; j < 4; ++j) { a.ch_lo[j] = 0; a.ch_hi[j] = 0; }
+  for (int j = 0; j < CP_MAX_SEG; ++j) { a.ch_lo[j] = 0; a.ch_hi[j] = 0; }
   a.ch_lo[0] = P.nseg >= 2 ? P.seg_start[P.nseg - 2] : 0; a.ch_hi[0] = P.ntc;
   for (int j = 1; j < a.nchain; ++j) { a.ch_lo[j] = P.seg_start[P.nseg - 2 - j]; a.ch_hi[j] = P.seg_start[P.nseg - 1 - j]; }
   if (!P.back_chains) { a.nchain = 1; a.ch_lo[0] = 0; }

@@ -687,7 +687,7 @@ struct mcp_ba {
   // more poses than a chain workgroup keeps in LDS; MCP_BA_TRIAL_FUSE=0).  Small bundles: one workgroup for all chains, as before.
   int trial_fuse = 1;
   int dissect_on = 1;                // MCP_BA_CHOL_CHAINS=1: one chain (the poses in add order), see prepare()
-  int chain_arcs = 3;                // MCP_BA_CHOL_ARCS=2: the cut has two arcs at most
+  int chain_arcs = 4;                // MCP_BA_CHOL_ARCS=k: the cut has k arcs at most (2 ... 4)
   std::vector<int> chol_segs;        // first tile of every chain of the factorisation plan (empty: one)
   int trial_chain_blocks() const {
     if (P.npose > TA_MAX_POSES) return 0;
@@ -988,7 +988,7 @@ int mcp_ba::prepare() {
   // ---- the same topology as an earlier call's (structure cache, above)?  128-bit hash over what the structure is built from
   cache_insert = false;
   { const char* e = getenv("MCP_BA_CHOL_CHAINS"); dissect_on = !(e && atoi(e) == 1); }
-  { const char* e = getenv("MCP_BA_CHOL_ARCS"); chain_arcs = e ? atoi(e) : 3; }
+  { const char* e = getenv("MCP_BA_CHOL_ARCS"); chain_arcs = e ? atoi(e) : 4; }
   if (StructCache::get().enabled() && !multi() && nmeas > 0) {
     constexpr size_t HB = 8192;
     const size_t nbm = ((size_t)nmeas + HB - 1)/HB;
@@ -1012,7 +1012,7 @@ int mcp_ba::prepare() {
     // (what else decides the structure: the grouping policy and its run-time switches)
     const char* e_al = getenv("MCP_BA_ASM_LONG");
     key.flags = grp_lmax_pol | (point_order_refine ? 32 : 0) | (sch4_on ? 64 : 0) | (env_on("MCP_BA_SCHUR4_ORDER", true) ? 128 : 0) | (group_points(npoint) << 8) |
-                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16) | (dissect_on ? chain_arcs << 18 : 0);
+                ((e_al ? 1 + (atoi(e_al) != 0) : 0) << 16) | (dissect_on ? (chain_arcs & 7) << 18 : 0);
     { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) key.flags ^= (unsigned)(atoi(e) & 0xff) << 21; }
     cache_key = key;
     {
@@ -1228,11 +1228,13 @@ int mcp_ba::prepare() {
     auto set_range = [&](u64* m, int r, int lo, int hi) { for (int q = lo; q < hi; ++q) { const int u = (q + r) % nf; m[u >> 6] |= 1ull << (u & 63); } };      // positions [lo, hi) of the ring opened at r
     auto touches = [&](int u, const u64* m) { const u64* a = &adj[(size_t)u*W]; int c = 0; for (int q = 0; q < W; ++q) c += __builtin_popcountll(a[q] & m[q]); return c; };
     lap("  chains: coupling graph");
-    // A cut: the ring opened at r into k arcs (k = 2 or 3) of len[i] poses, gap g[i] behind arc i (the last gap closes the ring; 0 = an open band)
-    struct Cut { int steps, sep, k, r, g[3], len[3];
+    // A cut: the ring opened at r into k arcs (2 ... MAXA) of len[i] poses, gap g[i] behind arc i (the last gap closes the ring; 0 = an open band)
+    constexpr int MAXA = 4;
+    static_assert(MAXA + 1 <= CP_MAX_SEG, "a chain of the plan per arc + the separator's");
+    struct Cut { int steps, sep, k, r, g[MAXA], len[MAXA];
                  bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : k != o.k ? k < o.k : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g[0] != o.g[0] ? g[0] < o.g[0] : g[1] < o.g[1]; } };
     constexpr int KEEP = 4;
-    const Cut none{1 << 30, 0, 0, 0, {0, 0, 0}, {0, 0, 0}};
+    Cut none; std::memset(&none, 0, sizeof none); none.steps = 1 << 30;
     auto arc_masks = [&](const Cut& c, u64* m /* [k][W] */) {
       std::fill(m, m + (size_t)c.k*W, 0);
       int p0 = 0;
@@ -1242,21 +1244,21 @@ int mcp_ba::prepare() {
     // (two arcs: the smaller side); the best four go on
     static const int gaps[] = {0, 8, 16, 32};
     const int rstride = std::max(1, nf/40), nrot = (nf + rstride - 1)/rstride;
+    const int max_arcs = std::max(2, std::min(chain_arcs, MAXA));
     std::vector<Cut> best_t((size_t)T*KEEP, none);
     auto keep = [&](Cut* top, const Cut& c) { for (int k = 0; k < KEEP; ++k) if (c < top[k]) { for (int q = KEEP - 1; q > k; --q) top[q] = top[q - 1]; top[k] = c; break; } };
     par([&](int tid) {
-      std::vector<u64> m((size_t)3*W), oth(W);
+      std::vector<u64> m((size_t)MAXA*W), oth(W);
       Cut* top = &best_t[(size_t)tid*KEEP];
       auto score = [&](Cut c) {
         arc_masks(c, m.data());
-        int nx[3] = {0, 0, 0}, p0 = 0, lmax = 0;
+        int nx[MAXA] = {0, 0, 0, 0}, p0 = 0, lmax = 0, nxs = 0, gs = 0;
         for (int i = 0; i < c.k; ++i) {
           for (int q = 0; q < W; ++q) { oth[q] = 0; for (int j = 0; j < c.k; ++j) if (j != i) oth[q] |= m[(size_t)j*W + q]; }
           for (int q = p0; q < p0 + c.len[i]; ++q) nx[i] += touches((q + c.r) % nf, oth.data()) != 0;
-          p0 += c.len[i] + c.g[i]; lmax = std::max(lmax, c.len[i]);
+          p0 += c.len[i] + c.g[i]; lmax = std::max(lmax, c.len[i]); nxs += nx[i]; gs += c.g[i];
         }
-        const int cov = c.k == 2 ? std::min(nx[0], nx[1]) : (nx[0] + nx[1] + nx[2])/2;
-        c.sep = c.g[0] + c.g[1] + c.g[2] + cov;
+        c.sep = gs + (c.k == 2 ? std::min(nx[0], nx[1]) : nxs/2);
         c.steps = tiles_of(lmax) + tiles_of(c.sep);
         keep(top, c);
       };
@@ -1266,11 +1268,15 @@ int mcp_ba::prepare() {
           for (int g2 : gaps) {
             if (g2 == 0 && r != 0) continue;
             const int rest = nf - g1 - g2, la = rest/2, lb = rest - la;
-            if (la >= 32) score(Cut{0, 0, 2, r, {g1, g2, 0}, {la, lb, 0}});
+            Cut c = none; c.k = 2; c.r = r; c.g[0] = g1; c.g[1] = g2; c.len[0] = la; c.len[1] = lb;
+            if (la >= 32) score(c);
           }
-          if (chain_arcs >= 3 && g1 <= 16) {
-            const int rest = nf - 3*g1, l = rest/3;
-            if (l >= 32) score(Cut{0, 0, 3, r, {g1, g1, g1}, {l, l, rest - 2*l}});
+          for (int k = 3; k <= max_arcs && g1 <= 16; ++k) {
+            const int rest = nf - k*g1, l = rest/k;
+            if (l < 32) break;
+            Cut c = none; c.k = k; c.r = r;
+            for (int i = 0; i < k; ++i) { c.g[i] = g1; c.len[i] = i + 1 < k ? l : rest - (k - 1)*l; }
+            score(c);
           }
         }
       }
@@ -1278,20 +1284,20 @@ int mcp_ba::prepare() {
     Cut top[KEEP] = {none, none, none, none};
     for (const Cut& c : best_t) if (c.steps < (1 << 30)) keep(top, c);
     lap("  chains: cuts");
-    // stage 2, per kept cut: the gap behind the first arc slid over +- 20 poses (three arcs: then the gap behind the second, the first
-    // one where it was best), the cover taken greedily (most couplings into other arcs first, degrees kept up to date); every arc but the
-    // last a multiple of 16 poses; a separator under three tiles takes the poses at the last arc's end
-    struct Fine { int steps = 1 << 30, cut = 0, s0 = 0, s1 = 0, ncover = 0; std::vector<int> arc[3], S;
-                  bool better(const Fine& o) const { return steps != o.steps ? steps < o.steps : cut != o.cut ? cut < o.cut : s0 != o.s0 ? s0 < o.s0 : s1 < o.s1; } };
+    // stage 2, per kept cut: the gaps behind the arcs but the last slid one after the other over +- 20 poses (pass p slides gap p, the
+    // gaps before it where their cover was smallest), the cover taken greedily (most couplings into other arcs first, degrees kept up to
+    // date); every arc but the last a multiple of 16 poses; a separator under three tiles takes the poses at the last arc's end
+    struct Fine { int steps = 1 << 30, cut = 0, s[MAXA] = {0, 0, 0, 0}, ncover = 0; std::vector<int> arc[MAXA], S;
+                  bool better(const Fine& o) const { if (steps != o.steps) return steps < o.steps; if (cut != o.cut) return cut < o.cut; for (int i = 0; i < MAXA; ++i) if (s[i] != o.s[i]) return s[i] < o.s[i]; return false; } };
     const int t_all = tiles_of(nf);
     constexpr int SLIDE = 20;
-    auto refine_cut = [&](int ci, int s0, int s1, int need_aligned, Fine& out, std::vector<u64>& m, std::vector<int>& deg, std::vector<int>& arc_of, std::vector<int>& cover) -> bool {
+    // shifts s[0 .. k-2]; need_aligned: how many leading arcs must end on a tile boundary; a partial pass (need_aligned < k - 1) returns with steps = 0
+    auto refine_cut = [&](int ci, const int* sh, int need_aligned, Fine& out, std::vector<u64>& m, std::vector<int>& deg, std::vector<int>& arc_of, std::vector<int>& cover) -> bool {
       Cut c = top[ci];
-      c.len[0] += s0; c.len[1] -= s0;
-      if (c.k == 3) { c.len[1] += s1; c.len[2] -= s1; }
+      for (int i = 0; i + 1 < c.k; ++i) { c.len[i] += sh[i]; c.len[i + 1] -= sh[i]; }
       for (int i = 0; i < c.k; ++i) if (c.len[i] < 16) return false;
       arc_masks(c, m.data());
-      u64* all = m.data() + (size_t)3*W;            // union of the arcs
+      u64* all = m.data() + (size_t)MAXA*W;            // union of the arcs
       for (int q = 0; q < W; ++q) { all[q] = 0; for (int i = 0; i < c.k; ++i) all[q] |= m[(size_t)i*W + q]; }
       std::fill(arc_of.begin(), arc_of.end(), -1);
       for (int i = 0; i < c.k; ++i) for (int q = 0; q < W; ++q) for (u64 b = m[(size_t)i*W + q]; b; b &= b - 1) arc_of[64*q + __builtin_ctzll(b)] = i;
@@ -1308,7 +1314,7 @@ int mcp_ba::prepare() {
         m[(size_t)arc_of[bv]*W + (bv >> 6)] &= ~(1ull << (bv & 63)); all[bv >> 6] &= ~(1ull << (bv & 63));
         arc_of[bv] = -1; deg[bv] = 0; cover.push_back(bv);
       }
-      Fine f; f.cut = ci; f.s0 = s0; f.s1 = s1; f.ncover = (int)cover.size();
+      Fine f; f.cut = ci; for (int i = 0; i + 1 < c.k; ++i) f.s[i] = sh[i]; f.ncover = (int)cover.size();
       int p0 = 0;
       for (int i = 0; i < c.k; ++i) {
         // two arcs: the second DEscending (both end at the gap between them; an open band's far end has nothing behind it)
@@ -1317,14 +1323,14 @@ int mcp_ba::prepare() {
         p0 += c.len[i] + c.g[i];
       }
       for (int i = 0; i < need_aligned; ++i) if (f.arc[i].size() % 16 || f.arc[i].size() < 16) return false;
-      if (need_aligned < c.k - 1) { out = std::move(f); out.steps = 0; return true; }      // (first pass of three arcs: only the first arc's length is looked at)
+      if (need_aligned < c.k - 1) { out = std::move(f); out.steps = 0; return true; }
       std::vector<int>& last = f.arc[c.k - 1];
       int inarcs = 0; for (int i = 0; i < c.k; ++i) inarcs += (int)f.arc[i].size();
       while (last.size() > 16 && t_all - 6*inarcs/CH_NB < 3) { f.S.push_back(last.back()); last.pop_back(); --inarcs; }
       p0 = 0;
       for (int i = 0; i < c.k; ++i) { for (int q = p0 + c.len[i]; q < p0 + c.len[i] + c.g[i]; ++q) f.S.push_back((q + c.r) % nf); p0 += c.len[i] + c.g[i]; }
       std::sort(cover.begin(), cover.end()); for (int u : cover) f.S.push_back(u);
-      int tb[4] = {0, 0, 0, 0}, cum = 0, tmax = 0;
+      int tb[MAXA + 1] = {0, 0, 0, 0, 0}, cum = 0, tmax = 0;
       for (int i = 0; i < c.k; ++i) { cum += (int)f.arc[i].size(); tb[i + 1] = 6*cum/CH_NB; tmax = std::max(tmax, tb[i + 1] - tb[i]); if (tb[i + 1] - tb[i] < 3) return false; }
       if (t_all - tb[c.k] < 3) return false;
       f.steps = tmax + (t_all - tb[c.k]);
@@ -1332,31 +1338,35 @@ int mcp_ba::prepare() {
       return true;
     };
     std::vector<Fine> fine_t(T);
-    std::vector<Fine> first_t((size_t)T*KEEP);          // three arcs, first pass: per kept cut the best slide of the first gap (fewest poses in the cover)
-    for (int pass = 0; pass < 2; ++pass) {
-      int s0_of[KEEP] = {0, 0, 0, 0}; bool any3 = false;
-      if (pass == 1) {
-        for (int ci = 0; ci < KEEP; ++ci) {
-          if (top[ci].k != 3) continue;
-          const Fine* b = nullptr;
-          for (int t = 0; t < T; ++t) { const Fine& f = first_t[(size_t)t*KEEP + ci]; if (f.steps == 0 && (!b || f.ncover < b->ncover || (f.ncover == b->ncover && std::abs(f.s0) < std::abs(b->s0)) || (f.ncover == b->ncover && std::abs(f.s0) == std::abs(b->s0) && f.s0 < b->s0))) b = &f; }
-          if (b) { s0_of[ci] = b->s0; any3 = true; } else s0_of[ci] = 1 << 20;
-        }
-        if (!any3) break;
-      }
+    int fixed[KEEP][MAXA] = {};                          // per kept cut: the slides settled by the passes so far
+    bool alive[KEEP]; for (int ci = 0; ci < KEEP; ++ci) alive[ci] = top[ci].steps < (1 << 30) && 10*top[ci].steps <= 9*t_all;      // (nothing to gain by a cut: not refined)
+    for (int pass = 0; pass + 1 < max_arcs; ++pass) {
+      // pass p: cuts of k = p + 2 arcs finish here (their last free gap), cuts of more arcs settle gap p by the smallest cover
+      std::vector<Fine> part_t((size_t)T*KEEP);
+      bool any = false; for (int ci = 0; ci < KEEP; ++ci) any = any || (alive[ci] && top[ci].k >= pass + 2);
+      if (!any) break;
       par([&](int tid) {
-        std::vector<u64> m((size_t)4*W); std::vector<int> deg(nf), arc_of(nf), cover;
+        std::vector<u64> m((size_t)(MAXA + 1)*W); std::vector<int> deg(nf), arc_of(nf), cover;
         for (int item = tid; item < KEEP*(2*SLIDE + 1); item += T) {
           const int ci = item/(2*SLIDE + 1), sl = item % (2*SLIDE + 1) - SLIDE;
           const Cut& c = top[ci];
-          if (c.steps == (1 << 30) || 10*c.steps > 9*t_all) continue;      // (nothing to gain by this cut: not refined)
+          if (!alive[ci] || c.k < pass + 2) continue;
+          int sh[MAXA]; for (int i = 0; i < MAXA; ++i) sh[i] = fixed[ci][i];
+          sh[pass] = sl;
           Fine f;
-          if (pass == 0 && c.k == 2) { if (refine_cut(ci, sl, 0, 1, f, m, deg, arc_of, cover) && f.better(fine_t[tid])) fine_t[tid] = std::move(f); }
-          else if (pass == 0) { Fine& b = first_t[(size_t)tid*KEEP + ci];
-            if (refine_cut(ci, sl, 0, 1, f, m, deg, arc_of, cover) && (b.steps != 0 || f.ncover < b.ncover || (f.ncover == b.ncover && (std::abs(f.s0) < std::abs(b.s0) || (std::abs(f.s0) == std::abs(b.s0) && f.s0 < b.s0))))) b = std::move(f); }
-          else if (c.k == 3 && s0_of[ci] != (1 << 20)) { if (refine_cut(ci, s0_of[ci], sl, 2, f, m, deg, arc_of, cover) && f.better(fine_t[tid])) fine_t[tid] = std::move(f); }
+          if (!refine_cut(ci, sh, pass + 1, f, m, deg, arc_of, cover)) continue;
+          if (c.k == pass + 2) { if (f.better(fine_t[tid])) fine_t[tid] = std::move(f); }
+          else { Fine& b = part_t[(size_t)tid*KEEP + ci];
+            if (b.steps != 0 || f.ncover < b.ncover || (f.ncover == b.ncover && (std::abs(sl) < std::abs(b.s[pass]) || (std::abs(sl) == std::abs(b.s[pass]) && sl < b.s[pass])))) b = std::move(f); }
         }
       });
+      for (int ci = 0; ci < KEEP; ++ci) {
+        if (!alive[ci] || top[ci].k <= pass + 2) continue;
+        const Fine* b = nullptr;
+        for (int t = 0; t < T; ++t) { const Fine& f = part_t[(size_t)t*KEEP + ci];
+          if (f.steps == 0 && (!b || f.ncover < b->ncover || (f.ncover == b->ncover && (std::abs(f.s[pass]) < std::abs(b->s[pass]) || (std::abs(f.s[pass]) == std::abs(b->s[pass]) && f.s[pass] < b->s[pass]))))) b = &f; }
+        if (b) fixed[ci][pass] = b->s[pass]; else alive[ci] = false;
+      }
     }
     Fine* fb = nullptr;
     for (auto& f : fine_t) if (f.steps < (1 << 30) && (!fb || f.better(*fb))) fb = &f;
@@ -1373,8 +1383,9 @@ int mcp_ba::prepare() {
       { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, chol_segs[1] - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
     }
     if (trace) {
-      if (fb) fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, %d arcs of %zu + %zu + %zu poses, gaps %d + %d + %d, separator %zu (%d of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
-                      nf, c1.r, c1.k, fb->arc[0].size(), fb->arc[1].size(), fb->arc[2].size(), c1.g[0], c1.g[1], c1.g[2], fb->S.size(), fb->ncover, fb->steps, t_all, take ? "chains + the separator's" : "one chain");
+      if (fb) { char arcs[128]; int o = 0; for (int i = 0; i < c1.k; ++i) o += snprintf(arcs + o, sizeof arcs - o, "%s%zu", i ? " + " : "", fb->arc[i].size());
+        fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, %d arcs of %s poses, gaps of %d (%d), separator %zu (%d of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
+                nf, c1.r, c1.k, arcs, c1.g[0], c1.g[c1.k - 1], fb->S.size(), fb->ncover, fb->steps, t_all, take ? "chains + the separator's" : "one chain"); }
       else fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; no cut found -> one chain\n", nf);
     }
     lap("  pose order (chains)");
