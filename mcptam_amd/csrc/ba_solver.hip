@@ -1199,16 +1199,25 @@ int mcp_ba::prepare() {
       });
     }
     lap("  chains: point masks");
+    std::vector<int> unk_of(npose); for (int i = 0; i < npose; ++i) unk_of[i] = poses[i].unk;
     par([&](int tid) {
       u64* at = adj_t.data() + (size_t)tid*nf*W; u64 row[16];
+      // (many points are seen by the same poses: a set that was expanded a moment ago is not expanded again -- a small direct-mapped memory of rows)
+      constexpr int RMEM = 512; std::vector<u64> rmem((size_t)RMEM*W, 0);
+      const int* uo = unk_of.data();
       for (long p = lo_of(tid, npoint), e = lo_of(tid + 1, npoint); p < e; ++p) {
         if (!points[p].active) continue;
         if (windows) {
           for (int k = 0; k < W; ++k) row[k] = 0;
-          for (int t = 0; t < T; ++t) for (u64 m = seen_t[(size_t)t*npoint + p]; m; m &= m - 1) { const int u = poses[seen_base[t] + __builtin_ctzll(m)].unk; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+          for (int t = 0; t < T; ++t) for (u64 m = seen_t[(size_t)t*npoint + p]; m; m &= m - 1) { const int u = uo[seen_base[t] + __builtin_ctzll(m)]; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
         } else for (int k = 0; k < W; ++k) row[k] = pmask[(size_t)p*W + k];
         const HChain& sc = chains[points[p].chain];
-        for (int k = 0; k < sc.len; ++k) { const int u = poses[sc.v[k]].unk; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+        for (int k = 0; k < sc.len; ++k) { const int u = uo[sc.v[k]]; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+        u64 h = 0; for (int k = 0; k < W; ++k) h = (h ^ row[k])*0x9e3779b97f4a7c15ull;
+        u64* slot = &rmem[(size_t)(h >> 55)*W];
+        bool same = true; for (int k = 0; k < W; ++k) same = same && slot[k] == row[k];
+        if (same) continue;
+        for (int k = 0; k < W; ++k) slot[k] = row[k];
         for (int k = 0; k < W; ++k) for (u64 m = row[k]; m; m &= m - 1) { u64* a = at + (size_t)(64*k + __builtin_ctzll(m))*W; for (int q = 0; q < W; ++q) a[q] |= row[q]; }
       }
     });
