@@ -1089,14 +1089,14 @@ int mcp_ba::prepare() {
   //  refine_point_order -- in the same private way: a first version added them up with atomics on shared arrays, 6 ms of cache-line
   //  ping-pong between the threads)
   const bool refine = point_order_refine;
-  // (for the chains of the factorisation, below: per point the poses that see it, as a 64-bit window per thread -- the adapters add the
-  //  measurements KeyFrame by KeyFrame, so a thread's range of the add order holds few observers, close together in pose index; a range
-  //  that does not fit the window is reported and the masks are taken again with atomics)
+  // (for the chains of the factorisation, below: per point the poses that see it, as a 64-bit set per thread -- the adapters add the
+  //  measurements KeyFrame by KeyFrame, so a thread's range of the add order holds few distinct observers: each gets a bit as it is first
+  //  met, whatever its pose index; a range with more than 64 of them is reported and the sets are taken again with atomics)
   const bool want_graph = dissect_on && npose >= 96 && npose <= 1024 + 64;
   typedef unsigned long long u64;
   scratch.reset(sizeof(int)*(size_t)(refine ? 3 : 1)*T*std::max(npoint, 1) + sizeof(SMeas)*(size_t)std::max(nmeas, 1) + (want_graph ? sizeof(u64)*(size_t)T*std::max(npoint, 1) : 0) + 512);
   u64* const seen_t = want_graph ? scratch.take<u64>((size_t)T*std::max(npoint, 1)) : nullptr;
-  std::vector<int> seen_base(T, -1), cobs; std::vector<unsigned char> seen_over(T, 0);
+  std::vector<int> seen_ids((size_t)T*64, -1), cobs; std::vector<unsigned char> seen_over(T, 0);
   if (want_graph) { cobs.resize(nch); for (size_t c = 0; c < nch; ++c) { int one = -1, nmov = 0; for (int k = 0; k < chains[c].len; ++k) if (!poses[chains[c].v[k]].fixed) { one = chains[c].v[k]; ++nmov; } cobs[c] = nmov == 1 ? one : nmov ? -2 : -1; } }
   int* const cnt_t = scratch.take<int>((size_t)T*std::max(npoint, 1));
   int* const sig_t = refine ? scratch.take<int>((size_t)2*T*std::max(npoint, 1)) : nullptr;      // [thread][max | sum][point]
@@ -1112,15 +1112,18 @@ int mcp_ba::prepare() {
       if (want_graph) {
         u64* sn = seen_t + (size_t)tid*npoint;
         std::memset(sn, 0, sizeof(u64)*(size_t)npoint);
-        const int* co = cobs.data(); int base = -1; bool over = false;
+        const int* co = cobs.data(); int* ids = &seen_ids[(size_t)tid*64]; int nids = 0, last_ob = -1, last_bit = 0; bool over = false;
         for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) {
           const int ob = co[mc[i]];
           if (ob < 0) { over |= ob == -2; continue; }
-          if (base < 0) base = std::max(0, ob - 8);
-          const unsigned d = (unsigned)(ob - base);
-          if (d < 64) sn[mp[i]] |= 1ull << d; else over = true;
+          if (ob != last_ob) {
+            int b = 0; while (b < nids && ids[b] != ob) ++b;
+            if (b == nids) { if (nids == 64) { over = true; continue; } ids[nids++] = ob; }
+            last_ob = ob; last_bit = b;
+          }
+          sn[mp[i]] |= 1ull << last_bit;
         }
-        seen_base[tid] = base; seen_over[tid] = over;
+        seen_over[tid] = over;
       }
       if (!refine) { for (long i = lo_of(tid, nmeas), e = lo_of(tid + 1, nmeas); i < e; ++i) { cu[mc[i]] = 1; ct[mp[i]]++; } return; }
       int* mx = sig_t + (size_t)2*tid*npoint; int* sm = mx + npoint;
@@ -1209,7 +1212,7 @@ int mcp_ba::prepare() {
         if (!points[p].active) continue;
         if (windows) {
           for (int k = 0; k < W; ++k) row[k] = 0;
-          for (int t = 0; t < T; ++t) for (u64 m = seen_t[(size_t)t*npoint + p]; m; m &= m - 1) { const int u = uo[seen_base[t] + __builtin_ctzll(m)]; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
+          for (int t = 0; t < T; ++t) for (u64 m = seen_t[(size_t)t*npoint + p]; m; m &= m - 1) { const int u = uo[seen_ids[(size_t)t*64 + __builtin_ctzll(m)]]; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
         } else for (int k = 0; k < W; ++k) row[k] = pmask[(size_t)p*W + k];
         const HChain& sc = chains[points[p].chain];
         for (int k = 0; k < sc.len; ++k) { const int u = uo[sc.v[k]]; if (u >= 0) row[u >> 6] |= 1ull << (u & 63); }
@@ -1233,6 +1236,47 @@ int mcp_ba::prepare() {
       for (int u = 0; u < nf; ++u) for (int v = 0; v < nf; ++v) if (bits[(size_t)u*nf + v] > 0) adj[(size_t)u*W + (v >> 6)] |= 1ull << (v & 63);
     }
     for (int u = 0; u < nf; ++u) adj[(size_t)u*W + (u >> 6)] &= ~(1ull << (u & 63));
+    // An add order that is not a trajectory's (MCPTAM hands its key frames over in the order of a std::set of pointers): when the couplings
+    // lie far apart in it, the poses are first relabelled breadth-first from a far end of the graph (Cuthill-McKee: neighbours by degree),
+    // which lays any trajectory out as a band -- a ring as a band of twice its width -- and the cut below is searched in THAT order.
+    bool relabelled = false;
+    {
+      auto deg_of = [&](int u) { int d = 0; for (int q = 0; q < W; ++q) d += __builtin_popcountll(adj[(size_t)u*W + q]); return d; };
+      std::vector<int> dg(nf); long dist_add = 0, nedge = 0;
+      for (int u = 0; u < nf; ++u) { dg[u] = deg_of(u);
+        for (int q = 0; q < W; ++q) for (u64 b = adj[(size_t)u*W + q]; b; b &= b - 1) { const int v = 64*q + __builtin_ctzll(b); const int d = std::abs(u - v); dist_add += std::min(d, nf - d); ++nedge; } }
+      if (nedge > 0 && dist_add > 12*nedge) {             // (mean distance round the ring above 12 poses: a trajectory in add order stays well below)
+        std::vector<int> cm; cm.reserve(nf); std::vector<unsigned char> seen(nf, 0);
+        auto bfs = [&](int start, std::vector<int>& out) {
+          out.clear(); std::vector<unsigned char> mark(nf, 0); std::vector<int> nb;
+          out.push_back(start); mark[start] = 1;
+          for (size_t h = 0; h < out.size(); ++h) {
+            const int u = out[h]; nb.clear();
+            for (int q = 0; q < W; ++q) for (u64 b = adj[(size_t)u*W + q]; b; b &= b - 1) { const int v = 64*q + __builtin_ctzll(b); if (!mark[v] && !seen[v]) { mark[v] = 1; nb.push_back(v); } }
+            std::sort(nb.begin(), nb.end(), [&](int x, int y) { return dg[x] != dg[y] ? dg[x] < dg[y] : x < y; });
+            for (int v : nb) out.push_back(v);
+          }
+        };
+        std::vector<int> comp;
+        for (;;) {
+          int s0 = -1; for (int u = 0; u < nf; ++u) if (!seen[u] && (s0 < 0 || dg[u] < dg[s0])) s0 = u;
+          if (s0 < 0) break;
+          bfs(s0, comp); bfs(comp.back(), comp); bfs(comp.back(), comp);       // (a far end of the component, twice refined)
+          for (int u : comp) { seen[u] = 1; cm.push_back(u); }
+        }
+        long dist_cm = 0; std::vector<int> pos(nf); for (int i = 0; i < nf; ++i) pos[cm[i]] = i;
+        for (int u = 0; u < nf; ++u) for (int q = 0; q < W; ++q) for (u64 b = adj[(size_t)u*W + q]; b; b &= b - 1) dist_cm += std::abs(pos[u] - pos[64*q + __builtin_ctzll(b)]);
+        if (2*dist_cm < dist_add) {
+          std::vector<u64> adj2((size_t)nf*W, 0); std::vector<int> fp2(nf);
+          for (int i = 0; i < nf; ++i) { fp2[i] = fp_pose[cm[i]];
+            for (int q = 0; q < W; ++q) for (u64 b = adj[(size_t)cm[i]*W + q]; b; b &= b - 1) { const int v = pos[64*q + __builtin_ctzll(b)]; adj2[(size_t)i*W + (v >> 6)] |= 1ull << (v & 63); } }
+          adj.swap(adj2); fp_pose.swap(fp2);
+          for (int u = 0; u < nf; ++u) poses[fp_pose[u]].unk = u;
+          relabelled = true;
+        }
+        if (trace) fprintf(stderr, "[mcp_ba prepare]   chains: couplings %.1f poses apart in add order, %.1f breadth-first -> %s\n", (double)dist_add/nedge, (double)dist_cm/nedge, relabelled ? "relabelled" : "add order kept");
+      }
+    }
     auto tiles_of = [](int nposes) { return (6*nposes + CH_NB - 1)/CH_NB; };
     auto set_range = [&](u64* m, int r, int lo, int hi) { for (int q = lo; q < hi; ++q) { const int u = (q + r) % nf; m[u >> 6] |= 1ull << (u & 63); } };      // positions [lo, hi) of the ring opened at r
     auto touches = [&](int u, const u64* m) { const u64* a = &adj[(size_t)u*W]; int c = 0; for (int q = 0; q < W; ++q) c += __builtin_popcountll(a[q] & m[q]); return c; };
@@ -1286,6 +1330,11 @@ int mcp_ba::prepare() {
             Cut c = none; c.k = k; c.r = r;
             for (int i = 0; i < k; ++i) { c.g[i] = g1; c.len[i] = i + 1 < k ? l : rest - (k - 1)*l; }
             score(c);
+            if (r == 0) {                       // an open band: nothing behind the last arc
+              const int rest2 = nf - (k - 1)*g1, l2 = rest2/k;
+              c.g[k - 1] = 0; for (int i = 0; i < k; ++i) c.len[i] = i + 1 < k ? l2 : rest2 - (k - 1)*l2;
+              score(c);
+            }
           }
         }
       }

@@ -396,6 +396,28 @@ CONFIGS = {
 }
 
 
+def shuffle_mkfs(p, seed=1):
+    """The same map with its MKFs handed over in another order (MCPTAM's adapters walk a std::set of MultiKeyFrame pointers,
+    /root/reference/src/BundleAdjusterMulti.cc:83-134: address order, not trajectory order): MKF k of the result is MKF perm[k] of `p`,
+    measurements again MKF-major then camera then point.  Poses, points and measurements are the same physical quantities."""
+    import copy
+    rng = np.random.default_rng([DEFAULT_SEED, 77, seed])
+    P = p.n_mkf
+    perm = rng.permutation(P)
+    inv = np.empty(P, dtype=np.int64); inv[perm] = np.arange(P)
+    q = copy.copy(p)
+    q.base_R = p.base_R[perm]; q.base_t = p.base_t[perm]; q.base_fixed = p.base_fixed[perm]
+    if p.true_base_R is not None:
+        q.true_base_R = p.true_base_R[perm]; q.true_base_t = p.true_base_t[perm]
+    q.pt_src = p.pt_src.copy(); q.pt_src[:, 0] = inv[p.pt_src[:, 0]]
+    mk = inv[p.ms_mkf]
+    order = np.lexsort((p.ms_pt, p.ms_cam, mk))
+    q.ms_mkf = mk[order].astype(p.ms_mkf.dtype); q.ms_cam = p.ms_cam[order]; q.ms_pt = p.ms_pt[order]
+    q.ms_uv = np.ascontiguousarray(p.ms_uv[order]); q.ms_level = p.ms_level[order]
+    q.ids = {}
+    return q
+
+
 def erase_measurements(p, outliers, ids=None):
     """The map after MapMakerServerBase::HandleOutliers (/root/reference/src/MapMakerServerBase.cc:1198-1238: kf.EraseMeasurementOfPoint for
     every measurement the adjustment flagged): the listed (point id, MKF id, camera index) measurements -- what GetOutlierMeasurements()

@@ -3,7 +3,7 @@
 walked once) whose poses see the points of their neighbours only -- the map MCPTAM builds while it explores -- with the factorisation
 as two chains + separator (the default for such a map) and as one chain (MCP_BA_CHOL_CHAINS=1).
 
-  python scripts/bench_band.py [arc|ring] [--steps K]
+  python scripts/bench_band.py [arc|ring|metric_shuffled] [--steps K]
 prints one JSON line: ms per LM iteration and the factorisation's stage time either way, the chains the plan was built with.
 """
 import json
@@ -17,7 +17,10 @@ sys.path.insert(0, ROOT)
 
 def run(shape, steps, warm=6):
     from mcptam_amd import chain_bundle, synth
-    p = synth.make_config("ring_metric" if shape == "ring" else "band_metric")
+    if shape == "metric_shuffled":          # the headline map with its MKFs handed over in a random order (as a std::set of pointers would)
+        p = synth.shuffle_mkfs(synth.make_config("metric"))
+    else:
+        p = synth.make_config("ring_metric" if shape == "ring" else "band_metric")
     out = {"workload": "%s: 4 cams, %d MKF, %d points, %d measurements" % (shape, p.n_mkf, p.n_points, p.n_meas)}
     for label, env in (("two_chains", None), ("one_chain", "1")):
         if env is None:

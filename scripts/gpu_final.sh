@@ -38,6 +38,6 @@ f=$(find $R/gpurun_out/prof_window -name '*kernel_stats.csv' | head -1); [ -n "$
 find $R/gpurun_out/prof_window -name '*kernel_trace.csv' -delete; cd $R
 timeout -k 10 120 python scripts/bench_window.py --calls 40 > gpurun_out/window.json 2> gpurun_out/window.err; cut -c1-400 gpurun_out/window.json
 # a band trajectory of the headline's sizes: the factorisation as two chains and as one
-( timeout -k 10 200 python scripts/bench_band.py arc; timeout -k 10 200 python scripts/bench_band.py ring ) > gpurun_out/band_bench.json 2> gpurun_out/band_bench.err; cut -c1-300 gpurun_out/band_bench.json
+( timeout -k 10 200 python scripts/bench_band.py arc; timeout -k 10 200 python scripts/bench_band.py ring; timeout -k 10 200 python scripts/bench_band.py metric_shuffled ) > gpurun_out/band_bench.json 2> gpurun_out/band_bench.err; cut -c1-300 gpurun_out/band_bench.json
 # device timeline of one c3 tracker frame (kernels + copies in start order with gaps)
 bash $R/scripts/gpu_trk_trace.sh > gpurun_out/trk_trace_stdout.log 2>&1; tail -9 gpurun_out/trk_trace.txt

@@ -1083,7 +1083,10 @@ def test_a_map_that_lost_its_outliers_adopts_the_cached_structure_of_the_call_be
     assert [(l["trials"], l["accepted"]) for l in near["logs"]] == [(l["trials"], l["accepted"]) for l in cold["logs"]]
     for a, b in zip(near["logs"], cold["logs"]):
         assert abs(a["chi2_end"] - b["chi2_end"]) <= 1e-9 * abs(b["chi2_end"]) and abs(a["sigma_sq"] - b["sigma_sq"]) <= 1e-9 * abs(b["sigma_sq"])
-    assert rel_err_elem(near["R"], cold["R"]) < 1e-9 and rel_err_elem(near["t"], cold["t"]) < 1e-9 and rel_err_elem(near["X"], cold["X"]) < 1e-9
+    # (a map whose factorisation is cut into chains: the cold Prepare() of the smaller map cuts ITS coupling graph, not the superset's --
+    #  another elimination order, state to 1e-8 as in test_a_trajectory_band_is_factorised_as_two_chains)
+    tol = 1e-8 if cfg in ("metric", "band", "ring") else 1e-9
+    assert rel_err_elem(near["R"], cold["R"]) < tol and rel_err_elem(near["t"], cold["t"]) < tol and rel_err_elem(near["X"], cold["X"]) < tol
     assert abs(near["sigma_sq"] - cold["sigma_sq"]) <= 1e-9 * cold["sigma_sq"] and abs(near["mean_chi2"] - cold["mean_chi2"]) <= 1e-9 * cold["mean_chi2"]
     assert sorted(near["outliers"]) == sorted(cold["outliers"])
     assert np.allclose(chi_near, chi_cold, rtol=1e-7, atol=1e-12)
@@ -1315,7 +1318,7 @@ def test_bench_spawns_its_own_ranks(gpu_required):
     assert "5000 points, 40000 measurements per rank" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("shape", ["arc", "ring", "chains_that_couple"])
+@pytest.mark.parametrize("shape", ["arc", "ring", "chains_that_couple", "ring_in_another_add_order"])
 def test_a_trajectory_band_is_factorised_as_two_chains(gpu_required, shape, monkeypatch):
     """A trajectory whose poses see only points of their neighbours -- an open arc, or a loop walked once -- has a banded (cyclic-banded)
     reduced system: prepare() orders its poses [one half | the other half, reversed | the poses between them (| where the ring closes)]
@@ -1325,7 +1328,9 @@ def test_a_trajectory_band_is_factorised_as_two_chains(gpu_required, shape, monk
     tiles of the first half handed to the second) breaks the promise the plan was given -- chains that do not couple: it must notice and
     build one chain, not hang or return another answer."""
     from mcptam_amd import synth
-    p = synth.make_config("ring" if shape == "ring" else "band")
+    p = synth.make_config("ring" if shape.startswith("ring") else "band")
+    if shape == "ring_in_another_add_order":      # MKFs handed over in a random order: relabelled breadth-first before the cut
+        p = synth.shuffle_mkfs(p)
     if shape == "chains_that_couple":
         monkeypatch.setenv("MCP_BA_TEST_CHOL_CUT", "2")
     b = _gpu(p.cams, disable_convergence=True)
