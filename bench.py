@@ -418,6 +418,7 @@ def main():
             result["config"]["reduced_system_solves"] = tm["n_solves"]
             result["config"]["trials_served_speculatively"] = tm["n_spec_hits"]
             result["config"]["persist_fallbacks"] = tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"]      # 0 in a healthy run (one-launch factorisation never timed out)
+            result["config"]["factorisation_chains"] = tm_run.get("chol_chains", 0)      # chains of block columns the one-launch factorisation walks beside each other (arcs of the cut + the separator; 1 = the poses in add order)
             result["stages"] = {"ms_total": stage_ms, "per_stage": {k: {kk: v[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_ms", "launches", "traffic", "limited_by", "mfma_executed", "plan_basis") if kk in v} for k, v in roofs.items()}}
     # CPU baselines on this box's host cores, same map, same run; the oracle's iteration log doubles as the
     # parity check of the GPU run that was just timed

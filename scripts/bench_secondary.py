@@ -81,7 +81,7 @@ def run(name, steps=10, warm=6, device=0):
                name, len(problem.cams), problem.n_mkf, np_ // 6, np_, problem.n_points, problem.n_meas,
                (" -- the headline map on a one-rank RCCL communicator, every collective of the multi-rank path executed (MCP_BA_FORCE_MULTI=1)" if forced else " -- rank 0's share of the c4 map split over 8 ranks, one-rank RCCL communicator, every collective of the multi-rank path executed") if shard else ""),
            "value": steps / dt, "unit": "LM iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "trials_per_iteration": trials / steps,
-           "reduced_system_solves": tm["n_solves"], "prepare_ms": prep_ms, "persist_fallbacks": tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"],
+           "reduced_system_solves": tm["n_solves"], "prepare_ms": prep_ms, "persist_fallbacks": tm_run["n_persist_fallbacks"] + tm["n_persist_fallbacks"], "factorisation_chains": tm_run.get("chol_chains", 0),
            "stages_ms_per_launch": {k: round(v["avg_ms"], 5) for k, v in roofs.items()},
            "stages_ms_total": {k: tm[k] for k in ("eval_ms", "select_ms", "linearize_ms", "schur_ms", "cholesky_ms", "solve_ms", "update_ms")},
            "roofline": {k: dom[1][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_ms", "plan_basis") if k in dom[1]} | {"kernel": dom[0], "traffic": None}}
