@@ -3255,9 +3255,14 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         ni = 2;
       }
       double rho = 0; int qmax = 0; int accepted = 0; double ss_last = 0; double trial_chi_raw = currentChi;
+      static const bool trace_trials = [] { const char* e = getenv("MCP_BA_TRACE"); return e && atoi(e) >= 3; }();
+      const auto it_t0 = std::chrono::steady_clock::now();
+      std::string it_line;
       do {
         bool ok2 = true;
+        const int pre0 = dbg_pre;
         if (solve_trial(lambda, ok2, ni)) return MCP_ERR_RUNTIME;
+        if (trace_trials) { char b[64]; snprintf(b, sizeof b, " %s%.0f", dbg_pre != pre0 ? "a" : (sys_cur ? "s" : "m"), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - it_t0).count()); it_line += b; }
         if (start_pending) take_start();
         if (head_failed) { head_failed = false; set_err("the head of an iteration (k_head_large) gave up at a barrier"); return MCP_ERR_RUNTIME; }
         if (test_fail_trial > 0 && ++test_trial_no == test_fail_trial) ok2 = false;      // (test hook: this trial's factorisation "failed")
@@ -3325,6 +3330,7 @@ int mcp_ba::compute(volatile unsigned char* abort_flag, int n_iter, double user_
         }
         ++qmax;
       } while (rho < 0 && qmax < prm.max_trials_after_failure && !terminate());
+      if (trace_trials) fprintf(stderr, "[mcp_ba trials] it %d: results at (us; m = solved for this trial, a = evaluated ahead, s = system of the batch, trial run now)%s\n", it, it_line.c_str());
       if (cancel_spec_trials()) return MCP_ERR_RUNTIME;
       ok = !(qmax == prm.max_trials_after_failure || rho == 0);
       ++cj;
