@@ -58,7 +58,7 @@ BA_SYMBOLS = [
     "mcp_ba_num_outliers", "mcp_ba_get_outliers", "mcp_ba_sigma_squared", "mcp_ba_mean_chi_squared", "mcp_ba_max_cov",
     "mcp_ba_lambda", "mcp_ba_num_iter_logs", "mcp_ba_get_iter_logs", "mcp_ba_get_timing", "mcp_ba_set_allreduce",
     "mcp_ba_prepare", "mcp_ba_eval", "mcp_ba_robust_chi2", "mcp_ba_debug_solve", "mcp_dense_spd_solve",
-    "mcp_dense_spd_stress", "mcp_ba_debug_system", "mcp_chol_debug_factor", "mcp_chol_time",
+    "mcp_dense_spd_stress", "mcp_ba_debug_system", "mcp_chol_debug_factor", "mcp_chol_time", "mcp_debug_pose_cut",
     "mcp_ba_struct_cache_stats", "mcp_ba_struct_cache_near_hits", "mcp_ba_struct_cache_clear",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_ba_set_comm", "mcp_comm_allreduce", "mcp_comm_allreduce_lane",
 ]
@@ -101,6 +101,7 @@ def lib():
     L.mcp_ba_debug_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
     L.mcp_dense_spd_solve.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p]
     L.mcp_chol_debug_factor.argtypes = [c_double_p, ctypes.c_int, c_double_p, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_int)]
+    L.mcp_debug_pose_cut.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.mcp_chol_time.argtypes = [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p]
     L.mcp_dense_spd_stress.argtypes = [c_double_p, ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.POINTER(ctypes.c_int)]
     L.mcp_ba_debug_system.argtypes = [ctypes.c_void_p, ctypes.c_double, c_double_p]
@@ -206,6 +207,21 @@ def chol_debug_factor(A, b):
     if lib().mcp_chol_debug_factor(_dp(A), n, _dp(b), _dp(L), _dp(y), info) != 0:
         raise RuntimeError("mcp_chol_debug_factor failed: " + last_error())
     return L, y, info[0], info[1]
+
+
+def pose_cut(adjacency, max_arcs=4, threads=1):
+    """The cut of a pose coupling graph (nf x nf, nonzero = coupled; free poses in add order) that Prepare() gives the factorisation its
+    chains with (csrc/ba_cut.h; host code, no GPU).  Returns dict(order, segs, found, taken, relabelled, arcs, opened_at, steps,
+    steps_one_chain, separator, arc_len)."""
+    A = np.ascontiguousarray(np.asarray(adjacency) != 0, dtype=np.uint8)
+    nf = A.shape[0]
+    order = (ctypes.c_int * nf)(); segs = (ctypes.c_int * 6)(); info = (ctypes.c_int * 12)()
+    rc = lib().mcp_debug_pose_cut(A.ctypes.data_as(ctypes.c_char_p), nf, int(max_arcs), int(threads), order, segs, info)
+    if rc < 0:
+        raise RuntimeError("mcp_debug_pose_cut failed: " + last_error())
+    return dict(chains=rc, order=np.array(order[:], dtype=np.int64), segs=[v for v in segs[:] if v >= 0], found=bool(info[0]), taken=bool(info[1]),
+                relabelled=bool(info[2]), arcs=info[3], opened_at=info[4], steps=info[5], steps_one_chain=info[6], separator=info[7],
+                arc_len=[info[8 + i] for i in range(info[3])])
 
 
 def chol_time(A, b, nsys=1, reps=20, band=0):
