@@ -1374,3 +1374,31 @@ def test_a_map_without_a_small_separator_stays_one_chain(gpu_required, monkeypat
     one = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
     assert auto["rc"] == one["rc"] == 6 and auto["logs"] == one["logs"]
     assert np.array_equal(auto["R"], one["R"]) and np.array_equal(auto["t"], one["t"]) and np.array_equal(auto["X"], one["X"])
+
+
+@pytest.mark.parametrize("n,nsys", [(1216, 1), (1216, 4), (3008, 2), (416, 1)])
+def test_dissected_band_through_the_chain_kernels(gpu_required, n, nsys):
+    """k_chol_persist_seg + the back-substitution with a workgroup per chain, outside the solver: a band of six tiles ordered [left half |
+    right half reversed | the six block columns between them] and the plan told so (mcp_chol_time, band = -6: chains {0, h, ntc - 6}).
+    Solutions of (A + q I) x = b against numpy; two calls give the same bits."""
+    from mcptam_amd.chain_bundle import chol_time
+    ntc = n // 32
+    rng = np.random.default_rng(31 + n)
+    B = rng.normal(size=(n, n))
+    A = B @ B.T
+    for i in range(ntc):
+        for j in range(ntc):
+            if abs(i - j) > 6:
+                A[32 * i:32 * i + 32, 32 * j:32 * j + 32] = 0.0
+    A += 5 * n * np.eye(n)
+    h = (ntc - 6) // 2
+    order = list(range(h)) + list(range(ntc - 1, h + 5, -1)) + list(range(h, h + 6))
+    idx = np.concatenate([np.arange(32 * o, 32 * o + 32) for o in order])
+    A = A[np.ix_(idx, idx)]
+    b = rng.normal(size=n)
+    _, _, x = chol_time(np.tril(A), b, nsys=nsys, reps=20, band=-6)
+    _, _, x2 = chol_time(np.tril(A), b, nsys=nsys, reps=20, band=-6)
+    assert np.array_equal(x, x2)
+    for q in range(nsys):
+        ref = np.linalg.solve(A + q * np.eye(n), b)
+        assert rel_err(x[q], ref) < 1e-11, (n, q)
