@@ -1252,12 +1252,14 @@ def test_one_launch_and_step_kernels_agree_on_the_metric_map(gpu_required, monke
     assert a["outliers"] == b["outliers"]
 
 
-def test_handoff_timeout_falls_back_to_the_step_kernels(gpu_required, monkeypatch):
+@pytest.mark.parametrize("cfg", ["c2", "ring"])
+def test_handoff_timeout_falls_back_to_the_step_kernels(gpu_required, cfg, monkeypatch):
     """A hand-off of the one-launch factorisation that never arrives (forced: the critical workgroup of the third factorisation raises
     the error word) must not hang and must not be taken for a result: every spinner leaves, the failure flag says so, the host
-    redoes that solve with the per-step kernels and keeps them."""
+    redoes that solve with the per-step kernels and keeps them.  `ring`: a plan of several chains (k_chol_persist_seg, a chain
+    workgroup per arc in the back-substitution) -- every one of its critical workgroups has to leave."""
     from mcptam_amd import synth
-    p = synth.make_config("c2")
+    p = synth.make_config(cfg)
     ref = run_bundle(_gpu(p.cams, disable_convergence=True), p, 6)
     monkeypatch.setenv("MCP_BA_TEST_PERSIST_FAIL", "3")
     bundle = _gpu(p.cams, disable_convergence=True)
