@@ -241,10 +241,10 @@ int mcp_chol_debug_factor(const double* A, int n, const double* b, double* L_out
  * for (A + q I) x_q = b, q < nsys; band > 0: banded + bordered tile plan (i - j <= band, last `band` block rows dense) */
 int mcp_chol_time(const double* A, int n, const double* b, int nsys, int reps, int band, double* ms_factor, double* ms_back, double* x);
 /* the cut of the pose coupling graph Prepare() gives the factorisation its chains with (mcptam_amd/csrc/ba_cut.h; host code, no device
- * needed): adjacency[u*nf + v] != 0 = poses u and v (free poses in add order) couple.  order_out[nf]: position -> pose; segs_out[6]:
+ * needed): adjacency[u*nf + v] != 0 = poses u and v (free poses in add order) couple.  order_out[nf]: position -> pose; segs_out[8]:
  * first tile (32 unknowns = 16/3 poses) of every chain, the separator's last, -1 behind them (segs_out[1] < 0: one chain);
- * info_out[12]: found, taken, relabelled, arcs, ring opened at, block columns on the longest path, of one chain, separator poses,
- * arc lengths [4].  `threads` only splits the search (the result does not depend on it).  Returns the number of chains (1 = none). */
+ * info_out[14]: found, taken, relabelled, arcs, ring opened at, block columns on the longest path, of one chain, separator poses,
+ * arc lengths [6].  `threads` only splits the search (the result does not depend on it).  Returns the number of chains (1 = none). */
 int mcp_debug_pose_cut(const unsigned char* adjacency, int nf, int max_arcs, int threads, int* order_out, int* segs_out, int* info_out);
 /* the reduced pose system the solver would factor at the current state for `lambda`: S (np*np, row-major, lower
  * triangle meaningful inside the tiles of the factorisation plan, other entries 0), rhs (np) and J^T r (np) behind it;

@@ -209,13 +209,13 @@ def chol_debug_factor(A, b):
     return L, y, info[0], info[1]
 
 
-def pose_cut(adjacency, max_arcs=4, threads=1):
+def pose_cut(adjacency, max_arcs=6, threads=1):
     """The cut of a pose coupling graph (nf x nf, nonzero = coupled; free poses in add order) that Prepare() gives the factorisation its
     chains with (csrc/ba_cut.h; host code, no GPU).  Returns dict(order, segs, found, taken, relabelled, arcs, opened_at, steps,
     steps_one_chain, separator, arc_len)."""
     A = np.ascontiguousarray(np.asarray(adjacency) != 0, dtype=np.uint8)
     nf = A.shape[0]
-    order = (ctypes.c_int * nf)(); segs = (ctypes.c_int * 6)(); info = (ctypes.c_int * 12)()
+    order = (ctypes.c_int * nf)(); segs = (ctypes.c_int * 8)(); info = (ctypes.c_int * 14)()
     rc = lib().mcp_debug_pose_cut(A.ctypes.data_as(ctypes.c_char_p), nf, int(max_arcs), int(threads), order, segs, info)
     if rc < 0:
         raise RuntimeError("mcp_debug_pose_cut failed: " + last_error())

@@ -47,7 +47,7 @@ constexpr unsigned long long CP_SENT = ((unsigned long long)CP_SENT32 << 32) | C
 #define CP_HELPER_BATCH 1
 #endif
 constexpr int CP_HB = 4;              // tiles a helper keeps in flight ahead of its products (batched updates)
-constexpr int CP_MAX_SEG = 5;
+constexpr int CP_MAX_SEG = 7;
 struct CpHelper { int ti, tj, slot, dslot, upd0, nupd, kind, in_s, pre, pre_flag, pre_diag, pad; };
 // kind: 0 far tile, 1 band tile.  pre >= 0 -- far tile (i, i - CP_W): band slot its sum goes to BEFORE the solve with L_jj^-T (flag
 // index pre_flag), so that the band tiles of row i, whose last update needs L(i, i - CP_W), need not wait for this tile's own

@@ -25,7 +25,7 @@ struct PoseCut {
   std::vector<int> order;      // position in the new order -> index in the order the graph was given in
   std::vector<int> segs;       // first tile of every chain of the plan, the separator's last (empty: one chain)
   bool relabelled = false, found = false, taken = false, looked_at_order = false;
-  int k = 0, r = 0, g_first = 0, g_last = 0, steps = 0, t_all = 0, ncover = 0, sep = 0, arc_len[4] = {0, 0, 0, 0};
+  int k = 0, r = 0, g_first = 0, g_last = 0, steps = 0, t_all = 0, ncover = 0, sep = 0, arc_len[6] = {0, 0, 0, 0, 0, 0};
   double dist_add = 0, dist_cm = 0;      // mean distance of two coupled poses in the given order (round the ring) and breadth-first
 };
 
@@ -84,7 +84,7 @@ inline void pose_cut(std::vector<cut_u64>& adj, int nf, int max_arcs_wanted, int
     auto touches = [&](int u, const u64* m) { const u64* a = &adj[(size_t)u*W]; int c = 0; for (int q = 0; q < W; ++q) c += __builtin_popcountll(a[q] & m[q]); return c; };
     lap("  chains: coupling graph");
     // A cut: the ring opened at r into k arcs (2 ... MAXA) of len[i] poses, gap g[i] behind arc i (the last gap closes the ring; 0 = an open band)
-    constexpr int MAXA = 4;
+    constexpr int MAXA = 6;
     static_assert(MAXA + 1 <= CP_MAX_SEG, "a chain of the plan per arc + the separator's");
     struct Cut { int steps, sep, k, r, g[MAXA], len[MAXA];
                  bool operator<(const Cut& o) const { return steps != o.steps ? steps < o.steps : k != o.k ? k < o.k : sep != o.sep ? sep < o.sep : r != o.r ? r < o.r : g[0] != o.g[0] ? g[0] < o.g[0] : g[1] < o.g[1]; } };
@@ -107,7 +107,7 @@ inline void pose_cut(std::vector<cut_u64>& adj, int nf, int max_arcs_wanted, int
       Cut* top = &best_t[(size_t)tid*KEEP];
       auto score = [&](Cut c) {
         arc_masks(c, m.data());
-        int nx[MAXA] = {0, 0, 0, 0}, p0 = 0, lmax = 0, nxs = 0, gs = 0;
+        int nx[MAXA] = {}, p0 = 0, lmax = 0, nxs = 0, gs = 0;
         for (int i = 0; i < c.k; ++i) {
           for (int q = 0; q < W; ++q) { oth[q] = 0; for (int j = 0; j < c.k; ++j) if (j != i) oth[q] |= m[(size_t)j*W + q]; }
           for (int q = p0; q < p0 + c.len[i]; ++q) nx[i] += touches((q + c.r) % nf, oth.data()) != 0;
@@ -147,7 +147,7 @@ inline void pose_cut(std::vector<cut_u64>& adj, int nf, int max_arcs_wanted, int
     // stage 2, per kept cut: the gaps behind the arcs but the last slid one after the other over +- 20 poses (pass p slides gap p, the
     // gaps before it where their cover was smallest), the cover taken greedily (most couplings into other arcs first, degrees kept up to
     // date); every arc but the last a multiple of 16 poses; a separator under three tiles takes the poses at the last arc's end
-    struct Fine { int steps = 1 << 30, cut = 0, s[MAXA] = {0, 0, 0, 0}, ncover = 0; std::vector<int> arc[MAXA], S;
+    struct Fine { int steps = 1 << 30, cut = 0, s[MAXA] = {}, ncover = 0; std::vector<int> arc[MAXA], S;
                   bool better(const Fine& o) const { if (steps != o.steps) return steps < o.steps; if (cut != o.cut) return cut < o.cut; for (int i = 0; i < MAXA; ++i) if (s[i] != o.s[i]) return s[i] < o.s[i]; return false; } };
     const int t_all = tiles_of(nf);
     constexpr int SLIDE = 20;
@@ -190,7 +190,7 @@ inline void pose_cut(std::vector<cut_u64>& adj, int nf, int max_arcs_wanted, int
       p0 = 0;
       for (int i = 0; i < c.k; ++i) { for (int q = p0 + c.len[i]; q < p0 + c.len[i] + c.g[i]; ++q) f.S.push_back((q + c.r) % nf); p0 += c.len[i] + c.g[i]; }
       std::sort(cover.begin(), cover.end()); for (int u : cover) f.S.push_back(u);
-      int tb[MAXA + 1] = {0, 0, 0, 0, 0}, cum = 0, tmax = 0;
+      int tb[MAXA + 1] = {}, cum = 0, tmax = 0;
       for (int i = 0; i < c.k; ++i) { cum += (int)f.arc[i].size(); tb[i + 1] = 6*cum/CH_NB; tmax = std::max(tmax, tb[i + 1] - tb[i]); if (tb[i + 1] - tb[i] < 3) return false; }
       if (t_all - tb[c.k] < 3) return false;
       f.steps = tmax + (t_all - tb[c.k]);

@@ -688,7 +688,7 @@ struct mcp_ba {
   // more poses than a chain workgroup keeps in LDS; MCP_BA_TRIAL_FUSE=0).  Small bundles: one workgroup for all chains, as before.
   int trial_fuse = 1;
   int dissect_on = 1;                // MCP_BA_CHOL_CHAINS=1: one chain (the poses in add order), see prepare()
-  int chain_arcs = 4;                // MCP_BA_CHOL_ARCS=k: the cut has k arcs at most (2 ... 4)
+  int chain_arcs = 6;                // MCP_BA_CHOL_ARCS=k: the cut has k arcs at most (2 ... 6)
   std::vector<int> chol_segs;        // first tile of every chain of the factorisation plan (empty: one)
   int trial_chain_blocks() const {
     if (P.npose > TA_MAX_POSES) return 0;
@@ -989,7 +989,7 @@ int mcp_ba::prepare() {
   // ---- the same topology as an earlier call's (structure cache, above)?  128-bit hash over what the structure is built from
   cache_insert = false;
   { const char* e = getenv("MCP_BA_CHOL_CHAINS"); dissect_on = !(e && atoi(e) == 1); }
-  { const char* e = getenv("MCP_BA_CHOL_ARCS"); chain_arcs = e ? atoi(e) : 4; }
+  { const char* e = getenv("MCP_BA_CHOL_ARCS"); chain_arcs = e ? atoi(e) : 6; }
   if (StructCache::get().enabled() && !multi() && nmeas > 0) {
     constexpr size_t HB = 8192;
     const size_t nbm = ((size_t)nmeas + HB - 1)/HB;
@@ -1241,7 +1241,7 @@ int mcp_ba::prepare() {
     if (cut.taken) { const char* e = getenv("MCP_BA_TEST_CHOL_CUT"); if (e) chol_segs[1] = std::max(3, chol_segs[1] - atoi(e)); }      // (tests: the cut between the chains moved into the first one -- chains that couple: the plan must notice)
     if (trace) {
       if (cut.looked_at_order) fprintf(stderr, "[mcp_ba prepare]   chains: couplings %.1f poses apart in add order, %.1f breadth-first -> %s\n", cut.dist_add, cut.dist_cm, cut.relabelled ? "relabelled" : "add order kept");
-      if (cut.found) { char arcs[128]; int o = 0; for (int i = 0; i < cut.k; ++i) o += snprintf(arcs + o, sizeof arcs - o, "%s%d", i ? " + " : "", cut.arc_len[i]);
+      if (cut.found) { char arcs[192]; int o = 0; for (int i = 0; i < cut.k; ++i) o += snprintf(arcs + o, sizeof arcs - o, "%s%d", i ? " + " : "", cut.arc_len[i]);
         fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; ring opened at %d, %d arcs of %s poses, gaps of %d (%d), separator %d (%d of them for what still coupled the arcs): %d block columns on the longest path of %d -> %s\n",
                 nf, cut.r, cut.k, arcs, cut.g_first, cut.g_last, cut.sep, cut.ncover, cut.steps, cut.t_all, cut.taken ? "chains + the separator's" : "one chain"); }
       else fprintf(stderr, "[mcp_ba prepare]   chains: %d free poses; no cut found -> one chain\n", nf);
@@ -3807,9 +3807,9 @@ int mcp_debug_pose_cut(const unsigned char* adjacency, int nf, int max_arcs, int
   // (the thread ranges one after the other: the search must give the same cut however it is split)
   pose_cut(adj, nf, max_arcs, T, [&](const std::function<void(int)>& fn) { for (int t = 0; t < T; ++t) fn(t); }, [](const char*) {}, cut);
   for (int i = 0; i < nf; ++i) order_out[i] = cut.order[i];
-  for (int i = 0; i < 6; ++i) segs_out[i] = i < (int)cut.segs.size() ? cut.segs[i] : -1;
-  const int info[12] = { cut.found, cut.taken, cut.relabelled, cut.k, cut.r, cut.steps, cut.t_all, cut.sep, cut.arc_len[0], cut.arc_len[1], cut.arc_len[2], cut.arc_len[3] };
-  for (int i = 0; i < 12; ++i) info_out[i] = info[i];
+  for (int i = 0; i < 8; ++i) segs_out[i] = i < (int)cut.segs.size() ? cut.segs[i] : -1;
+  const int info[14] = { cut.found, cut.taken, cut.relabelled, cut.k, cut.r, cut.steps, cut.t_all, cut.sep, cut.arc_len[0], cut.arc_len[1], cut.arc_len[2], cut.arc_len[3], cut.arc_len[4], cut.arc_len[5] };
+  for (int i = 0; i < 14; ++i) info_out[i] = info[i];
   return cut.taken ? (int)cut.segs.size() : 1;
 }
 // device time of the factorisation and of the back-substitution launches (test / tuning hook): `reps` solves of (A + q I) x = b,

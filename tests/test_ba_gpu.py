@@ -1337,7 +1337,7 @@ def test_a_trajectory_band_is_factorised_as_two_chains(gpu_required, shape, monk
         monkeypatch.setenv("MCP_BA_TEST_CHOL_CUT", "2")
     b = _gpu(p.cams, disable_convergence=True)
     two = run_bundle(b, p, 8)
-    assert b.Timing()["chol_chains"] == 1 if shape == "chains_that_couple" else b.Timing()["chol_chains"] in (3, 4, 5)      # (two to four arcs + the separator)
+    assert b.Timing()["chol_chains"] == 1 if shape == "chains_that_couple" else b.Timing()["chol_chains"] in (3, 4, 5, 6, 7)      # (two to six arcs + the separator)
     two_again = run_bundle(_gpu(p.cams, disable_convergence=True), p, 8)
     assert two["logs"] == two_again["logs"] and np.array_equal(two["X"], two_again["X"]) and np.array_equal(two["t"], two_again["t"])
     if shape == "ring":      # the coupling graph from masks taken with atomics (an add order that is not KeyFrame by KeyFrame): the same cut
