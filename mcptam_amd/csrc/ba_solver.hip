@@ -1279,6 +1279,7 @@ int mcp_ba::prepare() {
     }
   }
   nsp = (int)order.size();
+  lap("  point order");
   // per (obs chain, src chain) activity mask, memoised in a dense table (chains are few: P*C for the Multi adapter)
   const bool dense_table = nch <= 4096;
   // (entries are written concurrently by the structure threads below: every writer stores the same value, relaxed atomics)
@@ -1316,6 +1317,7 @@ int mcp_ba::prepare() {
   H.l_i0.assign(nfl + 1, 0); H.l_i1.assign(nfl + 1, 0); H.l_sp.assign(nfl + 1, 0);
   H.sp_pt.resize(nsp); H.sp_m.assign(nsp + 1, 0); H.sp_i.assign(nsp + 1, 0); H.sp_big.assign(nsp, 0);
   perm.assign(nmeas, 0);
+  lap("  host arrays");
   std::vector<int> sp_of(std::max(npoint, 1), -1);
   for (int sp = 0; sp < nsp; ++sp) { H.sp_m[sp + 1] = H.sp_m[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]); sp_of[order[sp]] = sp; }
   // ---- every measurement to its final position, a range of the add order per thread (sequential reads, one scattered 40-byte
